@@ -1,0 +1,138 @@
+/*
+ * ns_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain scalar restatement of the BesTLA weight-only-quant path of intel/neural-speed, used ONLY as the
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under
+ * neural-speed_amd/ links, imports or calls this file.
+ *
+ * Parity pinning: the reference holds no golden vectors for this path, so every arithmetic
+ * routine here is pinned against the reference's own scalar kernels (bestla/bestla/kernel_ref.h) compiled
+ * from /root/reference into oracle/_ref/libkernel_ref.so (see oracle/Makefile, oracle/ref_shim.cpp) and the
+ * outputs are frozen as fixtures under tests/golden/ (generator: tests/golden/make_golden.py).  The blob
+ * container (bestla_storage.h) cannot be compiled here (it pulls in xbyak, which is not vendored), so the
+ * serialisation order is restated from the source text and self-checked by pack→parse→unpack round trips.
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#ifndef NS_ORACLE_H
+#define NS_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* BTLA_DTYPE bit encoding — bestla/bestla/bestla.h:38-87 */
+enum {
+  NSO_F32 = 32,
+  NSO_F16 = 16,
+  NSO_BF16 = 16 | (1 << 16),
+  NSO_S8 = 8 | (1 << 8),
+  NSO_S1_CLIP = 1 | (1 << 8),
+  NSO_S2_CLIP = 2 | (1 << 8),
+  NSO_S3_CLIP = 3 | (1 << 8),
+  NSO_S4_CLIP = 4 | (1 << 8),
+  NSO_S5_CLIP = 5 | (1 << 8),
+  NSO_S6_CLIP = 6 | (1 << 8),
+  NSO_S7_CLIP = 7 | (1 << 8),
+  NSO_F4_E2M1 = 4,
+  NSO_F4_BNB = 4 | (1 << 16),
+  NSO_F4_NF4 = 4 | (2 << 16),
+};
+
+/* GEMM cores a blob can be laid out for — neural_speed/core/layers/bestla_defs.h:36-54 */
+enum {
+  NSO_CORE_AVX2 = 0,            /* SCoreRowNAvx2<24,4>            NTILE 24 PACK 1 KTILE 1  fp32 */
+  NSO_CORE_AVX512F = 1,         /* SCoreRowNAvx512f<48,8>         NTILE 48 PACK 1 KTILE 1  fp32 */
+  NSO_CORE_AMX_BF16 = 2,        /* HCoreRowNAmxbf16<48,16>        NTILE 48 PACK 2 KTILE 32 bf16 */
+  NSO_CORE_AMX_FP16 = 3,        /* HCoreRowNAmxfp16<48,16>        NTILE 48 PACK 2 KTILE 32 fp16 */
+  NSO_CORE_AVX512_VNNI_KB = 4,  /* ICoreRowNAvx512vnniKBlock<48,4> NTILE 48 PACK 4 KTILE 4 u8s8 */
+  NSO_CORE_AVX512BW_KB = 5,     /* ICoreRowNAvx512bwKBlock<48,8>   NTILE 48 PACK 4 KTILE 4 u8s8 */
+  NSO_CORE_AVX_VNNI_KB = 6,     /* ICoreRowNAvxvnniKBlock<24,2>    NTILE 24 PACK 4 KTILE 4 u8s8 */
+  NSO_CORE_AVX2_VNNI_KB = 7,    /* ICoreRowNAvx2vnniKBlock<24,2>   NTILE 24 PACK 4 KTILE 4 u8s8 */
+  NSO_CORE_AMX_INT8_KB = 8,     /* ICoreRowNAmxint8KBlock<48,16>   NTILE 48 PACK 4 KTILE 64 u8s8 */
+  NSO_CORE_COUNT = 9
+};
+
+typedef struct nso_blob_info {
+  uint64_t size;
+  uint32_t prologue_id; /* 1 = WeightKBlockNInteger, 2 = WeightKBlockNFloat (bestla.h:91-102) */
+  uint64_t core_id;
+  int32_t npad, kpad, n, k;
+  uint32_t dtype;
+  int32_t blocksize, dq_blocksize;
+  uint32_t scale_dtype, zp_dtype, red_dtype;
+  int32_t cstep;
+  uint64_t csize;
+  int32_t ntile, packrow, comp, isa;
+  int32_t is_asym, has_reduce, has_shuffle;
+  /* byte offsets from the blob base (0 = absent) */
+  uint64_t q_off, q_bytes, scale_off, scale_bytes, zp_off, zp_bytes, red_off, red_bytes, shuf_off, shuf_bytes;
+} nso_blob_info;
+
+uint64_t nso_core_id(int core);
+int nso_core_attr(int core, int* ntile, int* packrow, int* ktile, int* comp, int* isa);
+
+/* scalar dtype helpers (bestla_utils.h:116-229) */
+uint16_t nso_f32_to_bf16(float v);
+float nso_bf16_to_f32(uint16_t v);
+uint16_t nso_f32_to_f16(float v);
+float nso_f16_to_f32(uint16_t v);
+
+/* kernel_ref.h:1608-1719  (src is the [K][N] matrix, i.e. already transposed to K-major) */
+int nso_quantize_int_rowblock(const float* src, int8_t* dst, int row, int col, int ld_src, int ld_dst, float* scales,
+                              int8_t* zero_points, int blocksize, uint32_t qtype);
+/* kernel_ref.h:1801-1822 */
+int nso_quantize_f4_rowblock(const float* src, int8_t* dst, int row, int col, int ld_src, int ld_dst, float* scales,
+                             int blocksize, uint32_t f4type);
+float nso_f4_unpack(uint32_t f4type, int code);
+int nso_f4_quantize(uint32_t f4type, float x);
+
+/* kernel_ref.h:39-57 */
+void nso_padding_interleave(const int8_t* src, int8_t* dst, int row, int col, int rowpad, int colpad, int src_step,
+                            int dst_step, int ntile, int rowpack);
+/* kernel_ref.h:155-365: compress `size` int8 codes into the bit planes of `qtype`; dst must hold nso_qbytes() */
+void nso_compress(const int8_t* src, uint8_t* dst, size_t size, uint32_t qtype);
+/* inverse (kernel_ref.h:420-526): planes -> signed codes (stored - 2^(b-1)); f4 -> raw 0..15 code */
+void nso_decompress(const uint8_t* src, int8_t* dst, size_t size, uint32_t qtype);
+size_t nso_qbytes(size_t elts, uint32_t qtype);
+
+/* bestla_storage.h:697-859 + bestla_prologue_b.h:120-127,1011-1017: serialized size of the blob */
+size_t nso_pack_size(int n, int k, int blocksize, uint32_t qtype, uint32_t stype, int asym, int core);
+/* BTLAGemmPackB (bestla_gemm.cpp:401-422, prologue_b.h:378-398): q [K][N] (ld = ldq), scales/zp [ceil(K/blk)][N] */
+int nso_pack_q(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k,
+               int blocksize, uint32_t qtype, uint32_t stype, int asym, int core);
+/* BTLAGemmQuantPackB (bestla_gemm.cpp:302-319): fp32 weight, [N][K] if is_trans (torch layout) else [K][N] */
+int nso_quant_pack(void* blob, const float* w, int n, int k, int ldw, int blocksize, uint32_t qtype, uint32_t stype,
+                   int asym, int core, int is_trans);
+int nso_blob_parse(const void* blob, nso_blob_info* info);
+/* BTLAGemmUnPackB (bestla_gemm.cpp:673-749): blob -> fp32 [K][N] (ld = ldb) */
+int nso_unpack_fp32(const void* blob, float* out, int ldb);
+/* blob -> canonical pieces: signed codes minus nothing (q [K][N]), scales fp32 [nblk][N], zp [nblk][N] (0 if sym) */
+int nso_unpack_canonical(const void* blob, int8_t* q, float* scales, int8_t* zps);
+
+/* comp-fp32 semantics (kernel_ref.h:2489-2531 generalised): C[m][n] = sum_k A[m][k] * W[k][n], W = unpacked fp32,
+ * accumulated in fp64 — the parity target for every HIP GEMM/GEMV. */
+int nso_gemm_f64(const float* a, int lda, const void* blob, double* c, int ldc, int m);
+/* same but A first rounded to fp16 (what the HIP kernels feed the MFMA/dot units) — used to separate
+ * activation-rounding error from kernel error in tests */
+int nso_gemm_f64_a16(const float* a, int lda, const void* blob, double* c, int ldc, int m);
+/* sequential-k fp32 accumulation exactly as gemv_4bit_fp32_fp32 does it (kernel_ref.h:2489-2531), threaded over N
+ * with OpenMP; used as the timed CPU baseline ("port") */
+int nso_gemv_f32(const float* a, int lda, const void* blob, float* c, int ldc, int m, int nthreads);
+
+/* activation side of the int8 compute path: kernel_ref.h:1824-1883 */
+int nso_quantize_fp_u8_colblock(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst,
+                                float* scales, int ld_scale, uint8_t* zps, int blocksize, float* blkreduce);
+/* int8-compute GEMM semantics (ut/bestla_gemm.cpp:159-190 ref_kblock_int8 / kernel_ref.h:2371-2429) */
+int nso_gemm_u8s8_f32(const float* a, int lda, const void* blob, float* c, int ldc, int m);
+
+/* epilogue helpers — bestla_common.hpp:121-215, ip_fusion_ffn.cpp */
+float nso_gelu(float x);
+float nso_silu(float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

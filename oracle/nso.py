@@ -1,0 +1,256 @@
+"""ctypes/numpy binding of the CPU ORACLE (oracle/libns_oracle.so) and of the real reference scalar kernels
+(oracle/_ref/libkernel_ref.so).  TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from the product package (neural-speed_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# BTLA_DTYPE codes (bestla/bestla/bestla.h:38-87)
+F32 = 32
+F16 = 16
+BF16 = 16 | (1 << 16)
+S8 = 8 | (1 << 8)
+S1, S2, S3, S4, S5, S6, S7 = [b | (1 << 8) for b in range(1, 8)]
+F4_E2M1 = 4
+F4_BNB = 4 | (1 << 16)
+F4_NF4 = 4 | (2 << 16)
+INT_TYPES = {1: S1, 2: S2, 3: S3, 4: S4, 5: S5, 6: S6, 7: S7, 8: S8}
+
+CORE_AVX2, CORE_AVX512F, CORE_AMX_BF16, CORE_AMX_FP16, CORE_AVX512_VNNI_KB, CORE_AVX512BW_KB, CORE_AVX_VNNI_KB, \
+    CORE_AVX2_VNNI_KB, CORE_AMX_INT8_KB = range(9)
+CORE_NAMES = ["avx2", "avx512f", "amx_bf16", "amx_fp16", "avx512_vnni_kb", "avx512bw_kb", "avx_vnni_kb",
+              "avx2_vnni_kb", "amx_int8_kb"]
+
+
+class BlobInfo(C.Structure):
+    _fields_ = [("size", C.c_uint64), ("prologue_id", C.c_uint32), ("core_id", C.c_uint64),
+                ("npad", C.c_int32), ("kpad", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+                ("dtype", C.c_uint32), ("blocksize", C.c_int32), ("dq_blocksize", C.c_int32),
+                ("scale_dtype", C.c_uint32), ("zp_dtype", C.c_uint32), ("red_dtype", C.c_uint32),
+                ("cstep", C.c_int32), ("csize", C.c_uint64),
+                ("ntile", C.c_int32), ("packrow", C.c_int32), ("comp", C.c_int32), ("isa", C.c_int32),
+                ("is_asym", C.c_int32), ("has_reduce", C.c_int32), ("has_shuffle", C.c_int32),
+                ("q_off", C.c_uint64), ("q_bytes", C.c_uint64), ("scale_off", C.c_uint64),
+                ("scale_bytes", C.c_uint64), ("zp_off", C.c_uint64), ("zp_bytes", C.c_uint64),
+                ("red_off", C.c_uint64), ("red_bytes", C.c_uint64), ("shuf_off", C.c_uint64),
+                ("shuf_bytes", C.c_uint64)]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+def build(force=False):
+    """(re)build the oracle .so files with oracle/Makefile.  Building the checker is not using it."""
+    so = os.path.join(HERE, "libns_oracle.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(HERE, "ns_oracle.cpp")):
+        subprocess.check_call(["make", "-C", HERE, "libns_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/bestla/bestla/kernel_ref.h"):
+        ref = os.path.join(HERE, "_ref", "libkernel_ref.so")
+        if force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(os.path.join(HERE, "ref_shim.cpp")):
+            subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(os.path.join(HERE, "libns_oracle.so"))
+        _lib.nso_pack_size.restype = C.c_size_t
+        _lib.nso_qbytes.restype = C.c_size_t
+        _lib.nso_core_id.restype = C.c_uint64
+        _lib.nso_bf16_to_f32.restype = C.c_float
+        _lib.nso_f16_to_f32.restype = C.c_float
+        _lib.nso_f32_to_bf16.restype = C.c_uint16
+        _lib.nso_f32_to_f16.restype = C.c_uint16
+        _lib.nso_f4_unpack.restype = C.c_float
+        _lib.nso_gelu.restype = C.c_float
+        _lib.nso_silu.restype = C.c_float
+        _lib.nso_bf16_to_f32.argtypes = [C.c_uint16]
+        _lib.nso_f16_to_f32.argtypes = [C.c_uint16]
+        _lib.nso_f32_to_bf16.argtypes = [C.c_float]
+        _lib.nso_f32_to_f16.argtypes = [C.c_float]
+        _lib.nso_f4_unpack.argtypes = [C.c_uint32, C.c_int]
+        _lib.nso_f4_quantize.argtypes = [C.c_uint32, C.c_float]
+        _lib.nso_gelu.argtypes = [C.c_float]
+        _lib.nso_silu.argtypes = [C.c_float]
+    return _lib
+
+
+def ref():
+    """The real reference kernels; None when oracle/_ref was never built (then tests relying on it skip)."""
+    global _ref
+    if _ref is None:
+        build()
+        p = os.path.join(HERE, "_ref", "libkernel_ref.so")
+        if not os.path.exists(p):
+            return None
+        _ref = C.CDLL(p)
+        _ref.ref_f4_unpack.restype = C.c_float
+        _ref.ref_lut.restype = C.c_float
+        _ref.ref_bf16_to_f32.restype = C.c_float
+        _ref.ref_f16_to_f32.restype = C.c_float
+        _ref.ref_f32_to_bf16.restype = C.c_uint16
+        _ref.ref_f32_to_f16.restype = C.c_uint16
+        _ref.ref_postop.restype = C.c_float
+        _ref.ref_f4_quantize.argtypes = [C.c_uint32, C.c_float]
+        _ref.ref_f32_to_bf16.argtypes = [C.c_float]
+        _ref.ref_f32_to_f16.argtypes = [C.c_float]
+        _ref.ref_bf16_to_f32.argtypes = [C.c_uint16]
+        _ref.ref_f16_to_f32.argtypes = [C.c_uint16]
+        _ref.ref_cast_f32_s8.argtypes = [C.c_float]
+        _ref.ref_cast_f32_u8.argtypes = [C.c_float]
+        _ref.ref_postop.argtypes = [C.c_float, C.c_int]
+    return _ref
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def aligned_bytes(nbytes, align=64, fill=0):
+    """uint8 buffer whose data pointer is `align`-byte aligned (blob bytes depend on the base address mod 64)."""
+    raw = np.full(nbytes + align, fill, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + nbytes]
+
+
+def is_int_type(qtype):
+    return ((qtype >> 8) & 0xff) == 1
+
+
+def nblk(k, blocksize):
+    return (k + blocksize - 1) // blocksize
+
+
+# ------------------------------------------------------------------ oracle wrappers
+def quantize(w_kn, blocksize, qtype, asym=False):
+    """w_kn: fp32 [K][N].  returns (q int8 [K][N], scales f32 [nblk][N], zps int8 [nblk][N] | None)."""
+    w_kn = np.ascontiguousarray(w_kn, dtype=np.float32)
+    k, n = w_kn.shape
+    bs = k if blocksize <= 0 else blocksize
+    q = np.zeros((k, n), np.int8)
+    sc = np.zeros((nblk(k, bs), n), np.float32)
+    if is_int_type(qtype):
+        zp = np.zeros((nblk(k, bs), n), np.int8) if asym else None
+        rc = lib().nso_quantize_int_rowblock(ptr(w_kn), ptr(q), k, n, n, n, ptr(sc), ptr(zp), bs, C.c_uint32(qtype))
+    else:
+        zp = None
+        rc = lib().nso_quantize_f4_rowblock(ptr(w_kn), ptr(q), k, n, n, n, ptr(sc), bs, C.c_uint32(qtype))
+    assert rc == 0
+    return q, sc, zp
+
+
+def pack_size(n, k, blocksize, qtype, stype, asym, core):
+    return lib().nso_pack_size(n, k, blocksize, C.c_uint32(qtype), C.c_uint32(stype), int(asym), core)
+
+
+def quant_pack(w, blocksize, qtype, stype=BF16, asym=False, core=CORE_AVX512_VNNI_KB, is_trans=True, fill=0):
+    """BTLAGemmQuantPackB.  w is [N][K] when is_trans (torch layout) else [K][N].  returns the blob (uint8, 64-aligned)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    n, k = w.shape if is_trans else w.shape[::-1]
+    size = pack_size(n, k, blocksize, qtype, stype, asym, core)
+    assert size > 0, "unsupported combination"
+    blob = aligned_bytes(size, fill=fill)
+    rc = lib().nso_quant_pack(ptr(blob), ptr(w), n, k, w.shape[1], blocksize, C.c_uint32(qtype), C.c_uint32(stype),
+                              int(asym), core, int(is_trans))
+    assert rc == 0
+    return blob
+
+
+def pack_q(q_kn, scales, zps, blocksize, qtype, stype=BF16, core=CORE_AVX512_VNNI_KB, fill=0):
+    q_kn = np.ascontiguousarray(q_kn, dtype=np.int8)
+    k, n = q_kn.shape
+    scales = np.ascontiguousarray(scales, dtype=np.float32)
+    asym = zps is not None
+    if asym:
+        zps = np.ascontiguousarray(zps, dtype=np.int8)
+    size = pack_size(n, k, blocksize, qtype, stype, asym, core)
+    assert size > 0
+    blob = aligned_bytes(size, fill=fill)
+    rc = lib().nso_pack_q(ptr(blob), ptr(q_kn), n, ptr(scales), ptr(zps), n, k, blocksize, C.c_uint32(qtype),
+                          C.c_uint32(stype), int(asym), core)
+    assert rc == 0
+    return blob
+
+
+def parse(blob):
+    bi = BlobInfo()
+    rc = lib().nso_blob_parse(ptr(blob), C.byref(bi))
+    assert rc == 0, "not a BTLA k-block blob"
+    return bi
+
+
+def unpack_fp32(blob):
+    bi = parse(blob)
+    out = np.zeros((bi.k, bi.n), np.float32)
+    assert lib().nso_unpack_fp32(ptr(blob), ptr(out), bi.n) == 0
+    return out
+
+
+def unpack_canonical(blob):
+    bi = parse(blob)
+    q = np.zeros((bi.k, bi.n), np.int8)
+    nb = nblk(bi.k, bi.blocksize)
+    sc = np.zeros((nb, bi.n), np.float32)
+    zp = np.zeros((nb, bi.n), np.int8)
+    assert lib().nso_unpack_canonical(ptr(blob), ptr(q), ptr(sc), ptr(zp)) == 0
+    return q, sc, zp
+
+
+def gemm_f64(a, blob, a16=False):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    bi = parse(blob)
+    m = a.shape[0]
+    c = np.zeros((m, bi.n), np.float64)
+    fn = lib().nso_gemm_f64_a16 if a16 else lib().nso_gemm_f64
+    assert fn(ptr(a), a.shape[1], ptr(blob), ptr(c), bi.n, m) == 0
+    return c
+
+
+def gemv_f32(a, blob, nthreads=0):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    bi = parse(blob)
+    m = a.shape[0]
+    c = np.zeros((m, bi.n), np.float32)
+    assert lib().nso_gemv_f32(ptr(a), a.shape[1], ptr(blob), ptr(c), bi.n, m, nthreads) == 0
+    return c
+
+
+def gemm_u8s8(a, blob):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    bi = parse(blob)
+    m = a.shape[0]
+    c = np.zeros((m, bi.n), np.float32)
+    assert lib().nso_gemm_u8s8_f32(ptr(a), a.shape[1], ptr(blob), ptr(c), bi.n, m) == 0
+    return c
+
+
+def compress(codes, qtype):
+    codes = np.ascontiguousarray(codes, dtype=np.int8).ravel()
+    nb = lib().nso_qbytes(C.c_size_t(codes.size), C.c_uint32(qtype))
+    out = np.zeros(nb, np.uint8)
+    lib().nso_compress(ptr(codes), ptr(out), C.c_size_t(codes.size), C.c_uint32(qtype))
+    return out
+
+
+def decompress(packed, size, qtype):
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    out = np.zeros(size, np.int8)
+    lib().nso_decompress(ptr(packed), ptr(out), C.c_size_t(size), C.c_uint32(qtype))
+    return out
+
+
+def rel_l2(y, yref):
+    """the reference's own metric: ||a-b|| / ||b||  (tests/test_python_api.py:27-33 cmpData diff2)"""
+    y = np.asarray(y, np.float64)
+    yref = np.asarray(yref, np.float64)
+    return float(np.linalg.norm(y - yref) / max(np.linalg.norm(yref), 1e-30))

@@ -1,0 +1,339 @@
+"""Pins the oracle restatement (oracle/ns_oracle.cpp) to the REAL reference scalar kernels
+(bestla/bestla/kernel_ref.h via oracle/_ref/libkernel_ref.so).  Bit-exact everywhere.
+Runs wherever oracle/_ref was built (this container builds it from /root/reference; the prebuilt .so
+travels to the GPU box)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+BITS = [1, 2, 3, 4, 5, 6, 7, 8]
+
+
+def _weights(rng, k, n, kind):
+    if kind == "normal":
+        return (rng.standard_normal((k, n)) * 0.02).astype(np.float32)
+    if kind == "uniform":  # the reference UT distribution, ut/bestla_ut.h:129-134
+        return rng.uniform(-0.5, 0.5, (k, n)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) * 0.02).astype(np.float32)
+    # adversarial blocks: all-zero group, dominant-positive group, single outlier, max == -min tie
+    w[0:32, 0] = 0
+    w[0:32, 1] = np.abs(w[0:32, 1])
+    w[0, 1] = 1.0
+    w[1, 1] = -0.7
+    w[5, 2] = 3.0
+    w[0:32, 3] = 0.01
+    w[0, 3] = 0.5
+    w[1, 3] = -0.5
+    w[0:32, 4] = -np.abs(w[0:32, 4])
+    return w
+
+
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("asym", [False, True])
+@pytest.mark.parametrize("kind", ["normal", "uniform", "adversarial"])
+def test_quantize_int(nso, refk, bits, asym, kind):
+    rng = np.random.default_rng(100 + bits)
+    k, n, bs = 160, 24, 32
+    w = _weights(rng, k, n, kind)
+    qt = nso.INT_TYPES[bits]
+    q, sc, zp = nso.quantize(w, bs, qt, asym)
+    q2 = np.zeros_like(q)
+    sc2 = np.zeros_like(sc)
+    zp2 = np.zeros_like(sc, dtype=np.int8) if asym else None
+    refk.ref_quantize_int(nso.ptr(w), nso.ptr(q2), k, n, n, n, nso.ptr(sc2), nso.ptr(zp2), bs, C.c_uint32(qt))
+    assert np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+    if asym:
+        assert np.array_equal(zp, zp2)
+    assert np.array_equal(q, q2)
+
+
+def test_quantize_int_tail_block(nso, refk):
+    rng = np.random.default_rng(7)
+    k, n, bs = 100, 16, 32  # last block has 4 rows (kernel_ref.h:1715-1716)
+    w = _weights(rng, k, n, "normal")
+    for asym in (False, True):
+        q, sc, zp = nso.quantize(w, bs, nso.S4, asym)
+        q2 = np.zeros_like(q)
+        sc2 = np.zeros_like(sc)
+        zp2 = np.zeros_like(sc, dtype=np.int8) if asym else None
+        refk.ref_quantize_int(nso.ptr(w), nso.ptr(q2), k, n, n, n, nso.ptr(sc2), nso.ptr(zp2), bs, C.c_uint32(nso.S4))
+        assert np.array_equal(q, q2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+
+
+@pytest.mark.parametrize("f4", ["F4_NF4", "F4_BNB", "F4_E2M1"])
+def test_quantize_f4(nso, refk, f4):
+    qt = getattr(nso, f4)
+    rng = np.random.default_rng(11)
+    k, n, bs = 128, 16, 32
+    for kind in ("normal", "uniform", "adversarial"):
+        w = _weights(rng, k, n, kind)
+        q, sc, _ = nso.quantize(w, bs, qt)
+        q2 = np.zeros_like(q)
+        sc2 = np.zeros_like(sc)
+        assert refk.ref_quantize_f4(nso.ptr(w), nso.ptr(q2), k, n, n, n, nso.ptr(sc2), bs, C.c_uint32(qt)) == 0
+        assert np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+        assert np.array_equal(q, q2)
+    # scalar tree vs flattened thresholds, incl. NaN / inf / signed zero
+    xs = np.concatenate([np.linspace(-1.2, 1.2, 4001, dtype=np.float32),
+                         np.array([np.nan, np.inf, -np.inf, 0.0, -0.0], np.float32)])
+    for x in xs:
+        assert nso.lib().nso_f4_quantize(C.c_uint32(qt), C.c_float(x)) == refk.ref_f4_quantize(C.c_uint32(qt), C.c_float(x))
+    for code in range(16):
+        a = np.float32(nso.lib().nso_f4_unpack(C.c_uint32(qt), code))
+        b = np.float32(refk.ref_f4_unpack(C.c_uint32(qt), code))
+        c = np.float32(refk.ref_lut(C.c_uint32(qt), code))
+        assert a.view(np.uint32) == b.view(np.uint32)
+        assert a == c
+
+
+def test_f4_thresholds_exact(nso, refk):
+    """feed every threshold value and its float neighbours (the trees use strict '>')."""
+    import re
+    src = open(nso.HERE + "/ns_oracle.cpp").read()
+    for name, qt in (("kThrNF4", nso.F4_NF4), ("kThrBNB", nso.F4_BNB)):
+        body = re.search(name + r"\[\d+\] = \{([^}]*)\}", src).group(1)
+        vals = [np.float32(float(t.strip().rstrip("f"))) for t in body.split(",") if t.strip()]
+        assert len(vals) in (7, 15)
+        for v in vals:
+            for x in (np.nextafter(v, np.float32(-9)), v, np.nextafter(v, np.float32(9))):
+                for s in (x, -x):
+                    assert nso.lib().nso_f4_quantize(C.c_uint32(qt), C.c_float(s)) == \
+                        refk.ref_f4_quantize(C.c_uint32(qt), C.c_float(s))
+    for num in (0.03125, 0.53125, 1.25, 1.75, 2.5, 3.5, 5.0):
+        v = np.float32(num) / np.float32(6)
+        for x in (np.nextafter(v, np.float32(-9)), v, np.nextafter(v, np.float32(9))):
+            for s in (x, -x):
+                assert nso.lib().nso_f4_quantize(C.c_uint32(nso.F4_E2M1), C.c_float(s)) == \
+                    refk.ref_f4_quantize(C.c_uint32(nso.F4_E2M1), C.c_float(s))
+
+
+@pytest.mark.parametrize("ntile,packrow", [(48, 1), (48, 2), (48, 4), (24, 1), (24, 4)])
+def test_padding_interleave(nso, refk, ntile, packrow):
+    rng = np.random.default_rng(3)
+    k, n = 70, 50
+    kpad = (k + packrow - 1) // packrow * packrow
+    npad = (n + ntile - 1) // ntile * ntile
+    src = rng.integers(-128, 128, (k, n), dtype=np.int8)
+    a = np.full(kpad * npad, 77, np.int8)
+    b = np.full(kpad * npad, 77, np.int8)
+    nso.lib().nso_padding_interleave(nso.ptr(src), nso.ptr(a), k, n, kpad, npad, n, kpad, ntile, packrow)
+    refk.ref_padding_interleave(nso.ptr(src), nso.ptr(b), k, n, kpad, npad, n, kpad, ntile, packrow)
+    assert np.array_equal(a, b)
+
+
+def _ref_compress(nso, refk, codes, bits):
+    n = codes.size
+    out = np.zeros(nso.lib().nso_qbytes(C.c_size_t(n), C.c_uint32(nso.INT_TYPES[bits])), np.uint8)
+    p = out.ctypes.data
+    vp = C.c_void_p
+    sz = C.c_size_t(n)
+    # plane offsets: bestla_prologue_b.h:512-547
+    if bits == 4:
+        refk.ref_compress_s8_s4(nso.ptr(codes), vp(p), sz)
+    elif bits == 7:
+        refk.ref_compress_7bit(nso.ptr(codes), vp(p), vp(p + n // 2), vp(p + n // 2 + n // 4), sz)
+    elif bits == 6:
+        refk.ref_compress_6bit(nso.ptr(codes), vp(p), vp(p + n // 2), sz)
+    elif bits == 5:
+        refk.ref_compress_5bit(nso.ptr(codes), vp(p), vp(p + n // 2), sz)
+    elif bits == 3:
+        refk.ref_compress_3bit(nso.ptr(codes), vp(p), vp(p + n // 4), sz)
+    elif bits == 2:
+        refk.ref_compress_2bit(nso.ptr(codes), vp(p), sz)
+    elif bits == 1:
+        refk.ref_compress_1bit(nso.ptr(codes), vp(p), sz)
+    return out
+
+
+def _ref_decompress(nso, refk, packed, n, bits):
+    out = np.zeros(n, np.int8)
+    p = packed.ctypes.data
+    vp = C.c_void_p
+    sz = C.c_size_t(n)
+    if bits == 4:
+        refk.ref_decompress_s4_s8(vp(p), nso.ptr(out), sz)
+    elif bits == 7:
+        refk.ref_decompress_s7_s8(vp(p), vp(p + n // 2), vp(p + n // 2 + n // 4), nso.ptr(out), sz)
+    elif bits == 6:
+        refk.ref_decompress_s6_s8(vp(p), vp(p + n // 2), nso.ptr(out), sz)
+    elif bits == 5:
+        refk.ref_decompress_s5_s8(vp(p), vp(p + n // 2), nso.ptr(out), sz)
+    elif bits == 3:
+        refk.ref_decompress_s3_s8(vp(p), vp(p + n // 4), nso.ptr(out), sz)
+    elif bits == 2:
+        refk.ref_decompress_s2_s8(vp(p), nso.ptr(out), sz)
+    elif bits == 1:
+        refk.ref_decompress_s1_s8(vp(p), nso.ptr(out), sz)
+    return out
+
+
+@pytest.mark.parametrize("bits", [1, 2, 3, 4, 5, 6, 7])
+def test_compress_decompress(nso, refk, bits):
+    rng = np.random.default_rng(bits)
+    n = 48 * 64
+    full = 1 << (bits - 1)
+    codes = rng.integers(-full, full, n, dtype=np.int8)
+    mine = nso.compress(codes, nso.INT_TYPES[bits])
+    theirs = _ref_compress(nso, refk, codes, bits)
+    assert np.array_equal(mine, theirs)
+    d_mine = nso.decompress(mine, n, nso.INT_TYPES[bits])
+    d_theirs = _ref_decompress(nso, refk, theirs, n, bits)
+    assert np.array_equal(d_mine, d_theirs)
+    if bits == 1:
+        # compress_1bit reads src[j + FullRange] = src[j+1] for the 5th element of every 8 (kernel_ref.h:355)
+        exp = codes.copy().reshape(-1, 8)
+        exp[:, 4] = exp[:, 1]
+        assert np.array_equal(d_mine, exp.ravel())
+    else:
+        assert np.array_equal(d_mine, codes)
+
+
+def test_compress_f4(nso, refk):
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, 16, 48 * 32, dtype=np.int8)
+    mine = nso.compress(codes, nso.F4_NF4)
+    theirs = np.zeros_like(mine)
+    refk.ref_compress_f4(nso.ptr(codes), nso.ptr(theirs), C.c_size_t(codes.size))
+    assert np.array_equal(mine, theirs)
+    assert np.array_equal(nso.decompress(mine, codes.size, nso.F4_NF4), codes)
+
+
+def test_scalar_casts(nso, refk):
+    rng = np.random.default_rng(9)
+    mant = rng.standard_normal(4000).astype(np.float32)
+    expo = np.float32(10) ** rng.integers(-8, 6, 4000).astype(np.float32)
+    vals = np.concatenate([mant * expo,
+                           np.array([0, -0.0, 1, -1, 65504, 65520, 1e-8, 6e-8, 6.1e-5, 3e38, 0.5, 1.5, 2.5, -2.5], np.float32)])
+    L = nso.lib()
+    for v in vals:
+        v = float(v)
+        assert L.nso_f32_to_bf16(v) == refk.ref_f32_to_bf16(v)
+        assert L.nso_f32_to_f16(v) == refk.ref_f32_to_f16(v)
+    for h in list(range(0, 65536, 7)) + [0x7c00, 0x7bff, 0x0001, 0x03ff, 0x8001]:
+        a = np.float32(L.nso_bf16_to_f32(h))
+        b = np.float32(refk.ref_bf16_to_f32(h))
+        assert a.view(np.uint32) == b.view(np.uint32)
+        a = np.float32(L.nso_f16_to_f32(h))
+        b = np.float32(refk.ref_f16_to_f32(h))
+        assert a.view(np.uint32) == b.view(np.uint32)
+    for x in np.linspace(-6, 6, 241, dtype=np.float32):
+        assert np.float32(L.nso_gelu(float(x))) == np.float32(refk.ref_postop(float(x), 0))
+        assert np.float32(L.nso_silu(float(x))) == np.float32(refk.ref_postop(float(x), 1))
+
+
+@pytest.mark.parametrize("core,packrow", [("CORE_AVX512F", 1), ("CORE_AMX_BF16", 2), ("CORE_AVX512_VNNI_KB", 4)])
+@pytest.mark.parametrize("stype", ["F32", "BF16"])
+@pytest.mark.parametrize("asym", [False, True])
+def test_unpack_matches_reference_tile_dequant(nso, refk, core, packrow, stype, asym):
+    """oracle unpack (whole blob) == the reference's tile dequant decompress_kblock_s4_fp run over the blob's
+    own packed image, scales and zero points."""
+    rng = np.random.default_rng(21)
+    n, k, bs = 96, 128, 32
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    blob = nso.quant_pack(w, bs, nso.S4, getattr(nso, stype), asym, getattr(nso, core))
+    bi = nso.parse(blob)
+    mine = nso.unpack_fp32(blob)  # [K][N]
+    for t in range(bi.npad // 48):
+        src = blob[bi.q_off + t * 48 * bi.kpad // 2:]
+        dst = np.zeros(bi.kpad * 48, np.float32)
+        sc = blob[bi.scale_off:]
+        zp = blob[bi.zp_off:] if asym else None
+        rc = refk.ref_decompress_kblock_s4_fp(packrow, nso.ptr(src), nso.ptr(dst), bi.kpad, nso.ptr(sc),
+                                              C.c_uint32(bi.scale_dtype), nso.ptr(zp), 0, t * 48, bs, bi.cstep)
+        assert rc == 0
+        # dst is the tile in interleaved order [K/PR][48][PR]
+        tile = dst.reshape(bi.kpad // packrow, 48, packrow).transpose(0, 2, 1).reshape(bi.kpad, 48)
+        assert np.array_equal(tile[:k, :].view(np.uint32), mine[:, t * 48:(t + 1) * 48].view(np.uint32))
+
+
+def test_unpack_s8_and_f4_match_reference(nso, refk):
+    rng = np.random.default_rng(22)
+    n, k, bs = 48, 64, 32
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    blob = nso.quant_pack(w, bs, nso.S8, nso.BF16, False, nso.CORE_AVX512F)
+    bi = nso.parse(blob)
+    dst = np.zeros(bi.kpad * 48, np.float32)
+    refk.ref_decompress_kblock_s8_fp(1, nso.ptr(blob[bi.q_off:]), nso.ptr(dst), bi.kpad, nso.ptr(blob[bi.scale_off:]),
+                                     C.c_uint32(bi.scale_dtype), None, 0, 0, bs, bi.cstep)
+    assert np.array_equal(dst.reshape(bi.kpad, 48)[:k].view(np.uint32), nso.unpack_fp32(blob).view(np.uint32))
+    for f4 in (nso.F4_NF4, nso.F4_BNB, nso.F4_E2M1):
+        blob = nso.quant_pack(w, bs, f4, nso.F32, False, nso.CORE_AVX512F)
+        bi = nso.parse(blob)
+        dst = np.zeros(bi.kpad * 48, np.float32)
+        sc = blob[bi.scale_off:bi.scale_off + bi.scale_bytes].view(np.float32).copy()
+        rc = refk.ref_decompress_kblock_f4_fp(C.c_uint32(f4), 1, nso.ptr(blob[bi.q_off:]), nso.ptr(dst), bi.kpad, 48,
+                                              nso.ptr(sc), 0, bs, bi.cstep)
+        assert rc == 0
+        assert np.array_equal(dst.reshape(bi.kpad, 48)[:k].view(np.uint32), nso.unpack_fp32(blob).view(np.uint32))
+
+
+def test_reduce_matches_reference(nso, refk):
+    rng = np.random.default_rng(23)
+    n, k, bs = 48, 96, 32
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    for asym in (False, True):
+        blob = nso.quant_pack(w, bs, nso.S4, nso.BF16, asym, nso.CORE_AVX512_VNNI_KB)
+        bi = nso.parse(blob)
+        assert bi.has_reduce
+        deq = nso.unpack_fp32(blob)
+        red = blob[bi.red_off:bi.red_off + bi.red_bytes].view(np.uint16).reshape(-1, bi.cstep)
+        for kb in range(k // bs):
+            out = np.zeros(n, np.uint16)
+            blk = np.ascontiguousarray(deq[kb * bs:(kb + 1) * bs])
+            refk.ref_row_reduce_sum_bf16(nso.ptr(blk), n, bs, n, nso.ptr(out))
+            assert np.array_equal(out, red[kb, :n])
+
+
+@pytest.mark.parametrize("scale_bf16", [False, True])
+@pytest.mark.parametrize("m", [1, 2, 4])
+@pytest.mark.parametrize("asym", [False, True])
+def test_gemv_fp32_matches_reference(nso, refk, scale_bf16, m, asym):
+    """oracle sequential-fp32 GEMV == gemv_4bit_fp32_fp32 (kernel_ref.h:2489-2531), bit for bit."""
+    rng = np.random.default_rng(31)
+    n, k, bs = 96, 256, 32
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    blob = nso.quant_pack(w, bs, nso.S4, nso.BF16 if scale_bf16 else nso.F32, asym, nso.CORE_AVX512F)
+    bi = nso.parse(blob)
+    mine = nso.gemv_f32(a, blob, nthreads=1)
+    for t in range(2):
+        cref = np.zeros((m, 48), np.float32)
+        b4 = blob[bi.q_off + t * 48 * bi.kpad // 2:]
+        es = 2 if scale_bf16 else 4
+        sc = blob[bi.scale_off + t * 48 * es:]
+        zp = blob[bi.zp_off + t * 48:] if asym else None
+        rc = refk.ref_gemv_4bit_fp32_fp32(nso.ptr(a), k, nso.ptr(b4), nso.ptr(sc), int(scale_bf16), nso.ptr(zp),
+                                          bi.cstep, nso.ptr(cref), 48, k, bs, m)
+        assert rc == 0
+        assert np.array_equal(cref.view(np.uint32), mine[:, t * 48:(t + 1) * 48].view(np.uint32))
+    # and the fp64 GEMM oracle agrees with it to fp32 round-off
+    assert nso.rel_l2(mine, nso.gemm_f64(a, blob)) < 2e-6
+
+
+def test_act_quant_and_u8s8_gemv(nso, refk):
+    rng = np.random.default_rng(41)
+    n, k, bs, m = 48, 256, 32, 1
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    nb = k // bs
+    aq = np.zeros((m, k), np.uint8)
+    asc = np.zeros((m, nb), np.float32)
+    azp = np.zeros((m, nb), np.uint8)
+    red = np.zeros((m, nb), np.float32)
+    aq2, asc2, azp2, red2 = [np.zeros_like(x) for x in (aq, asc, azp, red)]
+    nso.lib().nso_quantize_fp_u8_colblock(m, k, nso.ptr(a), k, nso.ptr(aq), k, nso.ptr(asc), nb, nso.ptr(azp), bs, nso.ptr(red))
+    refk.ref_quantize_fp_u8_colblock(m, k, nso.ptr(a), k, nso.ptr(aq2), k, nso.ptr(asc2), nb, nso.ptr(azp2), bs, nso.ptr(red2))
+    assert np.array_equal(aq, aq2) and np.array_equal(azp, azp2)
+    assert np.array_equal(asc.view(np.uint32), asc2.view(np.uint32)) and np.array_equal(red.view(np.uint32), red2.view(np.uint32))
+    for asym in (False, True):
+        blob = nso.quant_pack(w, bs, nso.S4, nso.F32, asym, nso.CORE_AVX512_VNNI_KB)
+        bi = nso.parse(blob)
+        mine = nso.gemm_u8s8(a, blob)
+        cref = np.zeros((1, 48), np.float32)
+        sc = blob[bi.scale_off:bi.scale_off + bi.scale_bytes].view(np.float32).copy()
+        zp = blob[bi.zp_off:] if asym else None
+        rc = refk.ref_gemv_4bit_u8s8_fp32(nso.ptr(aq), nso.ptr(asc), nso.ptr(azp), k, nb, nso.ptr(blob[bi.q_off:]),
+                                          nso.ptr(sc), nso.ptr(zp), bi.cstep, nso.ptr(cref), 48, k, bs)
+        assert rc == 0
+        assert np.array_equal(cref.view(np.uint32), mine.view(np.uint32))
