@@ -1,0 +1,177 @@
+/*
+ * ns_bestla.h — C ABI of libns_hip.so, the MI355X (gfx950) backend that drops in behind neural-speed's
+ * BesTLA operator surface.  Plain pointers and sizes only; no torch / HIP types in the signatures.
+ *
+ * Part 1 mirrors, name for name and argument for argument, the extern "C" surface of
+ *   /root/reference/neural_speed/core/ne_bestla.h:21-83
+ * so that a neural-speed build can link this library instead of its bestla layer.
+ * Pointers in part 1 are HOST pointers exactly as in the reference; calls are synchronous.
+ *
+ * Part 2 is the quantizer/packer side, C-callable twins of the C++ functions in
+ *   /root/reference/neural_speed/core/layers/bestla_gemm.h:38-55
+ *
+ * Part 3 is the device-resident API modelled on the reference's own device backend precedent
+ *   /root/reference/neural_speed/core/ne_bestla.h:85-112 (bestla_device_*):
+ * weights are loaded once into HBM in the MI355X layout, activations/outputs are DEVICE pointers and the
+ * `stream` argument is a hipStream_t passed as void*.
+ *
+ * Error behaviour follows the reference: forwards print "Err: invalid parameters" and
+ * return (release-build behaviour of inner_product.cpp:31-35); *_support() returning false is the only
+ * graceful refusal; sizes return 0 on failure; part-3 functions additionally return an int status
+ * (0 = ok) because they have no reference counterpart to stay silent for.
+ * If no HIP device is present every compute entry fails loudly (prints + returns error); there is NO CPU
+ * fallback in this library.
+ */
+#ifndef NS_BESTLA_H
+#define NS_BESTLA_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 1 — reference operator surface (ne_bestla.h).  Host pointers, synchronous.
+ * ---------------------------------------------------------------------------------------------- */
+void bestla_init(void);                    /* ne_bestla.h:33  */
+void bestla_timer(bool _init);             /* ne_bestla.h:23  */
+int bestla_set_threads(int _nth);          /* ne_bestla.h:25  (no host thread pool here: returns _nth) */
+void* bestla_get_thread_handle(void);      /* ne_bestla.h:27  (returns the backend context) */
+
+/* ne_bestla.h:35 / inner_product.cpp:20-25 */
+unsigned long long bestla_f32f32_get_workspace_size(int _m, int _n, int _k, void* wptr);
+/* ne_bestla.h:37-38 / inner_product.cpp:28-36:  output[m][n] = activation[m][k] * W[k][n] */
+void bestla_f32f32_forward(float* activation, void* weiptr, float* output, int _m, int _n, int _k, int lda, int ldo,
+                           void* workspace);
+
+/* ne_bestla.h:40-42 / inner_product.cpp:113-244 */
+bool bestla_fusion_add_f32f32_support(void* weiptr, int _m, int _n, int _k);
+void bestla_fusion_add_f32f32_forward(float* activation, void* weiptr, float* bias, float* output, int _m, int _n,
+                                      int _k, int lda, int ldo, bool boardcast_bias, void* workspace);
+
+/* ne_bestla.h:44-51 / ip_fusion_qkv.cpp:155-307: output = {Q | K | V}, each [m][ldo], stacked along dim 0 */
+unsigned long long bestla_fusion_QKV_f32f32_get_workspace_size(int _m, int _n, int _k, void* w1ptr);
+bool bestla_fusion_QKV_f32f32_support(void* wqptr, void* wkptr, void* wvptr, int _m, int _n, int _k);
+void bestla_fusion_QKV_f32f32_forward(float* activation, void* wqptr, void* wkptr, void* wvptr, float* output, int _m,
+                                      int _n, int _k, int lda, int ldo, void* workspace);
+
+/* ne_bestla.h:53-81 / ip_fusion_ffn.cpp:20-29,724-779 */
+unsigned long long bestla_fusion_FFN_f32f32_get_workspace_size(int seq, int fin, int fmid, int fout, void* w1ptr,
+                                                               void* w2ptr);
+bool bestla_fusion_FFN_Gelu_Mul_f32f32_support(void* w1ptr, void* w2ptr, void* w3ptr, int seq, int fin, int fmid,
+                                               int fout);
+void bestla_fusion_FFN_Gelu_Mul_f32f32_forward(float* activation, void* w1ptr, void* w2ptr, void* w3ptr, float* tmp1,
+                                               float* tmp2, float* output, int seq, int fin, int fmid, int fout,
+                                               void* workspace);
+bool bestla_fusion_FFN_SiLu_f32f32_support(void* w1ptr, void* w2ptr, void* w3ptr, int seq, int fin, int fmid, int fout);
+void bestla_fusion_FFN_SiLu_f32f32_forward(float* activation, void* w1ptr, void* w2ptr, void* w3ptr, float* tmp1,
+                                           float* tmp2, float* output, int seq, int fin, int fmid, int fout,
+                                           void* workspace);
+bool bestla_fusion_FFN_GeLu_f32f32_support(void* w1ptr, void* w2ptr, int seq, int fin, int fmid, int fout);
+void bestla_fusion_FFN_GeLu_f32f32_forward(float* activation, void* w1ptr, void* w2ptr, float* tmp1, float* output,
+                                           int seq, int fin, int fmid, int fout, void* workspace);
+bool bestla_fusion_FFN_Add_GeLu_f32f32_support(void* w1ptr, void* w2ptr, int seq, int fin, int fmid, int fout);
+void bestla_fusion_FFN_Add_GeLu_f32f32_forward(float* activation, void* w1ptr, void* w2ptr, float* b1ptr, float* b2ptr,
+                                               float* tmp1, float* output, int seq, int fin, int fmid, int fout,
+                                               bool boardcast_bias, void* workspace);
+
+/* ne_bestla.h:67-69 / ne_bestla.cpp:74-111 */
+void bestla_unpackweight_fp32(void* wptr, int n, int k, float* fp32data, int ld);
+void bestla_packweight_copyattr(const float* f32ptr, void* dstpr, int n, int k, int ld, void* srcptr);
+
+/* ne_bestla.h:71-75 / ne_bestla.cpp:113-164 */
+void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* FpIn,
+                               float* FpOut);
+void bestla_mul(int batch, int vsize, const float* tensor, const float* vector, int vstep, float* out);
+void bestla_add(int batch, int vsize, const float* tensor, const float* vector, int vstep, float* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 2 — quantize / pack (bestla_gemm.h:38-55).  dtypes are BTLA_DTYPE values (bestla.h:38-87),
+ * CompType is ne_comp_type (neural_speed/core/data_types.h:57-63), same numeric values as ns_comp_type below.
+ * The blob layout is CPU-ISA specific in the reference (chosen from CPUID, bestla_gemm.cpp:241-300); this
+ * library has no CPUID to consult, so the target core is a process-wide setting (default
+ * NS_CORE_AUTO: comp int8 -> AVX512_VNNI k-block core, bf16 -> AMX_BF16, fp16 -> AMX_FP16, else AVX512F),
+ * settable with ns_set_pack_core().  Loading accepts every reference core.
+ * ---------------------------------------------------------------------------------------------- */
+enum ns_comp_type { NS_COMP_UNDEF = 0, NS_COMP_F32 = 1, NS_COMP_BF16 = 2, NS_COMP_F16 = 3, NS_COMP_INT8 = 4 };
+enum ns_core {
+  NS_CORE_AVX2 = 0,
+  NS_CORE_AVX512F = 1,
+  NS_CORE_AMX_BF16 = 2,
+  NS_CORE_AMX_FP16 = 3,
+  NS_CORE_AVX512_VNNI_KB = 4,
+  NS_CORE_AVX512BW_KB = 5,
+  NS_CORE_AVX_VNNI_KB = 6,
+  NS_CORE_AVX2_VNNI_KB = 7,
+  NS_CORE_AMX_INT8_KB = 8,
+  NS_CORE_AUTO = -1
+};
+void ns_set_pack_core(int core);
+/* BTLAGemmPackBSize — bestla_gemm.cpp:626-639 */
+size_t ns_BTLAGemmPackBSize(size_t N, size_t K, size_t BlkSize, uint32_t QuantType, uint32_t ScaleDtype, bool isAsym,
+                            int CompType, int* shuffle_indice);
+/* BTLAGemmQuantPackB — bestla_gemm.cpp:641-655 (quantize + pack on the GPU, bit-exact blob) */
+bool ns_BTLAGemmQuantPackB(void* PackedBuf, const float* FpData, size_t N, size_t K, size_t ldb, size_t BlkSize,
+                           uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType, bool isTrans,
+                           void* ThreadPool);
+/* BTLAGemmPackB — bestla_gemm.cpp:657-671 (pre-quantized int8 codes + fp32 scales + zero points) */
+bool ns_BTLAGemmPackB(void* PackedBuf, const int8_t* QData, const float* Scales, const int8_t* Zp, size_t N, size_t K,
+                      size_t ldb, size_t BlkSize, uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType,
+                      int* shuffle_indice, void* ThreadPool);
+/* BTLAGemmUnPackB — bestla_gemm.cpp:673-749 */
+bool ns_BTLAGemmUnPackB(float* FpData, const void* PackedBuf, size_t N, size_t K, size_t ldb, void* ThreadPool);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 3 — device-resident API (precedent: bestla_device_* , ne_bestla.h:85-112)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ns_weight ns_weight; /* opaque: one weight matrix resident in HBM in the MI355X layout */
+
+int ns_hip_device_count(void);
+const char* ns_hip_last_error(void);
+/* host blob (reference format) -> device weight.  The blob is only read. */
+ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream);
+/* same, blob bytes already in device memory (dev_blob_base_mod64 = (host address the blob was packed at) & 63;
+ * blobs packed by this library at 64-byte aligned bases use 0) */
+ns_weight* ns_hip_weight_from_device_blob(const void* dev_blob, size_t blob_bytes, void* stream);
+void ns_hip_weight_free(ns_weight* w);
+int ns_hip_weight_info(const ns_weight* w, int* n, int* k, int* bits, int* blocksize, uint64_t* device_bytes);
+/* algorithmic bytes one forward over this weight streams: packed codes + scales (+ zero points), i.e.
+ * N*K*bits/8 + N*(K/g)*sizeof(scale) [+ N*(K/g)] — the reference benchmark's formula (ut/bestla_benchmark.cpp:583-586) */
+uint64_t ns_hip_weight_stream_bytes(const ns_weight* w);
+
+/* epilogue selector for the device forwards */
+enum ns_epilogue {
+  NS_EPI_NONE = 0,      /* AccumulatorWriteBackFp32 (bestla_epilogue.h:114-136) */
+  NS_EPI_ADD = 1,       /* custom::epilogue::Add      (bestla_common.hpp:121-147): C = acc + D */
+  NS_EPI_MUL = 2,       /* custom::epilogue::Mul      (bestla_common.hpp:149-181): C = acc * D */
+  NS_EPI_ADD_GELU = 3,  /* custom::epilogue::Add_Gelu (bestla_common.hpp:183-213): C = gelu(acc + D) */
+  NS_EPI_GELU = 4,      /* AccumulatorWriteBackWithGeluFp32 */
+  NS_EPI_SILU = 5       /* AccumulatorWriteBackWithSwishFp32 (alpha = -1) */
+};
+
+/* dC[m][ldc] = epi(dA[m][lda] * W, dD[m][ldd]);  ldd = 0 broadcasts one row of D (bias) */
+int ns_hip_f32f32_forward(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
+                          const float* dD, int ldd, void* stream);
+/* dC = {A*Wq | A*Wk | A*Wv} stacked along dim 0 exactly as ip_fusion_qkv.cpp:84-86 (C, C+m*ldc, C+2*m*ldc) */
+int ns_hip_fusion_qkv_forward(const float* dA, const ns_weight* wq, const ns_weight* wk, const ns_weight* wv, float* dC,
+                              int m, int lda, int ldc, void* stream);
+/* act: NS_EPI_SILU or NS_EPI_GELU.  tmp1 = act(A*W1); tmp2 = (A*W3) * tmp1; out = tmp2 * W2
+ * (ip_fusion_ffn.cpp:364-406).  tmp1 may be NULL on the device path (the fused gate/up kernel writes tmp2 only). */
+int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const ns_weight* w3,
+                               float* dTmp1, float* dTmp2, float* dOut, int seq, int act, void* stream);
+/* tmp1 = gelu(A*W1 [+ b1]); out = tmp1*W2 [+ b2]   (ip_fusion_ffn.cpp ffn_2w) */
+int ns_hip_fusion_ffn2_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const float* dB1,
+                               const float* dB2, float* dTmp1, float* dOut, int seq, bool broadcast_bias, void* stream);
+
+/* quantize + pack entirely on the device: dW fp32 [N][K] (is_trans) or [K][N]; writes the reference-format blob
+ * into dBlob (device memory, ns_BTLAGemmPackBSize bytes, 64-byte aligned) */
+int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, size_t ldb, size_t BlkSize,
+                             uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType, bool isTrans,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NS_BESTLA_H */

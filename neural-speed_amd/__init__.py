@@ -1,0 +1,157 @@
+"""neural-speed_amd — MI355X (gfx950) backend behind neural-speed's BesTLA operator surface.
+
+The product is the C-ABI shared library ``libns_hip.so`` (sources in ``csrc/``, interface in
+``include/ns_bestla.h``).  This Python module is only the thin ctypes loader used by tests, bench.py and
+__graft_entry__.py; it contains no compute and imports nothing from ``oracle/``.
+
+Because the directory name carries a hyphen (it mirrors the reference's repository name) it is loaded with
+``importlib`` — see ``load_package()`` in ``__graft_entry__.py``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libns_hip.so")
+
+# BTLA_DTYPE codes (reference: bestla/bestla/bestla.h:38-87)
+F32 = 32
+F16 = 16
+BF16 = 16 | (1 << 16)
+S8 = 8 | (1 << 8)
+S4 = 4 | (1 << 8)
+F4_E2M1 = 4
+F4_BNB = 4 | (1 << 16)
+F4_NF4 = 4 | (2 << 16)
+INT_TYPES = {b: b | (1 << 8) for b in range(1, 9)}
+# ne_comp_type (neural_speed/core/data_types.h:57-63)
+COMP_UNDEF, COMP_F32, COMP_BF16, COMP_F16, COMP_INT8 = range(5)
+# enum ns_epilogue
+EPI_NONE, EPI_ADD, EPI_MUL, EPI_ADD_GELU, EPI_GELU, EPI_SILU = range(6)
+CORE_AUTO = -1
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into neural-speed_amd/libns_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc"), "-j8"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises loudly when it has not been built: there is no Python/CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libns_hip.so is missing: run neural-speed_amd.build() (make -C neural-speed_amd/csrc)")
+        L = C.CDLL(LIB_PATH)
+        vp, i, u32, sz, f, b = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t, C.c_float, C.c_bool
+        L.ns_hip_last_error.restype = C.c_char_p
+        L.ns_hip_weight_from_blob.restype = vp
+        L.ns_hip_weight_from_blob.argtypes = [vp, vp]
+        L.ns_hip_weight_from_device_blob.restype = vp
+        L.ns_hip_weight_from_device_blob.argtypes = [vp, sz, vp]
+        L.ns_hip_weight_free.argtypes = [vp]
+        L.ns_hip_weight_free.restype = None
+        L.ns_hip_weight_stream_bytes.restype = C.c_uint64
+        L.ns_hip_weight_stream_bytes.argtypes = [vp]
+        L.ns_hip_weight_info.argtypes = [vp] + [vp] * 5
+        L.ns_hip_f32f32_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
+        L.ns_hip_fusion_qkv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
+        L.ns_hip_fusion_ffn3_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.ns_hip_fusion_ffn2_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, b, vp]
+        L.ns_hip_quant_pack_device.argtypes = [vp, vp, sz, sz, sz, sz, u32, u32, b, i, b, vp]
+        L.ns_BTLAGemmPackBSize.restype = sz
+        L.ns_BTLAGemmPackBSize.argtypes = [sz, sz, sz, u32, u32, b, i, vp]
+        L.ns_BTLAGemmQuantPackB.restype = b
+        L.ns_BTLAGemmQuantPackB.argtypes = [vp, vp, sz, sz, sz, sz, u32, u32, b, i, b, vp]
+        L.ns_BTLAGemmPackB.restype = b
+        L.ns_BTLAGemmPackB.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz, u32, u32, b, i, vp, vp]
+        L.ns_BTLAGemmUnPackB.restype = b
+        L.ns_BTLAGemmUnPackB.argtypes = [vp, vp, sz, sz, sz, vp]
+        L.ns_set_pack_core.argtypes = [i]
+        L.ns_set_pack_core.restype = None
+        L.bestla_f32f32_get_workspace_size.restype = C.c_ulonglong
+        L.bestla_f32f32_get_workspace_size.argtypes = [i, i, i, vp]
+        L.bestla_f32f32_forward.restype = None
+        L.bestla_f32f32_forward.argtypes = [vp, vp, vp, i, i, i, i, i, vp]
+        L.bestla_fusion_add_f32f32_support.restype = b
+        L.bestla_fusion_add_f32f32_support.argtypes = [vp, i, i, i]
+        L.bestla_fusion_add_f32f32_forward.restype = None
+        L.bestla_fusion_add_f32f32_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, i, b, vp]
+        L.bestla_fusion_QKV_f32f32_support.restype = b
+        L.bestla_fusion_QKV_f32f32_support.argtypes = [vp, vp, vp, i, i, i]
+        L.bestla_fusion_QKV_f32f32_forward.restype = None
+        L.bestla_fusion_QKV_f32f32_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        for name in ("SiLu", "Gelu_Mul"):
+            fs = getattr(L, "bestla_fusion_FFN_%s_f32f32_support" % name)
+            fs.restype = b
+            fs.argtypes = [vp, vp, vp, i, i, i, i]
+            ff = getattr(L, "bestla_fusion_FFN_%s_f32f32_forward" % name)
+            ff.restype = None
+            ff.argtypes = [vp] * 7 + [i, i, i, i, vp]
+        L.bestla_fusion_FFN_GeLu_f32f32_support.restype = b
+        L.bestla_fusion_FFN_GeLu_f32f32_support.argtypes = [vp, vp, i, i, i, i]
+        L.bestla_fusion_FFN_GeLu_f32f32_forward.restype = None
+        L.bestla_fusion_FFN_GeLu_f32f32_forward.argtypes = [vp] * 5 + [i, i, i, i, vp]
+        L.bestla_fusion_FFN_Add_GeLu_f32f32_support.restype = b
+        L.bestla_fusion_FFN_Add_GeLu_f32f32_support.argtypes = [vp, vp, i, i, i, i]
+        L.bestla_fusion_FFN_Add_GeLu_f32f32_forward.restype = None
+        L.bestla_fusion_FFN_Add_GeLu_f32f32_forward.argtypes = [vp] * 7 + [i, i, i, i, b, vp]
+        L.bestla_unpackweight_fp32.restype = None
+        L.bestla_unpackweight_fp32.argtypes = [vp, i, i, vp, i]
+        L.bestla_packweight_copyattr.restype = None
+        L.bestla_packweight_copyattr.argtypes = [vp, vp, i, i, i, vp]
+        L.bestla_layernormalization.restype = None
+        L.bestla_layernormalization.argtypes = [i, i, b, f, vp, vp]
+        L.bestla_mul.restype = None
+        L.bestla_mul.argtypes = [i, i, vp, vp, i, vp]
+        L.bestla_add.restype = None
+        L.bestla_add.argtypes = [i, i, vp, vp, i, vp]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().ns_hip_last_error().decode()
+
+
+def check(rc, what="call"):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, last_error()))
+
+
+class Weight:
+    """RAII wrapper of an ns_weight* (device-resident weight in the MI355X layout)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("weight creation failed: " + last_error())
+        self.h = handle
+        n, k, bits, bs = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        db = C.c_uint64()
+        lib().ns_hip_weight_info(self.h, C.byref(n), C.byref(k), C.byref(bits), C.byref(bs), C.byref(db))
+        self.n, self.k, self.bits, self.blocksize, self.device_bytes = n.value, k.value, bits.value, bs.value, db.value
+        self.stream_bytes = lib().ns_hip_weight_stream_bytes(self.h)
+
+    @classmethod
+    def from_host_blob(cls, blob_ptr, stream=None):
+        return cls(lib().ns_hip_weight_from_blob(blob_ptr, stream))
+
+    @classmethod
+    def from_device_blob(cls, dev_ptr, nbytes, stream=None):
+        return cls(lib().ns_hip_weight_from_device_blob(dev_ptr, nbytes, stream))
+
+    def free(self):
+        if self.h:
+            lib().ns_hip_weight_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,163 @@
+// ns_common.h — internal declarations of libns_hip.so (MI355X backend behind neural-speed's BesTLA surface).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <functional>
+#include <string>
+
+namespace ns {
+
+// ---- BTLA_DTYPE bit encoding (reference: bestla/bestla/bestla.h:38-87) --------------------------------------
+constexpr uint32_t DT_F32 = 32, DT_F16 = 16, DT_BF16 = 16 | (1u << 16), DT_S8 = 8 | (1u << 8);
+constexpr uint32_t DT_S4 = 4 | (1u << 8);
+constexpr uint32_t DT_F4_E2M1 = 4, DT_F4_BNB = 4 | (1u << 16), DT_F4_NF4 = 4 | (2u << 16);
+__host__ __device__ inline int dt_bits(uint32_t t) { return int(t & 0xff); }
+__host__ __device__ inline bool dt_is_int(uint32_t t) { return ((t >> 8) & 0xff) == 1; }
+inline bool dt_is_f4(uint32_t t) { return t == DT_F4_E2M1 || t == DT_F4_BNB || t == DT_F4_NF4; }
+
+// ---- reference GEMM cores a blob may be laid out for (bestla_defs.h:36-54, bestla_gemm.h CoreAttr :83-123) ----
+struct CoreDesc {
+  int ntile, packrow, ktile, comp, isa;
+  uint64_t id() const {
+    return uint64_t(ntile) | (uint64_t(packrow) << 8) | (uint64_t(comp) << 16) | (uint64_t(isa) << 32);
+  }
+};
+const CoreDesc& core_desc(int ns_core);  // index = enum ns_core
+int core_for_comp(int comp_type, uint32_t qtype, bool asym, size_t blocksize, int forced_core);
+
+// ---- parsed view of a reference-format blob (bestla_storage.h:250-357, :697-859) ------------------------------
+struct BlobView {
+  uint64_t size = 0;
+  uint32_t prologue = 0;  // 1 = WeightKBlockNInteger, 2 = WeightKBlockNFloat
+  uint64_t core_id = 0;
+  int npad = 0, kpad = 0, n = 0, k = 0;
+  uint32_t dtype = 0;
+  int blocksize = 0, dq_blocksize = 0;
+  uint32_t scale_dt = 0, zp_dt = 0, red_dt = 0;
+  int cstep = 0;
+  uint64_t csize = 0;
+  // section offsets (bytes from blob base) and sizes; 0 size = absent
+  uint64_t q_off = 0, q_bytes = 0, s_off = 0, s_bytes = 0, z_off = 0, z_bytes = 0, r_off = 0, r_bytes = 0,
+           shuf_off = 0, shuf_bytes = 0;
+  int ntile() const { return int(core_id & 0xff); }
+  int packrow() const { return int((core_id >> 8) & 0xff); }
+  int comp() const { return int((core_id >> 16) & 0xffff); }
+  bool asym() const { return z_bytes > 0; }
+  bool has_reduce() const { return r_bytes > 0; }
+};
+// Header access callback: (byte offset from the blob base, buffer, length, writing?)
+using BlobIo = std::function<void(size_t, void*, size_t, bool)>;
+// Parse the header found at `blob` (host memory) / behind an IO callback (device memory).
+bool blob_parse(const void* blob, BlobView* out, std::string* err);
+bool blob_parse_io(const BlobIo& io, BlobView* out, std::string* err);
+// Fill sizes/offsets for a NEW blob that will be serialised at address `base_addr`: the reference aligns each
+// section to 64 B in absolute-address terms (bestla_storage.h:85-95), so the layout depends on base_addr % 64.
+bool blob_describe(BlobView* out, size_t n, size_t k, size_t blocksize, uint32_t qtype, uint32_t stype, bool asym,
+                   int ns_core, uintptr_t base_addr, std::string* err);
+// Write every non-payload byte (sizes, pads, flags, ids) of a described blob.
+void blob_write_header(const BlobView& v, void* host_base);
+void blob_write_header_io(const BlobView& v, const BlobIo& io, uintptr_t base_addr);
+
+// ---- device weight -------------------------------------------------------------------------------------------
+enum WKind { WK_INT4 = 0, WK_INT8 = 1, WK_F4 = 2 };
+
+}  // namespace ns
+
+// One weight matrix resident in HBM in the MI355X streaming layout:
+//   codes : [ntiles][ksteps][64 lanes][16 B]   lane = c*16 + nn  (nn = column in the 16-wide tile, c = 0..3)
+//           4-bit: KSTEP = 128, dword j (0..3) of a lane holds k = s*128 + 32*j + 8*c + i, i = 0..7, nibble i at
+//                  bit {0,16,4,20,8,24,12,28}[i]   (so (x & 0x000f000f) and (x & 0x00f000f0) are MFMA k-pairs)
+//           8-bit: KSTEP = 64,  bytes 8*j .. 8*j+7 (j = 0..1) hold k = s*64 + 32*j + 8*c + i
+//   scales: [ntiles][G][16][SPS] in the blob's scale dtype; SPS = max(1, KSTEP/blocksize), G = ksteps (SPS>1 or
+//           blocksize == KSTEP) else ceil(K/blocksize)
+//   zps   : int8, same shape as scales (asymmetric only)
+struct ns_weight {
+  int n = 0, k = 0;
+  int ntiles = 0, ksteps = 0, kstep_len = 128;
+  int kind = 0;        // ns::WKind
+  uint32_t qtype = 0;  // BTLA_DTYPE of the codes
+  int blocksize = 0;
+  int sps = 1, srows = 0;  // scales per k-step per column; scale rows G
+  int srow_shift = 0;      // scale row of k-step s = (SPS>1||bs==KSTEP) ? s : (s*KSTEP)/blocksize
+  uint32_t scale_dt = 0;
+  bool asym = false;
+  uint4* codes = nullptr;
+  void* scales = nullptr;
+  int8_t* zps = nullptr;
+  size_t codes_bytes = 0, scales_bytes = 0, zps_bytes = 0;
+  uint64_t stream_bytes = 0;  // algorithmic bytes (reference formula)
+  int device = 0;
+  _Float16 lut[16];  // f4 value table as fp16 (kind == WK_F4)
+};
+
+namespace ns {
+// ---- launchers implemented in ns_kernels.hip ------------------------------------------------------------------
+struct RepackArgs {
+  const uint8_t* q;       // device: reference packed image
+  const uint8_t* scales;  // device: reference scales [nblk][cstep] in scale_dt
+  const int8_t* zps;      // device or null
+  int ref_ntile, ref_packrow, ref_kpad, ref_npad, cstep, ref_nblk;
+};
+hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st);
+
+struct GemmSeg {
+  const ns_weight* w;
+  float* c;  // output base of this segment
+};
+struct SmallMArgs {
+  const float* a;
+  int lda, m;
+  int ldc;
+  int nseg;        // 1..3 segments laid side by side in the grid (QKV); all share K and format
+  GemmSeg seg[3];
+  int epilogue;    // enum ns_epilogue
+  const float* d;  // epilogue operand
+  int ldd;
+  bool dual;       // gate/up fusion: seg[0] = W1, seg[1] = W3, out = act(A*W1) * (A*W3) -> seg[0].c ; tmp1 -> c2
+  float* c2;       // optional tmp1 output in dual mode
+};
+hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
+bool smallm_supported(const ns_weight* w, int m);
+
+hipError_t launch_unpack_fp32(const ns_weight* w, float* out, int ld, hipStream_t st);  // device [K][N]
+
+struct QuantArgs {
+  const float* w;  // device fp32
+  size_t n, k, ld;
+  bool is_trans;  // true: w is [N][K]
+  int blocksize;
+  uint32_t qtype, stype;
+  bool asym;
+  int ref_ntile, ref_packrow, ref_kpad, ref_npad, cstep;
+  bool has_reduce;
+  uint8_t* q_out;  // device blob sections
+  uint8_t* s_out;
+  int8_t* z_out;
+  uint16_t* r_out;
+};
+hipError_t launch_quant_pack(const QuantArgs& a, hipStream_t st);
+struct PackQArgs {
+  const int8_t* q;      // device [K][ldq] codes
+  const float* scales;  // device [nblk][N]
+  const int8_t* zps;    // device [nblk][N] or null
+  size_t n, k, ldq;
+  int blocksize;
+  uint32_t qtype, stype;
+  int ref_ntile, ref_packrow, ref_kpad, ref_npad, cstep;
+  bool has_reduce;
+  uint8_t* q_out;
+  uint8_t* s_out;
+  int8_t* z_out;
+  uint16_t* r_out;
+};
+hipError_t launch_pack_q(const PackQArgs& a, hipStream_t st);
+
+hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* out,
+                          hipStream_t st);
+hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float* v, int vstep, float* out, bool mul,
+                               hipStream_t st);
+
+void set_error(const std::string& s);
+}  // namespace ns

@@ -1,0 +1,618 @@
+// ns_kernels.hip — hand-written gfx950 (MI355X / CDNA4) kernels of libns_hip.so.
+//
+//   repack_*        reference blob image  -> MI355X streaming layout            (load time, byte shuffling, HBM-bound)
+//   smallm_kernel   C[M<=64][N] = A * dequant(W): weight-streaming MFMA kernel   (decode hot path, HBM-bound)
+//   unpack_kernel   device layout -> fp32 [K][N]                                (bestla_unpackweight_fp32)
+//   quant_* / pack_* fp32 -> codes/scales/zp -> reference blob image, bit-exact  (offline quantizer on the GPU)
+//
+// Reference semantics implemented (paths under /root/reference):
+//   dequant   w = (code - zp) * scale            bestla/bestla/kernel_ref.h:1027-1127 (decompress_kblock_s4_fp)
+//             w = LUT[code] * scale              kernel_ref.h:1456-1478 (decompress_kblock_f4_fp), LUTs bestla_utils.h:749-789
+//   gemv      acc += a * w                       kernel_ref.h:2489-2531 (gemv_4bit_fp32_fp32)  [fp16 a, fp32 acc here]
+//   quantize  per (k-block, column)              kernel_ref.h:1608-1719, :1801-1822
+//   pack      interleave + bit planes + reduce   kernel_ref.h:39-57, :155-365, :2132-2142; bestla_prologue_b.h:378-617
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "ns_common.h"
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+
+namespace ns {
+
+// ============================================================================================================
+// small device helpers
+// ============================================================================================================
+__device__ __forceinline__ half2_t as_half2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+__device__ __forceinline__ uint32_t as_u32(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
+  return float(__builtin_bit_cast(_Float16, (unsigned short)b));
+}
+__device__ __forceinline__ float load_scale(const void* base, size_t idx, uint32_t dt) {
+  if (dt == DT_F32) return static_cast<const float*>(base)[idx];
+  uint32_t h = static_cast<const unsigned short*>(base)[idx];
+  return dt == DT_BF16 ? bf16_bits_to_f32(h) : f16_bits_to_f32(h);
+}
+// streaming (read-once) 16-byte load: non-temporal so the weight stream does not evict A / scales from L2/MALL
+__device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+  const uint4v v = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p));
+  return uint4{v.x, v.y, v.z, v.w};
+}
+// nibble i (0..7, ascending k) of a device dword sits at this bit: pairs (0,1) (2,3) (4,5) (6,7) are MFMA k-pairs
+__device__ __host__ __forceinline__ int nib_shift(int i) { return ((i & 1) << 4) + ((i >> 1) << 2); }
+
+// element (k, n) of the reference's interleaved image: [N/NTILE][KPad/PACK][NTILE][PACK]
+// (padding_interleave kernel_ref.h:39-57 as driven by reorderWeight bestla_prologue_b.h:490-510)
+__device__ __forceinline__ size_t ref_tiled_index(int k, int n, int ntile, int packrow, int kpad) {
+  return size_t(n / ntile) * ntile * kpad + size_t(k / packrow) * ntile * packrow + size_t(n % ntile) * packrow +
+         (k % packrow);
+}
+// unsigned stored code of element e of a reference bit-plane image (compress_*, kernel_ref.h:155-365;
+// plane offsets bestla_prologue_b.h:512-547).  4/8-bit and f4 have a single plane.
+__device__ __forceinline__ int ref_stored_code(const uint8_t* img, size_t e, size_t elts, int bits) {
+  if (bits == 8) return img[e];
+  if (bits == 4) return (img[e >> 1] >> ((e & 1) * 4)) & 0xf;
+  const uint8_t* p = img;
+  int v = 0, sh = 0;
+  if (bits & 4) {
+    v |= (p[e >> 1] >> ((e & 1) * 4)) & 0xf;
+    p += elts / 2;
+    sh = 4;
+  }
+  if (bits & 2) {
+    v |= ((p[e >> 2] >> ((e & 3) * 2)) & 0x3) << sh;
+    p += elts / 4;
+    sh += 2;
+  }
+  if (bits & 1) v |= ((p[e >> 3] >> (e & 7)) & 0x1) << sh;
+  return v;
+}
+
+// ============================================================================================================
+// repack: reference blob sections -> device streaming layout (see ns_common.h ns_weight)
+// ============================================================================================================
+__global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint32_t* __restrict__ out, int n, int k,
+                                    int ntiles, int ksteps, int kind, int ref_bits, int ref_ntile, int ref_packrow,
+                                    int ref_kpad, int ref_npad) {
+  // one thread per output dword
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t total = size_t(ntiles) * ksteps * 64 * 4;
+  if (gid >= total) return;
+  const int d = int(gid & 3);
+  const int lane = int((gid >> 2) & 63);
+  const size_t ts = gid >> 8;
+  const int s = int(ts % ksteps);
+  const int t = int(ts / ksteps);
+  const int nn = lane & 15, c = lane >> 4;
+  const int col = t * 16 + nn;
+  const size_t elts = size_t(ref_npad) * ref_kpad;
+  uint32_t word = 0;
+  if (kind == WK_INT8) {
+    // dword d of the lane: j = d >> 1, bytes i = (d & 1) * 4 .. +3 ; k = s*64 + 32*j + 8*c + i
+    const int j = d >> 1;
+    for (int b = 0; b < 4; b++) {
+      const int kk = s * 64 + 32 * j + 8 * c + (d & 1) * 4 + b;
+      int q = 0;
+      if (kk < k && col < n) q = img[ref_tiled_index(kk, col, ref_ntile, ref_packrow, ref_kpad)];
+      word |= uint32_t(q & 0xff) << (8 * b);
+    }
+  } else {
+    // dword j = d: k = s*128 + 32*j + 8*c + i
+    const int zero_code = (kind == WK_INT4) ? 8 : 0;  // int4 stores code+8 (compress_s8_s4); f4 code 0 decodes to 0.0
+    for (int i = 0; i < 8; i++) {
+      const int kk = s * 128 + 32 * d + 8 * c + i;
+      int u = zero_code;
+      if (kk < k && col < n)
+        u = ref_stored_code(img, ref_tiled_index(kk, col, ref_ntile, ref_packrow, ref_kpad), elts, ref_bits);
+      word |= uint32_t(u & 0xf) << nib_shift(i);
+    }
+  }
+  out[gid] = word;
+}
+
+// scales / zero points: reference [nblk][cstep] -> [ntiles][G][16][SPS]
+template <typename T>
+__global__ void repack_corr_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int ntiles, int srows,
+                                   int sps, int cstep, int ref_nblk) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t total = size_t(ntiles) * srows * 16 * sps;
+  if (gid >= total) return;
+  const int sp = int(gid % sps);
+  const int nn = int((gid / sps) % 16);
+  const int row = int((gid / (size_t(sps) * 16)) % srows);
+  const int t = int(gid / (size_t(sps) * 16 * srows));
+  const int kb = row * sps + sp;
+  const int col = t * 16 + nn;
+  T v = T(0);
+  if (kb < ref_nblk && col < n) v = src[size_t(kb) * cstep + col];
+  dst[gid] = v;
+}
+
+hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st) {
+  const size_t dwords = size_t(w->ntiles) * w->ksteps * 64 * 4;
+  const int ref_bits = dt_bits(w->qtype);
+  hipLaunchKernelGGL(repack_codes_kernel, dim3((dwords + 255) / 256), dim3(256), 0, st, a.q, (uint32_t*)w->codes, w->n,
+                     w->k, w->ntiles, w->ksteps, w->kind, ref_bits, a.ref_ntile, a.ref_packrow, a.ref_kpad,
+                     a.ref_npad);
+  const size_t nsc = size_t(w->ntiles) * w->srows * 16 * w->sps;
+  if (w->scale_dt == DT_F32)
+    hipLaunchKernelGGL(repack_corr_kernel<uint32_t>, dim3((nsc + 255) / 256), dim3(256), 0, st,
+                       (const uint32_t*)a.scales, (uint32_t*)w->scales, w->n, w->ntiles, w->srows, w->sps, a.cstep,
+                       a.ref_nblk);
+  else
+    hipLaunchKernelGGL(repack_corr_kernel<uint16_t>, dim3((nsc + 255) / 256), dim3(256), 0, st,
+                       (const uint16_t*)a.scales, (uint16_t*)w->scales, w->n, w->ntiles, w->srows, w->sps, a.cstep,
+                       a.ref_nblk);
+  if (w->asym)
+    hipLaunchKernelGGL(repack_corr_kernel<int8_t>, dim3((nsc + 255) / 256), dim3(256), 0, st, a.zps, w->zps, w->n,
+                       w->ntiles, w->srows, w->sps, a.cstep, a.ref_nblk);
+  return hipGetLastError();
+}
+
+// ============================================================================================================
+// code -> fp16 converters (exact for integer codes)
+// ============================================================================================================
+// 8 nibbles of one dword -> 8 fp16 = (code - 8 - zp).  Magic 0x6400 = 1024.0h whose mantissa LSBs take the nibble:
+// (x & 0x000f000f)|0x64006400 = {1024+u, 1024+u'}, (x & 0x00f000f0)|0x64006400 = {1024+16u, 1024+16u'}.
+__device__ __forceinline__ half8_t cvt_i4x8(uint32_t x, half2_t off_lo, half2_t off_hi) {
+  constexpr uint32_t kMagic = 0x64006400u;
+  const half2_t k16 = {(_Float16)0.0625f, (_Float16)0.0625f};
+  const uint32_t y = x >> 8;
+  half2_t h0 = as_half2((x & 0x000f000fu) | kMagic) + off_lo;
+  half2_t h1 = as_half2((x & 0x00f000f0u) | kMagic) * k16 + off_hi;
+  half2_t h2 = as_half2((y & 0x000f000fu) | kMagic) + off_lo;
+  half2_t h3 = as_half2((y & 0x00f000f0u) | kMagic) * k16 + off_hi;
+  uint4v r = {as_u32(h0), as_u32(h1), as_u32(h2), as_u32(h3)};
+  return __builtin_bit_cast(half8_t, r);
+}
+// 8 signed bytes (two dwords) -> 8 fp16 = (q - zp): bias to unsigned, splice under 0x64, subtract 1152 + zp
+__device__ __forceinline__ half8_t cvt_i8x8(uint32_t x0, uint32_t x1, half2_t off) {
+  const uint32_t a = x0 ^ 0x80808080u, b = x1 ^ 0x80808080u;
+  half2_t h0 = as_half2(__builtin_amdgcn_perm(0x64646464u, a, 0x04010400u)) + off;
+  half2_t h1 = as_half2(__builtin_amdgcn_perm(0x64646464u, a, 0x04030402u)) + off;
+  half2_t h2 = as_half2(__builtin_amdgcn_perm(0x64646464u, b, 0x04010400u)) + off;
+  half2_t h3 = as_half2(__builtin_amdgcn_perm(0x64646464u, b, 0x04030402u)) + off;
+  uint4v r = {as_u32(h0), as_u32(h1), as_u32(h2), as_u32(h3)};
+  return __builtin_bit_cast(half8_t, r);
+}
+// 16-entry fp16 LUT held as byte planes: lo[e] / hi[e] for e = 0..15, four entries per dword
+struct F4Lut {
+  uint32_t lo[4], hi[4];
+};
+__device__ __forceinline__ uint32_t lut_bytes(uint32_t codes, const uint32_t* t) {
+  const uint32_t sel = codes & 0x07070707u;
+  const uint32_t mask = ((codes >> 3) & 0x01010101u) * 0xffu;
+  const uint32_t a = __builtin_amdgcn_perm(t[1], t[0], sel);
+  const uint32_t b = __builtin_amdgcn_perm(t[3], t[2], sel);
+  return (mask & b) | (~mask & a);
+}
+__device__ __forceinline__ half8_t cvt_f4x8(uint32_t x, const F4Lut& lut) {
+  const uint32_t t0 = x & 0x0f0f0f0fu;         // bytes: i0 i4 i1 i5
+  const uint32_t t1 = (x >> 4) & 0x0f0f0f0fu;  // bytes: i2 i6 i3 i7
+  const uint32_t lo0 = lut_bytes(t0, lut.lo), hi0 = lut_bytes(t0, lut.hi);
+  const uint32_t lo1 = lut_bytes(t1, lut.lo), hi1 = lut_bytes(t1, lut.hi);
+  uint4v r = {__builtin_amdgcn_perm(hi0, lo0, 0x06020400u), __builtin_amdgcn_perm(hi1, lo1, 0x06020400u),
+              __builtin_amdgcn_perm(hi0, lo0, 0x07030501u), __builtin_amdgcn_perm(hi1, lo1, 0x07030501u)};
+  return __builtin_bit_cast(half8_t, r);
+}
+
+// ============================================================================================================
+// smallm_kernel — weight-streaming MFMA kernel for M <= 16*MB rows (decode / batched decode)
+//
+// One workgroup = NW waves = one 16-column tile (or the same tile of two matrices in DUAL mode) over the whole K.
+// Wave w streams k-steps w, w+NW, ...: one 16-byte load per lane per k-step = 1 KiB contiguous per wave-load.
+// Lane (nn = l&15, c = l>>4) is column nn of the tile and k-slot c of the MFMA: its 16 B are the B operand of
+// NJ = 4 (4-bit) / 2 (8-bit) v_mfma_f32_16x16x32_f16, one per 32-deep k-slice j, so that every MFMA lives inside
+// one quantisation group (blocksize % 32 == 0) and the group scale is applied to the fp32 MFMA result:
+//     acc += scale[j][nn] * mfma(A_frag(j), codes(j) - zp, 0)
+// exactly the reference's w = (code - zp) * scale with fp32 accumulation (kernel_ref.h:2489-2531), except that
+// A is rounded to fp16 (north_star: fp16 activations).  A is staged once per workgroup in LDS as fp16.
+// ============================================================================================================
+constexpr int kNW = 8;  // waves per workgroup
+
+struct SmallMParams {
+  const float* a;
+  int lda, m, k;
+  int ksteps;       // k-steps of the weight (kpad / KSTEP)
+  int chunk_steps;  // k-steps staged in LDS at a time (multiple of kNW)
+  int nseg;
+  int tile_begin[4];  // first global tile of each segment (+ total)
+  const uint4* codes[3];
+  const void* scales[3];
+  const int8_t* zps[3];
+  float* c[3];
+  int n[3];
+  int ldc;
+  uint32_t scale_dt;
+  int asym;
+  int srows, srow_shift_num, srow_shift_den;  // scale row of k-step s = s * num / den
+  int epilogue;
+  const float* d;
+  int ldd;
+  float* c2;
+  F4Lut lut;
+};
+
+template <int SPS, int NJ>
+__device__ __forceinline__ void load_corr(const SmallMParams& p, int seg, size_t corr_idx, float (&sc)[4],
+                                          int (&zp)[4]) {
+  // corr_idx = ((tile * srows + row) * 16 + nn) * SPS ; returns the 4 per-slice scales (replicated when SPS < 4)
+  float s[SPS];
+  if (p.scale_dt == DT_F32) {
+    const float* b = static_cast<const float*>(p.scales[seg]) + corr_idx;
+#pragma unroll
+    for (int i = 0; i < SPS; i++) s[i] = b[i];
+  } else {
+    const unsigned short* b = static_cast<const unsigned short*>(p.scales[seg]) + corr_idx;
+    uint32_t raw[SPS];
+    if constexpr (SPS == 4) {
+      const uint2 v = *reinterpret_cast<const uint2*>(b);
+      raw[0] = v.x & 0xffff;
+      raw[1] = v.x >> 16;
+      raw[2] = v.y & 0xffff;
+      raw[3] = v.y >> 16;
+    } else if constexpr (SPS == 2) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(b);
+      raw[0] = v & 0xffff;
+      raw[1] = v >> 16;
+    } else {
+      raw[0] = b[0];
+    }
+#pragma unroll
+    for (int i = 0; i < SPS; i++) s[i] = (p.scale_dt == DT_BF16) ? bf16_bits_to_f32(raw[i]) : f16_bits_to_f32(raw[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) sc[j] = s[((j % NJ) * SPS) / NJ];
+  if (p.asym) {
+    const int8_t* z = p.zps[seg] + corr_idx;
+#pragma unroll
+    for (int j = 0; j < 4; j++) zp[j] = z[((j % NJ) * SPS) / NJ];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) zp[j] = 0;
+  }
+}
+
+__device__ __forceinline__ float epi_gelu(float x) {  // kernel_ref.h:1570-1572
+  return 0.5f * x * (1.f + tanhf(0.7978845834732056f * (x + 0.044714998453855515f * x * x * x)));
+}
+__device__ __forceinline__ float epi_silu(float x) { return x / (1.f + expf(-x)); }  // kernel_ref.h:1573-1575
+
+template <int KIND, int SPS, int MB, bool DUAL>
+__global__ __launch_bounds__(kNW * 64) void smallm_kernel(const SmallMParams p) {
+  constexpr int NJ = (KIND == WK_INT8) ? 2 : 4;
+  constexpr int KSTEP = NJ * 32;
+  constexpr int NACC = DUAL ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  _Float16* a_lds = reinterpret_cast<_Float16*>(smem);
+
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nn = l & 15, g = l >> 4;
+
+  // which segment / tile
+  int seg = 0;
+  int tile = blockIdx.x;
+  if (!DUAL) {
+    if (p.nseg > 1 && tile >= p.tile_begin[1]) seg = 1;
+    if (p.nseg > 2 && tile >= p.tile_begin[2]) seg = 2;
+    tile -= p.tile_begin[seg];
+  }
+
+  const int rows = min(p.m, 16 * MB);
+  const int chunk_k = p.chunk_steps * KSTEP;
+  const int row_stride = chunk_k + 8;  // halves; +16 B keeps 16-B alignment and skews banks
+
+  floatx4 acc[NACC][MB];
+#pragma unroll
+  for (int q = 0; q < NACC; q++)
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) acc[q][mb] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // A-fragment rows of this lane (clamped: rows >= m produce discarded output rows)
+  int arow[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++) arow[mb] = min(mb * 16 + nn, rows - 1);
+
+  const size_t tile_q_off = size_t(tile) * p.ksteps * 64 + l;  // uint4 units; + s * 64
+  const size_t tile_c_off = size_t(tile) * p.srows;            // scale-row units
+
+  for (int c0 = 0; c0 < p.ksteps; c0 += p.chunk_steps) {
+    const int cend = min(c0 + p.chunk_steps, p.ksteps);
+    // ---- issue this wave's first weight loads before staging A, so HBM latency overlaps the staging ----
+    int s = c0 + w;
+    uint4 qv[NACC];
+    bool have = s < cend;
+    if (have) {
+#pragma unroll
+      for (int q = 0; q < NACC; q++)
+        qv[q] = ld_stream(p.codes[DUAL ? q : seg] + tile_q_off + size_t(s) * 64);
+    }
+    // ---- stage A[:, chunk] as fp16 ----
+    if (c0 > 0) __syncthreads();
+    {
+      const int kbase = c0 * KSTEP;
+      const int quads = chunk_k >> 2;
+      const bool vec_ok = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
+      for (int idx = tid; idx < rows * quads; idx += kNW * 64) {
+        const int r = idx / quads;
+        const int kq = (idx - r * quads) << 2;
+        const int gk = kbase + kq;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* src = p.a + size_t(r) * p.lda + gk;
+        if (vec_ok && gk + 3 < p.k) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (gk + 0 < p.k) v.x = src[0];
+          if (gk + 1 < p.k) v.y = src[1];
+          if (gk + 2 < p.k) v.z = src[2];
+          if (gk + 3 < p.k) v.w = src[3];
+        }
+        half2_t h0 = {(_Float16)v.x, (_Float16)v.y}, h1 = {(_Float16)v.z, (_Float16)v.w};
+        uint2 packed = {as_u32(h0), as_u32(h1)};
+        *reinterpret_cast<uint2*>(a_lds + size_t(r) * row_stride + kq) = packed;
+      }
+    }
+    __syncthreads();
+
+    // ---- stream this wave's k-steps of the chunk ----
+    while (have) {
+      const int snext = s + kNW;
+      const bool have_next = snext < cend;
+      uint4 qn[NACC];
+      if (have_next) {
+#pragma unroll
+        for (int q = 0; q < NACC; q++)
+          qn[q] = ld_stream(p.codes[DUAL ? q : seg] + tile_q_off + size_t(snext) * 64);
+      }
+      const int srow = (s * p.srow_shift_num) / p.srow_shift_den;
+      const size_t cidx = ((tile_c_off + srow) * 16 + nn) * SPS;
+      const _Float16* abase = a_lds + (s - c0) * KSTEP + 8 * g;
+#pragma unroll
+      for (int q = 0; q < NACC; q++) {
+        float sc[4];
+        int zp[4];
+        load_corr<SPS, NJ>(p, DUAL ? q : seg, cidx, sc, zp);
+        const uint32_t xw[4] = {qv[q].x, qv[q].y, qv[q].z, qv[q].w};
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          half8_t b;
+          if constexpr (KIND == WK_INT4) {
+            const _Float16 zl = (_Float16)(-(1032.f + float(zp[j]))), zh = (_Float16)(-(72.f + float(zp[j])));
+            b = cvt_i4x8(xw[j], half2_t{zl, zl}, half2_t{zh, zh});
+          } else if constexpr (KIND == WK_INT8) {
+            const _Float16 zo = (_Float16)(-(1152.f + float(zp[j])));
+            b = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo, zo});
+          } else {
+            b = cvt_f4x8(xw[j], p.lut);
+          }
+#pragma unroll
+          for (int mb = 0; mb < MB; mb++) {
+            const half8_t afrag =
+                *reinterpret_cast<const half8_t*>(abase + size_t(arow[mb]) * row_stride + 32 * j);
+            const floatx4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, b, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc[q][mb] += dd * sc[j];
+          }
+        }
+      }
+      s = snext;
+      have = have_next;
+#pragma unroll
+      for (int q = 0; q < NACC; q++) qv[q] = qn[q];
+    }
+  }
+
+  // ---- cross-wave reduction through LDS, then epilogue ----
+  __syncthreads();
+  floatx4* red = reinterpret_cast<floatx4*>(smem);  // [kNW][NACC][MB][64]
+#pragma unroll
+  for (int q = 0; q < NACC; q++)
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) red[((w * NACC + q) * MB + mb) * 64 + l] = acc[q][mb];
+  __syncthreads();
+  if (w < MB) {
+    const int mb = w;
+    floatx4 sum[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; q++) {
+      sum[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ww = 0; ww < kNW; ww++) sum[q] += red[((ww * NACC + q) * MB + mb) * 64 + l];
+    }
+    const int col = tile * 16 + nn;
+    const int ncols = p.n[DUAL ? 0 : seg];
+    if (col < ncols) {
+      float* cbase = p.c[DUAL ? 0 : seg];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = mb * 16 + 4 * g + r;
+        if (row >= p.m) continue;
+        float v = sum[0][r];
+        if constexpr (DUAL) {
+          // tmp1 = act(A*W1) ; tmp2 = (A*W3) * tmp1   (ip_fusion_ffn.cpp:364-406)
+          const float t1 = (p.epilogue == 5) ? epi_silu(v) : epi_gelu(v);
+          if (p.c2) p.c2[size_t(row) * p.ldc + col] = t1;
+          v = sum[1][r] * t1;
+        } else {
+          const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
+          switch (p.epilogue) {
+            case 1: v = v + dv; break;                 // custom::epilogue::Add
+            case 2: v = v * dv; break;                 // custom::epilogue::Mul
+            case 3: v = epi_gelu(v + dv); break;       // custom::epilogue::Add_Gelu
+            case 4: v = epi_gelu(v); break;
+            case 5: v = epi_silu(v); break;
+            default: break;
+          }
+        }
+        cbase[size_t(row) * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+bool smallm_supported(const ns_weight* w, int m) {
+  (void)m;
+  const int kstep = w->kstep_len;
+  if (w->blocksize % 32 != 0 && w->blocksize < w->k) return false;
+  if (w->blocksize < kstep) return kstep % w->blocksize == 0;
+  return w->blocksize % kstep == 0 || w->blocksize >= w->k;
+}
+
+template <int KIND, int SPS, int MB>
+static hipError_t launch_smallm_t(const SmallMParams& p, bool dual, int grid, size_t lds, hipStream_t st) {
+  if (dual)
+    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, MB, true>), dim3(grid), dim3(kNW * 64), lds, st, p);
+  else
+    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, MB, false>), dim3(grid), dim3(kNW * 64), lds, st, p);
+  return hipGetLastError();
+}
+template <int KIND, int SPS>
+static hipError_t launch_smallm_mb(const SmallMParams& p, bool dual, int mb, int grid, size_t lds, hipStream_t st) {
+  switch (mb) {
+    case 1: return launch_smallm_t<KIND, SPS, 1>(p, dual, grid, lds, st);
+    case 2: return launch_smallm_t<KIND, SPS, 2>(p, dual, grid, lds, st);
+    default: return launch_smallm_t<KIND, SPS, 4>(p, dual, grid, lds, st);
+  }
+}
+
+static void f4_lut_planes(const _Float16* lut, F4Lut* out) {
+  for (int i = 0; i < 4; i++) out->lo[i] = out->hi[i] = 0;
+  for (int e = 0; e < 16; e++) {
+    unsigned short bits = __builtin_bit_cast(unsigned short, lut[e]);
+    out->lo[e >> 2] |= uint32_t(bits & 0xff) << (8 * (e & 3));
+    out->hi[e >> 2] |= uint32_t(bits >> 8) << (8 * (e & 3));
+  }
+}
+
+static void srow_rule(const ns_weight* w, int* num, int* den);
+
+hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
+  const ns_weight* w0 = a.seg[0].w;
+  SmallMParams p;
+  memset(&p, 0, sizeof(p));
+  p.a = a.a;
+  p.lda = a.lda;
+  p.m = a.m;
+  p.k = w0->k;
+  p.ksteps = w0->ksteps;
+  p.nseg = a.nseg;
+  int tiles = 0;
+  for (int i = 0; i < a.nseg; i++) {
+    const ns_weight* w = a.seg[i].w;
+    p.tile_begin[i] = tiles;
+    tiles += w->ntiles;
+    p.codes[i] = w->codes;
+    p.scales[i] = w->scales;
+    p.zps[i] = w->zps;
+    p.c[i] = a.seg[i].c;
+    p.n[i] = w->n;
+  }
+  p.tile_begin[a.nseg] = tiles;
+  p.ldc = a.ldc;
+  p.scale_dt = w0->scale_dt;
+  p.asym = w0->asym;
+  p.srows = w0->srows;
+  srow_rule(w0, &p.srow_shift_num, &p.srow_shift_den);
+  p.epilogue = a.epilogue;
+  p.d = a.d;
+  p.ldd = a.ldd;
+  p.c2 = a.c2;
+  if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
+
+  const int mb = a.m <= 16 ? 1 : (a.m <= 32 ? 2 : 4);
+  const int rows = a.m < 16 * mb ? a.m : 16 * mb;
+  // LDS: A chunk (rows x (chunk_k + 8) halves), at most ~64 KiB; and the reduction scratch
+  const int kstep = w0->kstep_len;
+  int chunk_steps = w0->ksteps;
+  const size_t budget = 64 * 1024;
+  while (size_t(rows) * (size_t(chunk_steps) * kstep + 8) * 2 > budget && chunk_steps > kNW) {
+    chunk_steps = ((chunk_steps / 2 + kNW - 1) / kNW) * kNW;
+  }
+  p.chunk_steps = chunk_steps;
+  size_t lds = size_t(rows) * (size_t(chunk_steps) * kstep + 8) * 2;
+  const size_t red = size_t(kNW) * (a.dual ? 2 : 1) * mb * 64 * 16;
+  if (red > lds) lds = red;
+  const int grid = a.dual ? w0->ntiles : tiles;
+
+#define NS_DISPATCH(KIND)                                                                   \
+  switch (w0->sps) {                                                                        \
+    case 4: return launch_smallm_mb<KIND, 4>(p, a.dual, mb, grid, lds, st);                 \
+    case 2: return launch_smallm_mb<KIND, 2>(p, a.dual, mb, grid, lds, st);                 \
+    default: return launch_smallm_mb<KIND, 1>(p, a.dual, mb, grid, lds, st);                \
+  }
+  if (w0->kind == WK_INT4) {
+    NS_DISPATCH(WK_INT4)
+  } else if (w0->kind == WK_INT8) {
+    if (w0->sps == 2) return launch_smallm_mb<WK_INT8, 2>(p, a.dual, mb, grid, lds, st);
+    return launch_smallm_mb<WK_INT8, 1>(p, a.dual, mb, grid, lds, st);
+  } else {
+    NS_DISPATCH(WK_F4)
+  }
+#undef NS_DISPATCH
+}
+
+// ============================================================================================================
+// unpack: device layout -> fp32 [K][N]   (BTLAGemmUnPackB semantics: w = (code - zp) * scale / LUT[code] * scale)
+// ============================================================================================================
+struct Lut16 {
+  float v[16];
+};
+__global__ void unpack_kernel(const uint32_t* __restrict__ codes, const void* __restrict__ scales,
+                              const int8_t* __restrict__ zps, float* __restrict__ out, int ld, int n, int k, int ksteps,
+                              int kind, int sps, int srows, int num, int den, uint32_t scale_dt, Lut16 lut) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= size_t(n) * k) return;
+  const int col = int(gid % n);
+  const int kk = int(gid / n);
+  const int t = col >> 4, nn = col & 15;
+  const int kstep = (kind == WK_INT8) ? 64 : 128;
+  const int s = kk / kstep, r = kk % kstep;
+  const int j = r >> 5, c = (r >> 3) & 3, i = r & 7;
+  const size_t lane_base = ((size_t(t) * ksteps + s) * 64 + (c * 16 + nn)) * 4;
+  const int nj = (kind == WK_INT8) ? 2 : 4;
+  const int srow = (s * num) / den;
+  const size_t cidx = ((size_t(t) * srows + srow) * 16 + nn) * sps + (j * sps) / nj;
+  const float sc = load_scale(scales, cidx, scale_dt);
+  const int zp = zps ? zps[cidx] : 0;
+  float v;
+  if (kind == WK_INT8) {
+    const uint32_t word = codes[lane_base + 2 * j + (i >> 2)];
+    v = float(int(int8_t((word >> (8 * (i & 3))) & 0xff)) - zp);
+  } else {
+    const int u = (codes[lane_base + j] >> nib_shift(i)) & 0xf;
+    v = (kind == WK_INT4) ? float(u - 8 - zp) : lut.v[u];
+  }
+  out[size_t(kk) * ld + col] = v * sc;
+}
+
+static void srow_rule(const ns_weight* w, int* num, int* den) {
+  if (w->sps > 1 || w->blocksize == w->kstep_len) {
+    *num = 1;
+    *den = 1;
+  } else if (w->blocksize >= w->k) {
+    *num = 0;
+    *den = 1;
+  } else {
+    *num = w->kstep_len;
+    *den = w->blocksize;
+  }
+}
+
+hipError_t launch_unpack_fp32(const ns_weight* w, float* out, int ld, hipStream_t st) {
+  Lut16 lut;
+  for (int i = 0; i < 16; i++) lut.v[i] = float(w->lut[i]);
+  int num, den;
+  srow_rule(w, &num, &den);
+  const size_t total = size_t(w->n) * w->k;
+  hipLaunchKernelGGL(unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const uint32_t*)w->codes, w->scales,
+                     w->zps, out, ld, w->n, w->k, w->ksteps, w->kind, w->sps, w->srows, num, den, w->scale_dt, lut);
+  return hipGetLastError();
+}
+
+}  // namespace ns

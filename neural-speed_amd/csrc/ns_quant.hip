@@ -1,0 +1,394 @@
+// ns_quant.hip — the offline side on the GPU: quantize, interleave, bit-pack, reduce (bit-exact with the
+// reference's CPU pipeline) plus the small element-wise entry points of the operator surface.
+//
+// Reference pipeline (paths under /root/reference/bestla/bestla):
+//   packTransposeWeight/packWeight     bestla_prologue_b.h:180-210
+//   quantizeWeight -> quantize_f32_sign_int_rowblock   kernel_ref.h:1608-1719 (always the scalar code: kernel_wrapper.h:511-530)
+//                  -> quantize_f32_f4_rowblock         kernel_ref.h:1801-1822
+//   packQWeight                        bestla_prologue_b.h:378-398
+//     setQuantCorrection               :244-335   (fp32 -> bf16/f16/f32, zero padding)
+//     reorderWeight/padding_interleave :490-510, kernel_ref.h:39-57
+//     compressWeight                   :606-617, kernel_ref.h:155-365
+//     reduceWeight/row_reduce_sum      :455-470, kernel_ref.h:2132-2142
+// All fp32 arithmetic below is written with explicit single-rounding intrinsics so that hipcc cannot contract
+// a*b+c into an FMA: the CPU reference rounds after every operation.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "ns_common.h"
+
+namespace ns {
+
+namespace {
+
+// ---- x86 float->int conversions as the reference binary performs them ------------------------------------------
+// cast<float,int>(x) = int(roundf(x)) (bestla_utils.h:523-526): cvttss2si yields INT_MIN for NaN / out of range.
+__device__ __forceinline__ int cvt_round_int_x86(float v) {
+  const float r = roundf(v);
+  if (!(r >= -2147483648.f && r < 2147483648.f)) return INT_MIN;
+  return int(r);
+}
+// cast<float,int8_t>(x) (bestla_utils.h:507-513): roundf, clamp to [-128,127]; NaN observed to come out as 0
+__device__ __forceinline__ int cvt_round_s8_x86(float v) {
+  if (v != v) return 0;
+  float r = roundf(v);
+  r = r > 127.f ? 127.f : r;
+  r = r < -128.f ? -128.f : r;
+  return int(r);
+}
+__device__ __forceinline__ int wrap_add(int a, int b) { return int(uint32_t(a) + uint32_t(b)); }
+__device__ __forceinline__ int clipi(int s, int lo, int hi) { return min(max(s, lo), hi); }
+
+// bf16::fromfloat (bestla_utils.h:146-153)
+__device__ __forceinline__ uint16_t f32_to_bf16_ref(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return uint16_t(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(uint32_t(h) << 16); }
+// fp16::operator=(float) (bestla_utils.h:184-196) — the reference's own bit recipe, not IEEE cvt
+__device__ __forceinline__ uint16_t f32_to_f16_ref(float f) {
+  const uint32_t b = __float_as_uint(f) + 0x00001000u;
+  const uint32_t e = (b & 0x7F800000u) >> 23;
+  const uint32_t m = b & 0x007FFFFFu;
+  uint32_t r = (b & 0x80000000u) >> 16;
+  if (e > 112) r |= (((e - 112) << 10) & 0x7C00u) | (m >> 13);
+  if (e < 113 && e > 101) r |= (((0x007FF000u + m) >> (125 - e)) + 1) >> 1;
+  if (e > 143) r |= 0x7FFFu;
+  return uint16_t(r);
+}
+// fp16::operator float (bestla_utils.h:197-207)
+__device__ __forceinline__ float f16_to_f32_ref(uint16_t x) {
+  const uint32_t e = (x & 0x7C00u) >> 10;
+  const uint32_t m = (x & 0x03FFu) << 13;
+  const uint32_t v = __float_as_uint(float(m)) >> 23;
+  uint32_t r = uint32_t(x & 0x8000u) << 16;
+  if (e != 0) r |= ((e + 112) << 23) | m;
+  if (e == 0 && m != 0) r |= ((v - 37) << 23) | ((m << (150 - v)) & 0x007FE000u);
+  return __uint_as_float(r);
+}
+
+// ---- f4 code books: thresholds of the reference decision trees flattened to "count thresholds below x" ---------
+// (kernel_ref.h:1234-1298, :1373-1413); values bestla_utils.h:749-789
+__constant__ float kThrNF4[15] = {-0.8480964004993439f, -0.6106329262256622f,  -0.4599952697753906f,
+                                  -0.33967943489551544f, -0.23460740596055984f, -0.13791173323988914f,
+                                  -0.045525018125772476f, 0.03979014977812767f, 0.1202552504837513f,
+                                  0.2035212516784668f,   0.2920137718319893f,   0.3893125355243683f,
+                                  0.5016634166240692f,   0.6427869200706482f,   0.8614784181118011f};
+__constant__ int kCodeNF4[16] = {7, 1, 2, 3, 4, 5, 6, 0, 8, 9, 10, 11, 12, 13, 14, 15};
+__constant__ float kThrBNB[7] = {0.00260417f, 0.0859375f, 0.20833333f, 0.29166667f, 0.4166667f, 0.583333f, 0.8333333f};
+__constant__ int kCodeBNB[8] = {0, 1, 6, 7, 4, 5, 2, 3};
+__constant__ float kThrE2M1[7] = {0.03125f / 6, 0.53125f / 6, 1.25f / 6, 1.75f / 6, 2.5f / 6, 3.5f / 6, 5.f / 6};
+
+__device__ __forceinline__ int f4_code(uint32_t t, float x) {
+  int c = 0;
+  if (t == DT_F4_NF4) {
+#pragma unroll
+    for (int i = 0; i < 15; i++) c += x > kThrNF4[i];
+    return kCodeNF4[c];
+  }
+  const int sign = x < 0.f ? 8 : 0;
+  const float ax = fabsf(x);
+  if (t == DT_F4_BNB) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) c += ax > kThrBNB[i];
+    return kCodeBNB[c] + sign;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; i++) c += ax > kThrE2M1[i];
+  return c + sign;
+}
+
+struct SrcView {  // fp32 weight, [N][K] when trans (torch layout) else [K][N]
+  const float* w;
+  size_t ld;
+  bool trans;
+  __device__ __forceinline__ float at(size_t k, size_t n) const { return trans ? w[n * ld + k] : w[k * ld + n]; }
+};
+
+// one thread per (k-block, column).  Codes go to q[k*qsk + n*qsn] (int8), scales/zps to [kb][N].
+__global__ void quantize_kernel(SrcView src, size_t n, size_t k, int bs, uint32_t qtype, bool asym, int8_t* q,
+                                size_t qsk, size_t qsn, float* scales, int8_t* zps) {
+  const size_t nblk = (k + bs - 1) / bs;
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= nblk * n) return;
+  // consecutive threads walk the contiguous axis of the source
+  const size_t kb = src.trans ? gid % nblk : gid / n;
+  const size_t col = src.trans ? gid / nblk : gid % n;
+  const size_t k0 = kb * bs;
+  const int len = int(min(size_t(bs), k - k0));
+  const size_t sidx = kb * n + col;
+  if (!dt_is_int(qtype)) {  // kernel_ref.h:1801-1822
+    float absmax = FLT_MIN;
+    for (int i = 0; i < len; i++) absmax = fmaxf(absmax, fabsf(src.at(k0 + i, col)));
+    scales[sidx] = absmax;
+    const float r = __fdiv_rn(1.f, absmax);
+    for (int i = 0; i < len; i++)
+      q[(k0 + i) * qsk + col * qsn] = int8_t(f4_code(qtype, __fmul_rn(src.at(k0 + i, col), r)));
+    return;
+  }
+  const int nbits = dt_bits(qtype);
+  const int full = 1 << (nbits - 1);
+  const int symv = full - 1;
+  if (!asym) {  // kernel_ref.h:1651-1671
+    float maxval = FLT_MIN, minval = FLT_MAX, absmax = 0.f;
+    for (int i = 0; i < len; i++) {
+      const float v = src.at(k0 + i, col);
+      // std::max(a,b) = (a<b)?b:a keeps `a` when b is NaN; fmaxf would drop the NaN the same way for finite data
+      maxval = (maxval < v) ? v : maxval;
+      minval = (v < minval) ? v : minval;
+      const float av = fabsf(v);
+      absmax = (absmax < av) ? av : absmax;
+    }
+    float nval = float(symv) + 0.5f;
+    const float sum = __fadd_rn(maxval, minval);
+    if (fabsf(sum) >= __fdiv_rn(absmax, float(full))) nval = sum > 0.f ? float(-full) : float(full);
+    const float scale = __fdiv_rn(absmax, nval);
+    const float rscale = __fdiv_rn(1.f, scale);
+    scales[sidx] = scale;
+    for (int i = 0; i < len; i++) {
+      const int c = cvt_round_s8_x86(__fmul_rn(src.at(k0 + i, col), rscale));
+      q[(k0 + i) * qsk + col * qsn] = int8_t(clipi(c, -full, symv));
+    }
+  } else {  // kernel_ref.h:1673-1692
+    float maxval = 0.f, minval = 0.f;
+    for (int i = 0; i < len; i++) {
+      const float v = src.at(k0 + i, col);
+      maxval = (maxval < v) ? v : maxval;
+      minval = (v < minval) ? v : minval;
+    }
+    const float scale = __fdiv_rn(__fsub_rn(maxval, minval), float((1 << nbits) - 1));
+    const float rscale = __fdiv_rn(1.f, scale);
+    scales[sidx] = scale;
+    int bzp = wrap_add(cvt_round_int_x86(__fmul_rn(__fsub_rn(0.f, minval), rscale)), -full);
+    bzp = clipi(bzp, -full, symv);
+    zps[sidx] = int8_t(bzp);
+    for (int i = 0; i < len; i++) {
+      const int t = wrap_add(cvt_round_int_x86(__fmul_rn(src.at(k0 + i, col), rscale)), bzp);
+      q[(k0 + i) * qsk + col * qsn] = int8_t(clipi(t, -full, symv));
+    }
+  }
+}
+
+// scales (fp32 [nblk][N]) -> blob scale section [rows][cstep] in `stype`, zero padded (prologue_b.h:244-281)
+__global__ void pack_scales_kernel(const float* __restrict__ s, uint8_t* __restrict__ out, size_t n, size_t rawnk,
+                                   size_t rows, size_t cstep, uint32_t stype) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= rows * cstep) return;
+  const size_t r = gid / cstep, c = gid % cstep;
+  const bool live = r < rawnk && c < n;
+  const float v = live ? s[r * n + c] : 0.f;
+  if (stype == DT_F32) {
+    reinterpret_cast<float*>(out)[gid] = live ? v : 0.f;
+  } else {
+    uint16_t h = 0;
+    if (live) h = (stype == DT_BF16) ? f32_to_bf16_ref(v) : f32_to_f16_ref(v);
+    reinterpret_cast<uint16_t*>(out)[gid] = h;
+  }
+}
+__global__ void pack_zps_kernel(const int8_t* __restrict__ z, int8_t* __restrict__ out, size_t n, size_t rawnk,
+                                size_t rows, size_t cstep) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= rows * cstep) return;
+  const size_t r = gid / cstep, c = gid % cstep;
+  out[gid] = (r < rawnk && c < n) ? z[r * n + c] : int8_t(0);
+}
+
+// codes -> interleaved, bit-packed image.  One thread per 8 consecutive elements of the interleaved image
+// [N/NTILE][KPad/PACK][NTILE][PACK]; NTILE*PACK is always a multiple of 8.
+struct TiledSrc {
+  const int8_t* q;
+  size_t sk, sn;  // strides of the canonical code array
+  size_t n, k;
+  int ntile, packrow, kpad;
+  __device__ __forceinline__ int at(size_t e) const {
+    const size_t per_tile = size_t(ntile) * kpad;
+    const size_t tile = e / per_tile, rem = e % per_tile;
+    const size_t kg = rem / (size_t(ntile) * packrow), r2 = rem % (size_t(ntile) * packrow);
+    const size_t kk = kg * packrow + r2 % packrow;
+    const size_t col = tile * ntile + r2 / packrow;
+    return (kk < k && col < n) ? int(q[kk * sk + col * sn]) : 0;
+  }
+};
+__global__ void pack_codes_kernel(TiledSrc src, uint8_t* __restrict__ out, size_t elts, uint32_t qtype) {
+  const size_t g8 = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t e0 = g8 * 8;
+  if (e0 >= elts) return;
+  const int nbits = dt_bits(qtype);
+  const bool is_int = dt_is_int(qtype);
+  int v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = src.at(e0 + i);
+  if (is_int && nbits == 8) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[e0 + i] = uint8_t(v[i]);
+    return;
+  }
+  const int full = is_int ? (1 << (nbits - 1)) : 0;
+  // compress_3bit / compress_1bit read the 5th element of every 8 from src[j + FullRange] (kernel_ref.h:313,:355)
+  if (is_int && nbits == 1) v[4] = v[1];
+  int u[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) u[i] = v[i] + full;
+  uint8_t* p = out;
+  int sh = 0;
+  const bool has4 = !is_int || nbits >= 4;
+  const bool has2 = is_int && (nbits == 7 || nbits == 6 || nbits == 3 || nbits == 2);
+  const bool has1 = is_int && (nbits == 7 || nbits == 5 || nbits == 3 || nbits == 1);
+  if (has4) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) p[e0 / 2 + i] = uint8_t((u[2 * i] & 0xf) | ((u[2 * i + 1] & 0xf) << 4));
+    p += elts / 2;
+    sh = 4;
+  }
+  if (has2) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int b = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) b |= ((u[4 * i + t] >> sh) & 0x3) << (2 * t);
+      p[e0 / 4 + i] = uint8_t(b);
+    }
+    p += elts / 4;
+    sh += 2;
+  }
+  if (has1) {
+    int b = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) b |= ((u[t] >> sh) & 0x1) << t;
+    p[e0 / 8] = uint8_t(b);
+  }
+}
+
+// reduce[kb][n] = bf16( sum_k float(code - zp) * stored_scale ), sequential fp32 sum (row_reduce_sum)
+__global__ void reduce_kernel(const int8_t* __restrict__ q, size_t sk, size_t sn, const uint8_t* __restrict__ sblob,
+                              const int8_t* __restrict__ zblob, uint16_t* __restrict__ rblob, size_t n, size_t k,
+                              int bs, size_t cstep, uint32_t stype) {
+  const size_t nblk = (k + bs - 1) / bs;
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= nblk * n) return;
+  const size_t kb = gid / n, col = gid % n;
+  float s;
+  if (stype == DT_F32)
+    s = reinterpret_cast<const float*>(sblob)[kb * cstep + col];
+  else if (stype == DT_BF16)
+    s = bf16_to_f32(reinterpret_cast<const uint16_t*>(sblob)[kb * cstep + col]);
+  else
+    s = f16_to_f32_ref(reinterpret_cast<const uint16_t*>(sblob)[kb * cstep + col]);
+  const int z = zblob ? zblob[kb * cstep + col] : 0;
+  float tmp = 0.f;
+  const size_t kend = min(k, (kb + 1) * size_t(bs));
+  for (size_t kk = kb * bs; kk < kend; kk++) tmp = __fadd_rn(tmp, __fmul_rn(float(int(q[kk * sk + col * sn]) - z), s));
+  rblob[kb * cstep + col] = f32_to_bf16_ref(tmp);
+}
+
+template <typename F>
+inline dim3 grid1d(size_t n, F bs) {
+  return dim3((unsigned)((n + bs - 1) / bs));
+}
+
+hipError_t pack_sections(const int8_t* q, size_t sk, size_t sn, const float* scales, const int8_t* zps, size_t n,
+                         size_t k, int bs, uint32_t qtype, uint32_t stype, int ref_ntile, int ref_packrow, int ref_kpad,
+                         int ref_npad, int cstep, bool has_reduce, uint8_t* q_out, uint8_t* s_out, int8_t* z_out,
+                         uint16_t* r_out, hipStream_t st) {
+  const size_t rawnk = (k + bs - 1) / bs;
+  const size_t rows = (size_t(ref_kpad) + bs - 1) / bs;
+  const size_t nsc = rows * cstep;
+  hipLaunchKernelGGL(pack_scales_kernel, grid1d(nsc, 256), dim3(256), 0, st, scales, s_out, n, rawnk, rows,
+                     size_t(cstep), stype);
+  if (z_out)
+    hipLaunchKernelGGL(pack_zps_kernel, grid1d(nsc, 256), dim3(256), 0, st, zps, z_out, n, rawnk, rows, size_t(cstep));
+  TiledSrc ts{q, sk, sn, n, k, ref_ntile, ref_packrow, ref_kpad};
+  const size_t elts = size_t(ref_npad) * ref_kpad;
+  hipLaunchKernelGGL(pack_codes_kernel, grid1d(elts / 8, 256), dim3(256), 0, st, ts, q_out, elts, qtype);
+  if (has_reduce)
+    hipLaunchKernelGGL(reduce_kernel, grid1d(rawnk * n, 256), dim3(256), 0, st, q, sk, sn, (const uint8_t*)s_out,
+                       (const int8_t*)z_out, r_out, n, k, bs, size_t(cstep), stype);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_quant_pack(const QuantArgs& a, hipStream_t st) {
+  const size_t nblk = (a.k + a.blocksize - 1) / a.blocksize;
+  int8_t* q = nullptr;
+  float* sc = nullptr;
+  int8_t* zp = nullptr;
+  hipError_t e;
+  if ((e = hipMallocAsync((void**)&q, a.n * a.k, st)) != hipSuccess) return e;
+  if ((e = hipMallocAsync((void**)&sc, nblk * a.n * sizeof(float), st)) != hipSuccess) return e;
+  if (a.asym && (e = hipMallocAsync((void**)&zp, nblk * a.n, st)) != hipSuccess) return e;
+  // canonical code array follows the source's contiguous axis so both reads and writes coalesce
+  const size_t qsk = a.is_trans ? 1 : a.n, qsn = a.is_trans ? a.k : 1;
+  SrcView sv{a.w, a.ld, a.is_trans};
+  hipLaunchKernelGGL(quantize_kernel, grid1d(nblk * a.n, 256), dim3(256), 0, st, sv, a.n, a.k, a.blocksize, a.qtype,
+                     a.asym, q, qsk, qsn, sc, zp);
+  e = pack_sections(q, qsk, qsn, sc, zp, a.n, a.k, a.blocksize, a.qtype, a.stype, a.ref_ntile, a.ref_packrow,
+                    a.ref_kpad, a.ref_npad, a.cstep, a.has_reduce, a.q_out, a.s_out, a.asym ? a.z_out : nullptr,
+                    a.r_out, st);
+  hipFreeAsync(q, st);
+  hipFreeAsync(sc, st);
+  if (zp) hipFreeAsync(zp, st);
+  return e;
+}
+
+hipError_t launch_pack_q(const PackQArgs& a, hipStream_t st) {
+  return pack_sections(a.q, a.ldq, 1, a.scales, a.zps, a.n, a.k, a.blocksize, a.qtype, a.stype, a.ref_ntile,
+                       a.ref_packrow, a.ref_kpad, a.ref_npad, a.cstep, a.has_reduce, a.q_out, a.s_out,
+                       a.zps ? a.z_out : nullptr, a.r_out, st);
+}
+
+// ============================================================================================================
+// element-wise members of the operator surface (ne_bestla.h:71-75)
+// ============================================================================================================
+// layernorm / rmsnorm — kernel_ref.h:2199-2245 semantics (no scale/bias at this entry: BTLALayerNorm passes nullptr)
+__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ in, float* __restrict__ out, int size,
+                                                   bool rms, float eps) {
+  __shared__ float red[2][4];
+  const float* src = in + size_t(blockIdx.x) * size;
+  float* dst = out + size_t(blockIdx.x) * size;
+  float s = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < size; i += 256) {
+    const float v = src[i];
+    s += v;
+    s2 += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const float mean = s / size;
+  const float var = rms ? sqrtf(s2 / size + eps) : sqrtf(s2 / size - mean * mean + eps);
+  const float inv = 1.f / var;
+  for (int i = threadIdx.x; i < size; i += 256) dst[i] = rms ? src[i] * inv : (src[i] - mean) * inv;
+}
+hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* out,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(norm_kernel, dim3(norm_count), dim3(256), 0, st, in, out, norm_size, isrms, eps);
+  return hipGetLastError();
+}
+
+__global__ void bcast_kernel(const float* __restrict__ t, const float* __restrict__ v, float* __restrict__ out,
+                             size_t total, int vsize, int vstep, bool mul) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const size_t b = gid / vsize, i = gid % vsize;
+  const float x = t[gid], y = v[b * vstep + i];
+  out[gid] = mul ? x * y : x + y;
+}
+hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float* v, int vstep, float* out, bool mul,
+                               hipStream_t st) {
+  const size_t total = size_t(batch) * vsize;
+  hipLaunchKernelGGL(bcast_kernel, grid1d(total, 256), dim3(256), 0, st, t, v, out, total, vsize, vstep, mul);
+  return hipGetLastError();
+}
+
+}  // namespace ns

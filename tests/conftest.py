@@ -24,3 +24,18 @@ def refk(nso):
     if r is None:
         pytest.skip("oracle/_ref/libkernel_ref.so not built (reference tree absent)")
     return r
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import __graft_entry__ as ge
+    p = ge.load_package()
+    import os as _os
+    if not _os.path.exists(p.LIB_PATH):
+        p.build()
+    return p
+
+
+@pytest.fixture(scope="session")
+def L(pkg):
+    return pkg.lib()

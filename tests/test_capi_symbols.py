@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads (no GPU needed) and exports every symbol
+include/ns_bestla.h declares; size functions and error behaviour work without a device."""
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "ns_bestla.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b((?:bestla|ns)_[A-Za-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if not n.startswith("ns_comp") and not n.startswith("ns_core")))
+
+
+def test_every_declared_symbol_is_exported(L):
+    names = _declared_functions()
+    assert len(names) > 35
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_reference_surface_names_present(L):
+    # ne_bestla.h:21-83 (the part of the reference surface that does not take ne_tensor structs)
+    for n in ["bestla_init", "bestla_timer", "bestla_set_threads", "bestla_get_thread_handle",
+              "bestla_f32f32_get_workspace_size", "bestla_f32f32_forward", "bestla_fusion_add_f32f32_support",
+              "bestla_fusion_add_f32f32_forward", "bestla_fusion_QKV_f32f32_get_workspace_size",
+              "bestla_fusion_QKV_f32f32_support", "bestla_fusion_QKV_f32f32_forward",
+              "bestla_fusion_FFN_f32f32_get_workspace_size", "bestla_fusion_FFN_Gelu_Mul_f32f32_support",
+              "bestla_fusion_FFN_Gelu_Mul_f32f32_forward", "bestla_fusion_FFN_SiLu_f32f32_support",
+              "bestla_fusion_FFN_SiLu_f32f32_forward", "bestla_fusion_FFN_GeLu_f32f32_support",
+              "bestla_fusion_FFN_GeLu_f32f32_forward", "bestla_fusion_FFN_Add_GeLu_f32f32_support",
+              "bestla_fusion_FFN_Add_GeLu_f32f32_forward", "bestla_unpackweight_fp32", "bestla_packweight_copyattr",
+              "bestla_layernormalization", "bestla_mul", "bestla_add"]:
+        assert hasattr(L, n), n
+
+
+def test_workspace_sizes_match_reference_formula(L):
+    # inner_product.cpp:20-25: m * padto(k,128) * 4
+    assert L.bestla_f32f32_get_workspace_size(3, 4096, 4000, None) == 3 * 4096 * 4
+    assert L.bestla_f32f32_get_workspace_size(1, 11008, 11008, None) == 11008 * 4
+
+
+def test_pack_size_matches_oracle(L, pkg, nso):
+    # the blob size is host logic: must agree with the oracle for every format/core
+    cases = [(pkg.S4, pkg.BF16, False, pkg.COMP_INT8, 32, nso.CORE_AVX512_VNNI_KB),
+             (pkg.S4, pkg.F32, True, pkg.COMP_INT8, 128, nso.CORE_AMX_INT8_KB),
+             (pkg.S8, pkg.BF16, False, pkg.COMP_F32, 32, nso.CORE_AVX512F),
+             (pkg.F4_NF4, pkg.BF16, False, pkg.COMP_BF16, 128, nso.CORE_AMX_BF16),
+             (pkg.INT_TYPES[3], pkg.F16, False, pkg.COMP_F32, 64, nso.CORE_AVX512F),
+             (pkg.INT_TYPES[7], pkg.F32, True, pkg.COMP_INT8, 32, nso.CORE_AVX512_VNNI_KB)]
+    for qt, st, asym, comp, bs, core in cases:
+        for n, k in [(4096, 4096), (100, 96), (48, 128), (11008, 4096)]:
+            if k % bs:
+                continue
+            mine = L.ns_BTLAGemmPackBSize(n, k, bs, qt, st, asym, comp, None)
+            assert mine == nso.pack_size(n, k, bs, qt, st, asym, core), (qt, st, asym, comp, bs, n, k)
+    # per-channel (blocksize -1)
+    assert L.ns_BTLAGemmPackBSize(64, 256, -1 & 0xFFFFFFFFFFFFFFFF, pkg.S4, pkg.F32, False, pkg.COMP_F32, None) == \
+        nso.pack_size(64, 256, -1, nso.S4, nso.F32, False, nso.CORE_AVX512F)
+
+
+def test_forced_core_and_unsupported(L, pkg, nso):
+    try:
+        for core in range(9):
+            L.ns_set_pack_core(core)
+            assert L.ns_BTLAGemmPackBSize(96, 128, 64, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, None) == \
+                nso.pack_size(96, 128, 64, nso.S4, nso.BF16, False, core)
+    finally:
+        L.ns_set_pack_core(pkg.CORE_AUTO)
+    assert L.ns_BTLAGemmPackBSize(96, 128, 64, 0x1234, pkg.BF16, False, pkg.COMP_INT8, None) == 0  # unknown dtype
+    idx = np.zeros(128, np.int32)
+    assert L.ns_BTLAGemmPackBSize(96, 128, 64, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, nso.ptr(idx)) == 0  # g_idx
+
+
+def test_no_device_fails_loudly(L, pkg, nso):
+    """Without a GPU the product must refuse (no CPU fallback); with one this test is a no-op."""
+    if L.ns_hip_device_count() > 0:
+        return
+    w = np.zeros((16, 128), np.float32)
+    blob = nso.quant_pack(w, 32, nso.S4)
+    assert not L.ns_hip_weight_from_blob(nso.ptr(blob), None)
+    assert "no HIP device" in pkg.last_error()
+    out = np.full((1, 16), 7.0, np.float32)
+    a = np.zeros((1, 128), np.float32)
+    L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), 1, 16, 128, 128, 16, None)  # prints Err, as the reference
+    assert np.all(out == 7.0)  # output untouched: nothing computed on the CPU
+    assert not L.bestla_fusion_QKV_f32f32_support(nso.ptr(blob), nso.ptr(blob), nso.ptr(blob), 1, 16, 128)

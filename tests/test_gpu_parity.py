@@ -1,0 +1,417 @@
+"""GPU parity tests proper: every call goes through the C ABI of libns_hip.so and is compared with the CPU oracle
+on the same seeded inputs.
+
+Bars (north_star): bit-exact for the quantize / pack step and for unpack; GEMM outputs within 1e-3 relative
+(metric = ||y - y_ref||_2 / ||y_ref||_2, the reference's own cmpData.diff2, tests/test_python_api.py:27-33) of the
+comp-fp32 semantics evaluated in fp64.  A tighter secondary bar isolates kernel error from the fp16 rounding of
+the activations: against the oracle fed the same fp16-rounded activations the HIP result must agree to 3e-5
+(integer weights: only fp32 accumulation order differs) / 6e-4 (f4 weights: LUT values are rounded to fp16).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3        # north_star tolerance
+TOL_A16_INT = 3e-5
+TOL_A16_F4 = 6e-4
+
+
+def _w(rng, n, k, kind="normal"):
+    if kind == "uniform":
+        return rng.uniform(-0.5, 0.5, (n, k)).astype(np.float32)
+    return (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+
+
+def _gpu_quant_pack(L, pkg, nso, w, bs, qt, st, asym, comp, is_trans=True):
+    n, k = w.shape if is_trans else w.shape[::-1]
+    size = L.ns_BTLAGemmPackBSize(n, k, bs & 0xFFFFFFFFFFFFFFFF, qt, st, asym, comp, None)
+    assert size > 0, pkg.last_error()
+    blob = nso.aligned_bytes(size)
+    ok = L.ns_BTLAGemmQuantPackB(nso.ptr(blob), nso.ptr(w), n, k, w.shape[1], bs & 0xFFFFFFFFFFFFFFFF, qt, st, asym,
+                                 comp, is_trans, None)
+    assert ok, pkg.last_error()
+    return blob
+
+
+# ---------------------------------------------------------------------------------------------- quantize / pack
+ALL_QT = [("S%d" % b, b | (1 << 8)) for b in range(1, 9)] + [("NF4", 4 | (2 << 16)), ("BNB", 4 | (1 << 16)), ("E2M1", 4)]
+
+
+@pytest.mark.parametrize("name,qt", ALL_QT)
+@pytest.mark.parametrize("asym", [False, True])
+def test_quant_pack_bit_exact(L, pkg, nso, name, qt, asym):
+    is_int = ((qt >> 8) & 0xff) == 1
+    if asym and not is_int:
+        pytest.skip("float weights have no zero point")
+    rng = np.random.default_rng(qt & 0xffff)
+    for core, comp in [(nso.CORE_AVX512_VNNI_KB, pkg.COMP_INT8), (nso.CORE_AVX512F, pkg.COMP_F32),
+                       (nso.CORE_AMX_BF16, pkg.COMP_BF16)]:
+        if core == nso.CORE_AVX512_VNNI_KB and (not is_int or (qt == pkg.S8 and asym)):
+            continue  # bestla_gemm.cpp:250: falls through to the next compute type
+        for (n, k, bs, st) in [(96, 128, 32, pkg.BF16), (100, 160, 32, pkg.F32), (48, 256, 128, pkg.F16),
+                               (50, 100, 32, pkg.BF16), (64, 96, -1, pkg.F32)]:
+            if not is_int and st == pkg.F16:
+                st = pkg.BF16
+            if core == nso.CORE_AMX_BF16 and (bs % 32 or bs < 0):
+                continue
+            for kind in ("normal", "uniform"):
+                w = _w(rng, n, k, kind)
+                if kind == "normal":
+                    w[0, 0:32] = 0.0  # all-zero group
+                    w[1, 0:32] = np.abs(w[1, 0:32])  # dominant-positive group
+                L.ns_set_pack_core(core)
+                try:
+                    mine = _gpu_quant_pack(L, pkg, nso, w, bs, qt, st, asym, comp)
+                finally:
+                    L.ns_set_pack_core(pkg.CORE_AUTO)
+                ref = nso.quant_pack(w, bs, qt, st, asym, core)
+                assert mine.size == ref.size
+                if not np.array_equal(mine, ref):
+                    bad = np.nonzero(mine != ref)[0]
+                    bi = nso.parse(ref)
+                    raise AssertionError("blob differs at %d bytes, first %d (q_off %d s_off %d z_off %d r_off %d) %s" % (
+                        bad.size, bad[0], bi.q_off, bi.scale_off, bi.zp_off, bi.red_off, (name, asym, core, n, k, bs, st)))
+
+
+def test_quant_pack_not_transposed_and_ld(L, pkg, nso):
+    rng = np.random.default_rng(5)
+    n, k, bs = 80, 128, 32
+    w_kn = np.ascontiguousarray(_w(rng, n, k).T)  # [K][N]
+    mine = _gpu_quant_pack(L, pkg, nso, w_kn, bs, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, is_trans=False)
+    ref = nso.quant_pack(w_kn, bs, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB, is_trans=False)
+    assert np.array_equal(mine, ref)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 5, 8])
+def test_pack_q_bit_exact(L, pkg, nso, bits):
+    rng = np.random.default_rng(bits)
+    n, k, bs = 70, 128, 32
+    full = 1 << (bits - 1)
+    q = rng.integers(-full, full, (k, n), dtype=np.int8)
+    sc = rng.uniform(0.001, 0.02, (k // bs, n)).astype(np.float32)
+    zp = rng.integers(-full, full, (k // bs, n), dtype=np.int8)
+    qt = pkg.INT_TYPES[bits]
+    for asym in (False, True):
+        size = L.ns_BTLAGemmPackBSize(n, k, bs, qt, pkg.BF16, asym, pkg.COMP_INT8, None)
+        blob = nso.aligned_bytes(size)
+        assert L.ns_BTLAGemmPackB(nso.ptr(blob), nso.ptr(q), nso.ptr(sc), nso.ptr(zp) if asym else None, n, k, n, bs, qt,
+                                  pkg.BF16, asym, pkg.COMP_INT8, None, None), pkg.last_error()
+        ref = nso.pack_q(q, sc, zp if asym else None, bs, qt, nso.BF16, nso.CORE_AVX512_VNNI_KB)
+        assert np.array_equal(blob, ref)
+
+
+# ---------------------------------------------------------------------------------------------- unpack
+@pytest.mark.parametrize("qt,st,asym,core", [
+    ("S4", "BF16", False, "CORE_AVX512_VNNI_KB"), ("S4", "F32", True, "CORE_AVX512F"), ("S4", "F16", True, "CORE_AMX_BF16"),
+    ("S8", "BF16", False, "CORE_AVX512F"), ("S8", "F32", True, "CORE_AVX2"), ("F4_NF4", "BF16", False, "CORE_AVX512F"),
+    ("F4_BNB", "F32", False, "CORE_AMX_BF16"), ("F4_E2M1", "F32", False, "CORE_AVX2"), ("S4", "BF16", False, "CORE_AMX_INT8_KB"),
+    ("S4", "BF16", True, "CORE_AVX_VNNI_KB")])
+def test_unpack_bit_exact(L, pkg, nso, qt, st, asym, core):
+    rng = np.random.default_rng(17)
+    for n, k, bs in [(100, 256, 32), (48, 128, 128), (33, 192, 64), (64, 320, -1), (70, 100, 32)]:
+        if core in ("CORE_AMX_BF16",) and (bs < 0 or bs % 32):
+            continue
+        if core == "CORE_AMX_INT8_KB" and bs % 64:
+            continue
+        w = _w(rng, n, k)
+        blob = nso.quant_pack(w, bs, getattr(nso, qt), getattr(nso, st), asym, getattr(nso, core))
+        out = np.zeros((k, n + 3), np.float32)
+        L.bestla_unpackweight_fp32(nso.ptr(blob), n, k, nso.ptr(out), n + 3)
+        ref = nso.unpack_fp32(blob)
+        assert np.array_equal(out[:, :n].view(np.uint32), ref.view(np.uint32)), (n, k, bs)
+        assert np.all(out[:, n:] == 0)
+
+
+# ---------------------------------------------------------------------------------------------- forward parity
+FWD_FORMATS = [
+    ("S4", "BF16", False, "CORE_AVX512_VNNI_KB", 32),   # "Q4_0" of the BesTLA path (core/README.md:97)
+    ("S4", "F32", False, "CORE_AVX512F", 32),
+    ("S4", "BF16", True, "CORE_AVX512_VNNI_KB", 32),
+    ("S4", "F16", True, "CORE_AVX512F", 64),
+    ("S4", "BF16", False, "CORE_AMX_INT8_KB", 128),
+    ("S4", "F32", True, "CORE_AMX_BF16", 256),
+    ("S4", "F32", False, "CORE_AVX512F", -1),
+    ("S8", "BF16", False, "CORE_AVX512F", 32),
+    ("S8", "F32", True, "CORE_AVX512F", 64),
+    ("S8", "BF16", False, "CORE_AMX_BF16", 128),
+    ("F4_NF4", "BF16", False, "CORE_AVX512F", 128),
+    ("F4_NF4", "F32", False, "CORE_AMX_BF16", 32),
+    ("F4_BNB", "F32", False, "CORE_AVX512F", 32),
+    ("F4_E2M1", "BF16", False, "CORE_AVX512F", 64),
+]
+
+
+def _check(nso, out, a, blob, is_f4):
+    ref = nso.gemm_f64(a, blob)
+    ref16 = nso.gemm_f64(a, blob, a16=True)
+    e = nso.rel_l2(out, ref)
+    e16 = nso.rel_l2(out, ref16)
+    assert e < TOL, "rel l2 vs fp32-activation oracle %g" % e
+    assert e16 < (TOL_A16_F4 if is_f4 else TOL_A16_INT), "rel l2 vs fp16-activation oracle %g" % e16
+    return e, e16
+
+
+@pytest.mark.parametrize("qt,st,asym,core,bs", FWD_FORMATS)
+@pytest.mark.parametrize("m", [1, 4, 8])
+def test_forward_formats(L, pkg, nso, qt, st, asym, core, bs, m):
+    rng = np.random.default_rng(1000 + m)
+    n, k = 272, 1024  # 17 tiles, 8 (4-bit) / 16 (8-bit) k-steps
+    w = _w(rng, n, k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    blob = nso.quant_pack(w, bs, getattr(nso, qt), getattr(nso, st), asym, getattr(nso, core))
+    out = np.zeros((m, n), np.float32)
+    L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), m, n, k, k, n, None)
+    _check(nso, out, a, blob, qt.startswith("F4"))
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 16, 17, 32, 33, 64, 65, 130])
+def test_forward_row_counts(L, pkg, nso, m):
+    rng = np.random.default_rng(m)
+    n, k, bs = 96, 512, 32
+    w = _w(rng, n, k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    blob = nso.quant_pack(w, bs, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    out = np.zeros((m, n), np.float32)
+    L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), m, n, k, k, n, None)
+    _check(nso, out, a, blob, False)
+
+
+@pytest.mark.parametrize("n,k", [(16, 128), (1, 128), (17, 160), (100, 96), (250, 1000), (48, 4096), (333, 2176)])
+def test_forward_ragged_shapes(L, pkg, nso, n, k):
+    """N not a multiple of 16/48, K not a multiple of 128 (tail k-step zero padded, tail quant block)."""
+    rng = np.random.default_rng(n * 7 + k)
+    for m in (1, 7):
+        w = _w(rng, n, k)
+        a = rng.standard_normal((m, k)).astype(np.float32)
+        for qt, core in ((nso.S4, nso.CORE_AVX512F), (nso.S8, nso.CORE_AVX512F)):
+            blob = nso.quant_pack(w, 32, qt, nso.BF16, False, core)
+            out = np.full((m, n + 2), -5.0, np.float32)
+            L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), m, n, k, k, n + 2, None)
+            assert np.all(out[:, n:] == -5.0)  # ldo honoured, nothing written past N
+            _check(nso, np.ascontiguousarray(out[:, :n]), a, blob, False)
+
+
+def test_forward_lda_and_uniform_distribution(L, pkg, nso):
+    rng = np.random.default_rng(77)
+    n, k, bs, m = 128, 768, 32, 3
+    w = _w(rng, n, k, "uniform")  # reference UT distribution (ut/bestla_ut.h:129-134)
+    abig = rng.uniform(-0.5, 0.5, (m, k + 5)).astype(np.float32)
+    blob = nso.quant_pack(w, bs, nso.S4, nso.F32, False, nso.CORE_AVX512F)
+    out = np.zeros((m, n), np.float32)
+    L.bestla_f32f32_forward(nso.ptr(abig), nso.ptr(blob), nso.ptr(out), m, n, k, k + 5, n, None)
+    a = np.ascontiguousarray(abig[:, :k])
+    _check(nso, out, a, blob, False)
+    # the reference's two-sided check (ut/bestla_prologue_b.cpp:673-722): vs the ORIGINAL weights at quant-noise
+    # tolerance INT4_ERR = 3.5 abs at K = 4096 scaled by sqrt(K) (ut/bestla_ut.h:80-127)
+    full = a.astype(np.float64) @ w.astype(np.float64).T
+    assert np.max(np.abs(out - full)) < 3.5 * np.sqrt(k / 4096.0)
+
+
+def test_forward_adversarial_values(L, pkg, nso):
+    rng = np.random.default_rng(99)
+    n, k, bs = 64, 256, 32
+    w = _w(rng, n, k)
+    w[0, :] = 0.0                      # all-zero column: scale -0.0
+    w[1, :32] = np.abs(w[1, :32]) + 1  # dominant positive -> negative scale
+    w[2, 5] = 40.0                     # outlier
+    w[3, :32] = 0.5 * np.where(np.arange(32) % 2 == 0, 1, -1)  # max == -min tie
+    a = rng.standard_normal((1, k)).astype(np.float32)
+    a[0, 7] = 300.0                    # large activation (fp16 range ok)
+    a[0, 9] = 1e-7                     # flushes to an fp16 subnormal / zero
+    for asym in (False, True):
+        blob = nso.quant_pack(w, bs, nso.S4, nso.BF16, asym, nso.CORE_AVX512_VNNI_KB)
+        out = np.zeros((1, n), np.float32)
+        L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), 1, n, k, k, n, None)
+        assert out[0, 0] == 0.0
+        _check(nso, out, a, blob, False)
+
+
+# ---------------------------------------------------------------------------------------------- fused entry points
+def test_fusion_add_bias(L, pkg, nso):
+    rng = np.random.default_rng(3)
+    n, k, m = 112, 512, 5
+    w = _w(rng, n, k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    blob = nso.quant_pack(w, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    assert L.bestla_fusion_add_f32f32_support(nso.ptr(blob), m, n, k)
+    ref = nso.gemm_f64(a, blob)
+    for bcast in (True, False):
+        bias = rng.standard_normal((1 if bcast else m, n)).astype(np.float32)
+        out = np.zeros((m, n), np.float32)
+        L.bestla_fusion_add_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(bias), nso.ptr(out), m, n, k, k, n, bcast, None)
+        assert nso.rel_l2(out, ref + bias) < TOL
+
+
+@pytest.mark.parametrize("m", [1, 6, 70])
+def test_fusion_qkv(L, pkg, nso, m):
+    rng = np.random.default_rng(4)
+    n, k = 160, 512
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    blobs = [nso.quant_pack(_w(rng, n, k), 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB) for _ in range(3)]
+    assert L.bestla_fusion_QKV_f32f32_support(*[nso.ptr(b) for b in blobs], m, n, k)
+    other = nso.quant_pack(_w(rng, n, k), 128, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    assert not L.bestla_fusion_QKV_f32f32_support(nso.ptr(blobs[0]), nso.ptr(other), nso.ptr(blobs[2]), m, n, k)
+    out = np.zeros((3, m, n), np.float32)
+    L.bestla_fusion_QKV_f32f32_forward(nso.ptr(a), *[nso.ptr(b) for b in blobs], nso.ptr(out), m, n, k, k, n, None)
+    for i in range(3):
+        assert nso.rel_l2(out[i], nso.gemm_f64(a, blobs[i])) < TOL
+
+
+def _act(nso, x, name):
+    f = nso.lib().nso_silu if name == "silu" else nso.lib().nso_gelu
+    return np.vectorize(lambda v: f(float(v)))(x.astype(np.float32)).astype(np.float64)
+
+
+@pytest.mark.parametrize("m", [1, 4, 66])
+@pytest.mark.parametrize("act", ["silu", "gelu"])
+def test_fusion_ffn3(L, pkg, nso, m, act):
+    """tmp1 = act(A*W1), tmp2 = (A*W3)*tmp1, out = tmp2*W2 (ip_fusion_ffn.cpp:364-406)"""
+    rng = np.random.default_rng(6)
+    fin, fmid, fout = 256, 352, 256
+    a = rng.standard_normal((m, fin)).astype(np.float32)
+    mk = lambda n, k: nso.quant_pack(_w(rng, n, k) * 3, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    b1, b3, b2 = mk(fmid, fin), mk(fmid, fin), mk(fout, fmid)
+    sup = L.bestla_fusion_FFN_SiLu_f32f32_support if act == "silu" else L.bestla_fusion_FFN_Gelu_Mul_f32f32_support
+    fwd = L.bestla_fusion_FFN_SiLu_f32f32_forward if act == "silu" else L.bestla_fusion_FFN_Gelu_Mul_f32f32_forward
+    assert sup(nso.ptr(b1), nso.ptr(b2), nso.ptr(b3), m, fin, fmid, fout)
+    t1 = np.zeros((m, fmid), np.float32)
+    t2 = np.zeros((m, fmid), np.float32)
+    out = np.zeros((m, fout), np.float32)
+    fwd(nso.ptr(a), nso.ptr(b1), nso.ptr(b2), nso.ptr(b3), nso.ptr(t1), nso.ptr(t2), nso.ptr(out), m, fin, fmid, fout, None)
+    r1 = _act(nso, nso.gemm_f64(a, b1), act)
+    r2 = nso.gemm_f64(a, b3) * r1
+    assert nso.rel_l2(t1, r1) < TOL
+    assert nso.rel_l2(t2, r2) < TOL
+    # last GEMM checked against the oracle fed the HIP tmp2 (isolates it), and end to end
+    assert nso.rel_l2(out, nso.gemm_f64(t2, b2)) < TOL
+    assert nso.rel_l2(out, nso.gemm_f64(r2.astype(np.float32), b2)) < 2 * TOL
+
+
+def test_fusion_ffn2_gelu_and_add_gelu(L, pkg, nso):
+    rng = np.random.default_rng(8)
+    m, fin, fmid, fout = 3, 256, 320, 128
+    a = rng.standard_normal((m, fin)).astype(np.float32)
+    mk = lambda n, k: nso.quant_pack(_w(rng, n, k) * 3, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    b1, b2 = mk(fmid, fin), mk(fout, fmid)
+    assert L.bestla_fusion_FFN_GeLu_f32f32_support(nso.ptr(b1), nso.ptr(b2), m, fin, fmid, fout)
+    t1 = np.zeros((m, fmid), np.float32)
+    out = np.zeros((m, fout), np.float32)
+    L.bestla_fusion_FFN_GeLu_f32f32_forward(nso.ptr(a), nso.ptr(b1), nso.ptr(b2), nso.ptr(t1), nso.ptr(out), m, fin, fmid, fout, None)
+    r1 = _act(nso, nso.gemm_f64(a, b1), "gelu")
+    assert nso.rel_l2(t1, r1) < TOL
+    assert nso.rel_l2(out, nso.gemm_f64(t1, b2)) < TOL
+    for bcast in (True, False):
+        bias1 = rng.standard_normal((1 if bcast else m, fmid)).astype(np.float32)
+        bias2 = rng.standard_normal((1 if bcast else m, fout)).astype(np.float32)
+        L.bestla_fusion_FFN_Add_GeLu_f32f32_forward(nso.ptr(a), nso.ptr(b1), nso.ptr(b2), nso.ptr(bias1), nso.ptr(bias2),
+                                                    nso.ptr(t1), nso.ptr(out), m, fin, fmid, fout, bcast, None)
+        r1 = _act(nso, nso.gemm_f64(a, b1) + bias1, "gelu")
+        assert nso.rel_l2(t1, r1) < TOL
+        assert nso.rel_l2(out, nso.gemm_f64(t1, b2) + bias2) < TOL
+
+
+def test_packweight_copyattr_roundtrip(L, pkg, nso):
+    """bestla_split_weight pattern (model_files.h:1538-1563): unpack -> slice -> re-quantize with copied attributes."""
+    rng = np.random.default_rng(12)
+    n, k = 96, 256
+    src = nso.quant_pack(_w(rng, n, k), 32, nso.S4, nso.BF16, True, nso.CORE_AVX512_VNNI_KB)
+    deq = np.zeros((k, n), np.float32)
+    L.bestla_unpackweight_fp32(nso.ptr(src), n, k, nso.ptr(deq), n)
+    half = np.ascontiguousarray(deq[:, : n // 2])  # ROW split (N slice)
+    size = nso.pack_size(n // 2, k, 32, nso.S4, nso.BF16, True, nso.CORE_AVX512_VNNI_KB)
+    dst = nso.aligned_bytes(size)
+    L.bestla_packweight_copyattr(nso.ptr(half), nso.ptr(dst), n // 2, k, n // 2, nso.ptr(src))
+    ref = nso.quant_pack(half, 32, nso.S4, nso.BF16, True, nso.CORE_AVX512_VNNI_KB, is_trans=False)
+    assert np.array_equal(dst, ref)
+
+
+def test_elementwise_entries(L, pkg, nso):
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((5, 300)).astype(np.float32)
+    out = np.zeros_like(x)
+    L.bestla_layernormalization(5, 300, True, 1e-6, nso.ptr(x), nso.ptr(out))
+    ref = x / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + 1e-6)
+    assert nso.rel_l2(out, ref) < 1e-6
+    L.bestla_layernormalization(5, 300, False, 1e-5, nso.ptr(x), nso.ptr(out))
+    xd = x.astype(np.float64)
+    ref = (xd - xd.mean(-1, keepdims=True)) / np.sqrt(xd.var(-1, keepdims=True) + 1e-5)
+    assert nso.rel_l2(out, ref) < 1e-5
+    v = rng.standard_normal((1, 300)).astype(np.float32)
+    L.bestla_mul(5, 300, nso.ptr(x), nso.ptr(v), 0, nso.ptr(out))
+    assert np.array_equal(out, x * v)
+    L.bestla_add(5, 300, nso.ptr(x), nso.ptr(x), 300, nso.ptr(out))
+    assert np.array_equal(out, x + x)
+
+
+# ---------------------------------------------------------------------------------------------- device-resident API
+def test_device_api_and_device_quantizer(L, pkg, nso):
+    import torch
+    rng = np.random.default_rng(21)
+    n, k, bs, m = 256, 1024, 32, 2
+    w = _w(rng, n, k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dW = torch.from_numpy(w).cuda()
+    size = L.ns_BTLAGemmPackBSize(n, k, bs, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, None)
+    dBlob = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    assert dBlob.data_ptr() % 64 == 0
+    pkg.check(L.ns_hip_quant_pack_device(dBlob.data_ptr(), dW.data_ptr(), n, k, k, bs, pkg.S4, pkg.BF16, False,
+                                         pkg.COMP_INT8, True, st))
+    torch.cuda.synchronize()
+    ref_blob = nso.quant_pack(w, bs, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    assert np.array_equal(dBlob.cpu().numpy(), ref_blob)
+    wt = pkg.Weight.from_device_blob(dBlob.data_ptr(), size, st)
+    assert (wt.n, wt.k, wt.bits, wt.blocksize) == (n, k, 4, bs)
+    assert wt.stream_bytes == n * k // 2 + n * (k // bs) * 2
+    dA = torch.from_numpy(a).cuda()
+    dC = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    pkg.check(L.ns_hip_f32f32_forward(dA.data_ptr(), wt.h, dC.data_ptr(), m, k, n, pkg.EPI_NONE, None, 0, st))
+    torch.cuda.synchronize()
+    assert nso.rel_l2(dC.cpu().numpy(), nso.gemm_f64(a, ref_blob)) < TOL
+    # idempotence: same launch twice gives the same bits (deterministic reduction order, no atomics)
+    dC2 = torch.empty_like(dC)
+    pkg.check(L.ns_hip_f32f32_forward(dA.data_ptr(), wt.h, dC2.data_ptr(), m, k, n, pkg.EPI_NONE, None, 0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(dC, dC2)
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE sizes
+@pytest.mark.parametrize("n,k", [(4096, 4096), (11008, 4096), (4096, 11008)])
+def test_full_size_properties(L, pkg, nso, n, k):
+    """Llama-2-7B shapes (BASELINE.json config 2), size-independent properties instead of the (slow) CPU oracle:
+       (a) GPU quantize -> GPU unpack == oracle dequant of the oracle-quantized SAMPLE columns (bit-exact);
+       (b) GEMV == fp64 matmul against the device-unpacked weights (the reference's own 'vs unpacked W' check);
+       (c) linearity in the activation."""
+    import torch
+    rng = np.random.default_rng(n + k)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(1000 + n)
+    dW = torch.randn((n, k), generator=g, device="cuda", dtype=torch.float32) * 0.02
+    size = L.ns_BTLAGemmPackBSize(n, k, 32, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, None)
+    dBlob = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    pkg.check(L.ns_hip_quant_pack_device(dBlob.data_ptr(), dW.data_ptr(), n, k, k, 32, pkg.S4, pkg.BF16, False,
+                                         pkg.COMP_INT8, True, st))
+    torch.cuda.synchronize()
+    blob = nso.aligned_bytes(size)
+    blob[:] = dBlob.cpu().numpy()
+    deq = np.zeros((k, n), np.float32)
+    L.bestla_unpackweight_fp32(nso.ptr(blob), n, k, nso.ptr(deq), n)
+    # (a) sample 48 columns, quantize them with the oracle
+    cols = np.sort(rng.choice(n, 48, replace=False))
+    wsub = dW[torch.from_numpy(cols).cuda()].cpu().numpy()
+    sub = nso.unpack_fp32(nso.quant_pack(wsub, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB))
+    assert np.array_equal(sub.view(np.uint32), deq[:, cols].view(np.uint32))
+    # (b), (c)
+    a1 = rng.standard_normal((1, k)).astype(np.float32)
+    a2 = rng.standard_normal((1, k)).astype(np.float32)
+    outs = []
+    for a in (a1, a2, a1 + a2):
+        o = np.zeros((1, n), np.float32)
+        L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(o), 1, n, k, k, n, None)
+        ref = a.astype(np.float64) @ deq.astype(np.float64)
+        assert nso.rel_l2(o, ref) < TOL
+        outs.append(o.astype(np.float64))
+    assert nso.rel_l2(outs[0] + outs[1], outs[2]) < 2 * TOL
