@@ -1,0 +1,359 @@
+#!/usr/bin/env python3
+"""bench.py — decode throughput of the Llama-2-7B "Q4_0" (BesTLA: int4 sym, group 32, bf16 scales) GEMM chain on MI355X.
+
+A *step* is one pass of the hot path over one token (batch 1): for each of the 32 layers
+    QKV  (fused, 3 x 4096->4096)  ->  WO (4096->4096)  ->  FFN gate/up (fused W1,W3 4096->11008, SiLU*mul)
+    ->  FFN down (W2 11008->4096)
+then lm_head (4096->32000) — 6 607 077 376 weights, 3 716 481 024 algorithmic bytes, all through the
+device-resident C ABI of libns_hip.so (include/ns_bestla.h part 3), captured once in a HIP graph and replayed.
+Inputs are resident in HBM when the timed region starts.  Weights are synthetic (seeded torch.randn, quantized and
+packed ON THE GPU by the product quantizer into reference-format blobs, then loaded like any reference blob).
+
+N > 1: 1-D tensor parallel exactly as the reference shards Llama (models/model_utils/model_files.h:145-190):
+wq/wk/wv/w1/w3 split on N, wo/w2 split on K + one fp32 all-reduce each (RCCL), lm_head replicated; one process per
+GPU under torch.distributed.  Total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+CFG = dict(name="llama-2-7b", n_embd=4096, n_ff=11008, n_layer=32, n_vocab=32000, group=32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--layers", type=int, default=CFG["n_layer"], help="debug only: fewer layers => INVALID number")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class Chain:
+    """Builds the per-rank weights and runs the decode GEMM chain through the C ABI."""
+
+    def __init__(self, pkg, n_layers, rank, world, keep_host_layer=False):
+        self.pkg, self.L = pkg, pkg.lib()
+        self.rank, self.world = rank, world
+        self.st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        d, ff, V = CFG["n_embd"], CFG["n_ff"], CFG["n_vocab"]
+        assert d % world == 0 and ff % world == 0
+        self.d, self.ff, self.V = d, ff, V
+        self.dl, self.ffl = d // world, ff // world
+        self.layers = []
+        self.host_blobs = None
+        self.stream_bytes = 0
+        t0 = time.time()
+        for il in range(n_layers):
+            seed = 1000 + il * 8
+            lw = {}
+            # norm-preserving synthetic init keeps activations O(1) through the chain (random data, no zeros)
+            lw["q"] = self._make(self.dl, d, seed + 0, d ** -0.5)
+            lw["k"] = self._make(self.dl, d, seed + 1, d ** -0.5)
+            lw["v"] = self._make(self.dl, d, seed + 2, d ** -0.5)
+            lw["o"] = self._make(d, self.dl, seed + 3, d ** -0.5)
+            lw["w1"] = self._make(self.ffl, d, seed + 4, d ** -0.5)
+            lw["w3"] = self._make(self.ffl, d, seed + 5, d ** -0.5)
+            lw["w2"] = self._make(d, self.ffl, seed + 6, (ff ** -0.5) / 0.6)
+            if keep_host_layer and il == 0:
+                self.host_blobs = {k: v[1] for k, v in lw.items()}
+            self.layers.append({k: v[0] for k, v in lw.items()})
+        head = self._make(V, d, 999, d ** -0.5)
+        if keep_host_layer:
+            self.host_blobs["head"] = head[1]
+        self.head = head[0]
+        torch.cuda.synchronize()
+        self.setup_s = time.time() - t0
+        dev = "cuda"
+        g = torch.Generator(device=dev).manual_seed(7)
+        self.x0 = torch.randn((1, d), generator=g, device=dev, dtype=torch.float32)
+        self.x = torch.empty_like(self.x0)
+        self.qkv = torch.empty((3, 1, self.dl), device=dev, dtype=torch.float32)
+        self.attn = torch.empty((1, d), device=dev, dtype=torch.float32)
+        self.t2 = torch.empty((1, self.ffl), device=dev, dtype=torch.float32)
+        self.logits = torch.empty((1, V), device=dev, dtype=torch.float32)
+
+    def _make(self, n, k, seed, std):
+        pkg, L = self.pkg, self.L
+        g = torch.Generator(device="cuda").manual_seed(seed * 64 + self.rank)
+        w = torch.randn((n, k), generator=g, device="cuda", dtype=torch.float32) * std
+        size = L.ns_BTLAGemmPackBSize(n, k, CFG["group"], pkg.S4, pkg.BF16, False, pkg.COMP_INT8, None)
+        blob = torch.zeros(size, dtype=torch.uint8, device="cuda")
+        pkg.check(L.ns_hip_quant_pack_device(blob.data_ptr(), w.data_ptr(), n, k, k, CFG["group"], pkg.S4, pkg.BF16,
+                                             False, pkg.COMP_INT8, True, self.st), "quant_pack_device")
+        wt = pkg.Weight.from_device_blob(blob.data_ptr(), size, self.st)
+        torch.cuda.synchronize()
+        self.stream_bytes += wt.stream_bytes
+        host = blob.cpu().numpy() if self.host_blobs is None and seed in (999,) or (1000 <= seed < 1008) else None
+        del w, blob
+        return wt, host
+
+    def step(self):
+        L, pkg, st = self.L, self.pkg, self.st
+        d = self.d
+        x_in = self.x0
+        for lw in self.layers:
+            pkg.check(L.ns_hip_fusion_qkv_forward(x_in.data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h, self.qkv.data_ptr(),
+                                                  1, d, self.dl, st))
+            # attention itself is outside this path; its output stands in as the Q slice
+            pkg.check(L.ns_hip_f32f32_forward(self.qkv.data_ptr(), lw["o"].h, self.attn.data_ptr(), 1, self.dl, d,
+                                              pkg.EPI_NONE, None, 0, st))
+            if self.world > 1:
+                torch.distributed.all_reduce(self.attn)  # ne_all_reduce after attn-out (llama.cpp:590-593)
+            pkg.check(L.ns_hip_fusion_ffn3_forward(self.attn.data_ptr(), lw["w1"].h, lw["w2"].h, lw["w3"].h, None,
+                                                   self.t2.data_ptr(), self.x.data_ptr(), 1, pkg.EPI_SILU, st))
+            if self.world > 1:
+                torch.distributed.all_reduce(self.x)  # ne_all_reduce after FFN (llama.cpp:690-694)
+            x_in = self.x
+        pkg.check(L.ns_hip_f32f32_forward(x_in.data_ptr(), self.head.h, self.logits.data_ptr(), 1, d, self.V,
+                                          pkg.EPI_NONE, None, 0, st))
+
+    def gateup_only(self):
+        """the dominant kernel alone: the fused W1/W3 gate-up GEMV of every layer, back to back."""
+        L, pkg, st = self.L, self.pkg, self.st
+        from_ptr = self.x0.data_ptr()
+        n = 0
+        for lw in self.layers:
+            a = C.c_void_p(from_ptr)
+            pkg.check(self._gateup(a, lw))
+            n += 1
+        return n
+
+    def _gateup(self, a, lw):
+        # ns_hip_fusion_ffn3_forward = gate/up kernel + down-proj kernel; to isolate gate/up we call the same fused
+        # launch through a helper exported for measurement: here the down projection is skipped by calling the
+        # QKV-style multi-segment entry with the dual epilogue is not exposed, so we time via the full ffn3 and
+        # subtract nothing — see roofline() which instead times gate/up through ns_hip_fusion_ffn3_forward's
+        # first launch using hipGraph kernel nodes.  (kept simple: handled in roofline()).
+        raise NotImplementedError
+
+
+def time_graph(fn, steps, warmup, use_graph, world):
+    """W warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize on both sides."""
+    if use_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        run = None
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fn()
+        run = graph.replay
+    else:
+        run = fn
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ev_ms = e0.elapsed_time(e1)
+    return wall_ms, ev_ms
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl")  # = RCCL on ROCm
+    pkg = ge.load_package()
+    chain = Chain(pkg, args.layers, rank, world, keep_host_layer=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    # the chain object itself carries the captured stream handle; under graph capture torch switches the current
+    # stream, so the stream pointer handed to the C ABI must be re-read inside the capture.
+    def step():
+        chain.st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        chain.step()
+
+    use_graph = not args.no_graph
+    try:
+        wall_ms, ev_ms = time_graph(step, args.steps, args.warmup, use_graph, world)
+    except Exception as e:  # graph capture unsupported (e.g. RCCL in capture): fall back to eager launches
+        if not use_graph:
+            raise
+        sys.stderr.write("graph capture failed (%s); falling back to eager launches\n" % e)
+        use_graph = False
+        wall_ms, ev_ms = time_graph(step, args.steps, args.warmup, False, world)
+    t = torch.tensor([wall_ms], device="cuda", dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    wall_ms = float(t.item())
+    ms_per_step = wall_ms / args.steps
+    value = 1000.0 / ms_per_step  # tokens/s of the whole TP group (batch 1: one token per step)
+
+    if rank == 0:
+        out = {
+            "metric": "decode_tokens_per_sec",
+            "value": round(value, 2),
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int4 weights (bf16 group scales) x fp16 activations, fp32 accumulate",
+            "data": "synthetic (seeded torch.randn weights quantized on the GPU by the product quantizer; randn activations)",
+            "config": {
+                "workload": "Llama-2-7B Q4_0 (BesTLA int4 sym g32 bf16-scale) batch=1 decode GEMM chain: %d layers x "
+                            "{QKV, WO, FFN gate/up, FFN down} + lm_head" % args.layers,
+                "parallelism": "tp%d" % world,
+                "launch": "hipGraph replay" if use_graph else "eager",
+                "weights_bytes_per_gpu": chain.stream_bytes,
+                "event_ms_per_step": round(ev_ms / args.steps, 5),
+            },
+        }
+        if args.layers != CFG["n_layer"]:
+            out["config"]["INVALID"] = "debug run with %d layers" % args.layers
+        alg_bytes = chain.stream_bytes + 4 * sum(
+            [(CFG["n_embd"] + 3 * chain.dl), (chain.dl + CFG["n_embd"]), (CFG["n_embd"] + chain.ffl),
+             (chain.ffl + CFG["n_embd"])]) * args.layers + 4 * (CFG["n_embd"] + CFG["n_vocab"])
+        out["config"]["algorithmic_bytes_per_step_per_gpu"] = alg_bytes
+        out["config"]["chain_hbm_GBps"] = round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1)
+        out["roofline"] = roofline(chain, pkg)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(chain, args.layers)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def roofline(chain, pkg):
+    """Dominant kernel = the fused FFN gate/up weight-streaming GEMV (smallm_kernel<INT4,SPS=4,MB=1,DUAL>): 2 x 4096 x
+    11008/tp int4 weights + bf16 group scales per launch = 27.6 % x 3 of every layer's bytes.  Average launch duration is
+    measured live with HIP events on the launch stream around a hipGraph that holds one gate/up launch per layer (each
+    layer's own weights, so nothing is cache resident), divided by the number of launches."""
+    L = pkg.lib()
+    d = chain.d
+    nl = len(chain.layers)
+    t2 = chain.t2
+
+    def body():
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for lw in chain.layers:
+            pkg.check(L.ns_hip_fusion_ffn3_gateup(chain.x0.data_ptr(), lw["w1"].h, lw["w3"].h, None, t2.data_ptr(), 1,
+                                                  pkg.EPI_SILU, st))
+
+    for _ in range(3):
+        body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * nl)
+    lw = chain.layers[0]
+    bytes_per_launch = lw["w1"].stream_bytes + lw["w3"].stream_bytes + 4 * (d + chain.ffl)
+    achieved = bytes_per_launch / (us * 1e-6) / 1e9
+    return {
+        "kernel": "smallm_kernel<INT4,SPS4,MB1,DUAL> (FFN gate/up GEMV)",
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "bytes_per_launch": bytes_per_launch,
+        "avg_launch_us": round(us, 3),
+        "note": "avg over %d back-to-back graph launches incl. ~1.2us inter-kernel boundary each" % (reps * nl),
+    }
+
+
+def cpu_baseline(chain, n_layers):
+    """The oracle's sequential-fp32 GEMV port (oracle/ns_oracle.cpp nso_gemv_f32 == kernel_ref.h gemv_4bit_fp32_fp32)
+    timed on this box's host cores with OpenMP over one layer's GEMMs + lm_head (bounded sample), scaled to a token."""
+    nso = ge.load_oracle()
+    hb = chain.host_blobs
+    if not hb:
+        return None
+    ncores = os.cpu_count() or 1
+    rng = np.random.default_rng(7)
+    blobs = {}
+    for k, v in hb.items():
+        b = nso.aligned_bytes(v.size)
+        b[:] = v
+        blobs[k] = b
+
+    def run_layer():
+        t0 = time.perf_counter()
+        x = rng.standard_normal((1, CFG["n_embd"])).astype(np.float32)
+        q = nso.gemv_f32(x, blobs["q"], ncores)
+        nso.gemv_f32(x, blobs["k"], ncores)
+        nso.gemv_f32(x, blobs["v"], ncores)
+        o = nso.gemv_f32(q, blobs["o"], ncores)
+        h1 = nso.gemv_f32(o, blobs["w1"], ncores)
+        h3 = nso.gemv_f32(o, blobs["w3"], ncores)
+        nso.gemv_f32((h1 * h3).astype(np.float32), blobs["w2"], ncores)
+        return time.perf_counter() - t0
+
+    def run_head():
+        t0 = time.perf_counter()
+        x = rng.standard_normal((1, CFG["n_embd"])).astype(np.float32)
+        nso.gemv_f32(x, blobs["head"], ncores)
+        return time.perf_counter() - t0
+
+    run_layer()
+    tl = min(run_layer() for _ in range(3))
+    th = min(run_head() for _ in range(2))
+    tok_s = 1.0 / (tl * CFG["n_layer"] + th)
+    return {
+        "value": round(tok_s, 3),
+        "unit": "tokens/s",
+        "cores": ncores,
+        "kind": "port",
+        "sample": "oracle scalar GEMV (kernel_ref gemv_4bit_fp32_fp32 restatement, OpenMP over N): 1 of 32 layers "
+                  "(7 GEMVs, best of 3) + lm_head (best of 2), scaled x32; not the BesTLA JIT path",
+        "layer_ms": round(tl * 1e3, 2),
+        "lm_head_ms": round(th * 1e3, 2),
+    }
+
+
+if __name__ == "__main__":
+    main()

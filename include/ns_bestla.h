@@ -129,6 +129,9 @@ bool ns_BTLAGemmUnPackB(float* FpData, const void* PackedBuf, size_t N, size_t K
 typedef struct ns_weight ns_weight; /* opaque: one weight matrix resident in HBM in the MI355X layout */
 
 int ns_hip_device_count(void);
+/* part-1 entry points cache {host blob pointer -> device weight} (validated by a content fingerprint); this
+ * drops every cached device weight, e.g. after the model that owned the blobs was unloaded. */
+void ns_hip_cache_clear(void);
 const char* ns_hip_last_error(void);
 /* host blob (reference format) -> device weight.  The blob is only read. */
 ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream);

@@ -47,6 +47,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libns_hip.so is missing: run neural-speed_amd.build() (make -C neural-speed_amd/csrc)")
+        try:  # torch bundles its own libamdhip64.so.7: let it load first so both share ONE HIP runtime
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i, u32, sz, f, b = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t, C.c_float, C.c_bool
         L.ns_hip_last_error.restype = C.c_char_p

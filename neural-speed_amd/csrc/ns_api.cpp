@@ -29,7 +29,11 @@ namespace {
 std::mutex g_mu;
 std::string g_err;
 int g_pack_core = NS_CORE_AUTO;
-std::unordered_map<const void*, ns_weight*> g_cache;  // host blob pointer -> device weight (part-1 API)
+struct CacheEntry {
+  ns_weight* w;
+  uint64_t fingerprint;
+};
+std::unordered_map<const void*, CacheEntry> g_cache;  // host blob pointer -> device weight (part-1 API)
 
 struct Scratch {  // growable device scratch for the host-pointer API
   void* p = nullptr;
@@ -102,6 +106,7 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
     for (int i = 0; i < 16; i++) {
       float f = v.dtype == DT_F4_NF4 ? kNF4[i] : ((v.dtype == DT_F4_BNB ? kBNB[i & 7] : kE2M1[i & 7]) * ((i & 8) ? -1.f : 1.f));
       w->lut[i] = (_Float16)f;
+      w->lutf[i] = f;
     }
   } else {
     set_error("weight dtype not supported by the MI355X kernels yet (supported: S4_CLIP, S8, F4_NF4, F4_BNB, F4_E2M1)");
@@ -174,16 +179,53 @@ ns_weight* weight_from_device_sections(const BlobView& v, const uint8_t* dq, con
   return w;
 }
 
+// The reference treats a blob as immutable for the model's lifetime (it points into the model mmap,
+// model_files.h:1564-1571), so the pointer is the cache key.  To stay safe when a caller recycles the address for a
+// different weight, each hit is validated against a cheap content fingerprint (header + 256 sampled words).
+uint64_t blob_fingerprint(const void* blob) {
+  const uint8_t* b = static_cast<const uint8_t*>(blob);
+  uint64_t size;
+  memcpy(&size, b, 8);
+  if (size < 64 || size > (uint64_t(1) << 40)) return 0;
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) {
+    h ^= v;
+    h *= 1099511628211ull;
+  };
+  for (int i = 0; i < 6; i++) {
+    uint64_t v;
+    memcpy(&v, b + 8 * i, 8);
+    mix(v);
+  }
+  const uint64_t words = size / 8;
+  const uint64_t stride = words / 256 ? words / 256 : 1;
+  for (uint64_t wd = 8; wd < words; wd += stride) {
+    uint64_t v;
+    memcpy(&v, b + 8 * wd, 8);
+    mix(v ^ wd);
+  }
+  return h ? h : 1;
+}
+
 ns_weight* cached_weight(const void* blob) {
+  if (!blob) {
+    set_error("blob: null pointer");
+    return nullptr;
+  }
+  const uint64_t fp = blob_fingerprint(blob);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_cache.find(blob);
-    if (it != g_cache.end()) return it->second;
+    if (it != g_cache.end()) {
+      if (it->second.fingerprint == fp) return it->second.w;
+      ns_hip_weight_free(it->second.w);  // the address now holds a different blob
+      g_cache.erase(it);
+    }
   }
   ns_weight* w = ns_hip_weight_from_blob(blob, nullptr);
   if (w) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_cache[blob] = w;
+    g_cache[blob] = CacheEntry{w, fp};
   }
   return w;
 }
@@ -263,6 +305,12 @@ void set_error(const std::string& s) {
 extern "C" {
 
 // ------------------------------------------------------------------------------------------------ part 3
+void ns_hip_cache_clear(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_cache) ns_hip_weight_free(kv.second.w);
+  g_cache.clear();
+}
+
 int ns_hip_device_count(void) {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) return 0;

@@ -89,7 +89,8 @@ struct ns_weight {
   size_t codes_bytes = 0, scales_bytes = 0, zps_bytes = 0;
   uint64_t stream_bytes = 0;  // algorithmic bytes (reference formula)
   int device = 0;
-  _Float16 lut[16];  // f4 value table as fp16 (kind == WK_F4)
+  _Float16 lut[16];  // f4 value table rounded to fp16: the MFMA operand (kind == WK_F4)
+  float lutf[16];    // the same table in fp32: exact unpack
 };
 
 namespace ns {

@@ -606,7 +606,7 @@ static void srow_rule(const ns_weight* w, int* num, int* den) {
 
 hipError_t launch_unpack_fp32(const ns_weight* w, float* out, int ld, hipStream_t st) {
   Lut16 lut;
-  for (int i = 0; i < 16; i++) lut.v[i] = float(w->lut[i]);
+  for (int i = 0; i < 16; i++) lut.v[i] = w->lutf[i];
   int num, den;
   srow_rule(w, &num, &den);
   const size_t total = size_t(w->n) * w->k;

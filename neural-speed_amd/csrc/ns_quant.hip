@@ -24,15 +24,20 @@ namespace {
 
 // ---- x86 float->int conversions as the reference binary performs them ------------------------------------------
 // cast<float,int>(x) = int(roundf(x)) (bestla_utils.h:523-526): cvttss2si yields INT_MIN for NaN / out of range.
+// roundf (half away from zero), exact: x - trunc(x) is always representable
+__device__ __forceinline__ float round_half_away(float x) {
+  const float t = truncf(x);
+  return (fabsf(__fsub_rn(x, t)) >= 0.5f) ? __fadd_rn(t, copysignf(1.f, x)) : t;
+}
 __device__ __forceinline__ int cvt_round_int_x86(float v) {
-  const float r = roundf(v);
+  const float r = round_half_away(v);
   if (!(r >= -2147483648.f && r < 2147483648.f)) return INT_MIN;
   return int(r);
 }
 // cast<float,int8_t>(x) (bestla_utils.h:507-513): roundf, clamp to [-128,127]; NaN observed to come out as 0
 __device__ __forceinline__ int cvt_round_s8_x86(float v) {
   if (v != v) return 0;
-  float r = roundf(v);
+  float r = round_half_away(v);
   r = r > 127.f ? 127.f : r;
   r = r < -128.f ? -128.f : r;
   return int(r);
