@@ -63,18 +63,19 @@ class Chain:
         for il in range(n_layers):
             seed = 1000 + il * 8
             lw = {}
+            kh = keep_host_layer and il == 0
             # norm-preserving synthetic init keeps activations O(1) through the chain (random data, no zeros)
-            lw["q"] = self._make(self.dl, d, seed + 0, d ** -0.5)
-            lw["k"] = self._make(self.dl, d, seed + 1, d ** -0.5)
-            lw["v"] = self._make(self.dl, d, seed + 2, d ** -0.5)
-            lw["o"] = self._make(d, self.dl, seed + 3, d ** -0.5)
-            lw["w1"] = self._make(self.ffl, d, seed + 4, d ** -0.5)
-            lw["w3"] = self._make(self.ffl, d, seed + 5, d ** -0.5)
-            lw["w2"] = self._make(d, self.ffl, seed + 6, (ff ** -0.5) / 0.6)
+            lw["q"] = self._make(self.dl, d, seed + 0, d ** -0.5, kh)
+            lw["k"] = self._make(self.dl, d, seed + 1, d ** -0.5, kh)
+            lw["v"] = self._make(self.dl, d, seed + 2, d ** -0.5, kh)
+            lw["o"] = self._make(d, self.dl, seed + 3, d ** -0.5, kh)
+            lw["w1"] = self._make(self.ffl, d, seed + 4, d ** -0.5, kh)
+            lw["w3"] = self._make(self.ffl, d, seed + 5, d ** -0.5, kh)
+            lw["w2"] = self._make(d, self.ffl, seed + 6, (ff ** -0.5) / 0.6, kh)
             if keep_host_layer and il == 0:
                 self.host_blobs = {k: v[1] for k, v in lw.items()}
             self.layers.append({k: v[0] for k, v in lw.items()})
-        head = self._make(V, d, 999, d ** -0.5)
+        head = self._make(V, d, 999, d ** -0.5, keep_host_layer)
         if keep_host_layer:
             self.host_blobs["head"] = head[1]
         self.head = head[0]
@@ -89,7 +90,7 @@ class Chain:
         self.t2 = torch.empty((1, self.ffl), device=dev, dtype=torch.float32)
         self.logits = torch.empty((1, V), device=dev, dtype=torch.float32)
 
-    def _make(self, n, k, seed, std):
+    def _make(self, n, k, seed, std, keep_host=False):
         pkg, L = self.pkg, self.L
         g = torch.Generator(device="cuda").manual_seed(seed * 64 + self.rank)
         w = torch.randn((n, k), generator=g, device="cuda", dtype=torch.float32) * std
@@ -100,7 +101,7 @@ class Chain:
         wt = pkg.Weight.from_device_blob(blob.data_ptr(), size, self.st)
         torch.cuda.synchronize()
         self.stream_bytes += wt.stream_bytes
-        host = blob.cpu().numpy() if self.host_blobs is None and seed in (999,) or (1000 <= seed < 1008) else None
+        host = blob.cpu().numpy() if keep_host else None
         del w, blob
         return wt, host
 
@@ -124,33 +125,9 @@ class Chain:
         pkg.check(L.ns_hip_f32f32_forward(x_in.data_ptr(), self.head.h, self.logits.data_ptr(), 1, d, self.V,
                                           pkg.EPI_NONE, None, 0, st))
 
-    def gateup_only(self):
-        """the dominant kernel alone: the fused W1/W3 gate-up GEMV of every layer, back to back."""
-        L, pkg, st = self.L, self.pkg, self.st
-        from_ptr = self.x0.data_ptr()
-        n = 0
-        for lw in self.layers:
-            a = C.c_void_p(from_ptr)
-            pkg.check(self._gateup(a, lw))
-            n += 1
-        return n
-
-    def _gateup(self, a, lw):
-        # ns_hip_fusion_ffn3_forward = gate/up kernel + down-proj kernel; to isolate gate/up we call the same fused
-        # launch through a helper exported for measurement: here the down projection is skipped by calling the
-        # QKV-style multi-segment entry with the dual epilogue is not exposed, so we time via the full ffn3 and
-        # subtract nothing — see roofline() which instead times gate/up through ns_hip_fusion_ffn3_forward's
-        # first launch using hipGraph kernel nodes.  (kept simple: handled in roofline()).
-        raise NotImplementedError
-
 
 def time_graph(fn, steps, warmup, use_graph, world):
     """W warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize on both sides."""
-    if use_graph:
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        graph = torch.cuda.CUDAGraph()
-        run = None
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -229,7 +206,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int4 weights (bf16 group scales) x fp16 activations, fp32 accumulate",
+            "dtype": "f16",  # int4 codes dequantized to fp16 MFMA operands, fp16 activations, fp32 accumulate/scales
             "data": "synthetic (seeded torch.randn weights quantized on the GPU by the product quantizer; randn activations)",
             "config": {
                 "workload": "Llama-2-7B Q4_0 (BesTLA int4 sym g32 bf16-scale) batch=1 decode GEMM chain: %d layers x "

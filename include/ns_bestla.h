@@ -164,6 +164,9 @@ int ns_hip_fusion_qkv_forward(const float* dA, const ns_weight* wq, const ns_wei
  * (ip_fusion_ffn.cpp:364-406).  tmp1 may be NULL on the device path (the fused gate/up kernel writes tmp2 only). */
 int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const ns_weight* w3,
                                float* dTmp1, float* dTmp2, float* dOut, int seq, int act, void* stream);
+/* the first stage of ffn3 alone: tmp2 = (A*W3) * act(A*W1) in ONE launch (tmp1 optional) */
+int ns_hip_fusion_ffn3_gateup(const float* dA, const ns_weight* w1, const ns_weight* w3, float* dTmp1, float* dTmp2,
+                              int seq, int act, void* stream);
 /* tmp1 = gelu(A*W1 [+ b1]); out = tmp1*W2 [+ b2]   (ip_fusion_ffn.cpp ffn_2w) */
 int ns_hip_fusion_ffn2_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const float* dB1,
                                const float* dB2, float* dTmp1, float* dOut, int seq, bool broadcast_bias, void* stream);

@@ -58,6 +58,7 @@ def lib():
         L.ns_hip_weight_from_blob.argtypes = [vp, vp]
         L.ns_hip_weight_from_device_blob.restype = vp
         L.ns_hip_weight_from_device_blob.argtypes = [vp, sz, vp]
+        L.ns_hip_cache_clear.restype = None
         L.ns_hip_weight_free.argtypes = [vp]
         L.ns_hip_weight_free.restype = None
         L.ns_hip_weight_stream_bytes.restype = C.c_uint64
@@ -66,6 +67,7 @@ def lib():
         L.ns_hip_f32f32_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
         L.ns_hip_fusion_qkv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
         L.ns_hip_fusion_ffn3_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.ns_hip_fusion_ffn3_gateup.argtypes = [vp, vp, vp, vp, vp, i, i, vp]
         L.ns_hip_fusion_ffn2_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, b, vp]
         L.ns_hip_quant_pack_device.argtypes = [vp, vp, sz, sz, sz, sz, u32, u32, b, i, b, vp]
         L.ns_BTLAGemmPackBSize.restype = sz

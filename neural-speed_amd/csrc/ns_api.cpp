@@ -429,22 +429,18 @@ int ns_hip_fusion_qkv_forward(const float* dA, const ns_weight* wq, const ns_wei
   return hip_ok(launch_smallm(a, st), "qkv launch") ? 0 : -1;
 }
 
-int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const ns_weight* w3,
-                               float* dTmp1, float* dTmp2, float* dOut, int seq, int act, void* stream) {
+int ns_hip_fusion_ffn3_gateup(const float* dA, const ns_weight* w1, const ns_weight* w3, float* dTmp1, float* dTmp2,
+                              int seq, int act, void* stream) {
   if (!have_device()) return -1;
-  if (!w1 || !w2 || !w3 || !dTmp2) {
-    set_error("ffn3: null argument");
+  if (!w1 || !w3 || !dTmp2 || !dA) {
+    set_error("ffn3 gate/up: null argument");
     return -1;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int fin = w1->k, fmid = w1->n, fout = w2->n;
+  const int fin = w1->k, fmid = w1->n;
   const bool same = w3->k == fin && w3->n == fmid && w3->kind == w1->kind && w3->blocksize == w1->blocksize &&
                     w3->scale_dt == w1->scale_dt && w3->asym == w1->asym && w3->qtype == w1->qtype;
-  if (w2->k != fmid) {
-    set_error("ffn3: shape mismatch");
-    return -1;
-  }
-  if (same && seq <= 64) {
+  if (same && seq <= 64 && smallm_supported(w1, seq)) {
     SmallMArgs a{};
     a.a = dA;
     a.lda = fin;
@@ -456,16 +452,29 @@ int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_we
     a.epilogue = act;
     a.dual = true;
     a.c2 = dTmp1;
-    if (!hip_ok(launch_smallm(a, st), "ffn gate/up launch")) return -1;
-  } else {
-    if (!dTmp1) {
-      set_error("ffn3: tmp1 required on the unfused path");
-      return -1;
-    }
-    if (forward_impl(dA, w1, dTmp1, seq, fin, fmid, act, nullptr, 0, st)) return -1;
-    if (forward_impl(dA, w3, dTmp2, seq, fin, fmid, NS_EPI_MUL, dTmp1, fmid, st)) return -1;
+    return hip_ok(launch_smallm(a, st), "ffn gate/up launch") ? 0 : -1;
   }
-  return forward_impl(dTmp2, w2, dOut, seq, fmid, fout, NS_EPI_NONE, nullptr, 0, st);
+  if (!dTmp1) {
+    set_error("ffn3: tmp1 required on the unfused path");
+    return -1;
+  }
+  if (forward_impl(dA, w1, dTmp1, seq, fin, fmid, act, nullptr, 0, st)) return -1;
+  return forward_impl(dA, w3, dTmp2, seq, fin, fmid, NS_EPI_MUL, dTmp1, fmid, st);
+}
+
+int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const ns_weight* w3,
+                               float* dTmp1, float* dTmp2, float* dOut, int seq, int act, void* stream) {
+  if (!have_device()) return -1;
+  if (!w1 || !w2 || !w3 || !dTmp2) {
+    set_error("ffn3: null argument");
+    return -1;
+  }
+  if (w2->k != w1->n) {
+    set_error("ffn3: shape mismatch");
+    return -1;
+  }
+  if (ns_hip_fusion_ffn3_gateup(dA, w1, w3, dTmp1, dTmp2, seq, act, stream)) return -1;
+  return forward_impl(dTmp2, w2, dOut, seq, w1->n, w2->n, NS_EPI_NONE, nullptr, 0, (hipStream_t)stream);
 }
 
 int ns_hip_fusion_ffn2_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const float* dB1,
