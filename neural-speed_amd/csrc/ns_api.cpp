@@ -440,7 +440,7 @@ int ns_hip_fusion_ffn3_gateup(const float* dA, const ns_weight* w1, const ns_wei
   const int fin = w1->k, fmid = w1->n;
   const bool same = w3->k == fin && w3->n == fmid && w3->kind == w1->kind && w3->blocksize == w1->blocksize &&
                     w3->scale_dt == w1->scale_dt && w3->asym == w1->asym && w3->qtype == w1->qtype;
-  if (same && seq <= 64 && smallm_supported(w1, seq)) {
+  if (same && smallm_dual_ok(seq) && smallm_supported(w1, seq)) {
     SmallMArgs a{};
     a.a = dA;
     a.lda = fin;

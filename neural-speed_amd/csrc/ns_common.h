@@ -121,6 +121,7 @@ struct SmallMArgs {
 };
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
 bool smallm_supported(const ns_weight* w, int m);
+bool smallm_dual_ok(int m);  // the fused gate/up launch handles up to 16 rows
 
 hipError_t launch_unpack_fp32(const ns_weight* w, float* out, int ld, hipStream_t st);  // device [K][N]
 

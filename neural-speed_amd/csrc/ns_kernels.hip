@@ -13,7 +13,9 @@
 //   pack      interleave + bit planes + reduce   kernel_ref.h:39-57, :155-365, :2132-2142; bestla_prologue_b.h:378-617
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <utility>
 
 #include "ns_common.h"
 
@@ -157,16 +159,23 @@ hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st) {
 // ============================================================================================================
 // code -> fp16 converters (exact for integer codes)
 // ============================================================================================================
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask, uint32_t bits) {
+  uint32_t r;  // hipcc splits (x & m) | c into v_and + v_or when both are literals; one VOP3 does it
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(mask), "v"(bits));
+  return r;
+}
 // 8 nibbles of one dword -> 8 fp16 = (code - 8 - zp).  Magic 0x6400 = 1024.0h whose mantissa LSBs take the nibble:
 // (x & 0x000f000f)|0x64006400 = {1024+u, 1024+u'}, (x & 0x00f000f0)|0x64006400 = {1024+16u, 1024+16u'}.
-__device__ __forceinline__ half8_t cvt_i4x8(uint32_t x, half2_t off_lo, half2_t off_hi) {
-  constexpr uint32_t kMagic = 0x64006400u;
+struct I4Consts {
+  uint32_t mlo, mhi, magic;
+};
+__device__ __forceinline__ half8_t cvt_i4x8(uint32_t x, const I4Consts& c, half2_t off_lo, half2_t off_hi) {
   const half2_t k16 = {(_Float16)0.0625f, (_Float16)0.0625f};
   const uint32_t y = x >> 8;
-  half2_t h0 = as_half2((x & 0x000f000fu) | kMagic) + off_lo;
-  half2_t h1 = as_half2((x & 0x00f000f0u) | kMagic) * k16 + off_hi;
-  half2_t h2 = as_half2((y & 0x000f000fu) | kMagic) + off_lo;
-  half2_t h3 = as_half2((y & 0x00f000f0u) | kMagic) * k16 + off_hi;
+  half2_t h0 = as_half2(and_or(x, c.mlo, c.magic)) + off_lo;
+  half2_t h1 = as_half2(and_or(x, c.mhi, c.magic)) * k16 + off_hi;
+  half2_t h2 = as_half2(and_or(y, c.mlo, c.magic)) + off_lo;
+  half2_t h3 = as_half2(and_or(y, c.mhi, c.magic)) * k16 + off_hi;
   uint4v r = {as_u32(h0), as_u32(h1), as_u32(h2), as_u32(h3)};
   return __builtin_bit_cast(half8_t, r);
 }
@@ -205,7 +214,8 @@ __device__ __forceinline__ half8_t cvt_f4x8(uint32_t x, const F4Lut& lut) {
 // smallm_kernel — weight-streaming MFMA kernel for M <= 16*MB rows (decode / batched decode)
 //
 // One workgroup = NW waves = one 16-column tile (or the same tile of two matrices in DUAL mode) over the whole K.
-// Wave w streams k-steps w, w+NW, ...: one 16-byte load per lane per k-step = 1 KiB contiguous per wave-load.
+// Wave w streams k-steps w, w+NW, ...: one 16-byte load per lane per k-step = 1 KiB contiguous per wave-load,
+// kPF k-steps (codes + scales) in flight per wave, refilled as they are consumed.
 // Lane (nn = l&15, c = l>>4) is column nn of the tile and k-slot c of the MFMA: its 16 B are the B operand of
 // NJ = 4 (4-bit) / 2 (8-bit) v_mfma_f32_16x16x32_f16, one per 32-deep k-slice j, so that every MFMA lives inside
 // one quantisation group (blocksize % 32 == 0) and the group scale is applied to the fp32 MFMA result:
@@ -213,68 +223,106 @@ __device__ __forceinline__ half8_t cvt_f4x8(uint32_t x, const F4Lut& lut) {
 // exactly the reference's w = (code - zp) * scale with fp32 accumulation (kernel_ref.h:2489-2531), except that
 // A is rounded to fp16 (north_star: fp16 activations).  A is staged once per workgroup in LDS as fp16.
 // ============================================================================================================
-constexpr int kNW = 8;  // waves per workgroup
+constexpr int kMaxNW = 16;  // waves per workgroup: 4, 8 or 16 (runtime, blockDim.x / 64)
+#ifndef NS_PF
+#define NS_PF 4
+#endif
+constexpr int kPF = NS_PF;  // k-steps each wave keeps in flight (codes + scales [+ zero points])
 
 struct SmallMParams {
   const float* a;
   int lda, m, k;
   int ksteps;       // k-steps of the weight (kpad / KSTEP)
-  int chunk_steps;  // k-steps staged in LDS at a time (multiple of kNW)
+  int chunk_steps;  // k-steps staged in LDS at a time (multiple of NW)
   int nseg;
   int tile_begin[4];  // first global tile of each segment (+ total)
   const uint4* codes[3];
   const void* scales[3];
   const int8_t* zps[3];
+  uint32_t codes_bytes[3], scales_bytes[3], zps_bytes[3];  // buffer-descriptor extents (each < 4 GiB)
   float* c[3];
   int n[3];
   int ldc;
   uint32_t scale_dt;
-  int asym;
-  int srows, srow_shift_num, srow_shift_den;  // scale row of k-step s = s * num / den
+  int srows;
+  int srow_mul, srow_shift;  // scale row of k-step s = (s * srow_mul) >> srow_shift  (branch-free s / ratio)
   int epilogue;
   const float* d;
   int ldd;
   float* c2;
   F4Lut lut;
 };
+// diagnostics only: build with -DNS_ABLATE=n (1 = no dequant/MFMA, 2 = no scale loads, 4 = no A staging)
+#ifndef NS_ABLATE
+#define NS_ABLATE 0
+#endif
+constexpr int kAblate = NS_ABLATE;
 
-template <int SPS, int NJ>
-__device__ __forceinline__ void load_corr(const SmallMParams& p, int seg, size_t corr_idx, float (&sc)[4],
-                                          int (&zp)[4]) {
-  // corr_idx = ((tile * srows + row) * 16 + nn) * SPS ; returns the 4 per-slice scales (replicated when SPS < 4)
-  float s[SPS];
-  if (p.scale_dt == DT_F32) {
-    const float* b = static_cast<const float*>(p.scales[seg]) + corr_idx;
-#pragma unroll
-    for (int i = 0; i < SPS; i++) s[i] = b[i];
+// raw (unconverted) per-k-step correction words of one lane: loaded early, converted at use
+enum ScaleKind { SK_BF16 = 0, SK_F16 = 1, SK_F32 = 2 };
+template <int SPS, int SK, bool ASYM>
+struct CorrRaw {
+  static constexpr bool S32 = SK == SK_F32;
+  static constexpr int NW32 = S32 ? SPS : (SPS + 1) / 2;
+  uint32_t s[NW32];
+  uint32_t z[ASYM ? 1 : 0];
+};
+
+// Buffer (SRD) loads: the per-lane part of every address is a loop-invariant 32-bit voffset and everything that
+// changes per k-step is a scalar soffset, so the streaming loop carries no 64-bit VGPR address arithmetic.
+using Rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ Rsrc make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <int SPS, int SK, bool ASYM>
+__device__ __forceinline__ void corr_issue(Rsrc rs, Rsrc rz, uint32_t voff_s, uint32_t voff_z, uint32_t soff_s,
+                                           uint32_t soff_z, CorrRaw<SPS, SK, ASYM>& r) {
+  constexpr int kBytes = SPS * (SK == SK_F32 ? 4 : 2);
+  if constexpr (kBytes == 16) {
+    const uint4v v = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff_s, soff_s, 0));
+    r.s[0] = v.x, r.s[1] = v.y, r.s[2] = v.z, r.s[3] = v.w;
+  } else if constexpr (kBytes == 8) {
+    typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+    const uint2v v = __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff_s, soff_s, 0));
+    r.s[0] = v.x, r.s[1] = v.y;
+  } else if constexpr (kBytes == 4) {
+    r.s[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_s, soff_s, 0);
   } else {
-    const unsigned short* b = static_cast<const unsigned short*>(p.scales[seg]) + corr_idx;
-    uint32_t raw[SPS];
-    if constexpr (SPS == 4) {
-      const uint2 v = *reinterpret_cast<const uint2*>(b);
-      raw[0] = v.x & 0xffff;
-      raw[1] = v.x >> 16;
-      raw[2] = v.y & 0xffff;
-      raw[3] = v.y >> 16;
-    } else if constexpr (SPS == 2) {
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(b);
-      raw[0] = v & 0xffff;
-      raw[1] = v >> 16;
-    } else {
-      raw[0] = b[0];
-    }
+    r.s[0] = __builtin_amdgcn_raw_buffer_load_b16(rs, voff_s, soff_s, 0);
+  }
+  if constexpr (ASYM) {
+    if constexpr (SPS == 4)
+      r.z[0] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z, soff_z, 0);
+    else if constexpr (SPS == 2)
+      r.z[0] = __builtin_amdgcn_raw_buffer_load_b16(rz, voff_z, soff_z, 0);
+    else
+      r.z[0] = __builtin_amdgcn_raw_buffer_load_b8(rz, voff_z, soff_z, 0);
+  }
+}
+
+template <int SPS, int SK, bool ASYM, int NJ>
+__device__ __forceinline__ void corr_decode(const CorrRaw<SPS, SK, ASYM>& r, float (&sc)[4], float (&zp)[4]) {
+  float s[SPS];
 #pragma unroll
-    for (int i = 0; i < SPS; i++) s[i] = (p.scale_dt == DT_BF16) ? bf16_bits_to_f32(raw[i]) : f16_bits_to_f32(raw[i]);
+  for (int i = 0; i < SPS; i++) {
+    if constexpr (SK == SK_F32) {
+      s[i] = __builtin_bit_cast(float, r.s[i]);
+    } else {
+      const uint32_t word = r.s[i >> 1];
+      if constexpr (SK == SK_BF16)
+        s[i] = __builtin_bit_cast(float, (i & 1) ? (word & 0xffff0000u) : (word << 16));
+      else
+        s[i] = f16_bits_to_f32((i & 1) ? (word >> 16) : (word & 0xffffu));
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 4; j++) sc[j] = s[((j % NJ) * SPS) / NJ];
-  if (p.asym) {
-    const int8_t* z = p.zps[seg] + corr_idx;
-#pragma unroll
-    for (int j = 0; j < 4; j++) zp[j] = z[((j % NJ) * SPS) / NJ];
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; j++) zp[j] = 0;
+  for (int j = 0; j < 4; j++) {
+    const int e = ((j % NJ) * SPS) / NJ;
+    sc[j] = s[e];
+    if constexpr (ASYM)
+      zp[j] = float(int(int8_t((r.z[0] >> (8 * e)) & 0xff)));
+    else
+      zp[j] = 0.f;
   }
 }
 
@@ -283,20 +331,31 @@ __device__ __forceinline__ float epi_gelu(float x) {  // kernel_ref.h:1570-1572
 }
 __device__ __forceinline__ float epi_silu(float x) { return x / (1.f + expf(-x)); }  // kernel_ref.h:1573-1575
 
-template <int KIND, int SPS, int MB, bool DUAL>
-__global__ __launch_bounds__(kNW * 64) void smallm_kernel(const SmallMParams p) {
+template <int KIND, int SPS, int MB, bool DUAL, int SK, bool ASYM>
+#ifndef NS_WPE1
+#define NS_WPE1 4
+#endif
+#ifndef NS_WPE2
+#define NS_WPE2 4
+#endif
+__global__ __launch_bounds__((MB == 1) ? kMaxNW * 64 : 512, (MB == 1) ? (DUAL ? NS_WPE2 : NS_WPE1) : 1) void smallm_kernel(
+    const SmallMParams p) {
   constexpr int NJ = (KIND == WK_INT8) ? 2 : 4;
   constexpr int KSTEP = NJ * 32;
-  constexpr int NACC = DUAL ? 2 : 1;
+  constexpr int NQ = DUAL ? 2 : 1;  // matrices streamed by one workgroup
+  static_assert(kPF % NQ == 0, "ring slots alternate between the two matrices");
+  constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
+  using Corr = CorrRaw<SPS, SK, ASYM>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   _Float16* a_lds = reinterpret_cast<_Float16*>(smem);
 
   const int tid = threadIdx.x;
+  const int NW = blockDim.x >> 6;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
   const int nn = l & 15, g = l >> 4;
 
-  // which segment / tile
+  // which segment / tile; descriptors of the matrices this workgroup streams are built ONCE from scalars
   int seg = 0;
   int tile = blockIdx.x;
   if (!DUAL) {
@@ -304,141 +363,216 @@ __global__ __launch_bounds__(kNW * 64) void smallm_kernel(const SmallMParams p) 
     if (p.nseg > 2 && tile >= p.tile_begin[2]) seg = 2;
     tile -= p.tile_begin[seg];
   }
+  Rsrc rq[NQ], rs[NQ], rz[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int sg = DUAL ? q : seg;
+    rq[q] = make_rsrc(sg == 0 ? p.codes[0] : (sg == 1 ? p.codes[1] : p.codes[2]),
+                      sg == 0 ? p.codes_bytes[0] : (sg == 1 ? p.codes_bytes[1] : p.codes_bytes[2]));
+    rs[q] = make_rsrc(sg == 0 ? p.scales[0] : (sg == 1 ? p.scales[1] : p.scales[2]),
+                      sg == 0 ? p.scales_bytes[0] : (sg == 1 ? p.scales_bytes[1] : p.scales_bytes[2]));
+    rz[q] = make_rsrc(sg == 0 ? p.zps[0] : (sg == 1 ? p.zps[1] : p.zps[2]),
+                      sg == 0 ? p.zps_bytes[0] : (sg == 1 ? p.zps_bytes[1] : p.zps_bytes[2]));
+  }
+  const uint32_t voff_q = l * 16, voff_s = nn * SBYTES, voff_z = nn * SPS;  // the only per-lane address parts
+  const uint32_t tile_q = uint32_t(tile) * p.ksteps * 1024u;                // + s * 1024
+  const uint32_t tile_c = uint32_t(tile) * p.srows * 16u;                   // (+ srow * 16) * SBYTES / SPS
+  const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
   const int rows = min(p.m, 16 * MB);
   const int chunk_k = p.chunk_steps * KSTEP;
   const int row_stride = chunk_k + 8;  // halves; +16 B keeps 16-B alignment and skews banks
 
-  floatx4 acc[NACC][MB];
+  floatx4 acc[NQ][MB];
 #pragma unroll
-  for (int q = 0; q < NACC; q++)
+  for (int q = 0; q < NQ; q++)
 #pragma unroll
     for (int mb = 0; mb < MB; mb++) acc[q][mb] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // A-fragment rows of this lane (clamped: rows >= m produce discarded output rows)
-  int arow[MB];
+  // A-fragment LDS offsets of this lane (rows >= m are clamped: their output rows are discarded)
+  int aoff[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; mb++) arow[mb] = min(mb * 16 + nn, rows - 1);
+  for (int mb = 0; mb < MB; mb++) aoff[mb] = min(mb * 16 + nn, rows - 1) * row_stride + 8 * g;
 
-  const size_t tile_q_off = size_t(tile) * p.ksteps * 64 + l;  // uint4 units; + s * 64
-  const size_t tile_c_off = size_t(tile) * p.srows;            // scale-row units
+  // ring of kPF in-flight items; item t of a wave = (k-step ordinal t / NQ, matrix t % NQ); slot i always holds
+  // matrix i % NQ, so every register index below is a compile-time constant
+  uint4v qv[kPF];
+  Corr cr[kPF];
+
+  auto issue = [&](auto slot_c, int s) {
+    constexpr int slot = decltype(slot_c)::value;
+    constexpr int q = slot % NQ;
+    const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
+    qv[slot] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rq[q], voff_q, tile_q + uint32_t(s) * 1024u, 2));
+    if constexpr (kAblate & 2) {
+#pragma unroll
+      for (int i = 0; i < Corr::NW32; i++) cr[slot].s[i] = 0x3c003c00u;
+      if constexpr (ASYM) cr[slot].z[0] = 0;
+    } else {
+      const uint32_t crow = (tile_c + srow * 16u);
+      corr_issue<SPS, SK, ASYM>(rs[q], rz[q], voff_s, voff_z, crow * SBYTES, crow * SPS, cr[slot]);
+    }
+  };
+
+  auto compute = [&](auto slot_c, int s_local) {
+    constexpr int slot = decltype(slot_c)::value;
+    constexpr int q = slot % NQ;
+    if constexpr (kAblate & 1) {  // diagnostics: keep the loads alive, skip all math
+      acc[q][0][0] += __builtin_bit_cast(float, (qv[slot].x ^ qv[slot].y ^ qv[slot].z ^ qv[slot].w ^ cr[slot].s[0]) & 0x007fffffu);
+      return;
+    }
+    const _Float16* abase = a_lds + s_local * KSTEP;
+    float sc[4], zp[4];
+    corr_decode<SPS, SK, ASYM, NJ>(cr[slot], sc, zp);
+    const uint32_t xw[4] = {qv[slot].x, qv[slot].y, qv[slot].z, qv[slot].w};
+    // dequantise all slices first, then issue the MFMAs back to back (independent accumulators), then scale:
+    // no MFMA-result -> VALU stall in between
+    half8_t b[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      if constexpr (KIND == WK_INT4) {
+        const _Float16 zl = (_Float16)(-1032.f - zp[j]), zh = (_Float16)(-72.f - zp[j]);
+        b[j] = cvt_i4x8(xw[j], i4c, half2_t{zl, zl}, half2_t{zh, zh});
+      } else if constexpr (KIND == WK_INT8) {
+        const _Float16 zo = (_Float16)(-1152.f - zp[j]);
+        b[j] = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo, zo});
+      } else {
+        b[j] = cvt_f4x8(xw[j], p.lut);
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+      floatx4 dd[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const half8_t afrag = *reinterpret_cast<const half8_t*>(abase + aoff[mb] + 32 * j);
+        dd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, b[j], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[q][mb] += dd[j] * sc[j];
+    }
+  };
+
+  // compile-time slot loop helper
+#define NS_FOR_SLOTS(BODY)                                        \
+  {                                                               \
+    [&]<int... I>(std::integer_sequence<int, I...>) {             \
+      (([&] { constexpr int i = I; std::integral_constant<int, I> ic; (void)i; BODY }()), ...); \
+    }(std::make_integer_sequence<int, kPF>{});                    \
+  }
 
   for (int c0 = 0; c0 < p.ksteps; c0 += p.chunk_steps) {
     const int cend = min(c0 + p.chunk_steps, p.ksteps);
-    // ---- issue this wave's first weight loads before staging A, so HBM latency overlaps the staging ----
-    int s = c0 + w;
-    uint4 qv[NACC];
-    bool have = s < cend;
-    if (have) {
-#pragma unroll
-      for (int q = 0; q < NACC; q++)
-        qv[q] = ld_stream(p.codes[DUAL ? q : seg] + tile_q_off + size_t(s) * 64);
+    const int first = c0 + w;
+    const int nst = first < cend ? (cend - first + NW - 1) / NW : 0;  // this wave's k-steps in the chunk
+    const int nitems = nst * NQ;
+    const int sl0 = first - c0;
+    // step of item t: first + (t / NQ) * NW
+    // ---- put the wave's first kPF items in flight BEFORE staging A: nothing below depends on them until
+    //      compute(), so HBM latency overlaps the staging, the barrier and the other waves.
+    //      The common case (nitems >= kPF) issues unconditionally so the compiler knows what is outstanding ----
+    const bool full_pipe = nitems >= kPF;
+    const int quads = chunk_k >> 2;
+    if (full_pipe) {
+      NS_FOR_SLOTS({ issue(ic, first + (i / NQ) * NW); })
+    } else {
+      NS_FOR_SLOTS({ if (i < nitems) issue(ic, first + (i / NQ) * NW); })
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- stage A[:, chunk] as fp16 ----
     if (c0 > 0) __syncthreads();
-    {
-      const int kbase = c0 * KSTEP;
-      const int quads = chunk_k >> 2;
-      const bool vec_ok = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
-      for (int idx = tid; idx < rows * quads; idx += kNW * 64) {
-        const int r = idx / quads;
-        const int kq = (idx - r * quads) << 2;
-        const int gk = kbase + kq;
-        float4 v = {0.f, 0.f, 0.f, 0.f};
-        const float* src = p.a + size_t(r) * p.lda + gk;
-        if (vec_ok && gk + 3 < p.k) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (gk + 0 < p.k) v.x = src[0];
-          if (gk + 1 < p.k) v.y = src[1];
-          if (gk + 2 < p.k) v.z = src[2];
-          if (gk + 3 < p.k) v.w = src[3];
+    if constexpr (!(kAblate & 4)) {
+      {
+        const int kbase = c0 * KSTEP;
+        const bool vec_ok = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
+        for (int idx = tid; idx < rows * quads; idx += blockDim.x) {
+          const int r = idx / quads;
+          const int kq = (idx - r * quads) << 2;
+          const int gk = kbase + kq;
+          float4 v = {0.f, 0.f, 0.f, 0.f};
+          const float* src = p.a + size_t(r) * p.lda + gk;
+          if (vec_ok && gk + 3 < p.k) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (gk + 0 < p.k) v.x = src[0];
+            if (gk + 1 < p.k) v.y = src[1];
+            if (gk + 2 < p.k) v.z = src[2];
+            if (gk + 3 < p.k) v.w = src[3];
+          }
+          half2_t h0 = {(_Float16)v.x, (_Float16)v.y}, h1 = {(_Float16)v.z, (_Float16)v.w};
+          uint2 packed = {as_u32(h0), as_u32(h1)};
+          *reinterpret_cast<uint2*>(a_lds + size_t(r) * row_stride + kq) = packed;
         }
-        half2_t h0 = {(_Float16)v.x, (_Float16)v.y}, h1 = {(_Float16)v.z, (_Float16)v.w};
-        uint2 packed = {as_u32(h0), as_u32(h1)};
-        *reinterpret_cast<uint2*>(a_lds + size_t(r) * row_stride + kq) = packed;
       }
     }
     __syncthreads();
 
-    // ---- stream this wave's k-steps of the chunk ----
-    while (have) {
-      const int snext = s + kNW;
-      const bool have_next = snext < cend;
-      uint4 qn[NACC];
-      if (have_next) {
-#pragma unroll
-        for (int q = 0; q < NACC; q++)
-          qn[q] = ld_stream(p.codes[DUAL ? q : seg] + tile_q_off + size_t(snext) * 64);
+    // ---- stream: steady-state rounds consume slot i and refill it kPF items ahead with NO conditions inside, so
+    //      the compiler emits counted vmcnt waits instead of draining the queue; the last rounds are peeled ----
+    const int rounds = nitems / kPF, rem = nitems - rounds * kPF;
+    constexpr int SPR = kPF / NQ;  // k-steps per round
+    if (full_pipe) {
+      int r = 0;
+      for (; r + 1 < rounds; r++) {
+        NS_FOR_SLOTS({
+          // pin the order consume-slot -> refill-slot: hipcc otherwise sinks all refills to the end of the round
+          compute(ic, sl0 + (r * SPR + i / NQ) * NW);
+          __builtin_amdgcn_sched_barrier(0);
+          issue(ic, first + ((r + 1) * SPR + i / NQ) * NW);
+          __builtin_amdgcn_sched_barrier(0);
+        })
       }
-      const int srow = (s * p.srow_shift_num) / p.srow_shift_den;
-      const size_t cidx = ((tile_c_off + srow) * 16 + nn) * SPS;
-      const _Float16* abase = a_lds + (s - c0) * KSTEP + 8 * g;
-#pragma unroll
-      for (int q = 0; q < NACC; q++) {
-        float sc[4];
-        int zp[4];
-        load_corr<SPS, NJ>(p, DUAL ? q : seg, cidx, sc, zp);
-        const uint32_t xw[4] = {qv[q].x, qv[q].y, qv[q].z, qv[q].w};
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          half8_t b;
-          if constexpr (KIND == WK_INT4) {
-            const _Float16 zl = (_Float16)(-(1032.f + float(zp[j]))), zh = (_Float16)(-(72.f + float(zp[j])));
-            b = cvt_i4x8(xw[j], half2_t{zl, zl}, half2_t{zh, zh});
-          } else if constexpr (KIND == WK_INT8) {
-            const _Float16 zo = (_Float16)(-(1152.f + float(zp[j])));
-            b = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo, zo});
-          } else {
-            b = cvt_f4x8(xw[j], p.lut);
-          }
-#pragma unroll
-          for (int mb = 0; mb < MB; mb++) {
-            const half8_t afrag =
-                *reinterpret_cast<const half8_t*>(abase + size_t(arow[mb]) * row_stride + 32 * j);
-            const floatx4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, b, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            acc[q][mb] += dd * sc[j];
-          }
-        }
-      }
-      s = snext;
-      have = have_next;
-#pragma unroll
-      for (int q = 0; q < NACC; q++) qv[q] = qn[q];
+      // last full round: refill only what the remainder needs
+      NS_FOR_SLOTS({
+        compute(ic, sl0 + (r * SPR + i / NQ) * NW);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < rem) issue(ic, first + ((r + 1) * SPR + i / NQ) * NW);
+        __builtin_amdgcn_sched_barrier(0);
+      })
+      r++;
+      NS_FOR_SLOTS({
+        if (i < rem) compute(ic, sl0 + (r * SPR + i / NQ) * NW);
+        __builtin_amdgcn_sched_barrier(0);
+      })
+    } else {
+      NS_FOR_SLOTS({
+        if (i < nitems) compute(ic, sl0 + (i / NQ) * NW);
+        __builtin_amdgcn_sched_barrier(0);
+      })
     }
   }
+#undef NS_FOR_SLOTS
 
   // ---- cross-wave reduction through LDS, then epilogue ----
   __syncthreads();
-  floatx4* red = reinterpret_cast<floatx4*>(smem);  // [kNW][NACC][MB][64]
+  floatx4* red = reinterpret_cast<floatx4*>(smem);  // [NW][NQ][MB][64]
 #pragma unroll
-  for (int q = 0; q < NACC; q++)
+  for (int q = 0; q < NQ; q++)
 #pragma unroll
-    for (int mb = 0; mb < MB; mb++) red[((w * NACC + q) * MB + mb) * 64 + l] = acc[q][mb];
+    for (int mb = 0; mb < MB; mb++) red[((w * NQ + q) * MB + mb) * 64 + l] = acc[q][mb];
   __syncthreads();
   if (w < MB) {
     const int mb = w;
-    floatx4 sum[NACC];
+    floatx4 sum[NQ];
 #pragma unroll
-    for (int q = 0; q < NACC; q++) {
+    for (int q = 0; q < NQ; q++) {
       sum[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ww = 0; ww < kNW; ww++) sum[q] += red[((ww * NACC + q) * MB + mb) * 64 + l];
+      for (int ww = 0; ww < NW; ww++) sum[q] += red[((ww * NQ + q) * MB + mb) * 64 + l];
     }
     const int col = tile * 16 + nn;
     const int ncols = p.n[DUAL ? 0 : seg];
     if (col < ncols) {
       float* cbase = p.c[DUAL ? 0 : seg];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = mb * 16 + 4 * g + r;
+      for (int rr = 0; rr < 4; rr++) {
+        const int row = mb * 16 + 4 * g + rr;
         if (row >= p.m) continue;
-        float v = sum[0][r];
+        float v = sum[0][rr];
         if constexpr (DUAL) {
           // tmp1 = act(A*W1) ; tmp2 = (A*W3) * tmp1   (ip_fusion_ffn.cpp:364-406)
           const float t1 = (p.epilogue == 5) ? epi_silu(v) : epi_gelu(v);
           if (p.c2) p.c2[size_t(row) * p.ldc + col] = t1;
-          v = sum[1][r] * t1;
+          v = sum[1][rr] * t1;
         } else {
           const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
           switch (p.epilogue) {
@@ -464,21 +598,37 @@ bool smallm_supported(const ns_weight* w, int m) {
   return w->blocksize % kstep == 0 || w->blocksize >= w->k;
 }
 
-template <int KIND, int SPS, int MB>
-static hipError_t launch_smallm_t(const SmallMParams& p, bool dual, int grid, size_t lds, hipStream_t st) {
-  if (dual)
-    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, MB, true>), dim3(grid), dim3(kNW * 64), lds, st, p);
+template <int KIND, int SPS, int SK, bool ASYM>
+static hipError_t launch_smallm_k(const SmallMParams& p, bool dual, int mb, int grid, int nw, size_t lds,
+                                  hipStream_t st) {
+  const dim3 g(grid), b(nw * 64);
+  if (dual && mb == 1)
+    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, 1, true, SK, ASYM>), g, b, lds, st, p);
+  else if (mb == 1)
+    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, 1, false, SK, ASYM>), g, b, lds, st, p);
+  else if (mb == 2)
+    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, 2, false, SK, ASYM>), g, b, lds, st, p);
   else
-    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, MB, false>), dim3(grid), dim3(kNW * 64), lds, st, p);
+    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, 4, false, SK, ASYM>), g, b, lds, st, p);
   return hipGetLastError();
 }
-template <int KIND, int SPS>
-static hipError_t launch_smallm_mb(const SmallMParams& p, bool dual, int mb, int grid, size_t lds, hipStream_t st) {
-  switch (mb) {
-    case 1: return launch_smallm_t<KIND, SPS, 1>(p, dual, grid, lds, st);
-    case 2: return launch_smallm_t<KIND, SPS, 2>(p, dual, grid, lds, st);
-    default: return launch_smallm_t<KIND, SPS, 4>(p, dual, grid, lds, st);
+template <int KIND, int SPS, int SK>
+static hipError_t launch_smallm_a(const SmallMParams& p, bool asym, bool dual, int mb, int grid, int nw, size_t lds,
+                                  hipStream_t st) {
+  if constexpr (KIND == WK_F4) {
+    (void)asym;
+    return launch_smallm_k<KIND, SPS, SK, false>(p, dual, mb, grid, nw, lds, st);
+  } else {
+    if (asym) return launch_smallm_k<KIND, SPS, SK, true>(p, dual, mb, grid, nw, lds, st);
+    return launch_smallm_k<KIND, SPS, SK, false>(p, dual, mb, grid, nw, lds, st);
   }
+}
+template <int KIND, int SPS>
+static hipError_t launch_smallm_s(const SmallMParams& p, bool asym, bool dual, int mb, int grid, int nw, size_t lds,
+                                  hipStream_t st) {
+  if (p.scale_dt == DT_F32) return launch_smallm_a<KIND, SPS, SK_F32>(p, asym, dual, mb, grid, nw, lds, st);
+  if (p.scale_dt == DT_F16) return launch_smallm_a<KIND, SPS, SK_F16>(p, asym, dual, mb, grid, nw, lds, st);
+  return launch_smallm_a<KIND, SPS, SK_BF16>(p, asym, dual, mb, grid, nw, lds, st);
 }
 
 static void f4_lut_planes(const _Float16* lut, F4Lut* out) {
@@ -491,6 +641,9 @@ static void f4_lut_planes(const _Float16* lut, F4Lut* out) {
 }
 
 static void srow_rule(const ns_weight* w, int* num, int* den);
+
+// dual (gate/up) launches need MB == 1; callers split larger M into the unfused path
+bool smallm_dual_ok(int m) { return m <= 16; }
 
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   const ns_weight* w0 = a.seg[0].w;
@@ -510,47 +663,83 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
     p.codes[i] = w->codes;
     p.scales[i] = w->scales;
     p.zps[i] = w->zps;
+    p.codes_bytes[i] = uint32_t(w->codes_bytes);
+    p.scales_bytes[i] = uint32_t(w->scales_bytes);
+    p.zps_bytes[i] = uint32_t(w->zps_bytes);
+    if (w->codes_bytes >= (size_t(1) << 32)) return hipErrorInvalidValue;
     p.c[i] = a.seg[i].c;
     p.n[i] = w->n;
   }
   p.tile_begin[a.nseg] = tiles;
   p.ldc = a.ldc;
   p.scale_dt = w0->scale_dt;
-  p.asym = w0->asym;
   p.srows = w0->srows;
-  srow_rule(w0, &p.srow_shift_num, &p.srow_shift_den);
+  {
+    int num, den;
+    srow_rule(w0, &num, &den);
+    if (num == 0) {  // one scale row for the whole K
+      p.srow_mul = 0;
+      p.srow_shift = 0;
+    } else if (num == den) {
+      p.srow_mul = 1;
+      p.srow_shift = 0;
+    } else {  // srow = s / ratio, ratio = blocksize / kstep_len: power of two -> shift, else a verified magic multiply
+      const int ratio = den / num;
+      if ((ratio & (ratio - 1)) == 0) {
+        p.srow_mul = 1;
+        p.srow_shift = __builtin_ctz(ratio);
+      } else {
+        p.srow_shift = 20;
+        p.srow_mul = ((1 << 20) + ratio - 1) / ratio;
+        for (int s = 0; s < w0->ksteps; s++)
+          if (((s * p.srow_mul) >> 20) != s / ratio) return hipErrorInvalidValue;
+      }
+    }
+  }
   p.epilogue = a.epilogue;
   p.d = a.d;
   p.ldd = a.ldd;
   p.c2 = a.c2;
   if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
+  static const int env_nw = getenv("NS_NW") ? atoi(getenv("NS_NW")) : 0;  // diagnostics: waves per workgroup
 
   const int mb = a.m <= 16 ? 1 : (a.m <= 32 ? 2 : 4);
+  if (a.dual && mb != 1) return hipErrorInvalidValue;
   const int rows = a.m < 16 * mb ? a.m : 16 * mb;
+  const int grid = a.dual ? w0->ntiles : tiles;
+  // waves per workgroup: every wave runs a kPF-deep load ring, so what matters is (a) enough waves on the chip to
+  // cover bandwidth x latency (~3-4k waves) and (b) as many k-steps per wave as possible so that dequant/MFMA of one
+  // step overlaps the loads of the next ones.  Measured on MI355X (profiles/r01*): many tiles -> few waves each.
+  int nw = 8;
+  if (mb == 1) {
+    const int target_waves = 2560;
+    nw = 16;
+    while (nw > 2 && grid * (nw / 2) >= target_waves) nw /= 2;
+    while (nw > 2 && w0->ksteps * (a.dual ? 2 : 1) < nw * kPF) nw /= 2;  // keep the ring full
+  }
+  if (env_nw == 8 || env_nw == 4 || env_nw == 2 || (env_nw == 16 && mb == 1)) nw = env_nw;
   // LDS: A chunk (rows x (chunk_k + 8) halves), at most ~64 KiB; and the reduction scratch
   const int kstep = w0->kstep_len;
-  int chunk_steps = w0->ksteps;
+  int chunk_steps = ((w0->ksteps + nw - 1) / nw) * nw;
   const size_t budget = 64 * 1024;
-  while (size_t(rows) * (size_t(chunk_steps) * kstep + 8) * 2 > budget && chunk_steps > kNW) {
-    chunk_steps = ((chunk_steps / 2 + kNW - 1) / kNW) * kNW;
-  }
+  while (size_t(rows) * (size_t(chunk_steps) * kstep + 8) * 2 > budget && chunk_steps > nw)
+    chunk_steps = ((chunk_steps / 2 + nw - 1) / nw) * nw;
   p.chunk_steps = chunk_steps;
   size_t lds = size_t(rows) * (size_t(chunk_steps) * kstep + 8) * 2;
-  const size_t red = size_t(kNW) * (a.dual ? 2 : 1) * mb * 64 * 16;
+  const size_t red = size_t(nw) * (a.dual ? 2 : 1) * mb * 64 * 16;
   if (red > lds) lds = red;
-  const int grid = a.dual ? w0->ntiles : tiles;
 
-#define NS_DISPATCH(KIND)                                                                   \
-  switch (w0->sps) {                                                                        \
-    case 4: return launch_smallm_mb<KIND, 4>(p, a.dual, mb, grid, lds, st);                 \
-    case 2: return launch_smallm_mb<KIND, 2>(p, a.dual, mb, grid, lds, st);                 \
-    default: return launch_smallm_mb<KIND, 1>(p, a.dual, mb, grid, lds, st);                \
+#define NS_DISPATCH(KIND)                                                                     \
+  switch (w0->sps) {                                                                          \
+    case 4: return launch_smallm_s<KIND, 4>(p, w0->asym, a.dual, mb, grid, nw, lds, st);      \
+    case 2: return launch_smallm_s<KIND, 2>(p, w0->asym, a.dual, mb, grid, nw, lds, st);      \
+    default: return launch_smallm_s<KIND, 1>(p, w0->asym, a.dual, mb, grid, nw, lds, st);     \
   }
   if (w0->kind == WK_INT4) {
     NS_DISPATCH(WK_INT4)
   } else if (w0->kind == WK_INT8) {
-    if (w0->sps == 2) return launch_smallm_mb<WK_INT8, 2>(p, a.dual, mb, grid, lds, st);
-    return launch_smallm_mb<WK_INT8, 1>(p, a.dual, mb, grid, lds, st);
+    if (w0->sps == 2) return launch_smallm_s<WK_INT8, 2>(p, w0->asym, a.dual, mb, grid, nw, lds, st);
+    return launch_smallm_s<WK_INT8, 1>(p, w0->asym, a.dual, mb, grid, nw, lds, st);
   } else {
     NS_DISPATCH(WK_F4)
   }
