@@ -167,10 +167,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl")  # = RCCL on ROCm
     pkg = ge.load_package()
+    from neural_speed_amd import parallel as par  # the replacement of parallel_context.{h,cpp}
+    par.init_parallel_context("nccl" if world > 1 else None)  # "nccl" = RCCL over xGMI on ROCm
     chain = Chain(pkg, args.layers, rank, world, keep_host_layer=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     # the chain object itself carries the captured stream handle; under graph capture torch switches the current
     # stream, so the stream pointer handed to the C ABI must be re-read inside the capture.

@@ -139,6 +139,13 @@ ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream);
  * blobs packed by this library at 64-byte aligned bases use 0) */
 ns_weight* ns_hip_weight_from_device_blob(const void* dev_blob, size_t blob_bytes, void* stream);
 void ns_hip_weight_free(ns_weight* w);
+/* Tensor-parallel shard producer (the reference's bestla_split_weight, models/model_utils/model_files.h:1538-1563,
+ * split rules :145-190): returns a NEW device weight holding columns [n0, n1) x rows [k0, k1) of `w`.
+ * Unlike the reference (dequantize -> slice -> re-quantize) the quantized codes/scales are sliced directly, so the
+ * shards are bit-identical to the unsharded quantization.  n0 must be a multiple of 16 and k0 a multiple of
+ * lcm(128 (64 for 8-bit), group size); the reference's re-quantizing behaviour is available on the host path via
+ * bestla_unpackweight_fp32 + bestla_packweight_copyattr. */
+ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k1, void* stream);
 int ns_hip_weight_info(const ns_weight* w, int* n, int* k, int* bits, int* blocksize, uint64_t* device_bytes);
 /* algorithmic bytes one forward over this weight streams: packed codes + scales (+ zero points), i.e.
  * N*K*bits/8 + N*(K/g)*sizeof(scale) [+ N*(K/g)] — the reference benchmark's formula (ut/bestla_benchmark.cpp:583-586) */

@@ -59,6 +59,8 @@ def lib():
         L.ns_hip_weight_from_device_blob.restype = vp
         L.ns_hip_weight_from_device_blob.argtypes = [vp, sz, vp]
         L.ns_hip_cache_clear.restype = None
+        L.ns_hip_weight_slice.restype = vp
+        L.ns_hip_weight_slice.argtypes = [vp, i, i, i, i, vp]
         L.ns_hip_weight_free.argtypes = [vp]
         L.ns_hip_weight_free.restype = None
         L.ns_hip_weight_stream_bytes.restype = C.c_uint64
@@ -150,6 +152,10 @@ class Weight:
     @classmethod
     def from_device_blob(cls, dev_ptr, nbytes, stream=None):
         return cls(lib().ns_hip_weight_from_device_blob(dev_ptr, nbytes, stream))
+
+    def slice(self, n0, n1, k0, k1, stream=None):
+        """tensor-parallel shard: columns [n0, n1) x rows [k0, k1), quantization preserved bit for bit"""
+        return Weight(lib().ns_hip_weight_slice(self.h, n0, n1, k0, k1, stream))
 
     def free(self):
         if self.h:

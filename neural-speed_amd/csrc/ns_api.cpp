@@ -124,7 +124,10 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
   w->ntiles = (v.n + 15) / 16;
   w->ksteps = (v.k + w->kstep_len - 1) / w->kstep_len;
   const int bs = v.blocksize;
-  if (bs < w->kstep_len) {
+  if (bs >= v.k) {  // per-channel (the reference stores blocksize = KPad): one scale row
+    w->sps = 1;
+    w->srows = 1;
+  } else if (bs < w->kstep_len) {
     if (bs % 32 != 0 || w->kstep_len % bs != 0) {
       set_error("group size must be a multiple of 32 (and divide 128) for the MI355X kernels");
       return false;
@@ -134,9 +137,6 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
   } else if (bs == w->kstep_len) {
     w->sps = 1;
     w->srows = w->ksteps;
-  } else if (bs >= v.k) {
-    w->sps = 1;
-    w->srows = 1;
   } else if (bs % w->kstep_len == 0) {
     w->sps = 1;
     w->srows = (v.k + bs - 1) / bs;
@@ -372,6 +372,74 @@ ns_weight* ns_hip_weight_from_device_blob(const void* dev_blob, size_t blob_byte
   ns_weight* w = weight_from_device_sections(v, base + v.q_off, base + v.s_off,
                                              v.asym() ? (const int8_t*)(base + v.z_off) : nullptr, st);
   return w;
+}
+
+ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k1, void* stream) {
+  if (!have_device()) return nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (!w || n0 < 0 || n1 > w->n || n0 >= n1 || k0 < 0 || k1 > w->k || k0 >= k1) {
+    set_error("slice: range outside the weight");
+    return nullptr;
+  }
+  const int ks = w->kstep_len, bs = w->blocksize;
+  const bool per_channel = bs >= w->k;
+  if (n0 % 16 != 0 || k0 % ks != 0 || (k1 % ks != 0 && k1 != w->k) ||
+      (!per_channel && (k0 % bs != 0 || (k1 % bs != 0 && k1 != w->k)))) {
+    set_error("slice: n0 must be a multiple of 16, k0/k1 multiples of the k-step and of the group size");
+    return nullptr;
+  }
+  ns_weight* o = new ns_weight(*w);
+  o->codes = nullptr;
+  o->scales = nullptr;
+  o->zps = nullptr;
+  o->n = n1 - n0;
+  o->k = k1 - k0;
+  o->ntiles = (o->n + 15) / 16;
+  o->ksteps = (o->k + ks - 1) / ks;
+  const int t0 = n0 / 16, s0 = k0 / ks;
+  int r0;  // first scale row
+  if (w->sps > 1 || bs == ks) {
+    o->srows = o->ksteps;
+    r0 = s0;
+  } else if (per_channel) {
+    o->srows = 1;
+    r0 = 0;
+    o->blocksize = bs;  // stays "whole K": kernels only test blocksize >= k
+  } else {
+    o->srows = (o->k + bs - 1) / bs;
+    r0 = k0 / bs;
+  }
+  const int sbytes = dt_bits(w->scale_dt) / 8;
+  o->codes_bytes = size_t(o->ntiles) * o->ksteps * 1024;
+  o->scales_bytes = size_t(o->ntiles) * o->srows * 16 * o->sps * sbytes;
+  o->zps_bytes = o->asym ? size_t(o->ntiles) * o->srows * 16 * o->sps : 0;
+  const uint64_t nblk = per_channel ? 1 : (uint64_t(o->k) + bs - 1) / bs;
+  o->stream_bytes = uint64_t(o->n) * o->k * dt_bits(o->qtype) / 8 + uint64_t(o->n) * nblk * sbytes +
+                    (o->asym ? uint64_t(o->n) * nblk : 0);
+  if (!alloc_weight(o)) {
+    ns_hip_weight_free(o);
+    return nullptr;
+  }
+  // every array is [tile][row][...]: one strided 2-D copy per array (rows = tiles)
+  bool ok = hip_ok(hipMemcpy2DAsync(o->codes, size_t(o->ksteps) * 1024,
+                                    reinterpret_cast<const uint8_t*>(w->codes) + (size_t(t0) * w->ksteps + s0) * 1024,
+                                    size_t(w->ksteps) * 1024, size_t(o->ksteps) * 1024, o->ntiles,
+                                    hipMemcpyDeviceToDevice, st), "slice codes");
+  const size_t srow_b = size_t(16) * w->sps * sbytes, zrow_b = size_t(16) * w->sps;
+  ok = ok && hip_ok(hipMemcpy2DAsync(o->scales, o->srows * srow_b,
+                                     static_cast<const uint8_t*>(w->scales) + (size_t(t0) * w->srows + r0) * srow_b,
+                                     w->srows * srow_b, o->srows * srow_b, o->ntiles, hipMemcpyDeviceToDevice, st),
+                    "slice scales");
+  if (o->asym)
+    ok = ok && hip_ok(hipMemcpy2DAsync(o->zps, o->srows * zrow_b,
+                                       reinterpret_cast<const uint8_t*>(w->zps) + (size_t(t0) * w->srows + r0) * zrow_b,
+                                       w->srows * zrow_b, o->srows * zrow_b, o->ntiles, hipMemcpyDeviceToDevice, st),
+                      "slice zps");
+  if (!ok) {
+    ns_hip_weight_free(o);
+    return nullptr;
+  }
+  return o;
 }
 
 void ns_hip_weight_free(ns_weight* w) {

@@ -593,9 +593,10 @@ __global__ __launch_bounds__((MB == 1) ? kMaxNW * 64 : 512, (MB == 1) ? (DUAL ? 
 bool smallm_supported(const ns_weight* w, int m) {
   (void)m;
   const int kstep = w->kstep_len;
-  if (w->blocksize % 32 != 0 && w->blocksize < w->k) return false;
+  if (w->blocksize >= w->k) return true;
+  if (w->blocksize % 32 != 0) return false;
   if (w->blocksize < kstep) return kstep % w->blocksize == 0;
-  return w->blocksize % kstep == 0 || w->blocksize >= w->k;
+  return w->blocksize % kstep == 0;
 }
 
 template <int KIND, int SPS, int SK, bool ASYM>
@@ -781,11 +782,11 @@ __global__ void unpack_kernel(const uint32_t* __restrict__ codes, const void* __
 }
 
 static void srow_rule(const ns_weight* w, int* num, int* den) {
-  if (w->sps > 1 || w->blocksize == w->kstep_len) {
-    *num = 1;
-    *den = 1;
-  } else if (w->blocksize >= w->k) {
+  if (w->blocksize >= w->k) {
     *num = 0;
+    *den = 1;
+  } else if (w->sps > 1 || w->blocksize == w->kstep_len) {
+    *num = 1;
     *den = 1;
   } else {
     *num = w->kstep_len;

@@ -1,0 +1,136 @@
+"""Tensor-parallel communication layer: the MI355X replacement of neural-speed's `parallel_class`
+(/root/reference/neural_speed/core/parallel_context.{h,cpp}, shared_memory_ccl.hpp).
+
+The reference bootstraps oneCCL over MPI, one process per CPU socket, and exposes eight functions
+(parallel_context.h:40-47): init_parallel_context, get_tp_size, get_tp_rank, is_master, barrier, broadcast,
+alltoall, reduce_add.  Here it is one process per GPU under torch.distributed — backend "nccl" IS RCCL on ROCm, i.e.
+all-reduce over the xGMI mesh — and "gloo" on CPU for the multi-process tests.  Same names, same argument meaning:
+buffers are fp32 tensors reduced/broadcast IN PLACE (ne_layers.c:5466-5476 does the same on dst->data).
+
+Split rules for Llama-family weights (model_files.h:145-190): wq/wk/wv/w1/w3 are split along N (TENSOR_1D_ROW),
+wo/w2 along K (TENSOR_1D_COLUMN) and followed by one all-reduce; everything else is replicated.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+TENSOR_NO_CHANGE, TENSOR_1D_ROW, TENSOR_1D_COLUMN = 0, 1, 2
+
+_ROW_KEYS = ("attention.wq.weight", "attention.wk.weight", "attention.wv.weight", "feed_forward.w1.weight",
+             "feed_forward.w3.weight", "attn.q_proj.weight", "attn.k_proj.weight", "attn.v_proj.weight",
+             "mlp.fc_in.weight", "mlp.fc_in.bias")
+_COL_KEYS = ("attention.wo.weight", "feed_forward.w2.weight", "attn.out_proj.weight", "mlp.fc_out.weight")
+
+
+def calc_split_type(name):
+    """model_load_tensor::calc_split_type (model_files.h:145-190)"""
+    if any(k in name for k in _ROW_KEYS):
+        return TENSOR_1D_ROW
+    if any(k in name for k in _COL_KEYS):
+        return TENSOR_1D_COLUMN
+    return TENSOR_NO_CHANGE
+
+
+class ParallelContext:
+    def __init__(self, backend=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend)
+
+    # parallel_context.h:40-47 ---------------------------------------------------------------------------------
+    def get_tp_size(self):
+        return self.world
+
+    def get_tp_rank(self):
+        return self.rank
+
+    def is_master(self):
+        return self.rank == 0
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def broadcast(self, buf, root=0):
+        """parallel_context.cpp:59-62: broadcast `buf` (in place) from `root`"""
+        if self.world > 1:
+            dist.broadcast(buf, src=root)
+        return buf
+
+    def alltoall(self, send, recv):
+        """declared in the reference, no caller (parallel_context.cpp:63-65)"""
+        if self.world > 1:
+            dist.all_to_all_single(recv, send)
+        else:
+            recv.copy_(send)
+        return recv
+
+    def reduce_add(self, buf):
+        """parallel_context.cpp:47-58: fp32 sum over ranks, in place"""
+        if self.world > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return buf
+
+    def shard_range(self, size, quantum=1):
+        """[begin, end) of this rank's slice of an axis of `size` split evenly (the reference requires divisibility,
+        model_files.h:1603-1680); `quantum` guards the kernel's alignment needs (16 columns / one k-step)."""
+        per = size // self.world
+        if per * self.world != size or per % quantum:
+            raise ValueError("axis %d does not split %d ways in units of %d" % (size, self.world, quantum))
+        return self.rank * per, (self.rank + 1) * per
+
+    def shard_weight(self, weight, split_type, stream=None):
+        """TP shard of a device weight (ns_hip_weight_slice): ROW -> N slice, COLUMN -> K slice."""
+        if self.world == 1 or split_type == TENSOR_NO_CHANGE:
+            return weight
+        if split_type == TENSOR_1D_ROW:
+            n0, n1 = self.shard_range(weight.n, 16)
+            return weight.slice(n0, n1, 0, weight.k, stream)
+        k0, k1 = self.shard_range(weight.k, 1)
+        return weight.slice(0, weight.n, k0, k1, stream)
+
+
+_ctx = None
+
+
+def init_parallel_context(backend=None):
+    global _ctx
+    if _ctx is None:
+        _ctx = ParallelContext(backend)
+    return _ctx
+
+
+def get_tp_size():
+    return init_parallel_context().get_tp_size()
+
+
+def get_tp_rank():
+    return init_parallel_context().get_tp_rank()
+
+
+def is_master():
+    return init_parallel_context().is_master()
+
+
+def barrier():
+    init_parallel_context().barrier()
+
+
+def broadcast(buf, root=0):
+    return init_parallel_context().broadcast(buf, root)
+
+
+def alltoall(send, recv):
+    return init_parallel_context().alltoall(send, recv)
+
+
+def reduce_add(buf):
+    return init_parallel_context().reduce_add(buf)
