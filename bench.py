@@ -224,6 +224,8 @@ def main():
         out["config"]["algorithmic_bytes_per_step_per_gpu"] = alg_bytes
         out["config"]["chain_hbm_GBps"] = round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1)
         out["roofline"] = roofline(chain, pkg)
+        if world == 1:
+            out["config"]["prefill_m2048_tflops"] = prefill_tflops(chain, pkg)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.layers)
         print(json.dumps(out))
@@ -282,6 +284,37 @@ def roofline(chain, pkg):
     }
 
 
+def prefill_tflops(chain, pkg, m=2048):
+    """second half of BASELINE.json's metric: prefill TFLOPS of one layer's GEMMs (same int4 g32 weights) at M = 2048
+    through the tiled MFMA GEMM kernel; 2*M*N*K flops per GEMM, HIP events on the launch stream."""
+    L = pkg.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lw = chain.layers[0]
+    d, ff = chain.d, chain.ffl
+    a_d = torch.randn((m, d), device="cuda", dtype=torch.float32)
+    a_ff = torch.randn((m, ff), device="cuda", dtype=torch.float32)
+    out_big = torch.empty((m, max(d, ff)), device="cuda", dtype=torch.float32)
+    gemms = [(a_d, lw[k]) for k in ("q", "k", "v", "o", "w1", "w3")] + [(a_ff, lw["w2"])]
+
+    def run():
+        for a, wt in gemms:
+            pkg.check(L.ns_hip_f32f32_forward(a.data_ptr(), wt.h, out_big.data_ptr(), m, wt.k, wt.n, pkg.EPI_NONE, None, 0, st))
+
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 5
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = sum(2.0 * m * wt.n * wt.k for _, wt in gemms)
+    return round(flops / ms / 1e9, 1)
+
+
 def cpu_baseline(chain, n_layers):
     """The oracle's sequential-fp32 GEMV port (oracle/ns_oracle.cpp nso_gemv_f32 == kernel_ref.h gemv_4bit_fp32_fp32)
     timed on this box's host cores with OpenMP over one layer's GEMMs + lm_head (bounded sample), scaled to a token."""
@@ -289,7 +322,8 @@ def cpu_baseline(chain, n_layers):
     hb = chain.host_blobs
     if not hb:
         return None
-    ncores = os.cpu_count() or 1
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncores = min(ncores, 64)  # the scalar port stops scaling long before that (85..667 column tiles per GEMV)
     rng = np.random.default_rng(7)
     blobs = {}
     for k, v in hb.items():

@@ -274,22 +274,20 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
     set_error("forward: weight format not supported");
     return -1;
   }
-  // rows are processed in panels of <= 64 by the weight-streaming kernel
-  for (int m0 = 0; m0 < m; m0 += 64) {
-    SmallMArgs a{};
-    a.a = dA + size_t(m0) * lda;
-    a.lda = lda;
-    a.m = std::min(64, m - m0);
-    a.ldc = ldc;
-    a.nseg = 1;
-    a.seg[0] = {w, dC + size_t(m0) * ldc};
-    a.epilogue = epilogue;
-    a.d = dD ? dD + size_t(m0) * ldd : nullptr;
-    a.ldd = ldd;
-    a.dual = false;
-    a.c2 = nullptr;
-    if (!hip_ok(launch_smallm(a, st), "smallm launch")) return -1;
-  }
+  // M <= 64: weight-streaming kernel (HBM-bound); larger M: tiled MFMA GEMM (weights reused across 128 rows)
+  SmallMArgs a{};
+  a.a = dA;
+  a.lda = lda;
+  a.m = m;
+  a.ldc = ldc;
+  a.nseg = 1;
+  a.seg[0] = {w, dC};
+  a.epilogue = epilogue;
+  a.d = dD;
+  a.ldd = ldd;
+  a.dual = false;
+  a.c2 = nullptr;
+  if (!hip_ok(m <= 64 ? launch_smallm(a, st) : launch_gemm(a, st), "gemm launch")) return -1;
   return 0;
 }
 

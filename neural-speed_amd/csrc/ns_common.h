@@ -120,6 +120,7 @@ struct SmallMArgs {
   float* c2;       // optional tmp1 output in dual mode
 };
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
+hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st);  // large-M tiled MFMA GEMM (single segment)
 bool smallm_supported(const ns_weight* w, int m);
 bool smallm_dual_ok(int m);  // the fused gate/up launch handles up to 16 rows
 

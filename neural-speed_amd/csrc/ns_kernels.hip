@@ -748,6 +748,281 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
 }
 
 // ============================================================================================================
+// gemm_kernel — prefill / large-M tiled MFMA GEMM: C[M][N] = A[M][K] * dequant(W)
+//
+// 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA 16x16 tiles), one
+// k-step (128 k for 4-bit, 64 for 8-bit) per iteration.  The weight tile comes straight from the streaming layout:
+// a lane's 16 B ARE the B fragments of k-slot c / column nn, so dequantised codes are written to LDS as
+// [tile][j][c][nn][8 halves] and read back as conflict-free ds_read_b128 MFMA operands.  A (fp32 at the boundary)
+// is converted to fp16 on the way into LDS.  Group scales are applied to the fp32 MFMA results (same exact
+// w = (code - zp) * scale, fp32 accumulate semantics as the decode kernel; reference kernel_ref.h:1027-1127).
+// Roofline: MFMA fp16 (2.5 PFLOP/s dense); this first version is single-buffered.
+// ============================================================================================================
+constexpr int kGemmBM = 128, kGemmTiles = 8;  // 8 column tiles of 16 = 128 columns
+
+struct GemmParams {
+  const float* a;
+  int lda, m, k, n;
+  int ksteps, ntiles;
+  const uint4* codes;
+  const void* scales;
+  const int8_t* zps;
+  uint32_t codes_bytes, scales_bytes, zps_bytes;
+  float* c;
+  int ldc;
+  int srows, srow_mul, srow_shift;
+  int epilogue;
+  const float* d;
+  int ldd;
+  F4Lut lut;
+};
+
+template <int KIND, int SPS, int SK, bool ASYM>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int NJ = (KIND == WK_INT8) ? 2 : 4;
+  constexpr int KSTEP = NJ * 32;
+  constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
+  constexpr int ASTR = KSTEP + 8;  // halves per A row in LDS (+16 B skews banks)
+  using Corr = CorrRaw<SPS, SK, ASYM>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  _Float16* a_lds = reinterpret_cast<_Float16*>(smem);                         // [128][ASTR]
+  uint4v* b_lds = reinterpret_cast<uint4v*>(smem + size_t(kGemmBM) * ASTR * 2);  // [8][NJ][4][16] x 16 B
+
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63, nn = l & 15, g = l >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int tile0 = blockIdx.x * kGemmTiles;  // first 16-column tile of this workgroup
+  const int row0 = blockIdx.y * kGemmBM;
+
+  const Rsrc rq = make_rsrc(p.codes, p.codes_bytes);
+  const Rsrc rs = make_rsrc(p.scales, p.scales_bytes);
+  const Rsrc rz = make_rsrc(p.zps, p.zps_bytes);
+  const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  for (int s = 0; s < p.ksteps; s++) {
+    const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
+    // ---- global loads of this k-step: two weight lanes per thread, the compute lanes' scales, 16 float4 of A ----
+    uint4v qv[2];
+    Corr zc[2];  // zero points ride in the CorrRaw container (scales of the staging lanes are not needed)
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int tl = w + 4 * r;  // tile of the workgroup this wave stages
+      const int tile = tile0 + tl;
+      const uint32_t soff = (uint32_t(tile) * p.ksteps + s) * 1024u;
+      qv[r] = tile < p.ntiles ? __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rq, l * 16, soff, 0))
+                              : uint4v{0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
+      if constexpr (ASYM) {
+        const uint32_t crow = uint32_t(tile) * p.srows * 16u + srow * 16u;
+        if constexpr (SPS == 4)
+          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b32(rz, nn * SPS, crow * SPS, 0);
+        else if constexpr (SPS == 2)
+          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b16(rz, nn * SPS, crow * SPS, 0);
+        else
+          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b8(rz, nn * SPS, crow * SPS, 0);
+      }
+    }
+    Corr sc_raw[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      const int tile = tile0 + wn * 4 + ni;
+      const uint32_t crow = uint32_t(tile) * p.srows * 16u + srow * 16u;
+      corr_issue<SPS, SK, false>(rs, rz, nn * SBYTES, 0, crow * SBYTES, 0, reinterpret_cast<CorrRaw<SPS, SK, false>&>(sc_raw[ni]));
+    }
+    // ---- A tile: fp32 -> fp16 -> LDS ----
+    __syncthreads();  // previous iteration's MFMAs are done with LDS
+    {
+      constexpr int QPR = KSTEP / 4;  // float4 per row
+      const bool vec_ok = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
+#pragma unroll 4
+      for (int idx = tid; idx < kGemmBM * QPR; idx += 256) {
+        const int r = idx / QPR, kq = (idx % QPR) * 4;
+        const int row = row0 + r, gk = s * KSTEP + kq;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < p.m) {
+          const float* src = p.a + size_t(row) * p.lda + gk;
+          if (vec_ok && gk + 3 < p.k) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (gk + 0 < p.k) v.x = src[0];
+            if (gk + 1 < p.k) v.y = src[1];
+            if (gk + 2 < p.k) v.z = src[2];
+            if (gk + 3 < p.k) v.w = src[3];
+          }
+        }
+        half2_t h0 = {(_Float16)v.x, (_Float16)v.y}, h1 = {(_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<uint2*>(a_lds + r * ASTR + kq) = uint2{as_u32(h0), as_u32(h1)};
+      }
+    }
+    // ---- B tile: dequantise (code - zp), exact in fp16, straight into MFMA fragment order ----
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int tl = w + 4 * r;
+      const uint32_t xw[4] = {qv[r].x, qv[r].y, qv[r].z, qv[r].w};
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        float zp = 0.f;
+        if constexpr (ASYM) zp = float(int(int8_t((zc[r].z[0] >> (8 * ((j * SPS) / NJ))) & 0xff)));
+        half8_t b;
+        if constexpr (KIND == WK_INT4) {
+          const _Float16 zl = (_Float16)(-1032.f - zp), zh = (_Float16)(-72.f - zp);
+          b = cvt_i4x8(xw[j], i4c, half2_t{zl, zl}, half2_t{zh, zh});
+        } else if constexpr (KIND == WK_INT8) {
+          const _Float16 zo = (_Float16)(-1152.f - zp);
+          b = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo, zo});
+        } else {
+          b = cvt_f4x8(xw[j], p.lut);
+        }
+        b_lds[((tl * NJ + j) * 4 + g) * 16 + nn] = __builtin_bit_cast(uint4v, b);
+      }
+    }
+    float sc[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      float zz[4];
+      corr_decode<SPS, SK, false, NJ>(reinterpret_cast<CorrRaw<SPS, SK, false>&>(sc_raw[ni]), sc[ni], zz);
+    }
+    __syncthreads();
+    // ---- MFMA: 4 x 4 tiles x NJ k-slices per wave ----
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      half8_t af[4], bf[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+        af[mi] = *reinterpret_cast<const half8_t*>(a_lds + (wm * 64 + mi * 16 + nn) * ASTR + 32 * j + 8 * g);
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+        bf[ni] = __builtin_bit_cast(half8_t, b_lds[(((wn * 4 + ni) * NJ + j) * 4 + g) * 16 + nn]);
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) {
+          const floatx4 dd = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc[mi][ni] += dd * sc[ni][j];
+        }
+    }
+  }
+  // ---- epilogue ----
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      const int col = (tile0 + wn * 4 + ni) * 16 + nn;
+      if (col >= p.n) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + wm * 64 + mi * 16 + 4 * g + r;
+        if (row >= p.m) continue;
+        float v = acc[mi][ni][r];
+        const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
+        switch (p.epilogue) {
+          case 1: v = v + dv; break;
+          case 2: v = v * dv; break;
+          case 3: v = epi_gelu(v + dv); break;
+          case 4: v = epi_gelu(v); break;
+          case 5: v = epi_silu(v); break;
+          default: break;
+        }
+        p.c[size_t(row) * p.ldc + col] = v;
+      }
+    }
+}
+
+static bool srow_params(const ns_weight* w0, int* mul, int* shift) {
+  int num, den;
+  srow_rule(w0, &num, &den);
+  if (num == 0) {
+    *mul = 0;
+    *shift = 0;
+  } else if (num == den) {
+    *mul = 1;
+    *shift = 0;
+  } else {
+    const int ratio = den / num;
+    if ((ratio & (ratio - 1)) == 0) {
+      *mul = 1;
+      *shift = __builtin_ctz(ratio);
+    } else {
+      *shift = 20;
+      *mul = ((1 << 20) + ratio - 1) / ratio;
+      for (int s = 0; s < w0->ksteps; s++)
+        if (((s * *mul) >> 20) != s / ratio) return false;
+    }
+  }
+  return true;
+}
+
+template <int KIND, int SPS, int SK>
+static hipError_t launch_gemm_k(const GemmParams& p, bool asym, dim3 grid, size_t lds, hipStream_t st) {
+  if constexpr (KIND == WK_F4) {
+    hipLaunchKernelGGL((gemm_kernel<KIND, SPS, SK, false>), grid, dim3(256), lds, st, p);
+  } else {
+    if (asym)
+      hipLaunchKernelGGL((gemm_kernel<KIND, SPS, SK, true>), grid, dim3(256), lds, st, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<KIND, SPS, SK, false>), grid, dim3(256), lds, st, p);
+  }
+  return hipGetLastError();
+}
+template <int KIND, int SPS>
+static hipError_t launch_gemm_s(const GemmParams& p, uint32_t scale_dt, bool asym, dim3 grid, size_t lds,
+                                hipStream_t st) {
+  if (scale_dt == DT_F32) return launch_gemm_k<KIND, SPS, SK_F32>(p, asym, grid, lds, st);
+  if (scale_dt == DT_F16) return launch_gemm_k<KIND, SPS, SK_F16>(p, asym, grid, lds, st);
+  return launch_gemm_k<KIND, SPS, SK_BF16>(p, asym, grid, lds, st);
+}
+
+hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st) {
+  const ns_weight* w0 = a.seg[0].w;
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.a = a.a;
+  p.lda = a.lda;
+  p.m = a.m;
+  p.k = w0->k;
+  p.n = w0->n;
+  p.ksteps = w0->ksteps;
+  p.ntiles = w0->ntiles;
+  p.codes = w0->codes;
+  p.scales = w0->scales;
+  p.zps = w0->zps;
+  p.codes_bytes = uint32_t(w0->codes_bytes);
+  p.scales_bytes = uint32_t(w0->scales_bytes);
+  p.zps_bytes = uint32_t(w0->zps_bytes);
+  p.c = a.seg[0].c;
+  p.ldc = a.ldc;
+  p.srows = w0->srows;
+  if (!srow_params(w0, &p.srow_mul, &p.srow_shift)) return hipErrorInvalidValue;
+  p.epilogue = a.epilogue;
+  p.d = a.d;
+  p.ldd = a.ldd;
+  if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
+  const int kstep = w0->kstep_len;
+  const dim3 grid((w0->ntiles + kGemmTiles - 1) / kGemmTiles, (a.m + kGemmBM - 1) / kGemmBM);
+  const size_t lds = size_t(kGemmBM) * (kstep + 8) * 2 + size_t(kGemmTiles) * kstep * 16 * 2;
+#define NS_GDISPATCH(KIND)                                                               \
+  switch (w0->sps) {                                                                     \
+    case 4: return launch_gemm_s<KIND, 4>(p, w0->scale_dt, w0->asym, grid, lds, st);     \
+    case 2: return launch_gemm_s<KIND, 2>(p, w0->scale_dt, w0->asym, grid, lds, st);     \
+    default: return launch_gemm_s<KIND, 1>(p, w0->scale_dt, w0->asym, grid, lds, st);    \
+  }
+  if (w0->kind == WK_INT4) {
+    NS_GDISPATCH(WK_INT4)
+  } else if (w0->kind == WK_INT8) {
+    if (w0->sps == 2) return launch_gemm_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, grid, lds, st);
+    return launch_gemm_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, grid, lds, st);
+  } else {
+    NS_GDISPATCH(WK_F4)
+  }
+#undef NS_GDISPATCH
+}
+
+// ============================================================================================================
 // unpack: device layout -> fp32 [K][N]   (BTLAGemmUnPackB semantics: w = (code - zp) * scale / LUT[code] * scale)
 // ============================================================================================================
 struct Lut16 {
