@@ -89,6 +89,14 @@ class Chain:
         self.attn = torch.empty((1, d), device=dev, dtype=torch.float32)
         self.t2 = torch.empty((1, self.ffl), device=dev, dtype=torch.float32)
         self.logits = torch.empty((1, V), device=dev, dtype=torch.float32)
+        # fp16 shadows of the activations (written by the producing GEMM's epilogue, read by the next GEMM's staging)
+        self.use_h = os.environ.get("NS_BENCH_NO_SHADOW", "0") != "1"
+        h = torch.float16
+        self.x0h = self.x0.to(h)
+        self.xh = torch.empty((1, d), device=dev, dtype=h)
+        self.qkvh = torch.empty((3, 1, self.dl), device=dev, dtype=h)
+        self.attnh = torch.empty((1, d), device=dev, dtype=h)
+        self.t2h = torch.empty((1, self.ffl), device=dev, dtype=h)
 
     def _make(self, n, k, seed, std, keep_host=False):
         pkg, L = self.pkg, self.L
@@ -108,22 +116,27 @@ class Chain:
     def step(self):
         L, pkg, st = self.L, self.pkg, self.st
         d = self.d
-        x_in = self.x0
+        H = self.use_h
+        p = lambda t: t.data_ptr() if H else None
+        tp_ = self.world > 1  # after an all-reduce the fp16 shadow of the summed vector is stale: fall back to fp32 A
+        x_in, x_in_h = self.x0, self.x0h
         for lw in self.layers:
-            pkg.check(L.ns_hip_fusion_qkv_forward(x_in.data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h, self.qkv.data_ptr(),
-                                                  1, d, self.dl, st))
+            pkg.check(L.ns_hip_fusion_qkv_forward_h(x_in.data_ptr(), p(x_in_h) if x_in_h is not None else None,
+                                                    lw["q"].h, lw["k"].h, lw["v"].h, self.qkv.data_ptr(), p(self.qkvh),
+                                                    1, d, self.dl, st))
             # attention itself is outside this path; its output stands in as the Q slice
-            pkg.check(L.ns_hip_f32f32_forward(self.qkv.data_ptr(), lw["o"].h, self.attn.data_ptr(), 1, self.dl, d,
-                                              pkg.EPI_NONE, None, 0, st))
-            if self.world > 1:
+            pkg.check(L.ns_hip_f32f32_forward_h(self.qkv.data_ptr(), p(self.qkvh), lw["o"].h, self.attn.data_ptr(),
+                                                None if tp_ else p(self.attnh), 1, self.dl, d, pkg.EPI_NONE, None, 0, st))
+            if tp_:
                 torch.distributed.all_reduce(self.attn)  # ne_all_reduce after attn-out (llama.cpp:590-593)
-            pkg.check(L.ns_hip_fusion_ffn3_forward(self.attn.data_ptr(), lw["w1"].h, lw["w2"].h, lw["w3"].h, None,
-                                                   self.t2.data_ptr(), self.x.data_ptr(), 1, pkg.EPI_SILU, st))
-            if self.world > 1:
+            pkg.check(L.ns_hip_fusion_ffn3_forward_h(self.attn.data_ptr(), None if tp_ else p(self.attnh), lw["w1"].h,
+                                                     lw["w2"].h, lw["w3"].h, None, self.t2.data_ptr(), p(self.t2h),
+                                                     self.x.data_ptr(), None if tp_ else p(self.xh), 1, pkg.EPI_SILU, st))
+            if tp_:
                 torch.distributed.all_reduce(self.x)  # ne_all_reduce after FFN (llama.cpp:690-694)
-            x_in = self.x
-        pkg.check(L.ns_hip_f32f32_forward(x_in.data_ptr(), self.head.h, self.logits.data_ptr(), 1, d, self.V,
-                                          pkg.EPI_NONE, None, 0, st))
+            x_in, x_in_h = self.x, (None if tp_ else self.xh)
+        pkg.check(L.ns_hip_f32f32_forward_h(x_in.data_ptr(), p(x_in_h) if x_in_h is not None else None, self.head.h,
+                                            self.logits.data_ptr(), None, 1, d, self.V, pkg.EPI_NONE, None, 0, st))
 
 
 def time_graph(fn, steps, warmup, use_graph, world):
@@ -247,8 +260,9 @@ def roofline(chain, pkg):
     def body():
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for lw in chain.layers:
-            pkg.check(L.ns_hip_fusion_ffn3_gateup(chain.x0.data_ptr(), lw["w1"].h, lw["w3"].h, None, t2.data_ptr(), 1,
-                                                  pkg.EPI_SILU, st))
+            pkg.check(L.ns_hip_fusion_ffn3_gateup_h(chain.x0.data_ptr(), chain.x0h.data_ptr() if chain.use_h else None,
+                                                    lw["w1"].h, lw["w3"].h, None, t2.data_ptr(),
+                                                    chain.t2h.data_ptr() if chain.use_h else None, 1, pkg.EPI_SILU, st))
 
     for _ in range(3):
         body()

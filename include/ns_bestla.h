@@ -178,6 +178,20 @@ int ns_hip_fusion_ffn3_gateup(const float* dA, const ns_weight* w1, const ns_wei
 int ns_hip_fusion_ffn2_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const float* dB1,
                                const float* dB2, float* dTmp1, float* dOut, int seq, bool broadcast_bias, void* stream);
 
+/* "_h" variants: the same operators with an optional fp16 SHADOW of the activations.  dA16 (may be NULL) is an fp16
+ * copy of dA with the same shape/leading dimension — the kernels compute with fp16 activations anyway, so a producer
+ * that already holds them saves the fp32->fp16 staging pass; dC16 (may be NULL) asks the epilogue to also write the
+ * fp16 copy of the fp32 output for the next GEMM.  Results are bit-identical to the plain entry points. */
+int ns_hip_f32f32_forward_h(const float* dA, const void* dA16, const ns_weight* w, float* dC, void* dC16, int m, int lda,
+                            int ldc, int epilogue, const float* dD, int ldd, void* stream);
+int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk,
+                                const ns_weight* wv, float* dC, void* dC16, int m, int lda, int ldc, void* stream);
+int ns_hip_fusion_ffn3_gateup_h(const float* dA, const void* dA16, const ns_weight* w1, const ns_weight* w3,
+                                float* dTmp1, float* dTmp2, void* dTmp2_16, int seq, int act, void* stream);
+int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_weight* w1, const ns_weight* w2,
+                                 const ns_weight* w3, float* dTmp1, float* dTmp2, void* dTmp2_16, float* dOut,
+                                 void* dOut16, int seq, int act, void* stream);
+
 /* quantize + pack entirely on the device: dW fp32 [N][K] (is_trans) or [K][N]; writes the reference-format blob
  * into dBlob (device memory, ns_BTLAGemmPackBSize bytes, 64-byte aligned) */
 int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, size_t ldb, size_t BlkSize,

@@ -69,6 +69,10 @@ def lib():
         L.ns_hip_f32f32_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
         L.ns_hip_fusion_qkv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
         L.ns_hip_fusion_ffn3_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.ns_hip_f32f32_forward_h.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, i, vp]
+        L.ns_hip_fusion_qkv_forward_h.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp]
+        L.ns_hip_fusion_ffn3_gateup_h.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.ns_hip_fusion_ffn3_forward_h.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
         L.ns_hip_fusion_ffn3_gateup.argtypes = [vp, vp, vp, vp, vp, i, i, vp]
         L.ns_hip_fusion_ffn2_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, b, vp]
         L.ns_hip_quant_pack_device.argtypes = [vp, vp, sz, sz, sz, sz, u32, u32, b, i, b, vp]

@@ -265,7 +265,7 @@ struct DevBuf {
 };
 
 int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
-                 const float* dD, int ldd, hipStream_t st) {
+                 const float* dD, int ldd, hipStream_t st, const void* dA16 = nullptr, void* dC16 = nullptr) {
   if (!w || !dA || !dC || m <= 0) {
     set_error("forward: null argument");
     return -1;
@@ -275,13 +275,18 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
     return -1;
   }
   // M <= 64: weight-streaming kernel (HBM-bound); larger M: tiled MFMA GEMM (weights reused across 128 rows)
+  if (m > 64 && dC16) {
+    set_error("forward: the fp16 output shadow is only produced on the M <= 64 path");
+    return -1;
+  }
   SmallMArgs a{};
   a.a = dA;
+  a.a16 = m <= 64 ? dA16 : nullptr;
   a.lda = lda;
   a.m = m;
   a.ldc = ldc;
   a.nseg = 1;
-  a.seg[0] = {w, dC};
+  a.seg[0] = {w, dC, dC16};
   a.epilogue = epilogue;
   a.d = dD;
   a.ldd = ldd;
@@ -468,6 +473,17 @@ int ns_hip_f32f32_forward(const float* dA, const ns_weight* w, float* dC, int m,
 
 int ns_hip_fusion_qkv_forward(const float* dA, const ns_weight* wq, const ns_weight* wk, const ns_weight* wv, float* dC,
                               int m, int lda, int ldc, void* stream) {
+  return ns_hip_fusion_qkv_forward_h(dA, nullptr, wq, wk, wv, dC, nullptr, m, lda, ldc, stream);
+}
+
+int ns_hip_f32f32_forward_h(const float* dA, const void* dA16, const ns_weight* w, float* dC, void* dC16, int m, int lda,
+                            int ldc, int epilogue, const float* dD, int ldd, void* stream) {
+  if (!have_device()) return -1;
+  return forward_impl(dA, w, dC, m, lda, ldc, epilogue, dD, ldd, (hipStream_t)stream, dA16, dC16);
+}
+
+int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk,
+                                const ns_weight* wv, float* dC, void* dC16, int m, int lda, int ldc, void* stream) {
   if (!have_device()) return -1;
   if (!wq || !wk || !wv) {
     set_error("qkv: null weight");
@@ -481,22 +497,31 @@ int ns_hip_fusion_qkv_forward(const float* dA, const ns_weight* wq, const ns_wei
   hipStream_t st = (hipStream_t)stream;
   if (!same || m > 64) {  // fall back to three launches (still on the GPU)
     for (int i = 0; i < 3; i++)
-      if (forward_impl(dA, ws[i], dC + size_t(i) * m * ldc, m, lda, ldc, NS_EPI_NONE, nullptr, 0, st)) return -1;
+      if (forward_impl(dA, ws[i], dC + size_t(i) * m * ldc, m, lda, ldc, NS_EPI_NONE, nullptr, 0, st, dA16,
+                       dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr))
+        return -1;
     return 0;
   }
   SmallMArgs a{};
   a.a = dA;
+  a.a16 = dA16;
   a.lda = lda;
   a.m = m;
   a.ldc = ldc;
   a.nseg = 3;
-  for (int i = 0; i < 3; i++) a.seg[i] = {ws[i], dC + size_t(i) * m * ldc};  // ip_fusion_qkv.cpp:84-86
+  for (int i = 0; i < 3; i++)  // ip_fusion_qkv.cpp:84-86
+    a.seg[i] = {ws[i], dC + size_t(i) * m * ldc, dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr};
   a.epilogue = NS_EPI_NONE;
   return hip_ok(launch_smallm(a, st), "qkv launch") ? 0 : -1;
 }
 
 int ns_hip_fusion_ffn3_gateup(const float* dA, const ns_weight* w1, const ns_weight* w3, float* dTmp1, float* dTmp2,
                               int seq, int act, void* stream) {
+  return ns_hip_fusion_ffn3_gateup_h(dA, nullptr, w1, w3, dTmp1, dTmp2, nullptr, seq, act, stream);
+}
+
+int ns_hip_fusion_ffn3_gateup_h(const float* dA, const void* dA16, const ns_weight* w1, const ns_weight* w3,
+                                float* dTmp1, float* dTmp2, void* dTmp2_16, int seq, int act, void* stream) {
   if (!have_device()) return -1;
   if (!w1 || !w3 || !dTmp2 || !dA) {
     set_error("ffn3 gate/up: null argument");
@@ -509,12 +534,13 @@ int ns_hip_fusion_ffn3_gateup(const float* dA, const ns_weight* w1, const ns_wei
   if (same && smallm_dual_ok(seq) && smallm_supported(w1, seq)) {
     SmallMArgs a{};
     a.a = dA;
+    a.a16 = dA16;
     a.lda = fin;
     a.m = seq;
     a.ldc = fmid;
     a.nseg = 2;
-    a.seg[0] = {w1, dTmp2};
-    a.seg[1] = {w3, dTmp2};
+    a.seg[0] = {w1, dTmp2, dTmp2_16};
+    a.seg[1] = {w3, dTmp2, nullptr};
     a.epilogue = act;
     a.dual = true;
     a.c2 = dTmp1;
@@ -524,8 +550,8 @@ int ns_hip_fusion_ffn3_gateup(const float* dA, const ns_weight* w1, const ns_wei
     set_error("ffn3: tmp1 required on the unfused path");
     return -1;
   }
-  if (forward_impl(dA, w1, dTmp1, seq, fin, fmid, act, nullptr, 0, st)) return -1;
-  return forward_impl(dA, w3, dTmp2, seq, fin, fmid, NS_EPI_MUL, dTmp1, fmid, st);
+  if (forward_impl(dA, w1, dTmp1, seq, fin, fmid, act, nullptr, 0, st, dA16, nullptr)) return -1;
+  return forward_impl(dA, w3, dTmp2, seq, fin, fmid, NS_EPI_MUL, dTmp1, fmid, st, dA16, dTmp2_16);
 }
 
 int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const ns_weight* w3,
@@ -541,6 +567,18 @@ int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_we
   }
   if (ns_hip_fusion_ffn3_gateup(dA, w1, w3, dTmp1, dTmp2, seq, act, stream)) return -1;
   return forward_impl(dTmp2, w2, dOut, seq, w1->n, w2->n, NS_EPI_NONE, nullptr, 0, (hipStream_t)stream);
+}
+
+int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_weight* w1, const ns_weight* w2,
+                                 const ns_weight* w3, float* dTmp1, float* dTmp2, void* dTmp2_16, float* dOut,
+                                 void* dOut16, int seq, int act, void* stream) {
+  if (!have_device()) return -1;
+  if (!w1 || !w2 || !w3 || !dTmp2 || w2->k != w1->n) {
+    set_error("ffn3: bad argument");
+    return -1;
+  }
+  if (ns_hip_fusion_ffn3_gateup_h(dA, dA16, w1, w3, dTmp1, dTmp2, dTmp2_16, seq, act, stream)) return -1;
+  return forward_impl(dTmp2, w2, dOut, seq, w1->n, w2->n, NS_EPI_NONE, nullptr, 0, (hipStream_t)stream, dTmp2_16, dOut16);
 }
 
 int ns_hip_fusion_ffn2_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const float* dB1,

@@ -105,10 +105,12 @@ hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st);
 
 struct GemmSeg {
   const ns_weight* w;
-  float* c;  // output base of this segment
+  float* c;       // output base of this segment
+  void* c16;      // optional fp16 shadow of the output (same shape / ldc), consumed as `a16` by the next GEMM
 };
 struct SmallMArgs {
   const float* a;
+  const void* a16;  // optional fp16 copy of A (same shape / lda): skips the fp32->fp16 staging conversion
   int lda, m;
   int ldc;
   int nseg;        // 1..3 segments laid side by side in the grid (QKV); all share K and format

@@ -231,6 +231,8 @@ constexpr int kPF = NS_PF;  // k-steps each wave keeps in flight (codes + scales
 
 struct SmallMParams {
   const float* a;
+  const _Float16* a16;  // optional fp16 shadow of A
+  _Float16* c16[3];     // optional fp16 shadow of C
   int lda, m, k;
   int ksteps;       // k-steps of the weight (kpad / KSTEP)
   int chunk_steps;  // k-steps staged in LDS at a time (multiple of NW)
@@ -331,15 +333,16 @@ __device__ __forceinline__ float epi_gelu(float x) {  // kernel_ref.h:1570-1572
 }
 __device__ __forceinline__ float epi_silu(float x) { return x / (1.f + expf(-x)); }  // kernel_ref.h:1573-1575
 
-template <int KIND, int SPS, int MB, bool DUAL, int SK, bool ASYM>
+template <int KIND, int SPS, int MB, bool DUAL, int SK, bool ASYM, bool WIDE>
 #ifndef NS_WPE1
 #define NS_WPE1 4
 #endif
 #ifndef NS_WPE2
 #define NS_WPE2 4
 #endif
-__global__ __launch_bounds__((MB == 1) ? kMaxNW * 64 : 512, (MB == 1) ? (DUAL ? NS_WPE2 : NS_WPE1) : 1) void smallm_kernel(
-    const SmallMParams p) {
+// WIDE = launched with 16 waves (1024 threads): caps the kernel at 128 VGPRs; the common <= 8-wave instantiation may
+// use more registers (no spills) at 2-3 waves per SIMD, which the kPF-deep load ring makes sufficient
+__global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const SmallMParams p) {
   constexpr int NJ = (KIND == WK_INT8) ? 2 : 4;
   constexpr int KSTEP = NJ * 32;
   constexpr int NQ = DUAL ? 2 : 1;  // matrices streamed by one workgroup
@@ -473,6 +476,26 @@ __global__ __launch_bounds__((MB == 1) ? kMaxNW * 64 : 512, (MB == 1) ? (DUAL ? 
     //      The common case (nitems >= kPF) issues unconditionally so the compiler knows what is outstanding ----
     const bool full_pipe = nitems >= kPF;
     const int quads = chunk_k >> 2;
+    // fp16 shadow available and small enough to sit in two registers per thread: fetch it BEFORE the weight ring so
+    // it retires first (vmcnt is in order) and the staging + barrier complete while the weights are in flight
+    const int octs = chunk_k >> 3;  // 16-byte units per row
+    constexpr int kA16It = 4;
+    const bool a16_first = p.a16 != nullptr && rows * octs <= kA16It * int(blockDim.x) && (p.lda & 7) == 0 &&
+                           ((reinterpret_cast<uintptr_t>(p.a16) & 15) == 0);
+    uint4v a16r[kA16It];
+    if (a16_first) {
+      const Rsrc ra = make_rsrc(p.a16, uint32_t(rows) * uint32_t(p.lda) * 2u);
+#pragma unroll
+      for (int it = 0; it < kA16It; it++) {
+        const int idx = tid + it * int(blockDim.x);
+        const int r = idx / octs, ko = idx - r * octs;
+        // beyond K (tail k-step) the row's own tail or the next row would be read: mask by range below
+        const uint32_t off = (uint32_t(r) * p.lda + uint32_t(c0 * KSTEP + ko * 8)) * 2u;
+        a16r[it] = (idx < rows * octs) ? __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0))
+                                       : uint4v{0, 0, 0, 0};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (full_pipe) {
       NS_FOR_SLOTS({ issue(ic, first + (i / NQ) * NW); })
     } else {
@@ -482,7 +505,37 @@ __global__ __launch_bounds__((MB == 1) ? kMaxNW * 64 : 512, (MB == 1) ? (DUAL ? 
     // ---- stage A[:, chunk] as fp16 ----
     if (c0 > 0) __syncthreads();
     if constexpr (!(kAblate & 4)) {
-      {
+      if (a16_first) {
+#pragma unroll
+        for (int it = 0; it < kA16It; it++) {
+          const int idx = tid + it * int(blockDim.x);
+          const int r = idx / octs, ko = idx - r * octs;
+          uint4v v = a16r[it];
+          const int gk = c0 * KSTEP + ko * 8;
+          if (gk + 8 > p.k) {  // zero the part of the last unit that lies beyond K
+            uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+              if (gk + e >= p.k) vw[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+          }
+          if (idx < rows * octs) *reinterpret_cast<uint4v*>(a_lds + size_t(r) * row_stride + ko * 8) = v;
+        }
+      } else if (p.a16 != nullptr && (p.lda & 7) == 0 && ((reinterpret_cast<uintptr_t>(p.a16) & 15) == 0)) {
+        const Rsrc ra = make_rsrc(p.a16, uint32_t(rows) * uint32_t(p.lda) * 2u);
+        for (int idx = tid; idx < rows * octs; idx += blockDim.x) {
+          const int r = idx / octs, ko = idx - r * octs;
+          const int gk = c0 * KSTEP + ko * 8;
+          uint4v v = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    ra, (uint32_t(r) * p.lda + uint32_t(gk)) * 2u, 0, 0));
+          if (gk + 8 > p.k) {
+            uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+              if (gk + e >= p.k) vw[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+          }
+          *reinterpret_cast<uint4v*>(a_lds + size_t(r) * row_stride + ko * 8) = v;
+        }
+      } else {
         const int kbase = c0 * KSTEP;
         const bool vec_ok = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
         for (int idx = tid; idx < rows * quads; idx += blockDim.x) {
@@ -585,6 +638,8 @@ __global__ __launch_bounds__((MB == 1) ? kMaxNW * 64 : 512, (MB == 1) ? (DUAL ? 
           }
         }
         cbase[size_t(row) * p.ldc + col] = v;
+        _Float16* c16 = p.c16[DUAL ? 0 : seg];
+        if (c16) c16[size_t(row) * p.ldc + col] = (_Float16)v;
       }
     }
   }
@@ -603,14 +658,26 @@ template <int KIND, int SPS, int SK, bool ASYM>
 static hipError_t launch_smallm_k(const SmallMParams& p, bool dual, int mb, int grid, int nw, size_t lds,
                                   hipStream_t st) {
   const dim3 g(grid), b(nw * 64);
+#define NS_LAUNCH(MBV, DUALV)                                                                             \
+  {                                                                                                       \
+    if (nw > 8) {                                                                                         \
+      if constexpr (MBV == 1 && !DUALV)                                                                   \
+        hipLaunchKernelGGL((smallm_kernel<KIND, SPS, MBV, DUALV, SK, ASYM, true>), g, b, lds, st, p);     \
+      else                                                                                                \
+        return hipErrorInvalidValue;                                                                      \
+    } else {                                                                                              \
+      hipLaunchKernelGGL((smallm_kernel<KIND, SPS, MBV, DUALV, SK, ASYM, false>), g, b, lds, st, p);      \
+    }                                                                                                     \
+  }
   if (dual && mb == 1)
-    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, 1, true, SK, ASYM>), g, b, lds, st, p);
+    NS_LAUNCH(1, true)
   else if (mb == 1)
-    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, 1, false, SK, ASYM>), g, b, lds, st, p);
+    NS_LAUNCH(1, false)
   else if (mb == 2)
-    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, 2, false, SK, ASYM>), g, b, lds, st, p);
+    NS_LAUNCH(2, false)
   else
-    hipLaunchKernelGGL((smallm_kernel<KIND, SPS, 4, false, SK, ASYM>), g, b, lds, st, p);
+    NS_LAUNCH(4, false)
+#undef NS_LAUNCH
   return hipGetLastError();
 }
 template <int KIND, int SPS, int SK>
@@ -651,6 +718,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   SmallMParams p;
   memset(&p, 0, sizeof(p));
   p.a = a.a;
+  p.a16 = static_cast<const _Float16*>(a.a16);
   p.lda = a.lda;
   p.m = a.m;
   p.k = w0->k;
@@ -669,6 +737,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
     p.zps_bytes[i] = uint32_t(w->zps_bytes);
     if (w->codes_bytes >= (size_t(1) << 32)) return hipErrorInvalidValue;
     p.c[i] = a.seg[i].c;
+    p.c16[i] = static_cast<_Float16*>(a.seg[i].c16);
     p.n[i] = w->n;
   }
   p.tile_begin[a.nseg] = tiles;
@@ -714,7 +783,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   int nw = 8;
   if (mb == 1) {
     const int target_waves = 2560;
-    nw = 16;
+    nw = 8;  // 16-wave workgroups are capped at 128 VGPRs and spill: not used by default
     while (nw > 2 && grid * (nw / 2) >= target_waves) nw /= 2;
     while (nw > 2 && w0->ksteps * (a.dual ? 2 : 1) < nw * kPF) nw /= 2;  // keep the ring full
   }

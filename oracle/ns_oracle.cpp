@@ -737,10 +737,14 @@ int nso_gemv_f32(const float* a, int lda, const void* blob, float* c, int ldc, i
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-#pragma omp parallel for schedule(static)
+  if (m > 8 || NT > 96) return -3;
+#pragma omp parallel for schedule(dynamic, 1)
   for (int t = 0; t < ntiles; t++) {
-    std::vector<float> acc(size_t(m) * NT, 0.f), sc(NT);
-    std::vector<int> zz(NT, 0);
+    float acc[8][96], sc[96], wv[96];
+    int zz[96];
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < NT; j++) acc[i][j] = 0.f;
+    for (int j = 0; j < NT; j++) zz[j] = 0;
     const size_t tile_base = size_t(t) * NT * bi.kpad;
     for (int kb = 0; kb * bi.blocksize < bi.k; kb++) {
       for (int j = 0; j < NT; j++) {
@@ -750,22 +754,28 @@ int nso_gemv_f32(const float* a, int lda, const void* blob, float* c, int ldc, i
       const int kend = std::min(bi.k, (kb + 1) * bi.blocksize);
       for (int kk = kb * bi.blocksize; kk < kend; kk++) {
         const size_t rowoff = tile_base + size_t(kk / PR) * NT * PR + (kk % PR);
-        for (int j = 0; j < NT; j++) {
-          const size_t e = rowoff + size_t(j) * PR;
-          float wv;
-          if (nbits == 8) {
-            wv = float(int(int8_t(qb[e])) - zz[j]);
-          } else {
-            int code = (qb[e / 2] >> (4 * (e & 1))) & 0xf;
-            wv = is_int ? float(code - 8 - zz[j]) : f4_unpack(bi.dtype, code);
+        if (nbits == 8) {
+          for (int j = 0; j < NT; j++) wv[j] = float(int(int8_t(qb[rowoff + size_t(j) * PR])) - zz[j]);
+        } else if (is_int) {
+          for (int j = 0; j < NT; j++) {
+            const size_t e = rowoff + size_t(j) * PR;
+            wv[j] = float(int((qb[e >> 1] >> (4 * (e & 1))) & 0xf) - 8 - zz[j]);
           }
-          for (int i = 0; i < m; i++) acc[size_t(i) * NT + j] += a[size_t(i) * lda + kk] * wv * sc[j];
+        } else {
+          for (int j = 0; j < NT; j++) {
+            const size_t e = rowoff + size_t(j) * PR;
+            wv[j] = f4_unpack(bi.dtype, (qb[e >> 1] >> (4 * (e & 1))) & 0xf);
+          }
+        }
+        for (int i = 0; i < m; i++) {
+          const float av = a[size_t(i) * lda + kk];
+          for (int j = 0; j < NT; j++) acc[i][j] += av * wv[j] * sc[j];  // (a * w) * scale, kernel_ref.h:2517
         }
       }
     }
     for (int i = 0; i < m; i++)
       for (int j = 0; j < NT; j++)
-        if (t * NT + j < bi.n) c[size_t(i) * ldc + t * NT + j] = acc[size_t(i) * NT + j];
+        if (t * NT + j < bi.n) c[size_t(i) * ldc + t * NT + j] = acc[i][j];
   }
   return 0;
 }

@@ -464,3 +464,27 @@ def test_weight_slice_tp_shards(L, pkg, nso, qt, st, asym, bs):
     # misaligned requests are refused
     assert not L.ns_hip_weight_slice(full.h, 8, 64, 0, k, st_)
     assert not L.ns_hip_weight_slice(full.h, 0, n, 48, k, st_)
+
+
+def test_fp16_shadow_variants_are_bit_identical(L, pkg, nso):
+    """_h entry points: feeding the fp16 copy of A and asking for the fp16 copy of C must not change a single bit of C,
+    and C16 must be the RNE rounding of C."""
+    import torch
+    rng = np.random.default_rng(77)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (n, k, m) in [(256, 1024, 1), (96, 512, 3), (250, 1000, 1), (256, 4096, 1)]:
+        blob = nso.quant_pack(_w(rng, n, k), 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+        wt = pkg.Weight.from_host_blob(nso.ptr(blob))
+        a = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float32)).cuda()
+        lda = k
+        a16 = a.to(torch.float16)
+        c0 = torch.empty((m, n), dtype=torch.float32, device="cuda")
+        c1 = torch.empty_like(c0)
+        c16 = torch.empty((m, n), dtype=torch.float16, device="cuda")
+        pkg.check(L.ns_hip_f32f32_forward(a.data_ptr(), wt.h, c0.data_ptr(), m, lda, n, 0, None, 0, st))
+        a_dummy = torch.zeros_like(a) if k % 8 == 0 else a  # with a shadow the fp32 A must not be needed
+        pkg.check(L.ns_hip_f32f32_forward_h(a_dummy.data_ptr(), a16.data_ptr() if k % 8 == 0 else None, wt.h, c1.data_ptr(),
+                                            c16.data_ptr(), m, lda, n, 0, None, 0, st))
+        torch.cuda.synchronize()
+        assert torch.equal(c0, c1), (n, k, m)
+        assert torch.equal(c16, c0.to(torch.float16))
