@@ -14,6 +14,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -89,6 +90,27 @@ const float kBNB[8] = {0.f, 5.208333333e-03f, 0.66666667f, 1.f, 0.33333333f, 0.5
 const float kE2M1[8] = {0.f, 0.010416666666666666f, 0.16666666666666666f, 0.25f, 0.3333333333333333f,
                         0.5f, 0.6666666666666666f, 1.f};
 
+// sizes and strides of the device arrays from (ntiles, ksteps, srows, sps, scale dtype, asym)
+void set_strides(ns_weight* w, int force_interleave = -1) {
+  const uint32_t sbytes = dt_bits(w->scale_dt) / 8;
+  const uint32_t cb = 16u * w->sps * sbytes, zb = w->asym ? 16u * w->sps : 0u;
+  static const bool no_il = getenv("NS_NO_INTERLEAVE") != nullptr;  // diagnostics
+  w->interleaved = force_interleave >= 0 ? force_interleave != 0 : (w->srows == w->ksteps) && !no_il;
+  if (w->interleaved) {
+    w->qstride = w->sstride = w->zstride = 1024u + cb + zb;
+    w->codes_bytes = size_t(w->ntiles) * w->ksteps * w->qstride;
+    w->scales_bytes = w->codes_bytes - 1024;
+    w->zps_bytes = w->asym ? w->codes_bytes - 1024 - cb : 0;
+  } else {
+    w->qstride = 1024;
+    w->sstride = cb;
+    w->zstride = 16u * w->sps;
+    w->codes_bytes = size_t(w->ntiles) * w->ksteps * 1024;
+    w->scales_bytes = size_t(w->ntiles) * w->srows * cb;
+    w->zps_bytes = w->asym ? size_t(w->ntiles) * w->srows * 16 * w->sps : 0;
+  }
+}
+
 // Decide the device layout for a parsed blob; returns false (with error) for formats the kernels do not cover.
 bool plan_weight(const BlobView& v, ns_weight* w) {
   w->n = v.n;
@@ -145,9 +167,7 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
     return false;
   }
   const int sbytes = dt_bits(v.scale_dt) / 8;
-  w->codes_bytes = size_t(w->ntiles) * w->ksteps * 1024;
-  w->scales_bytes = size_t(w->ntiles) * w->srows * 16 * w->sps * sbytes;
-  w->zps_bytes = w->asym ? size_t(w->ntiles) * w->srows * 16 * w->sps : 0;
+  set_strides(w);
   // reference benchmark formula (ut/bestla_benchmark.cpp:583-586): packed codes + scales (+ zero points)
   const uint64_t nblk = (uint64_t(v.k) + bs - 1) / bs;
   w->stream_bytes = uint64_t(v.n) * v.k * dt_bits(v.dtype) / 8 + uint64_t(v.n) * nblk * sbytes +
@@ -157,8 +177,14 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
 
 bool alloc_weight(ns_weight* w) {
   if (!hip_ok(hipMalloc((void**)&w->codes, w->codes_bytes), "hipMalloc(codes)")) return false;
-  if (!hip_ok(hipMalloc(&w->scales, w->scales_bytes), "hipMalloc(scales)")) return false;
-  if (w->asym && !hip_ok(hipMalloc((void**)&w->zps, w->zps_bytes), "hipMalloc(zps)")) return false;
+  if (w->interleaved) {  // scales / zps live inside the record stream
+    const size_t cb = size_t(16) * w->sps * (dt_bits(w->scale_dt) / 8);
+    w->scales = reinterpret_cast<uint8_t*>(w->codes) + 1024;
+    w->zps = w->asym ? reinterpret_cast<int8_t*>(w->codes) + 1024 + cb : nullptr;
+  } else {
+    if (!hip_ok(hipMalloc(&w->scales, w->scales_bytes), "hipMalloc(scales)")) return false;
+    if (w->asym && !hip_ok(hipMalloc((void**)&w->zps, w->zps_bytes), "hipMalloc(zps)")) return false;
+  }
   hipGetDevice(&w->device);
   return true;
 }
@@ -413,9 +439,12 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
     r0 = k0 / bs;
   }
   const int sbytes = dt_bits(w->scale_dt) / 8;
-  o->codes_bytes = size_t(o->ntiles) * o->ksteps * 1024;
-  o->scales_bytes = size_t(o->ntiles) * o->srows * 16 * o->sps * sbytes;
-  o->zps_bytes = o->asym ? size_t(o->ntiles) * o->srows * 16 * o->sps : 0;
+  if (w->interleaved && o->srows != o->ksteps) {
+    set_error("slice: layout class changed");
+    delete o;
+    return nullptr;
+  }
+  set_strides(o, w->interleaved ? 1 : 0);
   const uint64_t nblk = per_channel ? 1 : (uint64_t(o->k) + bs - 1) / bs;
   o->stream_bytes = uint64_t(o->n) * o->k * dt_bits(o->qtype) / 8 + uint64_t(o->n) * nblk * sbytes +
                     (o->asym ? uint64_t(o->n) * nblk : 0);
@@ -423,21 +452,23 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
     ns_hip_weight_free(o);
     return nullptr;
   }
-  // every array is [tile][row][...]: one strided 2-D copy per array (rows = tiles)
-  bool ok = hip_ok(hipMemcpy2DAsync(o->codes, size_t(o->ksteps) * 1024,
-                                    reinterpret_cast<const uint8_t*>(w->codes) + (size_t(t0) * w->ksteps + s0) * 1024,
-                                    size_t(w->ksteps) * 1024, size_t(o->ksteps) * 1024, o->ntiles,
+  // every array is [tile][row][...]: one strided 2-D copy per array (rows = tiles); interleaved records carry
+  // their scales / zero points along
+  bool ok = hip_ok(hipMemcpy2DAsync(o->codes, size_t(o->ksteps) * o->qstride,
+                                    reinterpret_cast<const uint8_t*>(w->codes) + (size_t(t0) * w->ksteps + s0) * w->qstride,
+                                    size_t(w->ksteps) * w->qstride, size_t(o->ksteps) * o->qstride, o->ntiles,
                                     hipMemcpyDeviceToDevice, st), "slice codes");
-  const size_t srow_b = size_t(16) * w->sps * sbytes, zrow_b = size_t(16) * w->sps;
-  ok = ok && hip_ok(hipMemcpy2DAsync(o->scales, o->srows * srow_b,
-                                     static_cast<const uint8_t*>(w->scales) + (size_t(t0) * w->srows + r0) * srow_b,
-                                     w->srows * srow_b, o->srows * srow_b, o->ntiles, hipMemcpyDeviceToDevice, st),
-                    "slice scales");
-  if (o->asym)
-    ok = ok && hip_ok(hipMemcpy2DAsync(o->zps, o->srows * zrow_b,
-                                       reinterpret_cast<const uint8_t*>(w->zps) + (size_t(t0) * w->srows + r0) * zrow_b,
-                                       w->srows * zrow_b, o->srows * zrow_b, o->ntiles, hipMemcpyDeviceToDevice, st),
-                      "slice zps");
+  if (!o->interleaved) {
+    ok = ok && hip_ok(hipMemcpy2DAsync(o->scales, size_t(o->srows) * o->sstride,
+                                       static_cast<const uint8_t*>(w->scales) + (size_t(t0) * w->srows + r0) * w->sstride,
+                                       size_t(w->srows) * w->sstride, size_t(o->srows) * o->sstride, o->ntiles,
+                                       hipMemcpyDeviceToDevice, st), "slice scales");
+    if (o->asym)
+      ok = ok && hip_ok(hipMemcpy2DAsync(o->zps, size_t(o->srows) * o->zstride,
+                                         reinterpret_cast<const uint8_t*>(w->zps) + (size_t(t0) * w->srows + r0) * w->zstride,
+                                         size_t(w->srows) * w->zstride, size_t(o->srows) * o->zstride, o->ntiles,
+                                         hipMemcpyDeviceToDevice, st), "slice zps");
+  }
   if (!ok) {
     ns_hip_weight_free(o);
     return nullptr;
@@ -448,8 +479,10 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
 void ns_hip_weight_free(ns_weight* w) {
   if (!w) return;
   if (w->codes) hipFree(w->codes);
-  if (w->scales) hipFree(w->scales);
-  if (w->zps) hipFree(w->zps);
+  if (!w->interleaved) {
+    if (w->scales) hipFree(w->scales);
+    if (w->zps) hipFree(w->zps);
+  }
   delete w;
 }
 
@@ -459,7 +492,7 @@ int ns_hip_weight_info(const ns_weight* w, int* n, int* k, int* bits, int* block
   if (k) *k = w->k;
   if (bits) *bits = dt_bits(w->qtype);
   if (blocksize) *blocksize = w->blocksize;
-  if (device_bytes) *device_bytes = w->codes_bytes + w->scales_bytes + w->zps_bytes;
+  if (device_bytes) *device_bytes = w->interleaved ? w->codes_bytes : w->codes_bytes + w->scales_bytes + w->zps_bytes;
   return 0;
 }
 

@@ -87,6 +87,12 @@ struct ns_weight {
   void* scales = nullptr;
   int8_t* zps = nullptr;
   size_t codes_bytes = 0, scales_bytes = 0, zps_bytes = 0;
+  // byte strides: codes per (tile, k-step) record, scales / zps per (tile, scale row).  When every k-step has its own
+  // scale row the three arrays are INTERLEAVED into one stream of records {1024 B codes | scales | zps} (qstride ==
+  // sstride == zstride, `scales`/`zps` point inside the `codes` allocation) so that a k-step's scales sit in the same
+  // DRAM page as its codes.
+  uint32_t qstride = 1024, sstride = 0, zstride = 0;
+  bool interleaved = false;
   uint64_t stream_bytes = 0;  // algorithmic bytes (reference formula)
   int device = 0;
   _Float16 lut[16];  // f4 value table rounded to fp16: the MFMA operand (kind == WK_F4)

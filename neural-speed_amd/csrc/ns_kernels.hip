@@ -78,9 +78,9 @@ __device__ __forceinline__ int ref_stored_code(const uint8_t* img, size_t e, siz
 // ============================================================================================================
 // repack: reference blob sections -> device streaming layout (see ns_common.h ns_weight)
 // ============================================================================================================
-__global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint32_t* __restrict__ out, int n, int k,
-                                    int ntiles, int ksteps, int kind, int ref_bits, int ref_ntile, int ref_packrow,
-                                    int ref_kpad, int ref_npad) {
+__global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ out, uint32_t qstride, int n,
+                                    int k, int ntiles, int ksteps, int kind, int ref_bits, int ref_ntile,
+                                    int ref_packrow, int ref_kpad, int ref_npad) {
   // one thread per output dword
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t total = size_t(ntiles) * ksteps * 64 * 4;
@@ -114,13 +114,13 @@ __global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint32_t* _
       word |= uint32_t(u & 0xf) << nib_shift(i);
     }
   }
-  out[gid] = word;
+  *reinterpret_cast<uint32_t*>(out + ts * qstride + size_t(lane) * 16 + d * 4) = word;
 }
 
 // scales / zero points: reference [nblk][cstep] -> [ntiles][G][16][SPS]
 template <typename T>
-__global__ void repack_corr_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int ntiles, int srows,
-                                   int sps, int cstep, int ref_nblk) {
+__global__ void repack_corr_kernel(const T* __restrict__ src, uint8_t* __restrict__ dst, uint32_t rstride, int n,
+                                   int ntiles, int srows, int sps, int cstep, int ref_nblk) {
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t total = size_t(ntiles) * srows * 16 * sps;
   if (gid >= total) return;
@@ -132,27 +132,27 @@ __global__ void repack_corr_kernel(const T* __restrict__ src, T* __restrict__ ds
   const int col = t * 16 + nn;
   T v = T(0);
   if (kb < ref_nblk && col < n) v = src[size_t(kb) * cstep + col];
-  dst[gid] = v;
+  *reinterpret_cast<T*>(dst + (size_t(t) * srows + row) * rstride + (size_t(nn) * sps + sp) * sizeof(T)) = v;
 }
 
 hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st) {
   const size_t dwords = size_t(w->ntiles) * w->ksteps * 64 * 4;
   const int ref_bits = dt_bits(w->qtype);
-  hipLaunchKernelGGL(repack_codes_kernel, dim3((dwords + 255) / 256), dim3(256), 0, st, a.q, (uint32_t*)w->codes, w->n,
-                     w->k, w->ntiles, w->ksteps, w->kind, ref_bits, a.ref_ntile, a.ref_packrow, a.ref_kpad,
-                     a.ref_npad);
+  hipLaunchKernelGGL(repack_codes_kernel, dim3((dwords + 255) / 256), dim3(256), 0, st, a.q, (uint8_t*)w->codes,
+                     w->qstride, w->n, w->k, w->ntiles, w->ksteps, w->kind, ref_bits, a.ref_ntile, a.ref_packrow,
+                     a.ref_kpad, a.ref_npad);
   const size_t nsc = size_t(w->ntiles) * w->srows * 16 * w->sps;
   if (w->scale_dt == DT_F32)
     hipLaunchKernelGGL(repack_corr_kernel<uint32_t>, dim3((nsc + 255) / 256), dim3(256), 0, st,
-                       (const uint32_t*)a.scales, (uint32_t*)w->scales, w->n, w->ntiles, w->srows, w->sps, a.cstep,
-                       a.ref_nblk);
+                       (const uint32_t*)a.scales, (uint8_t*)w->scales, w->sstride, w->n, w->ntiles, w->srows, w->sps,
+                       a.cstep, a.ref_nblk);
   else
     hipLaunchKernelGGL(repack_corr_kernel<uint16_t>, dim3((nsc + 255) / 256), dim3(256), 0, st,
-                       (const uint16_t*)a.scales, (uint16_t*)w->scales, w->n, w->ntiles, w->srows, w->sps, a.cstep,
-                       a.ref_nblk);
+                       (const uint16_t*)a.scales, (uint8_t*)w->scales, w->sstride, w->n, w->ntiles, w->srows, w->sps,
+                       a.cstep, a.ref_nblk);
   if (w->asym)
-    hipLaunchKernelGGL(repack_corr_kernel<int8_t>, dim3((nsc + 255) / 256), dim3(256), 0, st, a.zps, w->zps, w->n,
-                       w->ntiles, w->srows, w->sps, a.cstep, a.ref_nblk);
+    hipLaunchKernelGGL(repack_corr_kernel<int8_t>, dim3((nsc + 255) / 256), dim3(256), 0, st, a.zps, (uint8_t*)w->zps,
+                       w->zstride, w->n, w->ntiles, w->srows, w->sps, a.cstep, a.ref_nblk);
   return hipGetLastError();
 }
 
@@ -242,6 +242,7 @@ struct SmallMParams {
   const void* scales[3];
   const int8_t* zps[3];
   uint32_t codes_bytes[3], scales_bytes[3], zps_bytes[3];  // buffer-descriptor extents (each < 4 GiB)
+  uint32_t qstride, sstride, zstride;                      // ns_weight strides (interleaved records or 3 arrays)
   float* c[3];
   int n[3];
   int ldc;
@@ -378,8 +379,8 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
                       sg == 0 ? p.zps_bytes[0] : (sg == 1 ? p.zps_bytes[1] : p.zps_bytes[2]));
   }
   const uint32_t voff_q = l * 16, voff_s = nn * SBYTES, voff_z = nn * SPS;  // the only per-lane address parts
-  const uint32_t tile_q = uint32_t(tile) * p.ksteps * 1024u;                // + s * 1024
-  const uint32_t tile_c = uint32_t(tile) * p.srows * 16u;                   // (+ srow * 16) * SBYTES / SPS
+  const uint32_t tile_q = uint32_t(tile) * p.ksteps * p.qstride;            // + s * qstride
+  const uint32_t tile_c = uint32_t(tile) * p.srows;                         // + srow, times sstride / zstride
   const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
   const int rows = min(p.m, 16 * MB);
@@ -406,14 +407,14 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
     constexpr int slot = decltype(slot_c)::value;
     constexpr int q = slot % NQ;
     const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
-    qv[slot] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rq[q], voff_q, tile_q + uint32_t(s) * 1024u, 2));
+    qv[slot] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rq[q], voff_q, tile_q + uint32_t(s) * p.qstride, 2));
     if constexpr (kAblate & 2) {
 #pragma unroll
       for (int i = 0; i < Corr::NW32; i++) cr[slot].s[i] = 0x3c003c00u;
       if constexpr (ASYM) cr[slot].z[0] = 0;
     } else {
-      const uint32_t crow = (tile_c + srow * 16u);
-      corr_issue<SPS, SK, ASYM>(rs[q], rz[q], voff_s, voff_z, crow * SBYTES, crow * SPS, cr[slot]);
+      const uint32_t crow = tile_c + srow;
+      corr_issue<SPS, SK, ASYM>(rs[q], rz[q], voff_s, voff_z, crow * p.sstride, crow * p.zstride, cr[slot]);
     }
   };
 
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
     // it retires first (vmcnt is in order) and the staging + barrier complete while the weights are in flight
     const int octs = chunk_k >> 3;  // 16-byte units per row
     constexpr int kA16It = 4;
-    const bool a16_first = p.a16 != nullptr && rows * octs <= kA16It * int(blockDim.x) && (p.lda & 7) == 0 &&
+    const bool a16_first = !WIDE && p.a16 != nullptr && rows * octs <= kA16It * int(blockDim.x) && (p.lda & 7) == 0 &&
                            ((reinterpret_cast<uintptr_t>(p.a16) & 15) == 0);
     uint4v a16r[kA16It];
     if (a16_first) {
@@ -743,6 +744,9 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   p.tile_begin[a.nseg] = tiles;
   p.ldc = a.ldc;
   p.scale_dt = w0->scale_dt;
+  p.qstride = w0->qstride;
+  p.sstride = w0->sstride;
+  p.zstride = w0->zstride;
   p.srows = w0->srows;
   {
     int num, den;
@@ -783,7 +787,8 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   int nw = 8;
   if (mb == 1) {
     const int target_waves = 2560;
-    nw = 8;  // 16-wave workgroups are capped at 128 VGPRs and spill: not used by default
+    // 16-wave workgroups (capped at 128 VGPRs) only where a long K meets few tiles (e.g. the FFN down projection)
+    nw = (grid <= 320 && w0->ksteps >= 64) ? 16 : 8;
     while (nw > 2 && grid * (nw / 2) >= target_waves) nw /= 2;
     while (nw > 2 && w0->ksteps * (a.dual ? 2 : 1) < nw * kPF) nw /= 2;  // keep the ring full
   }
@@ -837,6 +842,7 @@ struct GemmParams {
   const void* scales;
   const int8_t* zps;
   uint32_t codes_bytes, scales_bytes, zps_bytes;
+  uint32_t qstride, sstride, zstride;
   float* c;
   int ldc;
   int srows, srow_mul, srow_shift;
@@ -883,25 +889,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     for (int r = 0; r < 2; r++) {
       const int tl = w + 4 * r;  // tile of the workgroup this wave stages
       const int tile = tile0 + tl;
-      const uint32_t soff = (uint32_t(tile) * p.ksteps + s) * 1024u;
+      const uint32_t soff = (uint32_t(tile) * p.ksteps + s) * p.qstride;
       qv[r] = tile < p.ntiles ? __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rq, l * 16, soff, 0))
                               : uint4v{0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
       if constexpr (ASYM) {
-        const uint32_t crow = uint32_t(tile) * p.srows * 16u + srow * 16u;
+        const uint32_t crow = uint32_t(tile) * p.srows + srow;
         if constexpr (SPS == 4)
-          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b32(rz, nn * SPS, crow * SPS, 0);
+          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b32(rz, nn * SPS, crow * p.zstride, 0);
         else if constexpr (SPS == 2)
-          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b16(rz, nn * SPS, crow * SPS, 0);
+          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b16(rz, nn * SPS, crow * p.zstride, 0);
         else
-          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b8(rz, nn * SPS, crow * SPS, 0);
+          zc[r].z[0] = __builtin_amdgcn_raw_buffer_load_b8(rz, nn * SPS, crow * p.zstride, 0);
       }
     }
     Corr sc_raw[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ni++) {
       const int tile = tile0 + wn * 4 + ni;
-      const uint32_t crow = uint32_t(tile) * p.srows * 16u + srow * 16u;
-      corr_issue<SPS, SK, false>(rs, rz, nn * SBYTES, 0, crow * SBYTES, 0, reinterpret_cast<CorrRaw<SPS, SK, false>&>(sc_raw[ni]));
+      const uint32_t crow = uint32_t(tile) * p.srows + srow;
+      corr_issue<SPS, SK, false>(rs, rz, nn * SBYTES, 0, crow * p.sstride, 0, reinterpret_cast<CorrRaw<SPS, SK, false>&>(sc_raw[ni]));
     }
     // ---- A tile: fp32 -> fp16 -> LDS ----
     __syncthreads();  // previous iteration's MFMAs are done with LDS
@@ -1063,6 +1069,9 @@ hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st) {
   p.codes_bytes = uint32_t(w0->codes_bytes);
   p.scales_bytes = uint32_t(w0->scales_bytes);
   p.zps_bytes = uint32_t(w0->zps_bytes);
+  p.qstride = w0->qstride;
+  p.sstride = w0->sstride;
+  p.zstride = w0->zstride;
   p.c = a.seg[0].c;
   p.ldc = a.ldc;
   p.srows = w0->srows;
@@ -1097,8 +1106,9 @@ hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st) {
 struct Lut16 {
   float v[16];
 };
-__global__ void unpack_kernel(const uint32_t* __restrict__ codes, const void* __restrict__ scales,
-                              const int8_t* __restrict__ zps, float* __restrict__ out, int ld, int n, int k, int ksteps,
+__global__ void unpack_kernel(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ scales,
+                              const uint8_t* __restrict__ zps, uint32_t qstride, uint32_t sstride, uint32_t zstride,
+                              float* __restrict__ out, int ld, int n, int k, int ksteps,
                               int kind, int sps, int srows, int num, int den, uint32_t scale_dt, Lut16 lut) {
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (gid >= size_t(n) * k) return;
@@ -1108,18 +1118,20 @@ __global__ void unpack_kernel(const uint32_t* __restrict__ codes, const void* __
   const int kstep = (kind == WK_INT8) ? 64 : 128;
   const int s = kk / kstep, r = kk % kstep;
   const int j = r >> 5, c = (r >> 3) & 3, i = r & 7;
-  const size_t lane_base = ((size_t(t) * ksteps + s) * 64 + (c * 16 + nn)) * 4;
+  const uint32_t* lane_words =
+      reinterpret_cast<const uint32_t*>(codes + (size_t(t) * ksteps + s) * qstride + size_t(c * 16 + nn) * 16);
   const int nj = (kind == WK_INT8) ? 2 : 4;
   const int srow = (s * num) / den;
-  const size_t cidx = ((size_t(t) * srows + srow) * 16 + nn) * sps + (j * sps) / nj;
-  const float sc = load_scale(scales, cidx, scale_dt);
-  const int zp = zps ? zps[cidx] : 0;
+  const size_t crow = size_t(t) * srows + srow;
+  const size_t cidx = size_t(nn) * sps + (j * sps) / nj;
+  const float sc = load_scale(scales + crow * sstride, cidx, scale_dt);
+  const int zp = zps ? int(int8_t(zps[crow * zstride + cidx])) : 0;
   float v;
   if (kind == WK_INT8) {
-    const uint32_t word = codes[lane_base + 2 * j + (i >> 2)];
+    const uint32_t word = lane_words[2 * j + (i >> 2)];
     v = float(int(int8_t((word >> (8 * (i & 3))) & 0xff)) - zp);
   } else {
-    const int u = (codes[lane_base + j] >> nib_shift(i)) & 0xf;
+    const int u = (lane_words[j] >> nib_shift(i)) & 0xf;
     v = (kind == WK_INT4) ? float(u - 8 - zp) : lut.v[u];
   }
   out[size_t(kk) * ld + col] = v * sc;
@@ -1144,8 +1156,9 @@ hipError_t launch_unpack_fp32(const ns_weight* w, float* out, int ld, hipStream_
   int num, den;
   srow_rule(w, &num, &den);
   const size_t total = size_t(w->n) * w->k;
-  hipLaunchKernelGGL(unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const uint32_t*)w->codes, w->scales,
-                     w->zps, out, ld, w->n, w->k, w->ksteps, w->kind, w->sps, w->srows, num, den, w->scale_dt, lut);
+  hipLaunchKernelGGL(unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const uint8_t*)w->codes,
+                     (const uint8_t*)w->scales, (const uint8_t*)w->zps, w->qstride, w->sstride, w->zstride, out, ld, w->n,
+                     w->k, w->ksteps, w->kind, w->sps, w->srows, num, den, w->scale_dt, lut);
   return hipGetLastError();
 }
 
