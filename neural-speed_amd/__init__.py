@@ -12,7 +12,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libns_hip.so")
+LIB_PATH = os.environ.get("NS_LIB_PATH") or os.path.join(HERE, "libns_hip.so")  # NS_LIB_PATH: diagnostics builds
 
 # BTLA_DTYPE codes (reference: bestla/bestla/bestla.h:38-87)
 F32 = 32

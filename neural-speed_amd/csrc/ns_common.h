@@ -93,6 +93,14 @@ struct ns_weight {
   // DRAM page as its codes.
   uint32_t qstride = 1024, sstride = 0, zstride = 0;
   bool interleaved = false;
+  // decode_kernel's stream-K fix-up workspace (ns_decode.hip): one flag and one partial-sum record per workgroup.
+  // Owned by the weight, so two streams may run decode GEMVs concurrently as long as they use different weights.
+  uint32_t* ws_flags = nullptr;
+  float* ws_parts = nullptr;
+  // codes, scales, zps and the workspace are ONE allocation: scales = codes + s_off, zps = codes + z_off
+  uint32_t s_off = 0, z_off = 0;
+  size_t alloc_bytes = 0;
+  bool single_span = false;  // the allocation is < 4 GiB, i.e. the offsets above are usable as 32-bit soffsets
   uint64_t stream_bytes = 0;  // algorithmic bytes (reference formula)
   int device = 0;
   _Float16 lut[16];  // f4 value table rounded to fp16: the MFMA operand (kind == WK_F4)
@@ -128,6 +136,11 @@ struct SmallMArgs {
   float* c2;       // optional tmp1 output in dual mode
 };
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
+// ns_decode.hip: persistent stream-K kernel for m <= 4; hipErrorNotSupported = outside its envelope (use smallm)
+hipError_t launch_decode(const SmallMArgs& a, hipStream_t st);
+constexpr int kMaxDecodeGrid = 1024;                             // workgroups (= CUs) the fix-up workspace covers
+constexpr size_t kDecodeWsBytes = size_t(kMaxDecodeGrid) * (2 * 256 + 4);  // per weight: partials + flags
+void srow_rule(const ns_weight* w, int* num, int* den);          // scale row of k-step s = s * num / den
 hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st);  // large-M tiled MFMA GEMM (single segment)
 bool smallm_supported(const ns_weight* w, int m);
 bool smallm_dual_ok(int m);  // the fused gate/up launch handles up to 16 rows

@@ -60,6 +60,8 @@ WORKER = textwrap.dedent('''
     par.reduce_add(yr)
     assert nso.rel_l2(yr.numpy(), y_full) < 5e-2
     par.barrier()
+    # one result file per rank: the two ranks' stdout lines can interleave
+    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank" + str(rk) + ".ok"), "w").write(repr(float(err)))
     print("rank", rk, "ok", err)
 ''') % (ROOT, ROOT)
 
@@ -72,4 +74,5 @@ def test_tp2_gloo(tmp_path):
            "127.0.0.1", "--master-port", "29517", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count(" ok ") == 2, r.stdout
+    for rk in range(2):
+        assert (tmp_path / ("rank%d.ok" % rk)).exists(), r.stdout + r.stderr[-2000:]
