@@ -136,6 +136,9 @@ struct SmallMArgs {
   float* c2;       // optional tmp1 output in dual mode
 };
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
+// ns_gemm.hip: second-generation prefill GEMM; hipErrorNotSupported = use the first-generation gemm_kernel
+hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st);
+void gemm_scratch_release();  // frees the per-stream fp16 activation scratch buffers
 // ns_decode.hip: persistent stream-K kernel for m <= 4; hipErrorNotSupported = outside its envelope (use smallm)
 hipError_t launch_decode(const SmallMArgs& a, hipStream_t st);
 constexpr int kMaxDecodeGrid = 1024;                             // workgroups (= CUs) the fix-up workspace covers

@@ -1,0 +1,427 @@
+// ns_gemm.hip — prefill / large-M GEMM, second generation:  C[M][N] = A[M][K] * dequant(W)      (MFMA-bound)
+//
+// Design for MI355X (one workgroup = 256 threads = 4 waves, 256 x 128 output tile, 64-deep K chunks):
+//   * each wave owns a 128 x 64 sub-tile = 8 x 4 v_mfma_f32_16x16x32_f16 accumulators (128 AGPR/VGPRs): per 32-deep
+//     k-slice it reads 8 A and 4 B fragments from LDS for 32 MFMAs — at 64 x 64 per wave the four SIMDs of a CU ask
+//     LDS for exactly its 128 B/clk, i.e. LDS would cap the kernel at the MFMA peak with no slack
+//   * weights are dequantised ONCE per workgroup and chunk into LDS, already in MFMA B-fragment order and already
+//     multiplied by their group scale (fp16: (code - zp) is an exact small integer, the product is rounded to 11 bits,
+//     2^-12 relative, far inside the 1e-3 budget), so the inner loop is a pure MFMA accumulate chain — the first
+//     generation applied the group scale to every MFMA result with 4 VALU FMAs, as much VALU time as MFMA time
+//   * activations are fp16 in memory (caller's shadow, or one conversion pass into a per-stream scratch buffer that
+//     is zero padded to the chunk size): 16-byte global loads, no conversion in the loop
+//   * two LDS stages; the global loads of chunk c+1 are in flight while chunk c is multiplied; one barrier per chunk
+//   * workgroup id -> (row block, column block) keeps the column blocks that share an XCD's L2 together
+// Reference semantics: w = (code - zp) * scale, fp32 accumulate (bestla/bestla/kernel_ref.h:1027-1127 dequant,
+// bestla_wrapper.h LauncherBase GEMM loop); A rounded to fp16 (north_star: fp16 activations).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "ns_common.h"
+#include "ns_dev.h"
+
+namespace ns {
+
+#ifndef NS_G2_MI
+#define NS_G2_MI 4
+#endif
+#ifndef NS_G2_STAGES
+#define NS_G2_STAGES 2
+#endif
+#ifndef NS_G2_OCC
+#define NS_G2_OCC 2
+#endif
+constexpr int kG2Stages = NS_G2_STAGES;  // LDS stages (2: one barrier per chunk; 1: two barriers, more workgroups per CU)
+constexpr int kG2MI = NS_G2_MI;  // 16-row MFMA tiles per wave along M: wave tile = 16*MI x 64, workgroup = 32*MI x 128
+constexpr int kG2BM = 32 * kG2MI, kG2Tiles = 8, kG2KC = 64;  // rows x 8 column tiles (128 columns) x 64-deep chunks
+constexpr int kG2AStr = kG2KC + 8;                    // halves per A row in LDS (+16 B skews banks)
+constexpr int kG2StageBytes = kG2BM * kG2AStr * 2 + kG2Tiles * 2 * 64 * 16;
+
+struct Gemm2Params {
+  const _Float16* a16;  // [m][lda16] fp16, zero padded to a multiple of 64 columns
+  int lda16, m, k, n;
+  int nchunks;          // ceil(k / 64)
+  int ksteps, ntiles;
+  const uint4* codes;
+  const void* scales;
+  const int8_t* zps;
+  uint32_t codes_bytes, scales_bytes, zps_bytes;
+  uint32_t qstride, sstride, zstride;
+  float* c;
+  int ldc;
+  int srows, srow_mul, srow_shift;
+  int epilogue;
+  const float* d;
+  int ldd;
+  int nbn, cpx;  // column blocks; column blocks per XCD
+  F4Lut lut;
+};
+
+template <int KIND, int SPS, int SK, bool ASYM>
+__global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params p) {
+  constexpr int NJ = (KIND == WK_INT8) ? 2 : 4;   // 32-deep slices per k-step record
+  constexpr int CPS = NJ / 2;                      // 64-deep chunks per k-step
+  constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
+  using Corr = CorrRaw<SPS, SK, ASYM>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps buffer soffsets in SGPRs
+  const int l = tid & 63, nn = l & 15, g = l >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  // workgroup -> (bm, bn): consecutive ids go to consecutive XCDs, so give each XCD its own run of column blocks and
+  // let it sweep the row blocks: an XCD's L2 then holds its few column blocks' weights while A streams through once
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int bn = xcd * p.cpx + local % p.cpx, bm = local / p.cpx;
+  if (bn >= p.nbn) return;
+  const int tile0 = bn * kG2Tiles, row0 = bm * kG2BM;
+
+  const Rsrc rq = make_rsrc(p.codes, p.codes_bytes);
+  const Rsrc rs = make_rsrc(p.scales, p.scales_bytes);
+  const Rsrc rz = make_rsrc(p.zps, p.zps_bytes);
+  const Rsrc ra = make_rsrc(p.a16, uint32_t(p.m) * uint32_t(p.lda16) * 2u);  // rows >= m read as zeros
+  const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
+
+  floatx4 acc[kG2MI][4];
+#pragma unroll
+  for (int mi = 0; mi < kG2MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging registers of the NEXT chunk ----
+  uint4v areg[kG2MI];
+  uint32_t breg[2][4];  // 16 weight codes per staging lane (INT8: 16 B; 4-bit: 8 B)
+  Corr creg[2];
+
+  auto load_chunk = [&](int c) {
+    const int s = c / CPS, h = c % CPS;  // k-step record and its 64-deep half
+#pragma unroll
+    for (int it = 0; it < kG2MI; it++) {
+      const int u = tid + 256 * it, r = u >> 3, ch = u & 7;
+      const uint32_t off = (uint32_t(row0 + r) * uint32_t(p.lda16) + uint32_t(c * kG2KC + ch * 8)) * 2u;
+      areg[it] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+    }
+    const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int tile = tile0 + w + 4 * r;
+      const bool live = tile < p.ntiles;
+      const uint32_t soff = (uint32_t(tile) * p.ksteps + s) * p.qstride;
+      if constexpr (KIND == WK_INT8) {
+        const uint4v v = live ? __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rq, l * 16, soff, 0))
+                              : uint4v{0, 0, 0, 0};
+        breg[r][0] = v.x, breg[r][1] = v.y, breg[r][2] = v.z, breg[r][3] = v.w;
+      } else {
+        typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+        const uint2v v = live ? __builtin_bit_cast(uint2v, __builtin_amdgcn_raw_buffer_load_b64(rq, l * 16 + 8 * h, soff, 0))
+                              : uint2v{0x88888888u, 0x88888888u};
+        breg[r][0] = v.x, breg[r][1] = v.y;
+      }
+      const uint32_t crow = uint32_t(live ? tile : 0) * p.srows + srow;
+      corr_issue<SPS, SK, ASYM>(rs, rz, nn * SBYTES, nn * SPS, crow * p.sstride, crow * p.zstride, creg[r]);
+    }
+  };
+
+  // registers -> LDS stage: A as is; B dequantised, scaled, in MFMA B-fragment order [tile][slice][g][nn] x 16 B
+  auto store_chunk = [&](int c, unsigned char* stage) {
+    const int h = c % CPS;
+    _Float16* a_lds = reinterpret_cast<_Float16*>(stage);
+    uint4v* b_lds = reinterpret_cast<uint4v*>(stage + kG2BM * kG2AStr * 2);
+#pragma unroll
+    for (int it = 0; it < kG2MI; it++) {
+      const int u = tid + 256 * it, r = u >> 3, ch = u & 7;
+      *reinterpret_cast<uint4v*>(a_lds + r * kG2AStr + ch * 8) = areg[it];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int tl = w + 4 * r;
+      float sc[4], zp[4];
+      corr_decode<SPS, SK, ASYM, NJ>(creg[r], sc, zp);
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) {
+        const int j = (KIND == WK_INT8) ? jj : 2 * h + jj;  // slice of the k-step record this chunk slice is
+        // corr_decode fills sc[j] / zp[j] for j < 4 with compile-time indices only: select without dynamic indexing
+        float s_j, z_j;
+        if constexpr (KIND == WK_INT8) {
+          s_j = sc[jj], z_j = zp[jj];
+        } else {
+          // bit select on registers: a ternary on the runtime `h` becomes a dynamically indexed scratch array
+          const uint32_t hm = 0u - uint32_t(h);
+          s_j = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, sc[jj]) & ~hm) |
+                                              (__builtin_bit_cast(uint32_t, sc[2 + jj]) & hm));
+          z_j = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, zp[jj]) & ~hm) |
+                                              (__builtin_bit_cast(uint32_t, zp[2 + jj]) & hm));
+        }
+        (void)j;
+        half8_t b;
+        if constexpr (KIND == WK_INT4) {
+          const _Float16 zl = (_Float16)(-1032.f - z_j), zh = (_Float16)(-72.f - z_j);
+          b = cvt_i4x8(breg[r][jj], i4c, half2_t{zl, zl}, half2_t{zh, zh});
+        } else if constexpr (KIND == WK_INT8) {
+          const _Float16 zo = (_Float16)(-1152.f - z_j);
+          b = cvt_i8x8(breg[r][2 * jj], breg[r][2 * jj + 1], half2_t{zo, zo});
+        } else {
+          b = cvt_f4x8(breg[r][jj], p.lut);
+        }
+        const _Float16 sh = (_Float16)s_j;
+        b = b * half8_t{sh, sh, sh, sh, sh, sh, sh, sh};
+        b_lds[((tl * 2 + jj) * 4 + g) * 16 + nn] = __builtin_bit_cast(uint4v, b);
+      }
+    }
+  };
+
+  auto compute = [&](const unsigned char* stage) {
+    const _Float16* a_lds = reinterpret_cast<const _Float16*>(stage);
+    const uint4v* b_lds = reinterpret_cast<const uint4v*>(stage + kG2BM * kG2AStr * 2);
+    // all fragments of the chunk are requested up front (one wave per SIMD: nobody else hides the LDS latency);
+    // the MFMAs of slice 0 then run while slice 1's fragments arrive
+    half8_t bf[2][4], af[2][kG2MI];
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+        bf[jj][ni] = __builtin_bit_cast(half8_t, b_lds[(((wn * 4 + ni) * 2 + jj) * 4 + g) * 16 + nn]);
+#pragma unroll
+      for (int mi = 0; mi < kG2MI; mi++)
+        af[jj][mi] =
+            *reinterpret_cast<const half8_t*>(a_lds + (wm * 16 * kG2MI + mi * 16 + nn) * kG2AStr + 32 * jj + 8 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks each fragment load to just before its first MFMA
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+      for (int mi = 0; mi < kG2MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[jj][mi], bf[jj][ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  unsigned char* stage0 = smem;
+  if constexpr (kG2Stages == 2) {
+    unsigned char* stage1 = smem + kG2StageBytes;
+    load_chunk(0);
+    store_chunk(0, stage0);
+    __syncthreads();
+    for (int c = 0; c < p.nchunks; c++) {
+      unsigned char* cur = (c & 1) ? stage1 : stage0;
+      unsigned char* nxt = (c & 1) ? stage0 : stage1;
+      const bool more = c + 1 < p.nchunks;
+      if (more) load_chunk(c + 1);
+      compute(cur);
+      if (more) store_chunk(c + 1, nxt);
+      __syncthreads();
+    }
+  } else {
+    load_chunk(0);
+    for (int c = 0; c < p.nchunks; c++) {
+      store_chunk(c, stage0);
+      __syncthreads();
+      if (c + 1 < p.nchunks) load_chunk(c + 1);
+      compute(stage0);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int mi = 0; mi < kG2MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      const int col = (tile0 + wn * 4 + ni) * 16 + nn;
+      if (col >= p.n) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + wm * 16 * kG2MI + mi * 16 + 4 * g + r;
+        if (row >= p.m) continue;
+        float v = acc[mi][ni][r];
+        const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
+        switch (p.epilogue) {
+          case 1: v = v + dv; break;            // custom::epilogue::Add
+          case 2: v = v * dv; break;            // custom::epilogue::Mul
+          case 3: v = epi_gelu(v + dv); break;  // custom::epilogue::Add_Gelu
+          case 4: v = epi_gelu(v); break;
+          case 5: v = epi_silu(v); break;
+          default: break;
+        }
+        p.c[size_t(row) * p.ldc + col] = v;
+      }
+    }
+}
+
+// fp32 [m][lda] -> fp16 [m][ld16], columns k..ld16-1 zero
+__global__ void cvt_a16_kernel(const float* __restrict__ a, _Float16* __restrict__ out, int m, int k, int lda, int ld16) {
+  const size_t idx = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) * 8;
+  const size_t total = size_t(m) * ld16;
+  if (idx >= total) return;
+  const int r = int(idx / ld16), c0 = int(idx % ld16);
+  half2_t h[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int c = c0 + 2 * e;
+    const float x = c < k ? a[size_t(r) * lda + c] : 0.f;
+    const float y = c + 1 < k ? a[size_t(r) * lda + c + 1] : 0.f;
+    h[e] = half2_t{(_Float16)x, (_Float16)y};
+  }
+  *reinterpret_cast<uint4v*>(out + idx) = uint4v{as_u32(h[0]), as_u32(h[1]), as_u32(h[2]), as_u32(h[3])};
+}
+
+// per-stream scratch for the fp16 copy of A (grow-only; never (re)allocated while the stream is capturing)
+static std::mutex g_scratch_mutex;
+static std::map<hipStream_t, std::pair<void*, size_t>> g_scratch;
+static void* scratch_for(hipStream_t st, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  auto& e = g_scratch[st];
+  if (e.second >= bytes) return e.first;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (e.first) {
+    hipStreamSynchronize(st);
+    hipFree(e.first);
+    e = {nullptr, 0};
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  e = {p, bytes};
+  return p;
+}
+void gemm_scratch_release() {
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  for (auto& kv : g_scratch)
+    if (kv.second.first) hipFree(kv.second.first);
+  g_scratch.clear();
+}
+
+template <int KIND, int SPS, int SK>
+static hipError_t launch_gemm2_k(const Gemm2Params& p, bool asym, dim3 grid, size_t lds, hipStream_t st) {
+  auto go = [&](auto kern) {
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(kG2Stages * kG2StageBytes));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    return hipGetLastError();
+  };
+  if constexpr (KIND == WK_F4) {
+    (void)asym;
+    return go(gemm2_kernel<KIND, SPS, SK, false>);
+  } else {
+    if (asym) return go(gemm2_kernel<KIND, SPS, SK, true>);
+    return go(gemm2_kernel<KIND, SPS, SK, false>);
+  }
+}
+template <int KIND, int SPS>
+static hipError_t launch_gemm2_s(const Gemm2Params& p, uint32_t scale_dt, bool asym, dim3 grid, size_t lds,
+                                 hipStream_t st) {
+  if (scale_dt == DT_F32) return launch_gemm2_k<KIND, SPS, SK_F32>(p, asym, grid, lds, st);
+  if (scale_dt == DT_F16) return launch_gemm2_k<KIND, SPS, SK_F16>(p, asym, grid, lds, st);
+  return launch_gemm2_k<KIND, SPS, SK_BF16>(p, asym, grid, lds, st);
+}
+
+static void f4_lut_planes_g(const _Float16* lut, F4Lut* out) {
+  for (int i = 0; i < 4; i++) out->lo[i] = out->hi[i] = 0;
+  for (int e = 0; e < 16; e++) {
+    unsigned short bits = __builtin_bit_cast(unsigned short, lut[e]);
+    out->lo[e >> 2] |= uint32_t(bits & 0xff) << (8 * (e & 3));
+    out->hi[e >> 2] |= uint32_t(bits >> 8) << (8 * (e & 3));
+  }
+}
+
+// hipErrorNotSupported = use the first-generation kernel (no scratch available while capturing, odd strides ...)
+hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
+  static const bool off = getenv("NS_GEMM_V1") != nullptr;  // diagnostics
+  if (off) return hipErrorNotSupported;
+  const ns_weight* w0 = a.seg[0].w;
+  Gemm2Params p;
+  memset(&p, 0, sizeof(p));
+  p.m = a.m;
+  p.k = w0->k;
+  p.n = w0->n;
+  p.nchunks = (w0->k + kG2KC - 1) / kG2KC;
+  const int kpad = p.nchunks * kG2KC;
+  // fp16 activations: the caller's shadow when it is usable as is, else one conversion pass into scratch
+  const _Float16* a16 = static_cast<const _Float16*>(a.a16);
+  if (a16 && (w0->k % kG2KC != 0 || (a.lda & 7) != 0 || (reinterpret_cast<uintptr_t>(a16) & 15) != 0)) a16 = nullptr;
+  if (a16) {
+    p.a16 = a16;
+    p.lda16 = a.lda;
+  } else {
+    const size_t bytes = size_t(a.m) * kpad * 2;
+    if (bytes >= (size_t(1) << 32)) return hipErrorNotSupported;
+    _Float16* sc = static_cast<_Float16*>(scratch_for(st, bytes));
+    if (!sc) return hipErrorNotSupported;
+    const size_t units = size_t(a.m) * kpad / 8;
+    hipLaunchKernelGGL(cvt_a16_kernel, dim3(unsigned((units + 255) / 256)), dim3(256), 0, st, a.a, sc, a.m, w0->k, a.lda, kpad);
+    p.a16 = sc;
+    p.lda16 = kpad;
+  }
+  if (size_t(a.m) * size_t(p.lda16) * 2 >= (size_t(1) << 32)) return hipErrorNotSupported;
+  p.ksteps = w0->ksteps;
+  p.ntiles = w0->ntiles;
+  p.codes = w0->codes;
+  p.scales = w0->scales;
+  p.zps = w0->zps;
+  p.codes_bytes = uint32_t(w0->codes_bytes);
+  p.scales_bytes = uint32_t(w0->scales_bytes);
+  p.zps_bytes = uint32_t(w0->zps_bytes);
+  p.qstride = w0->qstride;
+  p.sstride = w0->sstride;
+  p.zstride = w0->zstride;
+  p.c = a.seg[0].c;
+  p.ldc = a.ldc;
+  p.srows = w0->srows;
+  {
+    int num, den;
+    srow_rule(w0, &num, &den);
+    if (num == 0) {
+      p.srow_mul = 0, p.srow_shift = 0;
+    } else if (num == den) {
+      p.srow_mul = 1, p.srow_shift = 0;
+    } else {
+      const int ratio = den / num;
+      if ((ratio & (ratio - 1)) == 0) {
+        p.srow_mul = 1, p.srow_shift = __builtin_ctz(ratio);
+      } else {
+        p.srow_shift = 20;
+        p.srow_mul = ((1 << 20) + ratio - 1) / ratio;
+        for (int s = 0; s < w0->ksteps; s++)
+          if (((s * p.srow_mul) >> 20) != s / ratio) return hipErrorNotSupported;
+      }
+    }
+  }
+  p.epilogue = a.epilogue;
+  p.d = a.d;
+  p.ldd = a.ldd;
+  if (w0->kind == WK_F4) f4_lut_planes_g(w0->lut, &p.lut);
+  p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
+  p.cpx = (p.nbn + 7) / 8;
+  const int nbm = (a.m + kG2BM - 1) / kG2BM;
+  const dim3 grid(unsigned(8 * p.cpx * nbm));
+  const size_t lds = size_t(kG2Stages) * kG2StageBytes;
+#ifdef NS_GEMM_MIN  // development builds: the two bench formats only
+  if (w0->scale_dt != DT_BF16 || w0->asym) return hipErrorNotSupported;
+  if (w0->kind == WK_INT4 && w0->sps == 4) return launch_gemm2_k<WK_INT4, 4, SK_BF16>(p, false, grid, lds, st);
+  if (w0->kind == WK_INT8 && w0->sps == 2) return launch_gemm2_k<WK_INT8, 2, SK_BF16>(p, false, grid, lds, st);
+  return hipErrorNotSupported;
+#else
+#define NS_G2DISPATCH(KIND)                                                                \
+  switch (w0->sps) {                                                                       \
+    case 4: return launch_gemm2_s<KIND, 4>(p, w0->scale_dt, w0->asym, grid, lds, st);      \
+    case 2: return launch_gemm2_s<KIND, 2>(p, w0->scale_dt, w0->asym, grid, lds, st);      \
+    default: return launch_gemm2_s<KIND, 1>(p, w0->scale_dt, w0->asym, grid, lds, st);     \
+  }
+  if (w0->kind == WK_INT4) {
+    NS_G2DISPATCH(WK_INT4)
+  } else if (w0->kind == WK_INT8) {
+    if (w0->sps == 2) return launch_gemm2_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, grid, lds, st);
+    return launch_gemm2_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, grid, lds, st);
+  } else {
+    NS_G2DISPATCH(WK_F4)
+  }
+#undef NS_G2DISPATCH
+#endif
+}
+
+}  // namespace ns

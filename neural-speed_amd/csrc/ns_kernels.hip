@@ -958,6 +958,10 @@ static hipError_t launch_gemm_s(const GemmParams& p, uint32_t scale_dt, bool asy
 }
 
 hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st) {
+  {
+    const hipError_t e = launch_gemm2(a, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   const ns_weight* w0 = a.seg[0].w;
   GemmParams p;
   memset(&p, 0, sizeof(p));

@@ -6,9 +6,17 @@ cd "$(dirname "$0")/../neural-speed_amd/csrc"
 mkdir -p ../../variants
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  /opt/rocm/bin/hipcc -O3 -std=c++20 $flags -fPIC --offload-arch=gfx950 -c ns_kernels.hip -o /tmp/nsk_$name.o &
-  /opt/rocm/bin/hipcc -O3 -std=c++20 $flags -fPIC --offload-arch=gfx950 -c ns_decode.hip -o /tmp/nsd_$name.o &
+  # FILES = which kernel sources get the flags (the others are linked from the regular build)
+  objs=""
+  for f in ns_kernels ns_decode ns_gemm; do
+    if [[ " ${FILES:-ns_kernels ns_decode ns_gemm} " == *" $f "* ]]; then
+      /opt/rocm/bin/hipcc -O3 -std=c++20 $flags -fPIC --offload-arch=gfx950 -c $f.hip -o /tmp/${f}_$name.o &
+      objs="$objs /tmp/${f}_$name.o"
+    else
+      objs="$objs $f.o"
+    fi
+  done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libns_hip_$name.so ns_api.o ns_blob.o /tmp/nsk_$name.o /tmp/nsd_$name.o ns_quant.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libns_hip_$name.so ns_api.o ns_blob.o $objs ns_quant.o
   echo built variants/libns_hip_$name.so
 done
