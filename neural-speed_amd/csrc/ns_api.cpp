@@ -119,10 +119,10 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
   w->blocksize = v.blocksize;
   w->scale_dt = v.scale_dt;
   w->asym = v.asym();
-  if (v.prologue == 1 && v.dtype == DT_S4) {
-    w->kind = WK_INT4;
-  } else if (v.prologue == 1 && v.dtype == DT_S8) {
-    w->kind = WK_INT8;
+  if (v.prologue == 1 && dt_is_int(v.dtype) && dt_bits(v.dtype) >= 1 && dt_bits(v.dtype) <= 4) {
+    w->kind = WK_INT4;  // S1..S3 are widened to nibbles by the repack (HBM holds 4 bits per weight for them)
+  } else if (v.prologue == 1 && dt_is_int(v.dtype) && dt_bits(v.dtype) >= 5 && dt_bits(v.dtype) <= 8) {
+    w->kind = WK_INT8;  // S5..S7 widened to bytes
   } else if (v.prologue == 2 && dt_is_f4(v.dtype)) {
     w->kind = WK_F4;
     for (int i = 0; i < 16; i++) {
@@ -131,7 +131,7 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
       w->lutf[i] = f;
     }
   } else {
-    set_error("weight dtype not supported by the MI355X kernels yet (supported: S4_CLIP, S8, F4_NF4, F4_BNB, F4_E2M1)");
+    set_error("weight dtype not supported by the MI355X kernels yet (supported: S1..S8, F4_NF4, F4_BNB, F4_E2M1)");
     return false;
   }
   if (v.shuf_bytes) {

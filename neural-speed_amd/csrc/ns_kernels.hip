@@ -68,23 +68,30 @@ __global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint8_t* __
   const int col = t * 16 + nn;
   const size_t elts = size_t(ref_npad) * ref_kpad;
   uint32_t word = 0;
+  // integer types narrower than the device container (1-3 bit in nibbles, 5-7 bit in bytes) are widened here: the
+  // reference stores code + 2^(b-1) in bit planes (decompress_s{1..7}_s8, kernel_ref.h:367-526)
+  const int full = 1 << (ref_bits - 1);
   if (kind == WK_INT8) {
     // dword d of the lane: j = d >> 1, bytes i = (d & 1) * 4 .. +3 ; k = s*64 + 32*j + 8*c + i
     const int j = d >> 1;
     for (int b = 0; b < 4; b++) {
       const int kk = s * 64 + 32 * j + 8 * c + (d & 1) * 4 + b;
       int q = 0;
-      if (kk < k && col < n) q = img[ref_tiled_index(kk, col, ref_ntile, ref_packrow, ref_kpad)];
+      if (kk < k && col < n) {
+        const size_t e = ref_tiled_index(kk, col, ref_ntile, ref_packrow, ref_kpad);
+        q = ref_bits == 8 ? int(img[e]) : ref_stored_code(img, e, elts, ref_bits) - full;
+      }
       word |= uint32_t(q & 0xff) << (8 * b);
     }
   } else {
     // dword j = d: k = s*128 + 32*j + 8*c + i
     const int zero_code = (kind == WK_INT4) ? 8 : 0;  // int4 stores code+8 (compress_s8_s4); f4 code 0 decodes to 0.0
+    const int rebias = (kind == WK_INT4) ? 8 - full : 0;  // 0 for 4-bit
     for (int i = 0; i < 8; i++) {
       const int kk = s * 128 + 32 * d + 8 * c + i;
       int u = zero_code;
       if (kk < k && col < n)
-        u = ref_stored_code(img, ref_tiled_index(kk, col, ref_ntile, ref_packrow, ref_kpad), elts, ref_bits);
+        u = ref_stored_code(img, ref_tiled_index(kk, col, ref_ntile, ref_packrow, ref_kpad), elts, ref_bits) + rebias;
       word |= uint32_t(u & 0xf) << nib_shift(i);
     }
   }

@@ -15,8 +15,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3        # north_star tolerance
-TOL_A16_INT = 3e-5
+TOL_A16_INT = 3e-5   # small-M kernels: exact (code - zp) * scale in fp32, only A is rounded to fp16
 TOL_A16_F4 = 6e-4
+TOL_A16_GEMM = 5e-4  # M > 64 (prefill GEMM): weights are rounded to fp16 AFTER scaling, 2^-12 relative each
 
 
 def _w(rng, n, k, kind="normal"):
@@ -152,7 +153,8 @@ def _check(nso, out, a, blob, is_f4):
     e = nso.rel_l2(out, ref)
     e16 = nso.rel_l2(out, ref16)
     assert e < TOL, "rel l2 vs fp32-activation oracle %g" % e
-    assert e16 < (TOL_A16_F4 if is_f4 else TOL_A16_INT), "rel l2 vs fp16-activation oracle %g" % e16
+    tol16 = TOL_A16_F4 if is_f4 else (TOL_A16_GEMM if out.shape[0] > 64 else TOL_A16_INT)
+    assert e16 < tol16, "rel l2 vs fp16-activation oracle %g" % e16
     return e, e16
 
 
@@ -167,6 +169,26 @@ def test_forward_formats(L, pkg, nso, qt, st, asym, core, bs, m):
     out = np.zeros((m, n), np.float32)
     L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), m, n, k, k, n, None)
     _check(nso, out, a, blob, qt.startswith("F4"))
+
+
+@pytest.mark.parametrize("bits", [1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("m", [1, 3, 70])
+def test_forward_odd_bit_widths(L, pkg, nso, bits, m):
+    """S1..S3 / S5..S7 (the reference GEMV's 1,2,3,5,6,7-bit twins, kernel_ref.h:2533-3370): bit-plane blobs are widened
+    to the nibble / byte containers at load; the forward must match the oracle like the native widths do."""
+    rng = np.random.default_rng(40 + bits * 7 + m)
+    n, k, bs = 144, 768, 32
+    w = _w(rng, n, k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    for asym, st, core in ((False, nso.BF16, nso.CORE_AVX512_VNNI_KB), (True, nso.F32, nso.CORE_AVX512F)):
+        blob = nso.quant_pack(w, bs, nso.INT_TYPES[bits], st, asym, core)
+        out = np.zeros((m, n), np.float32)
+        L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), m, n, k, k, n, None)
+        _check(nso, out, a, blob, False)
+        # and the device unpack agrees with the reference's dequantisation bit for bit
+        deq = np.zeros((k, n), np.float32)
+        L.bestla_unpackweight_fp32(nso.ptr(blob), n, k, nso.ptr(deq), n)
+        assert np.array_equal(deq, nso.unpack_fp32(blob))
 
 
 @pytest.mark.parametrize("m", [1, 2, 3, 5, 16, 17, 32, 33, 64, 65, 130])
