@@ -247,6 +247,20 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def pmc_traffic(chain):
+    """HBM bytes per gate/up launch from the TCC FETCH_SIZE counter.  PMC collection needs its own rocprofv3 pass
+    (scripts/pmc_traffic.sh; the driver runs bench.py bare), so the measured per-launch figure is read back from the
+    committed summary; only valid for the tp=1 shapes it was measured on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_fetch_size.json")
+    if chain.world != 1 or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        return d["gate_up"]["hbm_bytes_corrected"]
+    except Exception:
+        return None
+
+
 def roofline(chain, pkg):
     """Dominant kernel = the fused FFN gate/up weight-streaming GEMV (smallm_kernel<INT4,SPS=4,MB=1,DUAL>): 2 x 4096 x
     11008/tp int4 weights + bf16 group scales per launch = 27.6 % x 3 of every layer's bytes.  Average launch duration is
@@ -291,7 +305,9 @@ def roofline(chain, pkg):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None,
+        "traffic": pmc_traffic(chain),
+        "traffic_source": "rocprofv3 --pmc FETCH_SIZE (own pass, scripts/pmc_traffic.sh), x2 gfx950 correction, "
+                          "bytes per gate/up launch at tp=1: profiles/pmc_fetch_size.json",
         "bytes_per_launch": bytes_per_launch,
         "avg_launch_us": round(us, 3),
         "note": "avg over %d back-to-back graph launches incl. ~1.2us inter-kernel boundary each" % (reps * nl),
