@@ -198,6 +198,64 @@ int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, s
                              uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType, bool isTrans,
                              void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Part 4 — fused attention: the C surface `ne_compute_forward_flash_attn_f32_f16_f16`
+ * (/root/reference/neural_speed/core/ne_layers.c:10110-10214) marshals into.  Struct layouts are those of
+ * /root/reference/neural_speed/core/layers/mha_dense.h:24-95 so that the ggml-side dispatch code compiles unchanged.
+ * Semantics = bestla_fusion_attn_forward_ref (mha_dense_wrapper.h:1371-1517) in its PREFER_FP32 form:
+ *   S[i][j] = (q_i . k_j) * QK_scale * Q_sc * K_sc  [tanh30: 30*tanh(S/30)]  + j * alibi_slope(head)
+ *   causal: j <= i + (sl_kv - sl_q);  P = softmax_j(S);  dst[i] = (P . V) * V_sc / dst_sc
+ * GQA: kv head = head / (head_num / heads_kv).  Only ATTN_FWD_LAYOUT_PLAIN tensors with arbitrary element strides
+ * (incl. transposed K) are taken; the CPU-specific reordered kv-cache (NTILE48/24 row packs) is declined through
+ * bestla_reordered_attn_fp32_support() == false, the reference's graceful path (llama.cpp:160-165).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct attn_shape_t {
+  int batch_size, head_num, heads_kv, head_size, sl_q, sl_kv;
+} attn_shape_t; /* mha_dense.h:24-26 */
+
+typedef enum ATTN_FWD_LAYOUT {
+  ATTN_FWD_LAYOUT_PLAIN,
+  ATTN_FWD_LAYOUT_NTILE48_ROWPACK4,
+  ATTN_FWD_LAYOUT_NTILE48_ROWPACK2,
+  ATTN_FWD_LAYOUT_NTILE24_ROWPACK1,
+} ATTN_FWD_LAYOUT; /* mha_dense.h:35-47 */
+
+typedef uint32_t ns_attn_flags_t; /* ne_attn_flags_t, ne_layers.h:65-72 */
+enum {
+  NS_ATTN_FLAG_NONE = 0,
+  NS_ATTN_FLAG_IS_CAUSAL = 1 << 0,
+  NS_ATTN_FLAG_IS_ALIBI8 = 1 << 1,
+  NS_ATTN_FLAG_PREFER_FP32 = 1 << 2,
+  NS_ATTN_FLAG_IS_TANH30 = 1 << 3,
+};
+
+typedef struct attn_fp32_fp16_fp16_fp32_fwd_args_t {
+  float* Q;
+  uint16_t* K; /* ne_fp16_t */
+  uint16_t* V;
+  float* dst;
+  float Q_sc, K_sc, V_sc, dst_sc;
+  char* tmp;
+  float QK_scale;
+  ns_attn_flags_t attn_flags;
+  int batch_size, head_num, heads_kv, head_size, sl_q, sl_kv;
+  ATTN_FWD_LAYOUT Q_layout, K_layout, V_layout, dst_layout;
+  int step_q_bs, step_q_head_num, step_q_sl;
+  int step_k_bs, step_k_head_num, step_k_sl, step_k_head_size;
+  int step_v_bs, step_v_head_num, step_v_sl, step_v_head_size;
+  int step_dst_bs, step_dst_head_num, step_dst_sl;
+} attn_fp32_fp16_fp16_fp32_fwd_args_t; /* mha_dense.h:66-81 */
+
+/* mha_dense.h:27: scratch the CALLER allocates; this backend keeps its scratch in registers / LDS */
+size_t bestla_fusion_attn_workspace_size(const attn_shape_t* params);
+/* mha_dense.h:85-86.  Host pointers: Q/K/V are uploaded, dst downloaded, synchronous (reference semantics). */
+bool bestla_fusion_attn_fp32_fp16_fp16_fp32_support(const attn_shape_t* params);
+void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* params);
+/* mha_dense.h:123: the reordered (CPU tile-packed) kv-cache path is not offered: graphs fall back to the plain cache */
+bool bestla_reordered_attn_fp32_support(const attn_shape_t* params);
+/* same operator on DEVICE pointers, asynchronous on `stream`; returns 0 on success */
+int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* dparams, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

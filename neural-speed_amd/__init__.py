@@ -29,6 +29,47 @@ COMP_UNDEF, COMP_F32, COMP_BF16, COMP_F16, COMP_INT8 = range(5)
 # enum ns_epilogue
 EPI_NONE, EPI_ADD, EPI_MUL, EPI_ADD_GELU, EPI_GELU, EPI_SILU = range(6)
 CORE_AUTO = -1
+# ne_attn_flags_t (neural_speed/core/ne_layers.h:65-72)
+ATTN_CAUSAL, ATTN_ALIBI8, ATTN_PREFER_FP32, ATTN_TANH30 = 1, 2, 4, 8
+
+
+class AttnShape(C.Structure):
+    """attn_shape_t (mha_dense.h:24-26)"""
+    _fields_ = [(n, C.c_int) for n in ("batch_size", "head_num", "heads_kv", "head_size", "sl_q", "sl_kv")]
+
+
+class AttnArgs(C.Structure):
+    """attn_fp32_fp16_fp16_fp32_fwd_args_t (mha_dense.h:66-81)"""
+    _fields_ = ([("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("dst", C.c_void_p),
+                 ("Q_sc", C.c_float), ("K_sc", C.c_float), ("V_sc", C.c_float), ("dst_sc", C.c_float),
+                 ("tmp", C.c_void_p), ("QK_scale", C.c_float), ("attn_flags", C.c_uint32)] +
+                [(n, C.c_int) for n in ("batch_size", "head_num", "heads_kv", "head_size", "sl_q", "sl_kv",
+                                        "Q_layout", "K_layout", "V_layout", "dst_layout",
+                                        "step_q_bs", "step_q_head_num", "step_q_sl",
+                                        "step_k_bs", "step_k_head_num", "step_k_sl", "step_k_head_size",
+                                        "step_v_bs", "step_v_head_num", "step_v_sl", "step_v_head_size",
+                                        "step_dst_bs", "step_dst_head_num", "step_dst_sl")])
+
+
+def attn_args(q_ptr, k_ptr, v_ptr, dst_ptr, bs, hn, hkv, hs, sl_q, sl_kv, qk_scale, flags=0, k_trans=False):
+    """args for the tensor layouts of mha_dense_tests.cpp:232-262: q/dst [bs][sl][heads][hs], k/v [bs][sl_kv][hkv][hs]
+    (k_trans: k is [bs][hkv][hs][sl_kv])."""
+    a = AttnArgs()
+    a.Q, a.K, a.V, a.dst = q_ptr, k_ptr, v_ptr, dst_ptr
+    a.Q_sc = a.K_sc = a.V_sc = a.dst_sc = 1.0
+    a.tmp = None
+    a.QK_scale, a.attn_flags = qk_scale, flags
+    a.batch_size, a.head_num, a.heads_kv, a.head_size, a.sl_q, a.sl_kv = bs, hn, hkv, hs, sl_q, sl_kv
+    a.Q_layout = a.K_layout = a.V_layout = a.dst_layout = 0
+    a.step_q_bs, a.step_q_head_num, a.step_q_sl = sl_q * hn * hs, hs, hn * hs
+    a.step_k_bs = sl_kv * hkv * hs
+    if k_trans:
+        a.step_k_head_num, a.step_k_sl, a.step_k_head_size = hs * sl_kv, 1, sl_kv
+    else:
+        a.step_k_head_num, a.step_k_sl, a.step_k_head_size = hs, hkv * hs, 1
+    a.step_v_bs, a.step_v_head_num, a.step_v_sl, a.step_v_head_size = sl_kv * hkv * hs, hs, hkv * hs, 1
+    a.step_dst_bs, a.step_dst_head_num, a.step_dst_sl = sl_q * hn * hs, hs, hn * hs
+    return a
 
 
 def build(verbose=False):
@@ -76,6 +117,15 @@ def lib():
         L.ns_hip_fusion_ffn3_gateup.argtypes = [vp, vp, vp, vp, vp, i, i, vp]
         L.ns_hip_fusion_ffn2_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, b, vp]
         L.ns_hip_quant_pack_device.argtypes = [vp, vp, sz, sz, sz, sz, u32, u32, b, i, b, vp]
+        L.bestla_fusion_attn_workspace_size.restype = sz
+        L.bestla_fusion_attn_workspace_size.argtypes = [vp]
+        L.bestla_fusion_attn_fp32_fp16_fp16_fp32_support.restype = b
+        L.bestla_fusion_attn_fp32_fp16_fp16_fp32_support.argtypes = [vp]
+        L.bestla_reordered_attn_fp32_support.restype = b
+        L.bestla_reordered_attn_fp32_support.argtypes = [vp]
+        L.bestla_fusion_attn_fp32_fp16_fp16_fp32_forward.restype = None
+        L.bestla_fusion_attn_fp32_fp16_fp16_fp32_forward.argtypes = [vp]
+        L.ns_hip_attn_fp32_fp16_fp16_fp32_forward.argtypes = [vp, vp]
         L.ns_BTLAGemmPackBSize.restype = sz
         L.ns_BTLAGemmPackBSize.argtypes = [sz, sz, sz, u32, u32, b, i, vp]
         L.ns_BTLAGemmQuantPackB.restype = b

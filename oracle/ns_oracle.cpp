@@ -843,4 +843,49 @@ int nso_gemm_u8s8_f32(const float* a, int lda, const void* blob, float* c, int l
 float nso_gelu(float x) { return 0.5f * x * (1.f + tanhf(0.7978845834732056f * (x + 0.044714998453855515f * x * x * x))); }
 float nso_silu(float x) { return float(x / (1 + exp(-x))); }
 
+// bestla_fusion_attn_forward_ref — mha_dense_wrapper.h:1371-1517 (PLAIN layouts; fp32 accumulation in the loop order
+// of the reference: scores j ascending / k ascending, then exp, then P.V k ascending)
+int nso_attn_ref(const nso_attn_args* a, int bf16_gemm) {
+  const bool is_causal = (a->flags & 1u) != 0, is_alibi = (a->flags & 2u) != 0;
+  if (is_causal && a->sl_q > a->sl_kv) return -1;
+  if (a->heads_kv <= 0 || a->head_num % a->heads_kv) return -1;
+  const int group_heads = a->head_num / a->heads_kv;
+  const int lf = 1 << int(floor(log2(double(a->head_num))));  // :1424-1426
+  const float m0 = powf(2.0f, -(8.f) / lf), m1 = powf(2.0f, -(8.f / 2.0f) / lf);
+  auto bf = [&](float x) { return bf16_gemm ? nso_bf16_to_f32(nso_f32_to_bf16(x)) : x; };
+  std::vector<float> row(size_t(a->sl_kv));
+  for (int ibs = 0; ibs < a->batch_size; ibs++)
+    for (int ihn = 0; ihn < a->head_num; ihn++)
+      for (int i = 0; i < a->sl_q; i++) {
+        const int ihkv = ihn / group_heads;
+        const float* q = a->q + ibs * a->step_q_bs + ihn * a->step_q_head_num + i * a->step_q_sl;
+        float* dst = a->dst + ibs * a->step_dst_bs + ihn * a->step_dst_head_num + i * a->step_dst_sl;
+        const uint16_t* kc = a->k + ibs * a->step_k_bs + ihkv * a->step_k_head_num;
+        const uint16_t* vc = a->v + ibs * a->step_v_bs + ihkv * a->step_v_head_num;
+        const int unmasked = is_causal ? (a->sl_kv - a->sl_q) + i + 1 : a->sl_kv;  // :1440-1441
+        const float slope = !is_alibi ? 0.f : (ihn < lf ? powf(m0, float(ihn + 1)) : powf(m1, float(2 * (ihn - lf) + 1)));
+        float row_max = -INFINITY;
+        for (int j = 0; j < unmasked; j++) {  // :1451-1474
+          float s = 0.f;
+          for (int k = 0; k < a->head_size; k++)
+            s += bf(q[k]) * bf(nso_f16_to_f32(kc[j * a->step_k_sl + k * a->step_k_head_size]));
+          s = s * a->qk_scale * a->q_sc * a->k_sc + j * slope;
+          row[size_t(j)] = s;
+          row_max = std::max(row_max, s);
+        }
+        float exp_sum = 0.f;
+        for (int j = 0; j < unmasked; j++) {  // :1477-1481
+          row[size_t(j)] = expf(row[size_t(j)] - row_max);
+          exp_sum += row[size_t(j)];
+        }
+        for (int j = 0; j < unmasked; j++) row[size_t(j)] = bf(row[size_t(j)] / exp_sum);  // :1487-1490
+        for (int j = 0; j < a->head_size; j++) {  // :1494-1512
+          float acc = 0.f;
+          for (int k = 0; k < unmasked; k++) acc += row[size_t(k)] * bf(nso_f16_to_f32(vc[k * a->step_v_sl + j]));
+          dst[j] = acc * a->v_sc / a->dst_sc;
+        }
+      }
+  return 0;
+}
+
 }  // extern "C"

@@ -132,6 +132,27 @@ int nso_gemm_u8s8_f32(const float* a, int lda, const void* blob, float* c, int l
 float nso_gelu(float x);
 float nso_silu(float x);
 
+/* fused attention — bestla_fusion_attn_forward_ref, neural_speed/core/layers/mha_dense_wrapper.h:1371-1517, for
+ * Q fp32 / K,V fp16 / dst fp32 in ATTN_FWD_LAYOUT_PLAIN with element strides.  `bf16_gemm` != 0 reproduces the
+ * reference's default rounding of Q, K and P to bf16 (IS_BF16_GEMM, :1389-1394); 0 = its NE_ATTN_FLAG_PREFER_FP32
+ * form.  flags: 1 causal, 2 alibi8 (TANH30 is not part of forward_ref).  PARITY UNPINNED: mha_dense_wrapper.h needs
+ * the xbyak-dependent BesTLA headers and cannot be compiled here; this is a line-by-line restatement checked only
+ * against an independent fp64 softmax(QK^T)V (tests/test_attention_oracle.py). */
+typedef struct nso_attn_args {
+  const float* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  float* dst;
+  float q_sc, k_sc, v_sc, dst_sc, qk_scale;
+  uint32_t flags;
+  int batch_size, head_num, heads_kv, head_size, sl_q, sl_kv;
+  long long step_q_bs, step_q_head_num, step_q_sl;
+  long long step_k_bs, step_k_head_num, step_k_sl, step_k_head_size;
+  long long step_v_bs, step_v_head_num, step_v_sl;
+  long long step_dst_bs, step_dst_head_num, step_dst_sl;
+} nso_attn_args;
+int nso_attn_ref(const nso_attn_args* a, int bf16_gemm);
+
 #ifdef __cplusplus
 }
 #endif

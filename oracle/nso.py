@@ -225,6 +225,46 @@ def gemv_f32(a, blob, nthreads=0):
     return c
 
 
+class AttnArgs(C.Structure):
+    """nso_attn_args (ns_oracle.h)"""
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("dst", C.c_void_p),
+                ("q_sc", C.c_float), ("k_sc", C.c_float), ("v_sc", C.c_float), ("dst_sc", C.c_float),
+                ("qk_scale", C.c_float), ("flags", C.c_uint32),
+                ("batch_size", C.c_int), ("head_num", C.c_int), ("heads_kv", C.c_int), ("head_size", C.c_int),
+                ("sl_q", C.c_int), ("sl_kv", C.c_int),
+                ("step_q_bs", C.c_longlong), ("step_q_head_num", C.c_longlong), ("step_q_sl", C.c_longlong),
+                ("step_k_bs", C.c_longlong), ("step_k_head_num", C.c_longlong), ("step_k_sl", C.c_longlong),
+                ("step_k_head_size", C.c_longlong),
+                ("step_v_bs", C.c_longlong), ("step_v_head_num", C.c_longlong), ("step_v_sl", C.c_longlong),
+                ("step_dst_bs", C.c_longlong), ("step_dst_head_num", C.c_longlong), ("step_dst_sl", C.c_longlong)]
+
+
+def attn_ref(q, k, v, qk_scale, flags=0, k_trans=False, bf16_gemm=False, scales=(1.0, 1.0, 1.0, 1.0)):
+    """q fp32 [bs][sl_q][heads][hs]; k, v fp16 [bs][sl_kv][heads_kv][hs] (k_trans: k is [bs][heads_kv][hs][sl_kv]).
+    Returns dst fp32 [bs][sl_q][heads][hs] — the tensor layouts of mha_dense_tests.cpp:232-262."""
+    q = np.ascontiguousarray(q, np.float32)
+    k = np.ascontiguousarray(k, np.float16)
+    v = np.ascontiguousarray(v, np.float16)
+    bs, sl_q, hn, hs = q.shape
+    sl_kv, hkv = v.shape[1], v.shape[2]
+    dst = np.zeros_like(q)
+    a = AttnArgs()
+    a.q, a.k, a.v, a.dst = q.ctypes.data, k.ctypes.data, v.ctypes.data, dst.ctypes.data
+    a.q_sc, a.k_sc, a.v_sc, a.dst_sc = scales
+    a.qk_scale, a.flags = qk_scale, flags
+    a.batch_size, a.head_num, a.heads_kv, a.head_size, a.sl_q, a.sl_kv = bs, hn, hkv, hs, sl_q, sl_kv
+    a.step_q_bs, a.step_q_head_num, a.step_q_sl = sl_q * hn * hs, hs, hn * hs
+    a.step_k_bs = sl_kv * hkv * hs
+    if k_trans:
+        a.step_k_head_num, a.step_k_sl, a.step_k_head_size = hs * sl_kv, 1, sl_kv
+    else:
+        a.step_k_head_num, a.step_k_sl, a.step_k_head_size = hs, hkv * hs, 1
+    a.step_v_bs, a.step_v_head_num, a.step_v_sl = sl_kv * hkv * hs, hs, hkv * hs
+    a.step_dst_bs, a.step_dst_head_num, a.step_dst_sl = sl_q * hn * hs, hs, hn * hs
+    assert lib().nso_attn_ref(C.byref(a), 1 if bf16_gemm else 0) == 0
+    return dst
+
+
 def gemm_u8s8(a, blob):
     a = np.ascontiguousarray(a, dtype=np.float32)
     bi = parse(blob)
