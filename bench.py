@@ -113,30 +113,76 @@ class Chain:
         del w, blob
         return wt, host
 
-    def step(self):
-        L, pkg, st = self.L, self.pkg, self.st
+    def segments(self):
+        """The token step as a list of ("gemm", callable) / ("reduce", tensor) items: the GEMM runs between two
+        all-reduces are graph-capturable on their own, the collectives stay outside (TP only)."""
+        L, pkg = self.L, self.pkg
         d = self.d
         H = self.use_h
         p = lambda t: t.data_ptr() if H else None
         tp_ = self.world > 1  # after an all-reduce the fp16 shadow of the summed vector is stale: fall back to fp32 A
+        items = []
         x_in, x_in_h = self.x0, self.x0h
         for lw in self.layers:
-            pkg.check(L.ns_hip_fusion_qkv_forward_h(x_in.data_ptr(), p(x_in_h) if x_in_h is not None else None,
-                                                    lw["q"].h, lw["k"].h, lw["v"].h, self.qkv.data_ptr(), p(self.qkvh),
-                                                    1, d, self.dl, st))
-            # attention itself is outside this path; its output stands in as the Q slice
-            pkg.check(L.ns_hip_f32f32_forward_h(self.qkv.data_ptr(), p(self.qkvh), lw["o"].h, self.attn.data_ptr(),
-                                                None if tp_ else p(self.attnh), 1, self.dl, d, pkg.EPI_NONE, None, 0, st))
+            def attn_block(lw=lw, x_in=x_in, x_in_h=x_in_h):
+                st = self.st
+                pkg.check(L.ns_hip_fusion_qkv_forward_h(x_in.data_ptr(), p(x_in_h) if x_in_h is not None else None,
+                                                        lw["q"].h, lw["k"].h, lw["v"].h, self.qkv.data_ptr(),
+                                                        p(self.qkvh), 1, d, self.dl, st))
+                # attention itself is outside this chain (its own operator, ns_attn.hip); its output stands in as the
+                # Q slice
+                pkg.check(L.ns_hip_f32f32_forward_h(self.qkv.data_ptr(), p(self.qkvh), lw["o"].h, self.attn.data_ptr(),
+                                                    None if tp_ else p(self.attnh), 1, self.dl, d, pkg.EPI_NONE, None,
+                                                    0, st))
+            items.append(("gemm", attn_block))
             if tp_:
-                torch.distributed.all_reduce(self.attn)  # ne_all_reduce after attn-out (llama.cpp:590-593)
-            pkg.check(L.ns_hip_fusion_ffn3_forward_h(self.attn.data_ptr(), None if tp_ else p(self.attnh), lw["w1"].h,
-                                                     lw["w2"].h, lw["w3"].h, None, self.t2.data_ptr(), p(self.t2h),
-                                                     self.x.data_ptr(), None if tp_ else p(self.xh), 1, pkg.EPI_SILU, st))
+                items.append(("reduce", self.attn))  # ne_all_reduce after attn-out (llama.cpp:590-593)
+
+            def ffn_block(lw=lw):
+                st = self.st
+                pkg.check(L.ns_hip_fusion_ffn3_forward_h(self.attn.data_ptr(), None if tp_ else p(self.attnh),
+                                                         lw["w1"].h, lw["w2"].h, lw["w3"].h, None, self.t2.data_ptr(),
+                                                         p(self.t2h), self.x.data_ptr(), None if tp_ else p(self.xh), 1,
+                                                         pkg.EPI_SILU, st))
+            items.append(("gemm", ffn_block))
             if tp_:
-                torch.distributed.all_reduce(self.x)  # ne_all_reduce after FFN (llama.cpp:690-694)
+                items.append(("reduce", self.x))  # ne_all_reduce after FFN (llama.cpp:690-694)
             x_in, x_in_h = self.x, (None if tp_ else self.xh)
-        pkg.check(L.ns_hip_f32f32_forward_h(x_in.data_ptr(), p(x_in_h) if x_in_h is not None else None, self.head.h,
-                                            self.logits.data_ptr(), None, 1, d, self.V, pkg.EPI_NONE, None, 0, st))
+
+        def head_block(x_in=x_in, x_in_h=x_in_h):
+            st = self.st
+            pkg.check(L.ns_hip_f32f32_forward_h(x_in.data_ptr(), p(x_in_h) if x_in_h is not None else None, self.head.h,
+                                                self.logits.data_ptr(), None, 1, d, self.V, pkg.EPI_NONE, None, 0, st))
+        items.append(("gemm", head_block))
+        return items
+
+    def step(self):
+        for kind, it in self.segments():
+            if kind == "gemm":
+                it()
+            else:
+                torch.distributed.all_reduce(it)
+
+
+def capture(fn):
+    """fn() captured into a CUDAGraph on a side stream; `with torch.cuda.stream` restores the current stream even when
+    the capture is invalidated half way (torch.cuda.graph's own __exit__ does not)."""
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        try:
+            fn()
+        except Exception:
+            try:
+                graph.capture_end()
+            except Exception:
+                pass
+            raise
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    return graph
 
 
 def time_graph(fn, steps, warmup, use_graph, world):
@@ -144,11 +190,19 @@ def time_graph(fn, steps, warmup, use_graph, world):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
-    if use_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            fn()
-        run = graph.replay
+    if use_graph == "segments":
+        # TP: one graph per GEMM run between two all-reduces; the collectives are launched eagerly in between, so
+        # nothing depends on RCCL being capturable
+        plan = [(k, capture(it) if k == "gemm" else it) for k, it in fn.segments()]
+
+        def run():
+            for k, it in plan:
+                if k == "gemm":
+                    it.replay()
+                else:
+                    torch.distributed.all_reduce(it)
+    elif use_graph:
+        run = capture(fn).replay
     else:
         run = fn
     for _ in range(warmup):
@@ -179,25 +233,48 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     pkg = ge.load_package()
     from neural_speed_amd import parallel as par  # the replacement of parallel_context.{h,cpp}
-    par.init_parallel_context("nccl" if world > 1 else None)  # "nccl" = RCCL over xGMI on ROCm
+    # "nccl" = RCCL over xGMI on ROCm.  NS_DIST_BACKEND=gloo lets the TP code path be smoke-tested with several ranks
+    # on ONE GPU (RCCL refuses two ranks per device); numbers from such a run are not bench results.
+    backend = os.environ.get("NS_DIST_BACKEND", "nccl")
+    par.init_parallel_context(backend if world > 1 else None)
     chain = Chain(pkg, args.layers, rank, world, keep_host_layer=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     # the chain object itself carries the captured stream handle; under graph capture torch switches the current
     # stream, so the stream pointer handed to the C ABI must be re-read inside the capture.
-    def step():
-        chain.st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        chain.step()
+    class Step:
+        """callable token step; segments() re-reads the current stream for every GEMM run (capture switches it)"""
+
+        def __call__(self):
+            chain.st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            chain.step()
+
+        def segments(self):
+            def wrap(f):
+                def g():
+                    chain.st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    f()
+                return g
+            return [(k, wrap(it) if k == "gemm" else it) for k, it in chain.segments()]
+
+    step = Step()
 
     use_graph = not args.no_graph
+    if use_graph and world > 1 and os.environ.get("NS_BENCH_FULL_GRAPH") is None:
+        use_graph = "segments"  # NS_BENCH_FULL_GRAPH=1: try to capture the RCCL all-reduces too
     try:
         wall_ms, ev_ms = time_graph(step, args.steps, args.warmup, use_graph, world)
     except Exception as e:  # graph capture unsupported (e.g. RCCL in capture): fall back to eager launches
         if not use_graph:
             raise
-        sys.stderr.write("graph capture failed (%s); falling back to eager launches\n" % e)
+        sys.stderr.write("graph capture failed (%s); falling back to eager launches\n" % str(e).splitlines()[0])
         use_graph = False
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        pkg.lib().ns_hip_reset_error()  # the invalidated capture leaves a sticky error behind
         wall_ms, ev_ms = time_graph(step, args.steps, args.warmup, False, world)
     t = torch.tensor([wall_ms], device="cuda", dtype=torch.float64)
     if world > 1:
@@ -224,13 +301,16 @@ def main():
                 "workload": "Llama-2-7B Q4_0 (BesTLA int4 sym g32 bf16-scale) batch=1 decode GEMM chain: %d layers x "
                             "{QKV, WO, FFN gate/up, FFN down} + lm_head" % args.layers,
                 "parallelism": "tp%d" % world,
-                "launch": "hipGraph replay" if use_graph else "eager",
+                "launch": ("hipGraph replay" if use_graph is True else
+                           "hipGraph per GEMM run + eager all-reduce" if use_graph == "segments" else "eager"),
                 "weights_bytes_per_gpu": chain.stream_bytes,
                 "event_ms_per_step": round(ev_ms / args.steps, 5),
             },
         }
         if args.layers != CFG["n_layer"]:
             out["config"]["INVALID"] = "debug run with %d layers" % args.layers
+        if world > 1 and backend != "nccl":
+            out["config"]["INVALID"] = "smoke run of the TP path over %s, not RCCL" % backend
         alg_bytes = chain.stream_bytes + 4 * sum(
             [(CFG["n_embd"] + 3 * chain.dl), (chain.dl + CFG["n_embd"]), (CFG["n_embd"] + chain.ffl),
              (chain.ffl + CFG["n_embd"])]) * args.layers + 4 * (CFG["n_embd"] + CFG["n_vocab"])

@@ -129,6 +129,8 @@ bool ns_BTLAGemmUnPackB(float* FpData, const void* PackedBuf, size_t N, size_t K
 typedef struct ns_weight ns_weight; /* opaque: one weight matrix resident in HBM in the MI355X layout */
 
 int ns_hip_device_count(void);
+/* clears a sticky HIP runtime error (e.g. left by an invalidated stream capture) and ns_hip_last_error() */
+void ns_hip_reset_error(void);
 /* part-1 entry points cache {host blob pointer -> device weight} (validated by a content fingerprint); this
  * drops every cached device weight, e.g. after the model that owned the blobs was unloaded. */
 void ns_hip_cache_clear(void);

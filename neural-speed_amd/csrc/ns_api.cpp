@@ -66,6 +66,9 @@ bool have_device() {
     count = c;
   }
   if (count <= 0) set_error("no HIP device visible: libns_hip.so has no CPU fallback");
+  // every entry point passes here first: drop a stale runtime error (another library's failed call, an invalidated
+  // stream capture ...) so that the hipGetLastError() after our own launches reports only those launches
+  if (count > 0) (void)hipGetLastError();
   return count > 0;
 }
 
@@ -353,6 +356,13 @@ void set_error(const std::string& s) {
 extern "C" {
 
 // ------------------------------------------------------------------------------------------------ part 3
+void ns_hip_reset_error(void) {
+  // drops a sticky HIP error (e.g. after a stream capture was invalidated) and the library's error string
+  for (int i = 0; i < 8 && hipGetLastError() != hipSuccess; i++) {
+  }
+  set_error("");
+}
+
 void ns_hip_cache_clear(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_cache) ns_hip_weight_free(kv.second.w);
