@@ -403,12 +403,17 @@ def prefill_tflops(chain, pkg, m=2048):
     d, ff = chain.d, chain.ffl
     a_d = torch.randn((m, d), device="cuda", dtype=torch.float32)
     a_ff = torch.randn((m, ff), device="cuda", dtype=torch.float32)
+    # device-resident chain: every GEMM reads the fp16 shadow its producer wrote and writes fp32 C plus the fp16 shadow
+    # for its consumer (the "_h" entry points), exactly like the decode chain above
+    a_d16, a_ff16 = a_d.half(), a_ff.half()
     out_big = torch.empty((m, max(d, ff)), device="cuda", dtype=torch.float32)
-    gemms = [(a_d, lw[k]) for k in ("q", "k", "v", "o", "w1", "w3")] + [(a_ff, lw["w2"])]
+    out_big16 = torch.empty((m, max(d, ff)), device="cuda", dtype=torch.float16)
+    gemms = [(a_d, a_d16, lw[k]) for k in ("q", "k", "v", "o", "w1", "w3")] + [(a_ff, a_ff16, lw["w2"])]
 
     def run():
-        for a, wt in gemms:
-            pkg.check(L.ns_hip_f32f32_forward(a.data_ptr(), wt.h, out_big.data_ptr(), m, wt.k, wt.n, pkg.EPI_NONE, None, 0, st))
+        for a, a16, wt in gemms:
+            pkg.check(L.ns_hip_f32f32_forward_h(a.data_ptr(), a16.data_ptr(), wt.h, out_big.data_ptr(),
+                                                out_big16.data_ptr(), m, wt.k, wt.n, pkg.EPI_NONE, None, 0, st))
 
     for _ in range(2):
         run()
@@ -421,7 +426,7 @@ def prefill_tflops(chain, pkg, m=2048):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    flops = sum(2.0 * m * wt.n * wt.k for _, wt in gemms)
+    flops = sum(2.0 * m * wt.n * wt.k for _, _, wt in gemms)
     return round(flops / ms / 1e9, 1)
 
 

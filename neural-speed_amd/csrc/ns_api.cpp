@@ -323,13 +323,9 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
     return -1;
   }
   // M <= 64: weight-streaming kernel (HBM-bound); larger M: tiled MFMA GEMM (weights reused across 128 rows)
-  if (m > 64 && dC16) {
-    set_error("forward: the fp16 output shadow is only produced on the M <= 64 path");
-    return -1;
-  }
   SmallMArgs a{};
   a.a = dA;
-  a.a16 = m <= 64 ? dA16 : nullptr;
+  a.a16 = dA16;
   a.lda = lda;
   a.m = m;
   a.ldc = ldc;

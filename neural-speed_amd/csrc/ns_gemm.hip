@@ -52,6 +52,7 @@ struct Gemm2Params {
   uint32_t codes_bytes, scales_bytes, zps_bytes;
   uint32_t qstride, sstride, zstride;
   float* c;
+  _Float16* c16;  // optional fp16 shadow of C (same leading dimension) for the next GEMM's activations
   int ldc;
   int srows, srow_mul, srow_shift;
   int epilogue;
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
           default: break;
         }
         p.c[size_t(row) * p.ldc + col] = v;
+        if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
       }
     }
 }
@@ -370,6 +372,7 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   p.sstride = w0->sstride;
   p.zstride = w0->zstride;
   p.c = a.seg[0].c;
+  p.c16 = static_cast<_Float16*>(a.seg[0].c16);
   p.ldc = a.ldc;
   p.srows = w0->srows;
   {

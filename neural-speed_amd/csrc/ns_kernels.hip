@@ -970,6 +970,7 @@ hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st) {
     if (e != hipErrorNotSupported) return e;
   }
   const ns_weight* w0 = a.seg[0].w;
+  if (a.seg[0].c16) return hipErrorInvalidValue;  // the fp16 output shadow is produced by gemm2_kernel / smallm_kernel
   GemmParams p;
   memset(&p, 0, sizeof(p));
   p.a = a.a;

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Secondary BASELINE.json configs on one MI355X (synthetic weights, device-resident API, HIP-event timing):
+  config 4  Mistral-7B NF4 g128 (RTN, bf16 scales), batch = 8 decode   -> tokens/s of the GEMM chain
+  config 5  Llama-2-70B Q4_0 g32, batch = 1 decode, the PER-RANK shard of TP = 8 -> ms/token of one rank's GEMMs
+  PCIe      part-1 host-pointer bestla_f32f32_forward at M = 1 (upload A, download C, sync) vs device-resident
+Every distinct layer shape is timed once with its own weights and multiplied by the layer count."""
+import ctypes as C, json, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package(); L = pkg.lib()
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make(n, k, qt, st_dt, bs, comp, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    w = torch.randn((n, k), generator=g, device="cuda") * 0.02
+    size = L.ns_BTLAGemmPackBSize(n, k, bs, qt, st_dt, False, comp, None)
+    blob = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    pkg.check(L.ns_hip_quant_pack_device(blob.data_ptr(), w.data_ptr(), n, k, k, bs, qt, st_dt, False, comp, True, st))
+    wt = pkg.Weight.from_device_blob(blob.data_ptr(), size, st)
+    torch.cuda.synchronize()
+    return wt, blob
+
+
+def time_us(fn, reps=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn_stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        fn(fn_stream)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def chain_time(shapes, qt, st_dt, bs, comp, m, nrep=3):
+    """shapes: list of (name, n, k, count).  Each shape gets `nrep` different weights streamed back to back."""
+    out, total_us, total_bytes = {}, 0.0, 0
+    for name, n, k, count in shapes:
+        ws = [make(n, k, qt, st_dt, bs, comp, 7 + i) for i in range(nrep)]
+        a = torch.randn((m, k), device="cuda")
+        ah = a.half()
+        c = torch.empty((m, n), device="cuda")
+
+        def fn(s=None):
+            s = s or C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for wt, _ in ws:
+                pkg.check(L.ns_hip_f32f32_forward_h(a.data_ptr(), ah.data_ptr(), wt.h, c.data_ptr(), None, m, k, n,
+                                                    pkg.EPI_NONE, None, 0, s))
+        us = time_us(fn) / nrep
+        byt = ws[0][0].stream_bytes
+        out[name] = {"n": n, "k": k, "count": count, "us": round(us, 2), "GBps": round(byt / us / 1e3, 1)}
+        total_us += us * count
+        total_bytes += byt * count
+        for wt, _ in ws:
+            wt.free()
+    return out, total_us, total_bytes
+
+
+res = {}
+# ---- config 4: Mistral-7B NF4 g128 batch 8 (wk/wv are 1024 wide: GQA, QKV not fused — llama.cpp:215) ----
+nl = 32
+shapes = [("wq", 4096, 4096, nl), ("wk", 1024, 4096, nl), ("wv", 1024, 4096, nl), ("wo", 4096, 4096, nl),
+          ("w1", 14336, 4096, nl), ("w3", 14336, 4096, nl), ("w2", 4096, 14336, nl), ("lm_head", 32000, 4096, 1)]
+per, us, byt = chain_time(shapes, pkg.F4_NF4, pkg.BF16, 128, pkg.COMP_BF16, 8)
+res["config4_mistral7b_nf4_g128_batch8"] = {"per_shape": per, "ms_per_step": round(us / 1e3, 4),
+                                            "tokens_per_s": round(8 * 1e6 / us, 1), "weight_bytes": byt,
+                                            "chain_GBps": round(byt / us / 1e3, 1)}
+# ---- config 5: Llama-2-70B Q4_0, one rank of TP = 8 (N or K divided by 8, model_files.h:145-190) ----
+nl = 80
+d, ff, kvd = 8192, 28672, 1024
+shapes = [("wq/8", d // 8, d, nl), ("wk/8", kvd // 8, d, nl), ("wv/8", kvd // 8, d, nl), ("wo/8 (K split)", d, d // 8, nl),
+          ("w1/8", ff // 8, d, nl), ("w3/8", ff // 8, d, nl), ("w2/8 (K split)", d, ff // 8, nl), ("lm_head", 32000, d, 1)]
+per, us, byt = chain_time(shapes, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, 1)
+res["config5_llama70b_q4_0_rank_of_tp8"] = {"per_shape": per, "gemm_ms_per_token_per_rank": round(us / 1e3, 4),
+                                            "weight_bytes_per_rank": byt, "chain_GBps": round(byt / us / 1e3, 1),
+                                            "note": "GEMMs of one rank only; 160 all-reduces of 32 KB per token come on top"}
+# ---- PCIe-inclusive rate of the part-1 host-pointer API ----
+n, k = 11008, 4096
+wt, blob = make(n, k, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, 3)
+hb = blob.cpu().numpy()
+a = np.random.default_rng(1).standard_normal((1, k)).astype(np.float32)
+c = np.zeros((1, n), np.float32)
+f = lambda: L.bestla_f32f32_forward(a.ctypes.data, hb.ctypes.data, c.ctypes.data, 1, n, k, k, n, None)
+for _ in range(5):
+    f()
+t0 = time.perf_counter()
+for _ in range(200):
+    f()
+host_us = (time.perf_counter() - t0) * 1e6 / 200
+ad, cd = torch.from_numpy(a).cuda(), torch.empty((1, n), device="cuda")
+dev_us = time_us(lambda s=None: pkg.check(L.ns_hip_f32f32_forward(ad.data_ptr(), wt.h, cd.data_ptr(), 1, k, n, 0, None, 0,
+                                          s or C.c_void_p(torch.cuda.current_stream().cuda_stream))))
+res["pcie_inclusive_m1_11008x4096"] = {"host_pointer_api_us": round(host_us, 1), "device_resident_us": round(dev_us, 2),
+                                       "weight_GBps_host_api": round(wt.stream_bytes / host_us / 1e3, 1)}
+print(json.dumps(res, indent=1))

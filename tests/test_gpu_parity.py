@@ -218,6 +218,33 @@ def test_forward_ragged_shapes(L, pkg, nso, n, k):
             _check(nso, np.ascontiguousarray(out[:, :n]), a, blob, False)
 
 
+def test_prefill_fp16_shadow_in_and_out(L, pkg, nso):
+    """M > 64 (gemm2_kernel): a caller-provided fp16 activation shadow gives bit-identical results to the internal
+    conversion pass, and the fp16 output shadow equals the rounded fp32 output."""
+    import torch
+    import ctypes as C
+    rng = np.random.default_rng(123)
+    n, k, m, bs = 272, 1024, 150, 32
+    w = _w(rng, n, k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    blob = nso.quant_pack(w, bs, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wt = pkg.Weight.from_host_blob(nso.ptr(blob), st)
+    da = torch.from_numpy(a).cuda()
+    da16 = da.half()
+    c0 = torch.zeros((m, n), device="cuda")
+    c1 = torch.zeros((m, n), device="cuda")
+    c16 = torch.zeros((m, n), device="cuda", dtype=torch.float16)
+    pkg.check(L.ns_hip_f32f32_forward(da.data_ptr(), wt.h, c0.data_ptr(), m, k, n, pkg.EPI_NONE, None, 0, st))
+    pkg.check(L.ns_hip_f32f32_forward_h(da.data_ptr(), da16.data_ptr(), wt.h, c1.data_ptr(), c16.data_ptr(), m, k, n,
+                                        pkg.EPI_NONE, None, 0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1)
+    assert torch.equal(c16, c1.half())
+    _check(nso, c1.cpu().numpy(), a, blob, False)
+    wt.free()
+
+
 def test_forward_lda_and_uniform_distribution(L, pkg, nso):
     rng = np.random.default_rng(77)
     n, k, bs, m = 128, 768, 32, 3
