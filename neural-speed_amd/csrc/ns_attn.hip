@@ -10,12 +10,20 @@
 //            consecutive halves of a V row (coalesced); partitions are summed through LDS at the end
 // fp32 throughout (the reference's NE_ATTN_FLAG_PREFER_FP32 form; its default path rounds Q, K and P to bf16 and is
 // checked against this form at 1e-2 by its own tests, mha_dense_tests.cpp:147).
-// HBM-bound on K and V (2 * sl_kv * head_size * 2 B per query row and kv head); this first version is written for
-// correctness and the decode shape, not yet tuned (no MFMA for long query blocks, no split-K over the context).
+//
+// attn_split_kernel (the fast path: contiguous head dimension, head group of 1/2/4/8): flash-decoding layout.
+//   grid = (context splits, kv heads x query rows, batch).  A workgroup reads each K / V row of its context range ONCE
+//   and serves all `G` query heads that share the kv head (GQA); 16 lanes x 16 B cover one row, so a wave works on 4 keys
+//   and the workgroup on 16 keys at a time, each 16-lane group carrying its own online-softmax state (m, l, acc) — no
+//   communication inside the loop.  States are merged by shuffles inside a wave, through LDS across waves, and across
+//   splits by attn_merge_kernel (plain stores + a kernel boundary: no device-scope fences, which cost an L2 write-back
+//   per XCD on MI355X).  HBM-bound on K and V: 2 * sl_kv * heads_kv * head_size * 2 B per query row.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -147,6 +155,181 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// split-KV kernel
+// ---------------------------------------------------------------------------------------------------------------
+struct AttnSplitParams {
+  AttnParams a;
+  float* ws;       // [batch][sl_q][head][nsplit][2 + head_size] partial (m, l, acc) when nsplit > 1
+  int nsplit;
+  int keys_per_split;
+};
+
+template <int G, int DPL>  // G query heads per kv head; DPL head dims per lane (8: head_size <= 128, 16: <= 256)
+__global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSplitParams sp) {
+  const AttnParams& p = sp.a;
+  __shared__ float ml_s[4][G][2];
+  extern __shared__ float acc_s[];  // [4 waves][G][16 * DPL]
+  const int split = blockIdx.x;
+  const int ihkv = blockIdx.y % p.heads_kv, i = blockIdx.y / p.heads_kv, ibs = blockIdx.z;
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int kg = t >> 4;  // key group 0..15
+  const int dl = l & 15;  // dim lane
+  const int hs = p.head_size;
+  const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
+  const bool alibi = (p.flags & NS_ATTN_FLAG_IS_ALIBI8) != 0;
+  const bool tanh30 = (p.flags & NS_ATTN_FLAG_IS_TANH30) != 0;
+  const int unmasked = causal ? (p.sl_kv - p.sl_q) + i + 1 : p.sl_kv;
+  const int j0 = split * sp.keys_per_split, j1 = min(unmasked, j0 + sp.keys_per_split);
+  const int d0 = dl * DPL;
+  const bool dact = d0 < hs;  // head sizes that are not a multiple of DPL are rejected by the host
+
+  const _Float16* kb = p.k + ibs * p.step_k_bs + ihkv * p.step_k_head_num + d0;
+  const _Float16* vb = p.v + ibs * p.step_v_bs + ihkv * p.step_v_head_num + d0;
+
+  float q[G][DPL], acc[G][DPL], m[G], lsum[G], slope[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const int ihn = ihkv * G + g;
+    const float* qp = p.q + ibs * p.step_q_bs + ihn * p.step_q_head_num + i * p.step_q_sl + d0;
+#pragma unroll
+    for (int e = 0; e < DPL; e++) {
+      q[g][e] = dact ? qp[e] * p.qk_scale : 0.f;
+      acc[g][e] = 0.f;
+    }
+    m[g] = -INFINITY;
+    lsum[g] = 0.f;
+    slope[g] = 0.f;
+    if (alibi)
+      slope[g] = ihn < p.alibi_log2_floor ? powf(p.alibi_m0, float(ihn + 1))
+                                          : powf(p.alibi_m1, float(2 * (ihn - p.alibi_log2_floor) + 1));
+  }
+
+  typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+  for (int j = j0 + kg; j < j1; j += 16) {
+    float kf[DPL], vf[DPL];
+#pragma unroll
+    for (int c = 0; c < DPL / 8; c++) {
+      half8_t kv = half8_t{0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+      if (dact) {
+        kv = *reinterpret_cast<const half8_t*>(kb + (long long)j * p.step_k_sl + 8 * c);
+        vv = *reinterpret_cast<const half8_t*>(vb + (long long)j * p.step_v_sl + 8 * c);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        kf[8 * c + e] = float(kv[e]);
+        vf[8 * c + e] = float(vv[e]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < DPL; e++) s += q[g][e] * kf[e];
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 1, 64);
+      if (tanh30) s = 30.f * tanhf(s * (1.f / 30.f));
+      s += float(j) * slope[g];
+      const float m_new = fmaxf(m[g], s);
+      const float corr = expf(m[g] - m_new), pj = expf(s - m_new);
+      lsum[g] = lsum[g] * corr + pj;
+#pragma unroll
+      for (int e = 0; e < DPL; e++) acc[g][e] = acc[g][e] * corr + pj * vf[e];
+      m[g] = m_new;
+    }
+  }
+
+  // ---- merge the 4 key groups of a wave (lanes with equal dl) by shuffles ----
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float mo = __shfl_xor(m[g], off, 64), lo = __shfl_xor(lsum[g], off, 64);
+      const float mn = fmaxf(m[g], mo);
+      const float ca = mn == -INFINITY ? 0.f : expf(m[g] - mn), cb = mn == -INFINITY ? 0.f : expf(mo - mn);
+      lsum[g] = lsum[g] * ca + lo * cb;
+#pragma unroll
+      for (int e = 0; e < DPL; e++) acc[g][e] = acc[g][e] * ca + __shfl_xor(acc[g][e], off, 64) * cb;
+      m[g] = mn;
+    }
+  }
+  // ---- across the 4 waves through LDS ----
+  if (l < 16) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (l == 0) {
+        ml_s[w][g][0] = m[g];
+        ml_s[w][g][1] = lsum[g];
+      }
+#pragma unroll
+      for (int e = 0; e < DPL; e++) acc_s[(w * G + g) * 16 * DPL + d0 + e] = acc[g][e];
+    }
+  }
+  __syncthreads();
+  // thread (g, d) finishes output dim d of head g
+  for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
+    const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
+    if (dd >= hs) continue;
+    float mb = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++) mb = fmaxf(mb, ml_s[ww][g][0]);
+    float lb = 0.f, ab = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++) {
+      const float c = ml_s[ww][g][0] == -INFINITY ? 0.f : expf(ml_s[ww][g][0] - mb);
+      lb += ml_s[ww][g][1] * c;
+      ab += acc_s[(ww * G + g) * 16 * DPL + dd] * c;
+    }
+    const int ihn = ihkv * G + g;
+    if (sp.nsplit == 1) {
+      float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
+      dst[dd] = ab / lb * p.out_scale;
+    } else {
+      float* wp = sp.ws + ((((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit + split) * (2 + hs);
+      if (dd == 0) {
+        wp[0] = mb;
+        wp[1] = lb;
+      }
+      wp[2 + dd] = ab;
+    }
+  }
+}
+
+// one workgroup of 64 threads per (batch, query row, head): combine the splits' (m, l, acc)
+__global__ void attn_merge_kernel(const AttnSplitParams sp) {
+  const AttnParams& p = sp.a;
+  const int ihn = blockIdx.x, i = blockIdx.y, ibs = blockIdx.z;
+  const int hs = p.head_size;
+  const float* wp = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit * (2 + hs);
+  float mb = -INFINITY;
+  for (int s = 0; s < sp.nsplit; s++) mb = fmaxf(mb, wp[s * (2 + hs)]);
+  float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
+  for (int d = threadIdx.x; d < hs; d += blockDim.x) {
+    float lb = 0.f, ab = 0.f;
+    for (int s = 0; s < sp.nsplit; s++) {
+      const float ms = wp[s * (2 + hs)];
+      const float c = ms == -INFINITY ? 0.f : expf(ms - mb);
+      lb += wp[s * (2 + hs) + 1] * c;
+      ab += wp[s * (2 + hs) + 2 + d] * c;
+    }
+    dst[d] = ab / lb * p.out_scale;
+  }
+}
+
+template <int G>
+static hipError_t launch_split_g(const AttnSplitParams& sp, dim3 grid, hipStream_t st) {
+  const int hs = sp.a.head_size;
+  if (hs <= 128) {
+    hipLaunchKernelGGL((attn_split_kernel<G, 8>), grid, dim3(kAttnThreads), size_t(4) * G * 128 * 4, st, sp);
+  } else {
+    hipLaunchKernelGGL((attn_split_kernel<G, 16>), grid, dim3(kAttnThreads), size_t(4) * G * 256 * 4, st, sp);
+  }
+  return hipGetLastError();
+}
+
 static bool attn_shape_ok(int head_num, int heads_kv, int head_size, int sl_q, int sl_kv, bool causal, std::string* why) {
   if (head_size < 1 || head_size > 256) {
     *why = "attention: head_size must be 1..256";
@@ -196,11 +379,49 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   p.alibi_log2_floor = lf;
   p.alibi_m0 = powf(2.0f, -8.f / float(lf));
   p.alibi_m1 = powf(2.0f, -4.f / float(lf));
-  const dim3 grid(unsigned(a.sl_q), unsigned(a.head_num), unsigned(a.batch_size));
-  if (a.head_num > 65535 || a.batch_size > 65535) {
-    *why = "attention: head_num / batch_size above the grid limit";
+  if (a.head_num > 65535 || a.batch_size > 65535 || size_t(a.heads_kv) * a.sl_q > 65535) {
+    *why = "attention: head_num / batch_size / heads_kv*sl_q above the grid limit";
     return hipErrorInvalidValue;
   }
+  // ---- fast path: contiguous head dimension, 16-byte aligned rows, head group 1/2/4/8 ----
+  static const bool no_split = getenv("NS_ATTN_V1") != nullptr;  // diagnostics
+  const int G = a.head_num / a.heads_kv;
+  const int dpl = a.head_size <= 128 ? 8 : 16;
+  const bool fast = !no_split && (G == 1 || G == 2 || G == 4 || G == 8) && a.step_k_head_size == 1 &&
+                    a.step_v_head_size == 1 && a.head_size % dpl == 0 && a.step_k_sl % 8 == 0 && a.step_v_sl % 8 == 0 &&
+                    a.step_k_head_num % 8 == 0 && a.step_v_head_num % 8 == 0 && a.step_k_bs % 8 == 0 &&
+                    a.step_v_bs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
+  if (fast) {
+    AttnSplitParams sp;
+    sp.a = p;
+    const size_t base_blocks = size_t(a.heads_kv) * a.sl_q * a.batch_size;
+    int nsplit = int((1024 + base_blocks - 1) / base_blocks);          // aim at ~4 workgroups per CU
+    nsplit = std::min(nsplit, std::max(1, (a.sl_kv + 127) / 128));     // at least 128 keys per split
+    nsplit = std::min(nsplit, 64);
+    float* ws = nullptr;
+    if (nsplit > 1) {
+      const size_t bytes = size_t(a.batch_size) * a.sl_q * a.head_num * nsplit * (2 + a.head_size) * 4;
+      ws = static_cast<float*>(stream_scratch(st, bytes, 1));
+      if (!ws) nsplit = 1;  // cannot allocate while the stream is capturing: unsplit, still correct
+    }
+    sp.ws = ws;
+    sp.nsplit = nsplit;
+    sp.keys_per_split = (a.sl_kv + nsplit - 1) / nsplit;
+    const dim3 grid(unsigned(nsplit), unsigned(a.heads_kv * a.sl_q), unsigned(a.batch_size));
+    hipError_t e = G == 1 ? launch_split_g<1>(sp, grid, st)
+                 : G == 2 ? launch_split_g<2>(sp, grid, st)
+                 : G == 4 ? launch_split_g<4>(sp, grid, st)
+                          : launch_split_g<8>(sp, grid, st);
+    if (e != hipSuccess) return e;
+    if (nsplit > 1) {
+      hipLaunchKernelGGL(attn_merge_kernel, dim3(unsigned(a.head_num), unsigned(a.sl_q), unsigned(a.batch_size)), dim3(64), 0,
+                         st, sp);
+      e = hipGetLastError();
+    }
+    return e;
+  }
+  const dim3 grid(unsigned(a.sl_q), unsigned(a.head_num), unsigned(a.batch_size));
   hipLaunchKernelGGL(attn_kernel, grid, dim3(kAttnThreads), 0, st, p);
   return hipGetLastError();
 }

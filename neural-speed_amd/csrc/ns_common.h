@@ -138,7 +138,10 @@ struct SmallMArgs {
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
 // ns_gemm.hip: second-generation prefill GEMM; hipErrorNotSupported = use the first-generation gemm_kernel
 hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st);
-void gemm_scratch_release();  // frees the per-stream fp16 activation scratch buffers
+void gemm_scratch_release();  // frees the per-stream scratch buffers
+// grow-only device scratch per (stream, slot): slot 0 = fp16 copy of A (prefill GEMM), slot 1 = attention partials.
+// Returns nullptr when it would have to (re)allocate while the stream is capturing.
+void* stream_scratch(hipStream_t st, size_t bytes, int slot);
 // ns_decode.hip: persistent stream-K kernel for m <= 4; hipErrorNotSupported = outside its envelope (use smallm)
 hipError_t launch_decode(const SmallMArgs& a, hipStream_t st);
 constexpr int kMaxDecodeGrid = 1024;                             // workgroups (= CUs) the fix-up workspace covers

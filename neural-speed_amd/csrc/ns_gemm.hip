@@ -273,10 +273,10 @@ __global__ void cvt_a16_kernel(const float* __restrict__ a, _Float16* __restrict
 
 // per-stream scratch for the fp16 copy of A (grow-only; never (re)allocated while the stream is capturing)
 static std::mutex g_scratch_mutex;
-static std::map<hipStream_t, std::pair<void*, size_t>> g_scratch;
-static void* scratch_for(hipStream_t st, size_t bytes) {
+static std::map<std::pair<hipStream_t, int>, std::pair<void*, size_t>> g_scratch;
+void* stream_scratch(hipStream_t st, size_t bytes, int slot) {
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
-  auto& e = g_scratch[st];
+  auto& e = g_scratch[{st, slot}];
   if (e.second >= bytes) return e.first;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
@@ -352,7 +352,7 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   } else {
     const size_t bytes = size_t(a.m) * kpad * 2;
     if (bytes >= (size_t(1) << 32)) return hipErrorNotSupported;
-    _Float16* sc = static_cast<_Float16*>(scratch_for(st, bytes));
+    _Float16* sc = static_cast<_Float16*>(stream_scratch(st, bytes, 0));
     if (!sc) return hipErrorNotSupported;
     const size_t units = size_t(a.m) * kpad / 8;
     hipLaunchKernelGGL(cvt_a16_kernel, dim3(unsigned((units + 255) / 256)), dim3(256), 0, st, a.a, sc, a.m, w0->k, a.lda, kpad);

@@ -18,6 +18,9 @@ CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags, k_trans
     (1, 4, 4, 256, 2, 64, 0, False),       # unmasked, largest head
     (1, 8, 8, 128, 4, 260, 1, True),       # transposed K (step_k_head_size = sl_kv)
     (1, 6, 3, 32, 1, 1, 1, False),         # single key
+    (1, 64, 8, 128, 1, 3000, 1, False),    # Llama-2-70B head grouping (8 query heads per kv head)
+    (1, 16, 2, 256, 2, 700, 1, False),     # group of 8 at the largest head size
+    (1, 12, 4, 64, 1, 999, 0, False),      # group of 3: not a fast-path group size -> generic kernel
 ]
 
 
