@@ -155,6 +155,14 @@ constexpr int kMaxNW = 16;  // waves per workgroup: 4, 8 or 16 (runtime, blockDi
 #define NS_PF 4
 #endif
 constexpr int kPF = NS_PF;  // k-steps each wave keeps in flight (codes + scales [+ zero points])
+#ifndef NS_PF_WIDE
+#define NS_PF_WIDE 2
+#endif
+constexpr int kPFWide = NS_PF_WIDE;  // same for the 16-wave variant
+#ifndef NS_A16F_WIDE
+#define NS_A16F_WIDE 0
+#endif
+constexpr bool kA16FirstWide = NS_A16F_WIDE != 0;  // fetch the fp16 shadow ahead of the ring in the 16-wave variant too
 
 struct SmallMParams {
   const float* a;
@@ -215,7 +223,10 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
   constexpr int NJ = (KIND == WK_INT8) ? 2 : 4;
   constexpr int KSTEP = NJ * 32;
   constexpr int NQ = DUAL ? 2 : 1;  // matrices streamed by one workgroup
-  static_assert(kPF % NQ == 0, "ring slots alternate between the two matrices");
+  // ring depth: the 16-wave (WIDE) variant already has 16 x 2 KiB per workgroup in flight and is capped at 128 VGPRs;
+  // a 2-deep ring measured faster there (down projection 9.2 -> 8.6 us) and does not spill
+  constexpr int PF = WIDE ? kPFWide : kPF;
+  static_assert(PF % NQ == 0, "ring slots alternate between the two matrices");
   constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
   using Corr = CorrRaw<SPS, SK, ASYM>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -269,8 +280,8 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
 
   // ring of kPF in-flight items; item t of a wave = (k-step ordinal t / NQ, matrix t % NQ); slot i always holds
   // matrix i % NQ, so every register index below is a compile-time constant
-  uint4v qv[kPF];
-  Corr cr[kPF];
+  uint4v qv[PF];
+  Corr cr[PF];
 
   auto issue = [&](auto slot_c, int s) {
     constexpr int slot = decltype(slot_c)::value;
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
   {                                                               \
     [&]<int... I>(std::integer_sequence<int, I...>) {             \
       (([&] { constexpr int i = I; std::integral_constant<int, I> ic; (void)i; BODY }()), ...); \
-    }(std::make_integer_sequence<int, kPF>{});                    \
+    }(std::make_integer_sequence<int, PF>{});                     \
   }
 
   for (int c0 = 0; c0 < p.ksteps; c0 += p.chunk_steps) {
@@ -344,13 +355,13 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
     // ---- put the wave's first kPF items in flight BEFORE staging A: nothing below depends on them until
     //      compute(), so HBM latency overlaps the staging, the barrier and the other waves.
     //      The common case (nitems >= kPF) issues unconditionally so the compiler knows what is outstanding ----
-    const bool full_pipe = nitems >= kPF;
+    const bool full_pipe = nitems >= PF;
     const int quads = chunk_k >> 2;
     // fp16 shadow available and small enough to sit in two registers per thread: fetch it BEFORE the weight ring so
     // it retires first (vmcnt is in order) and the staging + barrier complete while the weights are in flight
     const int octs = chunk_k >> 3;  // 16-byte units per row
     constexpr int kA16It = 4;
-    const bool a16_first = !WIDE && p.a16 != nullptr && rows * octs <= kA16It * int(blockDim.x) && (p.lda & 7) == 0 &&
+    const bool a16_first = (!WIDE || kA16FirstWide) && p.a16 != nullptr && rows * octs <= kA16It * int(blockDim.x) && (p.lda & 7) == 0 &&
                            ((reinterpret_cast<uintptr_t>(p.a16) & 15) == 0);
     uint4v a16r[kA16It];
     if (a16_first) {
@@ -434,8 +445,8 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
 
     // ---- stream: steady-state rounds consume slot i and refill it kPF items ahead with NO conditions inside, so
     //      the compiler emits counted vmcnt waits instead of draining the queue; the last rounds are peeled ----
-    const int rounds = nitems / kPF, rem = nitems - rounds * kPF;
-    constexpr int SPR = kPF / NQ;  // k-steps per round
+    const int rounds = nitems / PF, rem = nitems - rounds * PF;
+    constexpr int SPR = PF / NQ;  // k-steps per round
     if (full_pipe) {
       int r = 0;
 #ifdef NS_TRACE

@@ -17,6 +17,6 @@ for spec in "$@"; do
     fi
   done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libns_hip_$name.so ns_api.o ns_blob.o $objs ns_quant.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libns_hip_$name.so ns_api.o ns_blob.o $objs ns_attn.o ns_quant.o
   echo built variants/libns_hip_$name.so
 done
