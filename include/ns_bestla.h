@@ -194,6 +194,14 @@ int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_wei
                                  const ns_weight* w3, float* dTmp1, float* dTmp2, void* dTmp2_16, float* dOut,
                                  void* dOut16, int seq, int act, void* stream);
 
+/* activation prologue of the reference's int8-compute path: quantize_fp_u8_colblock
+ * (/root/reference/bestla/bestla/kernel_ref.h:1824-1883, driven by ActivationKBlockQuantize::run, bestla_prologue_a.h:133-154).
+ * dSrc fp32 [row][ld_src] -> dDst u8 [row][ld_dst], per (row, k-block) dScales / dZps [row][ld_scale] and, if not NULL,
+ * dBlkReduce = sum(round(a / scale)) * scale.  Bit-exact with the scalar reference, tail blocks included. */
+int ns_hip_quantize_fp_u8_colblock(int row, int col, const float* dSrc, int ld_src, uint8_t* dDst, int ld_dst,
+                                   float* dScales, int ld_scale, uint8_t* dZps, int blocksize, float* dBlkReduce,
+                                   void* stream);
+
 /* quantize + pack entirely on the device: dW fp32 [N][K] (is_trans) or [K][N]; writes the reference-format blob
  * into dBlob (device memory, ns_BTLAGemmPackBSize bytes, 64-byte aligned) */
 int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, size_t ldb, size_t BlkSize,

@@ -649,6 +649,18 @@ int ns_hip_fusion_ffn2_forward(const float* dA, const ns_weight* w1, const ns_we
   return forward_impl(dTmp1, w2, dOut, seq, fmid, fout, dB2 ? NS_EPI_ADD : NS_EPI_NONE, dB2, broadcast_bias ? 0 : fout, st);
 }
 
+int ns_hip_quantize_fp_u8_colblock(int row, int col, const float* dSrc, int ld_src, uint8_t* dDst, int ld_dst,
+                                   float* dScales, int ld_scale, uint8_t* dZps, int blocksize, float* dBlkReduce,
+                                   void* stream) {
+  if (!have_device()) return -1;
+  if (!dSrc || !dDst || !dScales || !dZps || row < 0 || col < 0 || blocksize <= 0) {
+    set_error("quantize_fp_u8_colblock: invalid argument");
+    return -1;
+  }
+  return hip_ok(launch_aquant_u8(row, col, dSrc, ld_src, dDst, ld_dst, dScales, ld_scale, dZps, blocksize, dBlkReduce,
+                                 (hipStream_t)stream), "activation quantize launch") ? 0 : -1;
+}
+
 int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, size_t ldb, size_t BlkSize,
                              uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType, bool isTrans,
                              void* stream) {

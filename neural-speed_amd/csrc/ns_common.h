@@ -186,6 +186,8 @@ hipError_t launch_pack_q(const PackQArgs& a, hipStream_t st);
 
 hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* out,
                           hipStream_t st);
+hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
+                            int ld_scale, uint8_t* zps, int blocksize, float* blkreduce, hipStream_t st);
 hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float* v, int vstep, float* out, bool mul,
                                hipStream_t st);
 

@@ -389,6 +389,59 @@ __global__ void bcast_kernel(const float* __restrict__ t, const float* __restric
   const float x = t[gid], y = v[b * vstep + i];
   out[gid] = mul ? x * y : x + y;
 }
+// ---- activation side of the int8-compute path: quantize_fp_u8_colblock (kernel_ref.h:1824-1883) ------------------
+// per (row, k-block): min / max including 0 (a full block starts max at FLT_MIN, a tail block at 0 — :1832 vs :1857),
+// scale = (max - min) / 255, zp = u8(-min / scale + 0.5), q = u8(zp + round(a / scale) + 0.5 truncated), optional block
+// sum * scale.  One thread per (row, k-block); every operation rounds like the scalar reference (no FMA contraction).
+__device__ __forceinline__ int cast_f32_u8_x86(float v) {  // bestla_utils.h:515-521: +0.5, clamp, truncate; NaN -> 0
+  if (v != v) return 0;
+  v = __fadd_rn(v, 0.5f);
+  v = v > 255.f ? 255.f : v;
+  v = v < 0.f ? 0.f : v;
+  return int(v);
+}
+__global__ void aquant_u8_kernel(int row, int col, const float* __restrict__ src, int ld_src, uint8_t* __restrict__ dst,
+                                 int ld_dst, float* __restrict__ scales, int ld_scale, uint8_t* __restrict__ zps,
+                                 int blocksize, float* __restrict__ blkreduce) {
+  const int nblk = (col + blocksize - 1) / blocksize;
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= size_t(row) * nblk) return;
+  const int i = int(gid / nblk), kb = int(gid % nblk);
+  const int j = kb * blocksize;
+  const bool tail = j + blocksize > col;
+  const int bs = tail ? col - j : blocksize;
+  const float* s = src + size_t(i) * ld_src + j;
+  float maxval = tail ? 0.f : FLT_MIN, minval = 0.f;
+  for (int ij = 0; ij < bs; ij++) {
+    const float f = s[ij];
+    maxval = f > maxval ? f : maxval;  // std::max(f, maxval): NaN in f keeps maxval
+    minval = f < minval ? f : minval;
+  }
+  const float scale = __fdiv_rn(__fsub_rn(maxval, minval), 255.f);
+  const int zp = cast_f32_u8_x86(__fdiv_rn(__fsub_rn(0.f, minval), scale));
+  const float rscale = __fdiv_rn(1.f, scale);
+  scales[size_t(i) * ld_scale + kb] = scale;
+  zps[size_t(i) * ld_scale + kb] = uint8_t(zp);
+  int sum = 0;
+  const float zpf = float(zp);
+  uint8_t* d = dst + size_t(i) * ld_dst + j;
+  for (int ij = 0; ij < bs; ij++) {
+    const int qtmp = cvt_round_int_x86(__fmul_rn(s[ij], rscale));
+    sum = wrap_add(sum, qtmp);
+    d[ij] = uint8_t(cast_f32_u8_x86(__fadd_rn(zpf, float(qtmp))));
+  }
+  if (blkreduce) blkreduce[size_t(i) * ld_scale + kb] = __fmul_rn(float(sum), scale);
+}
+hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
+                            int ld_scale, uint8_t* zps, int blocksize, float* blkreduce, hipStream_t st) {
+  const int nblk = (col + blocksize - 1) / blocksize;
+  const size_t total = size_t(row) * nblk;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(aquant_u8_kernel, grid1d(total, 128), dim3(128), 0, st, row, col, src, ld_src, dst, ld_dst, scales,
+                     ld_scale, zps, blocksize, blkreduce);
+  return hipGetLastError();
+}
+
 hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float* v, int vstep, float* out, bool mul,
                                hipStream_t st) {
   const size_t total = size_t(batch) * vsize;

@@ -245,6 +245,39 @@ def test_prefill_fp16_shadow_in_and_out(L, pkg, nso):
     wt.free()
 
 
+@pytest.mark.parametrize("m,k,bs", [(1, 4096, 32), (5, 1000, 128), (3, 96, 64), (2, 130, 32)])
+def test_activation_u8_quantize_bit_exact(L, pkg, nso, m, k, bs):
+    """a9: quantize_fp_u8_colblock (kernel_ref.h:1824-1883) on the GPU == the oracle (itself pinned to the reference),
+    byte for byte: codes, scales, zero points, block sums; tail blocks, all-zero and one-sided blocks included."""
+    import torch
+    import ctypes as C
+    rng = np.random.default_rng(m * 31 + k)
+    a = rng.standard_normal((m, k + 3)).astype(np.float32)
+    a[0, : min(k, bs)] = 0.0                       # all-zero block
+    if k >= 2 * bs:
+        a[0, bs:2 * bs] = np.abs(a[0, bs:2 * bs])  # one-sided block (min stays 0)
+    nblk = (k + bs - 1) // bs
+    q = np.zeros((m, k), np.uint8)
+    sc = np.zeros((m, nblk), np.float32)
+    zp = np.zeros((m, nblk), np.uint8)
+    red = np.zeros((m, nblk), np.float32)
+    assert nso.lib().nso_quantize_fp_u8_colblock(m, k, nso.ptr(a), k + 3, nso.ptr(q), k, nso.ptr(sc), nblk, nso.ptr(zp), bs,
+                                                 nso.ptr(red)) == 0
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    da = torch.from_numpy(a).cuda()
+    dq = torch.zeros((m, k), dtype=torch.uint8, device="cuda")
+    dsc = torch.zeros((m, nblk), device="cuda")
+    dzp = torch.zeros((m, nblk), dtype=torch.uint8, device="cuda")
+    dred = torch.zeros((m, nblk), device="cuda")
+    pkg.check(L.ns_hip_quantize_fp_u8_colblock(m, k, da.data_ptr(), k + 3, dq.data_ptr(), k, dsc.data_ptr(), nblk,
+                                               dzp.data_ptr(), bs, dred.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(dq.cpu().numpy(), q)
+    assert np.array_equal(dsc.cpu().numpy().view(np.uint32), sc.view(np.uint32))
+    assert np.array_equal(dzp.cpu().numpy(), zp)
+    assert np.array_equal(dred.cpu().numpy().view(np.uint32), red.view(np.uint32))
+
+
 def test_forward_lda_and_uniform_distribution(L, pkg, nso):
     rng = np.random.default_rng(77)
     n, k, bs, m = 128, 768, 32, 3
