@@ -260,22 +260,36 @@ def main():
 
     step = Step()
 
-    use_graph = not args.no_graph
-    if use_graph and world > 1 and os.environ.get("NS_BENCH_FULL_GRAPH") is None:
-        use_graph = "segments"  # NS_BENCH_FULL_GRAPH=1: try to capture the RCCL all-reduces too
-    try:
-        wall_ms, ev_ms = time_graph(step, args.steps, args.warmup, use_graph, world)
-    except Exception as e:  # graph capture unsupported (e.g. RCCL in capture): fall back to eager launches
-        if not use_graph:
-            raise
-        sys.stderr.write("graph capture failed (%s); falling back to eager launches\n" % str(e).splitlines()[0])
-        use_graph = False
+    # launch modes, most to least ambitious: True = the whole token in one HIP graph (TP: RCCL all-reduces captured too),
+    # "segments" = one graph per GEMM run + eager all-reduces (TP only), False = eager launches.  A failed attempt
+    # falls through to the next mode; every rank takes the same decision (all-reduce of the failure flag).
+    modes = [] if args.no_graph else [True]
+    if world > 1:
+        full = os.environ.get("NS_BENCH_FULL_GRAPH", "0") == "1" and backend == "nccl"
+        modes = ([True] if full and not args.no_graph else []) + ([] if args.no_graph else ["segments"])
+    modes.append(False)
+    wall_ms = ev_ms = None
+    for use_graph in modes:
+        failed, err = 0, None
         try:
-            torch.cuda.synchronize()
-        except Exception:
-            pass
-        pkg.lib().ns_hip_reset_error()  # the invalidated capture leaves a sticky error behind
-        wall_ms, ev_ms = time_graph(step, args.steps, args.warmup, False, world)
+            wall_ms, ev_ms = time_graph(step, args.steps, args.warmup, use_graph, world)
+        except Exception as e:
+            failed, err = 1, e
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            pkg.lib().ns_hip_reset_error()  # an invalidated capture leaves a sticky error behind
+        if world > 1:
+            flag = torch.tensor([failed], device="cuda", dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            failed = int(flag.item())
+        if not failed:
+            break
+        if use_graph is False:
+            raise err if err is not None else RuntimeError("another rank failed")
+        sys.stderr.write("launch mode %r failed (%s); trying the next one\n" %
+                         (use_graph, str(err).splitlines()[0] if err else "on another rank"))
     t = torch.tensor([wall_ms], device="cuda", dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
