@@ -298,23 +298,36 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   }
 }
 
-// one workgroup of 64 threads per (batch, query row, head): combine the splits' (m, l, acc)
-__global__ void attn_merge_kernel(const AttnSplitParams sp) {
+// one workgroup per (batch, query row, head): combine the splits' (m, l, acc).  The per-split (m, l) are fetched by
+// one thread each (one round trip instead of nsplit dependent ones), the weights exp(m_s - m) go through LDS, and the
+// accumulator columns are summed with independent loads.
+__global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams sp) {
   const AttnParams& p = sp.a;
+  __shared__ float c_s[64];
+  __shared__ float l_s[64];
   const int ihn = blockIdx.x, i = blockIdx.y, ibs = blockIdx.z;
-  const int hs = p.head_size;
-  const float* wp = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit * (2 + hs);
-  float mb = -INFINITY;
-  for (int s = 0; s < sp.nsplit; s++) mb = fmaxf(mb, wp[s * (2 + hs)]);
+  const int hs = p.head_size, t = threadIdx.x, ns = sp.nsplit;  // ns <= 64
+  const float* wp = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
+  float ms = -INFINITY, ls = 0.f;
+  if (t < ns) {
+    ms = wp[t * (2 + hs)];
+    ls = wp[t * (2 + hs) + 1];
+  }
+  float mb = ms;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mb = fmaxf(mb, __shfl_xor(mb, off, 64));  // splits live in wave 0 (ns <= 64)
+  if (t < 64) {
+    c_s[t] = (t < ns && ms != -INFINITY) ? expf(ms - mb) : 0.f;
+    l_s[t] = ls;
+  }
+  __syncthreads();
+  float lb = 0.f;
+  for (int s = 0; s < ns; s++) lb += l_s[s] * c_s[s];
   float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
-  for (int d = threadIdx.x; d < hs; d += blockDim.x) {
-    float lb = 0.f, ab = 0.f;
-    for (int s = 0; s < sp.nsplit; s++) {
-      const float ms = wp[s * (2 + hs)];
-      const float c = ms == -INFINITY ? 0.f : expf(ms - mb);
-      lb += wp[s * (2 + hs) + 1] * c;
-      ab += wp[s * (2 + hs) + 2 + d] * c;
-    }
+  for (int d = t; d < hs; d += blockDim.x) {
+    float ab = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < ns; s++) ab += wp[s * (2 + hs) + 2 + d] * c_s[s];
     dst[d] = ab / lb * p.out_scale;
   }
 }
@@ -415,7 +428,7 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
                           : launch_split_g<8>(sp, grid, st);
     if (e != hipSuccess) return e;
     if (nsplit > 1) {
-      hipLaunchKernelGGL(attn_merge_kernel, dim3(unsigned(a.head_num), unsigned(a.sl_q), unsigned(a.batch_size)), dim3(64), 0,
+      hipLaunchKernelGGL(attn_merge_kernel, dim3(unsigned(a.head_num), unsigned(a.sl_q), unsigned(a.batch_size)), dim3(128), 0,
                          st, sp);
       e = hipGetLastError();
     }
