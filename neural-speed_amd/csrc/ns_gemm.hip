@@ -254,20 +254,24 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
     }
 }
 
-// fp32 [m][lda] -> fp16 [m][ld16], columns k..ld16-1 zero
+// fp32 [m][lda] -> fp16 [m][ld16], columns k..ld16-1 zero.  One thread per 8 outputs: two 16-byte loads, one 16-byte store.
 __global__ void cvt_a16_kernel(const float* __restrict__ a, _Float16* __restrict__ out, int m, int k, int lda, int ld16) {
   const size_t idx = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) * 8;
   const size_t total = size_t(m) * ld16;
   if (idx >= total) return;
   const int r = int(idx / ld16), c0 = int(idx % ld16);
+  const float* src = a + size_t(r) * lda + c0;
+  float f[8];
+  if (c0 + 8 <= k && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0) {
+    const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+    f[0] = v0.x, f[1] = v0.y, f[2] = v0.z, f[3] = v0.w, f[4] = v1.x, f[5] = v1.y, f[6] = v1.z, f[7] = v1.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = c0 + e < k ? src[e] : 0.f;
+  }
   half2_t h[4];
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const int c = c0 + 2 * e;
-    const float x = c < k ? a[size_t(r) * lda + c] : 0.f;
-    const float y = c + 1 < k ? a[size_t(r) * lda + c + 1] : 0.f;
-    h[e] = half2_t{(_Float16)x, (_Float16)y};
-  }
+  for (int e = 0; e < 4; e++) h[e] = half2_t{(_Float16)f[2 * e], (_Float16)f[2 * e + 1]};
   *reinterpret_cast<uint4v*>(out + idx) = uint4v{as_u32(h[0]), as_u32(h[1]), as_u32(h[2]), as_u32(h[3])};
 }
 
