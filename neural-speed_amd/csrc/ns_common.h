@@ -147,6 +147,8 @@ hipError_t launch_decode(const SmallMArgs& a, hipStream_t st);
 constexpr int kMaxDecodeGrid = 1024;                             // workgroups (= CUs) the fix-up workspace covers
 constexpr size_t kDecodeWsBytes = size_t(kMaxDecodeGrid) * (2 * 256 + 4);  // per weight: partials + flags
 void srow_rule(const ns_weight* w, int* num, int* den);          // scale row of k-step s = s * num / den
+// the same rule as a branch-free (s * mul) >> shift, verified for every k-step; false = not expressible
+bool srow_params(const ns_weight* w, int* mul, int* shift);
 hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st);  // large-M tiled MFMA GEMM (single segment)
 bool smallm_supported(const ns_weight* w, int m);
 bool smallm_dual_ok(int m);  // the fused gate/up launch handles up to 16 rows

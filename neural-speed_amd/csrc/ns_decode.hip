@@ -590,15 +590,6 @@ static hipError_t launch_decode_s(const DecodeParams& p, uint32_t scale_dt, bool
 #endif
 }
 
-static void f4_lut_planes_d(const _Float16* lut, F4Lut* out) {
-  for (int i = 0; i < 4; i++) out->lo[i] = out->hi[i] = 0;
-  for (int e = 0; e < 16; e++) {
-    unsigned short bits = __builtin_bit_cast(unsigned short, lut[e]);
-    out->lo[e >> 2] |= uint32_t(bits & 0xff) << (8 * (e & 3));
-    out->hi[e >> 2] |= uint32_t(bits >> 8) << (8 * (e & 3));
-  }
-}
-
 static int device_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -689,23 +680,9 @@ hipError_t launch_decode(const SmallMArgs& a, hipStream_t st) {
   p.zstride = w0->zstride;
   p.srows = uint32_t(w0->srows);
   {
-    int num, den;
-    srow_rule(w0, &num, &den);
-    if (num == 0) {
-      p.srow_mul = 0, p.srow_shift = 0;
-    } else if (num == den) {
-      p.srow_mul = 1, p.srow_shift = 0;
-    } else {
-      const int ratio = den / num;
-      if ((ratio & (ratio - 1)) == 0) {
-        p.srow_mul = 1, p.srow_shift = uint32_t(__builtin_ctz(ratio));
-      } else {
-        p.srow_shift = 20;
-        p.srow_mul = uint32_t(((1 << 20) + ratio - 1) / ratio);
-        for (int s = 0; s < w0->ksteps; s++)
-          if (((uint32_t(s) * p.srow_mul) >> 20) != uint32_t(s / ratio)) return hipErrorNotSupported;
-      }
-    }
+    int mul, shift;
+    if (!srow_params(w0, &mul, &shift)) return hipErrorNotSupported;
+    p.srow_mul = uint32_t(mul), p.srow_shift = uint32_t(shift);
   }
   p.maxtl = maxtl;
   p.rshift = rshift;
@@ -721,7 +698,7 @@ hipError_t launch_decode(const SmallMArgs& a, hipStream_t st) {
   p.ldd = a.ldd;
   p.nseg = a.dual ? 1 : a.nseg;
   p.epilogue = a.epilogue;
-  if (w0->kind == WK_F4) f4_lut_planes_d(w0->lut, &p.lut);
+  if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
 #ifdef NS_TRACE
   p.trace = trace_buffer();
 #endif

@@ -189,4 +189,13 @@ __device__ __forceinline__ float epi_gelu(float x) {  // kernel_ref.h:1570-1572
 }
 __device__ __forceinline__ float epi_silu(float x) { return x / (1.f + expf(-x)); }  // kernel_ref.h:1573-1575
 
+// host side: fp16 LUT -> byte planes of F4Lut
+inline void f4_lut_planes(const _Float16* lut, F4Lut* out) {
+  for (int i = 0; i < 4; i++) out->lo[i] = out->hi[i] = 0;
+  for (int e = 0; e < 16; e++) {
+    unsigned short bits = __builtin_bit_cast(unsigned short, lut[e]);
+    out->lo[e >> 2] |= uint32_t(bits & 0xff) << (8 * (e & 3));
+    out->hi[e >> 2] |= uint32_t(bits >> 8) << (8 * (e & 3));
+  }
+}
 }  // namespace ns

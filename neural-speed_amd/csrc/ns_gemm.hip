@@ -326,15 +326,6 @@ static hipError_t launch_gemm2_s(const Gemm2Params& p, uint32_t scale_dt, bool a
   return launch_gemm2_k<KIND, SPS, SK_BF16>(p, asym, grid, lds, st);
 }
 
-static void f4_lut_planes_g(const _Float16* lut, F4Lut* out) {
-  for (int i = 0; i < 4; i++) out->lo[i] = out->hi[i] = 0;
-  for (int e = 0; e < 16; e++) {
-    unsigned short bits = __builtin_bit_cast(unsigned short, lut[e]);
-    out->lo[e >> 2] |= uint32_t(bits & 0xff) << (8 * (e & 3));
-    out->hi[e >> 2] |= uint32_t(bits >> 8) << (8 * (e & 3));
-  }
-}
-
 // hipErrorNotSupported = use the first-generation kernel (no scratch available while capturing, odd strides ...)
 hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   static const bool off = getenv("NS_GEMM_V1") != nullptr;  // diagnostics
@@ -379,29 +370,11 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   p.c16 = static_cast<_Float16*>(a.seg[0].c16);
   p.ldc = a.ldc;
   p.srows = w0->srows;
-  {
-    int num, den;
-    srow_rule(w0, &num, &den);
-    if (num == 0) {
-      p.srow_mul = 0, p.srow_shift = 0;
-    } else if (num == den) {
-      p.srow_mul = 1, p.srow_shift = 0;
-    } else {
-      const int ratio = den / num;
-      if ((ratio & (ratio - 1)) == 0) {
-        p.srow_mul = 1, p.srow_shift = __builtin_ctz(ratio);
-      } else {
-        p.srow_shift = 20;
-        p.srow_mul = ((1 << 20) + ratio - 1) / ratio;
-        for (int s = 0; s < w0->ksteps; s++)
-          if (((s * p.srow_mul) >> 20) != s / ratio) return hipErrorNotSupported;
-      }
-    }
-  }
+  if (!srow_params(w0, &p.srow_mul, &p.srow_shift)) return hipErrorNotSupported;
   p.epilogue = a.epilogue;
   p.d = a.d;
   p.ldd = a.ldd;
-  if (w0->kind == WK_F4) f4_lut_planes_g(w0->lut, &p.lut);
+  if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
   p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
   p.cpx = (p.nbn + 7) / 8;
   const int nbm = (a.m + kG2BM - 1) / kG2BM;

@@ -617,15 +617,6 @@ static hipError_t launch_smallm_s(const SmallMParams& p, bool asym, bool dual, i
   return launch_smallm_a<KIND, SPS, SK_BF16>(p, asym, dual, mb, grid, nw, lds, st);
 }
 
-static void f4_lut_planes(const _Float16* lut, F4Lut* out) {
-  for (int i = 0; i < 4; i++) out->lo[i] = out->hi[i] = 0;
-  for (int e = 0; e < 16; e++) {
-    unsigned short bits = __builtin_bit_cast(unsigned short, lut[e]);
-    out->lo[e >> 2] |= uint32_t(bits & 0xff) << (8 * (e & 3));
-    out->hi[e >> 2] |= uint32_t(bits >> 8) << (8 * (e & 3));
-  }
-}
-
 
 // dual (gate/up) launches need MB == 1; callers split larger M into the unfused path
 bool smallm_dual_ok(int m) { return m <= 16; }
@@ -671,28 +662,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   p.trace = trace_buffer();
 #endif
   p.srows = w0->srows;
-  {
-    int num, den;
-    srow_rule(w0, &num, &den);
-    if (num == 0) {  // one scale row for the whole K
-      p.srow_mul = 0;
-      p.srow_shift = 0;
-    } else if (num == den) {
-      p.srow_mul = 1;
-      p.srow_shift = 0;
-    } else {  // srow = s / ratio, ratio = blocksize / kstep_len: power of two -> shift, else a verified magic multiply
-      const int ratio = den / num;
-      if ((ratio & (ratio - 1)) == 0) {
-        p.srow_mul = 1;
-        p.srow_shift = __builtin_ctz(ratio);
-      } else {
-        p.srow_shift = 20;
-        p.srow_mul = ((1 << 20) + ratio - 1) / ratio;
-        for (int s = 0; s < w0->ksteps; s++)
-          if (((s * p.srow_mul) >> 20) != s / ratio) return hipErrorInvalidValue;
-      }
-    }
-  }
+  if (!srow_params(w0, &p.srow_mul, &p.srow_shift)) return hipErrorInvalidValue;
   p.epilogue = a.epilogue;
   p.d = a.d;
   p.ldd = a.ldd;
@@ -931,7 +901,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
 }
 
-static bool srow_params(const ns_weight* w0, int* mul, int* shift) {
+bool srow_params(const ns_weight* w0, int* mul, int* shift) {
   int num, den;
   srow_rule(w0, &num, &den);
   if (num == 0) {
