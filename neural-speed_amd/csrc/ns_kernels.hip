@@ -685,12 +685,17 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   int nw = 8;
   if (mb == 1) {
     const int target_waves = 2560;
-    // 16-wave workgroups (capped at 128 VGPRs) only where a long K meets few tiles (e.g. the FFN down projection)
-    nw = (grid <= 320 && w0->ksteps >= 64) ? 16 : 8;
+    // 16-wave workgroups where few tiles leave CUs short of waves (FFN down projection, attention output projection;
+    // measured: WO 5.75 -> 5.3 us at 16 waves)
+    const int pf = a.dual ? kPF : kPFWide;  // ring depth of the instantiation that will run
+    nw = (grid <= 320 && w0->ksteps >= 32 && !a.dual) ? 16 : 8;
     while (nw > 2 && grid * (nw / 2) >= target_waves) nw /= 2;
-    while (nw > 2 && w0->ksteps * (a.dual ? 2 : 1) < nw * kPF) nw /= 2;  // keep the ring full
+    while (nw > 2 && w0->ksteps * (a.dual ? 2 : 1) < nw * pf) nw /= 2;  // keep the ring full
   }
   if (env_nw == 8 || env_nw == 4 || env_nw == 2 || (env_nw == 16 && mb == 1)) nw = env_nw;
+  static const int env_nw_plain = getenv("NS_NW_PLAIN") ? atoi(getenv("NS_NW_PLAIN")) : 0;  // diagnostics
+  if (!a.dual && mb == 1 && (env_nw_plain == 2 || env_nw_plain == 4 || env_nw_plain == 8 || env_nw_plain == 16))
+    nw = env_nw_plain;
   // LDS: A chunk (rows x (chunk_k + 8) halves), at most ~64 KiB; and the reduction scratch
   const int kstep = w0->kstep_len;
   int chunk_steps = ((w0->ksteps + nw - 1) / nw) * nw;
