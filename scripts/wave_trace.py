@@ -48,8 +48,12 @@ def flush():
     del z
 
 
-DIMS = {"gateup": (256, 12), "qkv": (256, 12), "down": (256, 12), "wo": (256, 8)}  # grid, waves of the decode launch
-KARG = os.environ.get("NS_TRACE_KARG", "1") == "1"  # slot 7 = "kernargs arrived" (decode_kernel) instead of HW id
+# grid, waves of the decode launch: smallm_kernel (default) or decode_kernel (NS_DECODE_KERNEL=1)
+if os.environ.get("NS_DECODE_KERNEL", "0") == "1":
+    DIMS = {"gateup": (256, 12), "qkv": (256, 12), "down": (256, 12), "wo": (256, 8)}
+else:
+    DIMS = {"gateup": (688, 4), "qkv": (768, 4), "down": (256, 16), "wo": (256, 16)}
+KARG = os.environ.get("NS_DECODE_KERNEL", "0") == "1"  # slot 7 = "kernargs arrived" (decode_kernel) instead of HW id
 LAYERS = 3
 ORDER = ["qkv", "wo", "gateup", "down"]
 
