@@ -194,6 +194,13 @@ int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_wei
                                  const ns_weight* w3, float* dTmp1, float* dTmp2, void* dTmp2_16, float* dOut,
                                  void* dOut16, int seq, int act, void* stream);
 
+/* device-pointer twins of bestla_layernormalization / bestla_mul / bestla_add (ne_bestla.h:79-83; device precedent
+ * bestla_device_rms_norm_f32 / _mul_f32 / _add_f32, ne_bestla.h:99-105): asynchronous on `stream`, capturable */
+int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, float* dOut,
+                              void* stream);
+int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
+int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
+
 /* activation prologue of the reference's int8-compute path: quantize_fp_u8_colblock
  * (/root/reference/bestla/bestla/kernel_ref.h:1824-1883, driven by ActivationKBlockQuantize::run, bestla_prologue_a.h:133-154).
  * dSrc fp32 [row][ld_src] -> dDst u8 [row][ld_dst], per (row, k-block) dScales / dZps [row][ld_scale] and, if not NULL,

@@ -1077,6 +1077,34 @@ static bool host_unary(size_t in_elems, size_t out_elems, const float* in, float
          hip_ok(hipMemcpy(out, dO, out_elems * 4, hipMemcpyDeviceToHost), "D2H");
 }
 
+// device-pointer twins of the three element-wise operators (precedent: bestla_device_rms_norm_f32 / _mul_f32 / _add_f32,
+// ne_bestla.h:99-105): same arithmetic, asynchronous on `stream`, capturable
+int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, float* dOut,
+                              void* stream) {
+  if (!have_device()) return -1;
+  if (!dIn || !dOut || norm_count < 0 || norm_size <= 0) {
+    set_error("layernormalization: invalid argument");
+    return -1;
+  }
+  return hip_ok(launch_rmsnorm(norm_count, norm_size, isrms, epsilon, dIn, dOut, (hipStream_t)stream), "norm launch") ? 0 : -1;
+}
+int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream) {
+  if (!have_device()) return -1;
+  if (!dTensor || !dVector || !dOut || batch < 0 || vsize <= 0) {
+    set_error("mul: invalid argument");
+    return -1;
+  }
+  return hip_ok(launch_bcast_binary(batch, vsize, dTensor, dVector, vstep, dOut, true, (hipStream_t)stream), "mul launch") ? 0 : -1;
+}
+int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream) {
+  if (!have_device()) return -1;
+  if (!dTensor || !dVector || !dOut || batch < 0 || vsize <= 0) {
+    set_error("add: invalid argument");
+    return -1;
+  }
+  return hip_ok(launch_bcast_binary(batch, vsize, dTensor, dVector, vstep, dOut, false, (hipStream_t)stream), "add launch") ? 0 : -1;
+}
+
 void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* FpIn,
                                float* FpOut) {
   const size_t n = size_t(norm_count) * norm_size;

@@ -428,6 +428,21 @@ def test_elementwise_entries(L, pkg, nso):
     assert np.array_equal(out, x * v)
     L.bestla_add(5, 300, nso.ptr(x), nso.ptr(x), 300, nso.ptr(out))
     assert np.array_equal(out, x + x)
+    # device-pointer twins: bit-identical to the host-pointer entries
+    import torch
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dx, dv = torch.from_numpy(x).cuda(), torch.from_numpy(v).cuda()
+    do = torch.zeros_like(dx)
+    pkg.check(L.ns_hip_layernormalization(5, 300, True, 1e-6, dx.data_ptr(), do.data_ptr(), st))
+    L.bestla_layernormalization(5, 300, True, 1e-6, nso.ptr(x), nso.ptr(out))
+    torch.cuda.synchronize()
+    assert np.array_equal(do.cpu().numpy(), out)
+    pkg.check(L.ns_hip_mul(5, 300, dx.data_ptr(), dv.data_ptr(), 0, do.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(do.cpu().numpy(), x * v)
+    pkg.check(L.ns_hip_add(5, 300, dx.data_ptr(), dx.data_ptr(), 300, do.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(do.cpu().numpy(), x + x)
 
 
 # ---------------------------------------------------------------------------------------------- device-resident API
