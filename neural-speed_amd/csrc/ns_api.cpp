@@ -12,7 +12,6 @@
 // file: without a HIP device every compute entry reports an error.
 #include <hip/hip_runtime.h>
 
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -73,8 +72,19 @@ struct PinnedScratch {
     return p;
   }
 };
-PinnedScratch g_ha, g_hc, g_hd;
+PinnedScratch g_ha, g_hc, g_hd, g_ht1, g_ht2;
+Scratch g_s16;  // device fp16 shadow of the FFN intermediate on the zero-copy path
 constexpr size_t kZeroCopyMaxBytes = size_t(2) << 20;  // beyond this the staged-copy path wins
+inline float* mapped(PinnedScratch& s, size_t bytes, float** host) {
+  *host = static_cast<float*>(s.get(bytes));
+  void* d = nullptr;
+  if (!*host || hipHostGetDevicePointer(&d, *host, 0) != hipSuccess) return nullptr;
+  return static_cast<float*>(d);
+}
+inline bool zero_copy_enabled() {
+  static const bool off = getenv("NS_NO_ZERO_COPY") != nullptr;  // diagnostics
+  return !off;
+}
 
 bool hip_ok(hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
@@ -861,8 +871,7 @@ static bool host_forward(float* activation, void* weiptr, float* output, int m, 
     return false;
   }
   const size_t bytes_a = size_t(m) * k * 4, bytes_c = size_t(m) * n * 4, bytes_d = hostD ? size_t(ldd_rows) * n * 4 : 0;
-  static const bool no_zero_copy = getenv("NS_NO_ZERO_COPY") != nullptr;  // diagnostics
-  if (!no_zero_copy && m <= 64 && bytes_a + bytes_c + bytes_d <= kZeroCopyMaxBytes) {
+  if (zero_copy_enabled() && m <= 64 && bytes_a + bytes_c + bytes_d <= kZeroCopyMaxBytes) {
     float* hA = (float*)g_ha.get(bytes_a);
     float* hC = (float*)g_hc.get(bytes_c);
     float* hD = hostD ? (float*)g_hd.get(bytes_d) : nullptr;
@@ -955,6 +964,21 @@ void bestla_fusion_QKV_f32f32_forward(float* activation, void* wqptr, void* wkpt
     v = cached_weight(wvptr);
     ok = q && k && v;
   }
+  if (ok && zero_copy_enabled() && _m <= 64 && size_t(_m) * (size_t(_k) + 3 * size_t(_n)) * 4 <= kZeroCopyMaxBytes) {
+    // small M: A read from / QKV written to pinned device-mapped host memory, one launch + one synchronisation
+    float *hA = nullptr, *hC = nullptr;
+    float* dA = mapped(g_ha, size_t(_m) * _k * 4, &hA);
+    float* dC = mapped(g_hc, size_t(3) * _m * _n * 4, &hC);
+    if (dA && dC) {
+      for (int r = 0; r < _m; r++) memcpy(hA + size_t(r) * _k, activation + size_t(r) * lda, size_t(_k) * 4);
+      ok = ns_hip_fusion_qkv_forward(dA, q, k, v, dC, _m, _k, _n, nullptr) == 0 && hip_ok(hipStreamSynchronize(nullptr), "synchronize");
+      if (ok)
+        for (int r = 0; r < 3 * _m; r++) memcpy(output + size_t(r) * ldo, hC + size_t(r) * _n, size_t(_n) * 4);
+      if (!ok) invalid_parameters("bestla_fusion_QKV_f32f32_forward");
+      return;
+    }
+    (void)hipGetLastError();
+  }
   if (ok) {
     float* dA = (float*)g_sa.get(size_t(_m) * _k * 4);
     float* dC = (float*)g_sc.get(size_t(3) * _m * _n * 4);
@@ -992,6 +1016,30 @@ static void ffn3_forward(const char* who, float* activation, void* w1ptr, void* 
     w2 = cached_weight(w2ptr);
     w3 = cached_weight(w3ptr);
     ok = w1 && w2 && w3;
+  }
+  if (ok && zero_copy_enabled() && smallm_dual_ok(seq) &&
+      size_t(seq) * (size_t(fin) + 2 * size_t(fmid) + size_t(fout)) * 4 <= kZeroCopyMaxBytes) {
+    // small M: every host-visible tensor lives in pinned device-mapped memory; the down projection reads the fp16
+    // shadow of tmp2 that the gate/up epilogue leaves in HBM, so nothing but A crosses PCIe towards the GPU
+    float *hA = nullptr, *hT1 = nullptr, *hT2 = nullptr, *hO = nullptr;
+    float* dA = mapped(g_ha, size_t(seq) * fin * 4, &hA);
+    float* dT1 = mapped(g_ht1, size_t(seq) * fmid * 4, &hT1);
+    float* dT2 = mapped(g_ht2, size_t(seq) * fmid * 4, &hT2);
+    float* dO = mapped(g_hc, size_t(seq) * fout * 4, &hO);
+    void* d16 = g_s16.get(size_t(seq) * fmid * 2);
+    if (dA && dT1 && dT2 && dO && d16 && (fmid & 7) == 0) {
+      memcpy(hA, activation, size_t(seq) * fin * 4);
+      ok = ns_hip_fusion_ffn3_forward_h(dA, nullptr, w1, w2, w3, dT1, dT2, d16, dO, nullptr, seq, act, nullptr) == 0 &&
+           hip_ok(hipStreamSynchronize(nullptr), "synchronize");
+      if (ok) {
+        memcpy(output, hO, size_t(seq) * fout * 4);
+        if (tmp1) memcpy(tmp1, hT1, size_t(seq) * fmid * 4);
+        if (tmp2) memcpy(tmp2, hT2, size_t(seq) * fmid * 4);
+      }
+      if (!ok) invalid_parameters(who);
+      return;
+    }
+    (void)hipGetLastError();
   }
   if (ok) {
     float* dA = (float*)g_sa.get(size_t(seq) * fin * 4);
