@@ -199,6 +199,13 @@ int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_wei
 int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, float* dOut,
                               void* stream);
 int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
+/* RoPE on a contiguous fp32 tensor [batch][seq][heads][head_size] (in place when dDst == dSrc):
+ * ne_compute_forward_rope_f32, /root/reference/neural_speed/core/ne_layers.c:9243-9428 (device precedent
+ * bestla_device_rope_f32, ne_bestla.h:106).  mode 0 = adjacent pairs over the whole row, mode 2 = NeoX halves;
+ * freq_scale is the reciprocal already (1 / op_params[1]); ext_factor must be 0 (GLM, long-rope, shift and the YaRN
+ * mix are refused). */
+int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                    int mode, float freq_base, float freq_scale, float ext_factor, float attn_factor, void* stream);
 int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
 
 /* activation prologue of the reference's int8-compute path: quantize_fp_u8_colblock

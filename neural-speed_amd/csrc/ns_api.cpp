@@ -1182,6 +1182,21 @@ int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float e
   }
   return hip_ok(launch_rmsnorm(norm_count, norm_size, isrms, epsilon, dIn, dOut, (hipStream_t)stream), "norm launch") ? 0 : -1;
 }
+int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                    int mode, float freq_base, float freq_scale, float ext_factor, float attn_factor, void* stream) {
+  if (!have_device()) return -1;
+  if (!dSrc || !dDst || batch < 0 || seq < 0 || heads < 0 || head_size <= 0 || (head_size & 1) || n_dims <= 0 ||
+      (n_dims & 1) || n_dims > head_size || n_past < 0) {
+    set_error("rope: invalid argument");
+    return -1;
+  }
+  if ((mode & ~2) != 0 || ext_factor != 0.f) {
+    set_error("rope: only modes 0 and 2 (NeoX) without YaRN extrapolation are implemented (no GLM / long-rope / shift)");
+    return -1;
+  }
+  return hip_ok(launch_rope(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, mode, freq_base, freq_scale, attn_factor,
+                            (hipStream_t)stream), "rope launch") ? 0 : -1;
+}
 int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream) {
   if (!have_device()) return -1;
   if (!dTensor || !dVector || !dOut || batch < 0 || vsize <= 0) {

@@ -442,6 +442,56 @@ hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint
   return hipGetLastError();
 }
 
+// ---- RoPE: ne_compute_forward_rope_f32 (ne_layers.c:9243-9428), modes 0 and 2 (NeoX), ext_factor == 0 -------------
+// one thread per rotated pair; theta = p * theta_scale^idx built by the same sequential fp32 products as the reference
+// (this file is compiled with -ffp-contract=off), so only cosf / sinf differ from the CPU libm in the last ulp
+__global__ void rope_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int heads, int seq,
+                            int head_size, int n_past, int n_dims, int neox, float theta_scale, float freq_scale,
+                            float attn_factor) {
+  const int half = head_size / 2;  // pairs per row in both modes ((head_size / n_dims) * (n_dims / 2) for NeoX)
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(half);
+  if (gid >= rows * npairs) return;
+  const size_t row = gid / npairs;
+  const int pr = int(gid % npairs);
+  const int i2 = int((row / heads) % seq);
+  float theta_base = float(n_past + i2);
+  if (neox) theta_base = __fmul_rn(theta_base, freq_scale);
+  for (int t = 0; t < pr; t++) theta_base = __fmul_rn(theta_base, theta_scale);
+  const float theta = __fmul_rn(freq_scale, theta_base);
+  const float c = __fmul_rn(cosf(theta), attn_factor), s = __fmul_rn(sinf(theta), attn_factor);
+  int ia, ib;
+  if (neox) {
+    const int blk = pr / (n_dims / 2), ic = pr % (n_dims / 2);
+    ia = blk * n_dims + ic;
+    ib = ia + n_dims / 2;
+  } else {
+    ia = 2 * pr;
+    ib = ia + 1;
+  }
+  const float* x = src + row * head_size;
+  float* y = dst + row * head_size;
+  const float x0 = x[ia], x1 = x[ib];
+  y[ia] = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s));
+  y[ib] = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
+}
+hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                       int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st) {
+  const size_t rows = size_t(batch) * seq * heads;
+  if (rows == 0) return hipSuccess;
+  const bool neox = (mode & 2) != 0;
+  // dims the NeoX loop does not visit (head_size not a multiple of n_dims) keep their value
+  if (dst != src && neox && head_size % n_dims != 0) {
+    const hipError_t e = hipMemcpyAsync(dst, src, rows * head_size * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return e;
+  }
+  const float theta_scale = powf(freq_base, -2.0f / n_dims);
+  const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(head_size / 2);
+  hipLaunchKernelGGL(rope_kernel, grid1d(rows * npairs, 256), dim3(256), 0, st, src, dst, rows, heads, seq, head_size, n_past,
+                     n_dims, neox ? 1 : 0, theta_scale, freq_scale, attn_factor);
+  return hipGetLastError();
+}
+
 hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float* v, int vstep, float* out, bool mul,
                                hipStream_t st) {
   const size_t total = size_t(batch) * vsize;

@@ -843,6 +843,48 @@ int nso_gemm_u8s8_f32(const float* a, int lda, const void* blob, float* c, int l
 float nso_gelu(float x) { return 0.5f * x * (1.f + tanhf(0.7978845834732056f * (x + 0.044714998453855515f * x * x * x))); }
 float nso_silu(float x) { return float(x / (1 + exp(-x))); }
 
+// ne_compute_forward_rope_f32 — ne_layers.c:9243-9428 (see ns_oracle.h for the covered modes)
+int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                 int mode, float freq_base, float freq_scale, float attn_factor) {
+  if ((mode & ~2) != 0 || n_dims > head_size || (n_dims & 1) || n_dims <= 0) return -1;
+  const bool is_neox = (mode & 2) != 0;
+  const float theta_scale = powf(freq_base, -2.0f / n_dims);  // :9300
+  for (int i3 = 0; i3 < batch; i3++)
+    for (int i2 = 0; i2 < seq; i2++) {
+      const int p = n_past + i2;  // :9316 (mode & 1 == 0)
+      for (int i1 = 0; i1 < heads; i1++) {
+        const size_t row = ((size_t(i3) * seq + i2) * heads + i1) * head_size;
+        const float* x = src + row;
+        float* y = dst + row;
+        memcpy(y, x, size_t(head_size) * 4);  // dims not touched by the NeoX loop keep their value (dst == src in-place)
+        float theta_base = float(p);
+        if (!is_neox) {  // :9379-9395
+          for (int i0 = 0; i0 < head_size; i0 += 2) {
+            const float theta = freq_scale * theta_base;  // rope_yarn, ext_factor == 0 (:9207-9217)
+            const float c = cosf(theta) * attn_factor, s_ = sinf(theta) * attn_factor;
+            theta_base *= theta_scale;
+            const float x0 = x[i0], x1 = x[i0 + 1];
+            y[i0] = x0 * c - x1 * s_;
+            y[i0 + 1] = x0 * s_ + x1 * c;
+          }
+        } else {  // :9396-9423
+          theta_base = theta_base * freq_scale;
+          for (int ib = 0; ib < head_size / n_dims; ib++)
+            for (int ic = 0; ic < n_dims; ic += 2) {
+              const float theta = freq_scale * theta_base;
+              const float c = cosf(theta) * attn_factor, s_ = sinf(theta) * attn_factor;
+              theta_base *= theta_scale;
+              const int i0 = ib * n_dims + ic / 2;
+              const float x0 = x[i0], x1 = x[i0 + n_dims / 2];
+              y[i0] = x0 * c - x1 * s_;
+              y[i0 + n_dims / 2] = x0 * s_ + x1 * c;
+            }
+        }
+      }
+    }
+  return 0;
+}
+
 // bestla_fusion_attn_forward_ref — mha_dense_wrapper.h:1371-1517 (PLAIN layouts; fp32 accumulation in the loop order
 // of the reference: scores j ascending / k ascending, then exp, then P.V k ascending)
 int nso_attn_ref(const nso_attn_args* a, int bf16_gemm) {

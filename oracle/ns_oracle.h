@@ -153,6 +153,14 @@ typedef struct nso_attn_args {
 } nso_attn_args;
 int nso_attn_ref(const nso_attn_args* a, int bf16_gemm);
 
+/* RoPE — ne_compute_forward_rope_f32, neural_speed/core/ne_layers.c:9243-9428, for contiguous fp32 tensors
+ * [batch][seq][heads][head_size], modes 0 (adjacent pairs over the whole row) and 2 (NeoX halves inside n_dims-wide
+ * blocks), ext_factor = 0 (no YaRN mix), no GLM / long-rope / shift.  theta is the reference's sequential fp32 product
+ * (theta *= theta_scale per pair); the NeoX branch applies freq_scale twice, as the reference does (:9398 + :9207).
+ * PARITY UNPINNED (ne_layers.c does not compile standalone); checked against an fp64 closed form. */
+int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                 int mode, float freq_base, float freq_scale, float attn_factor);
+
 #ifdef __cplusplus
 }
 #endif

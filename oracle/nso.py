@@ -265,6 +265,17 @@ def attn_ref(q, k, v, qk_scale, flags=0, k_trans=False, bf16_gemm=False, scales=
     return dst
 
 
+def rope_f32(x, n_past, n_dims, mode, freq_base=10000.0, freq_scale=1.0, attn_factor=1.0):
+    """x fp32 [batch][seq][heads][head_size] -> rotated copy (ne_compute_forward_rope_f32 restatement)."""
+    x = np.ascontiguousarray(x, np.float32)
+    b, s, h, hs = x.shape
+    out = np.zeros_like(x)
+    rc = lib().nso_rope_f32(ptr(x), ptr(out), b, s, h, hs, n_past, n_dims, mode, C.c_float(freq_base), C.c_float(freq_scale),
+                            C.c_float(attn_factor))
+    assert rc == 0
+    return out
+
+
 def gemm_u8s8(a, blob):
     a = np.ascontiguousarray(a, dtype=np.float32)
     bi = parse(blob)

@@ -1,0 +1,67 @@
+"""RoPE (ne_compute_forward_rope_f32, ne_layers.c:9243-9428): the oracle's restatement against an fp64 closed form on
+CPU, and the GPU kernel against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _closed_form(x, n_past, n_dims, mode, base, fscale, attn):
+    b, s, h, hs = x.shape
+    y = x.astype(np.float64).copy()
+    xs = x.astype(np.float64)
+    ts = float(np.float32(base)) ** (-2.0 / n_dims)
+    for i2 in range(s):
+        p = float(n_past + i2)
+        if mode == 0:
+            idx = np.arange(hs // 2)
+            th = fscale * p * ts ** idx
+            c, sn = np.cos(th) * attn, np.sin(th) * attn
+            x0, x1 = xs[:, i2, :, 0::2], xs[:, i2, :, 1::2]
+            y[:, i2, :, 0::2] = x0 * c - x1 * sn
+            y[:, i2, :, 1::2] = x0 * sn + x1 * c
+        else:
+            k = 0
+            for ib in range(hs // n_dims):
+                for ic in range(0, n_dims, 2):
+                    th = fscale * (p * fscale) * ts ** k   # the reference applies freq_scale twice in this branch
+                    k += 1
+                    i0 = ib * n_dims + ic // 2
+                    x0, x1 = xs[:, i2, :, i0], xs[:, i2, :, i0 + n_dims // 2]
+                    y[:, i2, :, i0] = x0 * np.cos(th) * attn - x1 * np.sin(th) * attn
+                    y[:, i2, :, i0 + n_dims // 2] = x0 * np.sin(th) * attn + x1 * np.cos(th) * attn
+    return y
+
+
+CASES = [(1, 1, 32, 128, 17, 128, 0, 10000.0, 1.0, 1.0), (2, 5, 4, 64, 0, 64, 2, 10000.0, 1.0, 1.0),
+         (1, 3, 8, 128, 2000, 64, 2, 1000000.0, 0.25, 1.3), (1, 4, 2, 80, 9, 80, 0, 10000.0, 0.5, 1.0)]
+
+
+@pytest.mark.parametrize("b,s,h,hs,n_past,n_dims,mode,base,fscale,attn", CASES)
+def test_rope_oracle_matches_closed_form(nso, b, s, h, hs, n_past, n_dims, mode, base, fscale, attn):
+    x = np.random.default_rng(hs + n_past).standard_normal((b, s, h, hs)).astype(np.float32)
+    ref = _closed_form(x, n_past, n_dims, mode, base, fscale, attn)
+    out = nso.rope_f32(x, n_past, n_dims, mode, base, fscale, attn)
+    # sequential fp32 theta products + fp32 sin/cos at |theta| up to a few thousand: ~1e-4 absolute at worst
+    assert np.max(np.abs(out - ref)) < 2e-3
+    assert nso.rel_l2(out, ref) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,s,h,hs,n_past,n_dims,mode,base,fscale,attn", CASES)
+def test_rope_gpu_matches_oracle(L, pkg, nso, b, s, h, hs, n_past, n_dims, mode, base, fscale, attn):
+    import torch
+    x = np.random.default_rng(hs * 3 + n_past).standard_normal((b, s, h, hs)).astype(np.float32)
+    ref = nso.rope_f32(x, n_past, n_dims, mode, base, fscale, attn)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.zeros_like(dx)
+    pkg.check(L.ns_hip_rope_f32(dx.data_ptr(), dy.data_ptr(), b, s, h, hs, n_past, n_dims, mode, base, fscale, 0.0, attn, st))
+    pkg.check(L.ns_hip_rope_f32(dx.data_ptr(), dx.data_ptr(), b, s, h, hs, n_past, n_dims, mode, base, fscale, 0.0, attn, st))
+    torch.cuda.synchronize()
+    out = dy.cpu().numpy()
+    assert np.array_equal(out, dx.cpu().numpy())  # in place == out of place
+    # same theta bit for bit; only the device sinf / cosf differ from the host libm
+    assert np.max(np.abs(out - ref)) < 1e-5 * max(1.0, float(np.abs(x).max()))
+    # unsupported modes are refused loudly
+    assert L.ns_hip_rope_f32(dx.data_ptr(), dy.data_ptr(), b, s, h, hs, n_past, n_dims, 4, base, fscale, 0.0, attn, st) != 0
