@@ -199,6 +199,11 @@ int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_wei
 int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, float* dOut,
                               void* stream);
 int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
+/* layernormalization fused with the multiplication by the norm weight that follows it in every model graph
+ * (dGamma [norm_size], may be NULL) and with the fp16 shadow of the result (dOut16, may be NULL) that the "_h" GEMM
+ * entries read.  Same arithmetic as the two separate operators (the product is rounded separately). */
+int ns_hip_norm_mul_h(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, const float* dGamma,
+                      float* dOut, void* dOut16, void* stream);
 /* RoPE on a contiguous fp32 tensor [batch][seq][heads][head_size] (in place when dDst == dSrc):
  * ne_compute_forward_rope_f32, /root/reference/neural_speed/core/ne_layers.c:9243-9428 (device precedent
  * bestla_device_rope_f32, ne_bestla.h:106).  mode 0 = adjacent pairs over the whole row, mode 2 = NeoX halves;
@@ -207,6 +212,16 @@ int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector,
 int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                     int mode, float freq_base, float freq_scale, float ext_factor, float attn_factor, void* stream);
 int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
+
+/* RoPE of Q (in place, [seq][heads][head_size]) and of K ([seq][heads_kv][head_size]) fused with the kv-cache append:
+ * rotated K and V are stored as fp16 at cache positions n_past .. n_past+seq-1; cache element (position, head, e) lives
+ * at position*cache_step_sl + head*cache_step_head + e.  One launch for ne_rope(q), ne_rope(k) and the two kv-cache
+ * copies of the llama graph (/root/reference/neural_speed/models/llama/llama.cpp:232-262); same arithmetic as
+ * ns_hip_rope_f32 followed by a float->half conversion.  Batch 1. */
+int ns_hip_rope_qkv_append(float* dQ, const float* dK, const float* dV, void* dKcache16, void* dVcache16, int seq, int heads,
+                           int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base, float freq_scale,
+                           float ext_factor, float attn_factor, long long cache_step_sl, long long cache_step_head,
+                           void* stream);
 
 /* activation prologue of the reference's int8-compute path: quantize_fp_u8_colblock
  * (/root/reference/bestla/bestla/kernel_ref.h:1824-1883, driven by ActivationKBlockQuantize::run, bestla_prologue_a.h:133-154).
@@ -270,7 +285,8 @@ typedef struct attn_fp32_fp16_fp16_fp32_fwd_args_t {
   int step_dst_bs, step_dst_head_num, step_dst_sl;
 } attn_fp32_fp16_fp16_fp32_fwd_args_t; /* mha_dense.h:66-81 */
 
-/* mha_dense.h:27: scratch the CALLER allocates; this backend keeps its scratch in registers / LDS */
+/* mha_dense.h:27: scratch the CALLER allocates (`tmp`).  Here: the partial (max, sum, accumulator) records of the
+ * context splits; the device entry below uses `tmp` as DEVICE memory of this size when it is not NULL */
 size_t bestla_fusion_attn_workspace_size(const attn_shape_t* params);
 /* mha_dense.h:85-86.  Host pointers: Q/K/V are uploaded, dst downloaded, synchronous (reference semantics). */
 bool bestla_fusion_attn_fp32_fp16_fp16_fp32_support(const attn_shape_t* params);

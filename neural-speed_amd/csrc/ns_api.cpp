@@ -1182,6 +1182,16 @@ int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float e
   }
   return hip_ok(launch_rmsnorm(norm_count, norm_size, isrms, epsilon, dIn, dOut, (hipStream_t)stream), "norm launch") ? 0 : -1;
 }
+int ns_hip_norm_mul_h(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, const float* dGamma,
+                      float* dOut, void* dOut16, void* stream) {
+  if (!have_device()) return -1;
+  if (!dIn || !dOut || norm_count < 0 || norm_size <= 0) {
+    set_error("norm_mul: invalid argument");
+    return -1;
+  }
+  return hip_ok(launch_rmsnorm(norm_count, norm_size, isrms, epsilon, dIn, dOut, (hipStream_t)stream, dGamma, dOut16),
+                "norm launch") ? 0 : -1;
+}
 int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                     int mode, float freq_base, float freq_scale, float ext_factor, float attn_factor, void* stream) {
   if (!have_device()) return -1;
@@ -1196,6 +1206,24 @@ int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int head
   }
   return hip_ok(launch_rope(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, mode, freq_base, freq_scale, attn_factor,
                             (hipStream_t)stream), "rope launch") ? 0 : -1;
+}
+int ns_hip_rope_qkv_append(float* dQ, const float* dK, const float* dV, void* dKcache16, void* dVcache16, int seq, int heads,
+                           int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base, float freq_scale,
+                           float ext_factor, float attn_factor, long long cache_step_sl, long long cache_step_head,
+                           void* stream) {
+  if (!have_device()) return -1;
+  if (!dQ || !dK || !dV || !dKcache16 || !dVcache16 || seq < 0 || heads <= 0 || heads_kv <= 0 || head_size <= 0 ||
+      (head_size & 1) || n_dims <= 0 || (n_dims & 1) || n_dims > head_size || n_past < 0) {
+    set_error("rope_qkv_append: invalid argument");
+    return -1;
+  }
+  if ((mode & ~2) != 0 || ext_factor != 0.f || ((mode & 2) && head_size % n_dims != 0)) {
+    set_error("rope_qkv_append: only modes 0 and 2 (NeoX, head_size a multiple of n_dims) without YaRN extrapolation");
+    return -1;
+  }
+  return hip_ok(launch_rope_qkv_append(dQ, dK, dV, dKcache16, dVcache16, seq, heads, heads_kv, head_size, n_past, n_dims, mode,
+                                       freq_base, freq_scale, attn_factor, cache_step_sl, cache_step_head,
+                                       (hipStream_t)stream), "rope/kv-append launch") ? 0 : -1;
 }
 int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream) {
   if (!have_device()) return -1;

@@ -343,6 +343,18 @@ static hipError_t launch_split_g(const AttnSplitParams& sp, dim3 grid, hipStream
   return hipGetLastError();
 }
 
+// context splits of the fast path for a shape (1 = unsplit) — shared by the launcher and the workspace-size query
+static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv) {
+  const size_t base_blocks = size_t(heads_kv) * sl_q * batch;
+  int nsplit = int((1024 + base_blocks - 1) / base_blocks);       // aim at ~4 workgroups per CU
+  nsplit = std::min(nsplit, std::max(1, (sl_kv + 127) / 128));    // at least 128 keys per split
+  return std::min(nsplit, 64);
+}
+static size_t attn_ws_bytes(int batch, int head_num, int heads_kv, int head_size, int sl_q, int sl_kv) {
+  const int ns = attn_nsplit(batch, heads_kv, sl_q, sl_kv);
+  return ns > 1 ? size_t(batch) * sl_q * head_num * ns * (2 + head_size) * 4 : 0;
+}
+
 static bool attn_shape_ok(int head_num, int heads_kv, int head_size, int sl_q, int sl_kv, bool causal, std::string* why) {
   if (head_size < 1 || head_size > 256) {
     *why = "attention: head_size must be 1..256";
@@ -363,7 +375,8 @@ static bool attn_shape_ok(int head_num, int heads_kv, int head_size, int sl_q, i
   return true;
 }
 
-static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipStream_t st, std::string* why) {
+static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipStream_t st, std::string* why,
+                              bool device_tmp) {
   if (a.Q_layout != ATTN_FWD_LAYOUT_PLAIN || a.K_layout != ATTN_FWD_LAYOUT_PLAIN || a.V_layout != ATTN_FWD_LAYOUT_PLAIN ||
       a.dst_layout != ATTN_FWD_LAYOUT_PLAIN) {
     *why = "attention: only ATTN_FWD_LAYOUT_PLAIN tensors are supported";
@@ -408,14 +421,14 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   if (fast) {
     AttnSplitParams sp;
     sp.a = p;
-    const size_t base_blocks = size_t(a.heads_kv) * a.sl_q * a.batch_size;
-    int nsplit = int((1024 + base_blocks - 1) / base_blocks);          // aim at ~4 workgroups per CU
-    nsplit = std::min(nsplit, std::max(1, (a.sl_kv + 127) / 128));     // at least 128 keys per split
-    nsplit = std::min(nsplit, 64);
+    int nsplit = attn_nsplit(a.batch_size, a.heads_kv, a.sl_q, a.sl_kv);
     float* ws = nullptr;
     if (nsplit > 1) {
-      const size_t bytes = size_t(a.batch_size) * a.sl_q * a.head_num * nsplit * (2 + a.head_size) * 4;
-      ws = static_cast<float*>(stream_scratch(st, bytes, 1));
+      // partials go to the caller's workspace (`tmp`, sized by bestla_fusion_attn_workspace_size: the reference's own
+      // contract, and the only choice that works on a stream being captured for the first time); without one, to a
+      // grow-only per-stream scratch
+      ws = device_tmp ? reinterpret_cast<float*>(a.tmp) : nullptr;
+      if (!ws) ws = static_cast<float*>(stream_scratch(st, attn_ws_bytes(a.batch_size, a.head_num, a.heads_kv, a.head_size, a.sl_q, a.sl_kv), 1));
       if (!ws) nsplit = 1;  // cannot allocate while the stream is capturing: unsplit, still correct
     }
     sp.ws = ws;
@@ -450,9 +463,9 @@ using namespace ns;  // NOLINT
 
 extern "C" {
 
-size_t bestla_fusion_attn_workspace_size(const attn_shape_t* params) {
-  (void)params;
-  return 64;  // the kernel needs no caller scratch; non-zero so that callers that allocate it get a valid pointer
+size_t bestla_fusion_attn_workspace_size(const attn_shape_t* s) {
+  // (m, l, acc) partials of the context splits; 64 bytes minimum so that callers always get a valid pointer
+  return std::max<size_t>(64, attn_ws_bytes(s->batch_size, s->head_num, s->heads_kv, s->head_size, s->sl_q, s->sl_kv));
 }
 
 bool bestla_fusion_attn_fp32_fp16_fp16_fp32_support(const attn_shape_t* s) {
@@ -469,7 +482,8 @@ bool bestla_reordered_attn_fp32_support(const attn_shape_t* params) {
 
 int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* a, void* stream) {
   std::string why;
-  const hipError_t e = launch_attn(*a, static_cast<hipStream_t>(stream), &why);
+  // device API: `tmp`, when given, is DEVICE memory of bestla_fusion_attn_workspace_size(shape) bytes
+  const hipError_t e = launch_attn(*a, static_cast<hipStream_t>(stream), &why, a->tmp != nullptr);
   if (e != hipSuccess) {
     set_error(why.empty() ? std::string("attention launch: ") + hipGetErrorString(e) : why);
     return -1;
@@ -506,6 +520,7 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
     a.K = static_cast<uint16_t*>(dk);
     a.V = static_cast<uint16_t*>(dv);
     a.dst = static_cast<float*>(dd);
+    a.tmp = nullptr;  // the caller's tmp is host memory: partials go to the internal device scratch
     ok = ns_hip_attn_fp32_fp16_fp16_fp32_forward(&a, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
          hipMemcpy(hp->dst, dd, nd * 4, hipMemcpyDeviceToHost) == hipSuccess;
   } else {

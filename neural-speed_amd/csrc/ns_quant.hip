@@ -348,16 +348,37 @@ hipError_t launch_pack_q(const PackQArgs& a, hipStream_t st) {
 // element-wise members of the operator surface (ne_bestla.h:71-75)
 // ============================================================================================================
 // layernorm / rmsnorm — kernel_ref.h:2199-2245 semantics (no scale/bias at this entry: BTLALayerNorm passes nullptr)
+// optional fusions for a device-resident layer: gamma (the ne_mul by the norm weight that always follows, llama.cpp) and
+// an fp16 shadow of the result for the next GEMV's activations.
+// One workgroup per row.  Rows of up to 256 * 16 floats (every decoder width up to 4096) are read ONCE with all loads
+// in flight together and kept in registers; a single-workgroup kernel is latency-bound, a load-per-iteration loop took
+// 16 us per 4096-wide row.
+template <bool CACHED>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ in, float* __restrict__ out, int size,
-                                                   bool rms, float eps) {
+                                                   bool rms, float eps, const float* __restrict__ gamma,
+                                                   _Float16* __restrict__ out16) {
   __shared__ float red[2][4];
   const float* src = in + size_t(blockIdx.x) * size;
   float* dst = out + size_t(blockIdx.x) * size;
+  float4 v[4];
   float s = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < size; i += 256) {
-    const float v = src[i];
-    s += v;
-    s2 += v * v;
+  if constexpr (CACHED) {  // size % 4 == 0, size <= 4096, 16-byte aligned rows
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = (c * 256 + threadIdx.x) * 4;
+      v[c] = i < size ? *reinterpret_cast<const float4*>(src + i) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+      s2 += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < size; i += 256) {
+      const float x = src[i];
+      s += x;
+      s2 += x * x;
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     s += __shfl_xor(s, o);
@@ -373,11 +394,43 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ in,
   const float mean = s / size;
   const float var = rms ? sqrtf(s2 / size + eps) : sqrtf(s2 / size - mean * mean + eps);
   const float inv = 1.f / var;
-  for (int i = threadIdx.x; i < size; i += 256) dst[i] = rms ? src[i] * inv : (src[i] - mean) * inv;
+  auto fin = [&](float x, int i) {
+    float y = rms ? x * inv : (x - mean) * inv;
+    if (gamma) y = y * gamma[i];  // separate rounding, like the reference's two operators
+    return y;
+  };
+  if constexpr (CACHED) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = (c * 256 + threadIdx.x) * 4;
+      if (i >= size) continue;
+      const float4 y = {fin(v[c].x, i), fin(v[c].y, i + 1), fin(v[c].z, i + 2), fin(v[c].w, i + 3)};
+      *reinterpret_cast<float4*>(dst + i) = y;
+      if (out16) {
+        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<half4_t*>(out16 + size_t(blockIdx.x) * size + i) =
+            half4_t{(_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < size; i += 256) {
+      const float y = fin(src[i], i);
+      dst[i] = y;
+      if (out16) out16[size_t(blockIdx.x) * size + i] = (_Float16)y;
+    }
+  }
 }
 hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* out,
-                          hipStream_t st) {
-  hipLaunchKernelGGL(norm_kernel, dim3(norm_count), dim3(256), 0, st, in, out, norm_size, isrms, eps);
+                          hipStream_t st, const float* gamma, void* out16) {
+  const bool cached = norm_size <= 4096 && (norm_size & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(out16) & 7) == 0 &&
+                      (!gamma || (reinterpret_cast<uintptr_t>(gamma) & 3) == 0);
+  if (cached)
+    hipLaunchKernelGGL(norm_kernel<true>, dim3(norm_count), dim3(256), 0, st, in, out, norm_size, isrms, eps, gamma,
+                       static_cast<_Float16*>(out16));
+  else
+    hipLaunchKernelGGL(norm_kernel<false>, dim3(norm_count), dim3(256), 0, st, in, out, norm_size, isrms, eps, gamma,
+                       static_cast<_Float16*>(out16));
   return hipGetLastError();
 }
 
@@ -475,6 +528,70 @@ __global__ void rope_kernel(const float* __restrict__ src, float* __restrict__ d
   y[ia] = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s));
   y[ib] = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
 }
+// RoPE of Q (in place) and K fused with the kv-cache append: K is rotated and stored as fp16 at cache position
+// n_past + i, V is converted and stored — the three operators ne_rope(q), ne_rope(k), kv-cache cpy of the llama graph
+// (models/llama/llama.cpp:232-262) in one launch.  batch 1; cache element strides are given per position and per head.
+__global__ void rope_qkv_append_kernel(float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                       _Float16* __restrict__ kc, _Float16* __restrict__ vc, int seq, int heads, int heads_kv,
+                                       int head_size, int n_past, int n_dims, int neox, float theta_scale,
+                                       float freq_scale, float attn_factor, long long c_sl, long long c_head) {
+  const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(head_size / 2);
+  const size_t nq = size_t(seq) * heads * npairs, nk = size_t(seq) * heads_kv * npairs;
+  const size_t nv = size_t(seq) * heads_kv * head_size;
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid < nq + nk) {
+    const bool is_k = gid >= nq;
+    const size_t g = is_k ? gid - nq : gid;
+    const int hn = is_k ? heads_kv : heads;
+    const size_t row = g / npairs;  // (i2, head)
+    const int pr = int(g % npairs), i2 = int(row / hn), ih = int(row % hn);
+    float theta_base = float(n_past + i2);
+    if (neox) theta_base = __fmul_rn(theta_base, freq_scale);
+    for (int t = 0; t < pr; t++) theta_base = __fmul_rn(theta_base, theta_scale);
+    const float theta = __fmul_rn(freq_scale, theta_base);
+    const float c = __fmul_rn(cosf(theta), attn_factor), s = __fmul_rn(sinf(theta), attn_factor);
+    int ia, ib;
+    if (neox) {
+      const int blk = pr / (n_dims / 2), ic = pr % (n_dims / 2);
+      ia = blk * n_dims + ic;
+      ib = ia + n_dims / 2;
+    } else {
+      ia = 2 * pr;
+      ib = ia + 1;
+    }
+    const float* x = (is_k ? k : q) + row * head_size;
+    const float x0 = x[ia], x1 = x[ib];
+    const float y0 = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s)), y1 = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
+    if (is_k) {
+      _Float16* d = kc + (long long)(n_past + i2) * c_sl + (long long)ih * c_head;
+      d[ia] = (_Float16)y0;
+      d[ib] = (_Float16)y1;
+    } else {
+      q[row * head_size + ia] = y0;
+      q[row * head_size + ib] = y1;
+    }
+  } else if (gid < nq + nk + nv) {
+    const size_t g = gid - nq - nk;
+    const int e = int(g % head_size);
+    const size_t row = g / head_size;
+    const int i2 = int(row / heads_kv), ih = int(row % heads_kv);
+    vc[(long long)(n_past + i2) * c_sl + (long long)ih * c_head + e] = (_Float16)v[g];
+  }
+}
+hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void* kc, void* vc, int seq, int heads,
+                                  int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base,
+                                  float freq_scale, float attn_factor, long long c_sl, long long c_head, hipStream_t st) {
+  const bool neox = (mode & 2) != 0;
+  const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(head_size / 2);
+  const size_t total = size_t(seq) * (heads + heads_kv) * npairs + size_t(seq) * heads_kv * head_size;
+  if (total == 0) return hipSuccess;
+  const float theta_scale = powf(freq_base, -2.0f / n_dims);
+  hipLaunchKernelGGL(rope_qkv_append_kernel, grid1d(total, 256), dim3(256), 0, st, q, k, v, static_cast<_Float16*>(kc),
+                     static_cast<_Float16*>(vc), seq, heads, heads_kv, head_size, n_past, n_dims, neox ? 1 : 0, theta_scale,
+                     freq_scale, attn_factor, c_sl, c_head);
+  return hipGetLastError();
+}
+
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st) {
   const size_t rows = size_t(batch) * seq * heads;

@@ -63,6 +63,19 @@ def test_attention_device_api_and_scales(L, pkg, nso):
     pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), st))
     torch.cuda.synchronize()
     assert nso.rel_l2(dd.cpu().numpy(), ref) < TOL
+    # caller-provided device workspace (the reference's `tmp` contract) inside a graph capture on a fresh stream
+    shape = pkg.AttnShape(bs, hn, hkv, hs, sl_q, sl_kv)
+    ws = torch.empty(L.bestla_fusion_attn_workspace_size(C.byref(shape)), dtype=torch.uint8, device="cuda")
+    a.tmp = ws.data_ptr()
+    dd.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(
+            C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    g.replay()
+    torch.cuda.synchronize()
+    assert nso.rel_l2(dd.cpu().numpy(), ref) < TOL
+    a.tmp = None
     # causal with more queries than keys is rejected loudly, like the reference's assert (mha_dense_wrapper.h:1375)
     bad = pkg.attn_args(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dd.data_ptr(), bs, hn, hkv, hs, 9, 4, scale, 1)
     assert L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(bad), st) != 0

@@ -26,7 +26,8 @@ def _rope(x, pos0, base):  # x [seq][heads][hs], mode 0 (adjacent pairs), closed
     return out
 
 
-def test_llama_layer_prefill_then_decode(L, pkg, nso):
+@pytest.mark.parametrize("fused", [False, True])
+def test_llama_layer_prefill_then_decode(L, pkg, nso, fused):
     import torch
     rng = np.random.default_rng(2024)
     d, heads, hkv, hs, ff, ctx, eps, base = 512, 8, 4, 64, 1408, 64, 1e-5, 10000.0
@@ -53,7 +54,41 @@ def test_llama_layer_prefill_then_decode(L, pkg, nso):
     kc_ref = np.zeros((ctx, hkv, hs), np.float64)
     vc_ref = np.zeros((ctx, hkv, hs), np.float64)
 
+    def gpu_layer_fused(x_np, n_past):
+        """the same layer with the fused device operators: norm*gamma+fp16 shadow, RoPE(q,k)+kv-append, fp16 shadows
+        between GEMMs, residual add as the down projection's epilogue"""
+        m = x_np.shape[0]
+        x = torch.from_numpy(x_np).cuda()
+        f16 = lambda *s: torch.empty(*s, device="cuda", dtype=torch.float16)
+        h, h16 = torch.empty_like(x), f16(m, d)
+        pkg.check(L.ns_hip_norm_mul_h(m, d, True, eps, x.data_ptr(), dg1.data_ptr(), h.data_ptr(), h16.data_ptr(), st))
+        q, k, v = torch.empty((m, d), device="cuda"), torch.empty((m, dkv), device="cuda"), torch.empty((m, dkv), device="cuda")
+        for wt, out, n in ((wq, q, d), (wk, k, dkv), (wv, v, dkv)):
+            pkg.check(L.ns_hip_f32f32_forward_h(h.data_ptr(), h16.data_ptr(), wt.h, out.data_ptr(), None, m, d, n,
+                                                pkg.EPI_NONE, None, 0, st))
+        pkg.check(L.ns_hip_rope_qkv_append(q.data_ptr(), k.data_ptr(), v.data_ptr(), kc.data_ptr(), vc.data_ptr(), m, heads, hkv,
+                                           hs, n_past, hs, 0, base, 1.0, 0.0, 1.0, hkv * hs, hs, st))
+        att = torch.empty((m, d), device="cuda")
+        a = pkg.attn_args(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), att.data_ptr(), 1, heads, hkv, hs, m, n_past + m,
+                          float(hs) ** -0.5, pkg.ATTN_CAUSAL)
+        a.step_k_bs = a.step_v_bs = ctx * hkv * hs
+        pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), st))
+        r1 = torch.empty((m, d), device="cuda")
+        pkg.check(L.ns_hip_f32f32_forward(att.data_ptr(), wo.h, r1.data_ptr(), m, d, d, pkg.EPI_ADD, x.data_ptr(), d, st))
+        h2, h216 = torch.empty_like(r1), f16(m, d)
+        pkg.check(L.ns_hip_norm_mul_h(m, d, True, eps, r1.data_ptr(), dg2.data_ptr(), h2.data_ptr(), h216.data_ptr(), st))
+        t2, t216 = torch.empty((m, ff), device="cuda"), f16(m, ff)
+        pkg.check(L.ns_hip_fusion_ffn3_gateup_h(h2.data_ptr(), h216.data_ptr(), w1.h, w3.h, None, t2.data_ptr(), t216.data_ptr(),
+                                                m, pkg.EPI_SILU, st))
+        y = torch.empty((m, d), device="cuda")
+        pkg.check(L.ns_hip_f32f32_forward_h(t2.data_ptr(), t216.data_ptr(), w2.h, y.data_ptr(), None, m, ff, d, pkg.EPI_ADD,
+                                            r1.data_ptr(), d, st))
+        torch.cuda.synchronize()
+        return y.cpu().numpy()
+
     def gpu_layer(x_np, n_past):
+        if fused:
+            return gpu_layer_fused(x_np, n_past)
         m = x_np.shape[0]
         x = torch.from_numpy(x_np).cuda()
         h = torch.empty_like(x)

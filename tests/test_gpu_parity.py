@@ -443,6 +443,13 @@ def test_elementwise_entries(L, pkg, nso):
     pkg.check(L.ns_hip_add(5, 300, dx.data_ptr(), dx.data_ptr(), 300, do.data_ptr(), st))
     torch.cuda.synchronize()
     assert np.array_equal(do.cpu().numpy(), x + x)
+    # fused norm * gamma (+ fp16 shadow) == the two separate operators, bit for bit
+    d16 = torch.zeros((5, 300), dtype=torch.float16, device="cuda")
+    pkg.check(L.ns_hip_norm_mul_h(5, 300, True, 1e-6, dx.data_ptr(), dv.data_ptr(), do.data_ptr(), d16.data_ptr(), st))
+    torch.cuda.synchronize()
+    L.bestla_layernormalization(5, 300, True, 1e-6, nso.ptr(x), nso.ptr(out))
+    assert np.array_equal(do.cpu().numpy(), out * v)
+    assert torch.equal(d16, do.half())
 
 
 # ---------------------------------------------------------------------------------------------- device-resident API

@@ -65,3 +65,28 @@ def test_rope_gpu_matches_oracle(L, pkg, nso, b, s, h, hs, n_past, n_dims, mode,
     assert np.max(np.abs(out - ref)) < 1e-5 * max(1.0, float(np.abs(x).max()))
     # unsupported modes are refused loudly
     assert L.ns_hip_rope_f32(dx.data_ptr(), dy.data_ptr(), b, s, h, hs, n_past, n_dims, 4, base, fscale, 0.0, attn, st) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 2])
+def test_rope_qkv_append_equals_separate_ops(L, pkg, nso, mode):
+    import torch
+    seq, heads, hkv, hs, n_past, ctx = 3, 8, 2, 64, 5, 16
+    rng = np.random.default_rng(mode + 1)
+    q = rng.standard_normal((1, seq, heads, hs)).astype(np.float32)
+    k = rng.standard_normal((1, seq, hkv, hs)).astype(np.float32)
+    v = rng.standard_normal((1, seq, hkv, hs)).astype(np.float32)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dq, dk, dv = torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+    rq, rk = dq.clone(), dk.clone()
+    pkg.check(L.ns_hip_rope_f32(rq.data_ptr(), rq.data_ptr(), 1, seq, heads, hs, n_past, hs, mode, 10000.0, 1.0, 0.0, 1.0, st))
+    pkg.check(L.ns_hip_rope_f32(rk.data_ptr(), rk.data_ptr(), 1, seq, hkv, hs, n_past, hs, mode, 10000.0, 1.0, 0.0, 1.0, st))
+    kc = torch.full((ctx, hkv, hs), 9.0, dtype=torch.float16, device="cuda")
+    vc = torch.full((ctx, hkv, hs), 9.0, dtype=torch.float16, device="cuda")
+    pkg.check(L.ns_hip_rope_qkv_append(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), kc.data_ptr(), vc.data_ptr(), seq, heads,
+                                       hkv, hs, n_past, hs, mode, 10000.0, 1.0, 0.0, 1.0, hkv * hs, hs, st))
+    torch.cuda.synchronize()
+    assert torch.equal(dq, rq)
+    assert torch.equal(kc[n_past:n_past + seq], rk[0].half())
+    assert torch.equal(vc[n_past:n_past + seq], dv[0].half())
+    assert torch.all(kc[:n_past] == 9.0) and torch.all(vc[n_past + seq:] == 9.0)  # nothing else touched
