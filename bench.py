@@ -265,7 +265,8 @@ def main():
     # falls through to the next mode; every rank takes the same decision (all-reduce of the failure flag).
     modes = [] if args.no_graph else [True]
     if world > 1:
-        full = os.environ.get("NS_BENCH_FULL_GRAPH", "0") == "1" and backend == "nccl"
+        fg = os.environ.get("NS_BENCH_FULL_GRAPH", "0")
+        full = (fg == "1" and backend == "nccl") or fg == "force"  # "force": exercise the fallback chain on any backend
         modes = ([True] if full and not args.no_graph else []) + ([] if args.no_graph else ["segments"])
     modes.append(False)
     wall_ms = ev_ms = None
