@@ -346,6 +346,8 @@ struct DevBuf {
   bool alloc(size_t count) { return hip_ok(hipMalloc((void**)&p, count * sizeof(T) + 16), "hipMalloc(temp)"); }
 };
 
+// rows up to which the weight-streaming kernel is used; above, the tiled MFMA GEMM (measured crossover)
+constexpr int kSmallMMax = 64;
 int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
                  const float* dD, int ldd, hipStream_t st, const void* dA16 = nullptr, void* dC16 = nullptr) {
   if (!w || !dA || !dC || m <= 0) {
@@ -370,7 +372,11 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   a.ldd = ldd;
   a.dual = false;
   a.c2 = nullptr;
-  if (!hip_ok(m <= 64 ? launch_smallm(a, st) : launch_gemm(a, st), "gemm launch")) return -1;
+  static const int small_max = getenv("NS_SMALLM_MAX") ? atoi(getenv("NS_SMALLM_MAX")) : kSmallMMax;  // diagnostics
+  // measured crossover (scripts/m_sweep.py): the streaming kernel wins up to 32 rows everywhere and up to 64 rows on
+  // narrow weights; from 33 rows on wide weights (>= 512 column tiles) the tiled GEMM is already faster
+  const bool small = m <= small_max && (m <= 32 || w->ntiles < 512 || dC16 != nullptr);
+  if (!hip_ok(small ? launch_smallm(a, st) : launch_gemm(a, st), "gemm launch")) return -1;
   return 0;
 }
 

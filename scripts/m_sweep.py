@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Forward time vs M on a 4096x4096 and a 11008x4096 int4 g32 weight: where the weight-streaming kernel (M <= NS_SMALLM_MAX)
+hands over to the tiled GEMM."""
+import ctypes as C, json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package(); L = pkg.lib()
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+res = {}
+for n, k in ((4096, 4096), (11008, 4096)):
+    ws = []
+    for i in range(4):
+        w = torch.randn((n, k), device="cuda") * 0.02
+        size = L.ns_BTLAGemmPackBSize(n, k, 32, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, None)
+        blob = torch.zeros(size, dtype=torch.uint8, device="cuda")
+        pkg.check(L.ns_hip_quant_pack_device(blob.data_ptr(), w.data_ptr(), n, k, k, 32, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, True, st))
+        ws.append(pkg.Weight.from_device_blob(blob.data_ptr(), size, st))
+    torch.cuda.synchronize()
+    for m in (8, 16, 17, 32, 33, 48, 64, 65, 96, 128):
+        a = torch.randn((m, k), device="cuda"); a16 = a.half()
+        c = torch.empty((m, n), device="cuda")
+        def f():
+            for wt in ws:
+                pkg.check(L.ns_hip_f32f32_forward_h(a.data_ptr(), a16.data_ptr(), wt.h, c.data_ptr(), None, m, k, n, 0, None, 0, st))
+        for _ in range(3): f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): f()
+        e1.record(); torch.cuda.synchronize()
+        res["%dx%d m=%d" % (n, k, m)] = round(e0.elapsed_time(e1) * 1e3 / 40, 2)
+print(json.dumps(res))
