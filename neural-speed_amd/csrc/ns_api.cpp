@@ -373,9 +373,8 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   a.dual = false;
   a.c2 = nullptr;
   static const int small_max = getenv("NS_SMALLM_MAX") ? atoi(getenv("NS_SMALLM_MAX")) : kSmallMMax;  // diagnostics
-  // measured crossover (scripts/m_sweep.py): the streaming kernel wins up to 32 rows everywhere and up to 64 rows on
-  // narrow weights; from 33 rows on wide weights (>= 512 column tiles) the tiled GEMM is already faster
-  const bool small = m <= small_max && (m <= 32 || w->ntiles < 512 || dC16 != nullptr);
+  // measured crossover (scripts/m_sweep.py): the streaming kernel wins up to 64 rows on the 7B shapes
+  const bool small = m <= small_max;
   if (!hip_ok(small ? launch_smallm(a, st) : launch_gemm(a, st), "gemm launch")) return -1;
   return 0;
 }

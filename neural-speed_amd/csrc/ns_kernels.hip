@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
   constexpr int NQ = DUAL ? 2 : 1;  // matrices streamed by one workgroup
   // ring depth: the 16-wave (WIDE) variant already has 16 x 2 KiB per workgroup in flight and is capped at 128 VGPRs;
   // a 2-deep ring measured faster there (down projection 9.2 -> 8.6 us) and does not spill
-  constexpr int PF = WIDE ? kPFWide : kPF;
+  constexpr int PF = (WIDE || MB == 4) ? kPFWide : kPF;  // MB == 4: the 4-deep ring spilled 556 B per lane
   static_assert(PF % NQ == 0, "ring slots alternate between the two matrices");
   constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
   using Corr = CorrRaw<SPS, SK, ASYM>;
@@ -687,7 +687,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
     const int target_waves = 2560;
     // 16-wave workgroups where few tiles leave CUs short of waves (FFN down projection, attention output projection;
     // measured: WO 5.75 -> 5.3 us at 16 waves)
-    const int pf = a.dual ? kPF : kPFWide;  // ring depth of the instantiation that will run
+    const int pf = (a.dual || mb == 2) ? kPF : kPFWide;  // ring depth of the instantiation that will run
     nw = (grid <= 320 && w0->ksteps >= 32 && !a.dual) ? 16 : 8;
     while (nw > 2 && grid * (nw / 2) >= target_waves) nw /= 2;
     while (nw > 2 && w0->ksteps * (a.dual ? 2 : 1) < nw * pf) nw /= 2;  // keep the ring full
