@@ -59,6 +59,9 @@ struct Gemm2Params {
   const float* d;
   int ldd;
   int nbn, cpx;  // column blocks; column blocks per XCD
+  int ksplit;    // > 1: split-K (few output tiles): workgroup z = blockIdx.y takes chunks [z*cps, (z+1)*cps) and writes a
+  int cps;       //      raw fp32 partial tile to `part` [ksplit][m][n]; gemm2_reduce_kernel sums them and applies the epilogue
+  float* part;
   F4Lut lut;
 };
 
@@ -202,26 +205,28 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
   };
 
   unsigned char* stage0 = smem;
+  const int cbeg = p.ksplit > 1 ? int(blockIdx.y) * p.cps : 0;
+  const int cend = p.ksplit > 1 ? min(p.nchunks, cbeg + p.cps) : p.nchunks;
   if constexpr (kG2Stages == 2) {
     unsigned char* stage1 = smem + kG2StageBytes;
-    load_chunk(0);
-    store_chunk(0, stage0);
+    load_chunk(cbeg);
+    store_chunk(cbeg, stage0);
     __syncthreads();
-    for (int c = 0; c < p.nchunks; c++) {
-      unsigned char* cur = (c & 1) ? stage1 : stage0;
-      unsigned char* nxt = (c & 1) ? stage0 : stage1;
-      const bool more = c + 1 < p.nchunks;
+    for (int c = cbeg; c < cend; c++) {
+      unsigned char* cur = ((c - cbeg) & 1) ? stage1 : stage0;
+      unsigned char* nxt = ((c - cbeg) & 1) ? stage0 : stage1;
+      const bool more = c + 1 < cend;
       if (more) load_chunk(c + 1);
       compute(cur);
       if (more) store_chunk(c + 1, nxt);
       __syncthreads();
     }
   } else {
-    load_chunk(0);
-    for (int c = 0; c < p.nchunks; c++) {
+    load_chunk(cbeg);
+    for (int c = cbeg; c < cend; c++) {
       store_chunk(c, stage0);
       __syncthreads();
-      if (c + 1 < p.nchunks) load_chunk(c + 1);
+      if (c + 1 < cend) load_chunk(c + 1);
       compute(stage0);
       __syncthreads();
     }
@@ -239,6 +244,10 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
         const int row = row0 + wm * 16 * kG2MI + mi * 16 + 4 * g + r;
         if (row >= p.m) continue;
         float v = acc[mi][ni][r];
+        if (p.ksplit > 1) {  // raw partial; epilogue happens in gemm2_reduce_kernel
+          p.part[(size_t(blockIdx.y) * p.m + row) * p.n + col] = v;
+          continue;
+        }
         const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
         switch (p.epilogue) {
           case 1: v = v + dv; break;            // custom::epilogue::Add
@@ -252,6 +261,26 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
         if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
       }
     }
+}
+
+// split-K tail: C = epilogue(sum over the K splits, in split order -> deterministic)
+__global__ void gemm2_reduce_kernel(const Gemm2Params p) {
+  const size_t idx = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= size_t(p.m) * p.n) return;
+  const int row = int(idx / p.n), col = int(idx % p.n);
+  float v = 0.f;
+  for (int z = 0; z < p.ksplit; z++) v += p.part[(size_t(z) * p.m + row) * p.n + col];
+  const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
+  switch (p.epilogue) {
+    case 1: v = v + dv; break;
+    case 2: v = v * dv; break;
+    case 3: v = epi_gelu(v + dv); break;
+    case 4: v = epi_gelu(v); break;
+    case 5: v = epi_silu(v); break;
+    default: break;
+  }
+  p.c[size_t(row) * p.ldc + col] = v;
+  if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
 }
 
 // fp32 [m][lda] -> fp16 [m][ld16], columns k..ld16-1 zero.  One thread per 8 outputs: two 16-byte loads, one 16-byte store.
@@ -308,7 +337,13 @@ static hipError_t launch_gemm2_k(const Gemm2Params& p, bool asym, dim3 grid, siz
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(kG2Stages * kG2StageBytes));
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && p.ksplit > 1) {
+      const size_t total = size_t(p.m) * p.n;
+      hipLaunchKernelGGL(gemm2_reduce_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, p);
+      e = hipGetLastError();
+    }
+    return e;
   };
   if constexpr (KIND == WK_F4) {
     (void)asym;
@@ -378,7 +413,25 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
   p.cpx = (p.nbn + 7) / 8;
   const int nbm = (a.m + kG2BM - 1) / kG2BM;
-  const dim3 grid(unsigned(8 * p.cpx * nbm));
+  // few output tiles (M up to a few hundred rows): split K so that the launch still fills the chip
+  p.ksplit = 1;
+  p.cps = p.nchunks;
+  {
+    static const bool no_splitk = getenv("NS_NO_SPLITK") != nullptr;  // diagnostics
+    const int tiles = p.nbn * nbm;
+    int ks = 1;
+    while (ks < 8 && tiles * ks * 2 <= 256 && p.nchunks / (ks * 2) >= 8) ks *= 2;
+    if (ks > 1 && !no_splitk) {
+      const size_t bytes = size_t(ks) * a.m * w0->n * 4;
+      float* part = static_cast<float*>(stream_scratch(st, bytes, 2));
+      if (part) {
+        p.ksplit = ks;
+        p.cps = (p.nchunks + ks - 1) / ks;
+        p.part = part;
+      }
+    }
+  }
+  const dim3 grid(unsigned(8 * p.cpx * nbm), unsigned(p.ksplit));
   const size_t lds = size_t(kG2Stages) * kG2StageBytes;
 #ifdef NS_GEMM_MIN  // development builds: the two bench formats only
   if (w0->scale_dt != DT_BF16 || w0->asym) return hipErrorNotSupported;
