@@ -23,6 +23,9 @@ S4 = 4 | (1 << 8)
 F4_E2M1 = 4
 F4_BNB = 4 | (1 << 16)
 F4_NF4 = 4 | (2 << 16)
+F8_E4M3 = 8
+F8_E5M2 = 8 | (1 << 16)
+F8_E8M0 = 8 | (3 << 16)  # scale type of the fp8 weights: shared exponent
 INT_TYPES = {b: b | (1 << 8) for b in range(1, 9)}
 # ne_comp_type (neural_speed/core/data_types.h:57-63)
 COMP_UNDEF, COMP_F32, COMP_BF16, COMP_F16, COMP_INT8 = range(5)

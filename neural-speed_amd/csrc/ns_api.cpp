@@ -12,6 +12,7 @@
 // file: without a HIP device every compute entry reports an error.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -167,19 +168,23 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
       w->lut[i] = (_Float16)f;
       w->lutf[i] = f;
     }
+  } else if (v.prologue == 2 && dt_is_f8(v.dtype)) {
+    w->kind = WK_F8;
+    if (v.scale_dt == DT_F8_E8M0) w->scale_dt = DT_F32;  // shared exponents are expanded to fp32 scales by the repack
   } else {
-    set_error("weight dtype not supported by the MI355X kernels yet (supported: S1..S8, F4_NF4, F4_BNB, F4_E2M1)");
+    set_error("weight dtype not supported by the MI355X kernels yet (supported: S1..S8, F4_NF4, F4_BNB, F4_E2M1, F8_E4M3, F8_E5M2)");
     return false;
   }
   if (v.shuf_bytes) {
     set_error("activation-shuffle (g_idx) blobs are not supported");
     return false;
   }
-  if (v.scale_dt != DT_F32 && v.scale_dt != DT_BF16 && v.scale_dt != DT_F16) {
-    set_error("scale dtype not supported (F32/BF16/F16)");
+  if (v.scale_dt != DT_F32 && v.scale_dt != DT_BF16 && v.scale_dt != DT_F16 &&
+      !(v.scale_dt == DT_F8_E8M0 && w->kind == WK_F8)) {
+    set_error("scale dtype not supported (F32/BF16/F16; F8_E8M0 with fp8 weights)");
     return false;
   }
-  w->kstep_len = (w->kind == WK_INT8) ? 64 : 128;
+  w->kstep_len = (w->kind == WK_INT8 || w->kind == WK_F8) ? 64 : 128;
   w->ntiles = (v.n + 15) / 16;
   w->ksteps = (v.k + w->kstep_len - 1) / w->kstep_len;
   const int bs = v.blocksize;
@@ -245,6 +250,33 @@ bool alloc_weight(ns_weight* w) {
   return true;
 }
 
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  bool alloc(size_t count) { return hip_ok(hipMalloc((void**)&p, count * sizeof(T) + 16), "hipMalloc(temp)"); }
+};
+
+// gemm2 multiplies fp16 weights that already carry their group scale: pick the power of two that brings the largest
+// |scale| to [2^5, 2^6).  |code - zp| <= 383, so scaled weights stay below 2^15 (no overflow however large the
+// original weights are), and only groups more than 2^-19 below the largest one drop under fp16's normal range — bits
+// far beneath the 1e-3 budget relative to the output.  Powers of two change no rounding inside the normal range.
+void set_gemm_scale_range(ns_weight* w, uint32_t smax_bits) {
+  w->g2_pre = w->g2_post = 1.f;
+  float smax;
+  memcpy(&smax, &smax_bits, 4);
+  if (!(smax > 0.f)) return;
+  int e;
+  frexpf(smax, &e);           // smax = f * 2^e, f in [0.5, 1)
+  int shift = 6 - e;          // smax * 2^shift in [2^5, 2^6)
+  if (shift > 100) shift = 100;
+  if (shift < -100) shift = -100;
+  w->g2_pre = ldexpf(1.f, shift);
+  w->g2_post = ldexpf(1.f, -shift);
+}
+
 // sections already in device memory -> device weight
 ns_weight* weight_from_device_sections(const BlobView& v, const uint8_t* dq, const uint8_t* ds, const int8_t* dz,
                                        hipStream_t st) {
@@ -254,10 +286,26 @@ ns_weight* weight_from_device_sections(const BlobView& v, const uint8_t* dq, con
     return nullptr;
   }
   RepackArgs ra{dq, ds, dz, v.ntile(), v.packrow(), v.kpad, v.npad, v.cstep, int((v.kpad + v.blocksize - 1) / v.blocksize)};
-  if (!hip_ok(launch_repack(ra, w, st), "repack")) {
+  ra.src_scale_dt = v.scale_dt;
+  DevBuf<uint32_t> dinfo;  // [0] largest |scale| (fp32 bits), [1] out-of-range code flag
+  uint32_t info[2] = {0, 0};
+  bool ok = dinfo.alloc(2) && hip_ok(hipMemsetAsync(dinfo.p, 0, 8, st), "memset");
+  if (ok) {
+    ra.flags = dinfo.p + 1;
+    ok = hip_ok(launch_repack(ra, w, st), "repack") &&
+         hip_ok(launch_scale_absmax(ds, v.s_bytes / (dt_bits(v.scale_dt) / 8), v.scale_dt, dinfo.p, st), "scale range") &&
+         hip_ok(hipMemcpyAsync(info, dinfo.p, 8, hipMemcpyDeviceToHost, st), "load info D2H") &&
+         hip_ok(hipStreamSynchronize(st), "sync after repack");
+  }
+  if (ok && info[1]) {
+    set_error("F8_E5M2 blob holds codes with exponent field 31 (beyond the reference quantizer's max_norm and fp16)");
+    ok = false;
+  }
+  if (!ok) {
     ns_hip_weight_free(w);
     return nullptr;
   }
+  set_gemm_scale_range(w, info[0]);
   return w;
 }
 
@@ -336,15 +384,6 @@ bool plan_pack(PackPlan* pp, size_t N, size_t K, size_t BlkSize, uint32_t qt, ui
   }
   return true;
 }
-
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  ~DevBuf() {
-    if (p) hipFree(p);
-  }
-  bool alloc(size_t count) { return hip_ok(hipMalloc((void**)&p, count * sizeof(T) + 16), "hipMalloc(temp)"); }
-};
 
 // rows up to which the weight-streaming kernel is used; above, the tiled MFMA GEMM (measured crossover)
 constexpr int kSmallMMax = 64;

@@ -173,11 +173,16 @@ bool blob_describe(BlobView* out, size_t n, size_t k, size_t blocksize, uint32_t
                    int core, uintptr_t base_addr, std::string* err) {
   BlobView v;
   const bool is_int = dt_is_int(qtype);
-  if (!is_int && !dt_is_f4(qtype)) {
+  if (!is_int && !dt_is_f4(qtype) && !dt_is_f8(qtype)) {
     if (err) *err = "pack: unsupported weight dtype";
     return false;
   }
-  if (stype != DT_F32 && stype != DT_BF16 && stype != DT_F16) {
+  if (dt_is_f8(qtype)) {  // quantize_f32_f8_rowblock_mxscale handles E8M0 and F32 scales only (kernel_ref.h:1775-1789)
+    if (stype != DT_F8_E8M0 && stype != DT_F32) {
+      if (err) *err = "pack: fp8 weights take F8_E8M0 or F32 scales";
+      return false;
+    }
+  } else if (stype != DT_F32 && stype != DT_BF16 && stype != DT_F16) {
     if (err) *err = "pack: unsupported scale dtype";
     return false;
   }

@@ -15,7 +15,9 @@ constexpr uint32_t DT_S4 = 4 | (1u << 8);
 constexpr uint32_t DT_F4_E2M1 = 4, DT_F4_BNB = 4 | (1u << 16), DT_F4_NF4 = 4 | (2u << 16);
 __host__ __device__ inline int dt_bits(uint32_t t) { return int(t & 0xff); }
 __host__ __device__ inline bool dt_is_int(uint32_t t) { return ((t >> 8) & 0xff) == 1; }
+constexpr uint32_t DT_F8_E4M3 = 8, DT_F8_E5M2 = 8 | (1u << 16), DT_F8_E8M0 = 8 | (3u << 16);
 inline bool dt_is_f4(uint32_t t) { return t == DT_F4_E2M1 || t == DT_F4_BNB || t == DT_F4_NF4; }
+__host__ __device__ inline bool dt_is_f8(uint32_t t) { return t == DT_F8_E4M3 || t == DT_F8_E5M2; }
 
 // ---- reference GEMM cores a blob may be laid out for (bestla_defs.h:36-54, bestla_gemm.h CoreAttr :83-123) ----
 struct CoreDesc {
@@ -61,7 +63,7 @@ void blob_write_header(const BlobView& v, void* host_base);
 void blob_write_header_io(const BlobView& v, const BlobIo& io, uintptr_t base_addr);
 
 // ---- device weight -------------------------------------------------------------------------------------------
-enum WKind { WK_INT4 = 0, WK_INT8 = 1, WK_F4 = 2 };
+enum WKind { WK_INT4 = 0, WK_INT8 = 1, WK_F4 = 2, WK_F8 = 3 };
 
 }  // namespace ns
 
@@ -103,6 +105,9 @@ struct ns_weight {
   bool single_span = false;  // the allocation is < 4 GiB, i.e. the offsets above are usable as 32-bit soffsets
   uint64_t stream_bytes = 0;  // algorithmic bytes (reference formula)
   int device = 0;
+  // gemm2 (ns_gemm.hip) rounds `scale * g2_pre` to fp16 and multiplies its accumulators by g2_post = 1 / g2_pre: a
+  // power of two chosen at load time from the largest |scale| so that dequantised weights stay in fp16's normal range
+  float g2_pre = 1.f, g2_post = 1.f;
   _Float16 lut[16];  // f4 value table rounded to fp16: the MFMA operand (kind == WK_F4)
   float lutf[16];    // the same table in fp32: exact unpack
 };
@@ -114,8 +119,12 @@ struct RepackArgs {
   const uint8_t* scales;  // device: reference scales [nblk][cstep] in scale_dt
   const int8_t* zps;      // device or null
   int ref_ntile, ref_packrow, ref_kpad, ref_npad, cstep, ref_nblk;
+  uint32_t src_scale_dt = 0;  // dtype of `scales` when it differs from the device layout's (F8_E8M0 -> fp32)
+  uint32_t* flags = nullptr;  // device word, OR-ed with 1 when an E5M2 code lies outside fp16's range
 };
 hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st);
+// max |scale| over a reference scale section (finite values only), as fp32 bits, atomically max-ed into *out_bits
+hipError_t launch_scale_absmax(const void* scales, size_t count, uint32_t scale_dt, uint32_t* out_bits, hipStream_t st);
 
 struct GemmSeg {
   const ns_weight* w;

@@ -613,7 +613,7 @@ hipError_t launch_decode(const SmallMArgs& a, hipStream_t st) {
   // opt-in (NS_DECODE_KERNEL=1) until it wins
   static const bool off = getenv("NS_DECODE_KERNEL") == nullptr || atoi(getenv("NS_DECODE_KERNEL")) == 0;
   const ns_weight* w0 = a.seg[0].w;
-  if (off || a.m > kDecMaxRows || a.m < 1 || !w0->ws_flags) return hipErrorNotSupported;
+  if (off || a.m > kDecMaxRows || a.m < 1 || !w0->ws_flags || w0->kind == WK_F8) return hipErrorNotSupported;
 #ifdef NS_DECODE_MIN
   if (w0->scale_dt != DT_BF16) return hipErrorNotSupported;
 #endif

@@ -67,6 +67,33 @@ __device__ __forceinline__ half8_t cvt_i8x8(uint32_t x0, uint32_t x1, half2_t of
   uint4v r = {as_u32(h0), as_u32(h1), as_u32(h2), as_u32(h3)};
   return __builtin_bit_cast(half8_t, r);
 }
+// 8 fp8 codes (two dwords) -> 8 fp16, exact.  The reference's fp8 has no zero, subnormals, inf or nan (f8_to_fp32,
+// kernel_ref.h:984-1002): value = +-2^(e - bias) * (1 + m / 2^mbits) for every code.  With the byte in the high half
+// of a 16-bit lane (u = code << 8, sign already in place):
+//   E4M3 (bias 7):  fp16 = (u & 0x7f00) >> 1 + 0x2000        exponent field e + 8, mantissa m << 7
+//   E5M2 (bias 15): fp16 = u & 0x7f00 for e >= 1 (same fields); e == 0 is 2^-15 * (1 + m/4), an fp16 SUBNORMAL with
+//                   bits 0x200 + (m << 7) — both cases are max(u, (u >> 1) + 0x200)
+// so one formula with two constants covers both: abs = max(u & M, (u >> 1) + C);  E4M3: C = 0x2000, M = 0;
+// E5M2: C = 0x0200, M = 0xffff.  v_mfma_f32_16x16x32_f16 keeps fp16 subnormal inputs (default kernel mode).
+constexpr bool kind_is_8bit(int kind) { return kind == WK_INT8 || kind == WK_F8; }
+struct F8Consts {
+  uint32_t c2, m2;  // C and M replicated into both 16-bit halves
+};
+__device__ __forceinline__ uint32_t cvt_f8x2(uint32_t t, const F8Consts& k) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const uint32_t u = t & 0x7f007f00u;
+  const uint32_t v = (u >> 1) + k.c2;
+  const u16x2 mx = __builtin_elementwise_max(__builtin_bit_cast(u16x2, u & k.m2), __builtin_bit_cast(u16x2, v));
+  return (t & 0x80008000u) | __builtin_bit_cast(uint32_t, mx);
+}
+__device__ __forceinline__ half8_t cvt_f8x8(uint32_t x0, uint32_t x1, const F8Consts& k) {
+  uint4v r = {cvt_f8x2(__builtin_amdgcn_perm(0u, x0, 0x010c000cu), k), cvt_f8x2(__builtin_amdgcn_perm(0u, x0, 0x030c020cu), k),
+              cvt_f8x2(__builtin_amdgcn_perm(0u, x1, 0x010c000cu), k), cvt_f8x2(__builtin_amdgcn_perm(0u, x1, 0x030c020cu), k)};
+  return __builtin_bit_cast(half8_t, r);
+}
+inline F8Consts f8_consts(uint32_t qtype) {
+  return qtype == DT_F8_E5M2 ? F8Consts{0x02000200u, 0xffffffffu} : F8Consts{0x20002000u, 0u};
+}
 // 16-entry fp16 LUT held as byte planes: lo[e] / hi[e] for e = 0..15, four entries per dword
 struct F4Lut {
   uint32_t lo[4], hi[4];

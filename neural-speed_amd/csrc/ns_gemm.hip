@@ -62,6 +62,9 @@ struct Gemm2Params {
   int ksplit;    // > 1: split-K (few output tiles): workgroup z = blockIdx.y takes chunks [z*cps, (z+1)*cps) and writes a
   int cps;       //      raw fp32 partial tile to `part` [ksplit][m][n]; gemm2_reduce_kernel sums them and applies the epilogue
   float* part;
+  float spre, spost;  // power-of-two pair (spre * spost == 1): group scales are multiplied by spre before they are rounded
+                      // to fp16 and the accumulators by spost on the way out, so that weights with very small or very
+                      // large magnitudes stay inside fp16's normal range (1, 1 for ordinary LLM weights)
   F4Lut lut;
 };
 
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
         } else {
           b = cvt_f4x8(breg[r][jj], p.lut);
         }
-        const _Float16 sh = (_Float16)s_j;
+        const _Float16 sh = (_Float16)(s_j * p.spre);
         b = b * half8_t{sh, sh, sh, sh, sh, sh, sh, sh};
         b_lds[((tl * 2 + jj) * 4 + g) * 16 + nn] = __builtin_bit_cast(uint4v, b);
       }
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
       for (int r = 0; r < 4; r++) {
         const int row = row0 + wm * 16 * kG2MI + mi * 16 + 4 * g + r;
         if (row >= p.m) continue;
-        float v = acc[mi][ni][r];
+        float v = acc[mi][ni][r] * p.spost;
         if (p.ksplit > 1) {  // raw partial; epilogue happens in gemm2_reduce_kernel
           p.part[(size_t(blockIdx.y) * p.m + row) * p.n + col] = v;
           continue;
@@ -366,6 +369,9 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   static const bool off = getenv("NS_GEMM_V1") != nullptr;  // diagnostics
   if (off) return hipErrorNotSupported;
   const ns_weight* w0 = a.seg[0].w;
+  // fp8 weights span 2^-15 .. 2^15 per code before their scale: they stay on the first-generation kernel, which
+  // applies the group scale to the fp32 MFMA result
+  if (w0->kind == WK_F8) return hipErrorNotSupported;
   Gemm2Params p;
   memset(&p, 0, sizeof(p));
   p.m = a.m;
@@ -410,6 +416,8 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   p.d = a.d;
   p.ldd = a.ldd;
   if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
+  p.spre = w0->g2_pre;
+  p.spost = w0->g2_post;
   p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
   p.cpx = (p.nbn + 7) / 8;
   const int nbm = (a.m + kG2BM - 1) / kG2BM;

@@ -13,6 +13,7 @@
 //   pack      interleave + bit planes + reduce   kernel_ref.h:39-57, :155-365, :2132-2142; bestla_prologue_b.h:378-617
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -54,7 +55,7 @@ __device__ __forceinline__ int ref_stored_code(const uint8_t* img, size_t e, siz
 // ============================================================================================================
 __global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ out, uint32_t qstride, int n,
                                     int k, int ntiles, int ksteps, int kind, int ref_bits, int ref_ntile,
-                                    int ref_packrow, int ref_kpad, int ref_npad) {
+                                    int ref_packrow, int ref_kpad, int ref_npad, uint32_t* __restrict__ bad_e5m2) {
   // one thread per output dword
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t total = size_t(ntiles) * ksteps * 64 * 4;
@@ -71,7 +72,7 @@ __global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint8_t* __
   // integer types narrower than the device container (1-3 bit in nibbles, 5-7 bit in bytes) are widened here: the
   // reference stores code + 2^(b-1) in bit planes (decompress_s{1..7}_s8, kernel_ref.h:367-526)
   const int full = 1 << (ref_bits - 1);
-  if (kind == WK_INT8) {
+  if (kind == WK_INT8 || kind == WK_F8) {
     // dword d of the lane: j = d >> 1, bytes i = (d & 1) * 4 .. +3 ; k = s*64 + 32*j + 8*c + i
     const int j = d >> 1;
     for (int b = 0; b < 4; b++) {
@@ -80,6 +81,9 @@ __global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint8_t* __
       if (kk < k && col < n) {
         const size_t e = ref_tiled_index(kk, col, ref_ntile, ref_packrow, ref_kpad);
         q = ref_bits == 8 ? int(img[e]) : ref_stored_code(img, e, elts, ref_bits) - full;
+        // E5M2 codes with exponent field 31 (>= 65536 before scaling) do not fit fp16; the reference quantizer never
+        // emits them (max_norm = 57344, kernel_ref.h:1743-1744) — flag them so that the load fails loudly
+        if (bad_e5m2 && (q & 0x7c) == 0x7c) atomicOr(bad_e5m2, 1u);
       }
       word |= uint32_t(q & 0xff) << (8 * b);
     }
@@ -116,14 +120,35 @@ __global__ void repack_corr_kernel(const T* __restrict__ src, uint8_t* __restric
   *reinterpret_cast<T*>(dst + (size_t(t) * srows + row) * rstride + (size_t(nn) * sps + sp) * sizeof(T)) = v;
 }
 
+// E8M0 shared exponents -> fp32 scales 2^e (e = -127 is the fp32 subnormal 2^-127), same destination layout
+__device__ __forceinline__ uint32_t e8m0_bits(int e) { return e > -127 ? uint32_t(e + 127) << 23 : 0x00400000u; }
+__global__ void repack_e8m0_kernel(const int8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t rstride, int n,
+                                   int ntiles, int srows, int sps, int cstep, int ref_nblk) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t total = size_t(ntiles) * srows * 16 * sps;
+  if (gid >= total) return;
+  const int sp = int(gid % sps);
+  const int nn = int((gid / sps) % 16);
+  const int row = int((gid / (size_t(sps) * 16)) % srows);
+  const int t = int(gid / (size_t(sps) * 16 * srows));
+  const int kb = row * sps + sp;
+  const int col = t * 16 + nn;
+  uint32_t v = 0;
+  if (kb < ref_nblk && col < n) v = e8m0_bits(src[size_t(kb) * cstep + col]);
+  *reinterpret_cast<uint32_t*>(dst + (size_t(t) * srows + row) * rstride + (size_t(nn) * sps + sp) * 4) = v;
+}
+
 hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st) {
   const size_t dwords = size_t(w->ntiles) * w->ksteps * 64 * 4;
   const int ref_bits = dt_bits(w->qtype);
   hipLaunchKernelGGL(repack_codes_kernel, dim3((dwords + 255) / 256), dim3(256), 0, st, a.q, (uint8_t*)w->codes,
                      w->qstride, w->n, w->k, w->ntiles, w->ksteps, w->kind, ref_bits, a.ref_ntile, a.ref_packrow,
-                     a.ref_kpad, a.ref_npad);
+                     a.ref_kpad, a.ref_npad, w->qtype == DT_F8_E5M2 ? a.flags : nullptr);
   const size_t nsc = size_t(w->ntiles) * w->srows * 16 * w->sps;
-  if (w->scale_dt == DT_F32)
+  if (a.src_scale_dt == DT_F8_E8M0)
+    hipLaunchKernelGGL(repack_e8m0_kernel, dim3((nsc + 255) / 256), dim3(256), 0, st, (const int8_t*)a.scales,
+                       (uint8_t*)w->scales, w->sstride, w->n, w->ntiles, w->srows, w->sps, a.cstep, a.ref_nblk);
+  else if (w->scale_dt == DT_F32)
     hipLaunchKernelGGL(repack_corr_kernel<uint32_t>, dim3((nsc + 255) / 256), dim3(256), 0, st,
                        (const uint32_t*)a.scales, (uint8_t*)w->scales, w->sstride, w->n, w->ntiles, w->srows, w->sps,
                        a.cstep, a.ref_nblk);
@@ -134,6 +159,37 @@ hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st) {
   if (w->asym)
     hipLaunchKernelGGL(repack_corr_kernel<int8_t>, dim3((nsc + 255) / 256), dim3(256), 0, st, a.zps, (uint8_t*)w->zps,
                        w->zstride, w->n, w->ntiles, w->srows, w->sps, a.cstep, a.ref_nblk);
+  return hipGetLastError();
+}
+
+// largest finite |scale| of a reference scale section; positive fp32 bit patterns order like unsigned integers
+__global__ void scale_absmax_kernel(const uint8_t* __restrict__ s, size_t count, uint32_t scale_dt, uint32_t* out) {
+  uint32_t best = 0;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) {
+    uint32_t bits;
+    if (scale_dt == DT_F8_E8M0) {
+      bits = e8m0_bits(reinterpret_cast<const int8_t*>(s)[i]);
+    } else if (scale_dt == DT_F32) {
+      bits = reinterpret_cast<const uint32_t*>(s)[i];
+    } else if (scale_dt == DT_BF16) {
+      bits = uint32_t(reinterpret_cast<const uint16_t*>(s)[i]) << 16;
+    } else {
+      bits = __builtin_bit_cast(uint32_t, float(reinterpret_cast<const _Float16*>(s)[i]));
+    }
+    bits &= 0x7fffffffu;
+    if (bits < 0x7f800000u && bits > best) best = bits;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t other = uint32_t(__shfl_xor(int(best), o));
+    best = other > best ? other : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+}
+hipError_t launch_scale_absmax(const void* scales, size_t count, uint32_t scale_dt, uint32_t* out_bits, hipStream_t st) {
+  if (!count) return hipSuccess;
+  const unsigned blocks = unsigned(std::min<size_t>((count + 255) / 256, 1024));
+  hipLaunchKernelGGL(scale_absmax_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint8_t*>(scales), count,
+                     scale_dt, out_bits);
   return hipGetLastError();
 }
 
@@ -192,6 +248,7 @@ struct SmallMParams {
   int ldd;
   float* c2;
   F4Lut lut;
+  F8Consts f8;
 };
 // diagnostics only: build with -DNS_ABLATE=n (1 = no dequant/MFMA, 2 = no scale loads, 4 = no A staging)
 #ifndef NS_ABLATE
@@ -220,7 +277,7 @@ template <int KIND, int SPS, int MB, bool DUAL, int SK, bool ASYM, bool WIDE>
 // WIDE = launched with 16 waves (1024 threads): caps the kernel at 128 VGPRs; the common <= 8-wave instantiation may
 // use more registers (no spills) at 2-3 waves per SIMD, which the kPF-deep load ring makes sufficient
 __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const SmallMParams p) {
-  constexpr int NJ = (KIND == WK_INT8) ? 2 : 4;
+  constexpr int NJ = kind_is_8bit(KIND) ? 2 : 4;
   constexpr int KSTEP = NJ * 32;
   constexpr int NQ = DUAL ? 2 : 1;  // matrices streamed by one workgroup
   // ring depth: the 16-wave (WIDE) variant already has 16 x 2 KiB per workgroup in flight and is capped at 128 VGPRs;
@@ -320,6 +377,8 @@ __global__ __launch_bounds__(WIDE ? kMaxNW * 64 : 512) void smallm_kernel(const 
       } else if constexpr (KIND == WK_INT8) {
         const _Float16 zo = (_Float16)(-1152.f - zp[j]);
         b[j] = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo, zo});
+      } else if constexpr (KIND == WK_F8) {
+        b[j] = cvt_f8x8(xw[2 * j], xw[2 * j + 1], p.f8);
       } else {
         b[j] = cvt_f4x8(xw[j], p.lut);
       }
@@ -606,7 +665,7 @@ static hipError_t launch_smallm_k(const SmallMParams& p, bool dual, int mb, int 
 template <int KIND, int SPS, int SK>
 static hipError_t launch_smallm_a(const SmallMParams& p, bool asym, bool dual, int mb, int grid, int nw, size_t lds,
                                   hipStream_t st) {
-  if constexpr (KIND == WK_F4) {
+  if constexpr (KIND == WK_F4 || KIND == WK_F8) {
     (void)asym;
     return launch_smallm_k<KIND, SPS, SK, false>(p, dual, mb, grid, nw, lds, st);
   } else {
@@ -673,6 +732,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   p.ldd = a.ldd;
   p.c2 = a.c2;
   if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
+  p.f8 = f8_consts(w0->qtype);
   static const int env_nw = getenv("NS_NW") ? atoi(getenv("NS_NW")) : 0;  // diagnostics: waves per workgroup
 
   const int mb = a.m <= 16 ? 1 : (a.m <= 32 ? 2 : 4);
@@ -718,6 +778,9 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   } else if (w0->kind == WK_INT8) {
     if (w0->sps == 2) return launch_smallm_s<WK_INT8, 2>(p, w0->asym, a.dual, mb, grid, nw, lds, st);
     return launch_smallm_s<WK_INT8, 1>(p, w0->asym, a.dual, mb, grid, nw, lds, st);
+  } else if (w0->kind == WK_F8) {  // device scales are always fp32 (E8M0 shared exponents are expanded at load)
+    if (w0->sps == 2) return launch_smallm_a<WK_F8, 2, SK_F32>(p, false, a.dual, mb, grid, nw, lds, st);
+    return launch_smallm_a<WK_F8, 1, SK_F32>(p, false, a.dual, mb, grid, nw, lds, st);
   } else {
     NS_DISPATCH(WK_F4)
   }
@@ -753,11 +816,12 @@ struct GemmParams {
   const float* d;
   int ldd;
   F4Lut lut;
+  F8Consts f8;
 };
 
 template <int KIND, int SPS, int SK, bool ASYM>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-  constexpr int NJ = (KIND == WK_INT8) ? 2 : 4;
+  constexpr int NJ = kind_is_8bit(KIND) ? 2 : 4;
   constexpr int KSTEP = NJ * 32;
   constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
   constexpr int ASTR = KSTEP + 8;  // halves per A row in LDS (+16 B skews banks)
@@ -853,6 +917,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         } else if constexpr (KIND == WK_INT8) {
           const _Float16 zo = (_Float16)(-1152.f - zp);
           b = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo, zo});
+        } else if constexpr (KIND == WK_F8) {
+          b = cvt_f8x8(xw[2 * j], xw[2 * j + 1], p.f8);
         } else {
           b = cvt_f4x8(xw[j], p.lut);
         }
@@ -937,7 +1003,7 @@ bool srow_params(const ns_weight* w0, int* mul, int* shift) {
 
 template <int KIND, int SPS, int SK>
 static hipError_t launch_gemm_k(const GemmParams& p, bool asym, dim3 grid, size_t lds, hipStream_t st) {
-  if constexpr (KIND == WK_F4) {
+  if constexpr (KIND == WK_F4 || KIND == WK_F8) {
     hipLaunchKernelGGL((gemm_kernel<KIND, SPS, SK, false>), grid, dim3(256), lds, st, p);
   } else {
     if (asym)
@@ -988,6 +1054,7 @@ hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st) {
   p.d = a.d;
   p.ldd = a.ldd;
   if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
+  p.f8 = f8_consts(w0->qtype);
   const int kstep = w0->kstep_len;
   const dim3 grid((w0->ntiles + kGemmTiles - 1) / kGemmTiles, (a.m + kGemmBM - 1) / kGemmBM);
   const size_t lds = size_t(kGemmBM) * (kstep + 8) * 2 + size_t(kGemmTiles) * kstep * 16 * 2;
@@ -1002,6 +1069,9 @@ hipError_t launch_gemm(const SmallMArgs& a, hipStream_t st) {
   } else if (w0->kind == WK_INT8) {
     if (w0->sps == 2) return launch_gemm_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, grid, lds, st);
     return launch_gemm_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, grid, lds, st);
+  } else if (w0->kind == WK_F8) {
+    if (w0->sps == 2) return launch_gemm_k<WK_F8, 2, SK_F32>(p, false, grid, lds, st);
+    return launch_gemm_k<WK_F8, 1, SK_F32>(p, false, grid, lds, st);
   } else {
     NS_GDISPATCH(WK_F4)
   }
@@ -1017,18 +1087,19 @@ struct Lut16 {
 __global__ void unpack_kernel(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ scales,
                               const uint8_t* __restrict__ zps, uint32_t qstride, uint32_t sstride, uint32_t zstride,
                               float* __restrict__ out, int ld, int n, int k, int ksteps,
-                              int kind, int sps, int srows, int num, int den, uint32_t scale_dt, Lut16 lut) {
+                              int kind, int sps, int srows, int num, int den, uint32_t scale_dt, Lut16 lut,
+                              uint32_t qtype) {
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (gid >= size_t(n) * k) return;
   const int col = int(gid % n);
   const int kk = int(gid / n);
   const int t = col >> 4, nn = col & 15;
-  const int kstep = (kind == WK_INT8) ? 64 : 128;
+  const int kstep = kind_is_8bit(kind) ? 64 : 128;
   const int s = kk / kstep, r = kk % kstep;
   const int j = r >> 5, c = (r >> 3) & 3, i = r & 7;
   const uint32_t* lane_words =
       reinterpret_cast<const uint32_t*>(codes + (size_t(t) * ksteps + s) * qstride + size_t(c * 16 + nn) * 16);
-  const int nj = (kind == WK_INT8) ? 2 : 4;
+  const int nj = kind_is_8bit(kind) ? 2 : 4;
   const int srow = (s * num) / den;
   const size_t crow = size_t(t) * srows + srow;
   const size_t cidx = size_t(nn) * sps + (j * sps) / nj;
@@ -1038,6 +1109,11 @@ __global__ void unpack_kernel(const uint8_t* __restrict__ codes, const uint8_t* 
   if (kind == WK_INT8) {
     const uint32_t word = lane_words[2 * j + (i >> 2)];
     v = float(int(int8_t((word >> (8 * (i & 3))) & 0xff)) - zp);
+  } else if (kind == WK_F8) {  // f8_to_fp32, kernel_ref.h:984-1002
+    const uint32_t code = (lane_words[2 * j + (i >> 2)] >> (8 * (i & 3))) & 0xff;
+    const int ebits = qtype == DT_F8_E4M3 ? 4 : 5, mbits = 7 - ebits;
+    const uint32_t e = ((code & 0x7f) >> mbits) - (1u << (ebits - 1)) + 1 + 127;
+    v = __uint_as_float(((code << 24) & 0x80000000u) | (e << 23) | ((code << (23 - mbits)) & 0x007fffffu));
   } else {
     const int u = (lane_words[j] >> nib_shift(i)) & 0xf;
     v = (kind == WK_INT4) ? float(u - 8 - zp) : lut.v[u];
@@ -1066,7 +1142,7 @@ hipError_t launch_unpack_fp32(const ns_weight* w, float* out, int ld, hipStream_
   const size_t total = size_t(w->n) * w->k;
   hipLaunchKernelGGL(unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const uint8_t*)w->codes,
                      (const uint8_t*)w->scales, (const uint8_t*)w->zps, w->qstride, w->sstride, w->zstride, out, ld, w->n,
-                     w->k, w->ksteps, w->kind, w->sps, w->srows, num, den, w->scale_dt, lut);
+                     w->k, w->ksteps, w->kind, w->sps, w->srows, num, den, w->scale_dt, lut, w->qtype);
   return hipGetLastError();
 }
 

@@ -105,6 +105,37 @@ __device__ __forceinline__ int f4_code(uint32_t t, float x) {
   return c + sign;
 }
 
+// ---- fp8 weights (kernel_ref.h:1721-1799) --------------------------------------------------------------------------
+// floor(std::log2(float x)) as the reference's host libm evaluates it: log2f rounds to the integer k for the few floats
+// just below 2^k, so the floor is k there, not k-1.  The correctly rounded log2f reproduces that (checked against glibc
+// for every binade); it is obtained from the double-precision log2.
+__device__ __forceinline__ float floor_log2f_libm(float x) { return floorf(float(log2(double(x)))); }
+__device__ __forceinline__ float f8_maxnorm(uint32_t t) { return t == DT_F8_E4M3 ? 448.f : 57344.f; }  // get_mxfp_maxnorm
+__device__ __forceinline__ int f8_mx_code(float v, float scale, uint32_t t, bool e8m0) {
+  const int ebits = t == DT_F8_E4M3 ? 4 : 5, qm = t == DT_F8_E4M3 ? 5 : 4, sm = 7 - ebits;
+  v = __fdiv_rn(v, e8m0 ? ldexpf(1.f, int(scale)) : scale);
+  float pe = floor_log2f_libm(fabsf(v == 0.f ? __fadd_rn(v, 1.f) : v));
+  const float min_exp = float(2 - (1 << (ebits - 1)));
+  pe = pe < min_exp ? min_exp : pe;
+  // scale so that the kept mantissa bits are the integer part, round half away, scale back: all exact in fp32
+  v = ldexpf(v, (qm - 2) - int(pe));
+  const float av = fabsf(v), fl = floorf(av);
+  const float r = (__fsub_rn(av, fl) >= 0.5f) ? __fadd_rn(fl, 1.f) : fl;
+  v = ldexpf(v > 0.f ? r : -r, int(pe) - (qm - 2));
+  const float mx = f8_maxnorm(t);
+  v = (v < -mx) ? -mx : ((mx < v) ? mx : v);
+  uint32_t bits = __float_as_uint(v);
+  const uint32_t sign = (bits >> 24) & 0x80u;
+  bits <<= 1;
+  uint32_t e = ((bits >> 24) - 127u + (1u << (ebits - 1)) - 1u) & 0xffu;
+  if (e > (t == DT_F8_E4M3 ? 15u : 31u)) e = 0;
+  e = (e << sm) & 0xffu;
+  bits <<= 8;
+  const uint32_t mmask = (0xffu << (8 - sm)) & 0xffu;  // int8_t(-128 >> (sm - 1)): the top `sm` bits of the byte
+  const uint32_t m = ((bits >> 24) & mmask) >> (1 + ebits);
+  return int(sign | e | m);
+}
+
 struct SrcView {  // fp32 weight, [N][K] when trans (torch layout) else [K][N]
   const float* w;
   size_t ld;
@@ -113,8 +144,8 @@ struct SrcView {  // fp32 weight, [N][K] when trans (torch layout) else [K][N]
 };
 
 // one thread per (k-block, column).  Codes go to q[k*qsk + n*qsn] (int8), scales/zps to [kb][N].
-__global__ void quantize_kernel(SrcView src, size_t n, size_t k, int bs, uint32_t qtype, bool asym, int8_t* q,
-                                size_t qsk, size_t qsn, float* scales, int8_t* zps) {
+__global__ void quantize_kernel(SrcView src, size_t n, size_t k, int bs, uint32_t qtype, uint32_t stype, bool asym,
+                                int8_t* q, size_t qsk, size_t qsn, float* scales, int8_t* zps) {
   const size_t nblk = (k + bs - 1) / bs;
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (gid >= nblk * n) return;
@@ -124,6 +155,25 @@ __global__ void quantize_kernel(SrcView src, size_t n, size_t k, int bs, uint32_
   const size_t k0 = kb * bs;
   const int len = int(min(size_t(bs), k - k0));
   const size_t sidx = kb * n + col;
+  if (dt_is_f8(qtype)) {  // quantize_f32_f8_rowblock_mxscale, kernel_ref.h:1763-1799
+    const bool e8m0 = stype == DT_F8_E8M0;
+    float scale = FLT_MIN;
+    for (int i = 0; i < len; i++) {
+      const float av = fabsf(src.at(k0 + i, col));
+      scale = (scale < av) ? av : scale;
+    }
+    if (e8m0) {  // shared exponent: floor(log2(absmax)) - emax, not below -127
+      const float emax = qtype == DT_F8_E4M3 ? 8.f : 15.f;
+      scale = __fsub_rn(floor_log2f_libm(scale), emax);
+      scale = scale < -127.f ? -127.f : scale;
+    } else {
+      scale = __fdiv_rn(scale, f8_maxnorm(qtype));
+    }
+    scales[sidx] = scale;
+    for (int i = 0; i < len; i++)
+      q[(k0 + i) * qsk + col * qsn] = int8_t(f8_mx_code(src.at(k0 + i, col), scale, qtype, e8m0));
+    return;
+  }
   if (!dt_is_int(qtype)) {  // kernel_ref.h:1801-1822
     float absmax = FLT_MIN;
     for (int i = 0; i < len; i++) absmax = fmaxf(absmax, fabsf(src.at(k0 + i, col)));
@@ -184,7 +234,9 @@ __global__ void pack_scales_kernel(const float* __restrict__ s, uint8_t* __restr
   const size_t r = gid / cstep, c = gid % cstep;
   const bool live = r < rawnk && c < n;
   const float v = live ? s[r * n + c] : 0.f;
-  if (stype == DT_F32) {
+  if (stype == DT_F8_E8M0) {  // static_cast<int8_t>(shared exponent), bestla_prologue_b.h:1179-1195
+    out[gid] = live ? uint8_t(int8_t(v)) : uint8_t(0);
+  } else if (stype == DT_F32) {
     reinterpret_cast<float*>(out)[gid] = live ? v : 0.f;
   } else {
     uint16_t h = 0;
@@ -225,7 +277,7 @@ __global__ void pack_codes_kernel(TiledSrc src, uint8_t* __restrict__ out, size_
   int v[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) v[i] = src.at(e0 + i);
-  if (is_int && nbits == 8) {
+  if (nbits == 8) {  // S8 and the fp8 types are stored as they are (bestla_prologue_b.h:389-390, :1118-1119)
 #pragma unroll
     for (int i = 0; i < 8; i++) out[e0 + i] = uint8_t(v[i]);
     return;
@@ -328,7 +380,7 @@ hipError_t launch_quant_pack(const QuantArgs& a, hipStream_t st) {
   const size_t qsk = a.is_trans ? 1 : a.n, qsn = a.is_trans ? a.k : 1;
   SrcView sv{a.w, a.ld, a.is_trans};
   hipLaunchKernelGGL(quantize_kernel, grid1d(nblk * a.n, 256), dim3(256), 0, st, sv, a.n, a.k, a.blocksize, a.qtype,
-                     a.asym, q, qsk, qsn, sc, zp);
+                     a.stype, a.asym, q, qsk, qsn, sc, zp);
   e = pack_sections(q, qsk, qsn, sc, zp, a.n, a.k, a.blocksize, a.qtype, a.stype, a.ref_ntile, a.ref_packrow,
                     a.ref_kpad, a.ref_npad, a.cstep, a.has_reduce, a.q_out, a.s_out, a.asym ? a.z_out : nullptr,
                     a.r_out, st);

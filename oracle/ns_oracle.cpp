@@ -24,6 +24,7 @@ namespace {
 inline int dt_bits(uint32_t t) { return int(t & 0xff); }        // bestla_utils.h:408-410
 inline int dt_is_int(uint32_t t) { return ((t >> 8) & 0xff) == 1; }  // bestla_utils.h:414-416
 inline int dt_bytes(uint32_t t) { return dt_bits(t) >> 3; }     // bestla_utils.h:418-421
+inline bool dt_is_f8(uint32_t t) { return t == NSO_F8_E4M3 || t == NSO_F8_E5M2; }
 inline size_t updiv(size_t a, size_t b) { return (a + b - 1) / b; }
 inline size_t padto(size_t a, size_t b) { return updiv(a, b) * b; }
 
@@ -131,6 +132,68 @@ inline float f4_unpack(uint32_t t, int code) {
 
 // IEEE-754 binary16 round-to-nearest-even round trip (NOT the reference's fp16 recipe): used only to model the
 // activation rounding the HIP kernels apply before their fp16 dot/MFMA units.
+// ---- fp8 weights (MX-style) ------------------------------------------------------------------------------------
+// f8_to_fp32 — kernel_ref.h:984-1002: sign | exponent (ebits) | mantissa (7 - ebits); value = 2^(e - (2^(ebits-1) - 1))
+// * (1 + m / 2^mbits) for EVERY code: no zero, no subnormals, no inf/nan — code 0x00 decodes to 2^-7 (E4M3) / 2^-15 (E5M2).
+inline int f8_ebits(uint32_t t) { return t == NSO_F8_E4M3 ? 4 : 5; }        // bestla_utils.h:414-427
+inline int f8_quant_mbits(uint32_t t) { return t == NSO_F8_E4M3 ? 5 : 4; }  // bestla_utils.h:429-442
+inline float f8_to_f32(uint8_t code, uint32_t t) {
+  const int ebits = f8_ebits(t), mbits = 7 - ebits;
+  uint32_t sign = (uint32_t(code) << 24) & 0x80000000u;
+  uint32_t e = (uint32_t(code) & 0x7f) >> mbits;
+  e = e - (1u << (ebits - 1)) + 1 + 127;
+  uint32_t m = (uint32_t(code) << (23 - mbits)) & 0x007fffffu;
+  uint32_t bits = sign | (e << 23) | m;
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+// get_mxfp_maxnorm — bestla_utils.h:444-454 (E4M3: 2^8 * 1.75 = 448, E5M2: 2^15 * 1.75 = 57344)
+inline float f8_maxnorm(uint32_t t) {
+  const int ebits = f8_ebits(t), mant = f8_quant_mbits(t);
+  double emax = std::pow(2.0, ebits - 1);
+  if (t == NSO_F8_E5M2) emax -= 1;
+  double mx = std::pow(2.0, emax);
+  if (t != NSO_F8_E4M3)
+    mx *= (std::pow(2.0, mant - 1) - 1) / std::pow(2.0, mant - 2);
+  else
+    mx *= 1.75;
+  return float(mx);
+}
+// f8_mx_quantize — kernel_ref.h:1721-1761.  `scale` is the shared exponent (E8M0 scales) or the fp32 scale.
+// All intermediate types follow the reference: std::log2(float) and std::floor(float) are the float overloads,
+// std::pow(int, ...) promotes to double, each statement's result is rounded to float where the reference casts.
+inline int8_t f8_mx_quantize(float v, float scale, uint32_t t, uint32_t stype) {
+  if (stype == NSO_F8_E8M0)
+    v /= float(std::pow(2, scale));
+  else
+    v /= scale;
+  const int ebits = f8_ebits(t), quant_mantissa = f8_quant_mbits(t), store_mantissa = 7 - ebits;
+  float private_exp = std::floor(std::log2(std::abs(v == 0 ? v + 1 : v)));
+  const float min_exp = float(-1 * (std::pow(2, ebits - 1)) + 2);
+  private_exp = private_exp < min_exp ? min_exp : private_exp;
+  v = float(v / std::pow(2, private_exp) * std::pow(2, quant_mantissa - 2));
+  const int sign = v > 0 ? 1 : -1;
+  v = sign * float(std::floor(std::abs(v) + 0.5));
+  v = float(v / std::pow(2, quant_mantissa - 2) * std::pow(2, private_exp));
+  const float max_norm = f8_maxnorm(t);
+  v = std::clamp(v, -1 * max_norm, max_norm);
+  uint32_t bits;
+  memcpy(&bits, &v, 4);
+  const uint8_t store_signbit = uint8_t((bits >> 24) & 0x80);
+  bits <<= 1;
+  uint8_t store_ebit = uint8_t(bits >> 24);
+  store_ebit = uint8_t(store_ebit - 127 + uint8_t(std::pow(2, ebits - 1)) - 1);
+  if (store_ebit > 15 && t == NSO_F8_E4M3) store_ebit = 0;
+  if (store_ebit > 31 && t == NSO_F8_E5M2) store_ebit = 0;
+  store_ebit = uint8_t(store_ebit << store_mantissa);
+  bits <<= 8;
+  const int8_t ox80_shift = int8_t(-128 >> (store_mantissa - 1));
+  uint8_t store_mantissabit = uint8_t(uint8_t(bits >> 24) & uint8_t(ox80_shift));
+  store_mantissabit = uint8_t(store_mantissabit >> (1 + ebits));
+  return int8_t(store_signbit | store_ebit | store_mantissabit);
+}
+
 inline float round_through_ieee_f16(float f) {
   uint32_t x;
   memcpy(&x, &f, 4);
@@ -158,6 +221,8 @@ inline float round_through_ieee_f16(float f) {
 }
 
 inline float scale_to_f32(const uint8_t* sbase, uint32_t stype, size_t idx) {
+  if (stype == NSO_F8_E8M0)  // decompress_kblock_f8_fp, kernel_ref.h:1013-1016: scale = pow(2, int8 shared exponent)
+    return float(std::pow(2, int(int8_t(sbase[idx]))));
   if (stype == NSO_F32) {
     float f;
     memcpy(&f, sbase + idx * 4, 4);
@@ -241,8 +306,12 @@ bool describe(nso_blob_info& bi, int n, int k, int blocksize, uint32_t qtype, ui
   const CoreRow& c = kCores[core];
   memset(&bi, 0, sizeof(bi));
   bool is_int = dt_is_int(qtype);
-  if (!is_int && qtype != NSO_F4_NF4 && qtype != NSO_F4_BNB && qtype != NSO_F4_E2M1) return false;
-  if (stype != NSO_F32 && stype != NSO_BF16 && stype != NSO_F16) return false;
+  if (!is_int && qtype != NSO_F4_NF4 && qtype != NSO_F4_BNB && qtype != NSO_F4_E2M1 && !dt_is_f8(qtype)) return false;
+  if (dt_is_f8(qtype)) {  // quantize_f32_f8_rowblock_mxscale asserts E8M0 or F32 scales (kernel_ref.h:1775-1789)
+    if (stype != NSO_F8_E8M0 && stype != NSO_F32) return false;
+  } else if (stype != NSO_F32 && stype != NSO_BF16 && stype != NSO_F16) {
+    return false;
+  }
   bi.prologue_id = is_int ? 1 : 2;
   bi.core_id = make_core_id(c);
   bi.ntile = c.ntile;
@@ -457,6 +526,39 @@ int nso_quantize_f4_rowblock(const float* src, int8_t* dst, int row, int col, in
 float nso_f4_unpack(uint32_t f4type, int code) { return f4_unpack(f4type, code); }
 int nso_f4_quantize(uint32_t f4type, float x) { return f4_quantize(f4type, x); }
 
+// quantize_f32_f8_rowblock_mxscale — kernel_ref.h:1763-1799.  E8M0: scale = floor(log2(absmax)) - emax (shared
+// exponent, clamped at -127), stored as a float holding an integer; F32: scale = absmax / max_norm.
+int nso_quantize_f8_rowblock(const float* src, int8_t* dst, int row, int col, int ld_src, int ld_dst, float* scales,
+                             int blocksize, uint32_t f8type, uint32_t stype) {
+  if (!dt_is_f8(f8type) || (stype != NSO_F8_E8M0 && stype != NSO_F32)) return -1;
+  for (int i = 0; i < col; i++) {
+    for (int j = 0; j < row; j += blocksize) {
+      const int blk = std::min(blocksize, row - j);
+      float scale = std::numeric_limits<float>::min();
+      for (int ij = 0; ij < blk; ij++) scale = std::max(scale, std::abs(src[size_t(j + ij) * ld_src + i]));
+      if (stype == NSO_F8_E8M0) {
+        if (scale == 0) scale += std::abs(std::numeric_limits<float>::min());
+        scale = std::floor(std::log2(scale));
+        float emax = float(std::pow(2, f8_ebits(f8type) - 1));
+        if (f8type == NSO_F8_E5M2) emax -= 1;
+        scale -= emax;
+        const float scale_max = float(std::pow(2, 7)) - 1;
+        scale = scale < (-1 * scale_max) ? (-1 * scale_max) : scale;
+      } else {
+        scale /= f8_maxnorm(f8type);
+      }
+      scales[size_t(j / blocksize) * ld_dst + i] = scale;
+      for (int ij = 0; ij < blk; ij++)
+        dst[size_t(j + ij) * ld_dst + i] = f8_mx_quantize(src[size_t(j + ij) * ld_src + i], scale, f8type, stype);
+    }
+  }
+  return 0;
+}
+float nso_f8_to_f32(uint32_t f8type, int code) { return f8_to_f32(uint8_t(code), f8type); }
+int nso_f8_quantize(uint32_t f8type, uint32_t stype, float v, float scale) {
+  return int(uint8_t(f8_mx_quantize(v, scale, f8type, stype)));
+}
+
 // padding_interleave — kernel_ref.h:39-57
 void nso_padding_interleave(const int8_t* src, int8_t* dst, int row, int col, int rowpad, int colpad, int src_step,
                             int dst_step, int ntile, int rowpack) {
@@ -476,6 +578,10 @@ size_t nso_qbytes(size_t elts, uint32_t qtype) { return qbuf_bytes(elts, qtype);
 // j+4 for 3-bit, j+1 for 1-bit.  Restated as written.
 void nso_compress(const int8_t* src, uint8_t* dst, size_t size, uint32_t qtype) {
   const int nbits = dt_bits(qtype);
+  if (dt_is_f8(qtype)) {  // fp8 codes are stored as they are (packQWeight, bestla_prologue_b.h:1118-1119)
+    memcpy(dst, src, size);
+    return;
+  }
   if (!dt_is_int(qtype)) {  // compress_f4, :167-176
     for (size_t i = 0; i < size; i += 2) dst[i / 2] = uint8_t((src[i] & 0xf) | ((src[i + 1] & 0xf) << 4));
     return;
@@ -526,6 +632,10 @@ void nso_compress(const int8_t* src, uint8_t* dst, size_t size, uint32_t qtype) 
 // decompress_s{1..7}_s8 / decompress_s4_s8 — kernel_ref.h:367-526: stored unsigned code minus 2^(b-1).
 void nso_decompress(const uint8_t* src, int8_t* dst, size_t size, uint32_t qtype) {
   const int nbits = dt_bits(qtype);
+  if (dt_is_f8(qtype)) {
+    memcpy(dst, src, size);
+    return;
+  }
   if (!dt_is_int(qtype)) {
     for (size_t i = 0; i < size; i++) dst[i] = int8_t((src[i / 2] >> (4 * (i % 2))) & 0xf);
     return;
@@ -592,7 +702,9 @@ int nso_pack_q(void* blob, const int8_t* q, int ldq, const float* scales, const 
     for (int c = 0; c < n; c++) {
       float s = scales[size_t(r) * n + c];
       size_t idx = size_t(r) * bi.npad + c;
-      if (stype == NSO_F32) {
+      if (stype == NSO_F8_E8M0) {  // static_cast<int8_t>(shared exponent), bestla_prologue_b.h:1187
+        sp[idx] = uint8_t(int8_t(s));
+      } else if (stype == NSO_F32) {
         memcpy(sp + idx * 4, &s, 4);
       } else {
         uint16_t h = stype == NSO_BF16 ? nso_f32_to_bf16(s) : nso_f32_to_f16(s);
@@ -647,6 +759,8 @@ int nso_quant_pack(void* blob, const float* w, int n, int k, int ldw, int blocks
   if (dt_is_int(qtype))
     nso_quantize_int_rowblock(kn, q.data(), k, n, ld, n, sc.data(), bi.is_asym ? zp.data() : nullptr, bi.blocksize,
                               qtype);
+  else if (dt_is_f8(qtype))
+    nso_quantize_f8_rowblock(kn, q.data(), k, n, ld, n, sc.data(), bi.blocksize, qtype, stype);
   else
     nso_quantize_f4_rowblock(kn, q.data(), k, n, ld, n, sc.data(), bi.blocksize, qtype);
   return nso_pack_q(blob, q.data(), n, sc.data(), bi.is_asym ? zp.data() : nullptr, n, k, blocksize, qtype, stype,
@@ -684,7 +798,9 @@ int nso_unpack_fp32(const void* blob, float* out, int ldb) {
   for (int kk = 0; kk < bi.k; kk++)
     for (int c = 0; c < bi.n; c++) {
       const size_t si = size_t(kk / bi.blocksize) * bi.n + c;
-      float v = is_int ? float(int(q[size_t(kk) * bi.n + c]) - int(zp[si])) : f4_unpack(bi.dtype, q[size_t(kk) * bi.n + c]);
+      const int8_t code = q[size_t(kk) * bi.n + c];
+      float v = is_int ? float(int(code) - int(zp[si]))
+                       : (dt_is_f8(bi.dtype) ? f8_to_f32(uint8_t(code), bi.dtype) : f4_unpack(bi.dtype, code));
       out[size_t(kk) * ldb + c] = v * sc[si];
     }
   return 0;
@@ -754,7 +870,9 @@ int nso_gemv_f32(const float* a, int lda, const void* blob, float* c, int ldc, i
       const int kend = std::min(bi.k, (kb + 1) * bi.blocksize);
       for (int kk = kb * bi.blocksize; kk < kend; kk++) {
         const size_t rowoff = tile_base + size_t(kk / PR) * NT * PR + (kk % PR);
-        if (nbits == 8) {
+        if (nbits == 8 && !is_int) {
+          for (int j = 0; j < NT; j++) wv[j] = f8_to_f32(qb[rowoff + size_t(j) * PR], bi.dtype);
+        } else if (nbits == 8) {
           for (int j = 0; j < NT; j++) wv[j] = float(int(int8_t(qb[rowoff + size_t(j) * PR])) - zz[j]);
         } else if (is_int) {
           for (int j = 0; j < NT; j++) {

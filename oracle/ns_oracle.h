@@ -39,6 +39,9 @@ enum {
   NSO_F4_E2M1 = 4,
   NSO_F4_BNB = 4 | (1 << 16),
   NSO_F4_NF4 = 4 | (2 << 16),
+  NSO_F8_E4M3 = 8,              /* weight types of WeightKBlockNFloat besides the f4 family */
+  NSO_F8_E5M2 = 8 | (1 << 16),
+  NSO_F8_E8M0 = 8 | (3 << 16),  /* scale type: int8 shared exponent, scale = 2^e */
 };
 
 /* GEMM cores a blob can be laid out for — neural_speed/core/layers/bestla_defs.h:36-54 */
@@ -86,6 +89,12 @@ int nso_quantize_int_rowblock(const float* src, int8_t* dst, int row, int col, i
 /* kernel_ref.h:1801-1822 */
 int nso_quantize_f4_rowblock(const float* src, int8_t* dst, int row, int col, int ld_src, int ld_dst, float* scales,
                              int blocksize, uint32_t f4type);
+/* kernel_ref.h:1763-1799 (+ f8_mx_quantize :1721-1761, f8_to_fp32 :984-1002); stype = NSO_F8_E8M0 or NSO_F32.  The
+ * shared exponent is floor(std::log2(float)): it follows the host libm exactly where the reference would. */
+int nso_quantize_f8_rowblock(const float* src, int8_t* dst, int row, int col, int ld_src, int ld_dst, float* scales,
+                             int blocksize, uint32_t f8type, uint32_t stype);
+float nso_f8_to_f32(uint32_t f8type, int code);
+int nso_f8_quantize(uint32_t f8type, uint32_t stype, float v, float scale);
 float nso_f4_unpack(uint32_t f4type, int code);
 int nso_f4_quantize(uint32_t f4type, float x);
 

@@ -19,6 +19,9 @@ S1, S2, S3, S4, S5, S6, S7 = [b | (1 << 8) for b in range(1, 8)]
 F4_E2M1 = 4
 F4_BNB = 4 | (1 << 16)
 F4_NF4 = 4 | (2 << 16)
+F8_E4M3 = 8
+F8_E5M2 = 8 | (1 << 16)
+F8_E8M0 = 8 | (3 << 16)
 INT_TYPES = {1: S1, 2: S2, 3: S3, 4: S4, 5: S5, 6: S6, 7: S7, 8: S8}
 
 CORE_AVX2, CORE_AVX512F, CORE_AMX_BF16, CORE_AMX_FP16, CORE_AVX512_VNNI_KB, CORE_AVX512BW_KB, CORE_AVX_VNNI_KB, \
@@ -72,6 +75,9 @@ def lib():
         _lib.nso_f32_to_bf16.restype = C.c_uint16
         _lib.nso_f32_to_f16.restype = C.c_uint16
         _lib.nso_f4_unpack.restype = C.c_float
+        _lib.nso_f8_to_f32.restype = C.c_float
+        _lib.nso_f8_to_f32.argtypes = [C.c_uint32, C.c_int]
+        _lib.nso_f8_quantize.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float]
         _lib.nso_gelu.restype = C.c_float
         _lib.nso_silu.restype = C.c_float
         _lib.nso_bf16_to_f32.argtypes = [C.c_uint16]
@@ -95,6 +101,8 @@ def ref():
             return None
         _ref = C.CDLL(p)
         _ref.ref_f4_unpack.restype = C.c_float
+        _ref.ref_f8_to_f32.restype = C.c_float
+        _ref.ref_f8_to_f32.argtypes = [C.c_uint32, C.c_int]
         _ref.ref_lut.restype = C.c_float
         _ref.ref_bf16_to_f32.restype = C.c_float
         _ref.ref_f16_to_f32.restype = C.c_float
@@ -127,13 +135,18 @@ def is_int_type(qtype):
     return ((qtype >> 8) & 0xff) == 1
 
 
+def is_f8_type(qtype):
+    return qtype in (F8_E4M3, F8_E5M2)
+
+
 def nblk(k, blocksize):
     return (k + blocksize - 1) // blocksize
 
 
 # ------------------------------------------------------------------ oracle wrappers
-def quantize(w_kn, blocksize, qtype, asym=False):
-    """w_kn: fp32 [K][N].  returns (q int8 [K][N], scales f32 [nblk][N], zps int8 [nblk][N] | None)."""
+def quantize(w_kn, blocksize, qtype, asym=False, stype=F32):
+    """w_kn: fp32 [K][N].  returns (q int8 [K][N], scales f32 [nblk][N], zps int8 [nblk][N] | None).
+    `stype` matters for the fp8 weight types only (F8_E8M0: the scales are shared exponents)."""
     w_kn = np.ascontiguousarray(w_kn, dtype=np.float32)
     k, n = w_kn.shape
     bs = k if blocksize <= 0 else blocksize
@@ -142,6 +155,10 @@ def quantize(w_kn, blocksize, qtype, asym=False):
     if is_int_type(qtype):
         zp = np.zeros((nblk(k, bs), n), np.int8) if asym else None
         rc = lib().nso_quantize_int_rowblock(ptr(w_kn), ptr(q), k, n, n, n, ptr(sc), ptr(zp), bs, C.c_uint32(qtype))
+    elif is_f8_type(qtype):
+        zp = None
+        rc = lib().nso_quantize_f8_rowblock(ptr(w_kn), ptr(q), k, n, n, n, ptr(sc), bs, C.c_uint32(qtype),
+                                            C.c_uint32(stype))
     else:
         zp = None
         rc = lib().nso_quantize_f4_rowblock(ptr(w_kn), ptr(q), k, n, n, n, ptr(sc), bs, C.c_uint32(qtype))

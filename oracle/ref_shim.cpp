@@ -161,6 +161,36 @@ int ref_decompress_kblock_f4_fp(uint32_t f4type, int packrow, uint8_t* src, floa
   return -1;
 }
 
+/* fp8 weights: quantize_f32_f8_rowblock_mxscale<F8_T> (kernel_ref.h:1763-1799), f8_to_fp32 (:984-1002),
+ * decompress_kblock_f8_fp<float, PackRow, scale type> (:1004-1026) */
+int ref_quantize_f8(const float* src, int8_t* dst, int row, int col, int ld_src, int ld_dst, float* scales, int blocksize,
+                    uint32_t f8type, uint32_t stype) {
+  if ((BTLA_DTYPE)f8type == BTLA_DTYPE::F8_E4M3)
+    return (int)kr::quantize_f32_f8_rowblock_mxscale<BTLA_DTYPE::F8_E4M3>(src, dst, row, col, ld_src, ld_dst, scales,
+                                                                          blocksize, (BTLA_DTYPE)stype);
+  if ((BTLA_DTYPE)f8type == BTLA_DTYPE::F8_E5M2)
+    return (int)kr::quantize_f32_f8_rowblock_mxscale<BTLA_DTYPE::F8_E5M2>(src, dst, row, col, ld_src, ld_dst, scales,
+                                                                          blocksize, (BTLA_DTYPE)stype);
+  return -1;
+}
+float ref_f8_to_f32(uint32_t f8type, int code) { return kr::f8_to_fp32(utils::f8((int8_t)code), (BTLA_DTYPE)f8type); }
+int ref_decompress_kblock_f8_fp(uint32_t f8type, int packrow, int8_t* src, float* dst, int row, int col, void* scales,
+                                int scale_is_e8m0, int k_offset, int kblock, int npad) {
+#define NS_F8(P)                                                                                                      \
+  do {                                                                                                                \
+    if (scale_is_e8m0)                                                                                                \
+      return (int)kr::decompress_kblock_f8_fp<float, P, utils::f8>((utils::f8*)src, dst, row, col, col, col,          \
+                                                                   (utils::f8*)scales, k_offset, kblock, npad,        \
+                                                                   (BTLA_DTYPE)f8type);                               \
+    return (int)kr::decompress_kblock_f8_fp<float, P, float>((utils::f8*)src, dst, row, col, col, col, (float*)scales, \
+                                                             k_offset, kblock, npad, (BTLA_DTYPE)f8type);             \
+  } while (0)
+  if (packrow == 1) NS_F8(1);
+  if (packrow == 2) NS_F8(2);
+#undef NS_F8
+  return -1;
+}
+
 void ref_row_reduce_sum_bf16(const float* src, int ldsrc, int row, int col, uint16_t* reduce) {
   kr::row_reduce_sum<utils::bf16>(src, ldsrc, row, col, (utils::bf16*)reduce);
 }

@@ -33,6 +33,10 @@ CASES = [
     ("s5_asym_g32_f32_vnni", "S5", "F32", True, "CORE_AVX512_VNNI_KB", 32, 48, 128),
     ("s2_sym_g32_f16_avx512f", "S2", "F16", False, "CORE_AVX512F", 32, 48, 128),
     ("s7_asym_g32_bf16_vnni", "S7", "BF16", True, "CORE_AVX512_VNNI_KB", 32, 48, 128),
+    ("fp8_e4m3_g32_e8m0_avx512f", "F8_E4M3", "F8_E8M0", False, "CORE_AVX512F", 32, 96, 128),   # quant_utils.cpp:336-341
+    ("fp8_e5m2_g32_e8m0_amxbf16", "F8_E5M2", "F8_E8M0", False, "CORE_AMX_BF16", 32, 48, 128),
+    ("fp8_e4m3_g128_f32_avx512f", "F8_E4M3", "F32", False, "CORE_AVX512F", 128, 48, 256),
+    ("fp8_e5m2_g64_f32_avx512f", "F8_E5M2", "F32", False, "CORE_AVX512F", 64, 50, 192),
 ]
 
 
@@ -58,6 +62,9 @@ def main():
         zp = np.zeros((nb, n), np.int8) if asym else None
         if nso.is_int_type(qtype):
             ref.ref_quantize_int(nso.ptr(wkn), nso.ptr(q), k, n, n, n, nso.ptr(sc), nso.ptr(zp), bs_eff, C.c_uint32(qtype))
+        elif nso.is_f8_type(qtype):
+            ref.ref_quantize_f8(nso.ptr(wkn), nso.ptr(q), k, n, n, n, nso.ptr(sc), bs_eff, C.c_uint32(qtype),
+                                C.c_uint32(stype))
         else:
             ref.ref_quantize_f4(nso.ptr(wkn), nso.ptr(q), k, n, n, n, nso.ptr(sc), bs_eff, C.c_uint32(qtype))
         blob = nso.quant_pack(w, bs, qtype, stype, asym, getattr(nso, core))

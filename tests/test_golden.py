@@ -8,7 +8,7 @@ import pytest
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "btla_golden.npz"))
 NAMES = [str(x) for x in G["names"]]
 # formats the MI355X forward kernels cover today (the quantizer/packer covers all of them)
-FWD_OK = lambda qt: qt in (4 | (1 << 8), 8 | (1 << 8), 4, 4 | (1 << 16), 4 | (2 << 16))
+FWD_OK = lambda qt: qt in (4 | (1 << 8), 8 | (1 << 8), 4, 4 | (1 << 16), 4 | (2 << 16), 8, 8 | (1 << 16))
 
 
 def _meta(name):

@@ -18,14 +18,20 @@ FORMATS = [  # qtype, scale dtype, asym, core, group sizes that are legal for it
     ("S3", "BF16", False, "CORE_AVX512_VNNI_KB", (32,)),
     ("S6", "F32", True, "CORE_AVX512F", (32,)),
 ]
+FORMATS_F8 = [  # fp8 weights (WeightKBlockNFloat with F8_E4M3 / F8_E5M2, quant_utils.cpp:307-341)
+    ("F8_E4M3", "F8_E8M0", False, "CORE_AVX512F", (32, 64, 128)),
+    ("F8_E4M3", "F32", False, "CORE_AVX512F", (32, -1)),
+    ("F8_E5M2", "F8_E8M0", False, "CORE_AMX_BF16", (32, 128)),
+    ("F8_E5M2", "F32", False, "CORE_AVX512F", (64,)),
+]
 MS = [1, 2, 4, 5, 16, 17, 31, 32, 33, 63, 64, 65, 100, 129, 200, 300]
 
 
-def _cases(count, seed):
+def _cases(count, seed, formats=FORMATS):
     rng = np.random.default_rng(seed)
     out = []
     for i in range(count):
-        qt, st, asym, core, groups = FORMATS[int(rng.integers(len(FORMATS)))]
+        qt, st, asym, core, groups = formats[int(rng.integers(len(formats)))]
         bs = int(groups[int(rng.integers(len(groups)))])
         n = int(rng.integers(1, 40)) * 16 + int(rng.choice([0, 0, 1, 7, 15]))
         k = int(rng.integers(1, 17)) * 128 + int(rng.choice([0, 0, 0, 32, 64, 96]))
@@ -36,7 +42,7 @@ def _cases(count, seed):
     return out
 
 
-@pytest.mark.parametrize("i,qt,st,asym,core,bs,n,k,m", _cases(64, 20260925))
+@pytest.mark.parametrize("i,qt,st,asym,core,bs,n,k,m", _cases(64, 20260925) + [(100 + c[0],) + c[1:] for c in _cases(24, 7, FORMATS_F8)])
 def test_random_forward(L, pkg, nso, i, qt, st, asym, core, bs, n, k, m):
     rng = np.random.default_rng(1000 + i)
     w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)

@@ -337,3 +337,74 @@ def test_act_quant_and_u8s8_gemv(nso, refk):
                                           nso.ptr(sc), nso.ptr(zp), bi.cstep, nso.ptr(cref), 48, k, bs)
         assert rc == 0
         assert np.array_equal(cref.view(np.uint32), mine.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------- fp8 weights
+@pytest.mark.parametrize("f8", ["F8_E4M3", "F8_E5M2"])
+def test_f8_decode_all_codes(nso, refk, f8):
+    """f8_to_fp32 (kernel_ref.h:984-1002) for all 256 codes: no zero, no subnormals, no inf/nan in this encoding."""
+    t = getattr(nso, f8)
+    got = np.array([nso.lib().nso_f8_to_f32(t, c) for c in range(256)], np.float32)
+    want = np.array([refk.ref_f8_to_f32(t, c) for c in range(256)], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.all(np.isfinite(got)) and np.all(got != 0)
+
+
+@pytest.mark.parametrize("f8", ["F8_E4M3", "F8_E5M2"])
+@pytest.mark.parametrize("st", ["F8_E8M0", "F32"])
+@pytest.mark.parametrize("kind", ["normal", "uniform", "adversarial"])
+def test_quantize_f8(nso, refk, f8, st, kind):
+    """quantize_f32_f8_rowblock_mxscale (kernel_ref.h:1763-1799): codes and scales bit for bit, incl. a tail block."""
+    rng = np.random.default_rng(300 + len(kind))
+    k, n, bs = 176, 24, 32   # 176 = 5 * 32 + 16: tail block
+    w = _weights(rng, k, n, kind)
+    if kind == "adversarial":
+        w[40:48, 5] = np.float32(2.0) ** np.arange(-20, -12)      # tiny values next to ...
+        w[48, 5] = 3.0                                            # ... a large one (clamped private exponent)
+        w[64:96, 6] = np.nextafter(np.float32(0.25), np.float32(0))  # absmax just below a power of two
+        w[96:128, 7] = 448.0 * 2.0 ** -9                          # exact max_norm multiples
+    t, s_t = getattr(nso, f8), getattr(nso, st)
+    q, sc, _ = nso.quantize(w, bs, t, stype=s_t)
+    q_r = np.zeros_like(q)
+    sc_r = np.zeros_like(sc)
+    rc = refk.ref_quantize_f8(nso.ptr(w), nso.ptr(q_r), k, n, n, n, nso.ptr(sc_r), bs, C.c_uint32(t), C.c_uint32(s_t))
+    assert rc == 0
+    assert np.array_equal(sc.view(np.uint32), sc_r.view(np.uint32))
+    assert np.array_equal(q, q_r)
+
+
+@pytest.mark.parametrize("f8", ["F8_E4M3", "F8_E5M2"])
+@pytest.mark.parametrize("st", ["F8_E8M0", "F32"])
+@pytest.mark.parametrize("core,packrow", [("CORE_AVX512F", 1), ("CORE_AMX_BF16", 2)])
+def test_unpack_f8_matches_reference_tile_dequant(nso, refk, f8, st, core, packrow):
+    """blob -> fp32 through the oracle == the reference's decompress_kblock_f8_fp applied to the blob's own tiles."""
+    rng = np.random.default_rng(77)
+    n, k, bs = 96, 128, 32
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    blob = nso.quant_pack(w, bs, getattr(nso, f8), getattr(nso, st), False, getattr(nso, core))
+    bi = nso.parse(blob)
+    assert bi.prologue_id == 2 and bi.q_bytes == bi.npad * bi.kpad
+    mine = nso.unpack_fp32(blob)
+    nt = bi.ntile
+    sbytes = 1 if st == "F8_E8M0" else 4
+    for t in range(bi.npad // nt):
+        tile = np.ascontiguousarray(blob[bi.q_off + t * nt * bi.kpad: bi.q_off + (t + 1) * nt * bi.kpad]).view(np.int8)
+        sc = np.ascontiguousarray(
+            blob[bi.scale_off: bi.scale_off + bi.scale_bytes].reshape(-1, bi.cstep * sbytes)[:, t * nt * sbytes:(t + 1) * nt * sbytes])
+        # One call per k-block with the scale pointer advanced to that block's row: the scalar reference reads fp32
+        # scales as scales[j / PACK_ROW] without the k-block offset (kernel_ref.h:1017-1018, a typo the AVX2/AVX512
+        # product kernels do not have: kernel_avx512f.h:668-694 use sptr = scales + kpos * NPad for both scale types).
+        dst = np.zeros((bi.kpad // packrow, nt * packrow), np.float32)
+        rows_blk = bs // packrow
+        for kb in range(bi.kpad // bs):
+            src_blk = tile[kb * rows_blk * nt * packrow:]
+            dst_blk = dst[kb * rows_blk:]
+            sc_blk = np.ascontiguousarray(sc[kb])
+            rc = refk.ref_decompress_kblock_f8_fp(C.c_uint32(getattr(nso, f8)), packrow, nso.ptr(src_blk),
+                                                  nso.ptr(dst_blk), rows_blk, nt * packrow, nso.ptr(sc_blk),
+                                                  int(st == "F8_E8M0"), 0, rows_blk, nt)
+            assert rc == 0
+        # dst[k / P][j * P + k % P] -> [k][j]
+        deq = dst.reshape(bi.kpad // packrow, nt, packrow).transpose(0, 2, 1).reshape(bi.kpad, nt)
+        cols = min(nt, bi.n - t * nt)
+        assert np.array_equal(mine[:, t * nt:t * nt + cols].view(np.uint32), deq[:bi.k, :cols].view(np.uint32))
