@@ -175,8 +175,8 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
     set_error("weight dtype not supported by the MI355X kernels yet (supported: S1..S8, F4_NF4, F4_BNB, F4_E2M1, F8_E4M3, F8_E5M2)");
     return false;
   }
-  if (v.shuf_bytes) {
-    set_error("activation-shuffle (g_idx) blobs are not supported");
+  if (v.shuf_bytes && v.shuf_bytes != uint64_t(v.k) * sizeof(int)) {
+    set_error("blob: shuffle-index section does not hold K entries");
     return false;
   }
   if (v.scale_dt != DT_F32 && v.scale_dt != DT_BF16 && v.scale_dt != DT_F16 &&
@@ -277,6 +277,18 @@ void set_gemm_scale_range(ns_weight* w, uint32_t smax_bits) {
   w->g2_post = ldexpf(1.f, -shift);
 }
 
+// every shuffle index must address a column of A
+bool check_shuffle(const ns_weight* w) {
+  std::vector<int> h(size_t(w->k));
+  if (!hip_ok(hipMemcpy(h.data(), w->shuf, h.size() * sizeof(int), hipMemcpyDeviceToHost), "D2H shuffle")) return false;
+  for (int v : h)
+    if (v < 0 || v >= w->k) {
+      set_error("blob: shuffle index outside [0, K)");
+      return false;
+    }
+  return true;
+}
+
 // sections already in device memory -> device weight
 ns_weight* weight_from_device_sections(const BlobView& v, const uint8_t* dq, const uint8_t* ds, const int8_t* dz,
                                        hipStream_t st) {
@@ -369,7 +381,7 @@ struct PackPlan {
   int core;
 };
 bool plan_pack(PackPlan* pp, size_t N, size_t K, size_t BlkSize, uint32_t qt, uint32_t st, bool asym, int comp,
-               uintptr_t base_addr) {
+               uintptr_t base_addr, bool shuffle = false) {
   const size_t bs_eff = (int64_t(BlkSize) <= 0) ? K : BlkSize;
   pp->core = core_for_comp(comp, qt, asym, bs_eff, g_pack_core);
   const CoreDesc& cd = core_desc(pp->core);
@@ -378,7 +390,8 @@ bool plan_pack(PackPlan* pp, size_t N, size_t K, size_t BlkSize, uint32_t qt, ui
     return false;
   }
   std::string err;
-  if (!blob_describe(&pp->v, N, K, BlkSize, qt, st, asym, pp->core, base_addr, &err)) {
+  // shuffle indices exist for integer weights only (BTLAGemmPackBImpl, bestla_gemm.cpp:407-419)
+  if (!blob_describe(&pp->v, N, K, BlkSize, qt, st, asym, pp->core, base_addr, &err, shuffle && dt_is_int(qt))) {
     set_error(err);
     return false;
   }
@@ -396,6 +409,17 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   if (!smallm_supported(w, m)) {
     set_error("forward: weight format not supported");
     return -1;
+  }
+  if (w->shuf) {  // GPTQ act-order blob: gather A'[j] = A[shuf[j]] into scratch first (prologue_a.h:322-330)
+    float* ga = static_cast<float*>(stream_scratch(st, size_t(m) * w->k * 4, 3));
+    if (!ga) {
+      set_error("forward: no scratch for the activation shuffle (run once outside stream capture first)");
+      return -1;
+    }
+    if (!hip_ok(launch_gather_cols(dA, lda, w->shuf, ga, m, w->k, st), "activation shuffle")) return -1;
+    dA = ga;
+    lda = w->k;
+    dA16 = nullptr;  // the caller's fp16 shadow is in the unshuffled order
   }
   // M <= 64: weight-streaming kernel (HBM-bound); larger M: tiled MFMA GEMM (weights reused across 128 rows)
   SmallMArgs a{};
@@ -476,7 +500,10 @@ ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream) {
     if (!hip_ok(hipMemcpyAsync(dz.p, base + v.z_off, v.z_bytes, hipMemcpyHostToDevice, st), "H2D zps")) return nullptr;
   }
   ns_weight* w = weight_from_device_sections(v, dq.p, ds.p, dz.p, st);
-  if (!hip_ok(hipStreamSynchronize(st), "sync after repack")) {
+  if (w && v.shuf_bytes &&
+      (!hip_ok(hipMalloc((void**)&w->shuf, v.shuf_bytes), "hipMalloc(shuffle)") ||
+       !hip_ok(hipMemcpy(w->shuf, base + v.shuf_off, v.shuf_bytes, hipMemcpyHostToDevice), "H2D shuffle") ||
+       !check_shuffle(w))) {
     ns_hip_weight_free(w);
     return nullptr;
   }
@@ -503,6 +530,13 @@ ns_weight* ns_hip_weight_from_device_blob(const void* dev_blob, size_t blob_byte
   }
   ns_weight* w = weight_from_device_sections(v, base + v.q_off, base + v.s_off,
                                              v.asym() ? (const int8_t*)(base + v.z_off) : nullptr, st);
+  if (w && v.shuf_bytes &&
+      (!hip_ok(hipMalloc((void**)&w->shuf, v.shuf_bytes), "hipMalloc(shuffle)") ||
+       !hip_ok(hipMemcpy(w->shuf, base + v.shuf_off, v.shuf_bytes, hipMemcpyDeviceToDevice), "D2D shuffle") ||
+       !check_shuffle(w))) {
+    ns_hip_weight_free(w);
+    return nullptr;
+  }
   return w;
 }
 
@@ -520,10 +554,15 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
     set_error("slice: n0 must be a multiple of 16, k0/k1 multiples of the k-step and of the group size");
     return nullptr;
   }
+  if (w->shuf && (k0 != 0 || k1 != w->k)) {
+    set_error("slice: an activation-shuffle (g_idx) weight cannot be split along K");
+    return nullptr;
+  }
   ns_weight* o = new ns_weight(*w);
   o->codes = nullptr;
   o->scales = nullptr;
   o->zps = nullptr;
+  o->shuf = nullptr;
   o->n = n1 - n0;
   o->k = k1 - k0;
   o->ntiles = (o->n + 15) / 16;
@@ -572,6 +611,9 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
                                          size_t(w->srows) * w->zstride, size_t(o->srows) * o->zstride, o->ntiles,
                                          hipMemcpyDeviceToDevice, st), "slice zps");
   }
+  if (ok && w->shuf)
+    ok = hip_ok(hipMalloc((void**)&o->shuf, size_t(w->k) * sizeof(int)), "hipMalloc(shuffle)") &&
+         hip_ok(hipMemcpyAsync(o->shuf, w->shuf, size_t(w->k) * sizeof(int), hipMemcpyDeviceToDevice, st), "slice shuffle");
   if (!ok) {
     ns_hip_weight_free(o);
     return nullptr;
@@ -582,6 +624,7 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
 void ns_hip_weight_free(ns_weight* w) {
   if (!w) return;
   if (w->codes) hipFree(w->codes);  // scales / zps / workspace live in the same allocation
+  if (w->shuf) hipFree(w->shuf);
   delete w;
 }
 
@@ -626,6 +669,7 @@ int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weig
   for (int i = 1; i < 3; i++)
     same &= ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize &&
             ws[i]->scale_dt == wq->scale_dt && ws[i]->asym == wq->asym && ws[i]->qtype == wq->qtype;
+  same &= !wq->shuf && !wk->shuf && !wv->shuf;  // each shuffled weight gathers its own A' (unfused path)
   hipStream_t st = (hipStream_t)stream;
   if (!same || m > 64) {  // fall back to three launches (still on the GPU)
     for (int i = 0; i < 3; i++)
@@ -662,7 +706,8 @@ int ns_hip_fusion_ffn3_gateup_h(const float* dA, const void* dA16, const ns_weig
   hipStream_t st = (hipStream_t)stream;
   const int fin = w1->k, fmid = w1->n;
   const bool same = w3->k == fin && w3->n == fmid && w3->kind == w1->kind && w3->blocksize == w1->blocksize &&
-                    w3->scale_dt == w1->scale_dt && w3->asym == w1->asym && w3->qtype == w1->qtype;
+                    w3->scale_dt == w1->scale_dt && w3->asym == w1->asym && w3->qtype == w1->qtype && !w1->shuf &&
+                    !w3->shuf;
   if (same && smallm_dual_ok(seq) && smallm_supported(w1, seq)) {
     SmallMArgs a{};
     a.a = dA;
@@ -770,24 +815,38 @@ void ns_set_pack_core(int core) { g_pack_core = core; }
 
 size_t ns_BTLAGemmPackBSize(size_t N, size_t K, size_t BlkSize, uint32_t QuantType, uint32_t ScaleDtype, bool isAsym,
                             int CompType, int* shuffle_indice) {
-  if (shuffle_indice) {
-    set_error("pack: shuffle indices (g_idx) not supported");
-    return 0;
-  }
   PackPlan pp;
-  if (!plan_pack(&pp, N, K, BlkSize, QuantType, ScaleDtype, isAsym, CompType, 0)) return 0;
+  if (!plan_pack(&pp, N, K, BlkSize, QuantType, ScaleDtype, isAsym, CompType, 0, shuffle_indice != nullptr)) return 0;
   return pp.v.size;
 }
 
 static bool pack_common(void* PackedBuf, const float* FpData, const int8_t* QData, const float* Scales,
                         const int8_t* Zp, size_t N, size_t K, size_t ldb, size_t BlkSize, uint32_t qt, uint32_t stp,
-                        bool asym, int comp, bool isTrans) {
+                        bool asym, int comp, bool isTrans, const int* g_idx = nullptr) {
   if (!have_device()) return false;
   PackPlan pp;
-  if (!plan_pack(&pp, N, K, BlkSize, qt, stp, asym, comp, reinterpret_cast<uintptr_t>(PackedBuf))) return false;
+  if (!plan_pack(&pp, N, K, BlkSize, qt, stp, asym, comp, reinterpret_cast<uintptr_t>(PackedBuf), g_idx != nullptr))
+    return false;
+  std::vector<int> idx;
+  if (g_idx) {
+    // setShuffleIndices (bestla_prologue_b.h:337-356): slot g * blocksize + (members of group g seen so far) <- k.
+    // K ints of index bookkeeping on the host; the codes arrive already sorted this way (convert/common.py:667-681).
+    const size_t bs = size_t(pp.v.blocksize), groups = (K + bs - 1) / bs;
+    std::vector<int> count(groups, 0);
+    idx.assign(K, 0);
+    for (size_t i = 0; i < K; i++) {
+      const int g = g_idx[i];
+      if (g < 0 || size_t(g) >= groups || size_t(g) * bs + size_t(count[g]) >= K) {
+        set_error("pack: g_idx does not describe groups of `BlkSize` input channels");
+        return false;
+      }
+      idx[size_t(g) * bs + size_t(count[g]++)] = int(i);
+    }
+  }
   const BlobView& v = pp.v;
   uint8_t* host = static_cast<uint8_t*>(PackedBuf);
   blob_write_header(v, host);  // == stor.assign(PackedBuf), bestla_gemm.cpp:312
+  if (g_idx) memcpy(host + v.shuf_off, idx.data(), K * sizeof(int));
   DevBuf<uint8_t> dq, ds;
   DevBuf<int8_t> dz;
   DevBuf<uint16_t> dr;
@@ -849,13 +908,9 @@ bool ns_BTLAGemmPackB(void* PackedBuf, const int8_t* QData, const float* Scales,
                       size_t ldb, size_t BlkSize, uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType,
                       int* shuffle_indice, void* ThreadPool) {
   (void)ThreadPool;
-  if (shuffle_indice) {
-    set_error("pack: shuffle indices (g_idx) not supported");
-    return false;
-  }
   if (!dt_is_int(QuantType)) return false;  // bestla_gemm.cpp:431-433
   return pack_common(PackedBuf, nullptr, QData, Scales, isAsym ? Zp : nullptr, N, K, ldb, BlkSize, QuantType,
-                     ScaleDtype, isAsym, CompType, false);
+                     ScaleDtype, isAsym, CompType, false, shuffle_indice);
 }
 
 bool ns_BTLAGemmUnPackB(float* FpData, const void* PackedBuf, size_t N, size_t K, size_t ldb, void* ThreadPool) {
@@ -989,6 +1044,7 @@ bool bestla_fusion_QKV_f32f32_support(void* wqptr, void* wkptr, void* wvptr, int
   if (ns_hip_device_count() <= 0) return false;
   ns_weight *q = cached_weight(wqptr), *k = cached_weight(wkptr), *v = cached_weight(wvptr);
   if (!q || !k || !v) return false;
+  if (q->shuf || k->shuf || v->shuf) return false;  // ip_fusion_qkv.cpp:174-176: no QKV fusion with activation shuffle
   // samePackedWeight (bestla_common.hpp:90-119): identical shape + format for all three
   for (ns_weight* w : {q, k, v})
     if (w->n != _n || w->k != _k || w->kind != q->kind || w->blocksize != q->blocksize || w->scale_dt != q->scale_dt ||

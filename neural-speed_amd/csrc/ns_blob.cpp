@@ -170,7 +170,7 @@ static size_t code_bytes(size_t elts, uint32_t qtype) {  // bestla_storage.h:729
 }
 
 bool blob_describe(BlobView* out, size_t n, size_t k, size_t blocksize, uint32_t qtype, uint32_t stype, bool asym,
-                   int core, uintptr_t base_addr, std::string* err) {
+                   int core, uintptr_t base_addr, std::string* err, bool shuffle) {
   BlobView v;
   const bool is_int = dt_is_int(qtype);
   if (!is_int && !dt_is_f4(qtype) && !dt_is_f8(qtype)) {
@@ -208,6 +208,7 @@ bool blob_describe(BlobView* out, size_t n, size_t k, size_t blocksize, uint32_t
     v.z_bytes = asym ? v.csize : 0;
     const int btype = (cd.comp >> 4) & 0xf;  // integer compute cores carry the per-block reduce (storage.h:747-749)
     v.r_bytes = (btype == 3 || btype == 4) ? v.csize * 2 : 0;
+    if (shuffle) v.shuf_bytes = uint64_t(k) * sizeof(int);  // enable_shuffle, bestla_storage.h:761-765
   }
   // serialized size = sum of every object's getSerializedSize(): each present section reserves 16 + bytes + 64
   auto sec = [](uint64_t b) { return size_t(16 + b + 64); };

@@ -57,7 +57,7 @@ bool blob_parse_io(const BlobIo& io, BlobView* out, std::string* err);
 // Fill sizes/offsets for a NEW blob that will be serialised at address `base_addr`: the reference aligns each
 // section to 64 B in absolute-address terms (bestla_storage.h:85-95), so the layout depends on base_addr % 64.
 bool blob_describe(BlobView* out, size_t n, size_t k, size_t blocksize, uint32_t qtype, uint32_t stype, bool asym,
-                   int ns_core, uintptr_t base_addr, std::string* err);
+                   int ns_core, uintptr_t base_addr, std::string* err, bool shuffle = false);
 // Write every non-payload byte (sizes, pads, flags, ids) of a described blob.
 void blob_write_header(const BlobView& v, void* host_base);
 void blob_write_header_io(const BlobView& v, const BlobIo& io, uintptr_t base_addr);
@@ -108,6 +108,9 @@ struct ns_weight {
   // gemm2 (ns_gemm.hip) rounds `scale * g2_pre` to fp16 and multiplies its accumulators by g2_post = 1 / g2_pre: a
   // power of two chosen at load time from the largest |scale| so that dequantised weights stay in fp16's normal range
   float g2_pre = 1.f, g2_post = 1.f;
+  // activation shuffle of GPTQ act-order blobs (ShuffleIndices, bestla_storage.h:704): int[k] on the device, own
+  // allocation; the forward gathers A'[j] = A[shuf[j]] before the GEMM (prologue_a.h:322-330).  null = none.
+  int* shuf = nullptr;
   _Float16 lut[16];  // f4 value table rounded to fp16: the MFMA operand (kind == WK_F4)
   float lutf[16];    // the same table in fp32: exact unpack
 };
@@ -204,6 +207,8 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
                                   float freq_scale, float attn_factor, long long c_sl, long long c_head, hipStream_t st);
 hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
                             int ld_scale, uint8_t* zps, int blocksize, float* blkreduce, hipStream_t st);
+// A'[r][j] = A[r][idx[j]] (kernel_ref.h:28-37 shuffle_activation), fp32 [m][k] with leading dimension k
+hipError_t launch_gather_cols(const float* a, int lda, const int* idx, float* out, int m, int k, hipStream_t st);
 hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float* v, int vstep, float* out, bool mul,
                                hipStream_t st);
 

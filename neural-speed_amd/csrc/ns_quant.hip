@@ -661,6 +661,19 @@ hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int hea
   return hipGetLastError();
 }
 
+__global__ void gather_cols_kernel(const float* __restrict__ a, int lda, const int* __restrict__ idx,
+                                   float* __restrict__ out, int m, int k) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= size_t(m) * k) return;
+  const int r = int(gid / k), j = int(gid % k);
+  out[gid] = a[size_t(r) * lda + idx[j]];
+}
+hipError_t launch_gather_cols(const float* a, int lda, const int* idx, float* out, int m, int k, hipStream_t st) {
+  const size_t total = size_t(m) * k;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, a, lda, idx, out, m, k);
+  return hipGetLastError();
+}
+
 hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float* v, int vstep, float* out, bool mul,
                                hipStream_t st) {
   const size_t total = size_t(batch) * vsize;

@@ -301,7 +301,8 @@ size_t qbuf_bytes(size_t elts, uint32_t qtype) {  // bestla_storage.h:729-745, :
 
 // Fill every size field for a fresh storage object: createStorage + resize
 // (bestla_prologue_b.h:120-127 / :1011-1017; bestla_storage.h:725-753 / :842-858; :165-181)
-bool describe(nso_blob_info& bi, int n, int k, int blocksize, uint32_t qtype, uint32_t stype, int asym, int core) {
+bool describe(nso_blob_info& bi, int n, int k, int blocksize, uint32_t qtype, uint32_t stype, int asym, int core,
+              bool shuffle = false) {
   if (core < 0 || core >= NSO_CORE_COUNT) return false;
   const CoreRow& c = kCores[core];
   memset(&bi, 0, sizeof(bi));
@@ -338,7 +339,12 @@ bool describe(nso_blob_info& bi, int n, int k, int blocksize, uint32_t qtype, ui
     bi.has_reduce = comp_is_integer(c.comp);  // bestla_storage.h:747-749
     bi.zp_bytes = bi.is_asym ? bi.csize * 1 : 0;
     bi.red_bytes = bi.has_reduce ? bi.csize * 2 : 0;
+    if (shuffle) {  // enable_shuffle, bestla_storage.h:761-765: int[K] after the correction buffers
+      bi.shuf_bytes = uint64_t(k) * sizeof(int);
+      bi.has_shuffle = 1;
+    }
   } else {
+    if (shuffle) return false;  // BTLAGemmPackBImpl ignores shuffle indices for float weights (bestla_gemm.cpp:416-419)
     bi.zp_dtype = 0;  // EleBitsUndef, bestla_storage.h:849-850
     bi.red_dtype = 0;
   }
@@ -685,10 +691,10 @@ int nso_blob_parse(const void* blob, nso_blob_info* info) {
 
 // packQWeight — bestla_prologue_b.h:378-398 (integer) / :1109-1127 (float):
 //   setQuantCorrection (:244-335), reorderWeight (:490-510), compressWeight (:606-617), reduceWeight (:455-470)
-int nso_pack_q(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k,
-               int blocksize, uint32_t qtype, uint32_t stype, int asym, int core) {
+static int pack_q_impl(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k,
+                       int blocksize, uint32_t qtype, uint32_t stype, int asym, int core, const int* g_idx) {
   nso_blob_info bi;
-  if (!describe(bi, n, k, blocksize, qtype, stype, asym, core)) return -1;
+  if (!describe(bi, n, k, blocksize, qtype, stype, asym, core, g_idx != nullptr)) return -1;
   uint8_t* base = (uint8_t*)blob;
   Cursor cur{base, base, true};
   if (!walk(cur, bi)) return -1;  // == stor.assign(PackedBuf), bestla_gemm.cpp:312,:414
@@ -735,7 +741,34 @@ int nso_pack_q(void* blob, const int8_t* q, int ldq, const float* scales, const 
         rp[size_t(kb) * bi.cstep + c] = nso_f32_to_bf16(tmp);
       }
   }
+  // setShuffleIndices — bestla_prologue_b.h:337-356: position g * blocksize + (running count of group g) holds the
+  // original k index; the caller has already sorted the rows of q the same way (convert/common.py:667-681)
+  if (g_idx) {
+    int* sp32 = (int*)(base + bi.shuf_off);
+    const int groups = int(updiv(k, bi.blocksize));
+    std::vector<int> count(groups, 0);
+    for (int i = 0; i < k; i++) {
+      const int g = g_idx[i];
+      if (g < 0 || g >= groups) return -2;
+      const size_t pos = size_t(g) * bi.blocksize + count[g]++;
+      if (pos >= size_t(k)) return -2;
+      sp32[pos] = i;
+    }
+  }
   return 0;
+}
+int nso_pack_q(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k,
+               int blocksize, uint32_t qtype, uint32_t stype, int asym, int core) {
+  return pack_q_impl(blob, q, ldq, scales, zps, n, k, blocksize, qtype, stype, asym, core, nullptr);
+}
+int nso_pack_q_gidx(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k,
+                    int blocksize, uint32_t qtype, uint32_t stype, int asym, int core, const int* g_idx) {
+  return pack_q_impl(blob, q, ldq, scales, zps, n, k, blocksize, qtype, stype, asym, core, g_idx);
+}
+size_t nso_pack_size_gidx(int n, int k, int blocksize, uint32_t qtype, uint32_t stype, int asym, int core) {
+  nso_blob_info bi;
+  if (!describe(bi, n, k, blocksize, qtype, stype, asym, core, true)) return 0;
+  return bi.size;
 }
 
 // BTLAGemmQuantPackB — bestla_gemm.cpp:302-319 -> packTransposeWeight/packWeight (prologue_b.h:180-210, :1019-1040)
@@ -811,10 +844,12 @@ static int gemm_f64_impl(const float* a, int lda, const void* blob, double* c, i
   if (nso_blob_parse(blob, &bi)) return -1;
   std::vector<float> w(size_t(bi.k) * bi.n);
   nso_unpack_fp32(blob, w.data(), bi.n);
+  const int* shuf = bi.has_shuffle ? (const int*)((const uint8_t*)blob + bi.shuf_off) : nullptr;
   std::vector<double> arow(bi.k);
   for (int i = 0; i < m; i++) {
     for (int kk = 0; kk < bi.k; kk++) {
-      float av = a[size_t(i) * lda + kk];
+      // activation shuffle (g_idx blobs): A'[j] = A[indices[j]], kernel_ref.h:28-37 via prologue_a.h:322-330
+      float av = a[size_t(i) * lda + (shuf ? shuf[kk] : kk)];
       if (a16) av = round_through_ieee_f16(av);  // what v_cvt_f16_f32 (RNE) does on the device
       arow[kk] = av;
     }
@@ -842,6 +877,7 @@ int nso_gemv_f32(const float* a, int lda, const void* blob, float* c, int ldc, i
   if (nso_blob_parse(blob, &bi)) return -1;
   const int nbits = dt_bits(bi.dtype);
   if (nbits != 4 && nbits != 8) return -2;
+  if (bi.has_shuffle) return -4;
   const bool is_int = bi.prologue_id == 1;
   const uint8_t* base = (const uint8_t*)blob;
   const uint8_t* qb = base + bi.q_off;

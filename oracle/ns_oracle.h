@@ -112,6 +112,14 @@ size_t nso_pack_size(int n, int k, int blocksize, uint32_t qtype, uint32_t stype
 /* BTLAGemmPackB (bestla_gemm.cpp:401-422, prologue_b.h:378-398): q [K][N] (ld = ldq), scales/zp [ceil(K/blk)][N] */
 int nso_pack_q(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k,
                int blocksize, uint32_t qtype, uint32_t stype, int asym, int core);
+/* the same with GPTQ act-order group indices (g_idx[k] = group of input channel k; bestla_gemm.cpp:409-413 ->
+ * setShuffleIndices, bestla_prologue_b.h:337-356).  q's rows are already in group-sorted order (the converter does
+ * that, neural_speed/convert/common.py:667-681); the blob gains an int[K] section, and the GEMM gathers
+ * A'[j] = A[indices[j]] first (nso_gemm_f64* honour it; nso_unpack_* return the stored, sorted-order weights, as
+ * BTLAGemmUnPackB does). */
+int nso_pack_q_gidx(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k,
+                    int blocksize, uint32_t qtype, uint32_t stype, int asym, int core, const int* g_idx);
+size_t nso_pack_size_gidx(int n, int k, int blocksize, uint32_t qtype, uint32_t stype, int asym, int core);
 /* BTLAGemmQuantPackB (bestla_gemm.cpp:302-319): fp32 weight, [N][K] if is_trans (torch layout) else [K][N] */
 int nso_quant_pack(void* blob, const float* w, int n, int k, int ldw, int blocksize, uint32_t qtype, uint32_t stype,
                    int asym, int core, int is_trans);

@@ -68,6 +68,7 @@ def lib():
         build()
         _lib = C.CDLL(os.path.join(HERE, "libns_oracle.so"))
         _lib.nso_pack_size.restype = C.c_size_t
+        _lib.nso_pack_size_gidx.restype = C.c_size_t
         _lib.nso_qbytes.restype = C.c_size_t
         _lib.nso_core_id.restype = C.c_uint64
         _lib.nso_bf16_to_f32.restype = C.c_float
@@ -183,13 +184,24 @@ def quant_pack(w, blocksize, qtype, stype=BF16, asym=False, core=CORE_AVX512_VNN
     return blob
 
 
-def pack_q(q_kn, scales, zps, blocksize, qtype, stype=BF16, core=CORE_AVX512_VNNI_KB, fill=0):
+def pack_q(q_kn, scales, zps, blocksize, qtype, stype=BF16, core=CORE_AVX512_VNNI_KB, fill=0, g_idx=None):
+    """BTLAGemmPackB.  g_idx (int32 [K], group of every input channel) makes an activation-shuffle blob; q_kn's rows
+    must then already be in group-sorted order (see sort_rows_by_group)."""
     q_kn = np.ascontiguousarray(q_kn, dtype=np.int8)
     k, n = q_kn.shape
     scales = np.ascontiguousarray(scales, dtype=np.float32)
     asym = zps is not None
     if asym:
         zps = np.ascontiguousarray(zps, dtype=np.int8)
+    if g_idx is not None:
+        g_idx = np.ascontiguousarray(g_idx, dtype=np.int32)
+        size = lib().nso_pack_size_gidx(n, k, blocksize, C.c_uint32(qtype), C.c_uint32(stype), int(asym), core)
+        assert size > 0
+        blob = aligned_bytes(size, fill=fill)
+        rc = lib().nso_pack_q_gidx(ptr(blob), ptr(q_kn), n, ptr(scales), ptr(zps), n, k, blocksize, C.c_uint32(qtype),
+                                   C.c_uint32(stype), int(asym), core, ptr(g_idx))
+        assert rc == 0
+        return blob
     size = pack_size(n, k, blocksize, qtype, stype, asym, core)
     assert size > 0
     blob = aligned_bytes(size, fill=fill)
@@ -197,6 +209,18 @@ def pack_q(q_kn, scales, zps, blocksize, qtype, stype=BF16, core=CORE_AVX512_VNN
                           C.c_uint32(stype), int(asym), core)
     assert rc == 0
     return blob
+
+
+def sort_rows_by_group(x_kn, g_idx, blocksize):
+    """what the reference converter does to GPTQ act-order weights before packing (convert/common.py:667-681): row i
+    goes to position g_idx[i] * group_size + (how many rows of that group came before it)."""
+    out = np.empty_like(x_kn)
+    count = {}
+    for i, g in enumerate(np.asarray(g_idx).tolist()):
+        c = count.get(g, 0)
+        out[g * blocksize + c] = x_kn[i]
+        count[g] = c + 1
+    return out
 
 
 def parse(blob):

@@ -191,6 +191,12 @@ int ref_decompress_kblock_f8_fp(uint32_t f8type, int packrow, int8_t* src, float
   return -1;
 }
 
+/* activation shuffle of g_idx blobs: kernel_ref.h:28-37 */
+int ref_shuffle_activation(float* src, float* dst, int m, int k, int m_offset, int k_offset, int* indices, int src_stride,
+                           int dst_stride) {
+  return (int)kr::shuffle_activation<float>(src, dst, m, k, m_offset, k_offset, indices, src_stride, dst_stride);
+}
+
 void ref_row_reduce_sum_bf16(const float* src, int ldsrc, int row, int col, uint16_t* reduce) {
   kr::row_reduce_sum<utils::bf16>(src, ldsrc, row, col, (utils::bf16*)reduce);
 }

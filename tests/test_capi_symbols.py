@@ -71,8 +71,15 @@ def test_forced_core_and_unsupported(L, pkg, nso):
     finally:
         L.ns_set_pack_core(pkg.CORE_AUTO)
     assert L.ns_BTLAGemmPackBSize(96, 128, 64, 0x1234, pkg.BF16, False, pkg.COMP_INT8, None) == 0  # unknown dtype
+    # g_idx: the blob grows by the int[K] shuffle section (enable_shuffle, bestla_storage.h:761-765)
     idx = np.zeros(128, np.int32)
-    assert L.ns_BTLAGemmPackBSize(96, 128, 64, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, nso.ptr(idx)) == 0  # g_idx
+    L.ns_set_pack_core(nso.CORE_AVX512_VNNI_KB)
+    try:
+        with_idx = L.ns_BTLAGemmPackBSize(96, 128, 64, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, nso.ptr(idx))
+    finally:
+        L.ns_set_pack_core(pkg.CORE_AUTO)
+    assert with_idx == nso.lib().nso_pack_size_gidx(96, 128, 64, nso.S4, nso.BF16, 0, nso.CORE_AVX512_VNNI_KB)
+    assert with_idx > nso.pack_size(96, 128, 64, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
 
 
 def test_no_device_fails_loudly(L, pkg, nso):
