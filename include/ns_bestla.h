@@ -109,14 +109,18 @@ enum ns_core {
   NS_CORE_AUTO = -1
 };
 void ns_set_pack_core(int core);
-/* BTLAGemmPackBSize — bestla_gemm.cpp:626-639 */
+/* BTLAGemmPackBSize — bestla_gemm.cpp:626-639.  shuffle_indice != NULL (GPTQ act-order g_idx, host int[K]) adds the
+ * int[K] ShuffleIndices section to integer-weight blobs (bestla_gemm.cpp:230-232) */
 size_t ns_BTLAGemmPackBSize(size_t N, size_t K, size_t BlkSize, uint32_t QuantType, uint32_t ScaleDtype, bool isAsym,
                             int CompType, int* shuffle_indice);
 /* BTLAGemmQuantPackB — bestla_gemm.cpp:641-655 (quantize + pack on the GPU, bit-exact blob) */
 bool ns_BTLAGemmQuantPackB(void* PackedBuf, const float* FpData, size_t N, size_t K, size_t ldb, size_t BlkSize,
                            uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType, bool isTrans,
                            void* ThreadPool);
-/* BTLAGemmPackB — bestla_gemm.cpp:657-671 (pre-quantized int8 codes + fp32 scales + zero points) */
+/* BTLAGemmPackB — bestla_gemm.cpp:657-671 (pre-quantized int8 codes + fp32 scales + zero points).  With
+ * shuffle_indice (g_idx[k] = group of input channel k; QData rows already sorted by group, as the reference converter
+ * does) the blob records the permutation (setShuffleIndices, bestla_prologue_b.h:337-356) and every forward on it
+ * gathers A'[j] = A[indices[j]] first. */
 bool ns_BTLAGemmPackB(void* PackedBuf, const int8_t* QData, const float* Scales, const int8_t* Zp, size_t N, size_t K,
                       size_t ldb, size_t BlkSize, uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType,
                       int* shuffle_indice, void* ThreadPool);
