@@ -413,7 +413,7 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   if (w->shuf) {  // GPTQ act-order blob: gather A'[j] = A[shuf[j]] into scratch first (prologue_a.h:322-330)
     float* ga = static_cast<float*>(stream_scratch(st, size_t(m) * w->k * 4, 3));
     if (!ga) {
-      set_error("forward: no scratch for the activation shuffle (run once outside stream capture first)");
+      set_error("forward: no scratch for the activation shuffle (out of device memory)");
       return -1;
     }
     if (!hip_ok(launch_gather_cols(dA, lda, w->shuf, ga, m, w->k, st), "activation shuffle")) return -1;
@@ -436,8 +436,19 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   a.dual = false;
   a.c2 = nullptr;
   static const int small_max = getenv("NS_SMALLM_MAX") ? atoi(getenv("NS_SMALLM_MAX")) : kSmallMMax;  // diagnostics
-  // measured crossover (scripts/m_sweep.py): the streaming kernel wins up to 64 rows on the 7B shapes
-  const bool small = m <= small_max;
+  // Up to 16 rows the streaming kernel always wins.  From 17 to 64 rows every 16-column workgroup of it stages all rows
+  // of A over the whole K from L2, ntiles x m x K x sizeof(A element) bytes in total at about 6 TB/s: measured against
+  // the tiled GEMM (scripts/m_small_sweep.py) the break-even is near 140 MB of such staging traffic — 4096 x 4096 stays
+  // on the streaming kernel up to 64 rows with an fp16 shadow (21 vs 25 us), 14336 x 4096 leaves it at 17 (53 vs 44 us
+  // at 32 rows), fp32 activations leave earlier.
+  double staging = double(w->ntiles) * m * w->k * (dA16 ? 2.0 : 4.0);
+  const bool small = m <= 16 || (m <= small_max && (staging <= 140e6 || getenv("NS_SMALLM_MAX") != nullptr));
+  // fp32 activations, several rows, many column tiles: one conversion pass to fp16 (about 2 us) halves what every
+  // workgroup of the streaming kernel stages (14336 x 4096 at 16 rows: 39 -> 24 us; at 8 rows: 25 -> 18 us)
+  if (small && !dA16 && m >= 6 && staging > 60e6 && lda == w->k && w->k % 8 == 0) {
+    void* sc = stream_scratch(st, size_t(m) * w->k * 2, 0);
+    if (sc && hip_ok(launch_cvt_a16(dA, sc, m, w->k, lda, w->k, st), "activation fp16 pass")) a.a16 = sc;
+  }
   if (!hip_ok(small ? launch_smallm(a, st) : launch_gemm(a, st), "gemm launch")) return -1;
   return 0;
 }

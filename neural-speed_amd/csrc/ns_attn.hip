@@ -429,7 +429,7 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
       // grow-only per-stream scratch
       ws = device_tmp ? reinterpret_cast<float*>(a.tmp) : nullptr;
       if (!ws) ws = static_cast<float*>(stream_scratch(st, attn_ws_bytes(a.batch_size, a.head_num, a.heads_kv, a.head_size, a.sl_q, a.sl_kv), 1));
-      if (!ws) nsplit = 1;  // cannot allocate while the stream is capturing: unsplit, still correct
+      if (!ws) nsplit = 1;  // scratch allocation failed: unsplit, still correct
     }
     sp.ws = ws;
     sp.nsplit = nsplit;

@@ -151,9 +151,12 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
 // ns_gemm.hip: second-generation prefill GEMM; hipErrorNotSupported = use the first-generation gemm_kernel
 hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st);
 void gemm_scratch_release();  // frees the per-stream scratch buffers
-// grow-only device scratch per (stream, slot): slot 0 = fp16 copy of A (prefill GEMM), slot 1 = attention partials.
-// Returns nullptr when it would have to (re)allocate while the stream is capturing.
+// grow-only device scratch per (stream, slot): slot 0 = fp16 copy of A (prefill GEMM), 1 = attention partials,
+// 2 = split-K partials, 3 = shuffled activations.  Safe under stream capture (buffers handed out while capturing are
+// never freed or moved until gemm_scratch_release()); nullptr only when the allocation itself fails.
 void* stream_scratch(hipStream_t st, size_t bytes, int slot);
+// fp32 [m][lda] -> fp16 [m][ld16] (ld16 a multiple of 8, columns k..ld16-1 zero)
+hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, int ld16, hipStream_t st);
 // ns_decode.hip: persistent stream-K kernel for m <= 4; hipErrorNotSupported = outside its envelope (use smallm)
 hipError_t launch_decode(const SmallMArgs& a, hipStream_t st);
 constexpr int kMaxDecodeGrid = 1024;                             // workgroups (= CUs) the fix-up workspace covers

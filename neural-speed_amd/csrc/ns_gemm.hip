@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "ns_common.h"
 #include "ns_dev.h"
@@ -307,30 +308,66 @@ __global__ void cvt_a16_kernel(const float* __restrict__ a, _Float16* __restrict
   *reinterpret_cast<uint4v*>(out + idx) = uint4v{as_u32(h[0]), as_u32(h[1]), as_u32(h[2]), as_u32(h[3])};
 }
 
-// per-stream scratch for the fp16 copy of A (grow-only; never (re)allocated while the stream is capturing)
+hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, int ld16, hipStream_t st) {
+  const size_t units = size_t(m) * ld16 / 8;
+  hipLaunchKernelGGL(cvt_a16_kernel, dim3(unsigned((units + 255) / 256)), dim3(256), 0, st, a, static_cast<_Float16*>(out16), m,
+                     k, lda, ld16);
+  return hipGetLastError();
+}
+
+// Per-(stream, slot) device scratch, grow-only.  Work on one stream is ordered, so one buffer per stream and purpose is
+// enough; two streams never share one.  A buffer that was handed out while its stream was CAPTURING is baked into the
+// graph being built: such buffers are never freed or moved again (a larger request gets a new buffer, the old one is
+// retired until gemm_scratch_release()).  Allocating during a capture needs the thread's capture mode relaxed for the
+// duration of the hipMalloc (what PyTorch's caching allocator does as well), otherwise the capture is invalidated.
 static std::mutex g_scratch_mutex;
-static std::map<std::pair<hipStream_t, int>, std::pair<void*, size_t>> g_scratch;
+struct ScratchBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool in_graph = false;
+};
+static std::map<std::pair<hipStream_t, int>, ScratchBuf> g_scratch;
+static std::vector<void*> g_scratch_retired;
 void* stream_scratch(hipStream_t st, size_t bytes, int slot) {
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
-  auto& e = g_scratch[{st, slot}];
-  if (e.second >= bytes) return e.first;
+  ScratchBuf& e = g_scratch[{st, slot}];
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-  if (e.first) {
-    hipStreamSynchronize(st);
-    hipFree(e.first);
-    e = {nullptr, 0};
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) return nullptr;
+  const bool capturing = cs != hipStreamCaptureStatusNone;
+  if (e.bytes >= bytes) {
+    e.in_graph |= capturing;
+    return e.p;
+  }
+  if (e.p) {
+    if (e.in_graph || capturing) {
+      g_scratch_retired.push_back(e.p);  // a captured graph may point at it / no synchronous free inside a capture
+    } else {
+      hipStreamSynchronize(st);
+      hipFree(e.p);
+    }
+    e = ScratchBuf{};
   }
   void* p = nullptr;
-  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-  e = {p, bytes};
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  if (capturing) hipThreadExchangeStreamCaptureMode(&mode);
+  const hipError_t err = hipMalloc(&p, bytes);
+  if (capturing) hipThreadExchangeStreamCaptureMode(&mode);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  e.p = p;
+  e.bytes = bytes;
+  e.in_graph = capturing;
   return p;
 }
 void gemm_scratch_release() {
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   for (auto& kv : g_scratch)
-    if (kv.second.first) hipFree(kv.second.first);
+    if (kv.second.p) hipFree(kv.second.p);
   g_scratch.clear();
+  for (void* p : g_scratch_retired) hipFree(p);
+  g_scratch_retired.clear();
 }
 
 template <int KIND, int SPS, int SK>
@@ -364,7 +401,7 @@ static hipError_t launch_gemm2_s(const Gemm2Params& p, uint32_t scale_dt, bool a
   return launch_gemm2_k<KIND, SPS, SK_BF16>(p, asym, grid, lds, st);
 }
 
-// hipErrorNotSupported = use the first-generation kernel (no scratch available while capturing, odd strides ...)
+// hipErrorNotSupported = use the first-generation kernel (scratch allocation failed, sizes beyond 32-bit offsets ...)
 hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   static const bool off = getenv("NS_GEMM_V1") != nullptr;  // diagnostics
   if (off) return hipErrorNotSupported;

@@ -44,21 +44,30 @@ def time_us(fn, reps=30):
 
 
 def chain_time(shapes, qt, st_dt, bs, comp, m, nrep=3):
-    """shapes: list of (name, n, k, count).  Each shape gets `nrep` different weights streamed back to back."""
+    """shapes: list of (name, n, k, count).  Each shape gets `nrep` different weights streamed back to back.
+    A name starting with "gate+up" is the FFN's W1 and W3 through the fused entry (one launch, SiLU * mul epilogue), as
+    the reference graph runs them (bestla_fusion_FFN_SiLu_f32f32_forward, llama.cpp:609-643)."""
     out, total_us, total_bytes = {}, 0.0, 0
     for name, n, k, count in shapes:
-        ws = [make(n, k, qt, st_dt, bs, comp, 7 + i) for i in range(nrep)]
+        fused = name.startswith("gate+up")
+        ws = [make(n, k, qt, st_dt, bs, comp, 7 + i) for i in range(nrep * (2 if fused else 1))]
         a = torch.randn((m, k), device="cuda")
         ah = a.half()
         c = torch.empty((m, n), device="cuda")
+        c2 = torch.empty((m, n), device="cuda")
 
         def fn(s=None):
             s = s or C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if fused:
+                for i in range(nrep):
+                    pkg.check(L.ns_hip_fusion_ffn3_gateup_h(a.data_ptr(), ah.data_ptr(), ws[2 * i][0].h, ws[2 * i + 1][0].h,
+                                                            c2.data_ptr(), c.data_ptr(), None, m, pkg.EPI_SILU, s))
+                return
             for wt, _ in ws:
                 pkg.check(L.ns_hip_f32f32_forward_h(a.data_ptr(), ah.data_ptr(), wt.h, c.data_ptr(), None, m, k, n,
                                                     pkg.EPI_NONE, None, 0, s))
         us = time_us(fn) / nrep
-        byt = ws[0][0].stream_bytes
+        byt = ws[0][0].stream_bytes * (2 if fused else 1)
         out[name] = {"n": n, "k": k, "count": count, "us": round(us, 2), "GBps": round(byt / us / 1e3, 1)}
         total_us += us * count
         total_bytes += byt * count
@@ -71,7 +80,7 @@ res = {}
 # ---- config 4: Mistral-7B NF4 g128 batch 8 (wk/wv are 1024 wide: GQA, QKV not fused — llama.cpp:215) ----
 nl = 32
 shapes = [("wq", 4096, 4096, nl), ("wk", 1024, 4096, nl), ("wv", 1024, 4096, nl), ("wo", 4096, 4096, nl),
-          ("w1", 14336, 4096, nl), ("w3", 14336, 4096, nl), ("w2", 4096, 14336, nl), ("lm_head", 32000, 4096, 1)]
+          ("gate+up (w1, w3 fused)", 14336, 4096, nl), ("w2", 4096, 14336, nl), ("lm_head", 32000, 4096, 1)]
 per, us, byt = chain_time(shapes, pkg.F4_NF4, pkg.BF16, 128, pkg.COMP_BF16, 8)
 res["config4_mistral7b_nf4_g128_batch8"] = {"per_shape": per, "ms_per_step": round(us / 1e3, 4),
                                             "tokens_per_s": round(8 * 1e6 / us, 1), "weight_bytes": byt,
@@ -85,6 +94,19 @@ per, us, byt = chain_time(shapes, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, 1)
 res["config5_llama70b_q4_0_rank_of_tp8"] = {"per_shape": per, "gemm_ms_per_token_per_rank": round(us / 1e3, 4),
                                             "weight_bytes_per_rank": byt, "chain_GBps": round(byt / us / 1e3, 1),
                                             "note": "GEMMs of one rank only; 160 all-reduces of 32 KB per token come on top"}
+# ---- extra: Llama-2-7B fp8 weights (E4M3, shared-exponent E8M0 scales, g32), batch 1 decode and M = 2048 prefill ----
+nl = 32
+shapes = [("wq", 4096, 4096, 3 * nl), ("wo", 4096, 4096, nl), ("w1", 11008, 4096, 2 * nl), ("w2", 4096, 11008, nl),
+          ("lm_head", 32000, 4096, 1)]
+per, us, byt = chain_time(shapes, pkg.F8_E4M3, pkg.F8_E8M0, 32, pkg.COMP_F32, 1)
+res["extra_llama7b_fp8_e4m3_e8m0_g32_batch1"] = {"per_shape": per, "ms_per_step": round(us / 1e3, 4),
+                                                  "tokens_per_s": round(1e6 / us, 1), "weight_bytes": byt,
+                                                  "chain_GBps": round(byt / us / 1e3, 1),
+                                                  "note": "unfused launches; the device layout streams fp32 scales (4 B per group, the blob has 1)"}
+per, us, byt = chain_time(shapes[:4], pkg.F8_E4M3, pkg.F8_E8M0, 32, pkg.COMP_F32, 2048, nrep=1)
+flops = 2.0 * 2048 * sum(n * k * cnt for _, n, k, cnt in shapes[:4])
+res["extra_llama7b_fp8_e4m3_prefill_m2048"] = {"per_shape": per, "TFLOPS": round(flops / us / 1e6, 1),
+                                                "note": "first-generation GEMM (group scale applied to the fp32 MFMA result)"}
 # ---- PCIe-inclusive rate of the part-1 host-pointer API ----
 n, k = 11008, 4096
 wt, blob = make(n, k, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, 3)
