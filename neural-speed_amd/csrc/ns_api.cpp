@@ -28,6 +28,9 @@ using namespace ns;  // NOLINT
 namespace {
 
 std::mutex g_mu;
+// The host-pointer entry points share process-wide staging buffers (and the default stream).  The reference runs them
+// from one thread at a time (n_tasks = 1, ne_bestla.cpp:270-272); callers that do not are serialised here.
+std::mutex g_host_mu;
 std::string g_err;
 int g_pack_core = NS_CORE_AUTO;
 struct CacheEntry {
@@ -974,6 +977,7 @@ unsigned long long bestla_f32f32_get_workspace_size(int _m, int _n, int _k, void
 
 static bool host_forward(float* activation, void* weiptr, float* output, int m, int n, int k, int lda, int ldo,
                          int epi, const float* hostD, int ldd_rows, int ldd) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   ns_weight* w = cached_weight(weiptr);
   if (!w) return false;
   if (w->n != n || w->k != k) {
@@ -1066,6 +1070,7 @@ bool bestla_fusion_QKV_f32f32_support(void* wqptr, void* wkptr, void* wvptr, int
 
 void bestla_fusion_QKV_f32f32_forward(float* activation, void* wqptr, void* wkptr, void* wvptr, float* output, int _m,
                                       int _n, int _k, int lda, int ldo, void* workspace) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   (void)workspace;
   bool ok = have_device();
   ns_weight *q = nullptr, *k = nullptr, *v = nullptr;
@@ -1120,6 +1125,7 @@ static bool ffn3_support(void* w1ptr, void* w2ptr, void* w3ptr, int fin, int fmi
 
 static void ffn3_forward(const char* who, float* activation, void* w1ptr, void* w2ptr, void* w3ptr, float* tmp1,
                          float* tmp2, float* output, int seq, int fin, int fmid, int fout, int act) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   bool ok = have_device();
   ns_weight *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
   if (ok) {
@@ -1199,6 +1205,7 @@ static bool ffn2_support(void* w1ptr, void* w2ptr, int fin, int fmid, int fout) 
 }
 static void ffn2_forward(const char* who, float* activation, void* w1ptr, void* w2ptr, float* b1, float* b2,
                          float* tmp1, float* output, int seq, int fin, int fmid, int fout, bool bcast) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   bool ok = have_device();
   ns_weight *w1 = nullptr, *w2 = nullptr;
   if (ok) {
@@ -1355,6 +1362,7 @@ int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector,
 
 void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* FpIn,
                                float* FpOut) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   const size_t n = size_t(norm_count) * norm_size;
   if (!have_device() || !host_unary(n, n, FpIn, FpOut, [&](const float* i, float* o) {
         return launch_rmsnorm(norm_count, norm_size, isrms, epsilon, i, o, nullptr);
@@ -1364,6 +1372,7 @@ void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float 
 
 static void host_binary(const char* who, int batch, int vsize, const float* tensor, const float* vector, int vstep,
                         float* out, bool mul) {
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
   bool ok = have_device();
   if (ok) {
     const size_t n = size_t(batch) * vsize;

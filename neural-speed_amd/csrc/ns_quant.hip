@@ -372,10 +372,18 @@ hipError_t launch_quant_pack(const QuantArgs& a, hipStream_t st) {
   int8_t* q = nullptr;
   float* sc = nullptr;
   int8_t* zp = nullptr;
+  auto release = [&]() {
+    if (q) hipFreeAsync(q, st);
+    if (sc) hipFreeAsync(sc, st);
+    if (zp) hipFreeAsync(zp, st);
+  };
   hipError_t e;
-  if ((e = hipMallocAsync((void**)&q, a.n * a.k, st)) != hipSuccess) return e;
-  if ((e = hipMallocAsync((void**)&sc, nblk * a.n * sizeof(float), st)) != hipSuccess) return e;
-  if (a.asym && (e = hipMallocAsync((void**)&zp, nblk * a.n, st)) != hipSuccess) return e;
+  if ((e = hipMallocAsync((void**)&q, a.n * a.k, st)) != hipSuccess ||
+      (e = hipMallocAsync((void**)&sc, nblk * a.n * sizeof(float), st)) != hipSuccess ||
+      (a.asym && (e = hipMallocAsync((void**)&zp, nblk * a.n, st)) != hipSuccess)) {
+    release();
+    return e;
+  }
   // canonical code array follows the source's contiguous axis so both reads and writes coalesce
   const size_t qsk = a.is_trans ? 1 : a.n, qsn = a.is_trans ? a.k : 1;
   SrcView sv{a.w, a.ld, a.is_trans};
@@ -384,9 +392,7 @@ hipError_t launch_quant_pack(const QuantArgs& a, hipStream_t st) {
   e = pack_sections(q, qsk, qsn, sc, zp, a.n, a.k, a.blocksize, a.qtype, a.stype, a.ref_ntile, a.ref_packrow,
                     a.ref_kpad, a.ref_npad, a.cstep, a.has_reduce, a.q_out, a.s_out, a.asym ? a.z_out : nullptr,
                     a.r_out, st);
-  hipFreeAsync(q, st);
-  hipFreeAsync(sc, st);
-  if (zp) hipFreeAsync(zp, st);
+  release();
   return e;
 }
 

@@ -715,3 +715,34 @@ def test_fp16_shadow_variants_are_bit_identical(L, pkg, nso):
         torch.cuda.synchronize()
         assert torch.equal(c0, c1), (n, k, m)
         assert torch.equal(c16, c0.to(torch.float16))
+
+
+def test_host_entry_points_from_several_threads(L, pkg, nso):
+    """The reference drives this surface from one thread (n_tasks = 1); the drop-in shares staging buffers between calls,
+    so concurrent callers must be serialised inside, not corrupt each other."""
+    import threading
+    rng = np.random.default_rng(21)
+    n, k, bs = 128, 512, 32
+    jobs = []
+    for t in range(4):
+        w = _w(rng, n, k)
+        blob = nso.quant_pack(w, bs, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+        a = rng.standard_normal((3, k)).astype(np.float32)
+        jobs.append((blob, a, nso.gemm_f64(a, blob)))
+    errs = []
+
+    def run(blob, a, ref):
+        for _ in range(50):
+            out = np.zeros((a.shape[0], n), np.float32)
+            L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), a.shape[0], n, k, k, n, None)
+            e = nso.rel_l2(out, ref)
+            if not e < TOL:
+                errs.append(e)
+                return
+
+    threads = [threading.Thread(target=run, args=j) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
