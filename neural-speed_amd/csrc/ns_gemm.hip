@@ -343,15 +343,20 @@ void* stream_scratch(hipStream_t st, size_t bytes, int slot) {
       g_scratch_retired.push_back(e.p);  // a captured graph may point at it / no synchronous free inside a capture
     } else {
       hipStreamSynchronize(st);
+      hipStreamCaptureMode fmode = hipStreamCaptureModeRelaxed;
+      hipThreadExchangeStreamCaptureMode(&fmode);
       hipFree(e.p);
+      hipThreadExchangeStreamCaptureMode(&fmode);
     }
     e = ScratchBuf{};
   }
   void* p = nullptr;
+  // relaxed for the duration of the allocation: in the default (global) mode a hipMalloc invalidates ANY capture in
+  // progress in the process, this stream's or another thread's
   hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
-  if (capturing) hipThreadExchangeStreamCaptureMode(&mode);
+  hipThreadExchangeStreamCaptureMode(&mode);
   const hipError_t err = hipMalloc(&p, bytes);
-  if (capturing) hipThreadExchangeStreamCaptureMode(&mode);
+  hipThreadExchangeStreamCaptureMode(&mode);
   if (err != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
