@@ -215,6 +215,11 @@ int ns_hip_norm_mul_h(int norm_count, int norm_size, bool isrms, float epsilon, 
  * mix are refused). */
 int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                     int mode, float freq_base, float freq_scale, float ext_factor, float attn_factor, void* stream);
+/* the same with the YaRN extrapolation mix (ext_factor != 0; rope_yarn, ne_layers.c:9196-9231): op_params n_orig_ctx,
+ * beta_fast, beta_slow give the correction dims, attn_factor is scaled by 1 + 0.1 * log(1 / freq_scale) */
+int ns_hip_rope_f32_yarn(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past,
+                         int n_dims, int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
+                         float attn_factor, float beta_fast, float beta_slow, void* stream);
 int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
 
 /* RoPE of Q (in place, [seq][heads][head_size]) and of K ([seq][heads_kv][head_size]) fused with the kv-cache append:

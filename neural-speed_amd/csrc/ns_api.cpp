@@ -12,6 +12,7 @@
 // file: without a HIP device every compute entry reports an error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1325,6 +1326,35 @@ int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int head
   return hip_ok(launch_rope(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, mode, freq_base, freq_scale, attn_factor,
                             (hipStream_t)stream), "rope launch") ? 0 : -1;
 }
+// ne_compute_forward_rope_f32 with the YaRN extrapolation mix (ext_factor != 0): corr_dims from
+// ggml_rope_yarn_corr_dims (ne_layers.c:9219-9231) and the magnitude correction of rope_yarn (:9210) are evaluated here
+// with the host libm, exactly where the reference evaluates them.
+int ns_hip_rope_f32_yarn(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past,
+                         int n_dims, int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
+                         float attn_factor, float beta_fast, float beta_slow, void* stream) {
+  if (!have_device()) return -1;
+  if (!dSrc || !dDst || batch < 0 || seq < 0 || heads < 0 || head_size <= 0 || (head_size & 1) || n_dims <= 0 ||
+      (n_dims & 1) || n_dims > head_size || n_past < 0 || !(freq_scale > 0.f)) {
+    set_error("rope: invalid argument");
+    return -1;
+  }
+  if ((mode & ~(2 | 8)) != 0) {  // bit 3 ("use_yarn") carries no arithmetic in the reference
+    set_error("rope: only modes 0 and 2 (NeoX) are implemented (no GLM / long-rope / shift)");
+    return -1;
+  }
+  float corr0 = 0.f, corr1 = 0.f, mscale = attn_factor;
+  if (ext_factor != 0.f) {
+    auto corr_dim = [&](float n_rot) {
+      return n_dims * logf(n_orig_ctx / (n_rot * 2 * (float)3.14159265358979323846)) / (2 * logf(freq_base));
+    };
+    corr0 = std::max(0.f, floorf(corr_dim(beta_fast)));
+    corr1 = std::min(float(n_dims - 1), ceilf(corr_dim(beta_slow)));
+    mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+  }
+  return hip_ok(launch_rope(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, mode & 2, freq_base, freq_scale, mscale,
+                            (hipStream_t)stream, ext_factor, corr0, corr1), "rope launch") ? 0 : -1;
+}
+
 int ns_hip_rope_qkv_append(float* dQ, const float* dK, const float* dV, void* dKcache16, void* dVcache16, int seq, int heads,
                            int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base, float freq_scale,
                            float ext_factor, float attn_factor, long long cache_step_sl, long long cache_step_head,

@@ -556,9 +556,24 @@ hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint
 // ---- RoPE: ne_compute_forward_rope_f32 (ne_layers.c:9243-9428), modes 0 and 2 (NeoX), ext_factor == 0 -------------
 // one thread per rotated pair; theta = p * theta_scale^idx built by the same sequential fp32 products as the reference
 // (this file is compiled with -ffp-contract=off), so only cosf / sinf differ from the CPU libm in the last ulp
+// YaRN (rope_yarn / rope_yarn_ramp, ne_layers.c:9196-9217): theta = interp * (1 - mix) + extrap * mix with
+// mix = (1 - clamp((i0 / 2 - corr0) / max(0.001, corr1 - corr0), 0, 1)) * ext_factor; i0 is the element index in mode 0
+// and (int)(-ic / n_dims - ib) in the NeoX loop (:9399-9405), restated as written.  mscale already carries the
+// 1 + 0.1 * log(1 / freq_scale) factor (host libm, like the reference).
+struct RopeYarn {
+  float ext_factor, corr0, corr1;
+};
+__device__ __forceinline__ float rope_theta(float theta_extrap, float freq_scale, int i0, const RopeYarn& y) {
+  const float interp = __fmul_rn(freq_scale, theta_extrap);
+  if (y.ext_factor == 0.f) return interp;
+  const float t = __fdiv_rn(__fsub_rn(float(i0 / 2), y.corr0), fmaxf(0.001f, __fsub_rn(y.corr1, y.corr0)));
+  const float ramp = __fsub_rn(1.0f, fminf(1.0f, fmaxf(0.0f, t)));
+  const float mix = __fmul_rn(ramp, y.ext_factor);
+  return __fadd_rn(__fmul_rn(interp, __fsub_rn(1.f, mix)), __fmul_rn(theta_extrap, mix));
+}
 __global__ void rope_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int heads, int seq,
                             int head_size, int n_past, int n_dims, int neox, float theta_scale, float freq_scale,
-                            float attn_factor) {
+                            float attn_factor, RopeYarn yarn) {
   const int half = head_size / 2;  // pairs per row in both modes ((head_size / n_dims) * (n_dims / 2) for NeoX)
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(half);
@@ -569,17 +584,19 @@ __global__ void rope_kernel(const float* __restrict__ src, float* __restrict__ d
   float theta_base = float(n_past + i2);
   if (neox) theta_base = __fmul_rn(theta_base, freq_scale);
   for (int t = 0; t < pr; t++) theta_base = __fmul_rn(theta_base, theta_scale);
-  const float theta = __fmul_rn(freq_scale, theta_base);
-  const float c = __fmul_rn(cosf(theta), attn_factor), s = __fmul_rn(sinf(theta), attn_factor);
-  int ia, ib;
+  int ia, ib, i0;
   if (neox) {
     const int blk = pr / (n_dims / 2), ic = pr % (n_dims / 2);
     ia = blk * n_dims + ic;
     ib = ia + n_dims / 2;
+    i0 = int(__fsub_rn(__fmul_rn(__fdiv_rn(-1.f, float(n_dims)), float(2 * ic)), float(blk)));  // (int)cur_rot
   } else {
     ia = 2 * pr;
     ib = ia + 1;
+    i0 = ia;
   }
+  const float theta = rope_theta(theta_base, freq_scale, i0, yarn);
+  const float c = __fmul_rn(cosf(theta), attn_factor), s = __fmul_rn(sinf(theta), attn_factor);
   const float* x = src + row * head_size;
   float* y = dst + row * head_size;
   const float x0 = x[ia], x1 = x[ib];
@@ -651,7 +668,8 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
 }
 
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
-                       int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st) {
+                       int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st, float ext_factor,
+                       float corr0, float corr1) {
   const size_t rows = size_t(batch) * seq * heads;
   if (rows == 0) return hipSuccess;
   const bool neox = (mode & 2) != 0;
@@ -663,7 +681,7 @@ hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int hea
   const float theta_scale = powf(freq_base, -2.0f / n_dims);
   const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(head_size / 2);
   hipLaunchKernelGGL(rope_kernel, grid1d(rows * npairs, 256), dim3(256), 0, st, src, dst, rows, heads, seq, head_size, n_past,
-                     n_dims, neox ? 1 : 0, theta_scale, freq_scale, attn_factor);
+                     n_dims, neox ? 1 : 0, theta_scale, freq_scale, attn_factor, RopeYarn{ext_factor, corr0, corr1});
   return hipGetLastError();
 }
 

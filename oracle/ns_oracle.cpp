@@ -998,11 +998,41 @@ float nso_gelu(float x) { return 0.5f * x * (1.f + tanhf(0.7978845834732056f * (
 float nso_silu(float x) { return float(x / (1 + exp(-x))); }
 
 // ne_compute_forward_rope_f32 — ne_layers.c:9243-9428 (see ns_oracle.h for the covered modes)
-int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
-                 int mode, float freq_base, float freq_scale, float attn_factor) {
-  if ((mode & ~2) != 0 || n_dims > head_size || (n_dims & 1) || n_dims <= 0) return -1;
+// rope_yarn_ramp / rope_yarn — ne_layers.c:9196-9217
+static float rope_yarn_ramp(const float low, const float high, const int i0) {
+  const float y = (i0 / 2 - low) / std::max(0.001f, high - low);
+  return float(1.0 - std::min(1.0, std::max(0.0, double(y))));
+}
+static void rope_yarn(float theta_extrap, float freq_scale, const float corr_dims[2], int64_t i0, float ext_factor,
+                      float mscale, float* cos_theta, float* sin_theta) {
+  float theta_interp = freq_scale * theta_extrap;
+  float theta = theta_interp;
+  if (ext_factor != 0.0f) {
+    float ramp_mix = rope_yarn_ramp(corr_dims[0], corr_dims[1], int(i0)) * ext_factor;
+    theta = theta_interp * (1 - ramp_mix) + theta_extrap * ramp_mix;
+    mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+  }
+  *cos_theta = cosf(theta) * mscale;
+  *sin_theta = sinf(theta) * mscale;
+}
+// ggml_rope_yarn_corr_dim(s) — ne_layers.c:9219-9231
+static void rope_yarn_corr_dims(int n_dims, int n_orig_ctx, float freq_base, float beta_fast, float beta_slow, float dims[2]) {
+  auto corr_dim = [&](float n_rot) {
+    return n_dims * logf(n_orig_ctx / (n_rot * 2 * (float)3.14159265358979323846)) / (2 * logf(freq_base));
+  };
+  dims[0] = std::max(0.f, floorf(corr_dim(beta_fast)));
+  dims[1] = std::min(float(n_dims - 1), ceilf(corr_dim(beta_slow)));
+}
+
+int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                      int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
+                      float beta_fast, float beta_slow) {
+  if ((mode & ~(2 | 8)) != 0 || n_dims > head_size || (n_dims & 1) || n_dims <= 0) return -1;
   const bool is_neox = (mode & 2) != 0;
   const float theta_scale = powf(freq_base, -2.0f / n_dims);  // :9300
+  const float inv_ndims = -1.f / n_dims;                      // :9301
+  float corr_dims[2] = {0.f, 0.f};
+  if (ext_factor != 0.f) rope_yarn_corr_dims(n_dims, n_orig_ctx, freq_base, beta_fast, beta_slow, corr_dims);  // :9302-9303
   for (int i3 = 0; i3 < batch; i3++)
     for (int i2 = 0; i2 < seq; i2++) {
       const int p = n_past + i2;  // :9316 (mode & 1 == 0)
@@ -1014,8 +1044,8 @@ int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, in
         float theta_base = float(p);
         if (!is_neox) {  // :9379-9395
           for (int i0 = 0; i0 < head_size; i0 += 2) {
-            const float theta = freq_scale * theta_base;  // rope_yarn, ext_factor == 0 (:9207-9217)
-            const float c = cosf(theta) * attn_factor, s_ = sinf(theta) * attn_factor;
+            float c, s_;
+            rope_yarn(theta_base, freq_scale, corr_dims, i0, ext_factor, attn_factor, &c, &s_);
             theta_base *= theta_scale;
             const float x0 = x[i0], x1 = x[i0 + 1];
             y[i0] = x0 * c - x1 * s_;
@@ -1025,8 +1055,9 @@ int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, in
           theta_base = theta_base * freq_scale;
           for (int ib = 0; ib < head_size / n_dims; ib++)
             for (int ic = 0; ic < n_dims; ic += 2) {
-              const float theta = freq_scale * theta_base;
-              const float c = cosf(theta) * attn_factor, s_ = sinf(theta) * attn_factor;
+              const float cur_rot = inv_ndims * ic - ib;  // :9403
+              float c, s_;
+              rope_yarn(theta_base, freq_scale, corr_dims, (int)cur_rot, ext_factor, attn_factor, &c, &s_);
               theta_base *= theta_scale;
               const int i0 = ib * n_dims + ic / 2;
               const float x0 = x[i0], x1 = x[i0 + n_dims / 2];
@@ -1037,6 +1068,12 @@ int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, in
       }
     }
   return 0;
+}
+int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                 int mode, float freq_base, float freq_scale, float attn_factor) {
+  if ((mode & ~2) != 0) return -1;
+  return nso_rope_f32_yarn(src, dst, batch, seq, heads, head_size, n_past, n_dims, mode, freq_base, freq_scale, 0, 0.f,
+                           attn_factor, 0.f, 0.f);
 }
 
 // bestla_fusion_attn_forward_ref — mha_dense_wrapper.h:1371-1517 (PLAIN layouts; fp32 accumulation in the loop order

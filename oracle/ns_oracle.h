@@ -177,6 +177,11 @@ int nso_attn_ref(const nso_attn_args* a, int bf16_gemm);
  * PARITY UNPINNED (ne_layers.c does not compile standalone); checked against an fp64 closed form. */
 int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                  int mode, float freq_base, float freq_scale, float attn_factor);
+/* the same with the YaRN extrapolation mix (rope_yarn / rope_yarn_ramp / ggml_rope_yarn_corr_dims,
+ * ne_layers.c:9196-9231); ext_factor = 0 reduces to nso_rope_f32.  PARITY UNPINNED likewise. */
+int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                      int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
+                      float beta_fast, float beta_slow);
 
 #ifdef __cplusplus
 }

@@ -317,6 +317,17 @@ def rope_f32(x, n_past, n_dims, mode, freq_base=10000.0, freq_scale=1.0, attn_fa
     return out
 
 
+def rope_f32_yarn(x, n_past, n_dims, mode, freq_base, freq_scale, n_orig_ctx, ext_factor, attn_factor, beta_fast, beta_slow):
+    x = np.ascontiguousarray(x, np.float32)
+    b, s, h, hs = x.shape
+    out = np.zeros_like(x)
+    rc = lib().nso_rope_f32_yarn(ptr(x), ptr(out), b, s, h, hs, n_past, n_dims, mode, C.c_float(freq_base),
+                                 C.c_float(freq_scale), n_orig_ctx, C.c_float(ext_factor), C.c_float(attn_factor),
+                                 C.c_float(beta_fast), C.c_float(beta_slow))
+    assert rc == 0
+    return out
+
+
 def gemm_u8s8(a, blob):
     a = np.ascontiguousarray(a, dtype=np.float32)
     bi = parse(blob)

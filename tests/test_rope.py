@@ -90,3 +90,79 @@ def test_rope_qkv_append_equals_separate_ops(L, pkg, nso, mode):
     assert torch.equal(kc[n_past:n_past + seq], rk[0].half())
     assert torch.equal(vc[n_past:n_past + seq], dv[0].half())
     assert torch.all(kc[:n_past] == 9.0) and torch.all(vc[n_past + seq:] == 9.0)  # nothing else touched
+
+
+# ---------------------------------------------------------------------------------------------- YaRN extrapolation mix
+def _yarn_closed_form(x, n_past, n_dims, mode, base, fscale, n_orig, ext, attn, bfast, bslow):
+    """rope_yarn (ne_layers.c:9196-9217) in fp64, written independently of the oracle's loop structure"""
+    b, s, h, hs = x.shape
+    xs = x.astype(np.float64)
+    y = xs.copy()
+    ts = float(np.float32(base)) ** (-2.0 / n_dims)
+
+    def corr_dim(n_rot):
+        return n_dims * np.log(n_orig / (n_rot * 2 * np.pi)) / (2 * np.log(base))
+    lo = max(0.0, np.floor(corr_dim(bfast)))
+    hi = min(n_dims - 1.0, np.ceil(corr_dim(bslow)))
+    mscale = attn * (1.0 + 0.1 * np.log(1.0 / fscale))
+
+    def theta(extrap, i0):
+        interp = fscale * extrap
+        t = (int(i0 / 2) - lo) / max(0.001, hi - lo)      # C integer division truncates toward zero
+        mix = (1.0 - min(1.0, max(0.0, t))) * ext
+        return interp * (1 - mix) + extrap * mix
+    for i2 in range(s):
+        p = float(n_past + i2)
+        if mode == 0:
+            for k in range(hs // 2):
+                th = theta(p * ts ** k, 2 * k)
+                c, sn = np.cos(th) * mscale, np.sin(th) * mscale
+                x0, x1 = xs[:, i2, :, 2 * k], xs[:, i2, :, 2 * k + 1]
+                y[:, i2, :, 2 * k] = x0 * c - x1 * sn
+                y[:, i2, :, 2 * k + 1] = x0 * sn + x1 * c
+        else:
+            k = 0
+            for ib in range(hs // n_dims):
+                for ic in range(0, n_dims, 2):
+                    cur_rot = int(-ic / n_dims - ib)      # (int) of a float: toward zero
+                    th = theta(p * fscale * ts ** k, cur_rot)
+                    k += 1
+                    c, sn = np.cos(th) * mscale, np.sin(th) * mscale
+                    i0 = ib * n_dims + ic // 2
+                    x0, x1 = xs[:, i2, :, i0], xs[:, i2, :, i0 + n_dims // 2]
+                    y[:, i2, :, i0] = x0 * c - x1 * sn
+                    y[:, i2, :, i0 + n_dims // 2] = x0 * sn + x1 * c
+    return y
+
+
+YARN_CASES = [(1, 3, 4, 128, 100, 128, 0, 10000.0, 0.25, 4096, 1.0, 1.0, 32.0, 1.0),
+              (2, 2, 2, 64, 5000, 64, 0, 10000.0, 0.5, 2048, 0.7, 1.2, 32.0, 1.0),
+              (1, 3, 2, 128, 40, 64, 2, 10000.0, 0.25, 4096, 1.0, 1.0, 32.0, 1.0)]
+
+
+@pytest.mark.parametrize("b,s,h,hs,n_past,n_dims,mode,base,fscale,n_orig,ext,attn,bfast,bslow", YARN_CASES)
+def test_rope_yarn_oracle_matches_closed_form(nso, b, s, h, hs, n_past, n_dims, mode, base, fscale, n_orig, ext, attn, bfast, bslow):
+    x = np.random.default_rng(hs + n_past).standard_normal((b, s, h, hs)).astype(np.float32)
+    ref = _yarn_closed_form(x, n_past, n_dims, mode, base, fscale, n_orig, ext, attn, bfast, bslow)
+    out = nso.rope_f32_yarn(x, n_past, n_dims, mode, base, fscale, n_orig, ext, attn, bfast, bslow)
+    assert np.max(np.abs(out - ref)) < 3e-3
+    assert nso.rel_l2(out, ref) < 3e-4
+    # the mix matters: without it the result is measurably different, and ext_factor = 0 is the plain rope
+    plain = nso.rope_f32(x, n_past, n_dims, mode, base, fscale, attn)
+    assert nso.rel_l2(out, plain) > 1e-2
+    assert np.array_equal(nso.rope_f32_yarn(x, n_past, n_dims, mode, base, fscale, n_orig, 0.0, attn, bfast, bslow), plain)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,s,h,hs,n_past,n_dims,mode,base,fscale,n_orig,ext,attn,bfast,bslow", YARN_CASES)
+def test_rope_yarn_gpu_matches_oracle(L, pkg, nso, b, s, h, hs, n_past, n_dims, mode, base, fscale, n_orig, ext, attn, bfast, bslow):
+    import torch
+    x = np.random.default_rng(hs + n_past).standard_normal((b, s, h, hs)).astype(np.float32)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.zeros_like(dx)
+    pkg.check(L.ns_hip_rope_f32_yarn(dx.data_ptr(), dy.data_ptr(), b, s, h, hs, n_past, n_dims, mode, base, fscale, n_orig, ext,
+                                     attn, bfast, bslow, None))
+    torch.cuda.synchronize()
+    ref = nso.rope_f32_yarn(x, n_past, n_dims, mode, base, fscale, n_orig, ext, attn, bfast, bslow)
+    # theta, the ramp and the mix are the same fp32 operations; only sinf / cosf differ from the host libm
+    assert np.max(np.abs(dy.cpu().numpy() - ref)) < 2e-5 * max(1.0, attn * 1.3) * np.max(np.abs(x))
