@@ -220,6 +220,12 @@ int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int head
 int ns_hip_rope_f32_yarn(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past,
                          int n_dims, int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
                          float attn_factor, float beta_fast, float beta_slow, void* stream);
+/* long-rope (mode bit 0x10, ne_layers.c:9349-9377): dFactors = device array of n_dims / 2 per-pair divisors (the
+ * graph's dst->opt[1]), scale_factor multiplies cos and sin; rows are walked like the NeoX mode */
+int ns_hip_rope_f32_longrope(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past,
+                             int n_dims, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
+                             float attn_factor, float beta_fast, float beta_slow, const float* dFactors,
+                             float scale_factor, void* stream);
 int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
 
 /* RoPE of Q (in place, [seq][heads][head_size]) and of K ([seq][heads_kv][head_size]) fused with the kv-cache append:

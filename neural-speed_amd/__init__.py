@@ -126,6 +126,7 @@ def lib():
         L.ns_hip_rope_qkv_append.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, f, f, f, C.c_longlong, C.c_longlong, vp]
         L.ns_hip_rope_f32.argtypes = [vp, vp, i, i, i, i, i, i, i, f, f, f, f, vp]
         L.ns_hip_rope_f32_yarn.argtypes = [vp, vp, i, i, i, i, i, i, i, f, f, i, f, f, f, f, vp]
+        L.ns_hip_rope_f32_longrope.argtypes = [vp, vp, i, i, i, i, i, i, f, f, i, f, f, f, f, vp, f, vp]
         L.ns_hip_add.argtypes = [i, i, vp, vp, i, vp, vp]
         L.ns_hip_quantize_fp_u8_colblock.argtypes = [i, i, vp, i, vp, i, vp, i, vp, i, vp, vp]
         L.bestla_fusion_attn_workspace_size.restype = sz

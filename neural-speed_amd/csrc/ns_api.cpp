@@ -1329,17 +1329,18 @@ int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int head
 // ne_compute_forward_rope_f32 with the YaRN extrapolation mix (ext_factor != 0): corr_dims from
 // ggml_rope_yarn_corr_dims (ne_layers.c:9219-9231) and the magnitude correction of rope_yarn (:9210) are evaluated here
 // with the host libm, exactly where the reference evaluates them.
-int ns_hip_rope_f32_yarn(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past,
-                         int n_dims, int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
-                         float attn_factor, float beta_fast, float beta_slow, void* stream) {
+static int rope_ext(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                    int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
+                    float beta_fast, float beta_slow, const float* dFactors, float scale_factor, void* stream) {
   if (!have_device()) return -1;
   if (!dSrc || !dDst || batch < 0 || seq < 0 || heads < 0 || head_size <= 0 || (head_size & 1) || n_dims <= 0 ||
       (n_dims & 1) || n_dims > head_size || n_past < 0 || !(freq_scale > 0.f)) {
     set_error("rope: invalid argument");
     return -1;
   }
-  if ((mode & ~(2 | 8)) != 0) {  // bit 3 ("use_yarn") carries no arithmetic in the reference
-    set_error("rope: only modes 0 and 2 (NeoX) are implemented (no GLM / long-rope / shift)");
+  const bool longrope = (mode & 0x10) != 0;
+  if ((mode & ~(2 | 8 | 0x10)) != 0 || (longrope && !dFactors)) {  // bit 3 ("use_yarn") carries no arithmetic in the reference
+    set_error("rope: modes 0, 2 (NeoX) and 0x10 (long-rope, needs the factor array) are implemented (no GLM / shift)");
     return -1;
   }
   float corr0 = 0.f, corr1 = 0.f, mscale = attn_factor;
@@ -1351,8 +1352,32 @@ int ns_hip_rope_f32_yarn(const float* dSrc, float* dDst, int batch, int seq, int
     corr1 = std::min(float(n_dims - 1), ceilf(corr_dim(beta_slow)));
     mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
   }
-  return hip_ok(launch_rope(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, mode & 2, freq_base, freq_scale, mscale,
-                            (hipStream_t)stream, ext_factor, corr0, corr1), "rope launch") ? 0 : -1;
+  // the long-rope branch walks the row like the NeoX one (ne_layers.c:9349-9377)
+  return hip_ok(launch_rope(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, longrope ? 2 : (mode & 2), freq_base,
+                            freq_scale, mscale, (hipStream_t)stream, ext_factor, corr0, corr1, longrope ? dFactors : nullptr,
+                            scale_factor), "rope launch") ? 0 : -1;
+}
+// ne_compute_forward_rope_f32 with the YaRN extrapolation mix (ext_factor != 0): corr_dims from
+// ggml_rope_yarn_corr_dims (ne_layers.c:9219-9231) and the magnitude correction of rope_yarn (:9210) are evaluated on
+// the host with its libm, exactly where the reference evaluates them.
+int ns_hip_rope_f32_yarn(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past,
+                         int n_dims, int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
+                         float attn_factor, float beta_fast, float beta_slow, void* stream) {
+  if (mode & 0x10) {
+    set_error("rope: long-rope needs ns_hip_rope_f32_longrope (factor array)");
+    return -1;
+  }
+  return rope_ext(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, mode, freq_base, freq_scale, n_orig_ctx, ext_factor,
+                  attn_factor, beta_fast, beta_slow, nullptr, 1.f, stream);
+}
+// long-rope (mode bit 0x10, phi-3 style; ne_layers.c:9349-9377): theta / dFactors[pair] before rope_yarn, cos and sin
+// times scale_factor; dFactors is a device array of n_dims / 2 floats (the graph's dst->opt[1])
+int ns_hip_rope_f32_longrope(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past,
+                             int n_dims, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
+                             float attn_factor, float beta_fast, float beta_slow, const float* dFactors,
+                             float scale_factor, void* stream) {
+  return rope_ext(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, 0x10, freq_base, freq_scale, n_orig_ctx, ext_factor,
+                  attn_factor, beta_fast, beta_slow, dFactors, scale_factor, stream);
 }
 
 int ns_hip_rope_qkv_append(float* dQ, const float* dK, const float* dV, void* dKcache16, void* dVcache16, int seq, int heads,

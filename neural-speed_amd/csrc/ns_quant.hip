@@ -562,6 +562,8 @@ hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint
 // 1 + 0.1 * log(1 / freq_scale) factor (host libm, like the reference).
 struct RopeYarn {
   float ext_factor, corr0, corr1;
+  const float* lr_factor;  // long-rope (mode 0x10, ne_layers.c:9349-9377): per-pair divisor of theta, else null
+  float lr_scale;          // and the factor applied to cos / sin
 };
 __device__ __forceinline__ float rope_theta(float theta_extrap, float freq_scale, int i0, const RopeYarn& y) {
   const float interp = __fmul_rn(freq_scale, theta_extrap);
@@ -595,8 +597,16 @@ __global__ void rope_kernel(const float* __restrict__ src, float* __restrict__ d
     ib = ia + 1;
     i0 = ia;
   }
-  const float theta = rope_theta(theta_base, freq_scale, i0, yarn);
-  const float c = __fmul_rn(cosf(theta), attn_factor), s = __fmul_rn(sinf(theta), attn_factor);
+  float c, s;
+  if (yarn.lr_factor) {  // NeoX indexing; theta_base / factor[ic / 2] goes through rope_yarn, then scale_factor
+    const float theta = rope_theta(__fdiv_rn(theta_base, yarn.lr_factor[pr % (n_dims / 2)]), freq_scale, i0, yarn);
+    c = __fmul_rn(__fmul_rn(cosf(theta), attn_factor), yarn.lr_scale);
+    s = __fmul_rn(__fmul_rn(sinf(theta), attn_factor), yarn.lr_scale);
+  } else {
+    const float theta = rope_theta(theta_base, freq_scale, i0, yarn);
+    c = __fmul_rn(cosf(theta), attn_factor);
+    s = __fmul_rn(sinf(theta), attn_factor);
+  }
   const float* x = src + row * head_size;
   float* y = dst + row * head_size;
   const float x0 = x[ia], x1 = x[ib];
@@ -669,7 +679,7 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
 
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st, float ext_factor,
-                       float corr0, float corr1) {
+                       float corr0, float corr1, const float* lr_factor, float lr_scale) {
   const size_t rows = size_t(batch) * seq * heads;
   if (rows == 0) return hipSuccess;
   const bool neox = (mode & 2) != 0;
@@ -681,7 +691,7 @@ hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int hea
   const float theta_scale = powf(freq_base, -2.0f / n_dims);
   const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(head_size / 2);
   hipLaunchKernelGGL(rope_kernel, grid1d(rows * npairs, 256), dim3(256), 0, st, src, dst, rows, heads, seq, head_size, n_past,
-                     n_dims, neox ? 1 : 0, theta_scale, freq_scale, attn_factor, RopeYarn{ext_factor, corr0, corr1});
+                     n_dims, neox ? 1 : 0, theta_scale, freq_scale, attn_factor, RopeYarn{ext_factor, corr0, corr1, lr_factor, lr_scale});
   return hipGetLastError();
 }
 

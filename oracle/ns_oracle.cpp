@@ -1024,11 +1024,13 @@ static void rope_yarn_corr_dims(int n_dims, int n_orig_ctx, float freq_base, flo
   dims[1] = std::min(float(n_dims - 1), ceilf(corr_dim(beta_slow)));
 }
 
-int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
-                      int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
-                      float beta_fast, float beta_slow) {
-  if ((mode & ~(2 | 8)) != 0 || n_dims > head_size || (n_dims & 1) || n_dims <= 0) return -1;
+static int rope_impl(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                     int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
+                     float beta_fast, float beta_slow, const float* longrope_factor, float scale_factor) {
+  if ((mode & ~(2 | 8 | 0x10)) != 0 || n_dims > head_size || (n_dims & 1) || n_dims <= 0) return -1;
   const bool is_neox = (mode & 2) != 0;
+  const bool is_longrope = (mode & 0x10) != 0;
+  if (is_longrope && !longrope_factor) return -1;
   const float theta_scale = powf(freq_base, -2.0f / n_dims);  // :9300
   const float inv_ndims = -1.f / n_dims;                      // :9301
   float corr_dims[2] = {0.f, 0.f};
@@ -1042,7 +1044,24 @@ int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int head
         float* y = dst + row;
         memcpy(y, x, size_t(head_size) * 4);  // dims not touched by the NeoX loop keep their value (dst == src in-place)
         float theta_base = float(p);
-        if (!is_neox) {  // :9379-9395
+        if (is_longrope) {  // :9349-9377 (tested before the NeoX flag)
+          theta_base = theta_base * freq_scale;
+          for (int ib = 0; ib < head_size / n_dims; ib++)
+            for (int ic = 0; ic < n_dims; ic += 2) {
+              const float cur_rot = inv_ndims * ic - ib;
+              float c, s_;
+              const float tmp_factor = longrope_factor[ic / 2];
+              const float tmp_theta_base = theta_base / tmp_factor;
+              rope_yarn(tmp_theta_base, freq_scale, corr_dims, (int)cur_rot, ext_factor, attn_factor, &c, &s_);
+              c *= scale_factor;
+              s_ *= scale_factor;
+              theta_base *= theta_scale;
+              const int i0 = ib * n_dims + ic / 2;
+              const float x0 = x[i0], x1 = x[i0 + n_dims / 2];
+              y[i0] = x0 * c - x1 * s_;
+              y[i0 + n_dims / 2] = x0 * s_ + x1 * c;
+            }
+        } else if (!is_neox) {  // :9379-9395
           for (int i0 = 0; i0 < head_size; i0 += 2) {
             float c, s_;
             rope_yarn(theta_base, freq_scale, corr_dims, i0, ext_factor, attn_factor, &c, &s_);
@@ -1068,6 +1087,19 @@ int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int head
       }
     }
   return 0;
+}
+int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                      int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
+                      float beta_fast, float beta_slow) {
+  if (mode & 0x10) return -1;
+  return rope_impl(src, dst, batch, seq, heads, head_size, n_past, n_dims, mode, freq_base, freq_scale, n_orig_ctx, ext_factor,
+                   attn_factor, beta_fast, beta_slow, nullptr, 1.f);
+}
+int nso_rope_f32_longrope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                          float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
+                          float beta_fast, float beta_slow, const float* factors, float scale_factor) {
+  return rope_impl(src, dst, batch, seq, heads, head_size, n_past, n_dims, 0x10, freq_base, freq_scale, n_orig_ctx, ext_factor,
+                   attn_factor, beta_fast, beta_slow, factors, scale_factor);
 }
 int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                  int mode, float freq_base, float freq_scale, float attn_factor) {

@@ -182,6 +182,10 @@ int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, in
 int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                       int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
                       float beta_fast, float beta_slow);
+/* long-rope (mode 0x10, ne_layers.c:9349-9377): theta / factors[pair] through rope_yarn, cos / sin times scale_factor */
+int nso_rope_f32_longrope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                          float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
+                          float beta_fast, float beta_slow, const float* factors, float scale_factor);
 
 #ifdef __cplusplus
 }

@@ -328,6 +328,19 @@ def rope_f32_yarn(x, n_past, n_dims, mode, freq_base, freq_scale, n_orig_ctx, ex
     return out
 
 
+def rope_f32_longrope(x, n_past, n_dims, freq_base, freq_scale, n_orig_ctx, ext_factor, attn_factor, beta_fast, beta_slow,
+                      factors, scale_factor):
+    x = np.ascontiguousarray(x, np.float32)
+    factors = np.ascontiguousarray(factors, np.float32)
+    b, s, h, hs = x.shape
+    out = np.zeros_like(x)
+    rc = lib().nso_rope_f32_longrope(ptr(x), ptr(out), b, s, h, hs, n_past, n_dims, C.c_float(freq_base), C.c_float(freq_scale),
+                                     n_orig_ctx, C.c_float(ext_factor), C.c_float(attn_factor), C.c_float(beta_fast),
+                                     C.c_float(beta_slow), ptr(factors), C.c_float(scale_factor))
+    assert rc == 0
+    return out
+
+
 def gemm_u8s8(a, blob):
     a = np.ascontiguousarray(a, dtype=np.float32)
     bi = parse(blob)

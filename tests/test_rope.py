@@ -166,3 +166,52 @@ def test_rope_yarn_gpu_matches_oracle(L, pkg, nso, b, s, h, hs, n_past, n_dims, 
     ref = nso.rope_f32_yarn(x, n_past, n_dims, mode, base, fscale, n_orig, ext, attn, bfast, bslow)
     # theta, the ramp and the mix are the same fp32 operations; only sinf / cosf differ from the host libm
     assert np.max(np.abs(dy.cpu().numpy() - ref)) < 2e-5 * max(1.0, attn * 1.3) * np.max(np.abs(x))
+
+
+# ---------------------------------------------------------------------------------------------- long-rope (mode 0x10)
+def _longrope_closed_form(x, n_past, n_dims, base, fscale, attn, factors, scale):
+    b, s, h, hs = x.shape
+    xs = x.astype(np.float64)
+    y = xs.copy()
+    ts = float(np.float32(base)) ** (-2.0 / n_dims)
+    for i2 in range(s):
+        p = float(n_past + i2)
+        k = 0
+        for ib in range(hs // n_dims):
+            for ic in range(0, n_dims, 2):
+                th = fscale * (p * fscale * ts ** k) / float(factors[ic // 2])
+                k += 1
+                c, sn = np.cos(th) * attn * scale, np.sin(th) * attn * scale
+                i0 = ib * n_dims + ic // 2
+                x0, x1 = xs[:, i2, :, i0], xs[:, i2, :, i0 + n_dims // 2]
+                y[:, i2, :, i0] = x0 * c - x1 * sn
+                y[:, i2, :, i0 + n_dims // 2] = x0 * sn + x1 * c
+    return y
+
+
+@pytest.mark.parametrize("b,s,h,hs,n_past,n_dims", [(1, 3, 4, 96, 50, 96), (2, 2, 2, 128, 700, 64)])
+def test_rope_longrope_oracle_and_gpu(request, nso, b, s, h, hs, n_past, n_dims):
+    rng = np.random.default_rng(n_dims + n_past)
+    x = rng.standard_normal((b, s, h, hs)).astype(np.float32)
+    factors = rng.uniform(1.0, 8.0, n_dims // 2).astype(np.float32)
+    base, fscale, attn, scale = 10000.0, 0.5, 1.0, 1.19
+    ref = _longrope_closed_form(x, n_past, n_dims, base, fscale, attn, factors, scale)
+    out = nso.rope_f32_longrope(x, n_past, n_dims, base, fscale, 4096, 0.0, attn, 32.0, 1.0, factors, scale)
+    assert np.max(np.abs(out - ref)) < 2e-3 and nso.rel_l2(out, ref) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", [0.0, 1.0])
+def test_rope_longrope_gpu_matches_oracle(L, pkg, nso, ext):
+    import torch
+    rng = np.random.default_rng(5)
+    b, s, h, hs, n_past, n_dims = 1, 3, 4, 96, 50, 96
+    x = rng.standard_normal((b, s, h, hs)).astype(np.float32)
+    factors = rng.uniform(1.0, 8.0, n_dims // 2).astype(np.float32)
+    dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(factors).cuda()
+    dy = torch.zeros_like(dx)
+    pkg.check(L.ns_hip_rope_f32_longrope(dx.data_ptr(), dy.data_ptr(), b, s, h, hs, n_past, n_dims, 10000.0, 0.5, 4096, ext, 1.0,
+                                         32.0, 1.0, df.data_ptr(), 1.19, None))
+    torch.cuda.synchronize()
+    ref = nso.rope_f32_longrope(x, n_past, n_dims, 10000.0, 0.5, 4096, ext, 1.0, 32.0, 1.0, factors, 1.19)
+    assert np.max(np.abs(dy.cpu().numpy() - ref)) < 4e-5 * np.max(np.abs(x))
