@@ -202,6 +202,12 @@ int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_wei
  * bestla_device_rms_norm_f32 / _mul_f32 / _add_f32, ne_bestla.h:99-105): asynchronous on `stream`, capturable */
 int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, float* dOut,
                               void* stream);
+/* bestla_device_elewise_f32 (NE_OP_SILU; ne_bestla.h:103-104, ne_bestla_sycl.cpp:297-326): y = x / (1 + expf(-x)) */
+int ns_hip_silu_f32(const float* dSrc, float* dDst, size_t n, void* stream);
+/* bestla_device_dup_f32 (ne_bestla.h:109, ne_bestla_sycl.cpp:537-591): 4-D strided copy of fp32 into fp32 or fp16;
+ * ne = extents of dst, strides in BYTES as in ne_tensor::nb */
+int ns_hip_dup_f32(const float* dSrc, void* dDst, const long long ne[4], const long long src_nb[4],
+                   const long long dst_nb[4], bool dst_is_f16, void* stream);
 int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
 /* layernormalization fused with the multiplication by the norm weight that follows it in every model graph
  * (dGamma [norm_size], may be NULL) and with the fp16 shadow of the result (dOut16, may be NULL) that the "_h" GEMM

@@ -122,6 +122,8 @@ def lib():
         L.ns_hip_quant_pack_device.argtypes = [vp, vp, sz, sz, sz, sz, u32, u32, b, i, b, vp]
         L.ns_hip_layernormalization.argtypes = [i, i, b, f, vp, vp, vp]
         L.ns_hip_mul.argtypes = [i, i, vp, vp, i, vp, vp]
+        L.ns_hip_silu_f32.argtypes = [vp, vp, sz, vp]
+        L.ns_hip_dup_f32.argtypes = [vp, vp, vp, vp, vp, b, vp]
         L.ns_hip_norm_mul_h.argtypes = [i, i, b, f, vp, vp, vp, vp, vp]
         L.ns_hip_rope_qkv_append.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, f, f, f, C.c_longlong, C.c_longlong, vp]
         L.ns_hip_rope_f32.argtypes = [vp, vp, i, i, i, i, i, i, i, f, f, f, f, vp]

@@ -1398,6 +1398,30 @@ int ns_hip_rope_qkv_append(float* dQ, const float* dK, const float* dV, void* dK
                                        freq_base, freq_scale, attn_factor, cache_step_sl, cache_step_head,
                                        (hipStream_t)stream), "rope/kv-append launch") ? 0 : -1;
 }
+// device twins of bestla_device_elewise_f32 (NE_OP_SILU) and bestla_device_dup_f32 (ne_bestla.h:103-109)
+int ns_hip_silu_f32(const float* dSrc, float* dDst, size_t n, void* stream) {
+  if (!have_device()) return -1;
+  if (n && (!dSrc || !dDst)) {
+    set_error("silu: null argument");
+    return -1;
+  }
+  return hip_ok(launch_silu(dSrc, dDst, n, (hipStream_t)stream), "silu launch") ? 0 : -1;
+}
+int ns_hip_dup_f32(const float* dSrc, void* dDst, const long long ne[4], const long long src_nb[4],
+                   const long long dst_nb[4], bool dst_is_f16, void* stream) {
+  if (!have_device()) return -1;
+  if (!dSrc || !dDst || !ne || !src_nb || !dst_nb) {
+    set_error("dup: null argument");
+    return -1;
+  }
+  for (int i = 0; i < 4; i++)
+    if (ne[i] < 0) {
+      set_error("dup: negative extent");
+      return -1;
+    }
+  return hip_ok(launch_dup(dSrc, dDst, ne, src_nb, dst_nb, dst_is_f16, (hipStream_t)stream), "dup launch") ? 0 : -1;
+}
+
 int ns_hip_mul(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream) {
   if (!have_device()) return -1;
   if (!dTensor || !dVector || !dOut || batch < 0 || vsize <= 0) {

@@ -695,6 +695,49 @@ hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int hea
   return hipGetLastError();
 }
 
+// ---- the remaining members of the reference's device-backend operator set (ne_bestla.h:99-111, ne_bestla_sycl.cpp) ----
+// bestla_device_elewise_f32 (:297-326): NE_OP_SILU is the one operator it implements — ne_silu_f32(x) = x / (1 + expf(-x))
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = __fdiv_rn(x[i], __fadd_rn(1.0f, expf(-x[i])));
+}
+hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(silu_kernel, grid1d(n, 256), dim3(256), 0, st, x, y, n);
+  return hipGetLastError();
+}
+// bestla_device_dup_f32 (:537-591): 4-D strided copy of fp32 into fp32 or fp16 (the graph's kv-cache writes and permutes)
+struct DupDims {
+  long long ne[4], snb[4], dnb[4];  // extents of dst, byte strides of src and dst
+};
+__global__ void dup_kernel(const char* __restrict__ src, char* __restrict__ dst, DupDims d, int dst_f16) {
+  const long long total = d.ne[0] * d.ne[1] * d.ne[2] * d.ne[3];
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long i0 = i % d.ne[0];
+  i /= d.ne[0];
+  const long long i1 = i % d.ne[1];
+  i /= d.ne[1];
+  const long long i2 = i % d.ne[2];
+  const long long i3 = i / d.ne[2];
+  const float v = *reinterpret_cast<const float*>(src + i0 * d.snb[0] + i1 * d.snb[1] + i2 * d.snb[2] + i3 * d.snb[3]);
+  char* o = dst + i0 * d.dnb[0] + i1 * d.dnb[1] + i2 * d.dnb[2] + i3 * d.dnb[3];
+  if (dst_f16)
+    *reinterpret_cast<_Float16*>(o) = (_Float16)v;
+  else
+    *reinterpret_cast<float*>(o) = v;
+}
+hipError_t launch_dup(const void* src, void* dst, const long long* ne, const long long* snb, const long long* dnb, bool dst_f16,
+                      hipStream_t st) {
+  DupDims d;
+  for (int i = 0; i < 4; i++) d.ne[i] = ne[i], d.snb[i] = snb[i], d.dnb[i] = dnb[i];
+  const long long total = ne[0] * ne[1] * ne[2] * ne[3];
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dup_kernel, grid1d(size_t(total), 256), dim3(256), 0, st, static_cast<const char*>(src),
+                     static_cast<char*>(dst), d, dst_f16 ? 1 : 0);
+  return hipGetLastError();
+}
+
 __global__ void gather_cols_kernel(const float* __restrict__ a, int lda, const int* __restrict__ idx,
                                    float* __restrict__ out, int m, int k) {
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;

@@ -746,3 +746,38 @@ def test_host_entry_points_from_several_threads(L, pkg, nso):
     for th in threads:
         th.join()
     assert not errs, errs
+
+
+def test_device_silu_and_dup(L, pkg, nso):
+    """the last two members of the reference's device-backend operator set (ne_bestla.h:103-109): SiLU and the 4-D strided
+    fp32 -> fp32 / fp16 copy the graph uses for kv-cache writes and permutes"""
+    import torch
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal(5000) * 4).astype(np.float32)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.zeros_like(dx)
+    pkg.check(L.ns_hip_silu_f32(dx.data_ptr(), dy.data_ptr(), x.size, None))
+    torch.cuda.synchronize()
+    want = x.astype(np.float64) / (1 + np.exp(-x.astype(np.float64)))
+    assert np.max(np.abs(dy.cpu().numpy() - want)) < 1e-6 * max(1.0, np.max(np.abs(want)))
+    # permute [seq][head][dim] -> [head][dim][seq] while converting to fp16 (a V-cache style write)
+    seq, heads, dim = 7, 3, 16
+    src = rng.standard_normal((seq, heads, dim)).astype(np.float32)
+    dsrc = torch.from_numpy(src).cuda()
+    ddst = torch.zeros((heads, dim, seq + 2), dtype=torch.float16, device="cuda")   # padded rows stay untouched
+    ne = (C.c_longlong * 4)(seq, dim, heads, 1)                        # dst extents, fastest first
+    snb = (C.c_longlong * 4)(heads * dim * 4, 4, dim * 4, 0)           # src byte strides for (seq, dim, head)
+    dnb = (C.c_longlong * 4)(2, (seq + 2) * 2, dim * (seq + 2) * 2, 0)
+    pkg.check(L.ns_hip_dup_f32(dsrc.data_ptr(), ddst.data_ptr(), ne, snb, dnb, True, None))
+    torch.cuda.synchronize()
+    got = ddst.cpu().numpy()
+    assert np.array_equal(got[:, :, :seq], src.transpose(1, 2, 0).astype(np.float16))
+    assert np.all(got[:, :, seq:] == 0)
+    # fp32 -> fp32 contiguous copy with a leading-dimension change
+    d32 = torch.zeros((seq, heads * dim + 5), device="cuda")
+    ne = (C.c_longlong * 4)(heads * dim, seq, 1, 1)
+    snb = (C.c_longlong * 4)(4, heads * dim * 4, 0, 0)
+    dnb = (C.c_longlong * 4)(4, (heads * dim + 5) * 4, 0, 0)
+    pkg.check(L.ns_hip_dup_f32(dsrc.data_ptr(), d32.data_ptr(), ne, snb, dnb, False, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(d32.cpu().numpy()[:, :heads * dim], src.reshape(seq, -1))
