@@ -375,6 +375,143 @@ static bool attn_shape_ok(int head_num, int heads_kv, int head_size, int sl_q, i
   return true;
 }
 
+// ============================================================================================================
+// attn_mfma_kernel — prefill / multi-row attention on the matrix cores (head size 64 or 128, contiguous head dim)
+//
+// One 256-thread workgroup = 64 query rows of one (batch, head); wave w owns rows 16w .. 16w+15.  KV positions are
+// walked in blocks of 32 with the online-softmax recurrence:
+//   S^T = K . Q^T   v_mfma_f32_16x16x32_f16 with A = K rows (lane (nn, g): 16 B of K[pos0 + 16t + nn][32j + 8g ..]) and
+//                   B = Q rows (lane (nn, g): Q[q0 + nn][32j + 8g ..], converted to fp16 once): lane (nn, g) ends up
+//                   with the scores of query q0 + nn at positions pos0 + 16t + 4g + r (t = 0, 1; r = 0..3)
+//   softmax         per query = per nn: 8 values per lane, reduced over g with two xor-shuffles; running (m, l)
+//   O += P . V      the 8 probabilities a lane holds ARE its A operand if MFMA k-slot 8g + i is read as position
+//                   16 (i >> 2) + 4g + (i & 3) — the product does not care how k is enumerated as long as B agrees, so
+//                   no data moves between lanes.  B = V in that enumeration: V^T[d][pos] staged once per block and
+//                   workgroup in LDS (coalesced 16-byte global reads, transposed 2-byte LDS writes), read back as two
+//                   8-byte runs (positions 4g..4g+3 and 16+4g..) per 16-column output tile
+// The accumulator rows of a lane (queries q0 + 4g + r) differ from the query its softmax state belongs to (q0 + nn):
+// the rescale factors travel by __shfl from lane 4g + r.  fp16 operands, fp32 scores / statistics / accumulators.
+// ============================================================================================================
+typedef _Float16 ahalf8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 ahalf4_t __attribute__((ext_vector_type(4)));
+typedef float afloatx4 __attribute__((ext_vector_type(4)));
+constexpr int kAttnKB = 32;           // kv positions per block
+constexpr int kAttnVStr = kAttnKB + 4;  // halves per V^T row in LDS: keeps the 8-byte reads aligned, skews banks
+
+template <int HS>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
+  constexpr int NJ = HS / 32, NDT = HS / 16, CH = HS / 8;  // k-slices of QK^T, output column tiles, V halves per thread
+  __shared__ __attribute__((aligned(16))) _Float16 vt[HS * kAttnVStr];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nn = l & 15, g = l >> 4;
+  const int qblk = blockIdx.x, ihn = blockIdx.y, ibs = blockIdx.z;
+  const int ihkv = ihn / (p.head_num / p.heads_kv);
+  const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
+  const int off = p.sl_kv - p.sl_q;
+  const int q0 = qblk * 64 + w * 16;
+  const float* qb = p.q + ibs * p.step_q_bs + ihn * p.step_q_head_num;
+  const _Float16* kb = p.k + ibs * p.step_k_bs + ihkv * p.step_k_head_num;
+  const _Float16* vb = p.v + ibs * p.step_v_bs + ihkv * p.step_v_head_num;
+  float* db = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num;
+
+  ahalf8_t qf[NJ];
+  {
+    const float* qr = qb + (long long)min(q0 + nn, p.sl_q - 1) * p.step_q_sl + 8 * g;
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) qf[j][i] = (_Float16)qr[32 * j + i];
+  }
+  afloatx4 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; dt++) o[dt] = afloatx4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc = p.qk_scale * 1.4426950408889634f;  // scores in the exp2 domain
+  const int q_last = min(qblk * 64 + 63, p.sl_q - 1);
+  const int kv_end = causal ? min(p.sl_kv, q_last + off + 1) : p.sl_kv;            // workgroup-uniform
+  const int visible = min(p.sl_kv, causal ? q0 + nn + off + 1 : p.sl_kv);          // mha_dense_wrapper.h:1440-1441
+
+  for (int pos0 = 0; pos0 < kv_end; pos0 += kAttnKB) {
+    afloatx4 sv[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      sv[t] = afloatx4{0.f, 0.f, 0.f, 0.f};
+      const _Float16* kr = kb + (long long)min(pos0 + 16 * t + nn, p.sl_kv - 1) * p.step_k_sl + 8 * g;
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        sv[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const ahalf8_t*>(kr + 32 * j), qf[j], sv[t], 0, 0, 0);
+    }
+    float x[8], mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int pos = pos0 + 16 * (e >> 2) + 4 * g + (e & 3);
+      x[e] = pos < visible ? sv[e >> 2][e & 3] * sc : -INFINITY;
+      mx = fmaxf(mx, x[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;  // nothing visible yet: every exp2 below is exp2(-inf) = 0
+    const float alpha = exp2f(m_run - m_use);
+    float ps = 0.f;
+    ahalf8_t pf;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float pe = exp2f(x[e] - m_use);
+      ps += pe;
+      pf[e] = (_Float16)pe;
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    float ar[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) ar[r] = __shfl(alpha, 4 * g + r, 64);
+
+    __syncthreads();  // the previous block's V^T reads are done
+    {
+      const int vp = tid >> 3, c = tid & 7, vpos = pos0 + vp;
+      _Float16 vals[CH];
+      if (vpos < p.sl_kv) {
+        const _Float16* vr = vb + (long long)vpos * p.step_v_sl + c * CH;
+#pragma unroll
+        for (int u = 0; u < CH / 8; u++) {
+          const ahalf8_t v8 = *reinterpret_cast<const ahalf8_t*>(vr + 8 * u);
+#pragma unroll
+          for (int i = 0; i < 8; i++) vals[8 * u + i] = v8[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < CH; i++) vals[i] = (_Float16)0.f;  // P is zero there; keep 0 * x away from inf / nan bits
+      }
+#pragma unroll
+      for (int i = 0; i < CH; i++) vt[(c * CH + i) * kAttnVStr + vp] = vals[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++) {
+      const _Float16* vr = vt + (16 * dt + nn) * kAttnVStr + 4 * g;
+      const ahalf4_t lo = *reinterpret_cast<const ahalf4_t*>(vr), hi = *reinterpret_cast<const ahalf4_t*>(vr + 16);
+      const ahalf8_t vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[dt][r] *= ar[r];
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[dt], 0, 0, 0);
+    }
+  }
+  const float inv = l_run > 0.f ? p.out_scale / l_run : 0.f;
+  float ir[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) ir[r] = __shfl(inv, 4 * g + r, 64);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = q0 + 4 * g + r;
+    if (row >= p.sl_q) continue;
+    float* dr = db + (long long)row * p.step_dst_sl + nn;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++) dr[16 * dt] = o[dt][r] * ir[r];
+  }
+}
+
 static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipStream_t st, std::string* why,
                               bool device_tmp) {
   if (a.Q_layout != ATTN_FWD_LAYOUT_PLAIN || a.K_layout != ATTN_FWD_LAYOUT_PLAIN || a.V_layout != ATTN_FWD_LAYOUT_PLAIN ||
@@ -405,9 +542,24 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   p.alibi_log2_floor = lf;
   p.alibi_m0 = powf(2.0f, -8.f / float(lf));
   p.alibi_m1 = powf(2.0f, -4.f / float(lf));
-  if (a.head_num > 65535 || a.batch_size > 65535 || size_t(a.heads_kv) * a.sl_q > 65535) {
-    *why = "attention: head_num / batch_size / heads_kv*sl_q above the grid limit";
+  if (a.head_num > 65535 || a.batch_size > 65535) {
+    *why = "attention: head_num / batch_size above the grid limit";
     return hipErrorInvalidValue;
+  }
+  // ---- several query rows: matrix cores (head size 64 / 128, contiguous 16-byte aligned rows, no alibi / tanh) ----
+  static const bool no_mfma = getenv("NS_ATTN_NO_MFMA") != nullptr;  // diagnostics
+  const bool rows_ok = a.step_k_head_size == 1 && a.step_v_head_size == 1 && a.step_k_sl % 8 == 0 && a.step_v_sl % 8 == 0 &&
+                       a.step_k_head_num % 8 == 0 && a.step_v_head_num % 8 == 0 && a.step_k_bs % 8 == 0 &&
+                       a.step_v_bs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
+  if (!no_mfma && a.sl_q >= 16 && (a.head_size == 64 || a.head_size == 128) && rows_ok &&
+      (a.attn_flags & (NS_ATTN_FLAG_IS_ALIBI8 | NS_ATTN_FLAG_IS_TANH30)) == 0) {
+    const dim3 grid(unsigned((a.sl_q + 63) / 64), unsigned(a.head_num), unsigned(a.batch_size));
+    if (a.head_size == 64)
+      hipLaunchKernelGGL(attn_mfma_kernel<64>, grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL(attn_mfma_kernel<128>, grid, dim3(256), 0, st, p);
+    return hipGetLastError();
   }
   // ---- fast path: contiguous head dimension, 16-byte aligned rows, head group 1/2/4/8 ----
   static const bool no_split = getenv("NS_ATTN_V1") != nullptr;  // diagnostics
@@ -418,7 +570,7 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
                     a.step_k_head_num % 8 == 0 && a.step_v_head_num % 8 == 0 && a.step_k_bs % 8 == 0 &&
                     a.step_v_bs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
-  if (fast) {
+  if (fast && size_t(a.heads_kv) * a.sl_q <= 65535) {
     AttnSplitParams sp;
     sp.a = p;
     int nsplit = attn_nsplit(a.batch_size, a.heads_kv, a.sl_q, a.sl_kv);

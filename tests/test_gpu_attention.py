@@ -21,6 +21,14 @@ CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags, k_trans
     (1, 64, 8, 128, 1, 3000, 1, False),    # Llama-2-70B head grouping (8 query heads per kv head)
     (1, 16, 2, 256, 2, 700, 1, False),     # group of 8 at the largest head size
     (1, 12, 4, 64, 1, 999, 0, False),      # group of 3: not a fast-path group size -> generic kernel
+    # ---- several query rows -> matrix-core kernel (head size 64 / 128) ----
+    (1, 8, 8, 128, 64, 64, 1, False),      # one full 64-row block, causal prefill
+    (1, 8, 2, 128, 100, 333, 1, False),    # GQA, ragged rows and context, sl_q < sl_kv (chunked prefill)
+    (2, 4, 4, 64, 77, 77, 1, False),       # head size 64, batch 2
+    (1, 4, 4, 128, 40, 200, 0, False),     # unmasked
+    (1, 6, 3, 128, 16, 16, 1, False),      # smallest row count that takes this kernel
+    (1, 16, 16, 128, 300, 300, 1, False),  # several row blocks with different causal extents
+    (1, 4, 4, 64, 33, 1000, 1, False),     # long context, few rows
 ]
 
 
