@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=CFG["n_layer"], help="debug only: fewer layers => INVALID number")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain-only", action="store_true", help="diagnostics: skip the roofline / prefill / CPU legs")
     return ap.parse_args()
 
 
@@ -91,6 +92,10 @@ class Chain:
         self.logits = torch.empty((1, V), device=dev, dtype=torch.float32)
         # fp16 shadows of the activations (written by the producing GEMM's epilogue, read by the next GEMM's staging)
         self.use_h = os.environ.get("NS_BENCH_NO_SHADOW", "0") != "1"
+        # opt-in experiment: "workgroups:fraction" of every weight prefetched beside the previous GEMM run
+        pf = os.environ.get("NS_BENCH_PREFETCH", "")
+        self.prefetch = (int(pf.split(":")[0]), float(pf.split(":")[1]), pf.split(":")[2:] == ["fine"]) if pf else None
+        self.pf_stream = None
         h = torch.float16
         self.x0h = self.x0.to(h)
         self.xh = torch.empty((1, d), device=dev, dtype=h)
@@ -157,11 +162,79 @@ class Chain:
         return items
 
     def step(self):
+        if self.prefetch and self.world == 1:
+            return self.step_prefetch()
         for kind, it in self.segments():
             if kind == "gemm":
                 it()
             else:
                 torch.distributed.all_reduce(it)
+
+    def block_weights(self):
+        """weights streamed by each GEMM run of segments(), in launch order (tp1)"""
+        out = []
+        for lw in self.layers:
+            out.append([lw["q"], lw["k"], lw["v"], lw["o"]])
+            out.append([lw["w1"], lw["w3"], lw["w2"]])
+        out.append([self.head])
+        return out
+
+    def launches(self):
+        """tp1 only: the chain as single kernel launches, each with the weights it streams (the same C calls
+        segments() makes; the fused FFN entry is its gate/up entry + the down projection, ns_api.cpp)."""
+        L, pkg = self.L, self.pkg
+        d = self.d
+        H = self.use_h
+        p = lambda t: t.data_ptr() if H else None
+        out = []
+        x_in, x_in_h = self.x0, self.x0h
+        for lw in self.layers:
+            out.append((lambda lw=lw, x_in=x_in, x_in_h=x_in_h: pkg.check(L.ns_hip_fusion_qkv_forward_h(
+                x_in.data_ptr(), p(x_in_h), lw["q"].h, lw["k"].h, lw["v"].h, self.qkv.data_ptr(), p(self.qkvh), 1, d,
+                self.dl, self.st)), [lw["q"], lw["k"], lw["v"]]))
+            out.append((lambda lw=lw: pkg.check(L.ns_hip_f32f32_forward_h(
+                self.qkv.data_ptr(), p(self.qkvh), lw["o"].h, self.attn.data_ptr(), p(self.attnh), 1, self.dl, d,
+                pkg.EPI_NONE, None, 0, self.st)), [lw["o"]]))
+            out.append((lambda lw=lw: pkg.check(L.ns_hip_fusion_ffn3_gateup_h(
+                self.attn.data_ptr(), p(self.attnh), lw["w1"].h, lw["w3"].h, None, self.t2.data_ptr(), p(self.t2h), 1,
+                pkg.EPI_SILU, self.st)), [lw["w1"], lw["w3"]]))
+            out.append((lambda lw=lw: pkg.check(L.ns_hip_f32f32_forward_h(
+                self.t2.data_ptr(), p(self.t2h), lw["w2"].h, self.x.data_ptr(), p(self.xh), 1, self.ffl, d,
+                pkg.EPI_NONE, None, 0, self.st)), [lw["w2"]]))
+            x_in, x_in_h = self.x, self.xh
+        out.append((lambda x_in=x_in, x_in_h=x_in_h: pkg.check(L.ns_hip_f32f32_forward_h(
+            x_in.data_ptr(), p(x_in_h), self.head.h, self.logits.data_ptr(), None, 1, d, self.V, pkg.EPI_NONE, None, 0,
+            self.st)), [self.head]))
+        return out
+
+    def step_prefetch(self):
+        """The same chain with a second stream (a parallel graph branch under capture) that pulls the NEXT GEMM run's
+        weights into the Infinity Cache (ns_hip_weight_prefetch) while the current run streams its own: the ramp-up
+        and tail of every launch leave HBM idle.  Each prefetch waits for the start of the run
+        it runs beside, so it is never more than one run (<= 76 MB) ahead.  NS_BENCH_PREFETCH="workgroups:fraction[:fine]"."""
+        L, pkg = self.L, self.pkg
+        grid, frac, fine = self.prefetch
+        cur = torch.cuda.current_stream()
+        if self.pf_stream is None:
+            self.pf_stream = torch.cuda.Stream()
+        pf = self.pf_stream
+        pfh = C.c_void_p(pf.cuda_stream)
+        if fine:  # one prefetch per kernel launch instead of one per GEMM run
+            blocks, wl = zip(*self.launches())
+        else:
+            blocks = [it for kind, it in self.segments() if kind == "gemm"]
+            wl = self.block_weights()
+        assert len(wl) == len(blocks)
+        pf.wait_stream(cur)  # fork
+        for b, blk in enumerate(blocks):
+            if True:  # the last run (lm_head) prefetches layer 0 for the next token: weights are static
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                pf.wait_event(ev)
+                for w in wl[(b + 1) % len(blocks)]:
+                    pkg.check(L.ns_hip_weight_prefetch(w.h, 0, int(frac * w.stream_bytes), grid, pfh), "prefetch")
+            blk()
+        cur.wait_stream(pf)  # join
 
 
 def capture(fn):
@@ -322,6 +395,8 @@ def main():
                 "event_ms_per_step": round(ev_ms / args.steps, 5),
             },
         }
+        if chain.prefetch and world == 1:
+            out["config"]["weight_prefetch"] = "second graph branch, %d workgroups, first %.2f of the next %s's weights" % (chain.prefetch[0], chain.prefetch[1], "launch" if chain.prefetch[2] else "GEMM run")
         if args.layers != CFG["n_layer"]:
             out["config"]["INVALID"] = "debug run with %d layers" % args.layers
         if world > 1 and backend != "nccl":
@@ -331,6 +406,10 @@ def main():
              (chain.ffl + CFG["n_embd"])]) * args.layers + 4 * (CFG["n_embd"] + CFG["n_vocab"])
         out["config"]["algorithmic_bytes_per_step_per_gpu"] = alg_bytes
         out["config"]["chain_hbm_GBps"] = round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1)
+        if args.chain_only and world == 1:
+            out["config"]["INVALID"] = "chain-only diagnostic run (no roofline / cpu_baseline legs)"
+            print(json.dumps(out))
+            return
         out["roofline"] = roofline(chain, pkg)
         if world == 1:
             out["config"]["prefill_m2048_tflops"] = prefill_tflops(chain, pkg)

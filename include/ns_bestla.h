@@ -156,6 +156,12 @@ int ns_hip_weight_info(const ns_weight* w, int* n, int* k, int* bits, int* block
 /* algorithmic bytes one forward over this weight streams: packed codes + scales (+ zero points), i.e.
  * N*K*bits/8 + N*(K/g)*sizeof(scale) [+ N*(K/g)] — the reference benchmark's formula (ut/bestla_benchmark.cpp:583-586) */
 uint64_t ns_hip_weight_stream_bytes(const ns_weight* w);
+/* Pull [offset, offset + bytes) of a weight's device stream (codes, scales, zero points; bytes is clamped) into the
+ * Infinity Cache with a light read-only kernel of `workgroups` (<= 0: 64) workgroups on `stream`.  No reference
+ * counterpart (the CPU path relies on hardware prefetchers); meant for a second stream / graph branch running beside
+ * the previous GEMV of a decode chain, whose ramp-up and tail leave HBM idle.  Purely a cache hint: results of every
+ * forward are unchanged whether or not it ran. */
+int ns_hip_weight_prefetch(const ns_weight* w, uint64_t offset, uint64_t bytes, int workgroups, void* stream);
 
 /* epilogue selector for the device forwards */
 enum ns_epilogue {

@@ -655,6 +655,15 @@ int ns_hip_weight_info(const ns_weight* w, int* n, int* k, int* bits, int* block
 
 uint64_t ns_hip_weight_stream_bytes(const ns_weight* w) { return w ? w->stream_bytes : 0; }
 
+int ns_hip_weight_prefetch(const ns_weight* w, uint64_t offset, uint64_t bytes, int workgroups, void* stream) {
+  if (!have_device()) return -1;
+  if (!w) {
+    set_error("prefetch: null weight");
+    return -1;
+  }
+  return hip_ok(launch_prefetch(w, size_t(offset), size_t(bytes), workgroups, (hipStream_t)stream), "prefetch launch") ? 0 : -1;
+}
+
 int ns_hip_f32f32_forward(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
                           const float* dD, int ldd, void* stream) {
   if (!have_device()) return -1;

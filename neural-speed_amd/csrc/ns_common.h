@@ -214,6 +214,9 @@ hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint
                             int ld_scale, uint8_t* zps, int blocksize, float* blkreduce, hipStream_t st);
 // A'[r][j] = A[r][idx[j]] (kernel_ref.h:28-37 shuffle_activation), fp32 [m][k] with leading dimension k
 hipError_t launch_gather_cols(const float* a, int lda, const int* idx, float* out, int m, int k, hipStream_t st);
+// default-policy read of [offset, offset + bytes) of the weight's stream (codes, scales, zero points) into the cache
+// hierarchy; bytes is clamped to the stream, grid <= 0 picks 64 workgroups
+hipError_t launch_prefetch(const ns_weight* w, size_t offset, size_t bytes, int grid, hipStream_t st);
 hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t st);
 hipError_t launch_dup(const void* src, void* dst, const long long* ne, const long long* snb, const long long* dnb, bool dst_f16,
                       hipStream_t st);

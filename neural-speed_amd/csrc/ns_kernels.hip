@@ -1146,4 +1146,38 @@ hipError_t launch_unpack_fp32(const ns_weight* w, float* out, int ld, hipStream_
   return hipGetLastError();
 }
 
+// ---- weight prefetch ------------------------------------------------------------------------------------------------
+// Reads a span of a weight's streaming buffer with default-policy loads and throws the data away: the lines land in the
+// die-level Infinity Cache (256 MiB), so a decode launch that follows finds (part of) its stream there instead of in
+// HBM.  Meant to run on a second stream / graph branch beside the PREVIOUS GEMV of the chain, whose ramp-up and tail
+// leave HBM idle.  Few workgroups, eight 16-byte loads in flight per lane.
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4v* __restrict__ p, size_t n16, uint32_t* __restrict__ sink) {
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  uint32_t acc = 0;
+  for (size_t idx = size_t(blockIdx.x) * blockDim.x + threadIdx.x; idx < n16; idx += 8 * stride) {
+    uint4v v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const size_t j = idx + i * stride;
+      v[i] = j < n16 ? p[j] : uint4v{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc |= v[i].x & v[i].w;
+  }
+  // never true for real data in both words of every line; keeps the loads alive without a store in practice
+  if (acc == 0xdeadbeefu && sink) sink[0] = acc;
+}
+hipError_t launch_prefetch(const ns_weight* w, size_t offset, size_t bytes, int grid, hipStream_t st) {
+  const size_t span = w->alloc_bytes > kDecodeWsBytes ? w->alloc_bytes - kDecodeWsBytes : 0;
+  offset &= ~size_t(15);
+  if (offset >= span) return hipSuccess;
+  bytes = std::min(bytes, span - offset) & ~size_t(15);
+  if (!bytes) return hipSuccess;
+  if (grid <= 0) grid = 64;
+  grid = std::min(grid, 4096);
+  const uint4v* p = reinterpret_cast<const uint4v*>(reinterpret_cast<const unsigned char*>(w->codes) + offset);
+  hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, st, p, bytes / 16, w->ws_flags ? w->ws_flags + (kMaxDecodeGrid - 1) : nullptr);
+  return hipGetLastError();
+}
+
 }  // namespace ns
