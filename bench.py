@@ -338,7 +338,9 @@ def main():
     # falls through to the next mode; every rank takes the same decision (all-reduce of the failure flag).
     modes = [] if args.no_graph else [True]
     if world > 1:
-        fg = os.environ.get("NS_BENCH_FULL_GRAPH", "0")
+        # default: try to capture the whole token, RCCL all-reduces included (torch's ProcessGroupNCCL supports capture;
+        # serving stacks on MI300 replay RCCL inside HIP graphs routinely); NS_BENCH_FULL_GRAPH=0 starts at "segments"
+        fg = os.environ.get("NS_BENCH_FULL_GRAPH", "1")
         full = (fg == "1" and backend == "nccl") or fg == "force"  # "force": exercise the fallback chain on any backend
         modes = ([True] if full and not args.no_graph else []) + ([] if args.no_graph else ["segments"])
     modes.append(False)
