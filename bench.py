@@ -258,26 +258,48 @@ def capture(fn):
     return graph
 
 
+def agree_failed(failed, world):
+    """max over ranks of a failure flag (collective on every rank when world > 1)"""
+    if world == 1:
+        return bool(failed)
+    flag = torch.tensor([1 if failed else 0], device="cuda", dtype=torch.int32)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+    return bool(int(flag.item()))
+
+
 def time_graph(fn, steps, warmup, use_graph, world):
     """W warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize on both sides."""
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
-    if use_graph == "segments":
-        # TP: one graph per GEMM run between two all-reduces; the collectives are launched eagerly in between, so
-        # nothing depends on RCCL being capturable
-        plan = [(k, capture(it) if k == "gemm" else it) for k, it in fn.segments()]
+    err = None
+    try:
+        if use_graph == "segments":
+            # TP: one graph per GEMM run between two all-reduces; the collectives are launched eagerly in between, so
+            # nothing depends on RCCL being capturable
+            plan = [(k, capture(it) if k == "gemm" else it) for k, it in fn.segments()]
 
-        def run():
-            for k, it in plan:
-                if k == "gemm":
-                    it.replay()
-                else:
-                    torch.distributed.all_reduce(it)
-    elif use_graph:
-        run = capture(fn).replay
-    else:
-        run = fn
+            def run():
+                for k, it in plan:
+                    if k == "gemm":
+                        it.replay()
+                    else:
+                        torch.distributed.all_reduce(it)
+        elif use_graph:
+            run = capture(fn).replay
+        else:
+            run = fn
+    except Exception as e:  # noqa: BLE001 - any capture failure selects the next launch mode
+        err = e
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
+        ge.load_package().lib().ns_hip_reset_error()  # an invalidated capture leaves a sticky error behind
+    # every rank learns about a failed capture BEFORE any rank replays a captured collective: a rank that went on to
+    # its warm-up all-reduces while another one had already given up would pair mismatched collectives
+    if agree_failed(err is not None, world):
+        raise err if err is not None else RuntimeError("capture failed on another rank")
     for _ in range(warmup):
         run()
     torch.cuda.synchronize()
