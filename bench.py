@@ -34,6 +34,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s mea
 CFG = dict(name="llama-2-7b", n_embd=4096, n_ff=11008, n_layer=32, n_vocab=32000, group=32)
 
 
+def REDUCE(t):
+    """ne_all_reduce: the TP communication layer's reduce_add (one-shot peer-memory kernel or RCCL, parallel.py)"""
+    from neural_speed_amd import parallel as par
+    return par.reduce_add(t)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,7 +174,7 @@ class Chain:
             if kind == "gemm":
                 it()
             else:
-                torch.distributed.all_reduce(it)
+                REDUCE(it)
 
     def block_weights(self):
         """weights streamed by each GEMM run of segments(), in launch order (tp1)"""
@@ -284,7 +290,7 @@ def time_graph(fn, steps, warmup, use_graph, world):
                     if k == "gemm":
                         it.replay()
                     else:
-                        torch.distributed.all_reduce(it)
+                        REDUCE(it)
         elif use_graph:
             run = capture(fn).replay
         else:
@@ -334,7 +340,9 @@ def main():
     # "nccl" = RCCL over xGMI on ROCm.  NS_DIST_BACKEND=gloo lets the TP code path be smoke-tested with several ranks
     # on ONE GPU (RCCL refuses two ranks per device); numbers from such a run are not bench results.
     backend = os.environ.get("NS_DIST_BACKEND", "nccl")
-    par.init_parallel_context(backend if world > 1 else None)
+    pctx = par.init_parallel_context(backend if world > 1 else None)
+    # decode-sized all-reduces: one-shot kernel over peer-mapped HBM (xGMI), RCCL otherwise.  NS_P2P=0 keeps RCCL.
+    use_p2p = world > 1 and os.environ.get("NS_P2P", "1") != "0" and pctx.enable_p2p(1 << 20)
     chain = Chain(pkg, args.layers, rank, world, keep_host_layer=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     # the chain object itself carries the captured stream handle; under graph capture torch switches the current
     # stream, so the stream pointer handed to the C ABI must be re-read inside the capture.
@@ -355,19 +363,28 @@ def main():
 
     step = Step()
 
-    # launch modes, most to least ambitious: True = the whole token in one HIP graph (TP: RCCL all-reduces captured too),
-    # "segments" = one graph per GEMM run + eager all-reduces (TP only), False = eager launches.  A failed attempt
-    # falls through to the next mode; every rank takes the same decision (all-reduce of the failure flag).
-    modes = [] if args.no_graph else [True]
-    if world > 1:
-        # default: try to capture the whole token, RCCL all-reduces included (torch's ProcessGroupNCCL supports capture;
-        # serving stacks on MI300 replay RCCL inside HIP graphs routinely); NS_BENCH_FULL_GRAPH=0 starts at "segments"
-        fg = os.environ.get("NS_BENCH_FULL_GRAPH", "1")
-        full = (fg == "1" and backend == "nccl") or fg == "force"  # "force": exercise the fallback chain on any backend
-        modes = ([True] if full and not args.no_graph else []) + ([] if args.no_graph else ["segments"])
-    modes.append(False)
+    # launch modes, most to least ambitious: True = the whole token in one HIP graph (TP: all-reduces captured too — the
+    # peer-memory kernel is an ordinary kernel node, RCCL is capturable through torch's ProcessGroupNCCL), "segments" =
+    # one graph per GEMM run + eager all-reduces (TP only), False = eager launches.  With the peer-memory all-reduce
+    # enabled the list is walked with it first and, if every mode fails or a flag wait times out, again over RCCL.
+    # A failed attempt falls through to the next one; every rank takes the same decisions (failure flags are reduced).
+    def launch_modes(p2p_on):
+        if args.no_graph:
+            return [False]
+        if world == 1:
+            return [True, False]
+        fg = os.environ.get("NS_BENCH_FULL_GRAPH", "1")  # "0": start at "segments"; "force": try True on any backend
+        full = fg == "force" or (fg == "1" and (backend == "nccl" or p2p_on))
+        return ([True] if full else []) + ["segments", False]
+
+    attempts = ([(m, True) for m in launch_modes(True)] if use_p2p else []) + [(m, False) for m in launch_modes(False)]
     wall_ms = ev_ms = None
-    for use_graph in modes:
+    p2p_dead = False
+    for idx, (use_graph, with_p2p) in enumerate(attempts):
+        if with_p2p and p2p_dead:
+            continue
+        if not with_p2p and pctx.p2p_enabled():
+            pctx.disable_p2p()  # collective; reduce_add is RCCL from here on
         failed, err = 0, None
         try:
             wall_ms, ev_ms = time_graph(step, args.steps, args.warmup, use_graph, world)
@@ -378,16 +395,21 @@ def main():
             except Exception:
                 pass
             pkg.lib().ns_hip_reset_error()  # an invalidated capture leaves a sticky error behind
-        if world > 1:
-            flag = torch.tensor([failed], device="cuda", dtype=torch.int32)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-            failed = int(flag.item())
+        if with_p2p:
+            try:
+                p2p_dead = pctx.p2p_error()  # collective: a flag wait timed out on some rank -> numbers are void
+            except Exception as e:  # noqa: BLE001
+                p2p_dead, err = True, err or e
+            if p2p_dead and err is None:
+                err = RuntimeError("peer-memory all-reduce: a flag wait timed out")
+        failed = agree_failed(failed or (with_p2p and p2p_dead), world)
         if not failed:
             break
-        if use_graph is False:
+        if idx == len(attempts) - 1:
             raise err if err is not None else RuntimeError("another rank failed")
-        sys.stderr.write("launch mode %r failed (%s); trying the next one\n" %
-                         (use_graph, str(err).splitlines()[0] if err else "on another rank"))
+        sys.stderr.write("launch mode %r (%s all-reduce) failed (%s); trying the next one\n" %
+                         (use_graph, "peer-memory" if with_p2p else "RCCL",
+                          str(err).splitlines()[0] if err else "on another rank"))
     t = torch.tensor([wall_ms], device="cuda", dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -416,6 +438,9 @@ def main():
                 "launch": ("hipGraph replay" if use_graph is True else
                            "hipGraph per GEMM run + eager all-reduce" if use_graph == "segments" else "eager"),
                 "weights_bytes_per_gpu": chain.stream_bytes,
+                "all_reduce": (None if world == 1 else
+                               "one-shot kernel over peer-mapped HBM (HIP IPC, xGMI)" if pctx.p2p_enabled() else
+                               "torch.distributed all_reduce (%s)" % backend),
                 "event_ms_per_step": round(ev_ms / args.steps, 5),
             },
         }
@@ -441,6 +466,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(chain, args.layers)
         print(json.dumps(out))
     if world > 1:
+        pctx.disable_p2p()  # collective: unmap peers, barrier, free
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -323,6 +323,29 @@ bool bestla_reordered_attn_fp32_support(const attn_shape_t* params);
 /* same operator on DEVICE pointers, asynchronous on `stream`; returns 0 on success */
 int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* dparams, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Part 5 — tensor-parallel all-reduce over peer-mapped HBM.  The decode-sized fast path of
+ * `reduce_add` (/root/reference/neural_speed/core/parallel_context.cpp:47-58): the reference hands small buffers to
+ * `shm_all_reduce` (/root/reference/neural_speed/core/shared_memory_ccl.hpp:100-139 — copy into a shared segment,
+ * flag, wait, sum) and the rest to oneCCL; here small buffers go through ONE kernel that exchanges flags and reads the
+ * peers' copies over xGMI (HIP IPC mappings), the rest through RCCL (neural-speed_amd/parallel.py).  One process per
+ * GPU.  In-place fp32 sum, summed in rank order on every rank (bit-identical results everywhere).  Capturable.
+ *   create  : allocates this rank's segment (2 slots of max_bytes + flag page) and returns its IPC handle (64 bytes)
+ *   connect : maps the segments of all ranks; `all_handles` = world x 64 bytes in rank order (own entry ignored)
+ *   all_reduce_f32 : n * 4 <= max_bytes, dBuf 16-byte aligned; asynchronous on `stream`
+ *   error   : synchronous read of the sticky device status: 0 ok, 1 = a flag wait exceeded NS_P2P_TIMEOUT_MS (default
+ *             10000; a peer died or never launched the matching call — results after that are undefined), -1 = bad ctx
+ *   disconnect (every rank) -> barrier -> destroy
+ * ---------------------------------------------------------------------------------------------- */
+#define NS_P2P_HANDLE_BYTES 64
+typedef struct ns_p2p ns_p2p;
+ns_p2p* ns_hip_p2p_create(int rank, int world, size_t max_bytes, void* handle_out);
+int ns_hip_p2p_connect(ns_p2p* ctx, const void* all_handles);
+int ns_hip_p2p_all_reduce_f32(ns_p2p* ctx, float* dBuf, size_t n, void* stream);
+int ns_hip_p2p_error(ns_p2p* ctx);
+void ns_hip_p2p_disconnect(ns_p2p* ctx);
+void ns_hip_p2p_destroy(ns_p2p* ctx);
+
 #ifdef __cplusplus
 }
 #endif

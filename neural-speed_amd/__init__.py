@@ -110,6 +110,15 @@ def lib():
         L.ns_hip_weight_stream_bytes.restype = C.c_uint64
         L.ns_hip_weight_stream_bytes.argtypes = [vp]
         L.ns_hip_weight_prefetch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, vp]
+        L.ns_hip_p2p_create.restype = vp
+        L.ns_hip_p2p_create.argtypes = [i, i, sz, vp]
+        L.ns_hip_p2p_connect.argtypes = [vp, vp]
+        L.ns_hip_p2p_all_reduce_f32.argtypes = [vp, vp, sz, vp]
+        L.ns_hip_p2p_error.argtypes = [vp]
+        L.ns_hip_p2p_disconnect.restype = None
+        L.ns_hip_p2p_disconnect.argtypes = [vp]
+        L.ns_hip_p2p_destroy.restype = None
+        L.ns_hip_p2p_destroy.argtypes = [vp]
         L.ns_hip_weight_info.argtypes = [vp] + [vp] * 5
         L.ns_hip_f32f32_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
         L.ns_hip_fusion_qkv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]

@@ -10,6 +10,7 @@ buffers are fp32 tensors reduced/broadcast IN PLACE (ne_layers.c:5466-5476 does 
 Split rules for Llama-family weights (model_files.h:145-190): wq/wk/wv/w1/w3 are split along N (TENSOR_1D_ROW),
 wo/w2 along K (TENSOR_1D_COLUMN) and followed by one all-reduce; everything else is replicated.
 """
+import ctypes as C
 import os
 
 import torch
@@ -37,6 +38,7 @@ class ParallelContext:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self._p2p, self._p2p_max = None, 0
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend is None:
@@ -74,10 +76,74 @@ class ParallelContext:
         return recv
 
     def reduce_add(self, buf):
-        """parallel_context.cpp:47-58: fp32 sum over ranks, in place"""
+        """parallel_context.cpp:47-58: fp32 sum over ranks, in place.  Like the reference, which hands decode-sized
+        buffers to shm_all_reduce (shared_memory_ccl.hpp:100-139) and the rest to oneCCL, fp32 device buffers that fit
+        the peer-memory slot go through the one-shot xGMI kernel (enable_p2p), everything else through RCCL."""
         if self.world > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if (self._p2p is not None and buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+                    and buf.numel() * 4 <= self._p2p_max and buf.data_ptr() % 16 == 0):
+                from . import check, lib
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                check(lib().ns_hip_p2p_all_reduce_f32(self._p2p, buf.data_ptr(), buf.numel(), st), "p2p all-reduce")
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         return buf
+
+    # one-shot all-reduce over peer-mapped HBM (csrc/ns_p2p.hip) ----------------------------------------------------
+    def enable_p2p(self, max_bytes=1 << 20):
+        """Collective.  Every rank allocates its segment, the IPC handles travel through the process group, every rank
+        maps every peer.  True when ALL ranks connected (then reduce_add uses the kernel for buffers <= max_bytes);
+        on any failure every rank drops back to RCCL together."""
+        if self.world == 1:
+            return False
+        if self._p2p is not None:
+            return True
+        from . import lib
+        L = lib()
+        handle = C.create_string_buffer(64)
+        ctx = L.ns_hip_p2p_create(self.rank, self.world, max_bytes, handle)
+        infos = [None] * self.world
+        dist.all_gather_object(infos, (bool(ctx), bytes(handle.raw)))
+        ok = all(o for o, _ in infos)
+        if ok:
+            ok = L.ns_hip_p2p_connect(ctx, b"".join(h for _, h in infos)) == 0
+        oks = [None] * self.world
+        dist.all_gather_object(oks, bool(ok))
+        if not all(oks):
+            L.ns_hip_reset_error()
+            if ctx:
+                L.ns_hip_p2p_disconnect(ctx)
+            dist.barrier()  # nobody frees a segment a peer still maps
+            if ctx:
+                L.ns_hip_p2p_destroy(ctx)
+            return False
+        self._p2p, self._p2p_max = ctx, max_bytes
+        return True
+
+    def p2p_enabled(self):
+        return self._p2p is not None
+
+    def p2p_error(self):
+        """Collective: True when a flag wait timed out on ANY rank (synchronises the device)."""
+        if self._p2p is None:
+            return False
+        from . import lib
+        torch.cuda.synchronize()
+        bad = [None] * self.world
+        dist.all_gather_object(bad, lib().ns_hip_p2p_error(self._p2p) != 0)
+        return any(bad)
+
+    def disable_p2p(self):
+        """Collective: unmap the peers, barrier, free the own segment; reduce_add is RCCL again."""
+        if self._p2p is None:
+            return
+        from . import lib
+        L = lib()
+        torch.cuda.synchronize()
+        L.ns_hip_p2p_disconnect(self._p2p)
+        dist.barrier()
+        L.ns_hip_p2p_destroy(self._p2p)
+        self._p2p = None
 
     def shard_range(self, size, quantum=1):
         """[begin, end) of this rank's slice of an axis of `size` split evenly (the reference requires divisibility,
@@ -134,3 +200,7 @@ def alltoall(send, recv):
 
 def reduce_add(buf):
     return init_parallel_context().reduce_add(buf)
+
+
+def enable_p2p(max_bytes=1 << 20):
+    return init_parallel_context().enable_p2p(max_bytes)
