@@ -275,6 +275,8 @@ def agree_failed(failed, world):
 
 def time_graph(fn, steps, warmup, use_graph, world):
     """W warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize on both sides."""
+    if world > 1:
+        torch.distributed.barrier()  # ranks enter their first all-reduce together (the peer-memory kernel's wait is bounded)
     for _ in range(2):
         fn()
     torch.cuda.synchronize()

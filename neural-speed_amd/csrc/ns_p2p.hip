@@ -60,12 +60,14 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(const P2PParams p) 
   P2PHeader* self = reinterpret_cast<P2PHeader*>(p.peers[p.rank]);
   if (tid == 0) {
     s_seq = __hip_atomic_load(&self->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
-    s_fail = 0;
+    // once a wait has timed out the context is dead: later calls do not wait again (no 10-second stalls per call)
+    s_fail = __hip_atomic_load(&self->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
   }
   __syncthreads();
   const uint32_t seq = s_seq, par = seq & 1u;
   const size_t slot = kP2PDataOff + size_t(par) * p.slot_bytes;
   const unsigned int n4 = p.n >> 2;
+  const bool dead = s_fail != 0;  // read before any lane can raise s_fail below
 
   // 1. publish: volatile stores are system-scope write-through (and the allocation is uncached anyway)
   {
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(const P2PParams p) 
     P2PHeader* peer = reinterpret_cast<P2PHeader*>(p.peers[tid]);
     __hip_atomic_store(&peer->flags[par][p.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&self->flags[par][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+    while (!dead && __hip_atomic_load(&self->flags[par][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       if (wall_clock64() - t0 > p.timeout_ticks) {
         s_fail = 1;
         break;

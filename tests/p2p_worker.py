@@ -65,6 +65,29 @@ def main():
     dist.all_reduce(expect)
     assert torch.allclose(buf, expect, rtol=1e-6, atol=1e-6)
     assert not ctx.p2p_error()
+    if os.environ.get("NS_P2P_LATENCY"):  # diagnostics (scripts/final_check.sh): launch-to-launch latency inside a graph
+        v = torch.randn(4096, generator=g, device="cuda") * 1e-3
+        gl = torch.cuda.CUDAGraph()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gl.capture_begin()
+            for _ in range(64):
+                ctx.reduce_add(v)
+            gl.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        gl.replay()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            gl.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        if rank == 0:
+            print("P2P_LATENCY world=%d ranks on %d GPU(s): %.2f us per 16-KB all-reduce (64 per graph, 20 replays)"
+                  % (world, min(world, torch.cuda.device_count()), e0.elapsed_time(e1) * 1e3 / (64 * 20)))
+        assert not ctx.p2p_error()
     ctx.disable_p2p()
     dist.barrier()
     if rank == 0:
