@@ -77,23 +77,28 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(const P2PParams p) 
     volatile float* mine = reinterpret_cast<volatile float*>(p.peers[p.rank] + slot);
     for (unsigned int i = (n4 << 2) + tid; i < p.n; i += blockDim.x) mine[i] = p.buf[i];
   }
-  __threadfence_system();
+  // No release / acquire fences anywhere: a system-scope fence writes back (and invalidates) the whole L2 of the XCD,
+  // which costs microseconds per call.  Every access to a segment is itself system-scope (sc0 sc1: write-through
+  // stores, cache-bypassing loads, and the segments are uncached memory), so "payload stores drained (vmcnt 0) ->
+  // barrier -> flag store" on the producer and "flag seen -> barrier -> payload loads" on the consumer are ordered
+  // by the waits alone (the drained-sc1 hand-off of MI355X_MICROARCH.md).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // 2. + 3. one lane per peer: raise my flag over there, then wait for that peer's flag here
   if (tid < p.world && tid != p.rank) {
     P2PHeader* peer = reinterpret_cast<P2PHeader*>(p.peers[tid]);
-    __hip_atomic_store(&peer->flags[par][p.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&peer->flags[par][p.rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = wall_clock64();
-    while (!dead && __hip_atomic_load(&self->flags[par][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+    while (!dead && __hip_atomic_load(&self->flags[par][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       if (wall_clock64() - t0 > p.timeout_ticks) {
         s_fail = 1;
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  __threadfence_system();
   if (s_fail && tid == 0) __hip_atomic_store(&self->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // 4. sum every rank's copy in rank order (own copy through the same path: identical arithmetic on every rank)
   {
