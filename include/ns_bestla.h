@@ -163,6 +163,20 @@ uint64_t ns_hip_weight_stream_bytes(const ns_weight* w);
  * forward are unchanged whether or not it ran. */
 int ns_hip_weight_prefetch(const ns_weight* w, uint64_t offset, uint64_t bytes, int workgroups, void* stream);
 
+/* Numerics of the forwards over INTEGER weights (S1..S8).  The reference runs blobs packed for an integer compute core
+ * (compute_dtype=int8, the default) with dynamically quantized u8 activations: ActivationKBlockQuantize
+ * (bestla_prologue_a.h:133-154) + gemv_4bit_u8s8_fp32 (kernel_ref.h:2371-2429) / ref_kblock_int8
+ * (bestla/ut/bestla_gemm.cpp:159-190).  NS_COMPUTE_FP16 (default) multiplies the same weights by fp16 activations with
+ * fp32 accumulation — within 1e-3 of the reference's fp32-compute path and closer to it than the int8 path is;
+ * NS_COMPUTE_REF_INT8 reproduces the int8 path itself (bit-exact activation quantization, exact integer dots per
+ * k-block, fp32 scale products; only the fp32 summation order differs from the scalar reference) for callers that
+ * compare against CPU int8 baselines.  Float weights (NF4 / FP4 / FP8) have no int8 path in the reference either and
+ * are unaffected.  Process-wide; also NS_COMPUTE=ref_int8 in the environment.  set returns the previous mode, -1 on a
+ * bad argument.  A numerics mode, not a tuned kernel. */
+enum ns_compute_mode { NS_COMPUTE_FP16 = 0, NS_COMPUTE_REF_INT8 = 1 };
+int ns_hip_set_compute_mode(int mode);
+int ns_hip_get_compute_mode(void);
+
 /* epilogue selector for the device forwards */
 enum ns_epilogue {
   NS_EPI_NONE = 0,      /* AccumulatorWriteBackFp32 (bestla_epilogue.h:114-136) */

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -402,6 +403,15 @@ bool plan_pack(PackPlan* pp, size_t N, size_t K, size_t BlkSize, uint32_t qt, ui
   return true;
 }
 
+// numerics mode (ns_hip_set_compute_mode / NS_COMPUTE): 0 = fp16 activations x dequantised weights, fp32 accumulate
+// (default); 1 = the reference's int8-compute semantics for integer weights (ns_i8ref.hip)
+int env_compute_mode() {
+  const char* e = getenv("NS_COMPUTE");
+  return e && (!strcmp(e, "ref_int8") || !strcmp(e, "1")) ? NS_COMPUTE_REF_INT8 : NS_COMPUTE_FP16;
+}
+std::atomic<int> g_compute_mode{env_compute_mode()};
+bool ref_int8_for(const ns_weight* w) { return g_compute_mode.load() == NS_COMPUTE_REF_INT8 && w && i8ref_supported(w); }
+
 // rows up to which the weight-streaming kernel is used; above, the tiled MFMA GEMM (measured crossover)
 constexpr int kSmallMMax = 64;
 int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
@@ -425,6 +435,8 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
     lda = w->k;
     dA16 = nullptr;  // the caller's fp16 shadow is in the unshuffled order
   }
+  if (ref_int8_for(w))  // opt-in: quantize A to u8 per k-block and accumulate integer dots, like the CPU int8 cores
+    return hip_ok(launch_i8ref(dA, lda, w, dC, dC16, m, ldc, epilogue, dD, ldd, st), "int8-reference forward") ? 0 : -1;
   // M <= 64: weight-streaming kernel (HBM-bound); larger M: tiled MFMA GEMM (weights reused across 128 rows)
   SmallMArgs a{};
   a.a = dA;
@@ -655,6 +667,15 @@ int ns_hip_weight_info(const ns_weight* w, int* n, int* k, int* bits, int* block
 
 uint64_t ns_hip_weight_stream_bytes(const ns_weight* w) { return w ? w->stream_bytes : 0; }
 
+int ns_hip_set_compute_mode(int mode) {
+  if (mode != NS_COMPUTE_FP16 && mode != NS_COMPUTE_REF_INT8) {
+    set_error("compute mode: 0 (fp16 activations) or 1 (reference int8 compute)");
+    return -1;
+  }
+  return g_compute_mode.exchange(mode);
+}
+int ns_hip_get_compute_mode(void) { return g_compute_mode.load(); }
+
 int ns_hip_weight_prefetch(const ns_weight* w, uint64_t offset, uint64_t bytes, int workgroups, void* stream) {
   if (!have_device()) return -1;
   if (!w) {
@@ -694,6 +715,7 @@ int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weig
     same &= ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize &&
             ws[i]->scale_dt == wq->scale_dt && ws[i]->asym == wq->asym && ws[i]->qtype == wq->qtype;
   same &= !wq->shuf && !wk->shuf && !wv->shuf;  // each shuffled weight gathers its own A' (unfused path)
+  same &= !ref_int8_for(wq);                    // int8-reference mode: three plain forwards share nothing but A
   hipStream_t st = (hipStream_t)stream;
   if (!same || m > 64) {  // fall back to three launches (still on the GPU)
     for (int i = 0; i < 3; i++)
@@ -732,7 +754,8 @@ int ns_hip_fusion_ffn3_gateup_h(const float* dA, const void* dA16, const ns_weig
   const bool same = w3->k == fin && w3->n == fmid && w3->kind == w1->kind && w3->blocksize == w1->blocksize &&
                     w3->scale_dt == w1->scale_dt && w3->asym == w1->asym && w3->qtype == w1->qtype && !w1->shuf &&
                     !w3->shuf;
-  if (same && smallm_dual_ok(seq) && smallm_supported(w1, seq)) {
+  const bool ref8 = ref_int8_for(w1);  // int8-reference mode: the two GEMVs and the activation stay separate operators
+  if (same && smallm_dual_ok(seq) && smallm_supported(w1, seq) && !ref8) {
     SmallMArgs a{};
     a.a = dA;
     a.a16 = dA16;
@@ -747,6 +770,7 @@ int ns_hip_fusion_ffn3_gateup_h(const float* dA, const void* dA16, const ns_weig
     a.c2 = dTmp1;
     return hip_ok(launch_smallm(a, st), "ffn gate/up launch") ? 0 : -1;
   }
+  if (!dTmp1 && ref8) dTmp1 = static_cast<float*>(stream_scratch(st, size_t(seq) * fmid * 4, 5));
   if (!dTmp1) {
     set_error("ffn3: tmp1 required on the unfused path");
     return -1;

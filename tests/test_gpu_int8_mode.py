@@ -1,0 +1,103 @@
+"""NS_COMPUTE_REF_INT8: the reference's int8-compute numerics on the GPU (csrc/ns_i8ref.hip) against the oracle's
+restatement of gemv_4bit_u8s8_fp32 (kernel_ref.h:2371-2429; the oracle function is pinned to the real kernel in
+tests/test_oracle_vs_ref.py).  Activation quantization is bit-exact (tests/test_gpu_parity.py covers the prologue), the
+integer dots are exact, so the only difference is fp32 summation order: the bar is 2e-6 relative L2 — three orders of
+magnitude tighter than the distance between the int8 path and the fp32 truth, which the last test shows."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def int8_mode(L):
+    prev = L.ns_hip_set_compute_mode(1)
+    assert prev in (0, 1)
+    yield
+    L.ns_hip_set_compute_mode(prev)
+
+
+CASES = [  # qtype, scale dtype, asym, group, n, k, reference core the blob is packed for
+    ("S4", "BF16", False, 32, 512, 1024, "CORE_AVX512_VNNI_KB"),
+    ("S4", "F32", True, 128, 200, 1024, "CORE_AVX512_VNNI_KB"),   # asymmetric, ragged N
+    ("S4", "F16", False, 64, 256, 832, "CORE_AVX512_VNNI_KB"),    # K not a multiple of the 128-deep k-step
+    ("S8", "BF16", False, 32, 256, 512, "CORE_AVX512_VNNI_KB"),
+    ("S8", "F32", True, 64, 96, 704, "CORE_AVX512F"),
+    ("S3", "BF16", False, 32, 128, 512, "CORE_AVX512_VNNI_KB"),   # bit-plane type widened to the nibble container
+    ("S4", "F32", False, -1, 128, 1024, "CORE_AVX512F"),          # per-channel
+]
+
+
+@pytest.mark.parametrize("qt,st,asym,bs,n,k,core", CASES)
+@pytest.mark.parametrize("m", [1, 3, 9])
+def test_int8_mode_matches_reference_int8_semantics(L, pkg, nso, int8_mode, qt, st, asym, bs, n, k, core, m):
+    rng = np.random.default_rng(n * 7 + k * 3 + m)
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    blob = nso.quant_pack(w, bs, getattr(nso, qt), getattr(nso, st), asym, getattr(nso, core))
+    out = np.zeros((m, n), np.float32)
+    L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), m, n, k, k, n, None)
+    ref = nso.gemm_u8s8(a, blob)
+    assert nso.rel_l2(out, ref) < 2e-6, nso.rel_l2(out, ref)
+
+
+def test_int8_mode_device_entries_and_epilogues(L, pkg, nso, int8_mode):
+    import torch
+    rng = np.random.default_rng(5)
+    n, k, m, bs = 256, 512, 2, 32
+    mk = lambda: nso.quant_pack((rng.standard_normal((n, k)) * 0.05).astype(np.float32), bs, nso.S4, nso.BF16, False,
+                                nso.CORE_AVX512_VNNI_KB)
+    bq, bk, bv = mk(), mk(), mk()
+    wq, wk, wv = (pkg.Weight.from_host_blob(nso.ptr(b)) for b in (bq, bk, bv))
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    dA = torch.from_numpy(a).cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # fused QKV entry: three int8-reference forwards
+    dC = torch.zeros((3, m, n), device="cuda")
+    pkg.check(L.ns_hip_fusion_qkv_forward(dA.data_ptr(), wq.h, wk.h, wv.h, dC.data_ptr(), m, k, n, st))
+    torch.cuda.synchronize()
+    for i, b in enumerate((bq, bk, bv)):
+        assert nso.rel_l2(dC[i].cpu().numpy(), nso.gemm_u8s8(a, b)) < 2e-6
+    # epilogue: C = gelu(A W + bias), bias broadcast (ldd = 0)
+    bias = torch.randn((1, n), device="cuda")
+    dG = torch.zeros((m, n), device="cuda")
+    pkg.check(L.ns_hip_f32f32_forward(dA.data_ptr(), wq.h, dG.data_ptr(), m, k, n, pkg.EPI_ADD_GELU, bias.data_ptr(), 0, st))
+    torch.cuda.synchronize()
+    x = nso.gemm_u8s8(a, bq).astype(np.float64) + bias.cpu().numpy().astype(np.float64)
+    gelu = 0.5 * x * (1 + np.tanh(0.7978845834732056 * (x + 0.044714998453855515 * x ** 3)))
+    assert nso.rel_l2(dG.cpu().numpy(), gelu) < 1e-5
+    # gate/up entry without a tmp1 buffer: silu(A W1) * (A W3), unfused in this mode
+    dT2 = torch.zeros((m, n), device="cuda")
+    pkg.check(L.ns_hip_fusion_ffn3_gateup_h(dA.data_ptr(), None, wq.h, wk.h, None, dT2.data_ptr(), None, m, pkg.EPI_SILU, st))
+    torch.cuda.synchronize()
+    g = nso.gemm_u8s8(a, bq).astype(np.float64)
+    ref = g / (1 + np.exp(-g)) * nso.gemm_u8s8(a, bk).astype(np.float64)
+    assert nso.rel_l2(dT2.cpu().numpy(), ref) < 1e-5
+
+
+def test_modes_differ_as_the_reference_paths_do(L, pkg, nso):
+    """fp16-activation default vs int8 mode on the same blob: the int8 path sits ~1e-2 from the fp64 truth (u8
+    activations), the default within 1e-3 — and switching modes really switches kernels."""
+    rng = np.random.default_rng(11)
+    n, k, bs = 256, 2048, 32
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    a = rng.standard_normal((1, k)).astype(np.float32)
+    blob = nso.quant_pack(w, bs, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    truth = nso.gemm_f64(a, blob)
+    outs = {}
+    prev = L.ns_hip_get_compute_mode()
+    try:
+        for mode in (0, 1):
+            L.ns_hip_set_compute_mode(mode)
+            o = np.zeros((1, n), np.float32)
+            L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(o), 1, n, k, k, n, None)
+            outs[mode] = o
+    finally:
+        L.ns_hip_set_compute_mode(prev)
+    assert nso.rel_l2(outs[0], truth) < 1e-3
+    e1 = nso.rel_l2(outs[1], truth)
+    assert 1e-3 < e1 < 5e-2, e1
+    assert L.ns_hip_set_compute_mode(7) == -1   # bad argument
+    L.ns_hip_reset_error()
