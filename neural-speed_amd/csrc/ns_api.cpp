@@ -415,7 +415,8 @@ bool ref_int8_for(const ns_weight* w) { return g_compute_mode.load() == NS_COMPU
 // rows up to which the weight-streaming kernel is used; above, the tiled MFMA GEMM (measured crossover)
 constexpr int kSmallMMax = 64;
 int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
-                 const float* dD, int ldd, hipStream_t st, const void* dA16 = nullptr, void* dC16 = nullptr) {
+                 const float* dD, int ldd, hipStream_t st, const void* dA16 = nullptr, void* dC16 = nullptr,
+                 bool reuse_aq = false) {
   if (!w || !dA || !dC || m <= 0) {
     set_error("forward: null argument");
     return -1;
@@ -436,7 +437,8 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
     dA16 = nullptr;  // the caller's fp16 shadow is in the unshuffled order
   }
   if (ref_int8_for(w))  // opt-in: quantize A to u8 per k-block and accumulate integer dots, like the CPU int8 cores
-    return hip_ok(launch_i8ref(dA, lda, w, dC, dC16, m, ldc, epilogue, dD, ldd, st), "int8-reference forward") ? 0 : -1;
+    return hip_ok(launch_i8ref(dA, lda, w, dC, dC16, m, ldc, epilogue, dD, ldd, st, reuse_aq && !w->shuf),
+                  "int8-reference forward") ? 0 : -1;
   // M <= 64: weight-streaming kernel (HBM-bound); larger M: tiled MFMA GEMM (weights reused across 128 rows)
   SmallMArgs a{};
   a.a = dA;
@@ -718,9 +720,14 @@ int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weig
   same &= !ref_int8_for(wq);                    // int8-reference mode: three plain forwards share nothing but A
   hipStream_t st = (hipStream_t)stream;
   if (!same || m > 64) {  // fall back to three launches (still on the GPU)
+    // int8-reference mode: the three weights share one activation quantization when K and the group size agree
+    auto same_aq = [&](int i) {
+      return i > 0 && ref_int8_for(ws[i]) && ref_int8_for(ws[0]) && ws[i]->k == ws[0]->k &&
+             ws[i]->blocksize == ws[0]->blocksize && !ws[i]->shuf && !ws[0]->shuf;
+    };
     for (int i = 0; i < 3; i++)
       if (forward_impl(dA, ws[i], dC + size_t(i) * m * ldc, m, lda, ldc, NS_EPI_NONE, nullptr, 0, st, dA16,
-                       dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr))
+                       dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr, same_aq(i)))
         return -1;
     return 0;
   }
@@ -776,7 +783,8 @@ int ns_hip_fusion_ffn3_gateup_h(const float* dA, const void* dA16, const ns_weig
     return -1;
   }
   if (forward_impl(dA, w1, dTmp1, seq, fin, fmid, act, nullptr, 0, st, dA16, nullptr)) return -1;
-  return forward_impl(dA, w3, dTmp2, seq, fin, fmid, NS_EPI_MUL, dTmp1, fmid, st, dA16, dTmp2_16);
+  const bool same_aq = ref8 && ref_int8_for(w3) && w3->k == w1->k && w3->blocksize == w1->blocksize && !w1->shuf && !w3->shuf;
+  return forward_impl(dA, w3, dTmp2, seq, fin, fmid, NS_EPI_MUL, dTmp1, fmid, st, dA16, dTmp2_16, same_aq);
 }
 
 int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const ns_weight* w3,

@@ -220,7 +220,7 @@ hipError_t launch_prefetch(const ns_weight* w, size_t offset, size_t bytes, int 
 // ns_i8ref.hip: the reference's int8-compute semantics (u8 activation quantization + integer dot per k-block)
 bool i8ref_supported(const ns_weight* w);
 hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, void* c16, int m, int ldc, int epilogue,
-                        const float* d, int ldd, hipStream_t st);
+                        const float* d, int ldd, hipStream_t st, bool reuse_aq = false);
 hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t st);
 hipError_t launch_dup(const void* src, void* dst, const long long* ne, const long long* snb, const long long* dnb, bool dst_f16,
                       hipStream_t st);

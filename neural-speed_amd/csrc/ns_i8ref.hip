@@ -12,10 +12,11 @@
 // scale product per k-block, so that a caller who needs the CPU int8 path's numbers (regression baselines, token-exact
 // comparisons) gets them from the GPU.  Differences from the scalar reference are fp32 summation order only.
 //
-// Kernel: one 256-thread workgroup per 16-column tile of the streaming layout (ns_common.h: ns_weight), wave w takes
-// k-steps w, w+4, ...; lane (nn, c) owns column nn and the eight k of slot c in every 32-deep slice, exactly the bytes
-// the MFMA kernels read.  Up to four rows of A per pass (weights are re-read for more rows: this is a numerics mode, the
-// streaming loop is VALU-light enough to stay HBM-bound at decode sizes but it is not tuned).
+// Kernel: one 512-thread workgroup per 16-column tile of the streaming layout (ns_common.h: ns_weight), wave w takes
+// k-steps w, w+8, ...; lane (nn, c) owns column nn and the eight k of slot c in every 32-deep slice, exactly the bytes
+// the MFMA kernels read; integer dots with v_dot4_u32_u8 on the stored codes, activation codes staged in LDS.  Up to
+// four rows of A per pass (weights are re-read for more rows: a numerics mode for decode-sized calls, not a prefill
+// kernel).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -27,6 +28,7 @@ namespace ns {
 namespace {
 
 constexpr int kI8Rows = 4;
+constexpr int kI8Waves = 8, kI8Threads = kI8Waves * 64;  // wave w takes k-steps w, w + 8, ...; four records in flight each
 
 struct I8RefParams {
   const uint8_t* codes;
@@ -34,6 +36,7 @@ struct I8RefParams {
   const int8_t* zps;
   uint32_t qstride, sstride, zstride;
   int ksteps, kstep_len, nj;  // 128 / 4 (4-bit containers) or 64 / 2 (8-bit)
+  int chunk_steps;            // k-steps of A staged in LDS at a time
   int sps, srows, srow_mul, srow_shift;
   uint32_t scale_dt;
   int asym;
@@ -57,49 +60,149 @@ __device__ __forceinline__ float load_scale(const uint8_t* p, uint32_t dt) {
   return f16_bits_to_f32(h);
 }
 
-__global__ __launch_bounds__(256) void i8ref_kernel(const I8RefParams p) {
-  __shared__ float red[4][kI8Rows][16];
+// u8 x u8 dot products (v_dot4_u32_u8) on the STORED codes: with u = q + bias (bias 8 for nibbles, 128 for bytes),
+//   sum (a - za)(q - zb) = sum a*u - (zb + bias) * sum a - za * sum u + n * za * (zb + bias),   n = 8 per lane and slice,
+// every term an exact integer.  Activation codes of the row group are staged in LDS once per workgroup and chunk, the
+// eight codes of a lane's slot already in the byte order the nibble unpack produces ((x & 0x0f0f0f0f) = codes 0,4,1,5
+// and ((x >> 4) & 0x0f0f0f0f) = codes 2,6,3,7 of the dword), so a slice costs six dot instructions per row and no
+// per-element work.  Columns of A beyond K are staged as the row's last zero point: their term vanishes identically.
+template <bool FOUR>  // nibble container (4 slices of 32 per 128-deep k-step) or byte container (2 per 64-deep)
+__global__ __launch_bounds__(kI8Threads) void i8ref_kernel(const I8RefParams p) {
+  constexpr int NJ = FOUR ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char i8_smem[];
+  __shared__ float red[kI8Waves][kI8Rows][16];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nn = l & 15, cslot = l >> 4;
   const int tile = blockIdx.x;
-  const bool four = p.nj == 4;
+  constexpr bool four = FOUR;
+  const uint32_t bias = four ? 8u : 128u;
+  const int chunk_k = p.chunk_steps * p.kstep_len;  // bytes per staged row
+  const int sbytes = p.scale_dt == DT_F32 ? 4 : 2;
+  const int rec_sbytes = p.sps * sbytes;            // scale bytes of one lane's k-step record: 2, 4, 8 or 16
+  // LDS: [kI8Rows][chunk_k] activation codes | [kI8Rows][nblk] activation scales | [kI8Rows][nblk] zero points (int)
+  float* as_lds = reinterpret_cast<float*>(i8_smem + size_t(kI8Rows) * chunk_k);
+  int* az_lds = reinterpret_cast<int*>(as_lds + size_t(kI8Rows) * p.nblk);
   for (int r0 = 0; r0 < p.m; r0 += kI8Rows) {
     const int rows = min(kI8Rows, p.m - r0);
     float acc[kI8Rows] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = w; s < p.ksteps; s += 4) {
-      const uint4v rec = *reinterpret_cast<const uint4v*>(p.codes + (size_t(tile) * p.ksteps + s) * p.qstride + l * 16);
-      const uint32_t xw[4] = {rec.x, rec.y, rec.z, rec.w};
-      const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
-      const size_t crow = size_t(tile) * p.srows + srow;
-      for (int j = 0; j < p.nj; j++) {
-        const int k0 = s * p.kstep_len + 32 * j + 8 * cslot;
-        if (k0 >= p.k) continue;
-        const int e = (j * p.sps) / p.nj;
-        const int sbytes = p.scale_dt == DT_F32 ? 4 : 2;
-        const float sb = load_scale(p.scales + crow * p.sstride + (size_t(nn) * p.sps + e) * sbytes, p.scale_dt);
-        const int zb = p.asym ? int(p.zps[crow * p.zstride + nn * p.sps + e]) : 0;
-        // the eight weight codes of this lane's slot, as signed integers q = stored - bias
-        int q[8];
-        if (four) {
-          const uint32_t x = xw[j];  // nibble i sits at bit {0,16,4,20,8,24,12,28}[i]
-#pragma unroll
-          for (int i = 0; i < 8; i++) q[i] = int((x >> (((i & 1) << 4) + ((i >> 1) << 2))) & 15u) - 8;
+    __syncthreads();
+    for (int idx = tid; idx < rows * p.nblk; idx += kI8Threads) {  // the row group's activation scales / zero points
+      const int r = idx / p.nblk, kb = idx - r * p.nblk;
+      as_lds[r * p.nblk + kb] = p.ascale[size_t(r0 + r) * p.nblk + kb];
+      az_lds[r * p.nblk + kb] = int(p.azp[size_t(r0 + r) * p.nblk + kb]);
+    }
+    for (int c0 = 0; c0 < p.ksteps; c0 += p.chunk_steps) {
+      const int cend = min(c0 + p.chunk_steps, p.ksteps);
+      __syncthreads();  // previous chunk / row group fully consumed
+      // ---- stage: 8-byte groups, permuted for the nibble container ----
+      const int groups = chunk_k >> 3;
+      const bool vec_ok = (p.k & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aq) & 7) == 0;
+      for (int idx = tid; idx < rows * groups; idx += kI8Threads) {
+        const int r = idx / groups, gq = idx - r * groups;
+        const int k0 = c0 * p.kstep_len + gq * 8;
+        const size_t row = size_t(r0 + r);
+        const uint8_t* src = p.aq + row * p.k + k0;
+        uint32_t lo, hi;  // codes 0..3 and 4..7 of the group
+        if (vec_ok && k0 + 8 <= p.k) {
+          const uint2 v = *reinterpret_cast<const uint2*>(src);
+          lo = v.x, hi = v.y;
         } else {
-          const uint32_t lo = xw[2 * j], hi = xw[2 * j + 1];
+          const uint32_t zpad = p.azp[row * p.nblk + (p.nblk - 1)];
+          uint32_t b[8];
 #pragma unroll
-          for (int i = 0; i < 4; i++) q[i] = int(int8_t((lo >> (8 * i)) & 255u)), q[4 + i] = int(int8_t((hi >> (8 * i)) & 255u));  // raw int8
+          for (int i = 0; i < 8; i++) b[i] = (k0 + i < p.k) ? uint32_t(src[i]) : zpad;
+          lo = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+          hi = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
         }
-        const int kb = k0 / p.blocksize;  // a 32-deep slice never straddles a k-block (blocksize % 32 == 0)
-        const int kn = min(8, p.k - k0);
-        for (int r = 0; r < rows; r++) {
-          const size_t row = size_t(r0 + r);
-          const uint8_t* ap = p.aq + row * p.k + k0;
-          const int za = int(p.azp[row * p.nblk + kb]);
-          int isum = 0;
+        uint32_t d0 = lo, d1 = hi;
+        if (four) {  // (a0,a4,a1,a5) and (a2,a6,a3,a7): the byte order of the nibble unpack
+          d0 = __builtin_amdgcn_perm(hi, lo, 0x05010400u);
+          d1 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+        }
+        *reinterpret_cast<uint2*>(i8_smem + size_t(r) * chunk_k + gq * 8) = uint2{d0, d1};
+      }
+      __syncthreads();
+      // the scale / zero-point words of a lane's k-step record, fetched together with the codes
+      struct Corr {
+        uint32_t s[4];
+        uint32_t z;
+      };
+      auto fetch_corr = [&](int s) {
+        Corr c{{0, 0, 0, 0}, 0};
+        const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
+        const size_t crow = size_t(tile) * p.srows + srow;
+        const uint8_t* sp = p.scales + crow * p.sstride + size_t(nn) * rec_sbytes;
+        if (rec_sbytes == 16) {
+          const uint4v v = *reinterpret_cast<const uint4v*>(sp);
+          c.s[0] = v.x, c.s[1] = v.y, c.s[2] = v.z, c.s[3] = v.w;
+        } else if (rec_sbytes == 8) {
+          const uint2 v = *reinterpret_cast<const uint2*>(sp);
+          c.s[0] = v.x, c.s[1] = v.y;
+        } else if (rec_sbytes == 4) {
+          c.s[0] = *reinterpret_cast<const uint32_t*>(sp);
+        } else {
+          c.s[0] = *reinterpret_cast<const uint16_t*>(sp);
+        }
+        if (p.asym) {
+          const int8_t* zp = p.zps + crow * p.zstride + nn * p.sps;
+          for (int e = 0; e < p.sps; e++) c.z |= uint32_t(uint8_t(zp[e])) << (8 * e);
+        }
+        return c;
+      };
+      auto consume = [&](const uint4v& rec, const Corr& cr, int s) {
+        const uint32_t xw[4] = {rec.x, rec.y, rec.z, rec.w};
 #pragma unroll
-          for (int i = 0; i < 8; i++)
-            if (i < kn) isum += (int(ap[i]) - za) * (q[i] - zb);
-          acc[r] += float(isum) * (p.ascale[row * p.nblk + kb] * sb);
+        for (int j = 0; j < NJ; j++) {
+          const int k0 = s * p.kstep_len + 32 * j + 8 * cslot;
+          if (k0 >= p.k) continue;
+          const int e = (j * p.sps) / NJ;
+          // register-resident selects (a dynamically indexed local array would live in scratch memory)
+          auto pick = [&](int i) { return i == 0 ? cr.s[0] : (i == 1 ? cr.s[1] : (i == 2 ? cr.s[2] : cr.s[3])); };
+          float sb;
+          if (p.scale_dt == DT_F32) {
+            sb = __builtin_bit_cast(float, pick(e));
+          } else {
+            const uint32_t h = (pick(e >> 1) >> (16 * (e & 1))) & 0xffffu;
+            sb = p.scale_dt == DT_BF16 ? __builtin_bit_cast(float, h << 16) : f16_bits_to_f32(h);
+          }
+          const int zb = (p.asym ? int(int8_t((cr.z >> (8 * e)) & 0xffu)) : 0) + int(bias);
+          uint32_t u0, u1;
+          if (four) {
+            u0 = xw[j] & 0x0f0f0f0fu, u1 = (xw[j] >> 4) & 0x0f0f0f0fu;
+          } else {
+            u0 = xw[2 * j] ^ 0x80808080u, u1 = xw[2 * j + 1] ^ 0x80808080u;  // raw int8 -> q + 128
+          }
+          const int su = int(__builtin_amdgcn_udot4(u0, 0x01010101u, __builtin_amdgcn_udot4(u1, 0x01010101u, 0u, false), false));
+          const int kb = min(k0 / p.blocksize, p.nblk - 1);  // a 32-deep slice never straddles a k-block
+          const int loff = (s - c0) * p.kstep_len + 32 * j + 8 * cslot;
+#pragma unroll
+          for (int r = 0; r < kI8Rows; r++) {
+            if (r >= rows) break;
+            const uint2 av = *reinterpret_cast<const uint2*>(i8_smem + size_t(r) * chunk_k + loff);
+            const int za = az_lds[r * p.nblk + kb];
+            const int dot = int(__builtin_amdgcn_udot4(av.x, u0, __builtin_amdgcn_udot4(av.y, u1, 0u, false), false));
+            const int sa = int(__builtin_amdgcn_udot4(av.x, 0x01010101u, __builtin_amdgcn_udot4(av.y, 0x01010101u, 0u, false), false));
+            const int isum = dot - zb * sa - za * su + 8 * za * zb;
+            acc[r] += float(isum) * (as_lds[r * p.nblk + kb] * sb);
+          }
         }
+      };
+      // four records (codes + scale words) in flight per wave
+      auto load_rec = [&](int s) {
+        return *reinterpret_cast<const uint4v*>(p.codes + (size_t(tile) * p.ksteps + s) * p.qstride + l * 16);
+      };
+      for (int s = c0 + w; s < cend; s += 4 * kI8Waves) {
+        uint4v rec[4];
+        Corr cr[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int st = s + t * kI8Waves;
+          const bool on = st < cend;
+          rec[t] = on ? load_rec(st) : uint4v{0, 0, 0, 0};
+          cr[t] = on ? fetch_corr(st) : Corr{{0, 0, 0, 0}, 0};
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          if (s + t * kI8Waves < cend) consume(rec[t], cr[t], s + t * kI8Waves);
       }
     }
     // the four k-slots of a column live in lanes nn, nn+16, nn+32, nn+48; then the four waves through LDS
@@ -115,7 +218,9 @@ __global__ __launch_bounds__(256) void i8ref_kernel(const I8RefParams p) {
     if (tid < 16 * rows) {
       const int r = tid >> 4, col = tile * 16 + (tid & 15);
       if (col < p.n) {
-        float v = red[0][r][tid & 15] + red[1][r][tid & 15] + red[2][r][tid & 15] + red[3][r][tid & 15];
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < kI8Waves; ww++) v += red[ww][r][tid & 15];
         const size_t row = size_t(r0 + r);
         const float dv = p.d ? p.d[row * p.ldd + col] : 0.f;
         switch (p.epilogue) {
@@ -130,7 +235,6 @@ __global__ __launch_bounds__(256) void i8ref_kernel(const I8RefParams p) {
         if (p.c16) p.c16[row * p.ldc + col] = (_Float16)v;
       }
     }
-    __syncthreads();
   }
 }
 
@@ -141,8 +245,10 @@ bool i8ref_supported(const ns_weight* w) {
 }
 
 // C[m][n] = epi(dequant-free int8-compute product of quantize_u8(A) and the integer weight `w`)
+// reuse_aq: the stream's scratch already holds quantize_u8(A) for this (A, m, k, blocksize) from the previous call — the
+// fused QKV / gate-up entries quantize A once for all their weights, as the reference does (ip_fusion_qkv.cpp:84-86)
 hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, void* c16, int m, int ldc, int epilogue,
-                        const float* d, int ldd, hipStream_t st) {
+                        const float* d, int ldd, hipStream_t st, bool reuse_aq) {
   if (!i8ref_supported(w)) return hipErrorNotSupported;
   const int bs = w->blocksize >= w->k ? w->k : w->blocksize;
   const int nblk = (w->k + bs - 1) / bs;
@@ -154,8 +260,10 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   uint8_t* aq = base;
   float* as = reinterpret_cast<float*>(base + aq_bytes);
   uint8_t* az = base + aq_bytes + sc_bytes;
-  hipError_t e = launch_aquant_u8(m, w->k, a, lda, aq, w->k, as, nblk, az, bs, nullptr, st);
-  if (e != hipSuccess) return e;
+  if (!reuse_aq) {
+    const hipError_t e = launch_aquant_u8(m, w->k, a, lda, aq, w->k, as, nblk, az, bs, nullptr, st);
+    if (e != hipSuccess) return e;
+  }
   I8RefParams p{};
   p.codes = reinterpret_cast<const uint8_t*>(w->codes);
   p.scales = static_cast<const uint8_t*>(w->scales);
@@ -181,7 +289,20 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   p.epilogue = epilogue;
   p.d = d;
   p.ldd = ldd;
-  hipLaunchKernelGGL(i8ref_kernel, dim3(w->ntiles), dim3(256), 0, st, p);
+  // LDS (<= 60 KiB): the row group's activation scales / zero points, then up to four rows of u8 codes per chunk
+  const size_t corr_bytes = size_t(kI8Rows) * nblk * 8;
+  if (corr_bytes > 40 * 1024) return hipErrorNotSupported;
+  const size_t code_budget = 60 * 1024 - corr_bytes;
+  int chunk_steps = w->ksteps;
+  while ((size_t((chunk_steps + kI8Waves - 1) / kI8Waves * kI8Waves) * w->kstep_len * kI8Rows > code_budget) && chunk_steps > kI8Waves)
+    chunk_steps = (chunk_steps + 1) / 2;
+  chunk_steps = (chunk_steps + kI8Waves - 1) / kI8Waves * kI8Waves;  // whole rounds of the waves
+  p.chunk_steps = chunk_steps;
+  const size_t lds = size_t(chunk_steps) * w->kstep_len * kI8Rows + corr_bytes;
+  if (p.nj == 4)
+    hipLaunchKernelGGL(i8ref_kernel<true>, dim3(w->ntiles), dim3(kI8Threads), lds, st, p);
+  else
+    hipLaunchKernelGGL(i8ref_kernel<false>, dim3(w->ntiles), dim3(kI8Threads), lds, st, p);
   return hipGetLastError();
 }
 

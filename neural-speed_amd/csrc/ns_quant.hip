@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdlib>
 
 #include "ns_common.h"
 
@@ -543,13 +544,71 @@ __global__ void aquant_u8_kernel(int row, int col, const float* __restrict__ src
   }
   if (blkreduce) blkreduce[size_t(i) * ld_scale + kb] = __fmul_rn(float(sum), scale);
 }
+// The same arithmetic with LPB lanes per (row, k-block): lane e takes elements e, e + LPB, ... (coalesced), the block's
+// max / min and the integer code sum are combined by xor-shuffles.  All three are order-independent (max / min never
+// select a NaN, the sum wraps in two's complement), every element is quantized by exactly the operations of the
+// one-thread form above, so the results are bit-identical; only the latency of a decode-sized call changes (one
+// thread walking 32 dependent loads -> 4).
+template <int LPB>
+__global__ void aquant_u8_coop_kernel(int row, int col, const float* __restrict__ src, int ld_src, uint8_t* __restrict__ dst,
+                                      int ld_dst, float* __restrict__ scales, int ld_scale, uint8_t* __restrict__ zps,
+                                      int blocksize, float* __restrict__ blkreduce) {
+  const int nblk = (col + blocksize - 1) / blocksize;
+  const size_t gid = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) / LPB;
+  const int e = threadIdx.x % LPB;
+  const bool live = gid < size_t(row) * nblk;  // whole lane groups are live or dead together (blockDim % LPB == 0)
+  const int i = live ? int(gid / nblk) : 0, kb = live ? int(gid % nblk) : 0;
+  const int j = kb * blocksize;
+  const bool tail = j + blocksize > col;
+  const int bs = live ? (tail ? col - j : blocksize) : 0;
+  const float* s = src + size_t(i) * ld_src + j;
+  float maxval = tail ? 0.f : FLT_MIN, minval = 0.f;
+  for (int ij = e; ij < bs; ij += LPB) {
+    const float f = s[ij];
+    maxval = f > maxval ? f : maxval;
+    minval = f < minval ? f : minval;
+  }
+#pragma unroll
+  for (int d = 1; d < LPB; d <<= 1) {
+    const float om = __shfl_xor(maxval, d), on = __shfl_xor(minval, d);
+    maxval = om > maxval ? om : maxval;
+    minval = on < minval ? on : minval;
+  }
+  const float scale = __fdiv_rn(__fsub_rn(maxval, minval), 255.f);
+  const int zp = cast_f32_u8_x86(__fdiv_rn(__fsub_rn(0.f, minval), scale));
+  const float rscale = __fdiv_rn(1.f, scale);
+  int sum = 0;
+  const float zpf = float(zp);
+  uint8_t* d = dst + size_t(i) * ld_dst + j;
+  for (int ij = e; ij < bs; ij += LPB) {
+    const int qtmp = cvt_round_int_x86(__fmul_rn(s[ij], rscale));
+    sum = wrap_add(sum, qtmp);
+    d[ij] = uint8_t(cast_f32_u8_x86(__fadd_rn(zpf, float(qtmp))));
+  }
+#pragma unroll
+  for (int dd = 1; dd < LPB; dd <<= 1) sum = wrap_add(sum, __shfl_xor(sum, dd));
+  if (live && e == 0) {
+    scales[size_t(i) * ld_scale + kb] = scale;
+    zps[size_t(i) * ld_scale + kb] = uint8_t(zp);
+    if (blkreduce) blkreduce[size_t(i) * ld_scale + kb] = __fmul_rn(float(sum), scale);
+  }
+}
 hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
                             int ld_scale, uint8_t* zps, int blocksize, float* blkreduce, hipStream_t st) {
   const int nblk = (col + blocksize - 1) / blocksize;
   const size_t total = size_t(row) * nblk;
   if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(aquant_u8_kernel, grid1d(total, 128), dim3(128), 0, st, row, col, src, ld_src, dst, ld_dst, scales,
-                     ld_scale, zps, blocksize, blkreduce);
+  static const bool one_thread = getenv("NS_AQUANT_SERIAL") != nullptr;  // diagnostics: the one-thread-per-block form
+  if (one_thread) {
+    hipLaunchKernelGGL(aquant_u8_kernel, grid1d(total, 128), dim3(128), 0, st, row, col, src, ld_src, dst, ld_dst, scales,
+                       ld_scale, zps, blocksize, blkreduce);
+  } else if (blocksize >= 512) {  // per-channel / very wide groups: a whole wave per block
+    hipLaunchKernelGGL(aquant_u8_coop_kernel<64>, grid1d(total * 64, 256), dim3(256), 0, st, row, col, src, ld_src, dst,
+                       ld_dst, scales, ld_scale, zps, blocksize, blkreduce);
+  } else {
+    hipLaunchKernelGGL(aquant_u8_coop_kernel<8>, grid1d(total * 8, 256), dim3(256), 0, st, row, col, src, ld_src, dst,
+                       ld_dst, scales, ld_scale, zps, blocksize, blkreduce);
+  }
   return hipGetLastError();
 }
 
