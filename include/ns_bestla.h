@@ -338,6 +338,24 @@ bool bestla_reordered_attn_fp32_support(const attn_shape_t* params);
 int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* dparams, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Part 4b — mixture-of-experts matmul with the routing on the device.  Device twin of
+ * ne_compute_forward_mul_mat_id_q_f32_bestla (/root/reference/neural_speed/core/ne_layers.c:7783-7916), which reads the
+ * expert ids on the HOST and calls bestla_f32f32_forward once per (token, expert) — that path keeps working through the
+ * part-1 surface.  Here the ids stay on the device (they are the router's top-k output), so a decode step with experts
+ * can be captured in one HIP graph:
+ *     dC[t][:] = epi( dA[t][:] . W[ dIds[t * ids_stride + id] ],  dD[t][:] )        t = 0 .. m-1
+ * An expert group is n_as weights of identical shape and format (S1..S8, NF4 / FP4); an id outside [0, n_as) — the
+ * reference asserts — produces a zero product for that row.  fp16-activation numerics like every default forward.
+ * The `ffn_id_*` nodes (ne_layers.c:8053-8170) are three such calls (gate with NS_EPI_SILU, up with NS_EPI_MUL and
+ * dD = gate output, down).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ns_expert_group ns_expert_group;
+ns_expert_group* ns_hip_expert_group_create(const ns_weight* const* experts, int n_as);
+void ns_hip_expert_group_free(ns_expert_group* g);
+int ns_hip_mul_mat_id(const float* dA, const int32_t* dIds, int ids_stride, int id, const ns_expert_group* g, float* dC,
+                      int m, int lda, int ldc, int epilogue, const float* dD, int ldd, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Part 5 — tensor-parallel all-reduce over peer-mapped HBM.  The decode-sized fast path of
  * `reduce_add` (/root/reference/neural_speed/core/parallel_context.cpp:47-58): the reference hands small buffers to
  * `shm_all_reduce` (/root/reference/neural_speed/core/shared_memory_ccl.hpp:100-139 — copy into a shared segment,

@@ -110,6 +110,11 @@ def lib():
         L.ns_hip_weight_stream_bytes.restype = C.c_uint64
         L.ns_hip_weight_stream_bytes.argtypes = [vp]
         L.ns_hip_weight_prefetch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, vp]
+        L.ns_hip_expert_group_create.restype = vp
+        L.ns_hip_expert_group_create.argtypes = [vp, i]
+        L.ns_hip_expert_group_free.restype = None
+        L.ns_hip_expert_group_free.argtypes = [vp]
+        L.ns_hip_mul_mat_id.argtypes = [vp, vp, i, i, vp, vp, i, i, i, i, vp, i, vp]
         L.ns_hip_p2p_create.restype = vp
         L.ns_hip_p2p_create.argtypes = [i, i, sz, vp]
         L.ns_hip_p2p_connect.argtypes = [vp, vp]

@@ -1,0 +1,287 @@
+// ns_moe.hip — expert-indexed matmul with the routing ON THE DEVICE
+//
+// Reference: ne_compute_forward_mul_mat_id_q_f32_bestla (/root/reference/neural_speed/core/ne_layers.c:7783-7916): for
+// every token row t of src1, `row_id = ids[t][id]` selects one of `n_as` expert blobs and
+//       dst[t] = src1[t] . W[row_id]
+// is computed by one `bestla_f32f32_forward(row, expert blob, dst row, 1, ...)` call per (token, expert) after the HOST
+// has read the ids and grouped the rows (`matrix_rows`, :7855-7866).  That host round trip is what a device-resident,
+// graph-captured decode step cannot afford (the ids are the output of the router's top-k on the device), so here the
+// kernel itself reads the id: grid = (column tiles, token rows), each workgroup looks up its row's expert in a device
+// table of weight descriptors and streams that expert's tile.  The host-pointer surface keeps working unchanged through
+// bestla_f32f32_forward; this entry is its device twin.
+//
+// Numerics: the default semantics of this library — fp16-rounded activations, w = (code - zp) * scale (or LUT[code] *
+// scale for the 4-bit float types), fp32 accumulation — evaluated with VALU FMAs: a token row is an M = 1 product, the
+// matrix cores have nothing to add and the kernel is bound by the expert's weight stream.  First version: plain
+// streaming loop with four records in flight per wave, not tuned like smallm_kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ns_bestla.h"
+#include "ns_common.h"
+#include "ns_dev.h"
+
+namespace ns {
+namespace {
+
+constexpr int kMoeWaves = 8, kMoeThreads = kMoeWaves * 64;
+
+struct MoeExpert {  // one row of the device table
+  const uint8_t* codes;
+  const uint8_t* scales;
+  const int8_t* zps;
+};
+
+struct MoeParams {
+  const MoeExpert* table;
+  int n_as;
+  const int32_t* ids;
+  int ids_stride, id;
+  uint32_t qstride, sstride, zstride;
+  int ksteps, kstep_len, kind;
+  int sps, srows, srow_mul, srow_shift;
+  uint32_t scale_dt;
+  int asym;
+  int n, k, m;
+  const float* a;
+  int lda;
+  float* c;
+  int ldc;
+  int epilogue;
+  const float* d;
+  int ldd;
+  float lut[16];  // 4-bit float types: code -> value
+};
+
+template <int KIND>  // WK_INT4, WK_INT8 or WK_F4
+__global__ __launch_bounds__(kMoeThreads) void moe_gemv_kernel(const MoeParams p) {
+  constexpr int NJ = KIND == WK_INT8 ? 2 : 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char moe_smem[];
+  __shared__ float red[kMoeWaves][16];
+  __shared__ float lut_s[16];
+  _Float16* a_lds = reinterpret_cast<_Float16*>(moe_smem);  // the token row, rounded to fp16 like every default kernel
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nn = l & 15, cslot = l >> 4;
+  const int tile = blockIdx.x, row = blockIdx.y;
+  const int32_t e_id = p.ids[size_t(row) * p.ids_stride + p.id];
+  const bool valid = e_id >= 0 && e_id < p.n_as;  // the reference asserts this (:7860); here the row is zeroed
+  const MoeExpert ex = p.table[valid ? e_id : 0];
+  const int kpad = p.ksteps * p.kstep_len;
+  for (int i = tid; i < kpad; i += kMoeThreads) a_lds[i] = i < p.k ? (_Float16)p.a[size_t(row) * p.lda + i] : (_Float16)0.f;
+  if (KIND == WK_F4 && tid < 16) lut_s[tid] = p.lut[tid];
+  __syncthreads();
+  const int sbytes = p.scale_dt == DT_F32 ? 4 : 2;
+  const int rec_sbytes = p.sps * sbytes;
+  struct Corr {
+    uint32_t s[4];
+    uint32_t z;
+  };
+  auto fetch_corr = [&](int s) {
+    Corr c{{0, 0, 0, 0}, 0};
+    const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
+    const size_t crow = size_t(tile) * p.srows + srow;
+    const uint8_t* sp = ex.scales + crow * p.sstride + size_t(nn) * rec_sbytes;
+    if (rec_sbytes == 16) {
+      const uint4v v = *reinterpret_cast<const uint4v*>(sp);
+      c.s[0] = v.x, c.s[1] = v.y, c.s[2] = v.z, c.s[3] = v.w;
+    } else if (rec_sbytes == 8) {
+      const uint2 v = *reinterpret_cast<const uint2*>(sp);
+      c.s[0] = v.x, c.s[1] = v.y;
+    } else if (rec_sbytes == 4) {
+      c.s[0] = *reinterpret_cast<const uint32_t*>(sp);
+    } else {
+      c.s[0] = *reinterpret_cast<const uint16_t*>(sp);
+    }
+    if (p.asym) {
+      const int8_t* zp = ex.zps + crow * p.zstride + nn * p.sps;
+      for (int e = 0; e < p.sps; e++) c.z |= uint32_t(uint8_t(zp[e])) << (8 * e);
+    }
+    return c;
+  };
+  float acc = 0.f;
+  auto consume = [&](const uint4v& rec, const Corr& cr, int s) {
+    const uint32_t xw[4] = {rec.x, rec.y, rec.z, rec.w};
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int e = (j * p.sps) / NJ;
+      auto pick = [&](int i) { return i == 0 ? cr.s[0] : (i == 1 ? cr.s[1] : (i == 2 ? cr.s[2] : cr.s[3])); };
+      float sb;
+      if (p.scale_dt == DT_F32) {
+        sb = __builtin_bit_cast(float, pick(e));
+      } else {
+        const uint32_t h = (pick(e >> 1) >> (16 * (e & 1))) & 0xffffu;
+        sb = p.scale_dt == DT_BF16 ? __builtin_bit_cast(float, h << 16) : f16_bits_to_f32(h);
+      }
+      const float zb = p.asym ? float(int(int8_t((cr.z >> (8 * e)) & 0xffu))) : 0.f;
+      const half8_t av = *reinterpret_cast<const half8_t*>(a_lds + s * p.kstep_len + 32 * j + 8 * cslot);
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        float wv;
+        if constexpr (KIND == WK_INT8) {
+          const uint32_t word = i < 4 ? xw[2 * j] : xw[2 * j + 1];
+          wv = float(int(int8_t((word >> (8 * (i & 3))) & 255u))) - zb;
+        } else {
+          const uint32_t code = (xw[j] >> (((i & 1) << 4) + ((i >> 1) << 2))) & 15u;  // nibble i at bit {0,16,4,20,...}
+          if constexpr (KIND == WK_F4)
+            wv = lut_s[code];
+          else
+            wv = float(int(code) - 8) - zb;
+        }
+        dot = fmaf(float(av[i]), wv, dot);
+      }
+      acc = fmaf(dot, sb, acc);
+    }
+  };
+  auto load_rec = [&](int s) {
+    return *reinterpret_cast<const uint4v*>(ex.codes + (size_t(tile) * p.ksteps + s) * p.qstride + l * 16);
+  };
+  if (valid) {
+    for (int s = w; s < p.ksteps; s += 4 * kMoeWaves) {
+      uint4v rec[4];
+      Corr cr[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int st = s + t * kMoeWaves;
+        const bool on = st < p.ksteps;
+        rec[t] = on ? load_rec(st) : uint4v{0, 0, 0, 0};
+        cr[t] = on ? fetch_corr(st) : Corr{{0, 0, 0, 0}, 0};
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        if (s + t * kMoeWaves < p.ksteps) consume(rec[t], cr[t], s + t * kMoeWaves);
+    }
+  }
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  if (l < 16) red[w][l] = acc;
+  __syncthreads();
+  if (tid < 16) {
+    const int col = tile * 16 + tid;
+    if (col < p.n) {
+      float v = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < kMoeWaves; ww++) v += red[ww][tid];
+      const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
+      switch (p.epilogue) {
+        case 1: v = v + dv; break;
+        case 2: v = v * dv; break;
+        case 3: v = epi_gelu(v + dv); break;
+        case 4: v = epi_gelu(v); break;
+        case 5: v = epi_silu(v); break;
+        default: break;
+      }
+      p.c[size_t(row) * p.ldc + col] = v;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace ns
+
+struct ns_expert_group {
+  std::vector<const ns_weight*> experts;
+  ns::MoeExpert* table = nullptr;  // device
+};
+
+using namespace ns;
+
+extern "C" {
+
+ns_expert_group* ns_hip_expert_group_create(const ns_weight* const* experts, int n_as) {
+  if (!experts || n_as <= 0 || n_as > 4096) {
+    set_error("expert group: need 1..4096 experts");
+    return nullptr;
+  }
+  const ns_weight* w0 = experts[0];
+  std::vector<MoeExpert> host(n_as);
+  for (int i = 0; i < n_as; i++) {
+    const ns_weight* w = experts[i];
+    if (!w || !w0) {
+      set_error("expert group: null weight");
+      return nullptr;
+    }
+    // one kernel launch serves every expert: shapes and formats must agree (they do in every MoE checkpoint)
+    if (w->n != w0->n || w->k != w0->k || w->kind != w0->kind || w->qtype != w0->qtype || w->blocksize != w0->blocksize ||
+        w->scale_dt != w0->scale_dt || w->asym != w0->asym || w->qstride != w0->qstride || w->sstride != w0->sstride ||
+        w->zstride != w0->zstride || w->shuf || w->device != w0->device) {
+      set_error("expert group: experts differ in shape / format (or carry an activation shuffle)");
+      return nullptr;
+    }
+    host[i] = {reinterpret_cast<const uint8_t*>(w->codes), static_cast<const uint8_t*>(w->scales), w->zps};
+  }
+  if (w0->kind != WK_INT4 && w0->kind != WK_INT8 && w0->kind != WK_F4) {
+    set_error("expert group: S1..S8 and the 4-bit float types are supported (fp8 experts are not)");
+    return nullptr;
+  }
+  ns_expert_group* g = new ns_expert_group;
+  g->experts.assign(experts, experts + n_as);
+  if (hipMalloc((void**)&g->table, sizeof(MoeExpert) * n_as) != hipSuccess ||
+      hipMemcpy(g->table, host.data(), sizeof(MoeExpert) * n_as, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("expert group: device table allocation failed");
+    if (g->table) (void)hipFree(g->table);
+    delete g;
+    return nullptr;
+  }
+  return g;
+}
+
+void ns_hip_expert_group_free(ns_expert_group* g) {
+  if (!g) return;
+  if (g->table) (void)hipFree(g->table);
+  delete g;
+}
+
+int ns_hip_mul_mat_id(const float* dA, const int32_t* dIds, int ids_stride, int id, const ns_expert_group* g, float* dC,
+                      int m, int lda, int ldc, int epilogue, const float* dD, int ldd, void* stream) {
+  if (!g || !dA || !dIds || !dC || m <= 0 || id < 0 || id >= ids_stride) {
+    set_error("mul_mat_id: bad argument");
+    return -1;
+  }
+  if (m > 65535) {
+    set_error("mul_mat_id: at most 65535 token rows per call");
+    return -1;
+  }
+  const ns_weight* w = g->experts[0];
+  MoeParams p{};
+  p.table = g->table;
+  p.n_as = int(g->experts.size());
+  p.ids = dIds, p.ids_stride = ids_stride, p.id = id;
+  p.qstride = w->qstride, p.sstride = w->sstride, p.zstride = w->zstride;
+  p.ksteps = w->ksteps, p.kstep_len = w->kstep_len, p.kind = w->kind;
+  p.sps = w->sps, p.srows = w->srows;
+  if (!srow_params(w, &p.srow_mul, &p.srow_shift)) {
+    set_error("mul_mat_id: group size not expressible for this weight");
+    return -1;
+  }
+  p.scale_dt = w->scale_dt;
+  p.asym = w->asym ? 1 : 0;
+  p.n = w->n, p.k = w->k, p.m = m;
+  p.a = dA, p.lda = lda, p.c = dC, p.ldc = ldc;
+  p.epilogue = epilogue, p.d = dD, p.ldd = ldd;
+  for (int i = 0; i < 16; i++) p.lut[i] = w->lutf[i];
+  const size_t lds = size_t(w->ksteps) * w->kstep_len * 2;
+  if (lds > 60 * 1024) {
+    set_error("mul_mat_id: K beyond 30720 is not supported by this first version");
+    return -1;
+  }
+  const dim3 grid(w->ntiles, m), block(kMoeThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (w->kind == WK_INT8)
+    hipLaunchKernelGGL(moe_gemv_kernel<WK_INT8>, grid, block, lds, st, p);
+  else if (w->kind == WK_F4)
+    hipLaunchKernelGGL(moe_gemv_kernel<WK_F4>, grid, block, lds, st, p);
+  else
+    hipLaunchKernelGGL(moe_gemv_kernel<WK_INT4>, grid, block, lds, st, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(std::string("mul_mat_id launch: ") + hipGetErrorString(e));
+    return -1;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+"""Expert-indexed matmul with device-side routing (csrc/ns_moe.hip) against the reference semantics of
+ne_compute_forward_mul_mat_id_q_f32_bestla (ne_layers.c:7783-7916): dst[t] = src1[t] . W[ids[t][id]], one
+bestla_f32f32_forward per (token, expert) — restated with the oracle's fp64 product per row."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FORMATS = [  # qtype, scale dtype, asym, group, core
+    ("S4", "BF16", False, 32, "CORE_AVX512_VNNI_KB"),
+    ("S4", "F32", True, 128, "CORE_AVX512F"),
+    ("S8", "BF16", False, 32, "CORE_AVX512_VNNI_KB"),
+    ("F4_NF4", "BF16", False, 64, "CORE_AVX512F"),
+]
+
+
+def _group(L, pkg, nso, rng, n_as, n, k, qt, st, asym, bs, core):
+    blobs, weights = [], []
+    for _ in range(n_as):
+        w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+        blobs.append(nso.quant_pack(w, bs, getattr(nso, qt), getattr(nso, st), asym, getattr(nso, core)))
+        weights.append(pkg.Weight.from_host_blob(nso.ptr(blobs[-1])))
+    arr = (C.c_void_p * n_as)(*[w.h for w in weights])
+    g = L.ns_hip_expert_group_create(arr, n_as)
+    assert g, pkg.last_error()
+    return blobs, weights, g
+
+
+@pytest.mark.parametrize("qt,st,asym,bs,core", FORMATS)
+def test_mul_mat_id_matches_per_token_forwards(L, pkg, nso, qt, st, asym, bs, core):
+    import torch
+    rng = np.random.default_rng(len(qt) * 13 + bs)
+    n_as, n, k, m, topk = 4, 200, 832, 7, 2   # ragged N, K not a multiple of the 128-deep k-step
+    blobs, weights, g = _group(L, pkg, nso, rng, n_as, n, k, qt, st, asym, bs, core)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    ids = rng.integers(0, n_as, size=(m, topk)).astype(np.int32)
+    dA, dI = torch.from_numpy(a).cuda(), torch.from_numpy(ids).cuda()
+    st_ = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for sel in range(topk):
+        dC = torch.full((m, n), 7.0, device="cuda")
+        pkg.check(L.ns_hip_mul_mat_id(dA.data_ptr(), dI.data_ptr(), topk, sel, g, dC.data_ptr(), m, k, n, pkg.EPI_NONE,
+                                      None, 0, st_))
+        torch.cuda.synchronize()
+        out = dC.cpu().numpy()
+        ref = np.concatenate([nso.gemm_f64(a[t:t + 1], blobs[ids[t, sel]]) for t in range(m)], axis=0)
+        assert nso.rel_l2(out, ref) < 1e-3
+        ref16 = np.concatenate([nso.gemm_f64(a[t:t + 1], blobs[ids[t, sel]], a16=True) for t in range(m)], axis=0)
+        assert nso.rel_l2(out, ref16) < 5e-5   # same fp16-rounded activations: only fp32 summation order differs
+    L.ns_hip_expert_group_free(g)
+
+
+def test_ffn_id_composition_in_a_graph_and_bad_ids(L, pkg, nso):
+    """gate (SiLU) -> up (Mul) -> down through three mul_mat_id calls captured in ONE graph with the ids on the device
+    (ffn_id_silu, ne_layers.c:8053-8170); an out-of-range id zeroes its row instead of asserting."""
+    import torch
+    rng = np.random.default_rng(3)
+    n_as, d, ff, m = 3, 256, 512, 4
+    bg, wg, gg = _group(L, pkg, nso, rng, n_as, ff, d, "S4", "BF16", False, 32, "CORE_AVX512_VNNI_KB")
+    bu, wu, gu = _group(L, pkg, nso, rng, n_as, ff, d, "S4", "BF16", False, 32, "CORE_AVX512_VNNI_KB")
+    bd, wd, gd = _group(L, pkg, nso, rng, n_as, d, ff, "S4", "BF16", False, 32, "CORE_AVX512_VNNI_KB")
+    a = rng.standard_normal((m, d)).astype(np.float32)
+    ids = np.array([[0], [2], [1], [2]], np.int32)
+    dA, dI = torch.from_numpy(a).cuda(), torch.from_numpy(ids).cuda()
+    t1 = torch.zeros((m, ff), device="cuda")
+    t2 = torch.zeros((m, ff), device="cuda")
+    out = torch.zeros((m, d), device="cuda")
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        pkg.check(L.ns_hip_mul_mat_id(dA.data_ptr(), dI.data_ptr(), 1, 0, gg, t1.data_ptr(), m, d, ff, pkg.EPI_SILU, None, 0, s))
+        pkg.check(L.ns_hip_mul_mat_id(dA.data_ptr(), dI.data_ptr(), 1, 0, gu, t2.data_ptr(), m, d, ff, pkg.EPI_MUL, t1.data_ptr(), ff, s))
+        pkg.check(L.ns_hip_mul_mat_id(t2.data_ptr(), dI.data_ptr(), 1, 0, gd, out.data_ptr(), m, ff, d, pkg.EPI_NONE, None, 0, s))
+
+    def expect(idv):
+        rows = []
+        for t in range(m):
+            e = int(idv[t, 0])
+            gate = nso.gemm_f64(a[t:t + 1], bg[e])
+            up = nso.gemm_f64(a[t:t + 1], bu[e])
+            h = (gate / (1 + np.exp(-gate)) * up).astype(np.float32)
+            rows.append(nso.gemm_f64(h, bd[e]))
+        return np.concatenate(rows, axis=0)
+
+    gr.replay()
+    torch.cuda.synchronize()
+    assert nso.rel_l2(out.cpu().numpy(), expect(ids)) < 2e-3
+    # new routing decision, same graph: only device memory changed
+    ids2 = np.array([[1], [1], [0], [2]], np.int32)
+    dI.copy_(torch.from_numpy(ids2))
+    gr.replay()
+    torch.cuda.synchronize()
+    assert nso.rel_l2(out.cpu().numpy(), expect(ids2)) < 2e-3
+    # out-of-range id: that row of the product is zero
+    bad = torch.tensor([[0], [9], [-1], [1]], dtype=torch.int32, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pkg.check(L.ns_hip_mul_mat_id(dA.data_ptr(), bad.data_ptr(), 1, 0, gg, t1.data_ptr(), m, d, ff, pkg.EPI_NONE, None, 0, s))
+    torch.cuda.synchronize()
+    r = t1.cpu().numpy()
+    assert np.all(r[1] == 0) and np.all(r[2] == 0) and np.any(r[0] != 0) and np.any(r[3] != 0)
+    # experts of different shapes do not form a group
+    arr = (C.c_void_p * 2)(wg[0].h, wd[0].h)
+    assert not L.ns_hip_expert_group_create(arr, 2)
+    L.ns_hip_reset_error()
+    for g in (gg, gu, gd):
+        L.ns_hip_expert_group_free(g)
