@@ -19,7 +19,7 @@ for l in sys.stdin:
 done
 fi
 # peer-memory all-reduce latency with the ranks sharing this GPU (flags + fences + payload; no xGMI hop)
-for ws in 2 8; do
+for ws in 2 4; do
   NS_P2P_LATENCY=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node $ws \
     --master-addr 127.0.0.1 --master-port $((29600+ws)) tests/p2p_worker.py 2>gpurun_out/p2p_err_$ws.log | grep -E "P2P_" | tee -a gpurun_out/p2p_latency_$TAG.txt
 done
@@ -38,5 +38,6 @@ echo "BENCH exit $? after $(( $(date +%s) - T0 )) s"; cut -c1-400 gpurun_out/ben
 rm -rf gpurun_out/prof_$TAG
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof_${TAG}_bench.json 2>/dev/null
 echo "ROCPROF exit $? after $(( $(date +%s) - T0 )) s"
+timeout 120 python __graft_entry__.py smoke 2>&1 | tail -1
 python scripts/trace_summary.py gpurun_out/prof_$TAG/${TAG}_kernel_trace.csv smallm 2>&1 | tail -12
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete   # keep the merge under the 64 MiB cap
