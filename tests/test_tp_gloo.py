@@ -59,6 +59,15 @@ WORKER = textwrap.dedent('''
     yr = torch.from_numpy(nso.gemm_f64(h_loc.astype(np.float32), sh2r).astype(np.float32))
     par.reduce_add(yr)
     assert nso.rel_l2(yr.numpy(), y_full) < 5e-2
+    # the peer-memory all-reduce cannot be set up without a GPU: every rank must notice, fall back TOGETHER, and
+    # reduce_add must keep working through the process group (the same agreement path a failed IPC open takes)
+    if not torch.cuda.is_available():
+        assert ctx.enable_p2p(1 << 16) is False and not ctx.p2p_enabled()
+        assert ctx.p2p_error() is False
+        z = torch.full((8,), float(rk + 1))
+        par.reduce_add(z)
+        assert z.tolist() == [3.0] * 8
+        ctx.disable_p2p()   # no-op
     par.barrier()
     # one result file per rank: the two ranks' stdout lines can interleave
     open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank" + str(rk) + ".ok"), "w").write(repr(float(err)))
