@@ -95,3 +95,18 @@ def test_no_device_fails_loudly(L, pkg, nso):
     L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), 1, 16, 128, 128, 16, None)  # prints Err, as the reference
     assert np.all(out == 7.0)  # output untouched: nothing computed on the CPU
     assert not L.bestla_fusion_QKV_f32f32_support(nso.ptr(blob), nso.ptr(blob), nso.ptr(blob), 1, 16, 128)
+
+
+def test_header_is_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/ns_bestla.h must compile as C99 on its own (no C++, no HIP, no torch
+    types in any signature) — what a cgo / JNI / ctypes binding generator would consume"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "h.c"
+    src.write_text('#include "ns_bestla.h"\nint main(void) { return (int)sizeof(attn_shape_t) * 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
