@@ -252,6 +252,13 @@ int ns_hip_rope_f32_longrope(const float* dSrc, float* dDst, int batch, int seq,
                              int n_dims, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
                              float attn_factor, float beta_fast, float beta_slow, const float* dFactors,
                              float scale_factor, void* stream);
+/* GLM branch of the same operator (mode & 4, /root/reference/neural_speed/core/ne_layers.c:9317-9347; ChatGLM's
+ * two-dimensional position encoding): the first half of every head is rotated by min(max(p - n_padding, 0),
+ * prompt_size - 2 - n_padding), the second half by max(p - (prompt_size - 2), 0).  mode 4, or 5 (= 4 | skip: positions
+ * < n_past are left untouched and p = the row's index).  n_padding: HOST array [batch] (src1[ROPE_PARAMS_NUM + i],
+ * :9319), batch <= 32.  The "shift" form (n_keep >= 0) is asserted against by the reference itself (:9312). */
+int ns_hip_rope_f32_glm(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                        int mode, float freq_base, int prompt_size, const int* n_padding, void* stream);
 int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector, int vstep, float* dOut, void* stream);
 
 /* RoPE of Q (in place, [seq][heads][head_size]) and of K ([seq][heads_kv][head_size]) fused with the kv-cache append:

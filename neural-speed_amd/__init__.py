@@ -110,6 +110,7 @@ def lib():
         L.ns_hip_weight_stream_bytes.restype = C.c_uint64
         L.ns_hip_weight_stream_bytes.argtypes = [vp]
         L.ns_hip_weight_prefetch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, vp]
+        L.ns_hip_rope_f32_glm.argtypes = [vp, vp, i, i, i, i, i, i, i, f, i, vp, vp]
         L.ns_hip_expert_group_create.restype = vp
         L.ns_hip_expert_group_create.argtypes = [vp, i]
         L.ns_hip_expert_group_free.restype = None

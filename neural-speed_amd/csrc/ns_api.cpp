@@ -1361,11 +1361,27 @@ int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int head
     return -1;
   }
   if ((mode & ~2) != 0 || ext_factor != 0.f) {
-    set_error("rope: only modes 0 and 2 (NeoX) without YaRN extrapolation are implemented (no GLM / long-rope / shift)");
+    set_error("rope: this entry takes modes 0 and 2 (NeoX) without YaRN extrapolation (GLM: ns_hip_rope_f32_glm, YaRN / long-rope: their own entries; shift is asserted against by the reference itself)");
     return -1;
   }
   return hip_ok(launch_rope(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, mode, freq_base, freq_scale, attn_factor,
                             (hipStream_t)stream), "rope launch") ? 0 : -1;
+}
+// GLM branch (mode & 4) of ne_compute_forward_rope_f32, ne_layers.c:9317-9347
+int ns_hip_rope_f32_glm(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                        int mode, float freq_base, int prompt_size, const int* n_padding, void* stream) {
+  if (!have_device()) return -1;
+  if (!dSrc || !dDst || !n_padding || batch < 0 || batch > 32 || seq < 0 || heads < 0 || head_size <= 0 || (head_size & 3) ||
+      n_dims <= 0 || (n_dims & 1) || n_past < 0 || n_dims / 2 * 3 + head_size / 4 > head_size) {
+    set_error("rope (GLM): invalid argument (head_size % 4 == 0, 3 n_dims / 2 + head_size / 4 <= head_size, batch <= 32)");
+    return -1;
+  }
+  if (!(mode & 4) || (mode & ~5) != 0) {
+    set_error("rope (GLM): mode must be 4 (or 5 = 4 | skip)");
+    return -1;
+  }
+  return hip_ok(launch_rope_glm(dSrc, dDst, batch, seq, heads, head_size, n_past, n_dims, (mode & 1) != 0, freq_base,
+                                prompt_size, n_padding, (hipStream_t)stream), "rope (GLM) launch") ? 0 : -1;
 }
 // ne_compute_forward_rope_f32 with the YaRN extrapolation mix (ext_factor != 0): corr_dims from
 // ggml_rope_yarn_corr_dims (ne_layers.c:9219-9231) and the magnitude correction of rope_yarn (:9210) are evaluated here

@@ -207,6 +207,8 @@ hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int hea
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st,
                        float ext_factor = 0.f, float corr0 = 0.f, float corr1 = 0.f, const float* lr_factor = nullptr,
                        float lr_scale = 1.f);
+hipError_t launch_rope_glm(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                           bool skip, float freq_base, int prompt_size, const int* n_padding, hipStream_t st);
 hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void* kc, void* vc, int seq, int heads,
                                   int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base,
                                   float freq_scale, float attn_factor, long long c_sl, long long c_head, hipStream_t st);

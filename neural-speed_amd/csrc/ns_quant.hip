@@ -754,6 +754,59 @@ hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int hea
   return hipGetLastError();
 }
 
+// GLM branch of ne_compute_forward_rope_f32 (mode & 4, ne_layers.c:9317-9347): ChatGLM's two-dimensional positions.
+// One thread per (row, i0 < head_size / 4): the clamped token position rotates (x[i0], x[i0 + n_dims/2]), the block
+// position rotates (x[i0 + n_dims], x[i0 + 3 n_dims / 2]); both angles are the reference's sequential fp32 products
+// angle * theta_scale^i0.  Rows the "skip" form (mode & 1) does not visit are left alone.
+struct GlmPads {
+  int v[32];  // n_padding per batch entry (src1[ROPE_PARAMS_NUM + i3], :9319)
+};
+__global__ void rope_glm_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int heads, int seq,
+                                int head_size, int n_past, int n_dims, int skip, float theta_scale, int prompt_size,
+                                GlmPads pads) {
+  const int quarter = head_size / 4;
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= rows * quarter) return;
+  const size_t row = gid / quarter;
+  const int i0 = int(gid % quarter);
+  const int i2 = int((row / heads) % seq), i3 = int(row / (size_t(heads) * seq));
+  if (skip && i2 < n_past) return;
+  const long long p = skip ? i2 : (long long)n_past + i2;
+  const long long npad = pads.v[i3];
+  const long long tb = min(max(p - npad, 0ll), (long long)prompt_size - 2 - npad);
+  float theta_base = float(tb);
+  float block_theta = float(max(p - ((long long)prompt_size - 2), 0ll));
+  for (int t = 0; t < i0; t++) {
+    theta_base = __fmul_rn(theta_base, theta_scale);
+    block_theta = __fmul_rn(block_theta, theta_scale);
+  }
+  const float c = cosf(theta_base), s = sinf(theta_base), cb = cosf(block_theta), sb = sinf(block_theta);
+  const float* x = src + row * head_size + i0;
+  float* y = dst + row * head_size + i0;
+  const float x0 = x[0], x1 = x[n_dims / 2], x2 = x[n_dims], x3 = x[n_dims / 2 * 3];
+  y[0] = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, s));
+  y[n_dims / 2] = __fadd_rn(__fmul_rn(x0, s), __fmul_rn(x1, c));
+  y[n_dims] = __fsub_rn(__fmul_rn(x2, cb), __fmul_rn(x3, sb));
+  y[n_dims / 2 * 3] = __fadd_rn(__fmul_rn(x2, sb), __fmul_rn(x3, cb));
+}
+hipError_t launch_rope_glm(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                           bool skip, float freq_base, int prompt_size, const int* n_padding, hipStream_t st) {
+  const size_t rows = size_t(batch) * seq * heads;
+  if (rows == 0) return hipSuccess;
+  if (batch > 32) return hipErrorInvalidValue;
+  GlmPads pads{};
+  for (int i = 0; i < batch; i++) pads.v[i] = n_padding[i];
+  // elements the loop does not visit (and, in the skip form, whole rows) keep their value
+  if (dst != src) {
+    const hipError_t e = hipMemcpyAsync(dst, src, rows * head_size * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return e;
+  }
+  const float theta_scale = powf(freq_base, -2.0f / n_dims);
+  hipLaunchKernelGGL(rope_glm_kernel, grid1d(rows * (head_size / 4), 256), dim3(256), 0, st, src, dst, rows, heads, seq,
+                     head_size, n_past, n_dims, skip ? 1 : 0, theta_scale, prompt_size, pads);
+  return hipGetLastError();
+}
+
 // ---- the remaining members of the reference's device-backend operator set (ne_bestla.h:99-111, ne_bestla_sycl.cpp) ----
 // bestla_device_elewise_f32 (:297-326): NE_OP_SILU is the one operator it implements — ne_silu_f32(x) = x / (1 + expf(-x))
 __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {

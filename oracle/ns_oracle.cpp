@@ -1108,6 +1108,42 @@ int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, in
                            attn_factor, 0.f, 0.f);
 }
 
+// GLM branch of ne_compute_forward_rope_f32 (mode & 4) — ne_layers.c:9317-9347: two-dimensional position encoding of
+// ChatGLM.  Per row the first half of the head is rotated by the clamped token position, the second half by the block
+// position; both angles are multiplied by theta_scale after every element, cos / sin in fp32.  n_padding comes from
+// src1[ROPE_PARAMS_NUM + batch index] (:9319).  mode & 1 ("skip"): rows of positions < n_past are left untouched and
+// p = i2 (:9313-9314).
+int nso_rope_f32_glm(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                     int mode, float freq_base, int prompt_size, const int* n_padding) {
+  if (!(mode & 4) || (mode & ~5) || n_dims % 2 || n_dims / 2 * 3 + head_size / 4 > head_size) return -1;
+  const bool skip = mode & 1;
+  const float theta_scale = powf(freq_base, -2.0f / n_dims);
+  for (int64_t i3 = 0; i3 < batch; i3++)
+    for (int64_t i2 = (skip ? n_past : 0); i2 < seq; i2++) {
+      const int64_t p = skip ? i2 : n_past + i2;
+      for (int64_t i1 = 0; i1 < heads; i1++) {
+        const int64_t npad = n_padding[i3];
+        float theta_base = float(std::min(std::max(p - npad, int64_t(0)), int64_t(prompt_size) - 2 - npad));
+        float block_theta = float(std::max(p - (int64_t(prompt_size) - 2), int64_t(0)));
+        const size_t row = ((size_t(i3) * seq + i2) * heads + i1) * head_size;
+        for (int64_t i0 = 0; i0 < head_size / 4; i0++) {
+          const float cos_theta = cosf(theta_base), sin_theta = sinf(theta_base);
+          const float cos_block_theta = cosf(block_theta), sin_block_theta = sinf(block_theta);
+          theta_base *= theta_scale;
+          block_theta *= theta_scale;
+          const float* s = src + row + i0;
+          float* d = dst + row + i0;
+          const float x0 = s[0], x1 = s[n_dims / 2], x2 = s[n_dims], x3 = s[n_dims / 2 * 3];
+          d[0] = x0 * cos_theta - x1 * sin_theta;
+          d[n_dims / 2] = x0 * sin_theta + x1 * cos_theta;
+          d[n_dims] = x2 * cos_block_theta - x3 * sin_block_theta;
+          d[n_dims / 2 * 3] = x2 * sin_block_theta + x3 * cos_block_theta;
+        }
+      }
+    }
+  return 0;
+}
+
 // bestla_fusion_attn_forward_ref — mha_dense_wrapper.h:1371-1517 (PLAIN layouts; fp32 accumulation in the loop order
 // of the reference: scores j ascending / k ascending, then exp, then P.V k ascending)
 int nso_attn_ref(const nso_attn_args* a, int bf16_gemm) {

@@ -183,6 +183,9 @@ int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int head
                       int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
                       float beta_fast, float beta_slow);
 /* long-rope (mode 0x10, ne_layers.c:9349-9377): theta / factors[pair] through rope_yarn, cos / sin times scale_factor */
+/* GLM branch (mode & 4; mode & 1 = skip): ne_layers.c:9317-9347.  n_padding[batch].  PARITY UNPINNED likewise. */
+int nso_rope_f32_glm(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
+                     int mode, float freq_base, int prompt_size, const int* n_padding);
 int nso_rope_f32_longrope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                           float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
                           float beta_fast, float beta_slow, const float* factors, float scale_factor);

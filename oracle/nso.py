@@ -317,6 +317,19 @@ def rope_f32(x, n_past, n_dims, mode, freq_base=10000.0, freq_scale=1.0, attn_fa
     return out
 
 
+def rope_f32_glm(x, n_past, n_dims, mode, freq_base, prompt_size, n_padding):
+    """GLM branch of ne_compute_forward_rope_f32 (mode & 4); rows the reference leaves untouched keep x's values"""
+    x = np.ascontiguousarray(x, np.float32)
+    b, s, h, hs = x.shape
+    out = x.copy()
+    pad = np.ascontiguousarray(n_padding, np.int32)
+    assert pad.shape == (b,)
+    rc = lib().nso_rope_f32_glm(ptr(x), ptr(out), b, s, h, hs, n_past, n_dims, mode, C.c_float(freq_base), prompt_size,
+                                ptr(pad))
+    assert rc == 0
+    return out
+
+
 def rope_f32_yarn(x, n_past, n_dims, mode, freq_base, freq_scale, n_orig_ctx, ext_factor, attn_factor, beta_fast, beta_slow):
     x = np.ascontiguousarray(x, np.float32)
     b, s, h, hs = x.shape

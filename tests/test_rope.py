@@ -215,3 +215,64 @@ def test_rope_longrope_gpu_matches_oracle(L, pkg, nso, ext):
     torch.cuda.synchronize()
     ref = nso.rope_f32_longrope(x, n_past, n_dims, 10000.0, 0.5, 4096, ext, 1.0, 32.0, 1.0, factors, 1.19)
     assert np.max(np.abs(dy.cpu().numpy() - ref)) < 4e-5 * np.max(np.abs(x))
+
+
+# ---------------------------------------------------------------------------------------------- GLM branch (mode & 4)
+def _glm_closed_form(x, n_past, n_dims, mode, base, prompt_size, pads):
+    b, s, h, hs = x.shape
+    y = x.astype(np.float64).copy()
+    xs = x.astype(np.float64)
+    ts = float(np.float32(base)) ** (-2.0 / n_dims)
+    skip = bool(mode & 1)
+    idx = np.arange(hs // 4)
+    for i3 in range(b):
+        for i2 in range(n_past if skip else 0, s):
+            p = i2 if skip else n_past + i2
+            tb = min(max(p - pads[i3], 0), prompt_size - 2 - pads[i3])
+            bt = max(p - (prompt_size - 2), 0)
+            th, bth = tb * ts ** idx, bt * ts ** idx
+            x0, x1 = xs[i3, i2, :, idx], xs[i3, i2, :, idx + n_dims // 2]          # [hs/4][heads]
+            x2, x3 = xs[i3, i2, :, idx + n_dims], xs[i3, i2, :, idx + n_dims // 2 * 3]
+            c, sn, cb, sb = (np.cos(th)[:, None], np.sin(th)[:, None], np.cos(bth)[:, None], np.sin(bth)[:, None])
+            y[i3, i2, :, idx] = x0 * c - x1 * sn
+            y[i3, i2, :, idx + n_dims // 2] = x0 * sn + x1 * c
+            y[i3, i2, :, idx + n_dims] = x2 * cb - x3 * sb
+            y[i3, i2, :, idx + n_dims // 2 * 3] = x2 * sb + x3 * cb
+    return y
+
+
+GLM_CASES = [  # batch, seq, heads, head_size, n_past, n_dims, mode, base, prompt_size, n_padding
+    (1, 6, 4, 128, 0, 64, 4, 10000.0, 6, [0]),           # prompt pass: every token inside the prompt
+    (2, 1, 8, 128, 9, 64, 4, 10000.0, 7, [0, 3]),        # decode step past the prompt: block position counts up, padding per batch
+    (1, 5, 2, 64, 2, 32, 5, 10000.0, 4, [1]),            # skip form: rows below n_past untouched
+]
+
+
+@pytest.mark.parametrize("b,s,h,hs,n_past,n_dims,mode,base,psize,pads", GLM_CASES)
+def test_rope_glm_oracle_matches_closed_form(nso, b, s, h, hs, n_past, n_dims, mode, base, psize, pads):
+    x = np.random.default_rng(hs + n_past + mode).standard_normal((b, s, h, hs)).astype(np.float32)
+    ref = _glm_closed_form(x, n_past, n_dims, mode, base, psize, pads)
+    out = nso.rope_f32_glm(x, n_past, n_dims, mode, base, psize, pads)
+    assert np.max(np.abs(out - ref)) < 1e-4
+    if mode & 1:
+        assert np.array_equal(out[:, :n_past], x[:, :n_past])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,s,h,hs,n_past,n_dims,mode,base,psize,pads", GLM_CASES)
+def test_rope_glm_gpu_matches_oracle(L, pkg, nso, b, s, h, hs, n_past, n_dims, mode, base, psize, pads):
+    import torch
+    x = np.random.default_rng(hs * 5 + n_past).standard_normal((b, s, h, hs)).astype(np.float32)
+    ref = nso.rope_f32_glm(x, n_past, n_dims, mode, base, psize, pads)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pad = np.ascontiguousarray(pads, np.int32)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.zeros_like(dx)
+    pkg.check(L.ns_hip_rope_f32_glm(dx.data_ptr(), dy.data_ptr(), b, s, h, hs, n_past, n_dims, mode, base, psize, nso.ptr(pad), st))
+    pkg.check(L.ns_hip_rope_f32_glm(dx.data_ptr(), dx.data_ptr(), b, s, h, hs, n_past, n_dims, mode, base, psize, nso.ptr(pad), st))
+    torch.cuda.synchronize()
+    out = dy.cpu().numpy()
+    assert np.array_equal(out, dx.cpu().numpy())  # in place == out of place
+    assert np.max(np.abs(out - ref)) < 1e-5 * max(1.0, float(np.abs(x).max()))
+    assert L.ns_hip_rope_f32_glm(dx.data_ptr(), dy.data_ptr(), b, s, h, hs, n_past, n_dims, 2, base, psize, nso.ptr(pad), st) != 0
+    L.ns_hip_reset_error()
