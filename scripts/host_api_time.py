@@ -3,7 +3,22 @@
 import ctypes as C, os, sys, time, numpy as np
 sys.path.insert(0, os.getcwd())
 import __graft_entry__ as ge
-pkg = ge.load_package(); L = pkg.lib(); nso = ge.load_oracle()
+pkg = ge.load_package(); L = pkg.lib()
+
+
+class _Buf:  # pointer / aligned-buffer helpers (no dependency on the test oracle)
+    @staticmethod
+    def ptr(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    @staticmethod
+    def aligned_bytes(nbytes, align=64):
+        raw = np.zeros(nbytes + align, np.uint8)
+        off = (-raw.ctypes.data) % align
+        return raw[off:off + nbytes]
+
+
+nso = _Buf
 rng = np.random.default_rng(1)
 def mk(n, k):
     w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)

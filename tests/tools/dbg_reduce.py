@@ -1,6 +1,6 @@
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.load_package(); nso = ge.load_oracle(); L = pkg.lib()
 rng = np.random.default_rng(1)
