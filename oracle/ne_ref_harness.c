@@ -1,0 +1,165 @@
+/*
+ * ne_ref_harness.c — TEST INFRASTRUCTURE.  Drives the reference's own graph executor
+ * (/root/reference/neural_speed/core/ne_layers.c, compiled from where it lies into oracle/_ref/libne_ref.so by
+ * oracle/Makefile) through a few flat C entry points, so that
+ *   (1) the oracle's restatements of graph operators (RoPE in all its modes) are pinned against the real
+ *       ne_compute_forward_* code, and
+ *   (2) the reference's `ne_mul_mat` / fused QKV / fused FFN nodes over BTLA weight tensors can be executed with the
+ *       product library (libns_hip.so) answering the `bestla_*` calls — the drop-in boundary exercised from the
+ *       reference's side, unchanged graph code included (ne_compute_forward_mul_mat_q_f32_bestla, ne_layers.c:7219-7316).
+ *
+ * The three graph-struct entry points (bestla_parallel_for / bestla_support / bestla_backend_support) are the glue a
+ * maintainer adds on the ggml side; they are written here against the reference's headers.
+ * Every other `bestla_*` symbol has an aborting fallback in ne_ref_stubs.c, which libns_hip.so interposes when it is
+ * loaded with RTLD_GLOBAL before this library.
+ */
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ne.h"
+#include "ne_bestla.h"
+#include "ne_layers.h"
+
+/* ---- glue: INTEGRATION.md section 2 (reference: core/layers/ne_bestla.cpp:42-72, :176-276) -------------------- */
+void bestla_parallel_for(forward_compute_fptr f, struct ne_compute_params* mp, struct ne_tensor* node) {
+  struct ne_compute_params p = *mp; /* graphs run with one host thread here: every node has n_tasks == 1 */
+  p.ith = 0;
+  p.nth = 1;
+  p.type = NE_TASK_INIT;
+  f(&p, node);
+  p.type = NE_TASK_COMPUTE;
+  f(&p, node);
+  p.type = NE_TASK_FINALIZE;
+  f(&p, node);
+}
+
+bool bestla_support(struct ne_tensor* node, int n_threads, size_t* workspace, size_t* dev_workspace) {
+  (void)n_threads;
+  *workspace = 0;
+  *dev_workspace = 0;
+  switch (node->op) {
+    case NE_OP_MUL_MAT:
+    case NE_OP_MUL_MAT_BIAS:
+      if (node->src0->type != NE_TYPE_BTLA) return false;
+      *workspace = bestla_f32f32_get_workspace_size((int)node->src1->ne[1], (int)node->src0->ne[1], (int)node->src1->ne[0],
+                                                    node->src0->data);
+      break;
+    case NE_OP_MUL_QKV:
+      *workspace = bestla_fusion_QKV_f32f32_get_workspace_size((int)node->src0->ne[1], (int)node->src1->ne[1],
+                                                               (int)node->src1->ne[0], node->src1->data);
+      break;
+    case NE_OP_MUL_FFN_SILU:
+    case NE_OP_MUL_FFN_GELU:
+    case NE_OP_MUL_FFN_GELU_MUL:
+    case NE_OP_MUL_FFN_ADD_GELU:
+      *workspace = bestla_fusion_FFN_f32f32_get_workspace_size((int)node->src0->ne[1], (int)node->src0->ne[0],
+                                                               (int)node->src1->ne[1], (int)node->opt[0]->ne[1],
+                                                               node->src1->data, node->opt[0]->data);
+      break;
+    default:
+      return false;
+  }
+  node->n_tasks = 1;
+  return true;
+}
+
+enum ne_backend bestla_backend_support(struct ne_tensor* a, struct ne_tensor* b, enum ne_op op) {
+  (void)a;
+  (void)b;
+  (void)op;
+  return NE_BACKEND_CPU;
+}
+
+/* non-static builder of every RoPE flavour (ne_layers.c:3377-3434) */
+struct ne_tensor* ne_rope_impl(struct ne_context* ctx, struct ne_tensor* a, int n_past, int n_dims, int mode, int prompt_size,
+                               bool inplace, int n_keep, struct ne_tensor* cossin, int* n_padding, bool padding_left,
+                               float freq_base, float freq_scale, int yarn_orig_ctx, float ext_factor, float attn_factor,
+                               float beta_fast, float beta_slow, struct ne_tensor* factor, float scale_factor);
+
+static struct ne_cgraph g_graph; /* ~1 MB: not on the stack */
+
+static void run_graph(struct ne_context* ctx, struct ne_tensor* out) {
+  g_graph = ne_build_forward(out);
+  g_graph.n_threads = 1;
+  ne_graph_compute(ctx, &g_graph);
+}
+
+/* x, y: fp32 [batch][seq][heads][head_size].  op_freq_scale is the value the graph builder receives (the forward uses
+ * its reciprocal, ne_layers.c:9262).  factors: long-rope divisor table [n_dims / 2] or NULL.  n_padding: [batch] or NULL. */
+int neref_rope(const float* x, float* y, int batch, int seq, int heads, int head_size, int n_past, int n_dims, int mode,
+               int prompt_size, float freq_base, float op_freq_scale, int yarn_orig_ctx, float ext_factor, float attn_factor,
+               float beta_fast, float beta_slow, const int* n_padding, const float* factors, float scale_factor) {
+  const size_t n = (size_t)batch * seq * heads * head_size;
+  struct ne_init_params ip = {n * 4 + (16u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  if (!ctx) return -1;
+  struct ne_tensor* a = ne_new_tensor_4d(ctx, NE_TYPE_F32, head_size, heads, seq, batch, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(a->data, x, n * 4);
+  struct ne_tensor* f = NULL;
+  if (factors) {
+    f = ne_new_tensor_1d(ctx, NE_TYPE_F32, n_dims / 2, NE_SIZE_CALC, NE_BACKEND_CPU);
+    memcpy(f->data, factors, (size_t)(n_dims / 2) * 4);
+  }
+  int pads[64];
+  for (int i = 0; i < batch && i < 64; i++) pads[i] = n_padding ? n_padding[i] : 0;
+  struct ne_tensor* r = ne_rope_impl(ctx, a, n_past, n_dims, mode, prompt_size, true, -1, NULL, n_padding ? pads : NULL, true,
+                                     freq_base, op_freq_scale, yarn_orig_ctx, ext_factor, attn_factor, beta_fast, beta_slow, f,
+                                     scale_factor);
+  run_graph(ctx, r);
+  memcpy(y, a->data, n * 4);
+  ne_free(ctx);
+  return 0;
+}
+
+static struct ne_tensor* btla_tensor(struct ne_context* ctx, void* blob, size_t blob_bytes, int k, int n) {
+  /* what the model loader does for a BTLA tensor (model_files.h:1564-1571): ne = {K, N}, size = blob bytes, data -> blob */
+  struct ne_tensor* w = ne_new_tensor_2d(ctx, NE_TYPE_BTLA, k, n, blob_bytes, NE_BACKEND_CPU);
+  w->data = blob;
+  return w;
+}
+
+/* C[m][n] = A[m][k] . W through the reference graph: ne_mul_mat over a BTLA weight tensor -> NE_OP_MUL_MAT ->
+ * ne_compute_forward_mul_mat_q_f32_bestla -> bestla_f32f32_forward (whoever provides it) */
+int neref_mul_mat(const float* a, void* blob, size_t blob_bytes, float* c, int m, int n, int k) {
+  struct ne_init_params ip = {(size_t)m * (k + n) * 4 + (64u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  if (!ctx) return -1;
+  /* the tensor object of a BTLA weight is created without payload: data points into the caller's blob */
+  struct ne_init_params ipw = {1u << 20, NULL, true};
+  struct ne_context* wctx = ne_init(ipw);
+  if (!wctx) return -1;
+  struct ne_tensor* w = btla_tensor(wctx, blob, blob_bytes, k, n);
+  struct ne_tensor* x = ne_new_tensor_2d(ctx, NE_TYPE_F32, k, m, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(x->data, a, (size_t)m * k * 4);
+  struct ne_tensor* y = ne_mul_mat(ctx, w, x);
+  run_graph(ctx, y);
+  memcpy(c, y->data, (size_t)m * n * 4);
+  ne_free(ctx);
+  ne_free(wctx);
+  return 0;
+}
+
+/* out[m][d] = FFN_SiLU(A; W1 [ff x d], W2 [d x ff], W3 [ff x d]) through the reference's fused node
+ * (ne_ffn_silu -> NE_OP_MUL_FFN_SILU -> bestla_fusion_FFN_SiLu_f32f32_forward, ne_layers.c:8037-8051) */
+int neref_ffn_silu(const float* a, void* b1, size_t s1, void* b2, size_t s2, void* b3, size_t s3, float* out, int m, int d,
+                   int ff) {
+  struct ne_init_params ip = {(size_t)m * (d * 2 + ff * 2) * 4 + (64u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  struct ne_init_params ipw = {1u << 20, NULL, true};
+  struct ne_context* wctx = ne_init(ipw);
+  if (!ctx || !wctx) return -1;
+  struct ne_tensor* w1 = btla_tensor(wctx, b1, s1, d, ff);
+  struct ne_tensor* w2 = btla_tensor(wctx, b2, s2, ff, d);
+  struct ne_tensor* w3 = btla_tensor(wctx, b3, s3, d, ff);
+  struct ne_tensor* x = ne_new_tensor_2d(ctx, NE_TYPE_F32, d, m, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(x->data, a, (size_t)m * d * 4);
+  struct ne_tensor* y = ne_ffn_silu(ctx, w1, w2, w3, x);
+  run_graph(ctx, y);
+  memcpy(out, y->data, (size_t)m * d * 4);
+  ne_free(ctx);
+  ne_free(wctx);
+  return 0;
+}

@@ -52,6 +52,11 @@ def build(force=False):
     so = os.path.join(HERE, "libns_oracle.so")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(HERE, "ns_oracle.cpp")):
         subprocess.check_call(["make", "-C", HERE, "libns_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/neural_speed/core/ne_layers.c"):
+        nref = os.path.join(HERE, "_ref", "libne_ref.so")
+        srcs = [os.path.join(HERE, f) for f in ("ne_ref_harness.c", "ne_ref_stubs.c")]
+        if force or not os.path.exists(nref) or os.path.getmtime(nref) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", HERE, "neref"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/bestla/bestla/kernel_ref.h"):
         ref = os.path.join(HERE, "_ref", "libkernel_ref.so")
         if force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(os.path.join(HERE, "ref_shim.cpp")):
@@ -119,6 +124,47 @@ def ref():
         _ref.ref_cast_f32_u8.argtypes = [C.c_float]
         _ref.ref_postop.argtypes = [C.c_float, C.c_int]
     return _ref
+
+
+_neref = None
+
+
+def neref(product_lib_path=None):
+    """The reference's own graph executor (ne_layers.c compiled into oracle/_ref/libne_ref.so) behind the flat entry
+    points of ne_ref_harness.c; None when it was never built.  product_lib_path: load that library with RTLD_GLOBAL
+    first, so that the graph's bestla_* calls land in it (the drop-in test); must be given on the FIRST call."""
+    global _neref
+    if _neref is None:
+        build()
+        p = os.path.join(HERE, "_ref", "libne_ref.so")
+        if not os.path.exists(p):
+            return None
+        if product_lib_path:
+            C.CDLL(product_lib_path, mode=C.RTLD_GLOBAL)
+        _neref = C.CDLL(p)
+        _neref.provider = product_lib_path
+        f, i, vp = C.c_float, C.c_int, C.c_void_p
+        _neref.neref_rope.argtypes = [vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, f, f, f, vp, vp, f]
+        _neref.neref_mul_mat.argtypes = [vp, vp, C.c_size_t, vp, i, i, i]
+        _neref.neref_ffn_silu.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, i, i, i]
+    elif product_lib_path and _neref.provider != product_lib_path:
+        raise RuntimeError("libne_ref.so is already loaded without (or with another) bestla_* provider")
+    return _neref
+
+
+def neref_rope(x, n_past, n_dims, mode, freq_base=10000.0, freq_scale=1.0, prompt_size=0, n_orig_ctx=0, ext_factor=0.0,
+               attn_factor=1.0, beta_fast=0.0, beta_slow=0.0, n_padding=None, factors=None, scale_factor=0.0):
+    """RoPE through the reference graph (ne_rope_impl + ne_graph_compute).  freq_scale is the EFFECTIVE scale (what the
+    forward multiplies by); the graph parameter is its reciprocal (ne_layers.c:9262), so use powers of two."""
+    x = np.ascontiguousarray(x, np.float32)
+    b, s, h, hs = x.shape
+    out = np.zeros_like(x)
+    pad = None if n_padding is None else np.ascontiguousarray(n_padding, np.int32)
+    fac = None if factors is None else np.ascontiguousarray(factors, np.float32)
+    rc = neref().neref_rope(ptr(x), ptr(out), b, s, h, hs, n_past, n_dims, mode, prompt_size, freq_base, 1.0 / freq_scale,
+                            n_orig_ctx, ext_factor, attn_factor, beta_fast, beta_slow, ptr(pad), ptr(fac), scale_factor)
+    assert rc == 0
+    return out
 
 
 def ptr(a):

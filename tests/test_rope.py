@@ -276,3 +276,59 @@ def test_rope_glm_gpu_matches_oracle(L, pkg, nso, b, s, h, hs, n_past, n_dims, m
     assert np.max(np.abs(out - ref)) < 1e-5 * max(1.0, float(np.abs(x).max()))
     assert L.ns_hip_rope_f32_glm(dx.data_ptr(), dy.data_ptr(), b, s, h, hs, n_past, n_dims, 2, base, psize, nso.ptr(pad), st) != 0
     L.ns_hip_reset_error()
+
+
+# ------------------------------------------------------------------ the oracle pinned to the REAL reference operator
+# oracle/_ref/libne_ref.so is the reference's own ne_layers.c compiled from where it lies (oracle/Makefile `neref`) and
+# driven through its graph builder + ne_graph_compute by oracle/ne_ref_harness.c: ne_compute_forward_rope_f32 itself.
+@pytest.fixture(scope="module")
+def neref(nso):
+    if nso.neref() is None:
+        pytest.skip("oracle/_ref/libne_ref.so not built (reference tree absent)")
+    return nso
+
+
+PIN_SHAPES = [(1, 1, 32, 128, 17), (2, 5, 4, 64, 0), (1, 3, 8, 128, 2000), (1, 4, 2, 80, 9)]
+
+
+@pytest.mark.parametrize("b,s,h,hs,n_past", PIN_SHAPES)
+@pytest.mark.parametrize("mode,fscale", [(0, 1.0), (0, 0.25), (2, 1.0), (2, 0.5)])
+def test_rope_oracle_equals_reference_operator(neref, b, s, h, hs, n_past, mode, fscale):
+    x = np.random.default_rng(hs + n_past + mode).standard_normal((b, s, h, hs)).astype(np.float32)
+    for n_dims in {hs, hs // 2} if mode == 2 else {hs}:
+        ref = neref.neref_rope(x, n_past, n_dims, mode, 10000.0, fscale)
+        out = neref.rope_f32(x, n_past, n_dims, mode, 10000.0, fscale, 1.0)
+        if mode == 2 and hs % n_dims:   # dims the NeoX loop does not visit: in place, they keep x
+            out = np.where(out == 0, x, out)
+        assert np.array_equal(out, ref)   # same sequential fp32 products, same libm: bit for bit
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("ext,fscale", [(1.0, 0.25), (0.5, 0.5), (0.0, 0.25)])
+def test_rope_yarn_oracle_equals_reference_operator(neref, mode, ext, fscale):
+    b, s, h, hs, n_past, n_orig = 1, 4, 4, 128, 3000, 4096
+    x = np.random.default_rng(int(ext * 10) + mode).standard_normal((b, s, h, hs)).astype(np.float32)
+    ref = neref.neref_rope(x, n_past, hs, mode, 10000.0, fscale, n_orig_ctx=n_orig, ext_factor=ext, attn_factor=1.2,
+                           beta_fast=32.0, beta_slow=1.0)
+    out = neref.rope_f32_yarn(x, n_past, hs, mode, 10000.0, fscale, n_orig, ext, 1.2, 32.0, 1.0)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("ext", [0.0, 1.0])
+def test_rope_longrope_oracle_equals_reference_operator(neref, ext):
+    b, s, h, hs, n_past = 1, 3, 4, 96, 5000
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((b, s, h, hs)).astype(np.float32)
+    factors = (1.0 + rng.random(hs // 2) * 3).astype(np.float32)
+    ref = neref.neref_rope(x, n_past, hs, 0x10, 10000.0, 0.5, n_orig_ctx=4096, ext_factor=ext, attn_factor=1.0,
+                           beta_fast=32.0, beta_slow=1.0, factors=factors, scale_factor=1.19)
+    out = neref.rope_f32_longrope(x, n_past, hs, 10000.0, 0.5, 4096, ext, 1.0, 32.0, 1.0, factors, 1.19)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("b,s,h,hs,n_past,n_dims,mode,base,psize,pads", GLM_CASES)
+def test_rope_glm_oracle_equals_reference_operator(neref, b, s, h, hs, n_past, n_dims, mode, base, psize, pads):
+    x = np.random.default_rng(hs + 11 * n_past).standard_normal((b, s, h, hs)).astype(np.float32)
+    ref = neref.neref_rope(x, n_past, n_dims, mode, base, 1.0, prompt_size=psize, n_padding=pads)
+    out = neref.rope_f32_glm(x, n_past, n_dims, mode, base, psize, pads)
+    assert np.array_equal(out, ref)

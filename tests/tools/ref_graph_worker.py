@@ -1,0 +1,81 @@
+"""Worker of the reference-graph tests (fresh interpreter: the bestla_* provider must be loaded before libne_ref.so).
+argv[1] = "mock": build + load tests/tools/mock_bestla_provider.c, check the marshalling.
+argv[1] = "product": load neural-speed_amd/libns_hip.so, run ne_mul_mat / ne_ffn_silu over BTLA tensors through the
+reference's graph executor and compare with the oracle (GPU needed)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import nso  # noqa: E402
+
+
+class MockCall(C.Structure):
+    _fields_ = [("which", C.c_int), ("m", C.c_int), ("n", C.c_int), ("k", C.c_int), ("lda", C.c_int), ("ldo", C.c_int),
+                ("a", C.c_void_p), ("w", C.c_void_p), ("c", C.c_void_p), ("ws", C.c_void_p), ("w1", C.c_void_p),
+                ("w2", C.c_void_p), ("w3", C.c_void_p), ("seq", C.c_int), ("fin", C.c_int), ("fmid", C.c_int),
+                ("fout", C.c_int)]
+
+
+def blobs(rng, shapes, bs=32):
+    out = []
+    for n, k in shapes:
+        w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+        out.append(nso.quant_pack(w, bs, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB))
+    return out
+
+
+def main(kind):
+    rng = np.random.default_rng(21)
+    m, d, ff = 3, 256, 512
+    if kind == "mock":
+        so = os.path.join(tempfile.mkdtemp(), "libmock_bestla.so")
+        subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "tools", "mock_bestla_provider.c")])
+        provider = so
+    else:
+        provider = os.path.join(ROOT, "neural-speed_amd", "libns_hip.so")
+        import torch  # noqa: F401  (torch's HIP runtime first, as neural_speed_amd.lib() does)
+    ne = nso.neref(provider)
+    assert ne is not None, "oracle/_ref/libne_ref.so missing"
+    (bw,) = blobs(rng, [(ff, d)])
+    a = rng.standard_normal((m, d)).astype(np.float32)
+    c = np.zeros((m, ff), np.float32)
+    assert ne.neref_mul_mat(nso.ptr(a), nso.ptr(bw), bw.size, nso.ptr(c), m, ff, d) == 0
+    b1, b2, b3 = blobs(rng, [(ff, d), (d, ff), (ff, d)])
+    out = np.zeros((m, d), np.float32)
+    if kind == "mock":
+        mock = C.CDLL(provider)
+        mock.mock_last_call.restype = C.POINTER(MockCall)
+        lc = mock.mock_last_call().contents
+        # ne_compute_forward_mul_mat_q_f32_bestla (ne_layers.c:7312): (src1 data, BTLA blob, dst, ne1, ne0, ne10, nb11/4, nb1/4, wdata)
+        assert (lc.which, lc.m, lc.n, lc.k, lc.lda, lc.ldo) == (1, m, ff, d, d, ff), (lc.which, lc.m, lc.n, lc.k, lc.lda, lc.ldo)
+        assert lc.w == bw.ctypes.data and lc.ws          # the weight pointer is the caller's blob; a workspace was sized
+        assert np.array_equal(c, a[:, :1] + np.arange(ff, dtype=np.float32)[None, :])
+        assert ne.neref_ffn_silu(nso.ptr(a), nso.ptr(b1), b1.size, nso.ptr(b2), b2.size, nso.ptr(b3), b3.size, nso.ptr(out), m, d, ff) == 0
+        lc = mock.mock_last_call().contents
+        assert (lc.which, lc.seq, lc.fin, lc.fmid, lc.fout) == (2, m, d, ff, d)
+        assert (lc.w1, lc.w2, lc.w3) == (b1.ctypes.data, b2.ctypes.data, b3.ctypes.data)
+        assert np.all(out == 42.0)
+        print("REF_GRAPH_MOCK_OK")
+        return
+    # the real product behind the reference's graph
+    assert nso.rel_l2(c, nso.gemm_f64(a, bw)) < 1e-3
+    assert ne.neref_ffn_silu(nso.ptr(a), nso.ptr(b1), b1.size, nso.ptr(b2), b2.size, nso.ptr(b3), b3.size, nso.ptr(out), m, d, ff) == 0
+    g = nso.gemm_f64(a, b1)
+    h = (g / (1 + np.exp(-g)) * nso.gemm_f64(a, b3)).astype(np.float32)
+    assert nso.rel_l2(out, nso.gemm_f64(h, b2)) < 2e-3
+    # decode-sized call as the model issues it: one token row
+    c1 = np.zeros((1, ff), np.float32)
+    assert ne.neref_mul_mat(nso.ptr(a[:1].copy()), nso.ptr(bw), bw.size, nso.ptr(c1), 1, ff, d) == 0
+    assert nso.rel_l2(c1, nso.gemm_f64(a[:1], bw)) < 1e-3
+    print("REF_GRAPH_PRODUCT_OK")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
