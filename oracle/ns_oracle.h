@@ -174,16 +174,18 @@ int nso_attn_ref(const nso_attn_args* a, int bf16_gemm);
  * [batch][seq][heads][head_size], modes 0 (adjacent pairs over the whole row) and 2 (NeoX halves inside n_dims-wide
  * blocks), ext_factor = 0 (no YaRN mix), no GLM / long-rope / shift.  theta is the reference's sequential fp32 product
  * (theta *= theta_scale per pair); the NeoX branch applies freq_scale twice, as the reference does (:9398 + :9207).
- * PARITY UNPINNED (ne_layers.c does not compile standalone); checked against an fp64 closed form. */
+ * PINNED: bit-identical to the reference's own ne_compute_forward_rope_f32 run through its graph executor
+ * (oracle/_ref/libne_ref.so = ne_layers.c compiled from where it lies, oracle/ne_ref_harness.c; tests/test_rope.py),
+ * and checked against an fp64 closed form. */
 int nso_rope_f32(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                  int mode, float freq_base, float freq_scale, float attn_factor);
 /* the same with the YaRN extrapolation mix (rope_yarn / rope_yarn_ramp / ggml_rope_yarn_corr_dims,
- * ne_layers.c:9196-9231); ext_factor = 0 reduces to nso_rope_f32.  PARITY UNPINNED likewise. */
+ * ne_layers.c:9196-9231); ext_factor = 0 reduces to nso_rope_f32.  PINNED likewise (bit-identical). */
 int nso_rope_f32_yarn(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                       int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor, float attn_factor,
                       float beta_fast, float beta_slow);
 /* long-rope (mode 0x10, ne_layers.c:9349-9377): theta / factors[pair] through rope_yarn, cos / sin times scale_factor */
-/* GLM branch (mode & 4; mode & 1 = skip): ne_layers.c:9317-9347.  n_padding[batch].  PARITY UNPINNED likewise. */
+/* GLM branch (mode & 4; mode & 1 = skip): ne_layers.c:9317-9347.  n_padding[batch].  PINNED likewise (bit-identical). */
 int nso_rope_f32_glm(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                      int mode, float freq_base, int prompt_size, const int* n_padding);
 int nso_rope_f32_longrope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
