@@ -163,3 +163,33 @@ int neref_ffn_silu(const float* a, void* b1, size_t s1, void* b2, size_t s2, voi
   ne_free(wctx);
   return 0;
 }
+
+/* Attention as the reference's model graphs spell it when the fused kernel is not used (models/llama/llama.cpp non-fused
+ * branch): KQ = mul_mat(K, Q) -> scale -> diag_mask_inf(n_past) -> soft_max -> mul_mat(V^T, P).  fp32 tensors throughout
+ * (the caller passes fp16-representable K / V values), GQA through mul_mat's broadcast (head / (heads / heads_kv)).
+ * q [heads][sl_q][hs], k / v [heads_kv][sl_kv][hs], out [heads][sl_q][hs]; causal != 0 masks keys j > i + (sl_kv - sl_q). */
+int neref_attn_unfused(const float* q, const float* k, const float* v, float* out, int heads, int heads_kv, int hs, int sl_q,
+                       int sl_kv, float scale, int causal) {
+  const size_t nq = (size_t)heads * sl_q * hs, nk = (size_t)heads_kv * sl_kv * hs, np = (size_t)heads * sl_q * sl_kv;
+  struct ne_init_params ip = {(nq * 2 + nk * 2 + np * 4) * 4 + (64u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  if (!ctx) return -1;
+  struct ne_tensor* Q = ne_new_tensor_3d(ctx, NE_TYPE_F32, hs, sl_q, heads, NE_SIZE_CALC, NE_BACKEND_CPU);
+  struct ne_tensor* K = ne_new_tensor_3d(ctx, NE_TYPE_F32, hs, sl_kv, heads_kv, NE_SIZE_CALC, NE_BACKEND_CPU);
+  struct ne_tensor* Vt = ne_new_tensor_3d(ctx, NE_TYPE_F32, sl_kv, hs, heads_kv, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(Q->data, q, nq * 4);
+  memcpy(K->data, k, nk * 4);
+  for (int h = 0; h < heads_kv; h++)
+    for (int j = 0; j < sl_kv; j++)
+      for (int e = 0; e < hs; e++)
+        ((float*)Vt->data)[((size_t)h * hs + e) * sl_kv + j] = v[((size_t)h * sl_kv + j) * hs + e];
+  struct ne_tensor* KQ = ne_mul_mat(ctx, K, Q);
+  struct ne_tensor* KQs = ne_scale(ctx, KQ, ne_new_f32(ctx, scale));
+  struct ne_tensor* KQm = causal ? ne_diag_mask_inf(ctx, KQs, sl_kv - sl_q) : KQs;
+  struct ne_tensor* P = ne_soft_max(ctx, KQm);
+  struct ne_tensor* O = ne_mul_mat(ctx, Vt, P);
+  run_graph(ctx, O);
+  memcpy(out, O->data, nq * 4);
+  ne_free(ctx);
+  return 0;
+}

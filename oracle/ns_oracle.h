@@ -152,9 +152,11 @@ float nso_silu(float x);
 /* fused attention — bestla_fusion_attn_forward_ref, neural_speed/core/layers/mha_dense_wrapper.h:1371-1517, for
  * Q fp32 / K,V fp16 / dst fp32 in ATTN_FWD_LAYOUT_PLAIN with element strides.  `bf16_gemm` != 0 reproduces the
  * reference's default rounding of Q, K and P to bf16 (IS_BF16_GEMM, :1389-1394); 0 = its NE_ATTN_FLAG_PREFER_FP32
- * form.  flags: 1 causal, 2 alibi8 (TANH30 is not part of forward_ref).  PARITY UNPINNED: mha_dense_wrapper.h needs
- * the xbyak-dependent BesTLA headers and cannot be compiled here; this is a line-by-line restatement checked only
- * against an independent fp64 softmax(QK^T)V (tests/test_attention_oracle.py). */
+ * form.  flags: 1 causal, 2 alibi8 (TANH30 is not part of forward_ref).  PARITY: mha_dense_wrapper.h needs the xbyak-
+ * dependent BesTLA headers and cannot be compiled here, so forward_ref itself is unpinned; this line-by-line
+ * restatement is checked against an independent fp64 softmax(QK^T)V and PINNED IN ITS SEMANTICS (mask placement, scale,
+ * GQA mapping, normalisation) to the reference's own unfused attention graph executed by ne_layers.c
+ * (oracle/_ref/libne_ref.so, tests/test_attention_oracle.py; tolerance = that graph's fp16-table soft_max). */
 typedef struct nso_attn_args {
   const float* q;
   const uint16_t* k;

@@ -147,6 +147,7 @@ def neref(product_lib_path=None):
         _neref.neref_rope.argtypes = [vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, f, f, f, vp, vp, f]
         _neref.neref_mul_mat.argtypes = [vp, vp, C.c_size_t, vp, i, i, i]
         _neref.neref_ffn_silu.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, i, i, i]
+        _neref.neref_attn_unfused.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, i]
     elif product_lib_path and _neref.provider != product_lib_path:
         raise RuntimeError("libne_ref.so is already loaded without (or with another) bestla_* provider")
     return _neref
@@ -165,6 +166,22 @@ def neref_rope(x, n_past, n_dims, mode, freq_base=10000.0, freq_scale=1.0, promp
                             n_orig_ctx, ext_factor, attn_factor, beta_fast, beta_slow, ptr(pad), ptr(fac), scale_factor)
     assert rc == 0
     return out
+
+
+def neref_attn_unfused(q, k, v, qk_scale, causal):
+    """attention through the reference's UNFUSED graph (mul_mat -> scale -> diag_mask_inf -> soft_max -> mul_mat), fp32.
+    q [1][sl_q][heads][hs], k / v fp16 [1][sl_kv][heads_kv][hs] (attn_ref's layouts) -> dst [1][sl_q][heads][hs]"""
+    q = np.ascontiguousarray(q, np.float32)
+    assert q.shape[0] == 1
+    _, sl_q, hn, hs = q.shape
+    sl_kv, hkv = v.shape[1], v.shape[2]
+    qh = np.ascontiguousarray(q[0].transpose(1, 0, 2))                       # [heads][sl_q][hs]
+    kh = np.ascontiguousarray(np.asarray(k[0], np.float32).transpose(1, 0, 2))  # [heads_kv][sl_kv][hs]
+    vh = np.ascontiguousarray(np.asarray(v[0], np.float32).transpose(1, 0, 2))
+    out = np.zeros_like(qh)
+    rc = neref().neref_attn_unfused(ptr(qh), ptr(kh), ptr(vh), ptr(out), hn, hkv, hs, sl_q, sl_kv, qk_scale, 1 if causal else 0)
+    assert rc == 0
+    return np.ascontiguousarray(out.transpose(1, 0, 2))[None]
 
 
 def ptr(a):

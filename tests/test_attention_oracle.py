@@ -54,3 +54,33 @@ def test_attn_oracle_matches_fp64_softmax(nso, bs, hn, hkv, hs, sl_q, sl_kv, fla
     assert np.array_equal(nso.attn_ref(q, kt, v, scale, flags, k_trans=True), out)
     # the reference's default bf16 rounding of Q, K, P stays within its own test tolerance of the fp32 form
     assert np.max(np.abs(nso.attn_ref(q, k, v, scale, flags, bf16_gemm=True) - out)) < 3e-2
+
+
+# ---------------------------------------------------------------- pinned against the reference's own (unfused) graph
+# bestla_fusion_attn_forward_ref lives behind xbyak-dependent headers and cannot be compiled here, but the SAME operator
+# spelled as graph nodes can: mul_mat(K, Q) -> scale -> diag_mask_inf -> soft_max -> mul_mat(V^T, P), executed by the
+# reference's ne_layers.c (oracle/_ref/libne_ref.so).  That pins what a restatement can get wrong — mask placement for
+# sl_q != sl_kv, the scale, the GQA head mapping, the normalisation — against real reference code.  Tolerance: the
+# reference's soft_max goes through an fp16 exp table, i.e. ~2e-4 relative on the result.
+import numpy as _np
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("hn,hkv,hs,slq,slkv,causal", [(4, 4, 64, 5, 5, True), (8, 2, 128, 1, 37, True),
+                                                       (4, 2, 64, 6, 20, True), (4, 1, 32, 3, 9, False),
+                                                       (32, 32, 128, 2, 70, True)])
+def test_attention_oracle_matches_reference_unfused_graph(nso, hn, hkv, hs, slq, slkv, causal):
+    if nso.neref() is None:
+        _pytest.skip("oracle/_ref/libne_ref.so not built (reference tree absent)")
+    rng = _np.random.default_rng(hn * 100 + slkv)
+    q = rng.standard_normal((1, slq, hn, hs)).astype(_np.float32)
+    k = rng.standard_normal((1, slkv, hkv, hs)).astype(_np.float16)
+    v = rng.standard_normal((1, slkv, hkv, hs)).astype(_np.float16)
+    scale = hs ** -0.5
+    ours = nso.attn_ref(q, k, v, scale, 1 if causal else 0)
+    ref = nso.neref_attn_unfused(q, k, v, scale, causal)
+    assert nso.rel_l2(ours, ref) < 1e-3
+    # a wrong mask offset / head mapping is an O(1) error, not 1e-4: make the test's power explicit
+    if causal and slq > 1:
+        wrong = nso.attn_ref(q, k, v, scale, 0)
+        assert nso.rel_l2(wrong, ref) > 1e-2
