@@ -193,3 +193,25 @@ int neref_attn_unfused(const float* q, const float* k, const float* v, float* ou
   ne_free(ctx);
   return 0;
 }
+
+/* out[3][m][n] = {A Wq | A Wk | A Wv} through the reference's fused node (ne_mul_qkv -> NE_OP_MUL_QKV ->
+ * bestla_fusion_QKV_f32f32_forward, ne_layers.c:8037-8051) */
+int neref_mul_qkv(const float* a, void* bq, size_t sq, void* bk, size_t sk, void* bv, size_t sv, float* out, int m, int n,
+                  int k) {
+  struct ne_init_params ip = {(size_t)m * (k + 3 * n) * 4 + (64u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  struct ne_init_params ipw = {1u << 20, NULL, true};
+  struct ne_context* wctx = ne_init(ipw);
+  if (!ctx || !wctx) return -1;
+  struct ne_tensor* wq = btla_tensor(wctx, bq, sq, k, n);
+  struct ne_tensor* wk = btla_tensor(wctx, bk, sk, k, n);
+  struct ne_tensor* wv = btla_tensor(wctx, bv, sv, k, n);
+  struct ne_tensor* x = ne_new_tensor_2d(ctx, NE_TYPE_F32, k, m, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(x->data, a, (size_t)m * k * 4);
+  struct ne_tensor* y = ne_mul_qkv(ctx, wq, wk, wv, x);
+  run_graph(ctx, y);
+  memcpy(out, y->data, (size_t)3 * m * n * 4);
+  ne_free(ctx);
+  ne_free(wctx);
+  return 0;
+}

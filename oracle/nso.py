@@ -147,6 +147,7 @@ def neref(product_lib_path=None):
         _neref.neref_rope.argtypes = [vp, vp, i, i, i, i, i, i, i, i, f, f, i, f, f, f, f, vp, vp, f]
         _neref.neref_mul_mat.argtypes = [vp, vp, C.c_size_t, vp, i, i, i]
         _neref.neref_ffn_silu.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, i, i, i]
+        _neref.neref_mul_qkv.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, i, i, i]
         _neref.neref_attn_unfused.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, i]
     elif product_lib_path and _neref.provider != product_lib_path:
         raise RuntimeError("libne_ref.so is already loaded without (or with another) bestla_* provider")

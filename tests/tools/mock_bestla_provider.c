@@ -6,7 +6,7 @@
 #include <string.h>
 
 struct mock_call {
-  int which; /* 1 = f32f32_forward, 2 = FFN SiLU */
+  int which; /* 1 = f32f32_forward, 2 = FFN SiLU, 3 = QKV */
   int m, n, k, lda, ldo;
   void *a, *w, *c, *ws;
   void *w1, *w2, *w3;
@@ -20,6 +20,17 @@ int bestla_set_threads(int n) { return n > 0 ? n : 1; }
 unsigned long long bestla_f32f32_get_workspace_size(int m, int n, int k, void* w) {
   (void)n, (void)w;
   return (unsigned long long)m * k * 4;
+}
+unsigned long long bestla_fusion_QKV_f32f32_get_workspace_size(int m, int n, int k, void* w) {
+  (void)n, (void)w;
+  return (unsigned long long)m * k * 4;
+}
+void bestla_fusion_QKV_f32f32_forward(float* a, void* wq, void* wk, void* wv, float* out, int m, int n, int k, int lda, int ldo,
+                                      void* ws) {
+  memset(&g_last, 0, sizeof(g_last));
+  g_last.which = 3, g_last.a = a, g_last.w1 = wq, g_last.w2 = wk, g_last.w3 = wv, g_last.c = out, g_last.ws = ws;
+  g_last.m = m, g_last.n = n, g_last.k = k, g_last.lda = lda, g_last.ldo = ldo;
+  for (int i = 0; i < 3 * m * n; i++) out[i] = 7.f;
 }
 unsigned long long bestla_fusion_FFN_f32f32_get_workspace_size(int seq, int fin, int fmid, int fout, void* w1, void* w2) {
   (void)fin, (void)fout, (void)w1, (void)w2;

@@ -62,6 +62,13 @@ def main(kind):
         assert (lc.which, lc.seq, lc.fin, lc.fmid, lc.fout) == (2, m, d, ff, d)
         assert (lc.w1, lc.w2, lc.w3) == (b1.ctypes.data, b2.ctypes.data, b3.ctypes.data)
         assert np.all(out == 42.0)
+        bq, bk, bv = blobs(rng, [(ff, d)] * 3)
+        qkv = np.zeros((3, m, ff), np.float32)
+        assert ne.neref_mul_qkv(nso.ptr(a), nso.ptr(bq), bq.size, nso.ptr(bk), bk.size, nso.ptr(bv), bv.size, nso.ptr(qkv), m, ff, d) == 0
+        lc = mock.mock_last_call().contents
+        # ne_compute_forward_mul_qkv (ne_layers.c:8050): (src, qw, kw, vw, dst, m, n, k, lda = k, ldo = n, wdata)
+        assert (lc.which, lc.m, lc.n, lc.k, lc.lda, lc.ldo) == (3, m, ff, d, d, ff)
+        assert (lc.w1, lc.w2, lc.w3) == (bq.ctypes.data, bk.ctypes.data, bv.ctypes.data) and np.all(qkv == 7.0)
         print("REF_GRAPH_MOCK_OK")
         return
     # the real product behind the reference's graph
@@ -74,6 +81,12 @@ def main(kind):
     c1 = np.zeros((1, ff), np.float32)
     assert ne.neref_mul_mat(nso.ptr(a[:1].copy()), nso.ptr(bw), bw.size, nso.ptr(c1), 1, ff, d) == 0
     assert nso.rel_l2(c1, nso.gemm_f64(a[:1], bw)) < 1e-3
+    # fused QKV node: three products stacked along dim 0 (ip_fusion_qkv.cpp:84-86)
+    bq, bk, bv = blobs(rng, [(ff, d)] * 3)
+    qkv = np.zeros((3, m, ff), np.float32)
+    assert ne.neref_mul_qkv(nso.ptr(a), nso.ptr(bq), bq.size, nso.ptr(bk), bk.size, nso.ptr(bv), bv.size, nso.ptr(qkv), m, ff, d) == 0
+    for i, b in enumerate((bq, bk, bv)):
+        assert nso.rel_l2(qkv[i], nso.gemm_f64(a, b)) < 1e-3
     print("REF_GRAPH_PRODUCT_OK")
 
 
