@@ -215,3 +215,18 @@ int neref_mul_qkv(const float* a, void* bq, size_t sq, void* bk, size_t sk, void
   ne_free(wctx);
   return 0;
 }
+
+/* ne_norm / ne_rms_norm (ne_compute_forward_norm_f32 / _rms_norm_f32) on [rows][cols] fp32 */
+int neref_norm(const float* x, float* y, int rows, int cols, float eps, int is_rms) {
+  const size_t n = (size_t)rows * cols;
+  struct ne_init_params ip = {n * 8 + (16u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  if (!ctx) return -1;
+  struct ne_tensor* a = ne_new_tensor_2d(ctx, NE_TYPE_F32, cols, rows, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(a->data, x, n * 4);
+  struct ne_tensor* r = is_rms ? ne_rms_norm(ctx, a, eps) : ne_norm(ctx, a, eps);
+  run_graph(ctx, r);
+  memcpy(y, r->data, n * 4);
+  ne_free(ctx);
+  return 0;
+}

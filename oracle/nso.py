@@ -148,6 +148,7 @@ def neref(product_lib_path=None):
         _neref.neref_mul_mat.argtypes = [vp, vp, C.c_size_t, vp, i, i, i]
         _neref.neref_ffn_silu.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, i, i, i]
         _neref.neref_mul_qkv.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, i, i, i]
+        _neref.neref_norm.argtypes = [vp, vp, i, i, f, i]
         _neref.neref_attn_unfused.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, i]
     elif product_lib_path and _neref.provider != product_lib_path:
         raise RuntimeError("libne_ref.so is already loaded without (or with another) bestla_* provider")
@@ -166,6 +167,14 @@ def neref_rope(x, n_past, n_dims, mode, freq_base=10000.0, freq_scale=1.0, promp
     rc = neref().neref_rope(ptr(x), ptr(out), b, s, h, hs, n_past, n_dims, mode, prompt_size, freq_base, 1.0 / freq_scale,
                             n_orig_ctx, ext_factor, attn_factor, beta_fast, beta_slow, ptr(pad), ptr(fac), scale_factor)
     assert rc == 0
+    return out
+
+
+def neref_norm(x, eps, is_rms):
+    """ne_rms_norm / ne_norm of the reference graph on fp32 [rows][cols]"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    assert neref().neref_norm(ptr(x), ptr(out), x.shape[0], x.shape[1], eps, 1 if is_rms else 0) == 0
     return out
 
 

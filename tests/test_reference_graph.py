@@ -30,3 +30,4 @@ def test_reference_graph_marshalling_with_mock_provider():
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     assert "REF_GRAPH_MOCK_OK" in run_worker("mock")
+

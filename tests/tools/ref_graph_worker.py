@@ -87,6 +87,11 @@ def main(kind):
     assert ne.neref_mul_qkv(nso.ptr(a), nso.ptr(bq), bq.size, nso.ptr(bk), bk.size, nso.ptr(bv), bv.size, nso.ptr(qkv), m, ff, d) == 0
     for i, b in enumerate((bq, bk, bv)):
         assert nso.rel_l2(qkv[i], nso.gemm_f64(a, b)) < 1e-3
+    # ne_rms_norm / ne_norm nodes: their forwards call bestla_layernormalization unconditionally (ne_layers.c:4622)
+    x = rng.standard_normal((5, 300)).astype(np.float32)
+    xd = x.astype(np.float64)
+    assert nso.rel_l2(nso.neref_norm(x, 1e-6, True), xd / np.sqrt((xd ** 2).mean(-1, keepdims=True) + 1e-6)) < 1e-6
+    assert nso.rel_l2(nso.neref_norm(x, 1e-5, False), (xd - xd.mean(-1, keepdims=True)) / np.sqrt(xd.var(-1, keepdims=True) + 1e-5)) < 1e-5
     print("REF_GRAPH_PRODUCT_OK")
 
 
