@@ -230,3 +230,30 @@ int neref_norm(const float* x, float* y, int rows, int cols, float eps, int is_r
   ne_free(ctx);
   return 0;
 }
+
+/* The fused-attention node as the model graphs build it (models/llama/llama.cpp fused branch): Q / K / V are PERMUTED
+ * VIEWS of [bs][sl][heads][hs] buffers, ne_flash_attn creates NE_OP_FLASH_ATTN (+ its tmp tensor sized by
+ * bestla_fusion_attn_workspace_size), ne_compute_forward_flash_attn_f32_f16_f16 (ne_layers.c:10110-10214) turns the
+ * tensors' nb[] strides into attn_fp32_fp16_fp16_fp32_fwd_args_t and calls bestla_fusion_attn_fp32_fp16_fp16_fp32_forward.
+ * q fp32 [bs][sl_q][heads][hs]; k, v fp16 bits [bs][sl_kv][heads_kv][hs]; out fp32 [bs][sl_q][heads][hs]. */
+int neref_flash_attn(const float* q, const uint16_t* k, const uint16_t* v, float* out, int bs, int heads, int heads_kv, int hs,
+                     int sl_q, int sl_kv, float scale, unsigned flags) {
+  const size_t nq = (size_t)bs * sl_q * heads * hs, nk = (size_t)bs * sl_kv * heads_kv * hs;
+  struct ne_init_params ip = {nq * 8 + nk * 4 + (128u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  if (!ctx) return -1;
+  struct ne_tensor* Q4 = ne_new_tensor_4d(ctx, NE_TYPE_F32, hs, heads, sl_q, bs, NE_SIZE_CALC, NE_BACKEND_CPU);
+  struct ne_tensor* K4 = ne_new_tensor_4d(ctx, NE_TYPE_F16, hs, heads_kv, sl_kv, bs, NE_SIZE_CALC, NE_BACKEND_CPU);
+  struct ne_tensor* V4 = ne_new_tensor_4d(ctx, NE_TYPE_F16, hs, heads_kv, sl_kv, bs, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(Q4->data, q, nq * 4);
+  memcpy(K4->data, k, nk * 2);
+  memcpy(V4->data, v, nk * 2);
+  struct ne_tensor* Q = ne_permute(ctx, Q4, 0, 2, 1, 3); /* ne = {hs, sl_q, heads, bs} */
+  struct ne_tensor* K = ne_permute(ctx, K4, 0, 2, 1, 3); /* ne = {hs, sl_kv, heads_kv, bs} */
+  struct ne_tensor* V = ne_permute(ctx, V4, 1, 2, 0, 3); /* ne = {sl_kv, hs, heads_kv, bs} */
+  struct ne_tensor* O = ne_flash_attn(ctx, Q, K, V, scale, (ne_attn_flags_t)flags);
+  run_graph(ctx, O);
+  memcpy(out, O->data, nq * 4);
+  ne_free(ctx);
+  return 0;
+}

@@ -149,6 +149,7 @@ def neref(product_lib_path=None):
         _neref.neref_ffn_silu.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, i, i, i]
         _neref.neref_mul_qkv.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, i, i, i]
         _neref.neref_norm.argtypes = [vp, vp, i, i, f, i]
+        _neref.neref_flash_attn.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, f, C.c_uint]
         _neref.neref_attn_unfused.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, i]
     elif product_lib_path and _neref.provider != product_lib_path:
         raise RuntimeError("libne_ref.so is already loaded without (or with another) bestla_* provider")
@@ -175,6 +176,18 @@ def neref_norm(x, eps, is_rms):
     x = np.ascontiguousarray(x, np.float32)
     out = np.zeros_like(x)
     assert neref().neref_norm(ptr(x), ptr(out), x.shape[0], x.shape[1], eps, 1 if is_rms else 0) == 0
+    return out
+
+
+def neref_flash_attn(q, k, v, qk_scale, flags):
+    """the reference graph's fused-attention node (ne_flash_attn); needs a bestla_* provider.  attn_ref's layouts."""
+    q = np.ascontiguousarray(q, np.float32)
+    k = np.ascontiguousarray(k, np.float16)
+    v = np.ascontiguousarray(v, np.float16)
+    bs, sl_q, hn, hs = q.shape
+    sl_kv, hkv = v.shape[1], v.shape[2]
+    out = np.zeros_like(q)
+    assert neref().neref_flash_attn(ptr(q), ptr(k), ptr(v), ptr(out), bs, hn, hkv, hs, sl_q, sl_kv, qk_scale, flags) == 0
     return out
 
 

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <string.h>
 
+#include "../../include/ns_bestla.h" /* the C ABI under test: struct layouts of the attention surface */
+
 struct mock_call {
   int which; /* 1 = f32f32_forward, 2 = FFN SiLU, 3 = QKV */
   int m, n, k, lda, ldo;
@@ -14,6 +16,14 @@ struct mock_call {
 };
 static struct mock_call g_last;
 const struct mock_call* mock_last_call(void) { return &g_last; }
+
+static attn_fp32_fp16_fp16_fp32_fwd_args_t g_attn;
+const attn_fp32_fp16_fp16_fp32_fwd_args_t* mock_last_attn(void) { return &g_attn; }
+size_t bestla_fusion_attn_workspace_size(const attn_shape_t* p) { return (size_t)p->head_num * p->sl_q * 16; }
+void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* p) {
+  g_attn = *p;
+  for (int i = 0; i < p->batch_size * p->sl_q * p->head_num * p->head_size; i++) p->dst[i] = 3.f;
+}
 
 void bestla_init(void) {}
 int bestla_set_threads(int n) { return n > 0 ? n : 1; }

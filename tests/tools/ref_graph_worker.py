@@ -69,6 +69,29 @@ def main(kind):
         # ne_compute_forward_mul_qkv (ne_layers.c:8050): (src, qw, kw, vw, dst, m, n, k, lda = k, ldo = n, wdata)
         assert (lc.which, lc.m, lc.n, lc.k, lc.lda, lc.ldo) == (3, m, ff, d, d, ff)
         assert (lc.w1, lc.w2, lc.w3) == (bq.ctypes.data, bk.ctypes.data, bv.ctypes.data) and np.all(qkv == 7.0)
+        # fused-attention node: the tensors' nb[] strides become the args struct of include/ns_bestla.h
+        class AttnArgsC(C.Structure):
+            _fields_ = ([("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("dst", C.c_void_p)] +
+                        [(n_, C.c_float) for n_ in ("Q_sc", "K_sc", "V_sc", "dst_sc")] + [("tmp", C.c_void_p), ("QK_scale", C.c_float),
+                         ("attn_flags", C.c_uint32)] +
+                        [(n_, C.c_int) for n_ in ("batch_size", "head_num", "heads_kv", "head_size", "sl_q", "sl_kv", "Q_layout",
+                                                  "K_layout", "V_layout", "dst_layout", "step_q_bs", "step_q_head_num", "step_q_sl",
+                                                  "step_k_bs", "step_k_head_num", "step_k_sl", "step_k_head_size", "step_v_bs",
+                                                  "step_v_head_num", "step_v_sl", "step_v_head_size", "step_dst_bs",
+                                                  "step_dst_head_num", "step_dst_sl")])
+        bs_, hn, hkv, hs, slq, slkv = 2, 8, 2, 64, 3, 11
+        qa = rng.standard_normal((bs_, slq, hn, hs)).astype(np.float32)
+        ka = rng.standard_normal((bs_, slkv, hkv, hs)).astype(np.float16)
+        va = rng.standard_normal((bs_, slkv, hkv, hs)).astype(np.float16)
+        o = nso.neref_flash_attn(qa, ka, va, 0.125, 1)
+        mock.mock_last_attn.restype = C.POINTER(AttnArgsC)
+        g = mock.mock_last_attn().contents
+        assert (g.batch_size, g.head_num, g.heads_kv, g.head_size, g.sl_q, g.sl_kv) == (bs_, hn, hkv, hs, slq, slkv)
+        assert (g.step_q_bs, g.step_q_head_num, g.step_q_sl) == (slq * hn * hs, hs, hn * hs)
+        assert (g.step_k_bs, g.step_k_head_num, g.step_k_sl, g.step_k_head_size) == (slkv * hkv * hs, hs, hkv * hs, 1)
+        assert (g.step_v_bs, g.step_v_head_num, g.step_v_sl, g.step_v_head_size) == (slkv * hkv * hs, hs, hkv * hs, 1)
+        assert (g.step_dst_bs, g.step_dst_head_num, g.step_dst_sl) == (slq * hn * hs, hs, hn * hs)
+        assert abs(g.QK_scale - 0.125) < 1e-9 and g.attn_flags == 1 and g.tmp and np.all(o == 3.0)
         print("REF_GRAPH_MOCK_OK")
         return
     # the real product behind the reference's graph
@@ -87,6 +110,15 @@ def main(kind):
     assert ne.neref_mul_qkv(nso.ptr(a), nso.ptr(bq), bq.size, nso.ptr(bk), bk.size, nso.ptr(bv), bv.size, nso.ptr(qkv), m, ff, d) == 0
     for i, b in enumerate((bq, bk, bv)):
         assert nso.rel_l2(qkv[i], nso.gemm_f64(a, b)) < 1e-3
+    # fused-attention node (ne_flash_attn): the reference marshals tensor strides, the product's kernel answers; GQA,
+    # causal with sl_q < sl_kv, batch 2.  (The reference reads the flags back as a bool, ne_layers.c:10168: causal only.)
+    bs_, hn, hkv, hs, slq, slkv = 2, 8, 2, 64, 3, 11
+    qa = rng.standard_normal((bs_, slq, hn, hs)).astype(np.float32)
+    ka = rng.standard_normal((bs_, slkv, hkv, hs)).astype(np.float16)
+    va = rng.standard_normal((bs_, slkv, hkv, hs)).astype(np.float16)
+    for flags in (1, 0):
+        o = nso.neref_flash_attn(qa, ka, va, hs ** -0.5, flags)
+        assert nso.rel_l2(o, nso.attn_ref(qa, ka, va, hs ** -0.5, flags)) < 1e-3
     # ne_rms_norm / ne_norm nodes: their forwards call bestla_layernormalization unconditionally (ne_layers.c:4622)
     x = rng.standard_normal((5, 300)).astype(np.float32)
     xd = x.astype(np.float64)
