@@ -257,3 +257,45 @@ int neref_flash_attn(const float* q, const uint16_t* k, const uint16_t* v, float
   ne_free(ctx);
   return 0;
 }
+
+/* The remaining fused nodes of the path (ne_layers.c:7945-8022, :8076-8170):
+ *   kind 0  ne_mul_mat_with_bias(w1, bias[1][n], x)            -> bestla_fusion_add_f32f32_forward (broadcast bias)
+ *   kind 1  ne_ffn_gelu(w1, w2, x)                              -> bestla_fusion_FFN_GeLu_f32f32_forward
+ *   kind 2  ne_ffn_add_gelu(w1, w2, b1[1][ff], b2[1][d], x)     -> bestla_fusion_FFN_Add_GeLu_f32f32_forward
+ *   kind 3  ne_ffn_gelu_mul(w1, w2, w3, x)                      -> bestla_fusion_FFN_Gelu_Mul_f32f32_forward
+ * w1, w3: [ff x d]; w2: [d x ff]; x: [m][d]; out: [m][ff] for kind 0, [m][d] otherwise. */
+int neref_fused(int kind, const float* a, void* b1w, size_t s1, void* b2w, size_t s2, void* b3w, size_t s3, const float* bias1,
+                const float* bias2, float* out, int m, int d, int ff) {
+  struct ne_init_params ip = {(size_t)m * (d * 2 + ff * 3) * 4 + (size_t)(d + ff) * 4 + (64u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  struct ne_init_params ipw = {1u << 20, NULL, true};
+  struct ne_context* wctx = ne_init(ipw);
+  if (!ctx || !wctx) return -1;
+  struct ne_tensor* w1 = btla_tensor(wctx, b1w, s1, d, ff);
+  struct ne_tensor* w2 = b2w ? btla_tensor(wctx, b2w, s2, ff, d) : NULL;
+  struct ne_tensor* w3 = b3w ? btla_tensor(wctx, b3w, s3, d, ff) : NULL;
+  struct ne_tensor* x = ne_new_tensor_2d(ctx, NE_TYPE_F32, d, m, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(x->data, a, (size_t)m * d * 4);
+  struct ne_tensor *t1 = NULL, *t2 = NULL;
+  if (bias1) {
+    t1 = ne_new_tensor_2d(ctx, NE_TYPE_F32, ff, 1, NE_SIZE_CALC, NE_BACKEND_CPU);
+    memcpy(t1->data, bias1, (size_t)ff * 4);
+  }
+  if (bias2) {
+    t2 = ne_new_tensor_2d(ctx, NE_TYPE_F32, d, 1, NE_SIZE_CALC, NE_BACKEND_CPU);
+    memcpy(t2->data, bias2, (size_t)d * 4);
+  }
+  struct ne_tensor* y = NULL;
+  switch (kind) {
+    case 0: y = ne_mul_mat_with_bias(ctx, w1, t1, x); break;
+    case 1: y = ne_ffn_gelu(ctx, w1, w2, x); break;
+    case 2: y = ne_ffn_add_gelu(ctx, w1, w2, t1, t2, x); break;
+    case 3: y = ne_ffn_gelu_mul(ctx, w1, w2, w3, x); break;
+    default: return -1;
+  }
+  run_graph(ctx, y);
+  memcpy(out, y->data, (size_t)m * (kind == 0 ? ff : d) * 4);
+  ne_free(ctx);
+  ne_free(wctx);
+  return 0;
+}

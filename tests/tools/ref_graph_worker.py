@@ -110,6 +110,22 @@ def main(kind):
     assert ne.neref_mul_qkv(nso.ptr(a), nso.ptr(bq), bq.size, nso.ptr(bk), bk.size, nso.ptr(bv), bv.size, nso.ptr(qkv), m, ff, d) == 0
     for i, b in enumerate((bq, bk, bv)):
         assert nso.rel_l2(qkv[i], nso.gemm_f64(a, b)) < 1e-3
+    # the other fused nodes of the path: bias add, FFN GeLU / Add_GeLU / GeLU_Mul
+    def gelu(x):
+        return 0.5 * x * (1 + np.tanh(0.7978845834732056 * (x + 0.044714998453855515 * x ** 3)))
+
+    def fused(kind_, w1, w2=None, w3=None, bias1=None, bias2=None, n_out=d):
+        o = np.zeros((m, n_out), np.float32)
+        sz = lambda b: (nso.ptr(b), b.size) if b is not None else (None, 0)
+        assert ne.neref_fused(kind_, nso.ptr(a), *sz(w1), *sz(w2), *sz(w3), nso.ptr(bias1), nso.ptr(bias2), nso.ptr(o), m, d, ff) == 0
+        return o
+    bi1 = rng.standard_normal(ff).astype(np.float32)
+    bi2 = rng.standard_normal(d).astype(np.float32)
+    g1 = nso.gemm_f64(a, b1)
+    assert nso.rel_l2(fused(0, b1, bias1=bi1, n_out=ff), g1 + bi1) < 1e-3
+    assert nso.rel_l2(fused(1, b1, b2), nso.gemm_f64(gelu(g1).astype(np.float32), b2)) < 2e-3
+    assert nso.rel_l2(fused(2, b1, b2, bias1=bi1, bias2=bi2), nso.gemm_f64(gelu(g1 + bi1).astype(np.float32), b2) + bi2) < 2e-3
+    assert nso.rel_l2(fused(3, b1, b2, b3), nso.gemm_f64((gelu(g1) * nso.gemm_f64(a, b3)).astype(np.float32), b2)) < 2e-3
     # fused-attention node (ne_flash_attn): the reference marshals tensor strides, the product's kernel answers; GQA,
     # causal with sl_q < sl_kv, batch 2.  (The reference reads the flags back as a bool, ne_layers.c:10168: causal only.)
     bs_, hn, hkv, hs, slq, slkv = 2, 8, 2, 64, 3, 11
