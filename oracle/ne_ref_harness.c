@@ -17,6 +17,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #include "ne.h"
@@ -295,6 +296,59 @@ int neref_fused(int kind, const float* a, void* b1w, size_t s1, void* b2w, size_
   }
   run_graph(ctx, y);
   memcpy(out, y->data, (size_t)m * (kind == 0 ? ff : d) * 4);
+  ne_free(ctx);
+  ne_free(wctx);
+  return 0;
+}
+
+/* One Llama-style decoder layer over T tokens (prefill, no cache) written the way the reference's model code builds it
+ * (models/llama/llama.cpp:200-330, fused branch): rms_norm * g -> fused QKV -> views -> RoPE(q), RoPE(k) -> K, V copied
+ * to fp16 -> permuted views -> flash_attn (causal) -> attention output projection -> residual -> rms_norm * g ->
+ * fused FFN (SiLU) -> residual.  Every compute node reaches the bestla_* provider; views, permutes, reshapes and the
+ * fp32 -> fp16 copies are the reference's own code.  x, out: fp32 [T][d]; g1, g2: [d]; MHA (heads_kv == heads). */
+int neref_decoder_layer(const float* x, float* out, int T, int d, int heads, int ff, float eps, float freq_base, const float* g1,
+                        const float* g2, void* bq, size_t sq, void* bk, size_t sk, void* bv, size_t sv, void* bo, size_t so,
+                        void* b1, size_t s1, void* b2, size_t s2, void* b3, size_t s3) {
+  const int hs = d / heads;
+  struct ne_init_params ip = {(size_t)T * (d * 16 + ff * 4) * 4 + (size_t)heads * T * T * 4 + (256u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  struct ne_init_params ipw = {1u << 20, NULL, true};
+  struct ne_context* wctx = ne_init(ipw);
+  if (!ctx || !wctx) return -1;
+  struct ne_tensor* wq = btla_tensor(wctx, bq, sq, d, d);
+  struct ne_tensor* wk = btla_tensor(wctx, bk, sk, d, d);
+  struct ne_tensor* wv = btla_tensor(wctx, bv, sv, d, d);
+  struct ne_tensor* wo = btla_tensor(wctx, bo, so, d, d);
+  struct ne_tensor* w1 = btla_tensor(wctx, b1, s1, d, ff);
+  struct ne_tensor* w2 = btla_tensor(wctx, b2, s2, ff, d);
+  struct ne_tensor* w3 = btla_tensor(wctx, b3, s3, d, ff);
+  struct ne_tensor* inp = ne_new_tensor_2d(ctx, NE_TYPE_F32, d, T, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(inp->data, x, (size_t)T * d * 4);
+  struct ne_tensor* G1 = ne_new_tensor_1d(ctx, NE_TYPE_F32, d, NE_SIZE_CALC, NE_BACKEND_CPU);
+  struct ne_tensor* G2 = ne_new_tensor_1d(ctx, NE_TYPE_F32, d, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(G1->data, g1, (size_t)d * 4);
+  memcpy(G2->data, g2, (size_t)d * 4);
+
+  struct ne_tensor* cur = ne_mul(ctx, ne_rms_norm(ctx, inp, eps), G1);
+  struct ne_tensor* qkv = ne_mul_qkv(ctx, wq, wk, wv, cur); /* [d, T, 3] */
+  const size_t fsz = sizeof(float);
+  struct ne_tensor* Qc = ne_view_3d(ctx, qkv, hs, heads, T, hs * fsz, (size_t)d * fsz, 0);
+  struct ne_tensor* Kc = ne_view_3d(ctx, qkv, hs, heads, T, hs * fsz, (size_t)d * fsz, (size_t)1 * T * d * fsz);
+  struct ne_tensor* Vc = ne_view_3d(ctx, qkv, hs, heads, T, hs * fsz, (size_t)d * fsz, (size_t)2 * T * d * fsz);
+  Qc = ne_rope_inplace(ctx, Qc, 0, hs, 0, 0, freq_base, 1.0f);
+  Kc = ne_rope_inplace(ctx, Kc, 0, hs, 0, 0, freq_base, 1.0f);
+  struct ne_tensor* K16 = ne_cpy(ctx, Kc, ne_new_tensor_3d(ctx, NE_TYPE_F16, hs, heads, T, NE_SIZE_CALC, NE_BACKEND_CPU));
+  struct ne_tensor* V16 = ne_cpy(ctx, Vc, ne_new_tensor_3d(ctx, NE_TYPE_F16, hs, heads, T, NE_SIZE_CALC, NE_BACKEND_CPU));
+  struct ne_tensor* Q = ne_permute(ctx, Qc, 0, 2, 1, 3);  /* {hs, T, heads} */
+  struct ne_tensor* K = ne_permute(ctx, K16, 0, 2, 1, 3); /* {hs, T, heads} */
+  struct ne_tensor* V = ne_permute(ctx, V16, 1, 2, 0, 3); /* {T, hs, heads} */
+  struct ne_tensor* att = ne_flash_attn(ctx, Q, K, V, 1.0f / sqrtf((float)hs), NE_ATTN_FLAG_IS_CAUSAL); /* {hs, heads, T} */
+  struct ne_tensor* att2 = ne_reshape_2d(ctx, att, d, T);
+  struct ne_tensor* r1 = ne_add(ctx, inp, ne_mul_mat(ctx, wo, att2));
+  struct ne_tensor* h2 = ne_mul(ctx, ne_rms_norm(ctx, r1, eps), G2);
+  struct ne_tensor* y = ne_add(ctx, r1, ne_ffn_silu(ctx, w1, w2, w3, h2));
+  run_graph(ctx, y);
+  memcpy(out, y->data, (size_t)T * d * 4);
   ne_free(ctx);
   ne_free(wctx);
   return 0;

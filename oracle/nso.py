@@ -151,6 +151,7 @@ def neref(product_lib_path=None):
         _neref.neref_norm.argtypes = [vp, vp, i, i, f, i]
         _neref.neref_flash_attn.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, f, C.c_uint]
         _neref.neref_fused.argtypes = [i, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, i, i, i]
+        _neref.neref_decoder_layer.argtypes = [vp, vp, i, i, i, i, f, f, vp, vp] + [vp, C.c_size_t] * 7
         _neref.neref_attn_unfused.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, i]
     elif product_lib_path and _neref.provider != product_lib_path:
         raise RuntimeError("libne_ref.so is already loaded without (or with another) bestla_* provider")

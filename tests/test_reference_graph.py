@@ -31,3 +31,13 @@ def test_reference_graph_marshalling_with_mock_provider():
         pytest.skip("no gcc")
     assert "REF_GRAPH_MOCK_OK" in run_worker("mock")
 
+
+
+def test_reference_graph_decoder_layer_with_oracle_provider():
+    """A whole Llama-style decoder layer built the way the reference's model code builds it (fused QKV, views, RoPE,
+    fp16 K / V copies, permuted views, flash_attn, fused FFN, residuals) and executed by the reference's graph executor as
+    ONE graph; here the CPU oracle answers the bestla_* calls (tests/tools/oracle_bestla_provider.c), on the GPU
+    libns_hip.so does (tests/test_gpu_reference_graph.py runs the same graph)."""
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    assert "REF_GRAPH_ORACLE_OK" in run_worker("oracle")

@@ -1,0 +1,93 @@
+/* TEST INFRASTRUCTURE: the part-1 surface of include/ns_bestla.h answered by the CPU ORACLE (oracle/libns_oracle.so).
+ * It exists for one purpose: to debug and check, on a box without a GPU, multi-node graphs that the reference's own
+ * executor (oracle/_ref/libne_ref.so) runs over BTLA tensors — the same graphs then run on libns_hip.so in the GPU test.
+ * Never shipped, never loaded by the product, never measured. */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/ns_bestla.h"
+#include "../../oracle/ns_oracle.h"
+
+void bestla_init(void) {}
+void bestla_timer(bool m) { (void)m; }
+int bestla_set_threads(int n) { return n > 0 ? n : 1; }
+unsigned long long bestla_f32f32_get_workspace_size(int m, int n, int k, void* w) {
+  (void)n, (void)w;
+  return (unsigned long long)m * k * 4;
+}
+unsigned long long bestla_fusion_QKV_f32f32_get_workspace_size(int m, int n, int k, void* w) {
+  (void)n, (void)w;
+  return (unsigned long long)m * k * 4;
+}
+unsigned long long bestla_fusion_FFN_f32f32_get_workspace_size(int seq, int fin, int fmid, int fout, void* w1, void* w2) {
+  (void)fin, (void)fout, (void)w1, (void)w2;
+  return (unsigned long long)seq * fmid * 4;
+}
+size_t bestla_fusion_attn_workspace_size(const attn_shape_t* p) { return (size_t)p->head_num * p->sl_q * 16 + 64; }
+
+static void gemm(const float* a, int lda, void* w, float* c, int ldc, int m, int n) {
+  double* t = (double*)malloc((size_t)m * n * sizeof(double));
+  if (nso_gemm_f64(a, lda, w, t, n, m)) abort();
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < n; j++) c[(size_t)i * ldc + j] = (float)t[(size_t)i * n + j];
+  free(t);
+}
+void bestla_f32f32_forward(float* a, void* w, float* c, int m, int n, int k, int lda, int ldo, void* ws) {
+  (void)k, (void)ws;
+  gemm(a, lda, w, c, ldo, m, n);
+}
+void bestla_fusion_QKV_f32f32_forward(float* a, void* wq, void* wk, void* wv, float* out, int m, int n, int k, int lda, int ldo,
+                                      void* ws) {
+  (void)k, (void)ws;
+  gemm(a, lda, wq, out, ldo, m, n);
+  gemm(a, lda, wk, out + (size_t)m * ldo, ldo, m, n);
+  gemm(a, lda, wv, out + (size_t)2 * m * ldo, ldo, m, n);
+}
+void bestla_fusion_FFN_SiLu_f32f32_forward(float* a, void* w1, void* w2, void* w3, float* t1, float* t2, float* out, int seq,
+                                           int fin, int fmid, int fout, void* ws) {
+  (void)ws;
+  gemm(a, fin, w1, t1, fmid, seq, fmid);
+  gemm(a, fin, w3, t2, fmid, seq, fmid);
+  for (size_t i = 0; i < (size_t)seq * fmid; i++) t2[i] = t2[i] * nso_silu(t1[i]);
+  gemm(t2, fmid, w2, out, fout, seq, fout);
+}
+void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* p) {
+  nso_attn_args a;
+  memset(&a, 0, sizeof(a));
+  a.q = p->Q, a.k = p->K, a.v = p->V, a.dst = p->dst;
+  a.q_sc = p->Q_sc, a.k_sc = p->K_sc, a.v_sc = p->V_sc, a.dst_sc = p->dst_sc, a.qk_scale = p->QK_scale;
+  a.flags = p->attn_flags & 3u;
+  a.batch_size = p->batch_size, a.head_num = p->head_num, a.heads_kv = p->heads_kv, a.head_size = p->head_size;
+  a.sl_q = p->sl_q, a.sl_kv = p->sl_kv;
+  a.step_q_bs = p->step_q_bs, a.step_q_head_num = p->step_q_head_num, a.step_q_sl = p->step_q_sl;
+  a.step_k_bs = p->step_k_bs, a.step_k_head_num = p->step_k_head_num, a.step_k_sl = p->step_k_sl;
+  a.step_k_head_size = p->step_k_head_size;
+  a.step_v_bs = p->step_v_bs, a.step_v_head_num = p->step_v_head_num, a.step_v_sl = p->step_v_sl;
+  a.step_dst_bs = p->step_dst_bs, a.step_dst_head_num = p->step_dst_head_num, a.step_dst_sl = p->step_dst_sl;
+  if (nso_attn_ref(&a, 0)) abort();
+}
+void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* out) {
+  for (int r = 0; r < norm_count; r++) {
+    const float* x = in + (size_t)r * norm_size;
+    float* y = out + (size_t)r * norm_size;
+    double mean = 0, sq = 0;
+    for (int i = 0; i < norm_size; i++) mean += x[i], sq += (double)x[i] * x[i];
+    mean /= norm_size;
+    if (isrms) {
+      const double s = 1.0 / sqrt(sq / norm_size + eps);
+      for (int i = 0; i < norm_size; i++) y[i] = (float)(x[i] * s);
+    } else {
+      const double var = sq / norm_size - mean * mean, s = 1.0 / sqrt(var + eps);
+      for (int i = 0; i < norm_size; i++) y[i] = (float)((x[i] - mean) * s);
+    }
+  }
+}
+void bestla_mul(int batch, int vsize, const float* t, const float* v, int vstep, float* out) {
+  for (int b = 0; b < batch; b++)
+    for (int i = 0; i < vsize; i++) out[(size_t)b * vsize + i] = t[(size_t)b * vsize + i] * v[(size_t)b * vstep + i];
+}
+void bestla_add(int batch, int vsize, const float* t, const float* v, int vstep, float* out) {
+  for (int b = 0; b < batch; b++)
+    for (int i = 0; i < vsize; i++) out[(size_t)b * vsize + i] = t[(size_t)b * vsize + i] + v[(size_t)b * vstep + i];
+}

@@ -31,9 +31,74 @@ def blobs(rng, shapes, bs=32):
     return out
 
 
+def decoder_layer_case(ne, rng):
+    """A whole decoder layer as ONE reference graph (neref_decoder_layer) against an fp64 model of the same layer built
+    from the dequantized weights."""
+    T, d, heads, ff, eps, base = 6, 256, 4, 704, 1e-5, 10000.0
+    hs = d // heads
+
+    def qw(n, k):
+        w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+        b = nso.quant_pack(w, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+        return b, nso.unpack_fp32(b).astype(np.float64)   # dequantized [k][n]
+    (bq, Wq), (bk, Wk), (bv, Wv), (bo, Wo) = qw(d, d), qw(d, d), qw(d, d), qw(d, d)
+    (b1, W1), (b3, W3), (b2, W2) = qw(ff, d), qw(ff, d), qw(d, ff)
+    g1 = (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    g2 = (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    x = rng.standard_normal((T, d)).astype(np.float32)
+    out = np.zeros_like(x)
+    args = []
+    for b in (bq, bk, bv, bo, b1, b2, b3):
+        args += [nso.ptr(b), b.size]
+    assert ne.neref_decoder_layer(nso.ptr(x), nso.ptr(out), T, d, heads, ff, eps, base, nso.ptr(g1), nso.ptr(g2), *args) == 0
+
+    def rms(v, g):
+        return v / np.sqrt((v * v).mean(-1, keepdims=True) + eps) * g
+
+    def rope(v):   # [T][heads][hs], mode 0 (adjacent pairs), positions 0..T-1
+        o = v.copy()
+        ts = base ** (-2.0 / hs)
+        for i in range(T):
+            th = i * ts ** np.arange(hs // 2)
+            c, s_ = np.cos(th), np.sin(th)
+            x0, x1 = v[i, :, 0::2], v[i, :, 1::2]
+            o[i, :, 0::2] = x0 * c - x1 * s_
+            o[i, :, 1::2] = x0 * s_ + x1 * c
+        return o
+    xd = x.astype(np.float64)
+    h = rms(xd, g1)
+    q = rope((h @ Wq).reshape(T, heads, hs))
+    k = rope((h @ Wk).reshape(T, heads, hs)).astype(np.float16).astype(np.float64)   # kv tensors are fp16
+    v = (h @ Wv).reshape(T, heads, hs).astype(np.float16).astype(np.float64)
+    att = np.zeros((T, heads, hs))
+    for hd in range(heads):
+        sc = (q[:, hd] @ k[:, hd].T) / np.sqrt(hs)
+        sc = np.where(np.tril(np.ones((T, T), bool)), sc, -np.inf)
+        pr = np.exp(sc - sc.max(-1, keepdims=True))
+        att[:, hd] = (pr / pr.sum(-1, keepdims=True)) @ v[:, hd]
+    r1 = xd + att.reshape(T, d) @ Wo
+    h2 = rms(r1, g2)
+    gate = h2 @ W1
+    ref = r1 + (gate / (1 + np.exp(-gate)) * (h2 @ W3)) @ W2
+    err = nso.rel_l2(out, ref)
+    assert err < 3e-3, err
+    return err
+
+
 def main(kind):
     rng = np.random.default_rng(21)
     m, d, ff = 3, 256, 512
+    if kind == "oracle":
+        # the CPU oracle answers the bestla_* calls: multi-node reference graphs can be checked without a GPU
+        so = os.path.join(tempfile.mkdtemp(), "liboracle_bestla.so")
+        nso.build()
+        subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "tools", "oracle_bestla_provider.c"),
+                               "-L" + os.path.join(ROOT, "oracle"), "-lns_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lm"])
+        ne = nso.neref(so)
+        assert ne is not None, "oracle/_ref/libne_ref.so missing"
+        print("decoder layer through the reference graph, oracle provider: rel l2 %.2e" % decoder_layer_case(ne, rng))
+        print("REF_GRAPH_ORACLE_OK")
+        return
     if kind == "mock":
         so = os.path.join(tempfile.mkdtemp(), "libmock_bestla.so")
         subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "tools", "mock_bestla_provider.c")])
@@ -140,6 +205,7 @@ def main(kind):
     xd = x.astype(np.float64)
     assert nso.rel_l2(nso.neref_norm(x, 1e-6, True), xd / np.sqrt((xd ** 2).mean(-1, keepdims=True) + 1e-6)) < 1e-6
     assert nso.rel_l2(nso.neref_norm(x, 1e-5, False), (xd - xd.mean(-1, keepdims=True)) / np.sqrt(xd.var(-1, keepdims=True) + 1e-5)) < 1e-5
+    print("decoder layer through the reference graph on libns_hip.so: rel l2 %.2e" % decoder_layer_case(ne, rng))
     print("REF_GRAPH_PRODUCT_OK")
 
 
