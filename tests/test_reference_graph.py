@@ -40,4 +40,8 @@ def test_reference_graph_decoder_layer_with_oracle_provider():
     libns_hip.so does (tests/test_gpu_reference_graph.py runs the same graph)."""
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
-    assert "REF_GRAPH_ORACLE_OK" in run_worker("oracle")
+    out = run_worker("oracle")
+    assert "REF_GRAPH_ORACLE_OK" in out
+    # BASELINE config 1 (plumbing, no GPU): a GPT-2-small-shaped 12-layer decoder, int4 g32, greedy decode, every layer one
+    # reference graph, lm_head through ne_mul_mat — identical token ids with an fp64 model of the network
+    assert "config 1 (GPT-2-small-shaped greedy decode through the reference graph): tokens" in out

@@ -85,6 +85,93 @@ def decoder_layer_case(ne, rng):
     return err
 
 
+def gpt2_small_greedy(ne, n_new=4):
+    """BASELINE config 1 (plumbing): a GPT-2-small-SHAPED decoder (12 layers, d 768, 12 heads, d_ff 3072, vocab 50257 —
+    neural-speed has no GPT-2 graph, SURVEY.md section 8d restates the case on the Llama-style layer it does have), int4
+    sym g32 weights, greedy decode, every layer ONE reference graph (neref_decoder_layer), lm_head through ne_mul_mat.
+    Pass = the same token ids as an independent fp64 model of the network."""
+    rng = np.random.default_rng(1234)
+    L_, d, heads, ff, V, eps, base = 12, 768, 12, 3072, 50257, 1e-5, 10000.0
+    hs = d // heads
+
+    def qw(n, k, std):
+        w = (rng.standard_normal((n, k)) * std).astype(np.float32)
+        b = nso.quant_pack(w, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+        return b, nso.unpack_fp32(b).astype(np.float64)
+    layers = []
+    for _ in range(L_):
+        lw = dict(q=qw(d, d, d ** -0.5), k=qw(d, d, d ** -0.5), v=qw(d, d, d ** -0.5), o=qw(d, d, 0.5 * d ** -0.5),
+                  w1=qw(ff, d, d ** -0.5), w3=qw(ff, d, d ** -0.5), w2=qw(d, ff, 0.5 * ff ** -0.5),
+                  g1=(1 + 0.1 * rng.standard_normal(d)).astype(np.float32), g2=(1 + 0.1 * rng.standard_normal(d)).astype(np.float32))
+        layers.append(lw)
+    emb = (rng.standard_normal((V, d)) * 0.5).astype(np.float32)
+    gf = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    head_b, head_W = qw(V, d, d ** -0.5)
+
+    def rms(v, g):
+        return v / np.sqrt((v * v).mean(-1, keepdims=True) + eps) * g
+
+    def rope(v):
+        T = v.shape[0]
+        o = v.copy()
+        ts = base ** (-2.0 / hs)
+        for i in range(T):
+            th = i * ts ** np.arange(hs // 2)
+            c, s_ = np.cos(th), np.sin(th)
+            x0, x1 = v[i, :, 0::2], v[i, :, 1::2]
+            o[i, :, 0::2] = x0 * c - x1 * s_
+            o[i, :, 1::2] = x0 * s_ + x1 * c
+        return o
+
+    def model_fp64(tokens):
+        T = len(tokens)
+        x = emb[tokens].astype(np.float64)
+        for lw in layers:
+            h = rms(x, lw["g1"])
+            q = rope((h @ lw["q"][1]).reshape(T, heads, hs))
+            k = rope((h @ lw["k"][1]).reshape(T, heads, hs)).astype(np.float16).astype(np.float64)
+            v = (h @ lw["v"][1]).reshape(T, heads, hs).astype(np.float16).astype(np.float64)
+            att = np.zeros((T, heads, hs))
+            for hd in range(heads):
+                sc = (q[:, hd] @ k[:, hd].T) / np.sqrt(hs)
+                sc = np.where(np.tril(np.ones((T, T), bool)), sc, -np.inf)
+                pr = np.exp(sc - sc.max(-1, keepdims=True))
+                att[:, hd] = (pr / pr.sum(-1, keepdims=True)) @ v[:, hd]
+            r1 = x + att.reshape(T, d) @ lw["o"][1]
+            h2 = rms(r1, lw["g2"])
+            gate = h2 @ lw["w1"][1]
+            x = r1 + (gate / (1 + np.exp(-gate)) * (h2 @ lw["w3"][1])) @ lw["w2"][1]
+        return rms(x[-1:], gf) @ head_W
+
+    def model_graph(tokens):
+        T = len(tokens)
+        x = np.ascontiguousarray(emb[tokens])
+        for lw in layers:
+            out = np.zeros_like(x)
+            args = []
+            for key in ("q", "k", "v", "o", "w1", "w2", "w3"):
+                args += [nso.ptr(lw[key][0]), lw[key][0].size]
+            assert ne.neref_decoder_layer(nso.ptr(x), nso.ptr(out), T, d, heads, ff, eps, base, nso.ptr(lw["g1"]), nso.ptr(lw["g2"]), *args) == 0
+            x = out
+        last = np.ascontiguousarray((rms(x[-1:].astype(np.float64), gf)).astype(np.float32))
+        logits = np.zeros((1, V), np.float32)
+        assert ne.neref_mul_mat(nso.ptr(last), nso.ptr(head_b), head_b.size, nso.ptr(logits), 1, V, d) == 0
+        return logits
+
+    prompt = [464, 3290, 318, 257]
+    t_ref, t_graph = list(prompt), list(prompt)
+    margins = []
+    for _ in range(n_new):
+        lr, lg = model_fp64(t_ref)[0], model_graph(t_graph)[0]
+        top2 = np.sort(lr)[-2:]
+        margins.append(float(top2[1] - top2[0]))
+        t_ref.append(int(np.argmax(lr)))
+        t_graph.append(int(np.argmax(lg)))
+        assert nso.rel_l2(lg[None], lr[None]) < 5e-3
+    assert t_graph == t_ref, (t_graph, t_ref)
+    return t_graph[len(prompt):], margins
+
+
 def main(kind):
     rng = np.random.default_rng(21)
     m, d, ff = 3, 256, 512
@@ -97,6 +184,10 @@ def main(kind):
         ne = nso.neref(so)
         assert ne is not None, "oracle/_ref/libne_ref.so missing"
         print("decoder layer through the reference graph, oracle provider: rel l2 %.2e" % decoder_layer_case(ne, rng))
+        if os.environ.get("NS_REF_GRAPH_GPT2", "1") != "0":
+            toks, margins = gpt2_small_greedy(ne)
+            print("config 1 (GPT-2-small-shaped greedy decode through the reference graph): tokens", toks,
+                  "top-1 margins %s" % ["%.3f" % m for m in margins])
         print("REF_GRAPH_ORACLE_OK")
         return
     if kind == "mock":
