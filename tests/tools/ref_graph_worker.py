@@ -297,6 +297,9 @@ def main(kind):
     assert nso.rel_l2(nso.neref_norm(x, 1e-6, True), xd / np.sqrt((xd ** 2).mean(-1, keepdims=True) + 1e-6)) < 1e-6
     assert nso.rel_l2(nso.neref_norm(x, 1e-5, False), (xd - xd.mean(-1, keepdims=True)) / np.sqrt(xd.var(-1, keepdims=True) + 1e-5)) < 1e-5
     print("decoder layer through the reference graph on libns_hip.so: rel l2 %.2e" % decoder_layer_case(ne, rng))
+    if os.environ.get("NS_REF_GRAPH_GPT2_PRODUCT") == "1":   # opt-in until it has been run on a GPU box once
+        toks, margins = gpt2_small_greedy(ne)
+        print("config 1 on libns_hip.so: tokens", toks, "top-1 margins %s" % ["%.3f" % m_ for m_ in margins])
     print("REF_GRAPH_PRODUCT_OK")
 
 
