@@ -177,6 +177,12 @@ enum ns_compute_mode { NS_COMPUTE_FP16 = 0, NS_COMPUTE_REF_INT8 = 1 };
 int ns_hip_set_compute_mode(int mode);
 int ns_hip_get_compute_mode(void);
 
+/* Diagnostics / A-B switches of the decode kernels (process-wide, take effect at the next launch or capture):
+ *   "gemv2"  0 = first-generation streaming kernel only, 1 = second generation (default), 2 = second generation with
+ *            whole-tile workgroups only (no stream-K part);  also NS_GEMV2 in the environment.
+ * Returns 0, or -1 for an unknown key. */
+int ns_hip_set_tuning(const char* key, int value);
+
 /* epilogue selector for the device forwards */
 enum ns_epilogue {
   NS_EPI_NONE = 0,      /* AccumulatorWriteBackFp32 (bestla_epilogue.h:114-136) */

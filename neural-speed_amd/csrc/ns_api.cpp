@@ -678,6 +678,15 @@ int ns_hip_set_compute_mode(int mode) {
 }
 int ns_hip_get_compute_mode(void) { return g_compute_mode.load(); }
 
+int ns_hip_set_tuning(const char* key, int value) {
+  if (key && !strcmp(key, "gemv2")) {
+    set_gemv_mode(value);
+    return 0;
+  }
+  set_error("ns_hip_set_tuning: unknown key");
+  return -1;
+}
+
 int ns_hip_weight_prefetch(const ns_weight* w, uint64_t offset, uint64_t bytes, int workgroups, void* stream) {
   if (!have_device()) return -1;
   if (!w) {

@@ -686,7 +686,11 @@ static hipError_t launch_smallm_s(const SmallMParams& p, bool asym, bool dual, i
 bool smallm_dual_ok(int m) { return m <= 16; }
 
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
-  if (a.m <= 4) {  // token-by-token decode: the persistent, bandwidth-balanced kernel (ns_decode.hip)
+  if (a.m <= 16) {  // decode / small batches: the second-generation streaming kernel (ns_gemv.hip)
+    const hipError_t e = launch_gemv(a, st);
+    if (e != hipErrorNotSupported) return e;
+  }
+  if (a.m <= 4) {  // opt-in experiment (NS_DECODE_KERNEL=1): the persistent stream-K kernel of ns_decode.hip
     const hipError_t e = launch_decode(a, st);
     if (e != hipErrorNotSupported) return e;
   }
