@@ -160,7 +160,8 @@ hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, in
 // ns_gemv.hip: second-generation decode kernel (m <= 16): lean prologue, whole-tile + stream-K hybrid grid;
 // hipErrorNotSupported = outside its envelope (use smallm_kernel)
 hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st);
-void set_gemv_mode(int mode);  // 0 off, 1 on, 2 on without the stream-K part, -1 re-read NS_GEMV2
+void set_gemv_mode(int mode);
+int decode_waves(int grid, int ks, bool dual);  // waves per workgroup of a decode launch (both kernel generations)  // 0 off, 1 on, 2 on without the stream-K part, -1 re-read NS_GEMV2
 // ns_decode.hip: persistent stream-K kernel for m <= 4; hipErrorNotSupported = outside its envelope (use smallm)
 hipError_t launch_decode(const SmallMArgs& a, hipStream_t st);
 constexpr int kMaxDecodeGrid = 1024;                             // workgroups (= CUs) the fix-up workspace covers

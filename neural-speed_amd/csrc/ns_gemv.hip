@@ -3,26 +3,33 @@
 // Same arithmetic as smallm_kernel (ns_kernels.hip): per 1 KiB weight record NJ x v_mfma_f32_16x16x32_f16 on the raw
 // codes, the group scale applied to the fp32 MFMA result — exactly w = (code - zp) * scale with fp32 accumulation
 // (reference: bestla/bestla/kernel_ref.h:2489-2531 gemv_4bit_fp32_fp32, :1027-1127 decompress_kblock_s4_fp,
-// :1456-1478 decompress_kblock_f4_fp), fp16 activations.  What changed is everything AROUND the streaming loop,
-// because a decode launch on MI355X is latency-, not bandwidth-bound:
+// :1456-1478 decompress_kblock_f4_fp), fp16 activations; one workgroup = one 16-column tile over the whole K, waves
+// split the k-steps, deterministic cross-wave reduction.  What changed is everything AROUND the arithmetic, because a
+// decode launch on MI355X is latency-, not bandwidth-bound:
 //
 //   * lean prologue.  Every launch starts with cold instruction and scalar caches, so the time to the first weight
-//     request is the number of code lines and dependent kernarg fetches in front of it.  smallm_kernel had 1.8 KB of
-//     code and two kernarg round trips there (1.3-1.6 us); here the first 64 bytes of the argument block hold all the
-//     first loads need and the ring is filled within the first few cache lines of code.
-//   * balanced work.  MI355X shares HBM bandwidth per CU: 688 column tiles on 256 CUs leave 176 CUs with three tiles
-//     and 80 with two, and the launch ends 2 us after the light CUs went idle.  The grid is therefore a hybrid:
-//     whole tiles for floor(tiles / CUs) * CUs workgroups, and the remaining tiles cut into equal K-ranges over one
-//     workgroup per CU ("stream-K" part, dispatched first).  A tile shared by several workgroups is finished by the one
-//     that holds its first k-step; the others publish their partial sums through the weight's workspace (write-through
-//     stores + flag, no fences: 8 non-coherent L2s make an agent-scope release cost a whole-L2 write-back).  The
-//     stream-K workgroups are shorter than the whole-tile ones, so the hand-off is off the critical path.
-//     The same split lets a narrow tensor-parallel shard (fewer tiles than CUs) use every CU.
-//   * the activation vector is staged ONCE per workgroup and reused for every tile segment it streams.
+//     request is the number of code lines and of dependent kernel-argument fetches in front of it.  smallm_kernel had
+//     1.8 KB of code and two argument round trips there (first request 1.3-1.8 us after entry); here ONE batch of scalar
+//     loads fetches the 30 words the prologue needs (epilogue arguments are read late, through the argument pointer,
+//     so they neither delay the batch nor sit in SGPRs through the loop) and the ring is filled ~0.6 KB into the code.
+//   * weight records go HBM -> LDS directly (buffer_load ... lds into the wave's PRIVATE ring: codes, scales and zero
+//     points; no VGPRs, no cross-wave synchronisation).  The ring depth is therefore set by LDS, not by the register
+//     file: up to 8 records per wave, up to ~140 KiB per CU in flight from the first microsecond of a launch.
+//   * waits by hand.  No request of the stream returns to a register, so hipcc inserts no vmcnt waits of its own (it
+//     does not order an LDS read behind an LDS-DMA write at all); before a record is consumed the kernel waits for
+//     exactly the requests older than the ones that may stay in flight (requests retire in order): s_waitcnt
+//     vmcnt(OPS * min(PF - 1, records still to come)).  Nothing is ever requested that is not consumed (out-of-range
+//     "dead" requests were measured to cost a full pass through the address pipeline each, profiles/r02d-r02e).
+//
+// Tried here and dropped (profiles/r02a-r02b): cutting the 688 gate/up tiles into equal K-ranges over the CUs
+// ("stream-K") with partial sums handed between workgroups through write-through stores + flags.  The hand-off costs
+// 3-5 us under load (the poll queues behind the consumer CU's own weight requests) — more than the 2 us of imbalance it
+// removes in an 11 us launch; narrow tensor-parallel shards lost 3 us per launch to it.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -35,51 +42,61 @@ namespace ns {
 #ifndef NS_GV_PF
 #define NS_GV_PF 4
 #endif
-#ifndef NS_GV_PF_WIDE
-#define NS_GV_PF_WIDE 2
-#endif
-constexpr int kGvPF = NS_GV_PF;           // records each wave keeps in flight (<= 8-wave workgroups)
-constexpr int kGvPFWide = NS_GV_PF_WIDE;  // same for 16-wave workgroups (128-VGPR budget)
+// records each wave keeps in flight (fused gate/up: half of them per matrix).  A CU's memory pipeline holds about
+// 50 KiB of requests; beyond that the ISSUE of further requests stalls (profiles/r02h_wave_trace: ring fills of a
+// 24-wave CU complete 0.5 ... 6 us after entry), so a deeper ring only delays the other waves' first records:
+// 8 deep measured 12 % slower on the whole chain than 4 deep (profiles/r02g_sweep.txt)
+constexpr int kGvPF = NS_GV_PF;
 constexpr int kGvMaxRows = 16;
-constexpr size_t kGvMaxALds = 64 * 1024;  // staged activations (fp16) per workgroup
+constexpr size_t kGvMaxALds = 64 * 1024;    // staged activations (fp16) per workgroup
+constexpr size_t kGvMaxLds = 160 * 1024;
+
+// one matrix of a launch as the kernel sees it; a fused QKV launch looks its matrix up BY INDEX in the kernel-argument
+// segment (one scalar load) instead of carrying three of everything in SGPRs
+struct GemvMat {
+  const uint8_t* wbase;  // ONE allocation: records at 0, scales at s_off, zero points at z_off
+  uint32_t s_off, z_off;
+  uint32_t tile_begin;   // first global tile of this matrix in the launch
+  int n;
+  float* c;
+  _Float16* c16;
+};
+static_assert(sizeof(GemvMat) == 40, "GemvMat is addressed by index in the kernel-argument segment");
 
 struct GemvParams {
-  // ---- first 64 bytes: everything the first weight loads need ----
-  const uint8_t* wbase[3];  // per matrix ONE allocation: records at 0, scales at s_off, zero points at z_off
-  const _Float16* a16;      // fp16 activations (null: convert `a` while staging)
+  // ---- hot head: everything the prologue needs, fetched by one batch of scalar loads ----
+  const uint8_t* wbase0;    // matrix 0 (and, for the fused gate/up launch, matrix 1)
+  const uint8_t* wbase1;
+  const void* a;            // activations, fp16 [m][lda]
   uint32_t ks;              // k-steps per tile
   uint32_t qstride;         // bytes per (tile, k-step) record
-  uint32_t n_sk;            // stream-K workgroups = blocks [0, n_sk); block n_sk + t owns whole tile t
-  uint32_t sk_u0;           // first stream-K unit (= whole tiles * ks); a unit is one k-step of one tile
-  uint32_t sk_q, sk_r;      // stream-K block i covers units [sk_u0 + i * sk_q + min(i, sk_r), ... + sk_q + (i < sk_r))
-  uint32_t ks_magic;        // ceil(2^32 / ks)
   uint32_t nw_log2;         // log2(waves per workgroup)
-  // ---- second line ----
-  uint32_t s_off[3], z_off[3];
+  uint32_t s_off0, s_off1, z_off0, z_off1;
   uint32_t sstride, zstride;
   uint32_t srows, srow_mul, srow_shift;
-  uint32_t tile_begin[4];   // first global tile of each matrix laid side by side along N (QKV); [nseg] = total
+  uint32_t tb1, tb2;        // first global tile of matrices 1 and 2 of a fused QKV launch (2^32 - 1: absent)
   int m, k, lda;
-  uint32_t upr, upr_magic;  // 16-byte fp16 units per staged row (= ks * KSTEP / 8) and ceil(2^32 / upr)
   uint32_t row_stride;      // halves per staged row in LDS
-  uint32_t red_off;         // byte offset of the reduction scratch in LDS
-  const float* a;
-  // ---- epilogue ----
-  float* c[3];
-  _Float16* c16[3];
+  uint32_t ring_off;        // byte offset of the per-wave rings in LDS (the reduction scratch reuses them)
+  uint32_t ring_stride;     // bytes of one wave's ring = slots x slot size
+  // ---- cold: read late, through the kernel-argument pointer (keeps them out of the streaming loop's SGPRs) ----
+  GemvMat mat[3];
   float* c2;
   const float* d;
-  float* parts;     // stream-K partial sums: [n_sk][NQ][16 rows][16 columns]
-  uint32_t* flags;  // [n_sk], zero between launches
-  int n[3];
-  int ldc, ldd, nseg, epilogue;
-  uint32_t spin_limit;
+  int ldc, ldd, epilogue;
   F4Lut lut;
   F8Consts f8;
 #ifdef NS_TRACE
   unsigned long long* trace;
 #endif
 };
+// the kernel-argument segment as an opaque pointer: loads through it cannot be hoisted above the point it is made
+using KArgs = const __attribute__((address_space(4))) GemvParams*;
+__device__ __forceinline__ KArgs late_args() {
+  uint64_t v = reinterpret_cast<uint64_t>(__builtin_amdgcn_kernarg_segment_ptr());
+  asm volatile("" : "+s"(v));
+  return reinterpret_cast<KArgs>(v);
+}
 
 #ifdef NS_TRACE
 #define NS_GSTAMP(i)                                                                                     \
@@ -93,12 +110,22 @@ struct GemvParams {
 #define NS_GSTAMP(i)
 #endif
 
-template <int KIND, int SPS, int SK, bool ASYM, bool DUAL, bool WIDE>
-__global__ __launch_bounds__(WIDE ? 1024 : 512) void gemv_kernel(const GemvParams p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+enum GemvMode { GV_PLAIN = 0, GV_DUAL = 1, GV_MSEG = 2 };
+// MODE: one matrix / two matrices of one shape streamed in lockstep (gate/up, SiLU-mul epilogue) / several matrices
+// side by side along N (QKV).  Activations arrive as fp16 (the producer's shadow); fp32-only callers stay on
+// smallm_kernel, which converts while staging.
+template <int KIND, int SPS, int SK, bool ASYM, int MODE>
+__global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
+  constexpr bool DUAL = MODE == GV_DUAL, MSEG = MODE == GV_MSEG;
   constexpr int NJ = kind_is_8bit(KIND) ? 2 : 4;
   constexpr int KSTEP = NJ * 32;
   constexpr int NQ = DUAL ? 2 : 1;
-  constexpr int PF = WIDE ? kGvPFWide : kGvPF;
+  constexpr int PF = kGvPF;
   static_assert(PF % NQ == 0, "ring slots alternate between the two matrices");
   constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
   using Corr = CorrRaw<SPS, SK, ASYM>;
@@ -107,14 +134,14 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) void gemv_kernel(const GemvParam
   NS_GSTAMP(0);
 
   // every kernel argument the prologue needs is fetched by ONE batch of scalar loads: without this hipcc sinks each
-  // load to its first use and the first weight request waits for three dependent kernarg round trips
+  // load to its first use and the first weight request waits for several dependent argument round trips
   {
-    asm volatile("" ::"s"(p.wbase[0]), "s"(p.wbase[1]), "s"(p.wbase[2]), "s"(p.a16), "s"(p.ks), "s"(p.qstride),
-                 "s"(p.n_sk), "s"(p.sk_u0), "s"(p.sk_q), "s"(p.sk_r), "s"(p.ks_magic), "s"(p.nw_log2), "s"(p.s_off[0]),
-                 "s"(p.s_off[1]), "s"(p.s_off[2]), "s"(p.sstride), "s"(p.srows), "s"(p.srow_mul), "s"(p.srow_shift),
-                 "s"(p.tile_begin[1]), "s"(p.tile_begin[2]), "s"(p.m), "s"(p.k), "s"(p.lda), "s"(p.upr),
-                 "s"(p.upr_magic), "s"(p.row_stride), "s"(p.red_off));
-    if constexpr (ASYM) asm volatile("" ::"s"(p.z_off[0]), "s"(p.z_off[1]), "s"(p.z_off[2]), "s"(p.zstride));
+    asm volatile("" ::"s"(p.wbase0), "s"(p.a), "s"(p.ks), "s"(p.qstride), "s"(p.nw_log2), "s"(p.s_off0), "s"(p.sstride),
+                 "s"(p.srows), "s"(p.srow_mul), "s"(p.srow_shift), "s"(p.m), "s"(p.k), "s"(p.lda), "s"(p.row_stride),
+                 "s"(p.ring_off), "s"(p.ring_stride));
+    if constexpr (DUAL) asm volatile("" ::"s"(p.wbase1), "s"(p.s_off1));
+    if constexpr (MSEG) asm volatile("" ::"s"(p.tb1), "s"(p.tb2));
+    if constexpr (ASYM) asm volatile("" ::"s"(p.z_off0), "s"(p.z_off1), "s"(p.zstride));
   }
   const int tid = threadIdx.x;
   const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,63 +149,74 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) void gemv_kernel(const GemvParam
   const int nn = l & 15, g = l >> 4;
   const uint32_t NW = 1u << p.nw_log2;
   const uint32_t ks = p.ks;
-  const uint32_t b = blockIdx.x;
+  const uint32_t T = blockIdx.x;  // global tile (across the matrices of a fused QKV launch)
 
-  // ---- this workgroup's unit range [f0, f1): units are ordered [tile][k-step] like the records in memory ----
-  uint32_t f0, f1;
-  if (b < p.n_sk) {
-    f0 = p.sk_u0 + b * p.sk_q + min(b, p.sk_r);
-    f1 = f0 + p.sk_q + (b < p.sk_r ? 1u : 0u);
-  } else {
-    f0 = (b - p.n_sk) * ks;
-    f1 = f0 + ks;
-  }
-  uint32_t T = __umulhi(f0, p.ks_magic);  // current tile (global numbering across the matrices of a fused launch)
-  uint32_t sa = f0 - T * ks;              // segment = k-steps [sa, sb) of tile T
-  uint32_t sb = min(ks, f1 - T * ks);
-
-  // per-segment stream state: descriptors over the whole allocation of each matrix (codes, scales and zero points are
-  // reached from one base), record / scale-row bases of the tile
+  typedef __attribute__((address_space(3))) unsigned char* LdsPtr;
+  // ---- descriptors: one per matrix over its whole allocation (codes, scales and zero points share the base) ----
   Rsrc rw[NQ];
   uint32_t so[NQ], zo[NQ];
-  uint32_t tile_q, tile_c;
-  int sg = 0;        // matrix of the fused launch the tile belongs to (QKV)
-  uint32_t tl = 0;   // tile inside that matrix
-  auto setup = [&]() {
-    if constexpr (DUAL) {
-      rw[0] = make_rsrc(p.wbase[0], 0x80000000u);
-      rw[1] = make_rsrc(p.wbase[1], 0x80000000u);
-      so[0] = p.s_off[0], so[1] = p.s_off[1];
-      zo[0] = p.z_off[0], zo[1] = p.z_off[1];
-      tl = T;
-    } else {
-      // masks instead of selects: hipcc turns a select chain over kernel arguments into a table in scratch memory
-      const uint64_t b0 = reinterpret_cast<uint64_t>(p.wbase[0]), b1 = reinterpret_cast<uint64_t>(p.wbase[1]),
-                     b2 = reinterpret_cast<uint64_t>(p.wbase[2]);
-      const bool ge1 = T >= p.tile_begin[1], ge2 = T >= p.tile_begin[2];  // absent matrices begin at 2^32 - 1
-      const uint64_t M1 = 0ull - uint64_t(ge1), M2 = 0ull - uint64_t(ge2);
-      const uint32_t m1 = 0u - uint32_t(ge1), m2 = 0u - uint32_t(ge2);
-      rw[0] = make_rsrc(reinterpret_cast<const void*>(b0 + ((b1 - b0) & M1) + ((b2 - b1) & M2)), 0x80000000u);
-      so[0] = p.s_off[0] + ((p.s_off[1] - p.s_off[0]) & m1) + ((p.s_off[2] - p.s_off[1]) & m2);
-      zo[0] = p.z_off[0] + ((p.z_off[1] - p.z_off[0]) & m1) + ((p.z_off[2] - p.z_off[1]) & m2);
-      sg = int(ge1) + int(ge2);
-      tl = T - ((p.tile_begin[1] & m1) + ((p.tile_begin[2] - p.tile_begin[1]) & m2));
-    }
-    tile_q = tl * ks * p.qstride;
-    tile_c = tl * p.srows;
-  };
+  int sg = 0;       // matrix of the fused launch the tile belongs to (QKV)
+  uint32_t tl = T;  // tile inside that matrix
+  if constexpr (DUAL) {
+    rw[0] = make_rsrc(p.wbase0, 0x80000000u);
+    rw[1] = make_rsrc(p.wbase1, 0x80000000u);
+    so[0] = p.s_off0, so[1] = p.s_off1;
+    zo[0] = p.z_off0, zo[1] = p.z_off1;
+  } else if constexpr (MSEG) {
+    sg = int(T >= p.tb1) + int(T >= p.tb2);
+    const auto* mp = &reinterpret_cast<KArgs>(reinterpret_cast<uint64_t>(__builtin_amdgcn_kernarg_segment_ptr()))->mat[sg];
+    rw[0] = make_rsrc(mp->wbase, 0x80000000u);
+    so[0] = mp->s_off;
+    zo[0] = mp->z_off;
+    tl = T - mp->tile_begin;
+  } else {
+    rw[0] = make_rsrc(p.wbase0, 0x80000000u);
+    so[0] = p.s_off0;
+    zo[0] = p.z_off0;
+  }
+  const uint32_t tile_q = tl * ks * p.qstride;
+  const uint32_t tile_c = tl * p.srows;
   const uint32_t voff_q = l * 16, voff_s = nn * SBYTES, voff_z = nn * SPS;  // the only per-lane address parts
   const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
-  uint4v qv[PF];
-  Corr cr[PF];
+  // this wave's private ring: up to PF slots, a slot = image of one record {1024 B codes | 16 x SBYTES scales | 16 x SPS
+  // zero points}; slot i holds the record of item i (mod PF)
+  constexpr uint32_t SLOT = 1024u + 16u * SBYTES + (ASYM ? 16u * SPS : 0u);
+  constexpr int OPS = ASYM ? 3 : 2;  // requests per record
+  static_assert(OPS * PF <= 63, "vmcnt is a 6-bit counter");
+  const LdsPtr ring = (LdsPtr)(smem) + p.ring_off + w * p.ring_stride;
+  const uint32_t ring_lane = uint32_t(reinterpret_cast<uintptr_t>(ring)) + uint32_t(l) * 16u;  // LDS byte address
+  const uint32_t ring_corr = uint32_t(reinterpret_cast<uintptr_t>(ring)) + 1024u + uint32_t(nn) * SBYTES;
+
+  // item = (k-step s, matrix q = slot % NQ): codes (64 lanes x 16 B), then its scale row (SBYTES lanes x 16 B), then its
+  // zero-point row (SPS lanes x 16 B), all non-temporal HBM -> LDS
   auto issue = [&](auto slot_c, uint32_t s) {
     constexpr int slot = decltype(slot_c)::value;
     constexpr int q = slot % NQ;
-    const uint32_t srow = (s * p.srow_mul) >> p.srow_shift;
-    qv[slot] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rw[q], voff_q, tile_q + s * p.qstride, 2));
-    const uint32_t crow = tile_c + srow;
-    corr_issue<SPS, SK, ASYM>(rw[q], rw[q], voff_s, voff_z, so[q] + crow * p.sstride, zo[q] + crow * p.zstride, cr[slot]);
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc cannot type-check this builtin and would drop the kernel stub)
+    const uint32_t crow = tile_c + ((s * p.srow_mul) >> p.srow_shift);
+    const LdsPtr dst = ring + slot * SLOT;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, voff_q,
+                                             tile_q + s * p.qstride, 0, 2);
+    if (l < SBYTES)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst + 1024), 16,
+                                               voff_q, so[q] + crow * p.sstride, 0, 2);
+    if constexpr (ASYM) {
+      if (l < SPS)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst + 1024 + 16 * SBYTES),
+                                                 16, voff_q, zo[q] + crow * p.zstride, 0, 2);
+    }
+#endif
+  };
+  // wait until at most `younger` RECORDS requested after the one about to be consumed are still in flight
+  auto wait_records = [&](uint32_t younger) {
+    if (younger == uint32_t(PF - 1)) {  // steady state first
+      wait_vmcnt<OPS * (PF - 1)>();
+      return;
+    }
+    [&]<int... K>(std::integer_sequence<int, K...>) {
+      (void)((younger == uint32_t(K) ? (wait_vmcnt<OPS * K>(), true) : false) || ...);
+    }(std::make_integer_sequence<int, PF + 1>{});
   };
 
 #define NS_FOR_SLOTS(BODY)                                        \
@@ -188,111 +226,82 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) void gemv_kernel(const GemvParam
     }(std::make_integer_sequence<int, PF>{});                     \
   }
 
-  // items of this wave in segment [sa, sb): k-steps sa + w, sa + w + NW, ...; item t = (k-step ordinal t / NQ, matrix t % NQ)
-  uint32_t first, nitems;
-  auto ring_fill = [&]() {
-    first = sa + w;
-    const uint32_t nst = first < sb ? (sb - first + NW - 1) >> p.nw_log2 : 0u;
-    nitems = nst * NQ;
-    if (nitems >= uint32_t(PF)) {
-      NS_FOR_SLOTS({ issue(ic, first + ((i / NQ) << p.nw_log2)); })
-    } else {
-      NS_FOR_SLOTS({ if (uint32_t(i) < nitems) issue(ic, first + ((i / NQ) << p.nw_log2)); })
-    }
-  };
-
-  // ---- 1. activations requested first (they are small and must be in LDS before the first MFMA), then the ring ----
+  // ---- 1. activations requested first (small, and they must be in LDS before the first MFMA): fp16 rows go
+  //      HBM/L2 -> LDS directly in 1 KiB pieces, piece c of row r by wave (r * pieces + c) % NW; LDS row r holds
+  //      ks * KSTEP halves (columns >= K read as zero through the descriptor: k-step padding) ----
   const int rows = min(p.m, kGvMaxRows);
-  const uint32_t total_units = uint32_t(rows) * p.upr;
-  const uint32_t nthreads = blockDim.x;
-  constexpr int UN = 2;  // 16-byte units a thread has in flight per staging batch
-  const bool use_a16 = p.a16 != nullptr;
-  const Rsrc ra = use_a16 ? make_rsrc(p.a16, uint32_t(rows) * uint32_t(p.lda) * 2u)
-                          : make_rsrc(p.a, uint32_t(rows) * uint32_t(p.lda) * 4u);
-  // unit u of the staging = (row r, chunk ko of 8 elements): element offset in A, or kOob (the load then returns 0)
-  constexpr uint32_t kOob = 0xffffffffu;
-  auto a_unit = [&](uint32_t u, uint32_t& lds_halves) -> uint32_t {
-    uint32_t r = 0, ko = u;
-    if (rows > 1) {
-      r = __umulhi(u, p.upr_magic);
-      ko = u - r * p.upr;
-    }
-    lds_halves = r * p.row_stride + ko * 8;
-    const bool ok = u < total_units && int(ko * 8) < p.k;
-    return ok ? r * uint32_t(p.lda) + ko * 8 : kOob;
-  };
-  auto a16_load = [&](uint32_t e) {  // byte offset 2^31 is beyond every descriptor: reads as zero, no memory access
-    return __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(ra, e == kOob ? 0x80000000u : e * 2u, 0, 0));
-  };
-  uint4v a_first[UN];
-  uint32_t a_first_dst[UN];
-  if (use_a16) {
-#pragma unroll
-    for (int i = 0; i < UN; i++) {
-      a_first[i] = a16_load(a_unit(uint32_t(tid) + uint32_t(i) * nthreads, a_first_dst[i]));
+  {
+    const Rsrc ra = make_rsrc(p.a, uint32_t(rows - 1) * uint32_t(p.lda) * 2u + uint32_t(p.k) * 2u);
+    const uint32_t row_bytes = ks * uint32_t(KSTEP) * 2u;
+    const uint32_t pieces = (row_bytes + 1023u) >> 10;
+    const uint32_t total = uint32_t(rows) * pieces;
+    const LdsPtr al = (LdsPtr)(smem);
+    for (uint32_t u = w; u < total; u += NW) {
+      uint32_t r = 0, c = u;
+      if (rows > 1) {
+        r = u / pieces;
+        c = u - r * pieces;
+      }
+      const uint32_t left = row_bytes - (c << 10);  // bytes of the row from this piece on
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (uint32_t(l) * 16u < left)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(al + r * p.row_stride * 2u + (c << 10)),
+                                                 16, voff_q, r * uint32_t(p.lda) * 2u + (c << 10), 0, 0);
+#endif
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  setup();
-  ring_fill();
+
+  // ---- 2. fill the ring: k-steps w, w + NW, ... of the tile belong to wave w ----
+  const uint32_t first = w;
+  const uint32_t nst = first < ks ? (ks - first + NW - 1) >> p.nw_log2 : 0u;
+  NS_FOR_SLOTS({ if (uint32_t(i / NQ) < nst) issue(ic, first + ((i / NQ) << p.nw_log2)); })
   __builtin_amdgcn_sched_barrier(0);
   NS_GSTAMP(1);
 
-  // ---- 2. stage A as fp16: [rows][row_stride] halves, columns >= K are zero (k-step padding) ----
-  if (use_a16) {
-#pragma unroll
-    for (int i = 0; i < UN; i++)
-      if (uint32_t(tid) + uint32_t(i) * nthreads < total_units)
-        *reinterpret_cast<uint4v*>(a_lds + a_first_dst[i]) = a_first[i];
-    for (uint32_t u0 = UN * nthreads; u0 < total_units; u0 += UN * nthreads) {
-      uint4v v[UN];
-      uint32_t dst[UN];
-#pragma unroll
-      for (int i = 0; i < UN; i++) {
-        v[i] = a16_load(a_unit(u0 + uint32_t(tid) + uint32_t(i) * nthreads, dst[i]));
-      }
-#pragma unroll
-      for (int i = 0; i < UN; i++)
-        if (u0 + uint32_t(tid) + uint32_t(i) * nthreads < total_units) *reinterpret_cast<uint4v*>(a_lds + dst[i]) = v[i];
-    }
-  } else {
-    // fp32 activations: 8 floats per unit, converted on the way in; rows need not be 16-byte aligned
-    const bool vec_ok = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0);
-    for (uint32_t u = tid; u < total_units; u += nthreads) {
-      uint32_t dst;
-      const uint32_t e = a_unit(u, dst);
-      float f[8];
-      const int kk = e == kOob ? p.k : int(e % uint32_t(p.lda));  // column of the unit's first element
-      if (e != kOob && vec_ok && kk + 8 <= p.k) {
-        const uint4v v0 = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(ra, e * 4u, 0, 0));
-        const uint4v v1 = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(ra, e * 4u, 16, 0));
-        const uint32_t vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int t = 0; t < 8; t++) f[t] = __builtin_bit_cast(float, vw[t]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-          f[t] = kk + t < p.k ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (e + t) * 4u, 0, 0)) : 0.f;
-      }
-      half2_t h0 = {(_Float16)f[0], (_Float16)f[1]}, h1 = {(_Float16)f[2], (_Float16)f[3]};
-      half2_t h2 = {(_Float16)f[4], (_Float16)f[5]}, h3 = {(_Float16)f[6], (_Float16)f[7]};
-      *reinterpret_cast<uint4v*>(a_lds + dst) = uint4v{as_u32(h0), as_u32(h1), as_u32(h2), as_u32(h3)};
-    }
-  }
-  __syncthreads();
+  // ---- 3. this wave's activation pieces (the oldest requests in its queue) have landed once only its ring
+  //      requests are left in flight ----
+  wait_records(min(nst * uint32_t(NQ), uint32_t(PF)));
+  // workgroup barrier over the staged activations, written by hand: for __syncthreads() hipcc first waits for every
+  // LDS-DMA request in flight (it cannot know that the rings are wave-private), i.e. for the whole ring to land
+  asm volatile("s_barrier" ::: "memory");
   NS_GSTAMP(2);
 
   // A-fragment LDS offset of this lane (rows >= m are clamped: their output rows are discarded)
   const uint32_t aoff = uint32_t(min(nn, rows - 1)) * p.row_stride + 8 * g;
   floatx4 acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](auto slot_c, uint32_t s) {
     constexpr int slot = decltype(slot_c)::value;
     constexpr int q = slot % NQ;
     const _Float16* abase = a_lds + s * KSTEP + aoff;
+    // the record's scales / zero points of column nn and the lane's 16 B of codes, out of the ring slot
+    Corr cr;
+    {
+      typedef __attribute__((address_space(3))) const uint32_t* L32;
+      const uint32_t ca = ring_corr + uint32_t(slot) * SLOT;
+      if constexpr (SBYTES == 2) {
+        cr.s[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(ca);
+      } else {
+#pragma unroll
+        for (int t = 0; t < Corr::NW32; t++) cr.s[t] = reinterpret_cast<L32>(ca)[t];
+      }
+      if constexpr (ASYM) {
+        const uint32_t za = uint32_t(reinterpret_cast<uintptr_t>(ring)) + uint32_t(slot) * SLOT + 1024u + 16u * SBYTES + uint32_t(nn) * SPS;
+        if constexpr (SPS == 4)
+          cr.z[0] = *reinterpret_cast<L32>(za);
+        else if constexpr (SPS == 2)
+          cr.z[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(za);
+        else
+          cr.z[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint8_t*>(za);
+      }
+    }
     float sc[4], zp[4];
-    corr_decode<SPS, SK, ASYM, NJ>(cr[slot], sc, zp);
-    const uint32_t xw[4] = {qv[slot].x, qv[slot].y, qv[slot].z, qv[slot].w};
+    corr_decode<SPS, SK, ASYM, NJ>(cr, sc, zp);
+    const uint4v qvv = *reinterpret_cast<const __attribute__((address_space(3))) uint4v*>(ring_lane + uint32_t(slot) * SLOT);
+    const uint32_t xw[4] = {qvv.x, qvv.y, qvv.z, qvv.w};
     half8_t bq[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -318,135 +327,74 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) void gemv_kernel(const GemvParam
     for (int j = 0; j < NJ; j++) acc[q] += dd[j] * sc[j];
   };
 
-  floatx4* red = reinterpret_cast<floatx4*>(smem + p.red_off);  // [2 parities][NW][NQ][64 lanes]
-  uint32_t parity = 0;
-  for (;;) {
-#pragma unroll
-    for (int q = 0; q < NQ; q++) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-    // ---- 3. stream the segment: steady-state rounds consume slot i and refill it PF items ahead with no conditions
-    //      inside, so the compiler emits counted vmcnt waits; the last rounds are peeled ----
-    constexpr int SPR = PF / NQ;  // k-steps per round
-    const uint32_t rounds = nitems / PF, rem = nitems - rounds * PF;
-    if (nitems >= uint32_t(PF)) {
-      uint32_t r = 0;
-      for (; r + 1 < rounds; r++) {
-        NS_FOR_SLOTS({
-          compute(ic, first + ((r * SPR + i / NQ) << p.nw_log2));
-          __builtin_amdgcn_sched_barrier(0);
-          issue(ic, first + (((r + 1) * SPR + i / NQ) << p.nw_log2));
-          __builtin_amdgcn_sched_barrier(0);
-        })
+  // ---- 4. stream: consume the oldest record, refill its slot with the record PF items ahead ----
+  constexpr int SPR = PF / NQ;  // k-steps per round
+  const uint32_t rounds = (nst + SPR - 1) / SPR;
+  const uint32_t nitems = nst * NQ;
+  for (uint32_t r = 0; r < rounds; r++) {
+    NS_FOR_SLOTS({
+      const uint32_t ord = r * SPR + i / NQ;  // ordinal of the k-step among this wave's
+      if (ord < nst) {
+        const uint32_t t = r * PF + i;  // ordinal of the item
+        wait_records(min(nitems - t - 1, uint32_t(PF - 1)));
+        compute(ic, first + (ord << p.nw_log2));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ord + SPR < nst) issue(ic, first + ((ord + SPR) << p.nw_log2));
+        __builtin_amdgcn_sched_barrier(0);
       }
-      NS_FOR_SLOTS({
-        compute(ic, first + ((r * SPR + i / NQ) << p.nw_log2));
-        __builtin_amdgcn_sched_barrier(0);
-        if (uint32_t(i) < rem) issue(ic, first + (((r + 1) * SPR + i / NQ) << p.nw_log2));
-        __builtin_amdgcn_sched_barrier(0);
-      })
-      r++;
-      NS_FOR_SLOTS({
-        if (uint32_t(i) < rem) compute(ic, first + ((r * SPR + i / NQ) << p.nw_log2));
-        __builtin_amdgcn_sched_barrier(0);
-      })
-    } else {
-      NS_FOR_SLOTS({
-        if (uint32_t(i) < nitems) compute(ic, first + ((i / NQ) << p.nw_log2));
-        __builtin_amdgcn_sched_barrier(0);
-      })
-    }
-    NS_GSTAMP(4);
+    })
+  }
+  NS_GSTAMP(4);
 
-    // ---- 4. cross-wave reduction through LDS (two scratch parities: one barrier per segment) ----
-    floatx4* rp = red + size_t(parity) * NW * NQ * 64;
+  // ---- 5. cross-wave reduction: every wave writes its partial sums over ITS OWN ring, wave 0 adds them in wave order ----
+  floatx4* red = reinterpret_cast<floatx4*>(smem + p.ring_off);
+  const uint32_t kRedWave = p.ring_stride / 16;  // floatx4 per wave region (>= NQ KiB, checked by the host)
 #pragma unroll
-    for (int q = 0; q < NQ; q++) rp[(w * NQ + q) * 64 + l] = acc[q];
-    __syncthreads();
-    const bool has_next = T * ks + sb < f1;
-    if (w == 0) {
-      floatx4 sum[NQ];
+  for (int q = 0; q < NQ; q++) red[w * kRedWave + q * 64 + l] = acc[q];
+  const KArgs cold = late_args();  // epilogue-only arguments: fetched here, not held through the streaming loop
+  const auto* mp = &cold->mat[MSEG ? sg : 0];  // indexed scalar loads
+  const int ncols = mp->n;
+  float* cbase = mp->c;
+  _Float16* c16 = mp->c16;
+  const int ldc = cold->ldc, ldd = cold->ldd, epi = cold->epilogue;
+  const float* dptr = cold->d;
+  float* c2 = cold->c2;
+  __syncthreads();
+  if (w == 0) {
+    floatx4 sum[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        sum[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-        for (uint32_t ww = 0; ww < NW; ww++) sum[q] += rp[(ww * NQ + q) * 64 + l];
-      }
-      if (sa != 0) {
-        // the tile started in an earlier workgroup, which owns it: publish this workgroup's share.  Write-through
-        // (sc1) stores, drained, then the flag — no release fence (it would write back a whole L2)
+    for (int q = 0; q < NQ; q++) {
+      sum[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (uint32_t ww = 0; ww < NW; ww++) sum[q] += red[ww * kRedWave + q * 64 + l];
+    }
+    // ---- 6. epilogue: lane (nn, g) holds rows 4g .. 4g+3 of column nn ----
+    const int col = int(tl) * 16 + nn;
+    if (col < ncols) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          float* dst = p.parts + ((size_t(b) * NQ + q) * 64 + l) * 4;
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-            if (4 * g + e < rows) __hip_atomic_store(dst + e, sum[q][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (l == 0) __hip_atomic_store(p.flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (sb < ks) {
-          // continued by the following stream-K workgroups: add their published shares in workgroup order (bit-wise
-          // reproducible), then hand the flags back at zero for the next launch
-          for (uint32_t c = b + 1; c < p.n_sk; c++) {
-            const uint32_t f0c = p.sk_u0 + c * p.sk_q + min(c, p.sk_r);
-            if (f0c >= (T + 1) * ks) break;
-            // bounded: a protocol bug must not hang the GPU (the result is then wrong and the parity tests say so)
-            for (uint32_t spin = 0; spin < p.spin_limit; spin++) {
-              if (__hip_atomic_load(p.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-              __builtin_amdgcn_s_sleep(2);
-            }
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int q = 0; q < NQ; q++) {
-              const float* src = p.parts + ((size_t(c) * NQ + q) * 64 + l) * 4;
-#pragma unroll
-              for (int e = 0; e < 4; e++)
-                if (4 * g + e < rows) sum[q][e] += __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (l == 0) __hip_atomic_store(p.flags + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int rr = 0; rr < 4; rr++) {
+        const int row = 4 * g + rr;
+        if (row >= p.m) continue;
+        float v = sum[0][rr];
+        if constexpr (DUAL) {
+          // tmp1 = act(A*W1) ; tmp2 = (A*W3) * tmp1   (neural_speed/core/layers/ip_fusion_ffn.cpp:364-406)
+          const float t1 = (epi == 5) ? epi_silu(v) : epi_gelu(v);
+          if (c2) c2[size_t(row) * ldc + col] = t1;
+          v = sum[1][rr] * t1;
+        } else {
+          const float dv = dptr ? dptr[size_t(row) * ldd + col] : 0.f;
+          switch (epi) {
+            case 1: v = v + dv; break;            // custom::epilogue::Add
+            case 2: v = v * dv; break;            // custom::epilogue::Mul
+            case 3: v = epi_gelu(v + dv); break;  // custom::epilogue::Add_Gelu
+            case 4: v = epi_gelu(v); break;
+            case 5: v = epi_silu(v); break;
+            default: break;
           }
         }
-        // ---- 5. epilogue: lane (nn, g) holds rows 4g .. 4g+3 of column nn ----
-        const int col = int(tl) * 16 + nn;
-        const int ncols = DUAL ? p.n[0] : (sg == 0 ? p.n[0] : (sg == 1 ? p.n[1] : p.n[2]));
-        if (col < ncols) {
-          float* cbase = DUAL ? p.c[0] : (sg == 0 ? p.c[0] : (sg == 1 ? p.c[1] : p.c[2]));
-          _Float16* c16 = DUAL ? p.c16[0] : (sg == 0 ? p.c16[0] : (sg == 1 ? p.c16[1] : p.c16[2]));
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int row = 4 * g + rr;
-            if (row >= p.m) continue;
-            float v = sum[0][rr];
-            if constexpr (DUAL) {
-              // tmp1 = act(A*W1) ; tmp2 = (A*W3) * tmp1   (neural_speed/core/layers/ip_fusion_ffn.cpp:364-406)
-              const float t1 = (p.epilogue == 5) ? epi_silu(v) : epi_gelu(v);
-              if (p.c2) p.c2[size_t(row) * p.ldc + col] = t1;
-              v = sum[1][rr] * t1;
-            } else {
-              const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
-              switch (p.epilogue) {
-                case 1: v = v + dv; break;            // custom::epilogue::Add
-                case 2: v = v * dv; break;            // custom::epilogue::Mul
-                case 3: v = epi_gelu(v + dv); break;  // custom::epilogue::Add_Gelu
-                case 4: v = epi_gelu(v); break;
-                case 5: v = epi_silu(v); break;
-                default: break;
-              }
-            }
-            cbase[size_t(row) * p.ldc + col] = v;
-            if (c16) c16[size_t(row) * p.ldc + col] = (_Float16)v;
-          }
-        }
+        cbase[size_t(row) * ldc + col] = v;
+        if (c16) c16[size_t(row) * ldc + col] = (_Float16)v;
       }
     }
-    if (!has_next) break;
-    // ---- next segment: the first k-steps of the following tile ----
-    T += 1;
-    sa = 0;
-    sb = min(ks, f1 - T * ks);
-    parity ^= 1u;
-    setup();
-    ring_fill();
-    __builtin_amdgcn_sched_barrier(0);
   }
 #undef NS_FOR_SLOTS
   NS_GSTAMP(6);
@@ -461,62 +409,49 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512) void gemv_kernel(const GemvParam
 // host side
 // ============================================================================================================
 template <int KIND, int SPS, int SK, bool ASYM>
-static hipError_t launch_gemv_k(const GemvParams& p, bool dual, int grid, int nw, size_t lds, hipStream_t st) {
+static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw, size_t lds, hipStream_t st) {
   const dim3 g(grid), b(nw * 64);
-#define NS_GV_LAUNCH(DUALV, WIDEV)                                                                              \
+#define NS_GV_LAUNCH(MODEV)                                                                                     \
   {                                                                                                             \
-    auto k = gemv_kernel<KIND, SPS, SK, ASYM, DUALV, WIDEV>;                                                     \
+    auto k = gemv_kernel<KIND, SPS, SK, ASYM, MODEV>;                                                            \
     static const hipError_t attr =                                                                              \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kGvMaxLds)); \
     if (attr != hipSuccess && lds > 64 * 1024) return attr;                                                     \
     hipLaunchKernelGGL(k, g, b, lds, st, p);                                                                    \
   }
-  if (dual) {
-    if (nw > 8) return hipErrorInvalidValue;
-    NS_GV_LAUNCH(true, false)
-  } else {
-    // plain launches run the 128-VGPR / 2-deep-ring instantiation at every wave count (measured +2 % over the 4-deep
-    // one), the fused gate/up launch the 4-deep one
-    NS_GV_LAUNCH(false, true)
-  }
+  if (mode == GV_DUAL)
+    NS_GV_LAUNCH(GV_DUAL)
+  else if (mode == GV_MSEG)
+    NS_GV_LAUNCH(GV_MSEG)
+  else
+    NS_GV_LAUNCH(GV_PLAIN)
 #undef NS_GV_LAUNCH
   return hipGetLastError();
 }
 template <int KIND, int SPS, int SK>
-static hipError_t launch_gemv_a(const GemvParams& p, bool asym, bool dual, int grid, int nw, size_t lds, hipStream_t st) {
+static hipError_t launch_gemv_a(const GemvParams& p, bool asym, int mode, int grid, int nw, size_t lds,
+                                hipStream_t st) {
   if constexpr (KIND == WK_F4 || KIND == WK_F8) {
     (void)asym;
-    return launch_gemv_k<KIND, SPS, SK, false>(p, dual, grid, nw, lds, st);
+    return launch_gemv_k<KIND, SPS, SK, false>(p, mode, grid, nw, lds, st);
   } else {
-    if (asym) return launch_gemv_k<KIND, SPS, SK, true>(p, dual, grid, nw, lds, st);
-    return launch_gemv_k<KIND, SPS, SK, false>(p, dual, grid, nw, lds, st);
+    if (asym) return launch_gemv_k<KIND, SPS, SK, true>(p, mode, grid, nw, lds, st);
+    return launch_gemv_k<KIND, SPS, SK, false>(p, mode, grid, nw, lds, st);
   }
 }
 template <int KIND, int SPS>
-static hipError_t launch_gemv_s(const GemvParams& p, uint32_t scale_dt, bool asym, bool dual, int grid, int nw,
+static hipError_t launch_gemv_s(const GemvParams& p, uint32_t scale_dt, bool asym, int mode, int grid, int nw,
                                 size_t lds, hipStream_t st) {
-  if (scale_dt == DT_F32) return launch_gemv_a<KIND, SPS, SK_F32>(p, asym, dual, grid, nw, lds, st);
-  if (scale_dt == DT_F16) return launch_gemv_a<KIND, SPS, SK_F16>(p, asym, dual, grid, nw, lds, st);
-  return launch_gemv_a<KIND, SPS, SK_BF16>(p, asym, dual, grid, nw, lds, st);
-}
-
-static int gv_device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 1;
-  }
-  return cus;
+  if (scale_dt == DT_F32) return launch_gemv_a<KIND, SPS, SK_F32>(p, asym, mode, grid, nw, lds, st);
+  if (scale_dt == DT_F16) return launch_gemv_a<KIND, SPS, SK_F16>(p, asym, mode, grid, nw, lds, st);
+  return launch_gemv_a<KIND, SPS, SK_BF16>(p, asym, mode, grid, nw, lds, st);
 }
 
 #ifdef NS_TRACE
 unsigned long long* trace_buffer();
 #endif
 
-static std::atomic<int> g_gemv_mode{-1};  // -1: read NS_GEMV2 once; 0 off; 1 on; 2 on, whole tiles only (no stream-K part)
+static std::atomic<int> g_gemv_mode{-1};  // -1: read NS_GEMV2 once; 0 off (first-generation kernel); 1 on
 void set_gemv_mode(int mode) { g_gemv_mode.store(mode); }
 static int gemv_mode() {
   int m = g_gemv_mode.load();
@@ -528,93 +463,89 @@ static int gemv_mode() {
   return m;
 }
 
+// waves per workgroup of a decode launch (one 16-column tile per workgroup, k-steps dealt round-robin to the waves).
+// Shared with smallm_kernel so that both kernels add a tile's partial sums in the same order: a caller that passes the
+// fp16 shadow of A (gemv_kernel) gets bit for bit what the fp32-only caller (smallm_kernel) gets.
+int decode_waves(int grid, int ks, bool dual) {
+  // measured on the 7B shapes (profiles/r02g_sweep.txt): 256 tiles x 32 k-steps (attention output) 16 waves, 256 tiles
+  // x 86 k-steps (FFN down) 8 waves (7.5 vs 8.0 us at 16), 768 tiles 4 waves, 2000 tiles (lm_head) 2 waves
+  int nw = (grid <= 320 && ks >= 32 && ks <= 48 && !dual) ? 16 : 8;
+  if (dual) {
+    nw = grid * 4 >= 1300 ? 4 : 8;
+  } else {
+    const int target_waves = 2560;
+    while (nw > 2 && grid * (nw / 2) >= target_waves) nw /= 2;
+  }
+  static const int env_nw = getenv("NS_GV_NW") ? atoi(getenv("NS_GV_NW")) : 0;  // diagnostics
+  if (env_nw == 2 || env_nw == 4 || env_nw == 8 || (env_nw == 16 && !dual)) nw = env_nw;
+  while (nw > 1 && nw > ks) nw /= 2;
+  return nw;
+}
+
 // hipErrorNotSupported: outside the kernel's envelope — the caller falls back to smallm_kernel
 hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
-  const int mode = gemv_mode();
   const ns_weight* w0 = a.seg[0].w;
-  if (mode == 0 || a.m < 1 || a.m > kGvMaxRows) return hipErrorNotSupported;
-  const int nq = a.dual ? 2 : 1;
+  if (gemv_mode() == 0 || a.m < 1 || a.m > kGvMaxRows) return hipErrorNotSupported;
   const int nmat = a.nseg;  // matrices the launch touches (dual: 2)
   GemvParams p;
   memset(&p, 0, sizeof(p));
   uint32_t tiles = 0;
+  uint32_t tbeg[3] = {0, 0xffffffffu, 0xffffffffu};  // absent matrices begin beyond every tile
+  const uint8_t* wb[3] = {nullptr, nullptr, nullptr};
+  uint32_t soff[3] = {0, 0, 0}, zoff[3] = {0, 0, 0};
   for (int i = 0; i < nmat; i++) {
     const ns_weight* w = a.seg[i].w;
     if (!w->single_span || w->alloc_bytes >= (size_t(1) << 31)) return hipErrorNotSupported;
-    p.wbase[i] = reinterpret_cast<const uint8_t*>(w->codes);
-    p.s_off[i] = uint32_t(reinterpret_cast<const uint8_t*>(w->scales) - reinterpret_cast<const uint8_t*>(w->codes));
-    p.z_off[i] = w->zps ? uint32_t(reinterpret_cast<const uint8_t*>(w->zps) - reinterpret_cast<const uint8_t*>(w->codes)) : 0u;
-    p.tile_begin[i] = tiles;
+    wb[i] = reinterpret_cast<const uint8_t*>(w->codes);
+    soff[i] = uint32_t(reinterpret_cast<const uint8_t*>(w->scales) - wb[i]);
+    zoff[i] = w->zps ? uint32_t(reinterpret_cast<const uint8_t*>(w->zps) - wb[i]) : 0u;
+    tbeg[i] = a.dual ? 0u : tiles;
     if (!a.dual || i == 0) tiles += uint32_t(w->ntiles);
-    p.c[i] = a.seg[i].c;
-    p.c16[i] = static_cast<_Float16*>(a.seg[i].c16);
-    p.n[i] = w->n;
+    p.mat[i] = GemvMat{wb[i], soff[i], zoff[i], tbeg[i], w->n, a.seg[i].c, static_cast<_Float16*>(a.seg[i].c16)};
   }
-  for (int i = a.dual ? 1 : nmat; i < 4; i++) p.tile_begin[i] = 0xffffffffu;  // absent: no tile is >= it
+  const bool mseg = !a.dual && nmat > 1;
+  const int mode = a.dual ? GV_DUAL : (mseg ? GV_MSEG : GV_PLAIN);
+  p.wbase0 = wb[0];
+  p.wbase1 = wb[1];
+  p.s_off0 = soff[0], p.s_off1 = soff[1], p.z_off0 = zoff[0], p.z_off1 = zoff[1];
+  p.tb1 = mseg ? tbeg[1] : 0xffffffffu;
+  p.tb2 = (mseg && nmat > 2) ? tbeg[2] : 0xffffffffu;
   const uint32_t ks = uint32_t(w0->ksteps);
   const int kstep = w0->kstep_len;
-  if (tiles == 0 || ks == 0 || uint64_t(tiles) * ks * ks >= (uint64_t(1) << 32)) return hipErrorNotSupported;
-  if (!w0->ws_flags || !w0->ws_parts) return hipErrorNotSupported;
+  if (tiles == 0 || ks == 0) return hipErrorNotSupported;
 
   // staged activations: [rows][ks * KSTEP + 8] halves
   const int rows = a.m;
   const uint32_t row_stride = ks * uint32_t(kstep) + 8;
   const size_t a_bytes = size_t(rows) * row_stride * 2;
   if (a_bytes > kGvMaxALds) return hipErrorNotSupported;
-  p.a = a.a;
-  p.a16 = static_cast<const _Float16*>(a.a16);
-  if (p.a16 && ((a.lda & 7) != 0 || (w0->k & 7) != 0 || (reinterpret_cast<uintptr_t>(p.a16) & 15) != 0)) p.a16 = nullptr;
+  // fp16 activations with 16-byte aligned rows; several rows need K to fill whole k-steps (a row's padding columns
+  // would otherwise read the next row through the descriptor)
+  const bool a16 = a.a16 != nullptr && (a.lda & 7) == 0 && (w0->k & 7) == 0 && (reinterpret_cast<uintptr_t>(a.a16) & 15) == 0;
+  if (!a16 || (rows > 1 && w0->k % kstep != 0)) return hipErrorNotSupported;
+  p.a = a.a16;
   if (uint64_t(rows) * uint64_t(a.lda) * 4 >= (uint64_t(1) << 30)) return hipErrorNotSupported;  // staging offsets
 
-  // ---- work split ----
-  const uint32_t cus = uint32_t(gv_device_cus());
-  uint32_t t_dp = tiles, n_sk = 0, sk_q = 0, sk_r = 0;
-  static const int env_minu = getenv("NS_GV_MIN_UNITS") ? atoi(getenv("NS_GV_MIN_UNITS")) : 4;  // diagnostics
-  const uint32_t min_units = uint32_t(std::max(1, env_minu));
-  if (mode != 2 && tiles % cus != 0) {
-    const uint32_t per_cu_hi = (tiles + cus - 1) / cus;
-    const double imbalance = double(per_cu_hi) * cus / double(tiles);
-    if (imbalance > 1.04) {
-      t_dp = (tiles / cus) * cus;
-      const uint64_t U = uint64_t(tiles - t_dp) * ks;
-      n_sk = uint32_t(std::min<uint64_t>(cus, std::max<uint64_t>(1, U / min_units)));
-      if (n_sk > uint32_t(kMaxDecodeGrid / 4)) n_sk = uint32_t(kMaxDecodeGrid / 4);  // workspace: 2 KiB per workgroup
-      sk_q = uint32_t(U / n_sk);
-      sk_r = uint32_t(U % n_sk);
-    }
-  }
-  const uint32_t grid = n_sk + t_dp;
-
-  // waves per workgroup (as tuned for smallm_kernel, profiles/r01*): many tiles -> few waves each
-  int nw = 8;
+  // waves per workgroup: enough waves on the chip to overlap dequantisation with the stream (as tuned for
+  // smallm_kernel, profiles/r01*); the rings of a workgroup must fit in LDS beside the staged activations
+  const int grid = int(tiles);
+  const int nq = a.dual ? 2 : 1;
+  const uint32_t sbytes = uint32_t(w0->sps) * (w0->scale_dt == DT_F32 ? 4u : 2u);
+  const uint32_t slot = 1024u + 16u * sbytes + (w0->asym ? 16u * uint32_t(w0->sps) : 0u);
+  auto ring_bytes = [&](int waves) {  // a wave's ring: one slot per item it can have in flight, at least the reduction scratch
+    const uint32_t items = ((ks + uint32_t(waves) - 1) / uint32_t(waves)) * uint32_t(nq);
+    const size_t b = size_t(std::min<uint32_t>(items, uint32_t(kGvPF))) * slot;
+    return std::max<size_t>((b + 15) & ~size_t(15), size_t(nq) * 1024);
+  };
+  int nw = decode_waves(grid, int(ks), a.dual);
   {
-    const int pf = a.dual ? kGvPF : kGvPFWide;
-    const uint32_t per_wg = n_sk ? std::min<uint32_t>(ks, sk_q ? sk_q : ks) : ks;
-    nw = (grid <= 320 && per_wg >= 32 && !a.dual) ? 16 : 8;
-    if (a.dual) {
-      nw = grid * 4 >= 1300 ? 4 : 8;
-    } else {
-      const int target_waves = 2560;
-      while (nw > 2 && int(grid) * (nw / 2) >= target_waves) nw /= 2;
-    }
-    while (nw > 2 && int(per_wg) * nq < nw * pf) nw /= 2;  // keep the ring full
-    static const int env_nw = getenv("NS_GV_NW") ? atoi(getenv("NS_GV_NW")) : 0;  // diagnostics
-    if (env_nw == 2 || env_nw == 4 || env_nw == 8 || (env_nw == 16 && !a.dual)) nw = env_nw;
-    if (uint32_t(nw) > ks) {
-      nw = 1;
-      while (uint32_t(nw) * 2 <= ks) nw *= 2;
-    }
+    while (nw > 1 && ((a_bytes + 15) & ~size_t(15)) + size_t(nw) * ring_bytes(nw) > kGvMaxLds) nw /= 2;
   }
   uint32_t nw_log2 = 0;
   while ((1 << nw_log2) < nw) nw_log2++;
 
   p.ks = ks;
   p.qstride = w0->qstride;
-  p.n_sk = n_sk;
-  p.sk_u0 = t_dp * ks;
-  p.sk_q = sk_q;
-  p.sk_r = sk_r;
-  p.ks_magic = uint32_t(((uint64_t(1) << 32) + ks - 1) / ks);
   p.nw_log2 = nw_log2;
   p.sstride = w0->sstride;
   p.zstride = w0->zstride;
@@ -627,41 +558,36 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   p.m = a.m;
   p.k = w0->k;
   p.lda = a.lda;
-  p.upr = ks * uint32_t(kstep) / 8;
-  p.upr_magic = uint32_t(((uint64_t(1) << 32) + p.upr - 1) / p.upr);
-  if (uint64_t(rows) * p.upr * p.upr >= (uint64_t(1) << 32)) return hipErrorNotSupported;
   p.row_stride = row_stride;
-  p.red_off = uint32_t((a_bytes + 15) & ~size_t(15));
+  p.ring_off = uint32_t((a_bytes + 15) & ~size_t(15));
   p.c2 = a.c2;
   p.d = a.d;
-  p.parts = w0->ws_parts;
-  p.flags = w0->ws_flags;
   p.ldc = a.ldc;
   p.ldd = a.ldd;
-  p.nseg = a.dual ? 1 : a.nseg;
   p.epilogue = a.epilogue;
-  p.spin_limit = 1u << 18;
   if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
   p.f8 = f8_consts(w0->qtype);
 #ifdef NS_TRACE
   p.trace = trace_buffer();
 #endif
-  const size_t lds = size_t(p.red_off) + size_t(2) * nw * nq * 64 * 16;
+  p.ring_stride = uint32_t(ring_bytes(nw));
+  const size_t lds = size_t(p.ring_off) + size_t(nw) * p.ring_stride;
+  if (lds > kGvMaxLds) return hipErrorNotSupported;
 
-#define NS_DISPATCH(KIND)                                                                         \
-  switch (w0->sps) {                                                                              \
-    case 4: return launch_gemv_s<KIND, 4>(p, w0->scale_dt, w0->asym, a.dual, grid, nw, lds, st);  \
-    case 2: return launch_gemv_s<KIND, 2>(p, w0->scale_dt, w0->asym, a.dual, grid, nw, lds, st);  \
-    default: return launch_gemv_s<KIND, 1>(p, w0->scale_dt, w0->asym, a.dual, grid, nw, lds, st); \
+#define NS_DISPATCH(KIND)                                                                       \
+  switch (w0->sps) {                                                                            \
+    case 4: return launch_gemv_s<KIND, 4>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st);  \
+    case 2: return launch_gemv_s<KIND, 2>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st);  \
+    default: return launch_gemv_s<KIND, 1>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st); \
   }
   if (w0->kind == WK_INT4) {
     NS_DISPATCH(WK_INT4)
   } else if (w0->kind == WK_INT8) {
-    if (w0->sps == 2) return launch_gemv_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, a.dual, grid, nw, lds, st);
-    return launch_gemv_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, a.dual, grid, nw, lds, st);
+    if (w0->sps == 2) return launch_gemv_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st);
+    return launch_gemv_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st);
   } else if (w0->kind == WK_F8) {  // device scales are always fp32 (E8M0 shared exponents are expanded at load)
-    if (w0->sps == 2) return launch_gemv_a<WK_F8, 2, SK_F32>(p, false, a.dual, grid, nw, lds, st);
-    return launch_gemv_a<WK_F8, 1, SK_F32>(p, false, a.dual, grid, nw, lds, st);
+    if (w0->sps == 2) return launch_gemv_a<WK_F8, 2, SK_F32>(p, false, mode, grid, nw, lds, st);
+    return launch_gemv_a<WK_F8, 1, SK_F32>(p, false, mode, grid, nw, lds, st);
   } else {
     NS_DISPATCH(WK_F4)
   }

@@ -747,20 +747,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   // cover bandwidth x latency (~3-4k waves) and (b) as many k-steps per wave as possible so that dequant/MFMA of one
   // step overlaps the loads of the next ones.  Measured on MI355X (profiles/r01*): many tiles -> few waves each.
   int nw = 8;
-  if (mb == 1) {
-    const int target_waves = 2560;
-    // 16-wave workgroups where few tiles leave CUs short of waves (FFN down projection, attention output projection;
-    // measured: WO 5.75 -> 5.3 us at 16 waves)
-    const int pf = (a.dual || mb == 2) ? kPF : kPFWide;  // ring depth of the instantiation that will run
-    nw = (grid <= 320 && w0->ksteps >= 32 && !a.dual) ? 16 : 8;
-    // fused gate/up (two matrices per workgroup): 4 waves from 344 tiles up (the N-split shard of tensor-parallel 2:
-    // 12.9 -> 10.9 us, scripts/shard_bench.py), 8 below (172 / 86 tiles: 8.0 vs 8.9 us), never fewer than 4
-    if (a.dual)
-      nw = grid * 4 >= 1300 ? 4 : 8;
-    else
-      while (nw > 2 && grid * (nw / 2) >= target_waves) nw /= 2;
-    while (nw > 2 && w0->ksteps * (a.dual ? 2 : 1) < nw * pf) nw /= 2;  // keep the ring full
-  }
+  if (mb == 1) nw = decode_waves(grid, w0->ksteps, a.dual);  // the same split of K as gemv_kernel: bit-identical sums
   if (env_nw == 8 || env_nw == 4 || env_nw == 2 || (env_nw == 16 && mb == 1)) nw = env_nw;
   static const int env_nw_plain = getenv("NS_NW_PLAIN") ? atoi(getenv("NS_NW_PLAIN")) : 0;  // diagnostics
   if (!a.dual && mb == 1 && (env_nw_plain == 2 || env_nw_plain == 4 || env_nw_plain == 8 || env_nw_plain == 16))

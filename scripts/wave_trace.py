@@ -53,6 +53,8 @@ if os.environ.get("NS_DECODE_KERNEL", "0") == "1":
     DIMS = {"gateup": (256, 12), "qkv": (256, 12), "down": (256, 12), "wo": (256, 8)}
 else:
     DIMS = {"gateup": (688, 4), "qkv": (768, 4), "down": (256, 16), "wo": (256, 16)}
+if os.environ.get("NS_GV_NW"):  # gemv_kernel with a forced wave count
+    DIMS = {k: (v[0], int(os.environ["NS_GV_NW"])) for k, v in DIMS.items()}
 KARG = os.environ.get("NS_DECODE_KERNEL", "0") == "1"  # slot 7 = "kernargs arrived" (decode_kernel) instead of HW id
 LAYERS = 3
 ORDER = ["qkv", "wo", "gateup", "down"]
