@@ -223,32 +223,27 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
 }
 
 bool alloc_weight(ns_weight* w) {
-  // ONE allocation per weight: [codes | scales | zero points | decode workspace], each 256-byte aligned, so that a
-  // kernel addresses all streams from one base with 32-bit offsets (s_off / z_off)
+  // ONE allocation per weight: [codes | scales | zero points], each 256-byte aligned, so that a kernel addresses all
+  // streams from one base with 32-bit offsets (s_off / z_off)
   auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
-  size_t s_off, z_off, ws_off;
+  size_t s_off, z_off, total;
   if (w->interleaved) {  // scales / zps live inside the record stream
     const size_t cb = size_t(16) * w->sps * (dt_bits(w->scale_dt) / 8);
     s_off = 1024;
     z_off = w->asym ? 1024 + cb : 0;
-    ws_off = pad(w->codes_bytes);
+    total = pad(w->codes_bytes);
   } else {
     s_off = pad(w->codes_bytes);
     z_off = w->asym ? s_off + pad(w->scales_bytes) : 0;
-    ws_off = s_off + pad(w->scales_bytes) + pad(w->zps_bytes);
+    total = s_off + pad(w->scales_bytes) + pad(w->zps_bytes);
   }
-  const size_t total = ws_off + ns::kDecodeWsBytes;
   uint8_t* base = nullptr;
   if (!hip_ok(hipMalloc((void**)&base, total), "hipMalloc(weight)")) return false;
-  // decode_kernel's fix-up flags must start at zero (the kernel leaves them at zero)
-  if (!hip_ok(hipMemset(base + ws_off, 0, ns::kDecodeWsBytes), "hipMemset(workspace)")) return false;
   w->codes = reinterpret_cast<uint4*>(base);
   w->scales = base + s_off;
   w->zps = w->asym ? reinterpret_cast<int8_t*>(base + z_off) : nullptr;
   w->s_off = total < (size_t(1) << 32) ? uint32_t(s_off) : 0;
   w->z_off = total < (size_t(1) << 32) ? uint32_t(z_off) : 0;
-  w->ws_parts = reinterpret_cast<float*>(base + ws_off);
-  w->ws_flags = reinterpret_cast<uint32_t*>(base + ws_off + size_t(ns::kMaxDecodeGrid) * 2 * 256);
   w->single_span = total < (size_t(1) << 32);
   w->alloc_bytes = total;
   hipGetDevice(&w->device);

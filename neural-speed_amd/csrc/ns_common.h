@@ -95,11 +95,7 @@ struct ns_weight {
   // DRAM page as its codes.
   uint32_t qstride = 1024, sstride = 0, zstride = 0;
   bool interleaved = false;
-  // decode_kernel's stream-K fix-up workspace (ns_decode.hip): one flag and one partial-sum record per workgroup.
-  // Owned by the weight, so two streams may run decode GEMVs concurrently as long as they use different weights.
-  uint32_t* ws_flags = nullptr;
-  float* ws_parts = nullptr;
-  // codes, scales, zps and the workspace are ONE allocation: scales = codes + s_off, zps = codes + z_off
+  // codes, scales and zps are ONE allocation: scales = codes + s_off, zps = codes + z_off
   uint32_t s_off = 0, z_off = 0;
   size_t alloc_bytes = 0;
   bool single_span = false;  // the allocation is < 4 GiB, i.e. the offsets above are usable as 32-bit soffsets
@@ -162,10 +158,6 @@ hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, in
 hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st);
 void set_gemv_mode(int mode);
 int decode_waves(int grid, int ks, bool dual);  // waves per workgroup of a decode launch (both kernel generations)  // 0 off, 1 on, 2 on without the stream-K part, -1 re-read NS_GEMV2
-// ns_decode.hip: persistent stream-K kernel for m <= 4; hipErrorNotSupported = outside its envelope (use smallm)
-hipError_t launch_decode(const SmallMArgs& a, hipStream_t st);
-constexpr int kMaxDecodeGrid = 1024;                             // workgroups (= CUs) the fix-up workspace covers
-constexpr size_t kDecodeWsBytes = size_t(kMaxDecodeGrid) * (2 * 256 + 4);  // per weight: partials + flags
 void srow_rule(const ns_weight* w, int* num, int* den);          // scale row of k-step s = s * num / den
 // the same rule as a branch-free (s * mul) >> shift, verified for every k-step; false = not expressible
 bool srow_params(const ns_weight* w, int* mul, int* shift);

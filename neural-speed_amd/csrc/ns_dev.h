@@ -1,4 +1,4 @@
-// ns_dev.h — device-side helpers shared by the gfx950 kernels of libns_hip.so (ns_kernels.hip, ns_decode.hip):
+// ns_dev.h — device-side helpers shared by the gfx950 kernels of libns_hip.so (ns_kernels.hip, ns_gemv.hip, ns_gemm.hip):
 // code -> fp16 converters, raw scale / zero-point records, buffer-descriptor loads, epilogue activations.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -690,10 +690,6 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
     const hipError_t e = launch_gemv(a, st);
     if (e != hipErrorNotSupported) return e;
   }
-  if (a.m <= 4) {  // opt-in experiment (NS_DECODE_KERNEL=1): the persistent stream-K kernel of ns_decode.hip
-    const hipError_t e = launch_decode(a, st);
-    if (e != hipErrorNotSupported) return e;
-  }
   const ns_weight* w0 = a.seg[0].w;
   SmallMParams p;
   memset(&p, 0, sizeof(p));
@@ -1164,7 +1160,7 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const uint4v* __restrict_
   if (acc == 0xdeadbeefu && sink) sink[0] = acc;
 }
 hipError_t launch_prefetch(const ns_weight* w, size_t offset, size_t bytes, int grid, hipStream_t st) {
-  const size_t span = w->alloc_bytes > kDecodeWsBytes ? w->alloc_bytes - kDecodeWsBytes : 0;
+  const size_t span = w->alloc_bytes;
   offset &= ~size_t(15);
   if (offset >= span) return hipSuccess;
   bytes = std::min(bytes, span - offset) & ~size_t(15);
@@ -1172,7 +1168,7 @@ hipError_t launch_prefetch(const ns_weight* w, size_t offset, size_t bytes, int 
   if (grid <= 0) grid = 64;
   grid = std::min(grid, 4096);
   const uint4v* p = reinterpret_cast<const uint4v*>(reinterpret_cast<const unsigned char*>(w->codes) + offset);
-  hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, st, p, bytes / 16, w->ws_flags ? w->ws_flags + (kMaxDecodeGrid - 1) : nullptr);
+  hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, st, p, bytes / 16, static_cast<uint32_t*>(nullptr));
   return hipGetLastError();
 }
 

@@ -108,12 +108,13 @@ static double time_graph(hipGraphExec_t ge, int reps, int warm = 3) {
 int main(int argc, char** argv) {
   int L = 32, d = 4096, ff = 11008, V = 32000, group = 32, reps = 20, tp = 1;
   std::vector<int> modes = {0, 1};
-  bool shadow = true;
+  bool shadow = true, run_chain = false;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--layers")) L = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--tp")) tp = atoi(argv[++i]);  // per-rank shard shapes of tensor-parallel `tp`
     else if (!strcmp(argv[i], "--no-shadow")) shadow = false;
+    else if (!strcmp(argv[i], "--chain")) run_chain = true;
     else if (!strcmp(argv[i], "--modes")) {
       modes.clear();
       for (char* t = strtok(argv[++i], ","); t; t = strtok(nullptr, ",")) modes.push_back(atoi(t));
@@ -234,6 +235,67 @@ int main(int argc, char** argv) {
     fflush(stdout);
     for (hipGraphExec_t g : {gq, go, gg, gd, gh, gc}) CK(hipGraphExecDestroy(g));
   }
+  // ---- the whole chain as ONE persistent launch (experiments/ns_chain.hip; build with -DNS_HAVE_CHAIN) ----
+#ifdef NS_HAVE_CHAIN
+  if (run_chain) {
+    std::vector<ns_chain_op> ops;
+    const void* in = x0h;
+    for (auto& l : layers) {
+      ns_chain_op q{};
+      q.mode = NS_CHAIN_MSEG, q.nmat = 3, q.epilogue = NS_EPI_NONE;
+      q.w[0] = l.q, q.w[1] = l.k, q.w[2] = l.v;
+      q.in16 = in;
+      q.out16[0] = qkvh, q.out16[1] = qkvh + dl, q.out16[2] = qkvh + 2 * dl;
+      ops.push_back(q);
+      ns_chain_op o{};
+      o.mode = NS_CHAIN_PLAIN, o.epilogue = NS_EPI_NONE, o.w[0] = l.o, o.in16 = qkvh, o.out16[0] = attnh;
+      ops.push_back(o);
+      ns_chain_op gu{};
+      gu.mode = NS_CHAIN_DUAL, gu.epilogue = NS_EPI_SILU, gu.w[0] = l.w1, gu.w[1] = l.w3, gu.in16 = attnh, gu.out16[0] = t2h;
+      ops.push_back(gu);
+      ns_chain_op dn{};
+      dn.mode = NS_CHAIN_PLAIN, dn.epilogue = NS_EPI_NONE, dn.w[0] = l.w2, dn.in16 = t2h, dn.out16[0] = xh;
+      ops.push_back(dn);
+      in = xh;
+    }
+    ns_chain_op hd{};
+    hd.mode = NS_CHAIN_PLAIN, hd.epilogue = NS_EPI_NONE, hd.w[0] = head, hd.in16 = in, hd.out32[0] = logits;
+    ops.push_back(hd);
+    ns_chain* ch = ns_hip_chain_create(ops.data(), int(ops.size()));
+    if (!ch) {
+      fprintf(stderr, "chain create failed: %s\n", ns_hip_last_error());
+      return 5;
+    }
+    CK(hipMemsetAsync(logits, 0xff, size_t(V) * 4, g_st));  // poison
+    NSCK(ns_hip_chain_run(ch, g_st));
+    CK(hipStreamSynchronize(g_st));
+    const int err = ns_hip_chain_error(ch);
+    std::vector<float> lg(V);
+    CK(hipMemcpy(lg.data(), logits, size_t(V) * 4, hipMemcpyDeviceToHost));
+    const double diff = ref.empty() ? -1.0 : rel_l2(lg, ref.back());
+    hipGraphExec_t gch = capture([&] { NSCK(ns_hip_chain_run(ch, g_st)); });
+    const double tch = time_graph(gch, reps);
+    printf(",\n  {\"persistent_chain\": true, \"hand_off_error\": %d, \"chain_us\": %.1f, \"tok_s\": %.1f, \"chain_GBps\": %.0f, "
+           "\"logits_rel_l2_vs_first_mode\": %.3g}", err, tch, 1e6 / tch, double(wbytes) / tch / 1e3, diff);
+    CK(hipGraphExecDestroy(gch));
+    if (getenv("CHAIN_TRACE")) {
+      ns_hip_chain_trace(ch, 1, nullptr, 0);
+      for (int r = 0; r < 3; r++) NSCK(ns_hip_chain_run(ch, g_st));
+      CK(hipStreamSynchronize(g_st));
+      const int nshow = 10;
+      std::vector<double> tr(size_t(nshow) * 8);
+      const int got = ns_hip_chain_trace(ch, 0, tr.data(), nshow);
+      for (int i = 0; i < got; i++) {
+        fprintf(stderr, "op %2d:", i);
+        for (int k = 0; k < 7; k++) fprintf(stderr, " %8.2f", tr[size_t(i) * 8 + k]);
+        fprintf(stderr, "\n");
+      }
+    }
+    ns_hip_chain_free(ch);
+  }
+#else
+  (void)run_chain;
+#endif
   printf("\n]}\n");
   return 0;
 }
