@@ -55,6 +55,8 @@ def parse():
 class Chain:
     """Builds the per-rank weights and runs the decode GEMM chain through the C ABI."""
 
+    KEEP_HOST_LAYERS = 4  # host copies for the oracle legs: 4 x 114 MB + lm_head 74 MB = 0.53 GB working set (> any LLC)
+
     def __init__(self, pkg, n_layers, rank, world, keep_host_layer=False):
         self.pkg, self.L = pkg, pkg.lib()
         self.rank, self.world = rank, world
@@ -65,12 +67,13 @@ class Chain:
         self.dl, self.ffl = d // world, ff // world
         self.layers = []
         self.host_blobs = None
+        self.host_layers = []
         self.stream_bytes = 0
         t0 = time.time()
         for il in range(n_layers):
             seed = 1000 + il * 8
             lw = {}
-            kh = keep_host_layer and il == 0
+            kh = keep_host_layer and il < self.KEEP_HOST_LAYERS
             # norm-preserving synthetic init keeps activations O(1) through the chain (random data, no zeros)
             lw["q"] = self._make(self.dl, d, seed + 0, d ** -0.5, kh)
             lw["k"] = self._make(self.dl, d, seed + 1, d ** -0.5, kh)
@@ -79,8 +82,13 @@ class Chain:
             lw["w1"] = self._make(self.ffl, d, seed + 4, d ** -0.5, kh)
             lw["w3"] = self._make(self.ffl, d, seed + 5, d ** -0.5, kh)
             lw["w2"] = self._make(d, self.ffl, seed + 6, (ff ** -0.5) / 0.6, kh)
-            if keep_host_layer and il == 0:
-                self.host_blobs = {k: v[1] for k, v in lw.items()}
+            if kh:
+                if self.host_blobs is None:
+                    self.host_blobs = {}
+                    self.host_layers = []
+                self.host_layers.append({k: v[1] for k, v in lw.items()})
+                if il == 0:
+                    self.host_blobs = dict(self.host_layers[0])
             self.layers.append({k: v[0] for k, v in lw.items()})
         head = self._make(V, d, 999, d ** -0.5, keep_host_layer)
         if keep_host_layer:
@@ -461,9 +469,17 @@ def main():
             out["config"]["INVALID"] = "chain-only diagnostic run (no roofline / cpu_baseline legs)"
             print(json.dumps(out))
             return
+        if world == 1 and chain.host_blobs:
+            # the number only counts if the GPU path agrees with the oracle on the layer it times
+            par = parity_vs_oracle(chain, pkg)
+            out["config"]["parity_rel_l2_vs_oracle"] = par
+            worst = max(par.values())
+            if not worst <= 1e-3:
+                out["config"]["INVALID"] = "GPU chain disagrees with the oracle (rel-L2 %.3g > 1e-3)" % worst
         out["roofline"] = roofline(chain, pkg)
         if world == 1:
             out["config"]["prefill_m2048_tflops"] = prefill_tflops(chain, pkg)
+            out["config"]["prefill_m2048_tflops_int8w"] = prefill_tflops_int8w(chain, pkg)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.layers)
         print(json.dumps(out))
@@ -473,22 +489,30 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+ROOFLINE_KERNEL = "gemv_kernel<INT4,SPS4,BF16,sym,DUAL>"  # demangled: ns::gemv_kernel<0, 4, 0, false, 1>
+
+
 def pmc_traffic(chain):
     """HBM bytes per gate/up launch from the TCC FETCH_SIZE counter.  PMC collection needs its own rocprofv3 pass
     (scripts/pmc_traffic.sh; the driver runs bench.py bare), so the measured per-launch figure is read back from the
-    committed summary; only valid for the tp=1 shapes it was measured on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_fetch_size.json")
+    committed summary — only when that summary was taken on the SAME kernel and grid this run launches (the file records
+    both; a kernel or launch-geometry change makes the figure null until the counters are collected again)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_fetch_size.json")
     if chain.world != 1 or not os.path.exists(path):
         return None
     try:
         d = json.load(open(path))
-        return d["gate_up"]["hbm_bytes_corrected"]
+        g = d["gate_up"]
+        lw = chain.layers[0]
+        if g.get("kernel") != "gemv_kernel" or g.get("grid") != (lw["w1"].n + 15) // 16:
+            return None
+        return g["hbm_bytes_corrected"]
     except Exception:
         return None
 
 
 def roofline(chain, pkg):
-    """Dominant kernel = the fused FFN gate/up weight-streaming GEMV (smallm_kernel<INT4,SPS=4,MB=1,DUAL>): 2 x 4096 x
+    """Dominant kernel = the fused FFN gate/up weight-streaming GEMV (gemv_kernel, dual mode): 2 x 4096 x
     11008/tp int4 weights + bf16 group scales per launch = 27.6 % x 3 of every layer's bytes.  Average launch duration is
     measured live with HIP events on the launch stream around a hipGraph that holds one gate/up launch per layer (each
     layer's own weights, so nothing is cache resident), divided by the number of launches."""
@@ -525,7 +549,7 @@ def roofline(chain, pkg):
     bytes_per_launch = lw["w1"].stream_bytes + lw["w3"].stream_bytes + 4 * (d + chain.ffl)
     achieved = bytes_per_launch / (us * 1e-6) / 1e9
     return {
-        "kernel": "smallm_kernel<INT4,SPS4,MB1,DUAL> (FFN gate/up GEMV)",
+        "kernel": ROOFLINE_KERNEL + " (FFN gate/up GEMV)",
         "bound": "hbm",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
@@ -533,7 +557,7 @@ def roofline(chain, pkg):
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": pmc_traffic(chain),
         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (own pass, scripts/pmc_traffic.sh), x2 gfx950 correction, "
-                          "bytes per gate/up launch at tp=1: profiles/pmc_fetch_size.json",
+                          "bytes per gate/up launch at tp=1: profiles/r02_pmc_fetch_size.json",
         "bytes_per_launch": bytes_per_launch,
         "avg_launch_us": round(us, 3),
         "note": "avg over %d back-to-back graph launches incl. ~1.2us inter-kernel boundary each" % (reps * nl),
@@ -576,64 +600,189 @@ def prefill_tflops(chain, pkg, m=2048):
     return round(flops / ms / 1e9, 1)
 
 
-def cpu_baseline(chain, n_layers):
-    """The oracle's sequential-fp32 GEMV port (oracle/ns_oracle.cpp nso_gemv_f32 == kernel_ref.h gemv_4bit_fp32_fp32)
-    timed on this box's host cores with OpenMP over one layer's GEMMs + lm_head (bounded sample), scaled to a token."""
+def prefill_tflops_int8w(chain, pkg, m=2048):
+    """BASELINE config 3: prefill on INT8 weights (S8 sym g32, bf16 scales), fp16 compute, M = 2048, one layer's seven
+    GEMMs of the Llama-2-7B shapes through the tiled MFMA GEMM; same timing as prefill_tflops."""
+    L = pkg.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d, ff = chain.d, chain.ffl
+    ws = []
+    for i, (n, k) in enumerate([(d, d)] * 4 + [(ff, d)] * 2 + [(d, ff)]):
+        g = torch.Generator(device="cuda").manual_seed(4242 + i)
+        w = torch.randn((n, k), generator=g, device="cuda", dtype=torch.float32) * (k ** -0.5)
+        size = L.ns_BTLAGemmPackBSize(n, k, CFG["group"], pkg.S8, pkg.BF16, False, pkg.COMP_INT8, None)
+        blob = torch.zeros(size, dtype=torch.uint8, device="cuda")
+        pkg.check(L.ns_hip_quant_pack_device(blob.data_ptr(), w.data_ptr(), n, k, k, CFG["group"], pkg.S8, pkg.BF16, False,
+                                             pkg.COMP_INT8, True, st), "quant_pack_device(int8)")
+        ws.append(pkg.Weight.from_device_blob(blob.data_ptr(), size, st))
+        torch.cuda.synchronize()
+        del w, blob
+    a_d = torch.randn((m, d), device="cuda", dtype=torch.float32)
+    a_ff = torch.randn((m, ff), device="cuda", dtype=torch.float32)
+    a_d16, a_ff16 = a_d.half(), a_ff.half()
+    out_big = torch.empty((m, max(d, ff)), device="cuda", dtype=torch.float32)
+    out_big16 = torch.empty((m, max(d, ff)), device="cuda", dtype=torch.float16)
+
+    def run():
+        for wt in ws:
+            a, a16 = (a_d, a_d16) if wt.k == d else (a_ff, a_ff16)
+            pkg.check(L.ns_hip_f32f32_forward_h(a.data_ptr(), a16.data_ptr(), wt.h, out_big.data_ptr(), out_big16.data_ptr(), m,
+                                                wt.k, wt.n, pkg.EPI_NONE, None, 0, st))
+
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 5
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = sum(2.0 * m * wt.n * wt.k for wt in ws)
+    del ws
+    return round(flops / ms / 1e9, 1)
+
+
+def parity_vs_oracle(chain, pkg):
+    """Every GEMV of layer 0 + lm_head, as the timed chain launches it (fp16 shadow in, gemv_kernel), against the
+    oracle's sequential-fp32 GEMV (kernel_ref.h gemv_4bit_fp32_fp32 semantics) on the SAME inputs: relative L2 per
+    operator (the reference's cmpData.diff2); the north-star bar is 1e-3."""
     nso = ge.load_oracle()
-    hb = chain.host_blobs
-    if not hb:
-        return None
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    ncores = min(ncores, 64)  # the scalar port stops scaling long before that (85..667 column tiles per GEMV)
-    rng = np.random.default_rng(7)
-    blobs = {}
-    for k, v in hb.items():
+    L = pkg.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    hb, lw = chain.host_layers[0], chain.layers[0]
+    d, dl, ffl = chain.d, chain.dl, chain.ffl
+    ncores = min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+
+    def blob(v):
         b = nso.aligned_bytes(v.size)
         b[:] = v
-        blobs[k] = b
+        return b
 
-    def run_layer():
+    def gpu(wt, a, epi=pkg.EPI_NONE):
+        a16 = a.to(torch.float16)
+        c = torch.empty((1, wt.n), device="cuda", dtype=torch.float32)
+        pkg.check(L.ns_hip_f32f32_forward_h(a.data_ptr(), a16.data_ptr(), wt.h, c.data_ptr(), None, 1, wt.k, wt.n, epi, None, 0, st))
+        torch.cuda.synchronize()
+        return c
+
+    out = {}
+    x0 = chain.x0
+    x0n = x0.cpu().numpy()
+    # fused QKV launch (what the chain runs) vs three oracle GEMVs
+    qkv = torch.empty((3, 1, dl), device="cuda", dtype=torch.float32)
+    pkg.check(L.ns_hip_fusion_qkv_forward_h(x0.data_ptr(), chain.x0h.data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h, qkv.data_ptr(), None,
+                                            1, d, dl, st))
+    torch.cuda.synchronize()
+    for i, nm in enumerate("qkv"):
+        out["w" + nm] = nso.rel_l2(qkv[i].cpu().numpy(), nso.gemv_f32(x0n, blob(hb[nm]), ncores))
+    q_in = qkv[0]
+    o = gpu(lw["o"], q_in)
+    out["wo"] = nso.rel_l2(o.cpu().numpy(), nso.gemv_f32(q_in.cpu().numpy(), blob(hb["o"]), ncores))
+    # fused gate/up launch vs silu(x W1) * (x W3) from the oracle
+    t2 = torch.empty((1, ffl), device="cuda", dtype=torch.float32)
+    pkg.check(L.ns_hip_fusion_ffn3_gateup_h(o.data_ptr(), o.to(torch.float16).data_ptr(), lw["w1"].h, lw["w3"].h, None, t2.data_ptr(),
+                                            None, 1, pkg.EPI_SILU, st))
+    torch.cuda.synchronize()
+    on = o.cpu().numpy()
+    h1 = nso.gemv_f32(on, blob(hb["w1"]), ncores).astype(np.float64)
+    h3 = nso.gemv_f32(on, blob(hb["w3"]), ncores).astype(np.float64)
+    out["ffn_gate_up"] = nso.rel_l2(t2.cpu().numpy(), (h1 / (1.0 + np.exp(-h1))) * h3)
+    x = gpu(lw["w2"], t2)
+    out["ffn_down"] = nso.rel_l2(x.cpu().numpy(), nso.gemv_f32(t2.cpu().numpy(), blob(hb["w2"]), ncores))
+    lg = gpu(chain.head, x)
+    out["lm_head"] = nso.rel_l2(lg.cpu().numpy(), nso.gemv_f32(x.cpu().numpy(), blob(chain.host_blobs["head"]), ncores))
+    return {k: float("%.3g" % v) for k, v in out.items()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(chain, n_layers):
+    """The oracle's ports of the reference's two decode paths, timed on this box's host cores (SURVEY 8d / BASELINE.md
+    section 3): `fp32` = gemv_4bit_fp32_fp32 (kernel_ref.h:2489-2531), `u8s8` = the DEFAULT int8-compute path
+    (quantize_fp_u8_colblock + gemv_4bit_u8s8_fp32, kernel_ref.h:1824-1883, :2371-2429), both streamed from the packed
+    blobs with OpenMP over the column tiles.  Protocol: 5 warm-ups, then >= 50 timed layer passes (7 GEMVs each) cycling
+    through 4 DIFFERENT layers' weights + lm_head = 0.53 GB working set, larger than any last-level cache (the reference
+    benchmark cycles its weights the same way, ut/bestla_ut.h:69-76); steady-state MIN and median; tokens/s = 1 / (32 x
+    layer + lm_head).  A reported baseline (kernel_ref restatement, NOT the BesTLA JIT), not the target."""
+    nso = ge.load_oracle()
+    if not chain.host_layers:
+        return None
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # 64 threads: the port parallelises over 85..667 column tiles per GEMV with one OpenMP region each; on the 256-thread
+    # GPU hosts it runs 100x SLOWER at 256 threads than at 64 (0.04 vs 6 tokens/s, profiles/r02m_bench.json: fork/join and
+    # dynamic-schedule contention dominate 50 us of work per thread), so the baseline uses the setting that favours the CPU
+    ncores = min(avail, 64)
+    rng = np.random.default_rng(7)
+
+    def aligned(v):
+        b = nso.aligned_bytes(v.size)
+        b[:] = v
+        return b
+
+    layers = [{k: aligned(v) for k, v in hl.items()} for hl in chain.host_layers]
+    head = aligned(chain.host_blobs["head"])
+    x = rng.standard_normal((1, CFG["n_embd"])).astype(np.float32)
+    xf = rng.standard_normal((1, chain.ffl)).astype(np.float32)
+
+    def layer_pass(gemv, lw):
         t0 = time.perf_counter()
-        x = rng.standard_normal((1, CFG["n_embd"])).astype(np.float32)
-        q = nso.gemv_f32(x, blobs["q"], ncores)
-        nso.gemv_f32(x, blobs["k"], ncores)
-        nso.gemv_f32(x, blobs["v"], ncores)
-        o = nso.gemv_f32(q, blobs["o"], ncores)
-        h1 = nso.gemv_f32(o, blobs["w1"], ncores)
-        h3 = nso.gemv_f32(o, blobs["w3"], ncores)
-        nso.gemv_f32((h1 * h3).astype(np.float32), blobs["w2"], ncores)
+        for nm in ("q", "k", "v", "o", "w1", "w3"):
+            gemv(x, lw[nm], ncores)
+        gemv(xf, lw["w2"], ncores)
         return time.perf_counter() - t0
 
-    def run_head():
+    def head_pass(gemv):
         t0 = time.perf_counter()
-        x = rng.standard_normal((1, CFG["n_embd"])).astype(np.float32)
-        nso.gemv_f32(x, blobs["head"], ncores)
+        gemv(x, head, ncores)
         return time.perf_counter() - t0
 
-    # bounded sample: ~0.35 s of wall time on `ncores` threads (about 20 core-seconds on a 64-core host), best repetition
-    run_layer()
-    t_start = time.perf_counter()
-    tls, ths = [], []
-    while True:
-        tls.append(run_layer())
-        ths.append(run_head())
-        if len(tls) >= 3 and time.perf_counter() - t_start > 0.35:
-            break
-        if len(tls) >= 200:
-            break
-    tl, th = min(tls), min(ths)
-    wall = time.perf_counter() - t_start
-    tok_s = 1.0 / (tl * CFG["n_layer"] + th)
+    res = {}
+    t_begin = time.perf_counter()
+    for name, gemv in (("fp32", nso.gemv_f32), ("u8s8", nso.gemv_u8s8)):
+        for it in range(5):
+            layer_pass(gemv, layers[it % len(layers)])
+        head_pass(gemv)
+        tl, th = [], []
+        t_start = time.perf_counter()
+        it = 0
+        while it < 50 or (time.perf_counter() - t_start < 4.0 and it < 400):
+            tl.append(layer_pass(gemv, layers[it % len(layers)]))
+            if it % 4 == 0:
+                th.append(head_pass(gemv))
+            it += 1
+        res[name] = {
+            "tokens_per_s_min": round(1.0 / (min(tl) * CFG["n_layer"] + min(th)), 3),
+            "tokens_per_s_median": round(1.0 / (float(np.median(tl)) * CFG["n_layer"] + float(np.median(th))), 3),
+            "layer_ms_min": round(min(tl) * 1e3, 3), "layer_ms_median": round(float(np.median(tl)) * 1e3, 3),
+            "lm_head_ms_min": round(min(th) * 1e3, 3), "iterations": it,
+        }
+    wall = time.perf_counter() - t_begin
     return {
-        "value": round(tok_s, 3),
+        "value": res["u8s8"]["tokens_per_s_min"],
         "unit": "tokens/s",
         "cores": ncores,
+        "nproc": os.cpu_count(),
+        "affinity_cpus": avail,
+        "cpu_model": _cpu_model(),
         "kind": "port",
-        "sample": "oracle scalar GEMV (kernel_ref gemv_4bit_fp32_fp32 restatement, OpenMP over N): 1 of 32 layers "
-                  "(7 GEMVs) + lm_head, best of %d repetitions in %.2f s wall on %d threads (%.0f core-seconds), "
-                  "layer scaled x32; not the BesTLA JIT path" % (len(tls), wall, ncores, wall * ncores),
-        "layer_ms": round(tl * 1e3, 2),
-        "lm_head_ms": round(th * 1e3, 2),
+        "sample": "oracle ports of kernel_ref gemv_4bit_u8s8_fp32 (the reference's default compute_dtype=int8 path; `value`) and "
+                  "gemv_4bit_fp32_fp32, OpenMP over column tiles on %d threads; >= 50 layer passes (7 GEMVs) cycling through %d "
+                  "layers' weights + lm_head (%.2f GB working set), 5 warm-ups, steady-state min / median, layer x 32 + lm_head; "
+                  "%.1f s wall; kernel_ref restatement, not the BesTLA JIT"
+                  % (ncores, len(layers), (sum(sum(v.size for v in l.values()) for l in layers) + head.size) / 1e9, wall),
+        "u8s8": res["u8s8"],
+        "fp32": res["fp32"],
     }
 
 

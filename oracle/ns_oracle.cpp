@@ -993,6 +993,70 @@ int nso_gemm_u8s8_f32(const float* a, int lda, const void* blob, float* c, int l
   return 0;
 }
 
+// gemv_4bit_u8s8_fp32 read straight from the packed blob (kernel_ref.h:2371-2429 driven the way
+// LauncherIntKBlock::GEMVWrapper::gemv_kblock does it, bestla_wrapper.h:643-688): activations quantized once per call
+// to u8 (quantize_fp_u8_colblock), then per column tile and 4-k step acc += (a_q - zp_a) * (code - zp_b) * (scale_a *
+// scale_b) in fp32, k ascending — the same sums as nso_gemm_u8s8_f32 (tested equal), streamed and threaded over the
+// tiles.  4-bit and 8-bit integer weights.  This is the timed "port" of the reference's DEFAULT decode path.
+int nso_gemv_u8s8_f32(const float* a, int lda, const void* blob, float* c, int ldc, int m, int nthreads) {
+  nso_blob_info bi;
+  if (nso_blob_parse(blob, &bi) || bi.prologue_id != 1) return -1;
+  const int nbits = dt_bits(bi.dtype);
+  if (nbits != 4 && nbits != 8) return -2;
+  if (bi.has_shuffle) return -4;
+  const uint8_t* base = (const uint8_t*)blob;
+  const uint8_t* qb = base + bi.q_off;
+  const uint8_t* sp = base + bi.scale_off;
+  const int8_t* zp = bi.is_asym ? (const int8_t*)(base + bi.zp_off) : nullptr;
+  const int ntiles = bi.npad / bi.ntile;
+  const int NT = bi.ntile, PR = bi.packrow;
+  if (m > 8 || NT > 96) return -3;
+  const int nblk = int(updiv(bi.k, bi.blocksize));
+  std::vector<uint8_t> aq(size_t(m) * bi.k), azp(size_t(m) * nblk);
+  std::vector<float> as(size_t(m) * nblk);
+  nso_quantize_fp_u8_colblock(m, bi.k, a, lda, aq.data(), bi.k, as.data(), nblk, azp.data(), bi.blocksize, nullptr);
+  (void)nthreads;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int t = 0; t < ntiles; t++) {
+    float acc[8][96], sc[96];
+    int zz[96], wq[96];
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < NT; j++) acc[i][j] = 0.f;
+    for (int j = 0; j < NT; j++) zz[j] = 0;
+    const size_t tile_base = size_t(t) * NT * bi.kpad;
+    for (int kb = 0; kb < nblk; kb++) {
+      for (int j = 0; j < NT; j++) {
+        sc[j] = scale_to_f32(sp, bi.scale_dtype, size_t(kb) * bi.cstep + t * NT + j);
+        if (zp) zz[j] = zp[size_t(kb) * bi.cstep + t * NT + j];
+      }
+      const int kend = std::min(bi.k, (kb + 1) * bi.blocksize);
+      for (int kk = kb * bi.blocksize; kk < kend; kk++) {
+        const size_t rowoff = tile_base + size_t(kk / PR) * NT * PR + (kk % PR);
+        if (nbits == 8) {
+          for (int j = 0; j < NT; j++) wq[j] = int(int8_t(qb[rowoff + size_t(j) * PR])) - zz[j];
+        } else {
+          for (int j = 0; j < NT; j++) {
+            const size_t e = rowoff + size_t(j) * PR;
+            wq[j] = int((qb[e >> 1] >> (4 * (e & 1))) & 0xf) - 8 - zz[j];
+          }
+        }
+        for (int i = 0; i < m; i++) {
+          const float av = float(int(aq[size_t(i) * bi.k + kk]) - int(azp[size_t(i) * nblk + kb]));
+          const float sa = as[size_t(i) * nblk + kb];
+          for (int j = 0; j < NT; j++) acc[i][j] += av * float(wq[j]) * (sa * sc[j]);
+        }
+      }
+    }
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < NT; j++)
+        if (t * NT + j < bi.n) c[size_t(i) * ldc + t * NT + j] = acc[i][j];
+  }
+  return 0;
+}
+
 // postop — kernel_ref.h:1569-1578
 float nso_gelu(float x) { return 0.5f * x * (1.f + tanhf(0.7978845834732056f * (x + 0.044714998453855515f * x * x * x))); }
 float nso_silu(float x) { return float(x / (1 + exp(-x))); }

@@ -144,6 +144,9 @@ int nso_quantize_fp_u8_colblock(int row, int col, const float* src, int ld_src, 
                                 float* scales, int ld_scale, uint8_t* zps, int blocksize, float* blkreduce);
 /* int8-compute GEMM semantics (ut/bestla_gemm.cpp:159-190 ref_kblock_int8 / kernel_ref.h:2371-2429) */
 int nso_gemm_u8s8_f32(const float* a, int lda, const void* blob, float* c, int ldc, int m);
+/* the same sums read straight from the packed blob, OpenMP over the column tiles (the timed CPU-baseline port of the
+ * reference's default int8-compute decode path, bestla_wrapper.h:643-688) */
+int nso_gemv_u8s8_f32(const float* a, int lda, const void* blob, float* c, int ldc, int m, int nthreads);
 
 /* epilogue helpers — bestla_common.hpp:121-215, ip_fusion_ffn.cpp */
 float nso_gelu(float x);

@@ -57,6 +57,10 @@ def build(force=False):
         srcs = [os.path.join(HERE, f) for f in ("ne_ref_harness.c", "ne_ref_stubs.c")]
         if force or not os.path.exists(nref) or os.path.getmtime(nref) < max(os.path.getmtime(f) for f in srcs):
             subprocess.check_call(["make", "-C", HERE, "neref"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/bestla/bestla/bestla_storage.h"):
+        sref = os.path.join(HERE, "_ref", "libstor_ref.so")
+        if force or not os.path.exists(sref) or os.path.getmtime(sref) < os.path.getmtime(os.path.join(HERE, "stor_shim.cpp")):
+            subprocess.check_call(["make", "-C", HERE, "storref"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/bestla/bestla/kernel_ref.h"):
         ref = os.path.join(HERE, "_ref", "libkernel_ref.so")
         if force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(os.path.join(HERE, "ref_shim.cpp")):
@@ -124,6 +128,27 @@ def ref():
         _ref.ref_cast_f32_u8.argtypes = [C.c_float]
         _ref.ref_postop.argtypes = [C.c_float, C.c_int]
     return _ref
+
+
+_stor = None
+
+
+def storref():
+    """The reference's own blob container classes (bestla_storage.h compiled into oracle/_ref/libstor_ref.so by
+    `make -C oracle storref`, see oracle/stor_shim.cpp); None when it was never built."""
+    global _stor
+    if _stor is None:
+        p = os.path.join(HERE, "_ref", "libstor_ref.so")
+        if not os.path.exists(p) and os.path.exists("/root/reference/bestla/bestla/bestla_storage.h"):
+            subprocess.check_call(["make", "-C", HERE, "storref"], stdout=subprocess.DEVNULL)
+        if not os.path.exists(p):
+            return None
+        _stor = C.CDLL(p)
+        _stor.stor_assign.restype = C.c_uint64
+        _stor.stor_assign.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                      C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _stor.stor_deserialize.argtypes = [C.c_void_p, C.c_void_p]
+    return _stor
 
 
 _neref = None
@@ -351,6 +376,16 @@ def gemv_f32(a, blob, nthreads=0):
     m = a.shape[0]
     c = np.zeros((m, bi.n), np.float32)
     assert lib().nso_gemv_f32(ptr(a), a.shape[1], ptr(blob), ptr(c), bi.n, m, nthreads) == 0
+    return c
+
+
+def gemv_u8s8(a, blob, nthreads=0):
+    """the reference's default decode numerics (u8 activations x s8/s4 weights), streamed from the packed blob"""
+    a = np.ascontiguousarray(a, np.float32)
+    bi = parse(blob)
+    m = a.shape[0]
+    c = np.zeros((m, bi.n), np.float32)
+    assert lib().nso_gemv_u8s8_f32(ptr(a), a.shape[1], ptr(blob), ptr(c), bi.n, m, nthreads) == 0
     return c
 
 

@@ -10,7 +10,7 @@ for r in rows:
     if r.get("Counter_Name") != "FETCH_SIZE":
         continue
     name = r["Kernel_Name"]
-    if "smallm" not in name and "decode_kernel" not in name and "gemm" not in name:
+    if "smallm" not in name and "gemv_kernel" not in name and "gemm" not in name:
         continue
     short = name.split("(")[0].replace("void ns::", "")
     key = (short, r.get("Grid_Size", ""), r.get("Workgroup_Size", ""))
@@ -23,3 +23,14 @@ for (k, g, w), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print("%-56s %8s %6s %6d %14.1f %14.2f" % (k[:56], g, w, len(v), avg, mb))
     out["%s|%s|%s" % (k, g, w)] = {"calls": len(v), "fetch_size_kib_avg": avg, "hbm_bytes_corrected": avg * 1024 * 2}
 json.dump(out, open(sys.argv[1].replace(".csv", "_summary.json"), "w"), indent=1)
+# the summary bench.py reads back (roofline.traffic): the fused gate/up launch = gemv_kernel in dual mode (5th template
+# argument 1), recorded with the kernel name and the launch grid so that a change of either invalidates it
+gu = [(k, v) for k, v in out.items() if k.startswith("gemv_kernel<") and k.split("|")[0].rstrip(">").split(",")[4].strip() == "1"]
+if gu and len(sys.argv) > 2:
+    k, v = max(gu, key=lambda kv: kv[1]["calls"])
+    _, g, w = k.split("|")
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 3 --warmup 1 (scripts/pmc_traffic.sh)",
+               "correction": "FETCH_SIZE(KiB)*1024*2 (MI355X_MICROARCH.md HBM section: 128-B requests tallied at 64 B on gfx950)",
+               "gate_up": dict(v, kernel="gemv_kernel", kernel_full=k.split("|")[0], grid=int(g) // int(w), workgroup=int(w)),
+               "all": out}, open(sys.argv[2], "w"), indent=1)
+    print("wrote", sys.argv[2])

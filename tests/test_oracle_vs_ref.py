@@ -408,3 +408,15 @@ def test_unpack_f8_matches_reference_tile_dequant(nso, refk, f8, st, core, packr
         deq = dst.reshape(bi.kpad // packrow, nt, packrow).transpose(0, 2, 1).reshape(bi.kpad, nt)
         cols = min(nt, bi.n - t * nt)
         assert np.array_equal(mine[:, t * nt:t * nt + cols].view(np.uint32), deq[:bi.k, :cols].view(np.uint32))
+
+
+def test_streamed_u8s8_gemv_equals_canonical_form(nso):
+    """nso_gemv_u8s8_f32 (reads the packed tiles, threaded: bench.py's CPU-baseline port of the default int8-compute decode
+    path) adds exactly what nso_gemm_u8s8_f32 (unpacked, pinned above to gemv_4bit_u8s8_fp32) adds, in the same order"""
+    rng = np.random.default_rng(31)
+    for (n, k, bs, q, asym, core) in [(100, 256, 32, nso.S4, False, nso.CORE_AVX512_VNNI_KB), (64, 192, 64, nso.S8, True, nso.CORE_AMX_INT8_KB),
+                                      (50, 160, 32, nso.S4, True, nso.CORE_AVX2_VNNI_KB), (48, 128, 128, nso.S4, False, nso.CORE_AVX512F)]:
+        w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+        blob = nso.quant_pack(w, bs, q, nso.BF16, asym, core)
+        a = rng.standard_normal((3, k)).astype(np.float32)
+        assert np.array_equal(nso.gemm_u8s8(a, blob), nso.gemv_u8s8(a, blob, 4))
