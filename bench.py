@@ -353,6 +353,10 @@ def main():
     pctx = par.init_parallel_context(backend if world > 1 else None)
     # decode-sized all-reduces: one-shot kernel over peer-mapped HBM (xGMI), RCCL otherwise.  NS_P2P=0 keeps RCCL.
     use_p2p = world > 1 and os.environ.get("NS_P2P", "1") != "0" and pctx.enable_p2p(1 << 20)
+    # the collectives themselves go through the library's native layer (ns_tp_*: RCCL / the peer-memory kernel behind a
+    # C ABI); torch.distributed only bootstraps it (128-byte unique id) and carries the failure flags.  NS_TP_NATIVE=0
+    # keeps torch's ProcessGroup all-reduce instead.
+    use_native = world > 1 and os.environ.get("NS_TP_NATIVE", "1") != "0" and backend == "nccl" and pctx.enable_native()
     chain = Chain(pkg, args.layers, rank, world, keep_host_layer=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     # the chain object itself carries the captured stream handle; under graph capture torch switches the current
     # stream, so the stream pointer handed to the C ABI must be re-read inside the capture.
@@ -420,6 +424,7 @@ def main():
         sys.stderr.write("launch mode %r (%s all-reduce) failed (%s); trying the next one\n" %
                          (use_graph, "peer-memory" if with_p2p else "RCCL",
                           str(err).splitlines()[0] if err else "on another rank"))
+    comm = all_reduce_latency(chain, world, pctx.p2p_enabled() or backend == "nccl") if world > 1 else None  # collective
     t = torch.tensor([wall_ms], device="cuda", dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -449,8 +454,9 @@ def main():
                            "hipGraph per GEMM run + eager all-reduce" if use_graph == "segments" else "eager"),
                 "weights_bytes_per_gpu": chain.stream_bytes,
                 "all_reduce": (None if world == 1 else
-                               "one-shot kernel over peer-mapped HBM (HIP IPC, xGMI)" if pctx.p2p_enabled() else
-                               "torch.distributed all_reduce (%s)" % backend),
+                               ("ns_tp_reduce_add (native C ABI): " if pctx.native_enabled() else "") +
+                               ("one-shot kernel over peer-mapped HBM (HIP IPC, xGMI)" if pctx.p2p_enabled() else
+                                "RCCL all-reduce" if pctx.native_enabled() else "torch.distributed all_reduce (%s)" % backend)),
                 "event_ms_per_step": round(ev_ms / args.steps, 5),
             },
         }
@@ -477,6 +483,10 @@ def main():
             if not worst <= 1e-3:
                 out["config"]["INVALID"] = "GPU chain disagrees with the oracle (rel-L2 %.3g > 1e-3)" % worst
         out["roofline"] = roofline(chain, pkg)
+        if world > 1 and comm is not None:
+            out["config"]["all_reduce_us"] = comm["us"]
+            out["config"]["all_reduces_per_step"] = comm["per_step"]
+            out["config"]["comm_fraction"] = round(comm["us"] * comm["per_step"] / (ms_per_step * 1e3), 4)
         if world == 1:
             out["config"]["prefill_m2048_tflops"] = prefill_tflops(chain, pkg)
             out["config"]["prefill_m2048_tflops_int8w"] = prefill_tflops_int8w(chain, pkg)
@@ -484,12 +494,58 @@ def main():
             out["cpu_baseline"] = cpu_baseline(chain, args.layers)
         print(json.dumps(out))
     if world > 1:
+        pctx.disable_native()
         pctx.disable_p2p()  # collective: unmap peers, barrier, free
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
 ROOFLINE_KERNEL = "gemv_kernel<INT4,SPS4,BF16,sym,DUAL>"  # demangled: ns::gemv_kernel<0, 4, 0, false, 1>
+
+
+def all_reduce_latency(chain, world, try_graph):
+    """per-all-reduce time of the decode-sized buffer ([1][n_embd] fp32) on the path the timed step used: 64 back-to-back
+    calls in one HIP graph when that captures, eager otherwise; max over ranks."""
+    x = torch.zeros((1, chain.d), device="cuda", dtype=torch.float32)
+    n = 64
+
+    def body():
+        for _ in range(n):
+            REDUCE(x)
+
+    torch.distributed.barrier()
+    body()
+    torch.cuda.synchronize()
+    run = body
+    try:
+        if not try_graph:  # a process-group all-reduce that is not capturable (gloo) must not be called under capture
+            raise RuntimeError("eager")
+        g = capture(body)
+        run = g.replay
+        failed = 0
+    except Exception:  # noqa: BLE001
+        failed = 1
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
+        ge.load_package().lib().ns_hip_reset_error()
+    if agree_failed(failed, world):
+        run = body
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = torch.tensor([e0.elapsed_time(e1) * 1e3 / (reps * n)], device="cuda", dtype=torch.float64)
+    torch.distributed.all_reduce(us, op=torch.distributed.ReduceOp.MAX)
+    return {"us": round(float(us.item()), 2), "per_step": 2 * len(chain.layers)}
 
 
 def pmc_traffic(chain):

@@ -391,6 +391,42 @@ int ns_hip_p2p_error(ns_p2p* ctx);
 void ns_hip_p2p_disconnect(ns_p2p* ctx);
 void ns_hip_p2p_destroy(ns_p2p* ctx);
 
+/* ----------------------------------------------------------------------------------------------
+ * Part 6 — tensor-parallel communication layer: the eight functions of
+ * /root/reference/neural_speed/core/parallel_context.h:40-47 (impl parallel_context.cpp:19-160: oneCCL over MPI, one
+ * process per CPU socket) as a native C ABI over RCCL / xGMI, one process per GPU, DEVICE fp32 buffers, asynchronous on
+ * a stream, capturable.  RCCL is loaded at ns_tp_init (dlopen), not at library load.
+ *   bootstrap : rank 0 calls ns_tp_unique_id (128 bytes) and hands the bytes to the other ranks by any out-of-band means
+ *               (the reference uses MPI_Bcast of the oneCCL kvs address, parallel_context.cpp:86-98); every rank then
+ *               calls ns_tp_init(rank, world, id, device).  world == 1 accepts id == NULL.
+ *   reduce_add: fp32 sum over ranks (ne_compute_forward_all_reduce, ne_layers.c:5466-5476, calls it in place); buffers
+ *               that fit an attached peer-memory context (ns_tp_attach_p2p, part 5) take the one-shot xGMI kernel,
+ *               like the reference's shm_all_reduce shortcut (parallel_context.cpp:47-58)
+ *   broadcast : from rank 0 (parallel_context.cpp:59-62);  alltoall: count elements per peer (:63-65, no caller)
+ *   barrier   : synchronises the stream as well (the reference's is a blocking host call)
+ * The reference-named HOST-pointer functions (init_parallel_context, reduce_add, ...) for a ggml build are
+ * glue/parallel_context_hip.cpp.  All functions return 0 / non-NULL on success; ns_hip_last_error() has the reason.
+ * ---------------------------------------------------------------------------------------------- */
+#define NS_TP_UNIQUE_ID_BYTES 128
+typedef struct ns_tp ns_tp;
+int ns_tp_unique_id(void* out128);
+ns_tp* ns_tp_init(int rank, int world, const void* unique_id128, int device);
+void ns_tp_destroy(ns_tp* tp);
+int ns_tp_size(const ns_tp* tp);
+int ns_tp_rank(const ns_tp* tp);
+int ns_tp_is_master(const ns_tp* tp);
+int ns_tp_attach_p2p(ns_tp* tp, ns_p2p* p2p, size_t max_bytes);
+int ns_tp_reduce_add(ns_tp* tp, const float* dSend, float* dRecv, size_t count, void* stream);
+int ns_tp_broadcast(ns_tp* tp, float* dBuf, size_t count, void* stream);
+int ns_tp_alltoall(ns_tp* tp, const float* dSend, float* dRecv, size_t count, void* stream);
+int ns_tp_barrier(ns_tp* tp, void* stream);
+/* host-pointer forms (blocking, staged through device memory; with one rank plain copies that touch no GPU —
+ * ns_tp_init(0, 1, NULL, -1) creates such a context without a device) */
+int ns_tp_reduce_add_host(ns_tp* tp, const float* send, float* recv, size_t count);
+int ns_tp_broadcast_host(ns_tp* tp, float* buf, size_t count);
+int ns_tp_alltoall_host(ns_tp* tp, const float* send, float* recv, size_t count);
+int ns_tp_barrier_host(ns_tp* tp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,23 @@ def lib():
         L.ns_hip_p2p_disconnect.argtypes = [vp]
         L.ns_hip_p2p_destroy.restype = None
         L.ns_hip_p2p_destroy.argtypes = [vp]
+        L.ns_tp_unique_id.argtypes = [vp]
+        L.ns_tp_init.restype = vp
+        L.ns_tp_init.argtypes = [i, i, vp, i]
+        L.ns_tp_destroy.restype = None
+        L.ns_tp_destroy.argtypes = [vp]
+        for fn_ in (L.ns_tp_size, L.ns_tp_rank, L.ns_tp_is_master):
+            fn_.argtypes = [vp]
+        L.ns_tp_attach_p2p.argtypes = [vp, vp, sz]
+        L.ns_tp_reduce_add.argtypes = [vp, vp, vp, sz, vp]
+        L.ns_tp_broadcast.argtypes = [vp, vp, sz, vp]
+        L.ns_tp_alltoall.argtypes = [vp, vp, vp, sz, vp]
+        L.ns_tp_barrier.argtypes = [vp, vp]
+        L.ns_tp_reduce_add_host.argtypes = [vp, vp, vp, sz]
+        L.ns_tp_broadcast_host.argtypes = [vp, sz]
+        L.ns_tp_alltoall_host.argtypes = [vp, vp, vp, sz]
+        L.ns_tp_barrier_host.argtypes = [vp]
+        L.ns_hip_set_tuning.argtypes = [C.c_char_p, i]
         L.ns_hip_weight_info.argtypes = [vp] + [vp] * 5
         L.ns_hip_f32f32_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
         L.ns_hip_fusion_qkv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]

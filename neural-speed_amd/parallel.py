@@ -16,21 +16,42 @@ import os
 import torch
 import torch.distributed as dist
 
-TENSOR_NO_CHANGE, TENSOR_1D_ROW, TENSOR_1D_COLUMN = 0, 1, 2
+TENSOR_NO_CHANGE, TENSOR_1D_ROW, TENSOR_1D_COLUMN, TENSOR_1D_QKV_ROW, TENSOR_1D_QKV_COLUMN, TENSOR_1D_ONLY_MASTER = range(6)
 
-_ROW_KEYS = ("attention.wq.weight", "attention.wk.weight", "attention.wv.weight", "feed_forward.w1.weight",
-             "feed_forward.w3.weight", "attn.q_proj.weight", "attn.k_proj.weight", "attn.v_proj.weight",
-             "mlp.fc_in.weight", "mlp.fc_in.bias")
-_COL_KEYS = ("attention.wo.weight", "feed_forward.w2.weight", "attn.out_proj.weight", "mlp.fc_out.weight")
+# model_load_tensor::calc_split_type, model_files.h:145-190 — the full key table, in the reference's order of precedence
+# (later groups override earlier ones).  ".mlp.fc_in.bias" sits in the reference's COLUMN group: a 1-D tensor split
+# along its only axis, i.e. the N slice that goes with fc_in.weight's ROW split.
+_ROW_KEYS = (".attn.q_proj.weight", ".attn.k_proj.weight", ".attn.v_proj.weight", ".mlp.fc_in.weight",
+             ".mlp.gate_proj.weight", ".mlp.up_proj.weight",                 # baichuan
+             ".mlp.dense_h_to_4h.weight",                                      # chatglm2
+             ".attention.wq.weight", ".attention.wk.weight", ".attention.wv.weight", ".feed_forward.w1.weight",
+             ".feed_forward.w3.weight")                                        # llama
+_QKV_ROW_KEYS = (".self_attn.W_pack.weight", ".self_attention.query_key_value.weight")
+_QKV_COL_KEYS = (".self_attention.query_key_value.bias",)
+_COL_KEYS = (".mlp.fc_in.bias", ".mlp.fc_out.weight", ".attn.out_proj.weight", ".self_attention.dense.weight",
+             ".self_attn.o_proj.weight", ".mlp.down_proj.weight",            # baichuan
+             ".mlp.dense_4h_to_h.weight",                                      # chatglm2
+             ".attention.wo.weight", ".feed_forward.w2.weight")
+_MASTER_KEYS = (".mlp.fc_out.bias",)
 
 
 def calc_split_type(name):
-    """model_load_tensor::calc_split_type (model_files.h:145-190)"""
+    """model_load_tensor::calc_split_type (model_files.h:145-190): how a tensor is cut for tensor parallelism.
+    ROW = N slice (independent output columns), COLUMN = K slice (partial sums, all-reduced afterwards), QKV_ROW /
+    QKV_COLUMN = the fused q|k|v tensor cut inside each of its three parts, ONLY_MASTER = kept on rank 0 and zero on the
+    others (a bias that is added once, after the all-reduce).  Everything else is replicated."""
+    t = TENSOR_NO_CHANGE
     if any(k in name for k in _ROW_KEYS):
-        return TENSOR_1D_ROW
+        t = TENSOR_1D_ROW
+    if any(k in name for k in _QKV_ROW_KEYS):
+        t = TENSOR_1D_QKV_ROW
+    if any(k in name for k in _QKV_COL_KEYS):
+        t = TENSOR_1D_QKV_COLUMN
     if any(k in name for k in _COL_KEYS):
-        return TENSOR_1D_COLUMN
-    return TENSOR_NO_CHANGE
+        t = TENSOR_1D_COLUMN
+    if any(k in name for k in _MASTER_KEYS):
+        t = TENSOR_1D_ONLY_MASTER
+    return t
 
 
 class ParallelContext:
@@ -39,6 +60,7 @@ class ParallelContext:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self._p2p, self._p2p_max = None, 0
+        self._tp = None  # native communicator (ns_tp_*, RCCL without torch in the data path)
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend is None:
@@ -80,14 +102,63 @@ class ParallelContext:
         buffers to shm_all_reduce (shared_memory_ccl.hpp:100-139) and the rest to oneCCL, fp32 device buffers that fit
         the peer-memory slot go through the one-shot xGMI kernel (enable_p2p), everything else through RCCL."""
         if self.world > 1:
-            if (self._p2p is not None and buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
-                    and buf.numel() * 4 <= self._p2p_max and buf.data_ptr() % 16 == 0):
+            native_ok = buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+            if native_ok and self._tp is not None:
+                # ns_tp_reduce_add: the one-shot xGMI kernel for buffers that fit the attached peer-memory context, RCCL
+                # otherwise — C ABI end to end, asynchronous on the current stream, capturable
+                from . import check, lib
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                check(lib().ns_tp_reduce_add(self._tp, buf.data_ptr(), buf.data_ptr(), buf.numel(), st), "ns_tp_reduce_add")
+            elif (native_ok and self._p2p is not None and buf.numel() * 4 <= self._p2p_max and buf.data_ptr() % 16 == 0):
                 from . import check, lib
                 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 check(lib().ns_hip_p2p_all_reduce_f32(self._p2p, buf.data_ptr(), buf.numel(), st), "p2p all-reduce")
             else:
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         return buf
+
+    # native communicator: RCCL through the C ABI (csrc/ns_tp.cpp) ---------------------------------------------------
+    def enable_native(self):
+        """Collective.  Rank 0 draws the RCCL unique id, the process group carries its 128 bytes to the others, every
+        rank builds its communicator with ns_tp_init.  True when ALL ranks succeeded; otherwise every rank stays on
+        torch.distributed."""
+        if self.world == 1 or self._tp is not None:
+            return self._tp is not None
+        from . import lib
+        L = lib()
+        idbuf = C.create_string_buffer(128)
+        ok = True
+        if self.rank == 0:
+            ok = L.ns_tp_unique_id(idbuf) == 0
+        box = [(ok, bytes(idbuf.raw))]
+        dist.broadcast_object_list(box, src=0)
+        ok, raw = box[0]
+        tp = None
+        if ok:
+            tp = L.ns_tp_init(self.rank, self.world, raw, self.local_rank)
+        oks = [None] * self.world
+        dist.all_gather_object(oks, bool(tp))
+        if not all(oks):
+            L.ns_hip_reset_error()
+            if tp:
+                L.ns_tp_destroy(tp)
+            return False
+        self._tp = tp
+        if self._p2p is not None:
+            L.ns_tp_attach_p2p(self._tp, self._p2p, self._p2p_max)
+        return True
+
+    def native_enabled(self):
+        return self._tp is not None
+
+    def disable_native(self):
+        if self._tp is None:
+            return
+        from . import lib
+        torch.cuda.synchronize()
+        dist.barrier()
+        lib().ns_tp_destroy(self._tp)
+        self._tp = None
 
     # one-shot all-reduce over peer-mapped HBM (csrc/ns_p2p.hip) ----------------------------------------------------
     def enable_p2p(self, max_bytes=1 << 20):
@@ -118,6 +189,8 @@ class ParallelContext:
                 L.ns_hip_p2p_destroy(ctx)
             return False
         self._p2p, self._p2p_max = ctx, max_bytes
+        if self._tp is not None:
+            L.ns_tp_attach_p2p(self._tp, ctx, max_bytes)
         return True
 
     def p2p_enabled(self):
@@ -140,6 +213,8 @@ class ParallelContext:
         from . import lib
         L = lib()
         torch.cuda.synchronize()
+        if self._tp is not None:
+            L.ns_tp_attach_p2p(self._tp, None, 0)
         L.ns_hip_p2p_disconnect(self._p2p)
         dist.barrier()
         L.ns_hip_p2p_destroy(self._p2p)
@@ -157,6 +232,10 @@ class ParallelContext:
         """TP shard of a device weight (ns_hip_weight_slice): ROW -> N slice, COLUMN -> K slice."""
         if self.world == 1 or split_type == TENSOR_NO_CHANGE:
             return weight
+        if split_type in (TENSOR_1D_QKV_ROW, TENSOR_1D_QKV_COLUMN, TENSOR_1D_ONLY_MASTER):
+            # fused q|k|v tensors are cut inside each third (model_files.h:1603-1680) and master-only biases are fp32
+            # vectors: neither is a single N / K slice of a quantized weight — refuse instead of replicating silently
+            raise NotImplementedError("split type %d is not a plain N / K slice of a packed weight" % split_type)
         if split_type == TENSOR_1D_ROW:
             n0, n1 = self.shard_range(weight.n, 16)
             return weight.slice(n0, n1, 0, weight.k, stream)

@@ -9,7 +9,8 @@
  *       reference's side, unchanged graph code included (ne_compute_forward_mul_mat_q_f32_bestla, ne_layers.c:7219-7316).
  *
  * The three graph-struct entry points (bestla_parallel_for / bestla_support / bestla_backend_support) are the glue a
- * maintainer adds on the ggml side; they are written here against the reference's headers.
+ * maintainer adds on the ggml side: glue/ne_bestla_hip_glue.c, written against the
+ * reference's headers and linked into this library.
  * Every other `bestla_*` symbol has an aborting fallback in ne_ref_stubs.c, which libns_hip.so interposes when it is
  * loaded with RTLD_GLOBAL before this library.
  */
@@ -24,55 +25,8 @@
 #include "ne_bestla.h"
 #include "ne_layers.h"
 
-/* ---- glue: INTEGRATION.md section 2 (reference: core/layers/ne_bestla.cpp:42-72, :176-276) -------------------- */
-void bestla_parallel_for(forward_compute_fptr f, struct ne_compute_params* mp, struct ne_tensor* node) {
-  struct ne_compute_params p = *mp; /* graphs run with one host thread here: every node has n_tasks == 1 */
-  p.ith = 0;
-  p.nth = 1;
-  p.type = NE_TASK_INIT;
-  f(&p, node);
-  p.type = NE_TASK_COMPUTE;
-  f(&p, node);
-  p.type = NE_TASK_FINALIZE;
-  f(&p, node);
-}
-
-bool bestla_support(struct ne_tensor* node, int n_threads, size_t* workspace, size_t* dev_workspace) {
-  (void)n_threads;
-  *workspace = 0;
-  *dev_workspace = 0;
-  switch (node->op) {
-    case NE_OP_MUL_MAT:
-    case NE_OP_MUL_MAT_BIAS:
-      if (node->src0->type != NE_TYPE_BTLA) return false;
-      *workspace = bestla_f32f32_get_workspace_size((int)node->src1->ne[1], (int)node->src0->ne[1], (int)node->src1->ne[0],
-                                                    node->src0->data);
-      break;
-    case NE_OP_MUL_QKV:
-      *workspace = bestla_fusion_QKV_f32f32_get_workspace_size((int)node->src0->ne[1], (int)node->src1->ne[1],
-                                                               (int)node->src1->ne[0], node->src1->data);
-      break;
-    case NE_OP_MUL_FFN_SILU:
-    case NE_OP_MUL_FFN_GELU:
-    case NE_OP_MUL_FFN_GELU_MUL:
-    case NE_OP_MUL_FFN_ADD_GELU:
-      *workspace = bestla_fusion_FFN_f32f32_get_workspace_size((int)node->src0->ne[1], (int)node->src0->ne[0],
-                                                               (int)node->src1->ne[1], (int)node->opt[0]->ne[1],
-                                                               node->src1->data, node->opt[0]->data);
-      break;
-    default:
-      return false;
-  }
-  node->n_tasks = 1;
-  return true;
-}
-
-enum ne_backend bestla_backend_support(struct ne_tensor* a, struct ne_tensor* b, enum ne_op op) {
-  (void)a;
-  (void)b;
-  (void)op;
-  return NE_BACKEND_CPU;
-}
+/* the three graph-struct entry points live in glue/ne_bestla_hip_glue.c (product glue, compiled into this library by
+ * oracle/Makefile) */
 
 /* non-static builder of every RoPE flavour (ne_layers.c:3377-3434) */
 struct ne_tensor* ne_rope_impl(struct ne_context* ctx, struct ne_tensor* a, int n_past, int n_dims, int mode, int prompt_size,
@@ -353,3 +307,4 @@ int neref_decoder_layer(const float* x, float* out, int T, int d, int heads, int
   ne_free(wctx);
   return 0;
 }
+
