@@ -138,7 +138,14 @@ void ns_hip_reset_error(void);
 /* part-1 entry points cache {host blob pointer -> device weight} (validated by a content fingerprint); this
  * drops every cached device weight, e.g. after the model that owned the blobs was unloaded. */
 void ns_hip_cache_clear(void);
+/* per calling thread (like errno); valid until that thread's next failing call */
 const char* ns_hip_last_error(void);
+/* Header-only check of a reference-format blob, no device needed: the same validation every loader entry applies —
+ * geometry (n, k, pads, tile divisibility) AND that each section (codes, scales, zero points, reductions, shuffle
+ * indices) is at least as large as the geometry requires and ends inside the blob's serialized size.  avail_bytes
+ * (0 = unknown) additionally bounds the serialized size, e.g. by what is left of the model file.  0 = ok; -1 with
+ * ns_hip_last_error() otherwise.  A truncated / corrupt model file is refused here instead of faulting in HBM. */
+int ns_hip_blob_validate(const void* host_blob, size_t avail_bytes);
 /* host blob (reference format) -> device weight.  The blob is only read. */
 ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream);
 /* same, blob bytes already in device memory (dev_blob_base_mod64 = (host address the blob was packed at) & 63;
@@ -349,6 +356,10 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
 bool bestla_reordered_attn_fp32_support(const attn_shape_t* params);
 /* same operator on DEVICE pointers, asynchronous on `stream`; returns 0 on success */
 int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* dparams, void* stream);
+/* Tensor-parallel head split for NS_ATTN_FLAG_IS_ALIBI8 (mha_dense_wrapper.h:1418-1447 under NS_TP_MODEL: the slopes
+ * follow head_num * world and start at rank * head_num).  Process-wide (one process per GPU); (0, 0) clears it.
+ * A forward call whose heads do not fit the partition is refused. */
+int ns_hip_attn_set_head_partition(int global_head_num, int head_offset);
 
 /* ----------------------------------------------------------------------------------------------
  * Part 4b — mixture-of-experts matmul with the routing on the device.  Device twin of
@@ -377,7 +388,10 @@ int ns_hip_mul_mat_id(const float* dA, const int32_t* dIds, int ids_stride, int 
  * GPU.  In-place fp32 sum, summed in rank order on every rank (bit-identical results everywhere).  Capturable.
  *   create  : allocates this rank's segment (2 slots of max_bytes + flag page) and returns its IPC handle (64 bytes)
  *   connect : maps the segments of all ranks; `all_handles` = world x 64 bytes in rank order (own entry ignored)
- *   all_reduce_f32 : n * 4 <= max_bytes, dBuf 16-byte aligned; asynchronous on `stream`
+ *   all_reduce_f32 : n * 4 <= max_bytes, dBuf 16-byte aligned; asynchronous on `stream`.  ONE stream per context at a
+ *             time (the sequence counter in the segment is owned by the kernel in flight; a captured graph must be
+ *             replayed on a stream ordered with every other user of the context).  Returns -2, without launching,
+ *             once an earlier call's flag wait has timed out (the kernel raises a pinned host word; no sync needed)
  *   error   : synchronous read of the sticky device status: 0 ok, 1 = a flag wait exceeded NS_P2P_TIMEOUT_MS (default
  *             10000; a peer died or never launched the matching call — results after that are undefined), -1 = bad ctx
  *   disconnect (every rank) -> barrier -> destroy

@@ -173,6 +173,8 @@ def lib():
         L.bestla_fusion_attn_fp32_fp16_fp16_fp32_forward.restype = None
         L.bestla_fusion_attn_fp32_fp16_fp16_fp32_forward.argtypes = [vp]
         L.ns_hip_attn_fp32_fp16_fp16_fp32_forward.argtypes = [vp, vp]
+        L.ns_hip_attn_set_head_partition.argtypes = [i, i]
+        L.ns_hip_blob_validate.argtypes = [vp, sz]
         L.ns_BTLAGemmPackBSize.restype = sz
         L.ns_BTLAGemmPackBSize.argtypes = [sz, sz, sz, u32, u32, b, i, vp]
         L.ns_BTLAGemmQuantPackB.restype = b

@@ -33,7 +33,8 @@ std::mutex g_mu;
 // The host-pointer entry points share process-wide staging buffers (and the default stream).  The reference runs them
 // from one thread at a time (n_tasks = 1, ne_bestla.cpp:270-272); callers that do not are serialised here.
 std::mutex g_host_mu;
-std::string g_err;
+// Per calling thread, like errno: a failure on one thread is never reported to (or overwritten by) another.
+thread_local std::string g_err;
 int g_pack_core = NS_CORE_AUTO;
 struct CacheEntry {
   ns_weight* w;
@@ -239,7 +240,7 @@ bool alloc_weight(ns_weight* w) {
   }
   uint8_t* base = nullptr;
   if (!hip_ok(hipMalloc((void**)&base, total), "hipMalloc(weight)")) return false;
-  w->codes = reinterpret_cast<uint4*>(base);
+  w->codes = reinterpret_cast<uint4*>(base);  // owned by `w` from here on: ns_hip_weight_free releases it on any later failure
   w->scales = base + s_off;
   w->zps = w->asym ? reinterpret_cast<int8_t*>(base + z_off) : nullptr;
   w->s_off = total < (size_t(1) << 32) ? uint32_t(s_off) : 0;
@@ -355,20 +356,17 @@ ns_weight* cached_weight(const void* blob) {
     return nullptr;
   }
   const uint64_t fp = blob_fingerprint(blob);
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_cache.find(blob);
-    if (it != g_cache.end()) {
-      if (it->second.fingerprint == fp) return it->second.w;
-      ns_hip_weight_free(it->second.w);  // the address now holds a different blob
-      g_cache.erase(it);
-    }
+  // one lock over lookup + upload + insert: two threads presenting the same new blob must not both upload it
+  // (the loser's device copy would leak and its pointer dangle after the next cache_clear)
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_cache.find(blob);
+  if (it != g_cache.end()) {
+    if (it->second.fingerprint == fp) return it->second.w;
+    ns_hip_weight_free(it->second.w);  // the address now holds a different blob
+    g_cache.erase(it);
   }
   ns_weight* w = ns_hip_weight_from_blob(blob, nullptr);
-  if (w) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_cache[blob] = CacheEntry{w, fp};
-  }
+  if (w) g_cache[blob] = CacheEntry{w, fp};
   return w;
 }
 
@@ -469,10 +467,7 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
 }  // namespace
 
 namespace ns {
-void set_error(const std::string& s) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  g_err = s;
-}
+void set_error(const std::string& s) { g_err = s; }
 }  // namespace ns
 
 extern "C" {
@@ -497,11 +492,25 @@ int ns_hip_device_count(void) {
   return c;
 }
 
-const char* ns_hip_last_error(void) {
-  static thread_local std::string copy;
-  std::lock_guard<std::mutex> lk(g_mu);
-  copy = g_err;
-  return copy.c_str();
+const char* ns_hip_last_error(void) { return g_err.c_str(); }
+
+int ns_hip_blob_validate(const void* host_blob, size_t avail_bytes) {
+  // header-only, no device: the checks every loader entry applies (blob_parse -> check_view), plus the caller's bound
+  if (!host_blob) {
+    set_error("blob: null pointer");
+    return -1;
+  }
+  BlobView v;
+  std::string err;
+  if (!blob_parse(host_blob, &v, &err)) {
+    set_error(err);
+    return -1;
+  }
+  if (avail_bytes && v.size > avail_bytes) {
+    set_error("blob: serialized size " + std::to_string(v.size) + " exceeds the " + std::to_string(avail_bytes) + " bytes available");
+    return -1;
+  }
+  return 0;
 }
 
 ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream) {
@@ -550,6 +559,10 @@ ns_weight* ns_hip_weight_from_device_blob(const void* dev_blob, size_t blob_byte
   std::string err;
   if (!blob_parse_io(io, &v, &err) || !io_ok) {
     set_error(io_ok ? err : "device blob: header read failed");
+    return nullptr;
+  }
+  if (v.size > blob_bytes) {  // (the parser has checked every section against v.size)
+    set_error("device blob: the buffer is shorter than the blob's serialized size");
     return nullptr;
   }
   ns_weight* w = weight_from_device_sections(v, base + v.q_off, base + v.s_off,
@@ -1513,6 +1526,7 @@ void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float 
 static void host_binary(const char* who, int batch, int vsize, const float* tensor, const float* vector, int vstep,
                         float* out, bool mul) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
+  if (batch <= 0 || vsize <= 0) return;  // nothing to do (and batch - 1 below must not wrap)
   bool ok = have_device();
   if (ok) {
     const size_t n = size_t(batch) * vsize;

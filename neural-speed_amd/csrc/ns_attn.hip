@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -51,6 +52,7 @@ struct AttnParams {
   int hs_pad;  // power of two >= head_size (<= 256)
   float alibi_m0, alibi_m1;
   int alibi_log2_floor;
+  int alibi_head_off;  // tensor parallel: index of this rank's first head in the full model (0 otherwise)
 };
 
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
@@ -92,8 +94,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
   if (t < hs) q_s[t] = q[t] * p.qk_scale;
   float slope = 0.f;
   if (alibi)  // mha_dense_wrapper.h:1424-1447
-    slope = ihn < p.alibi_log2_floor ? powf(p.alibi_m0, float(ihn + 1))
-                                     : powf(p.alibi_m1, float(2 * (ihn - p.alibi_log2_floor) + 1));
+  {
+    const int gh = ihn + p.alibi_head_off;
+    slope = gh < p.alibi_log2_floor ? powf(p.alibi_m0, float(gh + 1)) : powf(p.alibi_m1, float(2 * (gh - p.alibi_log2_floor) + 1));
+  }
   __syncthreads();
 
   const int parts = kAttnThreads / p.hs_pad;  // key partitions of the P.V phase
@@ -201,9 +205,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
     m[g] = -INFINITY;
     lsum[g] = 0.f;
     slope[g] = 0.f;
-    if (alibi)
-      slope[g] = ihn < p.alibi_log2_floor ? powf(p.alibi_m0, float(ihn + 1))
-                                          : powf(p.alibi_m1, float(2 * (ihn - p.alibi_log2_floor) + 1));
+    if (alibi) {
+      const int gh = ihn + p.alibi_head_off;
+      slope[g] = gh < p.alibi_log2_floor ? powf(p.alibi_m0, float(gh + 1)) : powf(p.alibi_m1, float(2 * (gh - p.alibi_log2_floor) + 1));
+    }
   }
 
   typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -512,6 +517,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
   }
 }
 
+static std::atomic<int> g_alibi_heads{0}, g_alibi_off{0};  // ns_hip_attn_set_head_partition
+
 static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipStream_t st, std::string* why,
                               bool device_tmp) {
   if (a.Q_layout != ATTN_FWD_LAYOUT_PLAIN || a.K_layout != ATTN_FWD_LAYOUT_PLAIN || a.V_layout != ATTN_FWD_LAYOUT_PLAIN ||
@@ -538,7 +545,15 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   p.step_v_head_size = a.step_v_head_size;
   p.step_dst_bs = a.step_dst_bs, p.step_dst_head_num = a.step_dst_head_num, p.step_dst_sl = a.step_dst_sl;
   p.hs_pad = a.head_size <= 64 ? 64 : (a.head_size <= 128 ? 128 : 256);
-  const int lf = 1 << int(floor(log2(double(a.head_num))));  // mha_dense_wrapper.h:1424-1426
+  // mha_dense_wrapper.h:1418-1447: under tensor parallelism the slopes follow the FULL model's head count and this
+  // rank's first head (the reference takes world/rank from parallel_context; here ns_hip_attn_set_head_partition)
+  const int all_heads = g_alibi_heads.load() > 0 ? g_alibi_heads.load() : a.head_num;
+  p.alibi_head_off = g_alibi_heads.load() > 0 ? g_alibi_off.load() : 0;
+  if (p.alibi_head_off < 0 || p.alibi_head_off + a.head_num > all_heads) {
+    *why = "attention: head partition (ns_hip_attn_set_head_partition) does not contain this call's heads";
+    return hipErrorInvalidValue;
+  }
+  const int lf = 1 << int(floor(log2(double(all_heads))));
   p.alibi_log2_floor = lf;
   p.alibi_m0 = powf(2.0f, -8.f / float(lf));
   p.alibi_m1 = powf(2.0f, -4.f / float(lf));
@@ -614,6 +629,15 @@ static size_t span4(int n0, long long s0, int n1, long long s1, int n2, long lon
 using namespace ns;  // NOLINT
 
 extern "C" {
+
+int ns_hip_attn_set_head_partition(int global_head_num, int head_offset) {
+  if (global_head_num < 0 || head_offset < 0 || (global_head_num > 0 && head_offset >= global_head_num)) {
+    set_error("ns_hip_attn_set_head_partition: need 0 <= head_offset < global_head_num (or 0, 0 to clear)");
+    return -1;
+  }
+  g_alibi_heads.store(global_head_num), g_alibi_off.store(global_head_num > 0 ? head_offset : 0);
+  return 0;
+}
 
 size_t bestla_fusion_attn_workspace_size(const attn_shape_t* s) {
   // (m, l, acc) partials of the context splits; 64 bytes minimum so that callers always get a valid pointer

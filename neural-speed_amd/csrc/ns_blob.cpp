@@ -39,8 +39,17 @@ inline size_t round_up(size_t a, size_t b) { return ceil_div(a, b) * b; }
 class HeaderIO {
  public:
   HeaderIO(const BlobIo& io, uintptr_t base_addr, bool writing) : io_(io), pos_(0), addr_(base_addr), w_(writing) {}
+  // Reading: nothing is fetched at or beyond `limit` (the blob's own serialized size once its first word is known),
+  // so a corrupt section size cannot send the walk outside the buffer; ok() turns false instead.
+  void set_limit(uint64_t limit) { limit_ = limit; }
+  bool ok() const { return ok_; }
   template <typename T>
   void word(T& v) {
+    if (!w_ && (!ok_ || pos_ > limit_ || limit_ - pos_ < sizeof(T))) {
+      ok_ = false;
+      v = T();
+      return;
+    }
     if (io_) io_(pos_, &v, sizeof(T), w_);
     pos_ += sizeof(T);
   }
@@ -53,6 +62,11 @@ class HeaderIO {
       pad = round_up(after, 64) - after;
     }
     word(pad);
+    if (!w_ && (!ok_ || pad > limit_ - pos_ || bytes > limit_ - pos_ - pad)) {
+      ok_ = false;
+      bytes = 0, off = 0;
+      return;
+    }
     pos_ += pad;
     off = pos_;
     pos_ += bytes;
@@ -74,10 +88,13 @@ class HeaderIO {
   size_t pos_;
   uintptr_t addr_;
   bool w_;
+  uint64_t limit_ = ~uint64_t(0);
+  bool ok_ = true;
 };
 
 bool traverse(HeaderIO& io, BlobView& v, std::string* err) {
   io.word(v.size);
+  io.set_limit(v.size);
   io.word(v.prologue);
   io.word(v.core_id);
   io.word(v.npad);
@@ -107,6 +124,10 @@ bool traverse(HeaderIO& io, BlobView& v, std::string* err) {
     return false;
   }
   io.optional_section(v.shuf_bytes, v.shuf_off);
+  if (!io.ok()) {
+    if (err) *err = "blob: a header word or section lies beyond the serialized size";
+    return false;
+  }
   return true;
 }
 }  // namespace
@@ -134,12 +155,34 @@ int core_for_comp(int comp_type, uint32_t qtype, bool asym, size_t blocksize, in
   }
 }
 
+size_t code_bytes(size_t elts, uint32_t qtype);
+
+// A header that parsed is not yet a blob that can be trusted: the loaders launch kernels over the sections, so every
+// section must be at least as large as the geometry in the header implies (a truncated or corrupt model file would
+// otherwise make the repack read out of bounds in HBM — silent garbage weights or a GPU fault), and all of it must lie
+// inside the serialized size.
 static bool check_view(const BlobView* out, std::string* err) {
-  if (out->n <= 0 || out->k <= 0 || out->npad < out->n || out->kpad < out->k || out->blocksize <= 0 ||
-      out->ntile() <= 0 || out->packrow() <= 0 || out->npad % out->ntile() || out->kpad % out->packrow()) {
-    if (err) *err = "blob: inconsistent header";
+  auto bad = [&](const char* why) {
+    if (err) *err = std::string("blob: ") + why;
     return false;
-  }
+  };
+  if (out->n <= 0 || out->k <= 0 || out->npad < out->n || out->kpad < out->k || out->blocksize <= 0 ||
+      out->ntile() <= 0 || out->packrow() <= 0 || out->npad % out->ntile() || out->kpad % out->packrow())
+    return bad("inconsistent header");
+  const int sbits = dt_bits(out->scale_dt);
+  if (sbits != 8 && sbits != 16 && sbits != 32) return bad("unknown scale dtype");
+  if (out->cstep < out->n) return bad("correction step smaller than N");
+  const uint64_t rows = ceil_div(size_t(out->kpad), size_t(out->blocksize));
+  if (out->csize < rows * uint64_t(out->cstep)) return bad("correction size smaller than (k-blocks x step)");
+  if (out->q_bytes < code_bytes(size_t(out->npad) * out->kpad, out->dtype)) return bad("code section smaller than NPad x KPad codes");
+  if (out->s_bytes < out->csize * uint64_t(sbits / 8)) return bad("scale section smaller than the correction size");
+  if (out->z_bytes && out->z_bytes < out->csize) return bad("zero-point section smaller than the correction size");
+  if (out->r_bytes && out->r_bytes < out->csize * 2) return bad("reduce section smaller than the correction size");
+  if (out->shuf_bytes && out->shuf_bytes < uint64_t(out->k) * sizeof(int)) return bad("shuffle section smaller than K indices");
+  const uint64_t ends[5] = {out->q_off + out->q_bytes, out->s_off + out->s_bytes, out->z_bytes ? out->z_off + out->z_bytes : 0,
+                            out->r_bytes ? out->r_off + out->r_bytes : 0, out->shuf_bytes ? out->shuf_off + out->shuf_bytes : 0};
+  for (uint64_t e : ends)
+    if (e > out->size) return bad("a section ends beyond the serialized size");
   return true;
 }
 
@@ -160,7 +203,7 @@ bool blob_parse(const void* blob, BlobView* out, std::string* err) {
   return blob_parse_io(io, out, err);
 }
 
-static size_t code_bytes(size_t elts, uint32_t qtype) {  // bestla_storage.h:729-745
+size_t code_bytes(size_t elts, uint32_t qtype) {  // bestla_storage.h:729-745
   const int b = dt_bits(qtype);
   if (!dt_is_int(qtype) || b == 1 || b == 2 || b == 4 || b == 8) return ceil_div(elts * b, 8);
   size_t total = 0;

@@ -28,6 +28,10 @@
 #include "../../include/ns_bestla.h"
 #include "ns_common.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "ns_p2p.hip: the fence-free hand-off relies on gfx94x/gfx95x lowering system-scope accesses to sc0 sc1"
+#endif
+
 namespace ns {
 namespace {
 
@@ -49,6 +53,7 @@ struct P2PParams {
   float* buf;
   unsigned int n;
   unsigned long long timeout_ticks;  // 100 MHz wall clock
+  uint32_t* host_error;              // pinned host word (device-mapped): raised with the sticky error below
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -99,7 +104,10 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(const P2PParams p) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (s_fail && tid == 0) __hip_atomic_store(&self->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (s_fail && tid == 0) {
+    __hip_atomic_store(&self->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p.host_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   // 4. sum every rank's copy in rank order (own copy through the same path: identical arithmetic on every rank)
   {
     f32x4* out4 = reinterpret_cast<f32x4*>(p.buf);
@@ -139,6 +147,7 @@ struct ns_p2p {
   unsigned char* peers[ns::kP2PMaxWorld] = {};
   bool connected = false;
   unsigned long long timeout_ticks = 0;
+  uint32_t* host_error = nullptr;  // pinned + mapped: the kernel raises it, the launcher reads it without a sync
 };
 
 using namespace ns;
@@ -174,12 +183,17 @@ ns_p2p* ns_hip_p2p_create(int rank, int world, size_t max_bytes, void* handle_ou
   }
   c->peers[rank] = static_cast<unsigned char*>(base);
   hipIpcMemHandle_t h;
-  if (!p2p_ok(hipMemset(base, 0, c->total), "p2p: hipMemset") || !p2p_ok(hipDeviceSynchronize(), "p2p: synchronize") ||
+  void* herr = nullptr;
+  if (!p2p_ok(hipHostMalloc(&herr, 64, hipHostMallocMapped), "p2p: hipHostMalloc") ||
+      !p2p_ok(hipMemset(base, 0, c->total), "p2p: hipMemset") || !p2p_ok(hipDeviceSynchronize(), "p2p: synchronize") ||
       !p2p_ok(hipIpcGetMemHandle(&h, base), "p2p: hipIpcGetMemHandle")) {
+    if (herr) (void)hipHostFree(herr);
     (void)hipFree(base);
     delete c;
     return nullptr;
   }
+  c->host_error = static_cast<uint32_t*>(herr);
+  *c->host_error = 0;
   memcpy(handle_out, &h, sizeof(h));
   return c;
 }
@@ -215,7 +229,15 @@ int ns_hip_p2p_all_reduce_f32(ns_p2p* c, float* dBuf, size_t n, void* stream) {
     set_error("p2p all-reduce: buffer larger than the slot (use RCCL) or not 16-byte aligned");
     return -1;
   }
+  // A flag wait of an EARLIER call timed out (a peer died or never launched): the sums since then included stale
+  // peer slots.  Refuse from here on so the caller notices and falls back to RCCL; ns_hip_p2p_error() is the
+  // synchronous form of the same check.
+  if (__atomic_load_n(c->host_error, __ATOMIC_RELAXED)) {
+    set_error("p2p all-reduce: an earlier call timed out waiting for a peer; the context is dead");
+    return -2;
+  }
   P2PParams p;
+  p.host_error = c->host_error;
   for (int r = 0; r < kP2PMaxWorld; r++) p.peers[r] = r < c->world ? c->peers[r] : nullptr;
   p.rank = c->rank, p.world = c->world, p.slot_bytes = c->slot_bytes, p.buf = dBuf, p.n = (unsigned int)n;
   p.timeout_ticks = c->timeout_ticks;
@@ -241,6 +263,7 @@ void ns_hip_p2p_destroy(ns_p2p* c) {
   if (!c) return;
   ns_hip_p2p_disconnect(c);
   if (c->peers[c->rank]) (void)hipFree(c->peers[c->rank]);
+  if (c->host_error) (void)hipHostFree(c->host_error);
   delete c;
 }
 

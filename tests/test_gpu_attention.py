@@ -88,3 +88,37 @@ def test_attention_device_api_and_scales(L, pkg, nso):
     bad = pkg.attn_args(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dd.data_ptr(), bs, hn, hkv, hs, 9, 4, scale, 1)
     assert L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(bad), st) != 0
     assert b"causal" in L.ns_hip_last_error()
+
+
+def test_alibi_head_partition_matches_the_unsplit_model(L, pkg, nso):
+    """mha_dense_wrapper.h:1418-1447 (NS_TP_MODEL): a rank holding heads [off, off + local) must apply the FULL model's
+    slopes for those heads.  Two half-head calls with ns_hip_attn_set_head_partition equal the unsplit call."""
+    import torch
+    bs, hn, hs, sl_q, sl_kv = 1, 12, 64, 2, 200  # 12 heads: not a power of two, both slope branches are used
+    rng = np.random.default_rng(77)
+    q = rng.standard_normal((bs, sl_q, hn, hs)).astype(np.float32)
+    k = rng.standard_normal((bs, sl_kv, hn, hs)).astype(np.float16)
+    v = rng.standard_normal((bs, sl_kv, hn, hs)).astype(np.float16)
+    scale = float(1.0 / np.sqrt(hs))
+    ref = nso.attn_ref(q, k, v, scale, 3)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    half = hn // 2
+    try:
+        for r in range(2):
+            sl = slice(r * half, (r + 1) * half)
+            dq = torch.from_numpy(np.ascontiguousarray(q[:, :, sl])).cuda()
+            dk = torch.from_numpy(np.ascontiguousarray(k[:, :, sl])).cuda()
+            dv = torch.from_numpy(np.ascontiguousarray(v[:, :, sl])).cuda()
+            dd = torch.zeros_like(dq)
+            assert L.ns_hip_attn_set_head_partition(hn, r * half) == 0
+            a = pkg.attn_args(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dd.data_ptr(), bs, half, half, hs, sl_q, sl_kv,
+                              scale, 3)
+            pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), st))
+            torch.cuda.synchronize()
+            assert nso.rel_l2(dd.cpu().numpy(), ref[:, :, sl]) < TOL
+        # heads that do not fit the partition are refused
+        assert L.ns_hip_attn_set_head_partition(hn, hn - 1) == 0
+        assert L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), st) != 0
+        assert L.ns_hip_attn_set_head_partition(4, 4) != 0
+    finally:
+        assert L.ns_hip_attn_set_head_partition(0, 0) == 0
