@@ -31,7 +31,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
-CFG = dict(name="llama-2-7b", n_embd=4096, n_ff=11008, n_layer=32, n_vocab=32000, group=32)
+CFG = dict(name="llama-2-7b", n_embd=4096, n_ff=11008, n_layer=32, n_vocab=32000, group=32, n_head=32)
 
 
 def REDUCE(t):
@@ -488,6 +488,13 @@ def main():
             out["config"]["all_reduces_per_step"] = comm["per_step"]
             out["config"]["comm_fraction"] = round(comm["us"] * comm["per_step"] / (ms_per_step * 1e3), 4)
         if world == 1:
+            # the whole token (attention over a 2048-position fp16 kv-cache, norms, RoPE, residuals) on the same weights
+            ft, lg = full_token(chain, pkg, 2048, fused=True)
+            fu, lgu = full_token(chain, pkg, 2048, fused=False, iters=10)
+            rel = float((lg.double() - lgu.double()).norm() / lgu.double().norm())
+            out["config"]["full_token_tokens_per_s"] = ft["tokens_per_s"]
+            out["config"]["full_token"] = {"fused": ft, "one_launch_per_operator": fu,
+                                           "logits_rel_l2_fused_vs_unfused": round(rel, 6)}
             out["config"]["prefill_m2048_tflops"] = prefill_tflops(chain, pkg)
             out["config"]["prefill_m2048_tflops_int8w"] = prefill_tflops_int8w(chain, pkg)
         if world == 1 and not args.no_cpu_baseline:
@@ -500,7 +507,124 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-ROOFLINE_KERNEL = "gemv_kernel<INT4,SPS4,BF16,sym,DUAL>"  # demangled: ns::gemv_kernel<0, 4, 0, false, 1>
+def full_token(chain, pkg, ctx=2048, fused=True, iters=30):
+    """A WHOLE decode token of the same model on the same weights, device resident in one HIP graph (SURVEY 8f rows on
+    top of the GEMM chain): rms norm . gamma, fused QKV, RoPE(q, k), kv-cache append, fused attention over `ctx` cached
+    positions (fp16 cache), WO + residual, rms norm . gamma, fused gate/up, down + residual; final norm + lm_head.
+    fused=True: the norms are carried across the GEMMs (ns_norm_link) and RoPE + the cache append are the QKV launch's
+    epilogue (ns_qkv_rope) -> 5 launches per layer + the attention split merge; fused=False: one launch per operator."""
+    L = pkg.lib()
+    d, ff, V = chain.d, chain.ff, chain.V
+    heads, hs = CFG["n_head"], CFG["n_embd"] // CFG["n_head"]
+    nl = len(chain.layers)
+    dev, h16 = "cuda", torch.float16
+    ctx_max = ctx + 8
+    n_past = ctx - 1
+    g = torch.Generator(device=dev).manual_seed(11)
+    kc = [torch.randn((1, ctx_max, heads, hs), generator=g, device=dev).to(h16) for _ in range(nl)]
+    vc = [torch.randn((1, ctx_max, heads, hs), generator=g, device=dev).to(h16) for _ in range(nl)]
+    gam = [(torch.ones(d, device=dev), torch.ones(d, device=dev)) for _ in range(nl)]
+    gf = torch.ones(d, device=dev)
+    shape = pkg.AttnShape(1, heads, heads, hs, 1, ctx_max)
+    attn_ws = torch.empty(L.bestla_fusion_attn_workspace_size(C.byref(shape)), dtype=torch.uint8, device=dev)
+    f32 = lambda *sh: torch.empty(*sh, device=dev)
+    f16 = lambda *sh: torch.empty(*sh, device=dev, dtype=h16)
+    parts = d // 16
+    b = dict(h=f32(1, d), qkv=f32(3, 1, d), att=f32(1, d), r1=f32(1, d), h2=f32(1, d), t2=f32(1, ff), x=f32(1, d),
+             logits=f32(1, V), ssq_a=torch.zeros(1, parts, device=dev), ssq_b=torch.zeros(1, parts, device=dev))
+    sh = dict(h=f16(1, d), att=f16(1, d), r1=f16(1, d), t2=f16(1, ff), x=f16(1, d), x0=f16(1, d))
+    x0 = chain.x0
+    rope_tab = torch.zeros(1, hs // 2, 2, device=dev)
+    launches = [0]
+
+    def step():
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ck = pkg.check
+        n = 0
+        if fused:
+            ck(L.ns_hip_norm_prep(1, d, x0.data_ptr(), d, gam[0][0].data_ptr(), sh["x0"].data_ptr(), b["ssq_a"].data_ptr(), parts, st))
+            ck(L.ns_hip_rope_cos_sin(1, n_past, hs, 10000.0, 1.0, 1.0, rope_tab.data_ptr(), st))  # once per token, all layers
+            n += 2
+        xin, xin16 = x0, sh["x0"]
+        for il, lw in enumerate(chain.layers):
+            if fused:
+                lk = pkg.NormLink(b["ssq_a"].data_ptr(), parts, parts, 1e-5, d, None, None, 0)
+                rp = pkg.QkvRope(kc[il].data_ptr(), vc[il].data_ptr(), rope_tab.data_ptr(), heads, heads, hs, n_past, hs, 0,
+                                 heads * hs, hs)
+                ck(L.ns_hip_fusion_qkv_rope_forward_x(xin.data_ptr(), xin16.data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
+                                                      b["qkv"].data_ptr(), 1, d, d, C.byref(lk), C.byref(rp), st))
+                n += 1
+            else:
+                ck(L.ns_hip_norm_mul_h(1, d, True, 1e-5, xin.data_ptr(), gam[il][0].data_ptr(), b["h"].data_ptr(), sh["h"].data_ptr(), st))
+                ck(L.ns_hip_fusion_qkv_forward_h(b["h"].data_ptr(), sh["h"].data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
+                                                 b["qkv"].data_ptr(), None, 1, d, d, st))
+                ck(L.ns_hip_rope_qkv_append(b["qkv"][0].data_ptr(), b["qkv"][1].data_ptr(), b["qkv"][2].data_ptr(),
+                                            kc[il].data_ptr(), vc[il].data_ptr(), 1, heads, heads, hs, n_past, hs, 0, 10000.0,
+                                            1.0, 0.0, 1.0, heads * hs, hs, st))
+                n += 3
+            a = pkg.attn_args(b["qkv"][0].data_ptr(), kc[il].data_ptr(), vc[il].data_ptr(), b["att"].data_ptr(), 1, heads,
+                              heads, hs, 1, n_past + 1, hs ** -0.5, pkg.ATTN_CAUSAL)
+            a.step_k_bs = a.step_v_bs = ctx_max * heads * hs
+            a.tmp = attn_ws.data_ptr()
+            # the attention kernel also writes the fp16 shadow of its output (the WO projection's A operand)
+            ck(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(C.byref(a), sh["att"].data_ptr() if fused else None, st))
+            n += 2  # context splits + merge
+            xin_next_gamma = gam[il + 1][0] if il + 1 < nl else gf
+            if fused:
+                lk = pkg.NormLink(None, 0, 0, 0.0, 0, gam[il][1].data_ptr(), b["ssq_b"].data_ptr(), parts)
+                ck(L.ns_hip_f32f32_forward_x(b["att"].data_ptr(), sh["att"].data_ptr(), lw["o"].h, b["r1"].data_ptr(),
+                                             sh["r1"].data_ptr(), 1, d, d, pkg.EPI_ADD, xin.data_ptr(), d, C.byref(lk), st))
+                lk = pkg.NormLink(b["ssq_b"].data_ptr(), parts, parts, 1e-5, d, None, None, 0)
+                ck(L.ns_hip_fusion_ffn3_gateup_x(b["r1"].data_ptr(), sh["r1"].data_ptr(), lw["w1"].h, lw["w3"].h, None,
+                                                 b["t2"].data_ptr(), sh["t2"].data_ptr(), 1, pkg.EPI_SILU, C.byref(lk), st))
+                lk = pkg.NormLink(None, 0, 0, 0.0, 0, xin_next_gamma.data_ptr(), b["ssq_a"].data_ptr(), parts)
+                ck(L.ns_hip_f32f32_forward_x(b["t2"].data_ptr(), sh["t2"].data_ptr(), lw["w2"].h, b["x"].data_ptr(),
+                                             sh["x"].data_ptr(), 1, ff, d, pkg.EPI_ADD, b["r1"].data_ptr(), d, C.byref(lk), st))
+                n += 3
+            else:
+                ck(L.ns_hip_f32f32_forward(b["att"].data_ptr(), lw["o"].h, b["r1"].data_ptr(), 1, d, d, pkg.EPI_ADD, xin.data_ptr(), d, st))
+                ck(L.ns_hip_norm_mul_h(1, d, True, 1e-5, b["r1"].data_ptr(), gam[il][1].data_ptr(), b["h2"].data_ptr(), sh["h"].data_ptr(), st))
+                ck(L.ns_hip_fusion_ffn3_gateup_h(b["h2"].data_ptr(), sh["h"].data_ptr(), lw["w1"].h, lw["w3"].h, None,
+                                                 b["t2"].data_ptr(), sh["t2"].data_ptr(), 1, pkg.EPI_SILU, st))
+                ck(L.ns_hip_f32f32_forward_h(b["t2"].data_ptr(), sh["t2"].data_ptr(), lw["w2"].h, b["x"].data_ptr(), None, 1, ff, d,
+                                             pkg.EPI_ADD, b["r1"].data_ptr(), d, st))
+                n += 4
+            xin, xin16 = b["x"], sh["x"]
+        if fused:
+            lk = pkg.NormLink(b["ssq_a"].data_ptr(), parts, parts, 1e-5, d, None, None, 0)
+            ck(L.ns_hip_f32f32_forward_x(xin.data_ptr(), xin16.data_ptr(), chain.head.h, b["logits"].data_ptr(), None, 1, d, V,
+                                         pkg.EPI_NONE, None, 0, C.byref(lk), st))
+            n += 1
+        else:
+            ck(L.ns_hip_norm_mul_h(1, d, True, 1e-5, xin.data_ptr(), gf.data_ptr(), b["h"].data_ptr(), sh["h"].data_ptr(), st))
+            ck(L.ns_hip_f32f32_forward_h(b["h"].data_ptr(), sh["h"].data_ptr(), chain.head.h, b["logits"].data_ptr(), None, 1, d, V,
+                                         pkg.EPI_NONE, None, 0, st))
+            n += 2
+        launches[0] = n
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step()
+    for _ in range(3):
+        gr.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        gr.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    logits = b["logits"].clone()
+    return {"ctx": ctx, "ms_per_token": round(ms, 4), "tokens_per_s": round(1000.0 / ms, 1),
+            "launches_per_token": launches[0], "launches_per_layer": round((launches[0] - (3 if fused else 2)) / nl, 2),
+            "finite": bool(torch.isfinite(logits).all().item())}, logits
+
+
+ROOFLINE_KERNEL = "gemv_kernel<INT4,SPS4,BF16,sym,DUAL>"  # demangled: ns::gemv_kernel<0, 4, 0, false, 1, false>
 
 
 def all_reduce_latency(chain, world, try_graph):

@@ -231,6 +231,61 @@ int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_wei
                                  const ns_weight* w3, float* dTmp1, float* dTmp2, void* dTmp2_16, float* dOut,
                                  void* dOut16, int seq, int act, void* stream);
 
+/* "_x" variants: the RMS norm that precedes a GEMM in every model graph (ne_rms_norm -> ne_mul(gamma) -> ne_mul_mat,
+ * e.g. models/llama/llama.cpp:178-184, :385-391) CARRIED across operators instead of run as launches of its own.
+ * y = W (gamma . x / rms(x)) = (W (gamma . x)) / rms(x): the operator that PRODUCES x (attention-output or FFN-down
+ * projection with the residual add as its epilogue) also writes the fp16 shadow of gamma . x and, per 16-column output
+ * tile, the sum of x^2; the operator that CONSUMES it streams that shadow and divides its finished dot products by
+ * rms(x) = sqrt(sum / norm_size + eps) (ne_compute_forward_rms_norm_f32: scale = 1 / sqrtf(mean + eps)).  Sums are
+ * added in a fixed order (run-to-run identical results).  Decode sizes only: m <= 16, fp16 shadow required; anything
+ * else returns -1 (never a silently un-normalised result).
+ *   consumer side (in_ssq != NULL): dA16 holds gamma . x, not normalised; in_ssq[row * in_stride + t], t < in_parts
+ *                  (16-byte aligned, in_stride a multiple of 4); eps, norm_size of the norm
+ *   producer side (out_gamma and/or out_ssq != NULL; single-matrix forward only): dC16 <- fp16(v * out_gamma[col]),
+ *                  out_ssq[row * out_stride + tile] <- sum over the tile's columns of v^2 (tiles = ceil(N / 16))
+ * ns_hip_norm_prep does the producer side for a tensor that no GEMM produced (the embedding row of layer 0). */
+typedef struct ns_norm_link {
+  const float* in_ssq;
+  int in_parts, in_stride;
+  float eps;
+  int norm_size;
+  const float* out_gamma;
+  float* out_ssq;
+  int out_stride;
+} ns_norm_link;
+int ns_hip_f32f32_forward_x(const float* dA, const void* dA16, const ns_weight* w, float* dC, void* dC16, int m, int lda,
+                            int ldc, int epilogue, const float* dD, int ldd, const ns_norm_link* link, void* stream);
+int ns_hip_fusion_qkv_forward_x(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk,
+                                const ns_weight* wv, float* dC, void* dC16, int m, int lda, int ldc,
+                                const ns_norm_link* link, void* stream);
+int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weight* w1, const ns_weight* w3,
+                                float* dTmp1, float* dTmp2, void* dTmp2_16, int seq, int act, const ns_norm_link* link,
+                                void* stream);
+/* The fused QKV launch with ne_rope(q), ne_rope(k) and the kv-cache append (models/llama/llama.cpp:232-262; the three
+ * operators of ns_hip_rope_qkv_append) as its EPILOGUE: q is written rotated to dC[0], k rotated and v to dC[1], dC[2]
+ * and, as fp16, to cache position n_past + row.  RoPE mode 0 (adjacent pairs) over the whole head (n_dims ==
+ * head_size), no YaRN; wq->n == heads * head_size, wk->n == wv->n == heads_kv * head_size; m <= 16 rows = consecutive
+ * positions n_past, n_past + 1, ...; fp16 shadow of A required.  The angles do not depend on the layer: cos_sin is the
+ * table ns_hip_rope_cos_sin fills ONCE per token ([m][head_size / 2] pairs (cos, sin) * attn_factor, theta built by the
+ * reference's sequential fp32 products), shared by every layer's launch.  Same arithmetic as ns_hip_rope_qkv_append
+ * (bitwise). */
+typedef struct ns_qkv_rope {
+  void* kcache16;
+  void* vcache16;
+  const float* cos_sin;
+  int heads, heads_kv, head_size, n_past, n_dims, mode;
+  long long cache_step_sl, cache_step_head; /* cache element strides per position / per head */
+} ns_qkv_rope;
+int ns_hip_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, float freq_scale, float attn_factor,
+                        float* dCosSin, void* stream);
+int ns_hip_fusion_qkv_rope_forward_x(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk,
+                                     const ns_weight* wv, float* dC, int m, int lda, int ldc, const ns_norm_link* link,
+                                     const ns_qkv_rope* rope, void* stream);
+/* dX [m][ldx] fp32 -> dX16 [m][ldx] = fp16(x * dGamma[col]) and dSsq[row * ssq_stride + t] = sum of x^2 over columns
+ * 16 t .. 16 t + 15 (ssq_stride >= ceil(n / 16)) */
+int ns_hip_norm_prep(int m, int n, const float* dX, int ldx, const float* dGamma, void* dX16, float* dSsq, int ssq_stride,
+                     void* stream);
+
 /* device-pointer twins of bestla_layernormalization / bestla_mul / bestla_add (ne_bestla.h:79-83; device precedent
  * bestla_device_rms_norm_f32 / _mul_f32 / _add_f32, ne_bestla.h:99-105): asynchronous on `stream`, capturable */
 int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, float* dOut,
@@ -356,6 +411,9 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
 bool bestla_reordered_attn_fp32_support(const attn_shape_t* params);
 /* same operator on DEVICE pointers, asynchronous on `stream`; returns 0 on success */
 int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* dparams, void* stream);
+/* same, also writing the fp16 shadow of dst (dst16: same element strides as dst; may be NULL) that the "_h" / "_x" GEMM
+ * entries take as dA16 — the attention-output projection then needs no conversion pass */
+int ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(const attn_fp32_fp16_fp16_fp32_fwd_args_t* dparams, void* dst16, void* stream);
 /* Tensor-parallel head split for NS_ATTN_FLAG_IS_ALIBI8 (mha_dense_wrapper.h:1418-1447 under NS_TP_MODEL: the slopes
  * follow head_num * world and start at rank * head_num).  Process-wide (one process per GPU); (0, 0) clears it.
  * A forward call whose heads do not fit the partition is refused. */

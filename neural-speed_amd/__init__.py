@@ -36,6 +36,20 @@ CORE_AUTO = -1
 ATTN_CAUSAL, ATTN_ALIBI8, ATTN_PREFER_FP32, ATTN_TANH30 = 1, 2, 4, 8
 
 
+class NormLink(C.Structure):
+    """ns_norm_link (include/ns_bestla.h): an RMS norm carried from the operator that produces a tensor to the GEMM that
+    consumes it"""
+    _fields_ = [("in_ssq", C.c_void_p), ("in_parts", C.c_int), ("in_stride", C.c_int), ("eps", C.c_float),
+                ("norm_size", C.c_int), ("out_gamma", C.c_void_p), ("out_ssq", C.c_void_p), ("out_stride", C.c_int)]
+
+
+class QkvRope(C.Structure):
+    """ns_qkv_rope (include/ns_bestla.h)"""
+    _fields_ = ([("kcache16", C.c_void_p), ("vcache16", C.c_void_p), ("cos_sin", C.c_void_p)] +
+                [(n, C.c_int) for n in ("heads", "heads_kv", "head_size", "n_past", "n_dims", "mode")] +
+                [("cache_step_sl", C.c_longlong), ("cache_step_head", C.c_longlong)])
+
+
 class AttnShape(C.Structure):
     """attn_shape_t (mha_dense.h:24-26)"""
     _fields_ = [(n, C.c_int) for n in ("batch_size", "head_num", "heads_kv", "head_size", "sl_q", "sl_kv")]
@@ -149,6 +163,12 @@ def lib():
         L.ns_hip_f32f32_forward_h.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, i, vp]
         L.ns_hip_fusion_qkv_forward_h.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp]
         L.ns_hip_fusion_ffn3_gateup_h.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+        L.ns_hip_f32f32_forward_x.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, i, vp, vp]
+        L.ns_hip_fusion_qkv_forward_x.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp]
+        L.ns_hip_fusion_ffn3_gateup_x.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, vp, vp]
+        L.ns_hip_norm_prep.argtypes = [i, i, vp, i, vp, vp, vp, i, vp]
+        L.ns_hip_rope_cos_sin.argtypes = [i, i, i, f, f, f, vp, vp]
+        L.ns_hip_fusion_qkv_rope_forward_x.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp]
         L.ns_hip_fusion_ffn3_forward_h.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
         L.ns_hip_fusion_ffn3_gateup.argtypes = [vp, vp, vp, vp, vp, i, i, vp]
         L.ns_hip_fusion_ffn2_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, b, vp]
@@ -174,6 +194,7 @@ def lib():
         L.bestla_fusion_attn_fp32_fp16_fp16_fp32_forward.argtypes = [vp]
         L.ns_hip_attn_fp32_fp16_fp16_fp32_forward.argtypes = [vp, vp]
         L.ns_hip_attn_set_head_partition.argtypes = [i, i]
+        L.ns_hip_attn_fp32_fp16_fp16_fp32_forward_h.argtypes = [vp, vp, vp]
         L.ns_hip_blob_validate.argtypes = [vp, sz]
         L.ns_BTLAGemmPackBSize.restype = sz
         L.ns_BTLAGemmPackBSize.argtypes = [sz, sz, sz, u32, u32, b, i, vp]

@@ -407,13 +407,28 @@ bool ref_int8_for(const ns_weight* w) { return g_compute_mode.load() == NS_COMPU
 
 // rows up to which the weight-streaming kernel is used; above, the tiled MFMA GEMM (measured crossover)
 constexpr int kSmallMMax = 64;
+// a carried RMS norm (ns_norm_link) is honoured by gemv_kernel only: refuse everything that would leave its envelope
+bool link_ok(const ns_norm_link* link, const ns_weight* w, int m, const void* dA16) {
+  if (m > 16 || !dA16 || w->shuf || ref_int8_for(w)) {
+    set_error("norm link: needs m <= 16, the fp16 shadow of A, no activation shuffle and the fp16 compute mode");
+    return false;
+  }
+  if (link->in_ssq && (link->in_parts < 1 || link->norm_size < 1 || link->in_stride < link->in_parts || (link->in_stride & 3) ||
+                       (reinterpret_cast<uintptr_t>(link->in_ssq) & 15))) {
+    set_error("norm link: in_ssq must be 16-byte aligned with in_stride >= in_parts, a multiple of 4");
+    return false;
+  }
+  return true;
+}
+
 int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
                  const float* dD, int ldd, hipStream_t st, const void* dA16 = nullptr, void* dC16 = nullptr,
-                 bool reuse_aq = false) {
+                 bool reuse_aq = false, const ns_norm_link* link = nullptr) {
   if (!w || !dA || !dC || m <= 0) {
     set_error("forward: null argument");
     return -1;
   }
+  if (link && !link_ok(link, w, m, dA16)) return -1;
   if (!smallm_supported(w, m)) {
     set_error("forward: weight format not supported");
     return -1;
@@ -446,6 +461,7 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   a.ldd = ldd;
   a.dual = false;
   a.c2 = nullptr;
+  a.link = link;
   static const int small_max = getenv("NS_SMALLM_MAX") ? atoi(getenv("NS_SMALLM_MAX")) : kSmallMMax;  // diagnostics
   // Up to 16 rows the streaming kernel always wins.  From 17 to 64 rows every 16-column workgroup of it stages all rows
   // of A over the whole K from L2, ntiles x m x K x sizeof(A element) bytes in total at about 6 TB/s: measured against
@@ -717,12 +733,79 @@ int ns_hip_fusion_qkv_forward(const float* dA, const ns_weight* wq, const ns_wei
 
 int ns_hip_f32f32_forward_h(const float* dA, const void* dA16, const ns_weight* w, float* dC, void* dC16, int m, int lda,
                             int ldc, int epilogue, const float* dD, int ldd, void* stream) {
+  return ns_hip_f32f32_forward_x(dA, dA16, w, dC, dC16, m, lda, ldc, epilogue, dD, ldd, nullptr, stream);
+}
+
+int ns_hip_f32f32_forward_x(const float* dA, const void* dA16, const ns_weight* w, float* dC, void* dC16, int m, int lda,
+                            int ldc, int epilogue, const float* dD, int ldd, const ns_norm_link* link, void* stream) {
   if (!have_device()) return -1;
-  return forward_impl(dA, w, dC, m, lda, ldc, epilogue, dD, ldd, (hipStream_t)stream, dA16, dC16);
+  return forward_impl(dA, w, dC, m, lda, ldc, epilogue, dD, ldd, (hipStream_t)stream, dA16, dC16, false, link);
+}
+
+int ns_hip_norm_prep(int m, int n, const float* dX, int ldx, const float* dGamma, void* dX16, float* dSsq, int ssq_stride,
+                     void* stream) {
+  if (!have_device()) return -1;
+  if (!dX || m < 0 || n < 0 || ldx < n || (dSsq && ssq_stride < (n + 15) / 16)) {
+    set_error("norm_prep: invalid argument");
+    return -1;
+  }
+  return hip_ok(launch_norm_prep(m, n, dX, ldx, dGamma, dX16, dSsq, ssq_stride, (hipStream_t)stream), "norm_prep launch") ? 0 : -1;
 }
 
 int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk,
                                 const ns_weight* wv, float* dC, void* dC16, int m, int lda, int ldc, void* stream) {
+  return ns_hip_fusion_qkv_forward_x(dA, dA16, wq, wk, wv, dC, dC16, m, lda, ldc, nullptr, stream);
+}
+
+int ns_hip_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, float freq_scale, float attn_factor,
+                        float* dCosSin, void* stream) {
+  if (!have_device()) return -1;
+  if (m < 0 || n_past < 0 || n_dims < 2 || (n_dims & 1) || !dCosSin) {
+    set_error("rope_cos_sin: invalid argument");
+    return -1;
+  }
+  return hip_ok(launch_rope_cos_sin(m, n_past, n_dims, freq_base, freq_scale, attn_factor, dCosSin, (hipStream_t)stream),
+                "rope table launch") ? 0 : -1;
+}
+
+int ns_hip_fusion_qkv_rope_forward_x(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk,
+                                     const ns_weight* wv, float* dC, int m, int lda, int ldc, const ns_norm_link* link,
+                                     const ns_qkv_rope* rope, void* stream) {
+  if (!have_device()) return -1;
+  if (!wq || !wk || !wv || !dA || !dC || !rope || m < 1) {
+    set_error("qkv+rope: null argument");
+    return -1;
+  }
+  if (link && (link->out_gamma || link->out_ssq)) {
+    set_error("qkv+rope: the producer side of a norm link needs a single-matrix forward");
+    return -1;
+  }
+  const ns_weight* ws[3] = {wq, wk, wv};
+  bool same = !ref_int8_for(wq) && m <= 16 && dA16;
+  for (int i = 0; i < 3; i++)
+    same &= ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize &&
+            ws[i]->scale_dt == wq->scale_dt && ws[i]->asym == wq->asym && ws[i]->qtype == wq->qtype && !ws[i]->shuf;
+  if (!same || !smallm_supported(wq, m)) {
+    set_error("qkv+rope: needs three weights of one format, m <= 16, the fp16 shadow of A and the fp16 compute mode");
+    return -1;
+  }
+  SmallMArgs a{};
+  a.a = dA;
+  a.a16 = dA16;
+  a.lda = lda;
+  a.m = m;
+  a.ldc = ldc;
+  a.nseg = 3;
+  for (int i = 0; i < 3; i++) a.seg[i] = {ws[i], dC + size_t(i) * m * ldc, nullptr};
+  a.epilogue = NS_EPI_NONE;
+  a.link = link;
+  a.rope = rope;
+  return hip_ok(launch_smallm(a, (hipStream_t)stream), "qkv+rope launch") ? 0 : -1;
+}
+
+int ns_hip_fusion_qkv_forward_x(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk,
+                                const ns_weight* wv, float* dC, void* dC16, int m, int lda, int ldc,
+                                const ns_norm_link* link, void* stream) {
   if (!have_device()) return -1;
   if (!wq || !wk || !wv) {
     set_error("qkv: null weight");
@@ -736,6 +819,11 @@ int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weig
   same &= !wq->shuf && !wk->shuf && !wv->shuf;  // each shuffled weight gathers its own A' (unfused path)
   same &= !ref_int8_for(wq);                    // int8-reference mode: three plain forwards share nothing but A
   hipStream_t st = (hipStream_t)stream;
+  if (link && (link->out_gamma || link->out_ssq)) {
+    set_error("qkv: the producer side of a norm link needs a single-matrix forward");
+    return -1;
+  }
+  if (link && !link_ok(link, wq, m, dA16)) return -1;
   if (!same || m > 64) {  // fall back to three launches (still on the GPU)
     // int8-reference mode: the three weights share one activation quantization when K and the group size agree
     auto same_aq = [&](int i) {
@@ -744,7 +832,7 @@ int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weig
     };
     for (int i = 0; i < 3; i++)
       if (forward_impl(dA, ws[i], dC + size_t(i) * m * ldc, m, lda, ldc, NS_EPI_NONE, nullptr, 0, st, dA16,
-                       dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr, same_aq(i)))
+                       dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr, same_aq(i), link))
         return -1;
     return 0;
   }
@@ -758,6 +846,7 @@ int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weig
   for (int i = 0; i < 3; i++)  // ip_fusion_qkv.cpp:84-86
     a.seg[i] = {ws[i], dC + size_t(i) * m * ldc, dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr};
   a.epilogue = NS_EPI_NONE;
+  a.link = link;
   return hip_ok(launch_smallm(a, st), "qkv launch") ? 0 : -1;
 }
 
@@ -768,6 +857,12 @@ int ns_hip_fusion_ffn3_gateup(const float* dA, const ns_weight* w1, const ns_wei
 
 int ns_hip_fusion_ffn3_gateup_h(const float* dA, const void* dA16, const ns_weight* w1, const ns_weight* w3,
                                 float* dTmp1, float* dTmp2, void* dTmp2_16, int seq, int act, void* stream) {
+  return ns_hip_fusion_ffn3_gateup_x(dA, dA16, w1, w3, dTmp1, dTmp2, dTmp2_16, seq, act, nullptr, stream);
+}
+
+int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weight* w1, const ns_weight* w3,
+                                float* dTmp1, float* dTmp2, void* dTmp2_16, int seq, int act, const ns_norm_link* link,
+                                void* stream) {
   if (!have_device()) return -1;
   if (!w1 || !w3 || !dTmp2 || !dA) {
     set_error("ffn3 gate/up: null argument");
@@ -792,7 +887,16 @@ int ns_hip_fusion_ffn3_gateup_h(const float* dA, const void* dA16, const ns_weig
     a.epilogue = act;
     a.dual = true;
     a.c2 = dTmp1;
+    a.link = link;
+    if (link && ((link->out_gamma || link->out_ssq) || !link_ok(link, w1, seq, dA16))) {
+      if (link->out_gamma || link->out_ssq) set_error("ffn gate/up: the producer side of a norm link needs a single-matrix forward");
+      return -1;
+    }
     return hip_ok(launch_smallm(a, st), "ffn gate/up launch") ? 0 : -1;
+  }
+  if (link) {
+    set_error("ffn gate/up: a norm link needs the fused launch (matching formats, seq <= 16)");
+    return -1;
   }
   if (!dTmp1 && ref8) dTmp1 = static_cast<float*>(stream_scratch(st, size_t(seq) * fmid * 4, 5));
   if (!dTmp1) {

@@ -41,6 +41,7 @@ struct AttnParams {
   const _Float16* k;
   const _Float16* v;
   float* dst;
+  _Float16* dst16;  // optional fp16 shadow of dst (same element strides): the next GEMM's A operand
   float qk_scale;   // QK_scale * Q_sc * K_sc
   float out_scale;  // V_sc / dst_sc
   uint32_t flags;
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
   if (t < hs) {
     float o = 0.f;
     for (int pp = 0; pp < parts; pp++) o += part_s[pp * p.hs_pad + t];
-    dst[t] = o / l_run * p.out_scale;
+    const float y = o / l_run * p.out_scale;
+    dst[t] = y;
+    if (p.dst16) p.dst16[dst - p.dst + t] = (_Float16)y;
   }
 }
 
@@ -291,7 +294,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
     const int ihn = ihkv * G + g;
     if (sp.nsplit == 1) {
       float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
-      dst[dd] = ab / lb * p.out_scale;
+      const float y = ab / lb * p.out_scale;
+      dst[dd] = y;
+      if (p.dst16) p.dst16[dst - p.dst + dd] = (_Float16)y;
     } else {
       float* wp = sp.ws + ((((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit + split) * (2 + hs);
       if (dd == 0) {
@@ -333,7 +338,9 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
     float ab = 0.f;
 #pragma unroll 8
     for (int s = 0; s < ns; s++) ab += wp[s * (2 + hs) + 2 + d] * c_s[s];
-    dst[d] = ab / lb * p.out_scale;
+    const float y = ab / lb * p.out_scale;
+    dst[d] = y;
+    if (p.dst16) p.dst16[dst - p.dst + d] = (_Float16)y;
   }
 }
 
@@ -513,14 +520,18 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     if (row >= p.sl_q) continue;
     float* dr = db + (long long)row * p.step_dst_sl + nn;
 #pragma unroll
-    for (int dt = 0; dt < NDT; dt++) dr[16 * dt] = o[dt][r] * ir[r];
+    for (int dt = 0; dt < NDT; dt++) {
+      const float y = o[dt][r] * ir[r];
+      dr[16 * dt] = y;
+      if (p.dst16) p.dst16[dr - p.dst + 16 * dt] = (_Float16)y;
+    }
   }
 }
 
 static std::atomic<int> g_alibi_heads{0}, g_alibi_off{0};  // ns_hip_attn_set_head_partition
 
 static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipStream_t st, std::string* why,
-                              bool device_tmp) {
+                              bool device_tmp, void* dst16 = nullptr) {
   if (a.Q_layout != ATTN_FWD_LAYOUT_PLAIN || a.K_layout != ATTN_FWD_LAYOUT_PLAIN || a.V_layout != ATTN_FWD_LAYOUT_PLAIN ||
       a.dst_layout != ATTN_FWD_LAYOUT_PLAIN) {
     *why = "attention: only ATTN_FWD_LAYOUT_PLAIN tensors are supported";
@@ -534,6 +545,7 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   p.k = reinterpret_cast<const _Float16*>(a.K);
   p.v = reinterpret_cast<const _Float16*>(a.V);
   p.dst = a.dst;
+  p.dst16 = static_cast<_Float16*>(dst16);
   p.qk_scale = a.QK_scale * a.Q_sc * a.K_sc;
   p.out_scale = a.V_sc / a.dst_sc;
   p.flags = a.attn_flags;
@@ -657,9 +669,13 @@ bool bestla_reordered_attn_fp32_support(const attn_shape_t* params) {
 }
 
 int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* a, void* stream) {
+  return ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(a, nullptr, stream);
+}
+
+int ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(const attn_fp32_fp16_fp16_fp32_fwd_args_t* a, void* dst16, void* stream) {
   std::string why;
   // device API: `tmp`, when given, is DEVICE memory of bestla_fusion_attn_workspace_size(shape) bytes
-  const hipError_t e = launch_attn(*a, static_cast<hipStream_t>(stream), &why, a->tmp != nullptr);
+  const hipError_t e = launch_attn(*a, static_cast<hipStream_t>(stream), &why, a->tmp != nullptr, dst16);
   if (e != hipSuccess) {
     set_error(why.empty() ? std::string("attention launch: ") + hipGetErrorString(e) : why);
     return -1;

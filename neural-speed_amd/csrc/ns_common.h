@@ -7,6 +7,9 @@
 #include <functional>
 #include <string>
 
+struct ns_norm_link;  // include/ns_bestla.h
+struct ns_qkv_rope;
+
 namespace ns {
 
 // ---- BTLA_DTYPE bit encoding (reference: bestla/bestla/bestla.h:38-87) --------------------------------------
@@ -142,6 +145,8 @@ struct SmallMArgs {
   int ldd;
   bool dual;       // gate/up fusion: seg[0] = W1, seg[1] = W3, out = act(A*W1) * (A*W3) -> seg[0].c ; tmp1 -> c2
   float* c2;       // optional tmp1 output in dual mode
+  const ns_norm_link* link = nullptr;  // carried RMS norm (include/ns_bestla.h); gemv_kernel only
+  const ns_qkv_rope* rope = nullptr;   // RoPE(q, k) + kv-cache append as the QKV epilogue; gemv_kernel only
 };
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
 // ns_gemm.hip: second-generation prefill GEMM; hipErrorNotSupported = use the first-generation gemm_kernel
@@ -200,12 +205,16 @@ hipError_t launch_pack_q(const PackQArgs& a, hipStream_t st);
 
 hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* out,
                           hipStream_t st, const float* gamma = nullptr, void* out16 = nullptr);
+hipError_t launch_norm_prep(int m, int n, const float* x, int ldx, const float* gamma, void* x16, float* ssq,
+                            int ssq_stride, hipStream_t st);
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st,
                        float ext_factor = 0.f, float corr0 = 0.f, float corr1 = 0.f, const float* lr_factor = nullptr,
                        float lr_scale = 1.f);
 hipError_t launch_rope_glm(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                            bool skip, float freq_base, int prompt_size, const int* n_padding, hipStream_t st);
+hipError_t launch_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, float freq_scale, float attn_factor,
+                               float* out, hipStream_t st);
 hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void* kc, void* vc, int seq, int heads,
                                   int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base,
                                   float freq_scale, float attn_factor, long long c_sl, long long c_head, hipStream_t st);

@@ -29,11 +29,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
 
+#include "../../include/ns_bestla.h"
 #include "ns_common.h"
 #include "ns_dev.h"
 
@@ -63,6 +65,17 @@ struct GemvMat {
 };
 static_assert(sizeof(GemvMat) == 40, "GemvMat is addressed by index in the kernel-argument segment");
 
+// RoPE of q and k + kv-cache append as the epilogue of a fused QKV launch (ns_qkv_rope): adjacent-pair mode only, so
+// a pair always lies inside one 16-column tile
+struct GemvRope {
+  _Float16* kc;
+  _Float16* vc;
+  long long c_sl, c_head;  // cache element strides per position / per head
+  const float2* cos_sin;   // [row][head_size / 2] (cos, sin) * attn_factor of position n_past + row (ns_hip_rope_cos_sin)
+  int head_size, n_past;
+  int on;
+};
+
 struct GemvParams {
   // ---- hot head: everything the prologue needs, fetched by one batch of scalar loads ----
   const uint8_t* wbase0;    // matrix 0 (and, for the fused gate/up launch, matrix 1)
@@ -84,6 +97,17 @@ struct GemvParams {
   float* c2;
   const float* d;
   int ldc, ldd, epilogue;
+  // carried RMS norm, consumer side (ns_norm_link): per row, in_parts partial sums of squares of the un-normalised
+  // activations, staged into LDS at ssq_off beside A (nullptr: A is already normalised);
+  // row scale = 1 / sqrt(sum * in_inv_size + in_eps)
+  const float* in_ssq;
+  uint32_t in_parts, in_stride;
+  uint32_t ssq_off;
+  float in_eps, in_inv_size;
+  const float* out_gamma;     // carried norm, producer: fp16 shadow = v * gamma[col] ...
+  float* out_ssq;             // ... and out_ssq[row * out_stride + tile] = sum of v^2 over the tile's columns
+  uint32_t out_stride;
+  GemvRope rope;
   F4Lut lut;
   F8Consts f8;
 #ifdef NS_TRACE
@@ -119,7 +143,10 @@ enum GemvMode { GV_PLAIN = 0, GV_DUAL = 1, GV_MSEG = 2 };
 // MODE: one matrix / two matrices of one shape streamed in lockstep (gate/up, SiLU-mul epilogue) / several matrices
 // side by side along N (QKV).  Activations arrive as fp16 (the producer's shadow); fp32-only callers stay on
 // smallm_kernel, which converts while staging.
-template <int KIND, int SPS, int SK, bool ASYM, int MODE>
+// EXT: the launch carries an RMS norm (ns_norm_link) and / or the RoPE + kv-append epilogue (ns_qkv_rope).  A separate
+// instantiation, because even untaken these paths cost every launch 0.1-0.3 us (later argument fetch, longer cold
+// epilogue code: 1057 vs 1036 us on the 7B chain, profiles/r02o_ext_ab.txt).
+template <int KIND, int SPS, int SK, bool ASYM, int MODE, bool EXT>
 __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   constexpr bool DUAL = MODE == GV_DUAL, MSEG = MODE == GV_MSEG;
   constexpr int NJ = kind_is_8bit(KIND) ? 2 : 4;
@@ -259,6 +286,35 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   __builtin_amdgcn_sched_barrier(0);
   NS_GSTAMP(1);
 
+  // ---- 2b. carried norm (consumer side): the rows' partial sums of squares, in_parts floats per row, go to LDS as
+  //      1 KiB pieces too — requested AFTER the ring so that nothing is added in front of the first weight request
+  //      (its arguments are fetched here, late); only the epilogue reads them.  A wave that requests a piece waits
+  //      a little more strictly for its first records (the piece counts as one more request in flight), that is all.
+  const float* in_ssq = nullptr;
+  uint32_t in_parts = 0, ssq_off = 0;
+  if constexpr (EXT) {
+    const KArgs mid = late_args();
+    in_ssq = mid->in_ssq;
+    in_parts = mid->in_parts;
+    ssq_off = mid->ssq_off;
+  }
+  if (EXT && in_ssq) {
+    const uint32_t in_stride = late_args()->in_stride;
+    const uint32_t spieces = (in_parts * 4u + 1023u) >> 10;
+    const Rsrc rs = make_rsrc(in_ssq, (uint32_t(rows - 1) * in_stride + in_parts) * 4u);
+    const LdsPtr al = (LdsPtr)(smem);
+    for (uint32_t u = NW - 1u - w; u < uint32_t(rows) * spieces; u += NW) {  // last wave first: it has the fewest A pieces
+      const uint32_t r = u / spieces, c = u - r * spieces;
+      const uint32_t left = in_parts * 4u - (c << 10);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (uint32_t(l) * 16u < left)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, reinterpret_cast<__attribute__((address_space(3))) void*>(al + ssq_off + (u << 10)),
+                                                 16, voff_q, r * in_stride * 4u + (c << 10), 0, 0);
+#endif
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- 3. this wave's activation pieces (the oldest requests in its queue) have landed once only its ring
   //      requests are left in flight ----
   wait_records(min(nst * uint32_t(NQ), uint32_t(PF)));
@@ -359,6 +415,16 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   const int ldc = cold->ldc, ldd = cold->ldd, epi = cold->epilogue;
   const float* dptr = cold->d;
   float* c2 = cold->c2;
+  float in_eps = 0.f, in_inv = 0.f;
+  const float* ogamma = nullptr;
+  float* ossq = nullptr;
+  uint32_t ostride = 0;
+  if constexpr (EXT) {
+    in_eps = cold->in_eps, in_inv = cold->in_inv_size;
+    ogamma = cold->out_gamma;
+    ossq = cold->out_ssq;
+    ostride = cold->out_stride;
+  }
   __syncthreads();
   if (w == 0) {
     floatx4 sum[NQ];
@@ -368,18 +434,58 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
       for (uint32_t ww = 0; ww < NW; ww++) sum[q] += red[ww * kRedWave + q * 64 + l];
     }
     // ---- 6. epilogue: lane (nn, g) holds rows 4g .. 4g+3 of column nn ----
-    const int col = int(tl) * 16 + nn;
-    if (col < ncols) {
+    // carried norm, consumer side: A was gamma * x, not yet normalised; the row's 1 / rms scales the finished dot
+    // products (ne_compute_forward_rms_norm_f32, ne_layers.c: scale = 1 / sqrtf(mean + eps)).  The 16 lanes of a
+    // row group add the staged partial sums in a fixed order.
+    float rscale[4] = {1.f, 1.f, 1.f, 1.f};
+    if (EXT && in_ssq) {
+      const uint32_t ssq_ld = ((in_parts * 4u + 1023u) >> 10) << 8;  // floats per staged row
+      const float* sl = reinterpret_cast<const float*>(smem + ssq_off);
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
-        const int row = 4 * g + rr;
-        if (row >= p.m) continue;
-        float v = sum[0][rr];
+        const int row = min(4 * g + rr, rows - 1);
+        float t = 0.f;
+        for (uint32_t j = uint32_t(nn); j < in_parts; j += 16u) t += sl[uint32_t(row) * ssq_ld + j];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        rscale[rr] = 1.0f / sqrtf(t * in_inv + in_eps);
+      }
+    }
+    const int col = int(tl) * 16 + nn;
+    const bool col_ok = col < ncols;
+    const float gam = (EXT && ogamma && col_ok) ? ogamma[col] : 1.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int row = 4 * g + rr;
+      const bool ok = col_ok && row < p.m;
+      float v = sum[0][rr] * rscale[rr];
+      if constexpr (MSEG && EXT) {
+        if (cold->rope.on) {
+          // ne_rope (mode 0) on q and k, then the kv-cache append (models/llama/llama.cpp:232-262): the arithmetic of
+          // rope_qkv_append_kernel (ns_quant.hip) — theta by sequential fp32 products, separately rounded multiplies
+          const float vp = __shfl_xor(v, 1, 64);  // the pair's other element (same tile: 16 | even head_size)
+          const int hs = cold->rope.head_size;
+          const int head = col / hs, e = col - head * hs;
+          if (sg < 2) {
+            // (cos, sin) come from the per-token table: evaluating cosf / sinf here (argument reduction for angles up to
+            // the context length) cost 12 us per launch (profiles/r02n)
+            const float2 cs = cold->rope.cos_sin[min(row, rows - 1) * (hs >> 1) + (e >> 1)];
+            v = (e & 1) ? __fadd_rn(__fmul_rn(vp, cs.y), __fmul_rn(v, cs.x)) : __fsub_rn(__fmul_rn(v, cs.x), __fmul_rn(vp, cs.y));
+          }
+          if (ok && sg > 0) {
+            _Float16* cache = sg == 1 ? cold->rope.kc : cold->rope.vc;
+            cache[(long long)(cold->rope.n_past + row) * cold->rope.c_sl + (long long)head * cold->rope.c_head + e] = (_Float16)v;
+          }
+        }
+      }
+      if (ok) {
         if constexpr (DUAL) {
           // tmp1 = act(A*W1) ; tmp2 = (A*W3) * tmp1   (neural_speed/core/layers/ip_fusion_ffn.cpp:364-406)
           const float t1 = (epi == 5) ? epi_silu(v) : epi_gelu(v);
           if (c2) c2[size_t(row) * ldc + col] = t1;
-          v = sum[1][rr] * t1;
+          v = sum[1][rr] * rscale[rr] * t1;
         } else {
           const float dv = dptr ? dptr[size_t(row) * ldd + col] : 0.f;
           switch (epi) {
@@ -392,7 +498,17 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
           }
         }
         cbase[size_t(row) * ldc + col] = v;
-        if (c16) c16[size_t(row) * ldc + col] = (_Float16)v;
+        // carried norm, producer side: the shadow the NEXT operator streams is gamma * v (its norm's weight), the
+        // normalisation itself follows from the partial sums below
+        if (c16) c16[size_t(row) * ldc + col] = (_Float16)(v * gam);
+      }
+      if (EXT && ossq) {  // sum of squares of this tile's 16 columns of row `row`, fixed order
+        float t = ok ? v * v : 0.f;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        if (nn == 0 && row < p.m) ossq[size_t(row) * ostride + tl] = t;
       }
     }
   }
@@ -411,9 +527,14 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 template <int KIND, int SPS, int SK, bool ASYM>
 static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw, size_t lds, hipStream_t st) {
   const dim3 g(grid), b(nw * 64);
+  const bool ext = p.in_ssq || p.out_gamma || p.out_ssq || p.rope.on;
 #define NS_GV_LAUNCH(MODEV)                                                                                     \
   {                                                                                                             \
-    auto k = gemv_kernel<KIND, SPS, SK, ASYM, MODEV>;                                                            \
+    if (ext) NS_GV_LAUNCH_E(MODEV, true) else NS_GV_LAUNCH_E(MODEV, false)                                      \
+  }
+#define NS_GV_LAUNCH_E(MODEV, EXTV)                                                                             \
+  {                                                                                                             \
+    auto k = gemv_kernel<KIND, SPS, SK, ASYM, MODEV, EXTV>;                                                      \
     static const hipError_t attr =                                                                              \
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kGvMaxLds)); \
     if (attr != hipSuccess && lds > 64 * 1024) return attr;                                                     \
@@ -426,6 +547,7 @@ static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw,
   else
     NS_GV_LAUNCH(GV_PLAIN)
 #undef NS_GV_LAUNCH
+#undef NS_GV_LAUNCH_E
   return hipGetLastError();
 }
 template <int KIND, int SPS, int SK>
@@ -524,6 +646,36 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   const bool a16 = a.a16 != nullptr && (a.lda & 7) == 0 && (w0->k & 7) == 0 && (reinterpret_cast<uintptr_t>(a.a16) & 15) == 0;
   if (!a16 || (rows > 1 && w0->k % kstep != 0)) return hipErrorNotSupported;
   p.a = a.a16;
+  // carried RMS norm (ns_norm_link): consumer side stages in_parts floats per row behind A
+  size_t ssq_bytes = 0;
+  if (a.link) {
+    const ns_norm_link& k = *a.link;
+    if (k.in_ssq) {
+      if (k.in_parts < 1 || k.in_stride < k.in_parts || (k.in_stride & 3) || (reinterpret_cast<uintptr_t>(k.in_ssq) & 15) ||
+          k.norm_size < 1)
+        return hipErrorInvalidValue;
+      ssq_bytes = size_t(rows) * ((size_t(k.in_parts) * 4 + 1023) >> 10 << 10);
+      p.in_ssq = k.in_ssq;
+      p.in_parts = uint32_t(k.in_parts), p.in_stride = uint32_t(k.in_stride);
+      p.in_eps = k.eps, p.in_inv_size = 1.0f / float(k.norm_size);
+    }
+    if (k.out_ssq || k.out_gamma) {
+      if (a.dual || nmat != 1 || (k.out_ssq && k.out_stride < w0->ntiles)) return hipErrorInvalidValue;
+      p.out_gamma = k.out_gamma, p.out_ssq = k.out_ssq, p.out_stride = uint32_t(k.out_stride);
+    }
+  }
+  if (a.rope) {
+    const ns_qkv_rope& r = *a.rope;
+    if (mode != GV_MSEG || nmat != 3 || r.mode != 0 || r.head_size < 2 || (r.head_size & 1) || r.n_dims != r.head_size ||
+        !r.kcache16 || !r.vcache16 || !r.cos_sin || r.n_past < 0 || p.mat[0].n != r.heads * r.head_size ||
+        p.mat[1].n != r.heads_kv * r.head_size || p.mat[2].n != r.heads_kv * r.head_size)
+      return hipErrorInvalidValue;
+    p.rope.kc = static_cast<_Float16*>(r.kcache16), p.rope.vc = static_cast<_Float16*>(r.vcache16);
+    p.rope.c_sl = r.cache_step_sl, p.rope.c_head = r.cache_step_head;
+    p.rope.head_size = r.head_size, p.rope.n_past = r.n_past;
+    p.rope.cos_sin = reinterpret_cast<const float2*>(r.cos_sin);
+    p.rope.on = 1;
+  }
   if (uint64_t(rows) * uint64_t(a.lda) * 4 >= (uint64_t(1) << 30)) return hipErrorNotSupported;  // staging offsets
 
   // waves per workgroup: enough waves on the chip to overlap dequantisation with the stream (as tuned for
@@ -539,7 +691,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   };
   int nw = decode_waves(grid, int(ks), a.dual);
   {
-    while (nw > 1 && ((a_bytes + 15) & ~size_t(15)) + size_t(nw) * ring_bytes(nw) > kGvMaxLds) nw /= 2;
+    while (nw > 1 && ((a_bytes + 15) & ~size_t(15)) + ssq_bytes + size_t(nw) * ring_bytes(nw) > kGvMaxLds) nw /= 2;
   }
   uint32_t nw_log2 = 0;
   while ((1 << nw_log2) < nw) nw_log2++;
@@ -559,7 +711,8 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   p.k = w0->k;
   p.lda = a.lda;
   p.row_stride = row_stride;
-  p.ring_off = uint32_t((a_bytes + 15) & ~size_t(15));
+  p.ssq_off = uint32_t((a_bytes + 15) & ~size_t(15));
+  p.ring_off = p.ssq_off + uint32_t(ssq_bytes);
   p.c2 = a.c2;
   p.d = a.d;
   p.ldc = a.ldc;

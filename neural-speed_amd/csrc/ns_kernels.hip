@@ -690,6 +690,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
     const hipError_t e = launch_gemv(a, st);
     if (e != hipErrorNotSupported) return e;
   }
+  if (a.link || a.rope) return hipErrorNotSupported;  // carried norm / fused RoPE exist only in gemv_kernel: never silently dropped
   const ns_weight* w0 = a.seg[0].w;
   SmallMParams p;
   memset(&p, 0, sizeof(p));

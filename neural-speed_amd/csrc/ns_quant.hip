@@ -493,6 +493,31 @@ hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, 
   return hipGetLastError();
 }
 
+// Producer side of a carried RMS norm (ns_norm_link) for a tensor no GEMM produced: x16 = fp16(x * gamma), and per row and
+// 16-column tile the sum of x^2, in the layout and summation order of gemv_kernel's epilogue.
+__global__ __launch_bounds__(256) void norm_prep_kernel(int m, int n, const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma, _Float16* __restrict__ x16,
+                                                        float* __restrict__ ssq, int ssq_stride) {
+  const int row = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = col < n;
+  const float v = ok ? x[size_t(row) * ldx + col] : 0.f;
+  if (ok && x16) x16[size_t(row) * ldx + col] = (_Float16)(gamma ? v * gamma[col] : v);
+  float t = v * v;
+  t += __shfl_xor(t, 1, 64);
+  t += __shfl_xor(t, 2, 64);
+  t += __shfl_xor(t, 4, 64);
+  t += __shfl_xor(t, 8, 64);
+  if ((threadIdx.x & 15) == 0 && ok && ssq) ssq[size_t(row) * ssq_stride + (col >> 4)] = t;
+}
+hipError_t launch_norm_prep(int m, int n, const float* x, int ldx, const float* gamma, void* x16, float* ssq,
+                            int ssq_stride, hipStream_t st) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(norm_prep_kernel, dim3(unsigned((n + 255) / 256), unsigned(m)), dim3(256), 0, st, m, n, x, ldx, gamma,
+                     static_cast<_Float16*>(x16), ssq, ssq_stride);
+  return hipGetLastError();
+}
+
 __global__ void bcast_kernel(const float* __restrict__ t, const float* __restrict__ v, float* __restrict__ out,
                              size_t total, int vsize, int vstep, bool mul) {
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -722,6 +747,27 @@ __global__ void rope_qkv_append_kernel(float* __restrict__ q, const float* __res
     vc[(long long)(n_past + i2) * c_sl + (long long)ih * c_head + e] = (_Float16)v[g];
   }
 }
+// (cos, sin) * attn_factor of the mode-0 pairs of positions n_past .. n_past + m - 1: the angle arithmetic of
+// rope_qkv_append_kernel, once per token for all layers (ns_qkv_rope)
+__global__ void rope_cos_sin_kernel(int m, int n_past, int npairs, float theta_scale, float freq_scale, float attn_factor,
+                                    float2* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= m * npairs) return;
+  const int i2 = gid / npairs, pr = gid % npairs;
+  float theta_base = float(n_past + i2);
+  for (int t = 0; t < pr; t++) theta_base = __fmul_rn(theta_base, theta_scale);
+  const float theta = __fmul_rn(freq_scale, theta_base);
+  out[gid] = float2{__fmul_rn(cosf(theta), attn_factor), __fmul_rn(sinf(theta), attn_factor)};
+}
+hipError_t launch_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, float freq_scale, float attn_factor,
+                               float* out, hipStream_t st) {
+  const int total = m * (n_dims / 2);
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rope_cos_sin_kernel, grid1d(size_t(total), 64), dim3(64), 0, st, m, n_past, n_dims / 2,
+                     powf(freq_base, -2.0f / n_dims), freq_scale, attn_factor, reinterpret_cast<float2*>(out));
+  return hipGetLastError();
+}
+
 hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void* kc, void* vc, int seq, int heads,
                                   int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base,
                                   float freq_scale, float attn_factor, long long c_sl, long long c_head, hipStream_t st) {

@@ -39,6 +39,39 @@ def test_config1_gpt2_small_q4_0_decode(L, pkg, nso, n, k):
     _case(L, pkg, nso, n, k, 1, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8)
 
 
+@pytest.mark.parametrize("n,k", [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096)])
+@pytest.mark.parametrize("m", [1, 4])
+def test_config2_llama7b_q4_0_decode_full_size(L, pkg, nso, n, k, m):
+    """config 2 — the headline workload — at FULL size: every distinct GEMM shape of Llama-2-7B (wq/wk/wv/wo, gate/up,
+    down, lm_head), Q4_0 g32 bf16 scales, batch 1 (and 4: the widest row count of the M <= 4 envelope), against the
+    ORACLE's streaming GEMV over the whole blob (nso.gemv_f32, the call bench.py times as cpu_baseline) — every output
+    column, not a sample — and against the fp64 GEMM."""
+    import torch
+    rng = np.random.default_rng(n + k + m)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(n * 7 + k)
+    dW = torch.randn((n, k), generator=g, device="cuda") * 0.02
+    size = L.ns_BTLAGemmPackBSize(n, k, 32, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, None)
+    dBlob = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    pkg.check(L.ns_hip_quant_pack_device(dBlob.data_ptr(), dW.data_ptr(), n, k, k, 32, pkg.S4, pkg.BF16, False,
+                                         pkg.COMP_INT8, True, st))
+    torch.cuda.synchronize()
+    blob = nso.aligned_bytes(size)
+    blob[:] = dBlob.cpu().numpy()
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    out = np.zeros((m, n), np.float32)
+    L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), m, n, k, k, n, None)
+    ref32 = nso.gemv_f32(a, blob)
+    e32 = nso.rel_l2(out, ref32)
+    assert e32 < TOL, (n, k, m, e32)
+    # per-column: no single output may be off by more than 1e-3 of the output scale (a sampled-column check would
+    # miss a bad tile)
+    assert np.max(np.abs(out - ref32)) < 1e-3 * np.sqrt(np.mean(ref32.astype(np.float64) ** 2)) * 8
+    ref64 = nso.gemm_f64(a, blob)
+    assert nso.rel_l2(out, ref64) < TOL
+    L.ns_hip_cache_clear()
+
+
 @pytest.mark.parametrize("n,k", [(4096, 4096), (2752, 4096), (4096, 2752)])
 def test_config3_llama7b_int8_prefill(L, pkg, nso, n, k):
     """config 3: INT8 weights, fp16 compute, prefill (M > 64 -> gemm2_kernel); M = 192 and a quarter of the FFN width
