@@ -707,6 +707,14 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_gemv_mode(value);
     return 0;
   }
+  if (key && !strcmp(key, "attn_wg_target")) {
+    set_attn_tuning(value, 0);
+    return 0;
+  }
+  if (key && !strcmp(key, "attn_min_keys")) {
+    set_attn_tuning(0, value);
+    return 0;
+  }
   set_error("ns_hip_set_tuning: unknown key");
   return -1;
 }

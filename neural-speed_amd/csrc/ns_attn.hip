@@ -215,37 +215,66 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   }
 
   typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-  for (int j = j0 + kg; j < j1; j += 16) {
-    float kf[DPL], vf[DPL];
+  // U keys per thread and step: their K and V rows are requested together (a decode step of this kernel is bound by
+  // the bytes in flight — 2 x 16 B per lane and step kept a CU at ~16 KiB, 2.4 TB/s at 2048 positions,
+  // profiles/r02o), and one softmax update serves all U scores.
+  constexpr int U = G * DPL <= 16 ? 4 : (G * DPL <= 64 ? 2 : 1);  // register budget: acc and q are G x DPL each (8: no gain)
+  for (int jb = j0 + kg; jb < j1; jb += 16 * U) {
+    half8_t kv[U][DPL / 8], vv[U][DPL / 8];
 #pragma unroll
-    for (int c = 0; c < DPL / 8; c++) {
-      half8_t kv = half8_t{0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-      if (dact) {
-        kv = *reinterpret_cast<const half8_t*>(kb + (long long)j * p.step_k_sl + 8 * c);
-        vv = *reinterpret_cast<const half8_t*>(vb + (long long)j * p.step_v_sl + 8 * c);
-      }
+    for (int u = 0; u < U; u++) {
+      const int j = jb + 16 * u;
+      const bool live = dact && j < j1;
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        kf[8 * c + e] = float(kv[e]);
-        vf[8 * c + e] = float(vv[e]);
+      for (int c = 0; c < DPL / 8; c++) {
+        kv[u][c] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        vv[u][c] = kv[u][c];
+        if (live) {
+          kv[u][c] = *reinterpret_cast<const half8_t*>(kb + (long long)j * p.step_k_sl + 8 * c);
+          vv[u][c] = *reinterpret_cast<const half8_t*>(vb + (long long)j * p.step_v_sl + 8 * c);
+        }
       }
     }
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      float s = 0.f;
+      float s[U];
 #pragma unroll
-      for (int e = 0; e < DPL; e++) s += q[g][e] * kf[e];
-      s += __shfl_xor(s, 8, 64);
-      s += __shfl_xor(s, 4, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 1, 64);
-      if (tanh30) s = 30.f * tanhf(s * (1.f / 30.f));
-      s += float(j) * slope[g];
-      const float m_new = fmaxf(m[g], s);
-      const float corr = expf(m[g] - m_new), pj = expf(s - m_new);
-      lsum[g] = lsum[g] * corr + pj;
+      for (int u = 0; u < U; u++) {
+        float t2 = 0.f;
 #pragma unroll
-      for (int e = 0; e < DPL; e++) acc[g][e] = acc[g][e] * corr + pj * vf[e];
+        for (int e = 0; e < DPL; e++) t2 += q[g][e] * float(kv[u][e / 8][e % 8]);
+        s[u] = t2;
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+        for (int u = 0; u < U; u++) s[u] += __shfl_xor(s[u], off, 64);
+      }
+      float m_new = m[g];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int j = jb + 16 * u;
+        if (tanh30) s[u] = 30.f * tanhf(s[u] * (1.f / 30.f));
+        s[u] += float(j) * slope[g];
+        if (j >= j1) s[u] = -INFINITY;
+        m_new = fmaxf(m_new, s[u]);
+      }
+      // jb < j1: the first of the U keys is live, so m_new is finite here
+      const float corr = expf(m[g] - m_new);
+      float pj[U], psum = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        pj[u] = expf(s[u] - m_new);  // exp(-inf) = 0 for the keys past the end
+        psum += pj[u];
+      }
+      lsum[g] = lsum[g] * corr + psum;
+#pragma unroll
+      for (int e = 0; e < DPL; e++) {
+        float a2 = acc[g][e] * corr;
+#pragma unroll
+        for (int u = 0; u < U; u++) a2 += pj[u] * float(vv[u][e / 8][e % 8]);
+        acc[g][e] = a2;
+      }
       m[g] = m_new;
     }
   }
@@ -356,10 +385,16 @@ static hipError_t launch_split_g(const AttnSplitParams& sp, dim3 grid, hipStream
 }
 
 // context splits of the fast path for a shape (1 = unsplit) — shared by the launcher and the workspace-size query
+static std::atomic<int> g_attn_wg_target{1024}, g_attn_min_keys{128};  // ns_hip_set_tuning("attn_wg_target" / "attn_min_keys")
+void set_attn_tuning(int wg_target, int min_keys) {
+  if (wg_target > 0) g_attn_wg_target.store(wg_target);
+  if (min_keys > 0) g_attn_min_keys.store(min_keys);
+}
 static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv) {
   const size_t base_blocks = size_t(heads_kv) * sl_q * batch;
-  int nsplit = int((1024 + base_blocks - 1) / base_blocks);       // aim at ~4 workgroups per CU
-  nsplit = std::min(nsplit, std::max(1, (sl_kv + 127) / 128));    // at least 128 keys per split
+  const int target = g_attn_wg_target.load(), mk = g_attn_min_keys.load();
+  int nsplit = int((target + base_blocks - 1) / base_blocks);     // aim at ~4 workgroups per CU
+  nsplit = std::min(nsplit, std::max(1, (sl_kv + mk - 1) / mk));  // at least 128 keys per split
   return std::min(nsplit, 64);
 }
 static size_t attn_ws_bytes(int batch, int head_num, int heads_kv, int head_size, int sl_q, int sl_kv) {

@@ -84,14 +84,15 @@ struct GemvParams {
   uint32_t ks;              // k-steps per tile
   uint32_t qstride;         // bytes per (tile, k-step) record
   uint32_t nw_log2;         // log2(waves per workgroup)
-  uint32_t s_off0, s_off1, z_off0, z_off1;
-  uint32_t sstride, zstride;
+  uint32_t s_off0, s_off1;
+  uint32_t sstride;
   uint32_t srows, srow_mul, srow_shift;
   uint32_t tb1, tb2;        // first global tile of matrices 1 and 2 of a fused QKV launch (2^32 - 1: absent)
   int m, k, lda;
   uint32_t row_stride;      // halves per staged row in LDS
   uint32_t ring_off;        // byte offset of the per-wave rings in LDS (the reduction scratch reuses them)
   uint32_t ring_stride;     // bytes of one wave's ring = slots x slot size
+  uint32_t z_off0, z_off1, zstride;  // asymmetric formats only: last, so that the rest is one contiguous run of words
   // ---- cold: read late, through the kernel-argument pointer (keeps them out of the streaming loop's SGPRs) ----
   GemvMat mat[3];
   float* c2;
@@ -167,7 +168,9 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
                  "s"(p.srows), "s"(p.srow_mul), "s"(p.srow_shift), "s"(p.m), "s"(p.k), "s"(p.lda), "s"(p.row_stride),
                  "s"(p.ring_off), "s"(p.ring_stride));
     if constexpr (DUAL) asm volatile("" ::"s"(p.wbase1), "s"(p.s_off1));
-    if constexpr (MSEG) asm volatile("" ::"s"(p.tb1), "s"(p.tb2));
+    if constexpr (MSEG)
+      asm volatile("" ::"s"(p.tb1), "s"(p.tb2), "s"(p.mat[0].wbase), "s"(p.mat[1].wbase), "s"(p.mat[2].wbase), "s"(p.mat[0].s_off),
+                   "s"(p.mat[1].s_off), "s"(p.mat[2].s_off));
     if constexpr (ASYM) asm volatile("" ::"s"(p.z_off0), "s"(p.z_off1), "s"(p.zstride));
   }
   const int tid = threadIdx.x;
@@ -190,12 +193,15 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
     so[0] = p.s_off0, so[1] = p.s_off1;
     zo[0] = p.z_off0, zo[1] = p.z_off1;
   } else if constexpr (MSEG) {
+    // all three matrices' bases and offsets come with the one batch of argument loads and are SELECTED (a lookup by
+    // index in the argument segment would be a second, dependent round trip in front of the first weight request)
     sg = int(T >= p.tb1) + int(T >= p.tb2);
-    const auto* mp = &reinterpret_cast<KArgs>(reinterpret_cast<uint64_t>(__builtin_amdgcn_kernarg_segment_ptr()))->mat[sg];
-    rw[0] = make_rsrc(mp->wbase, 0x80000000u);
-    so[0] = mp->s_off;
-    zo[0] = mp->z_off;
-    tl = T - mp->tile_begin;
+    const uint8_t* wb = sg == 0 ? p.mat[0].wbase : (sg == 1 ? p.mat[1].wbase : p.mat[2].wbase);
+    rw[0] = make_rsrc(wb, 0x80000000u);
+    so[0] = sg == 0 ? p.mat[0].s_off : (sg == 1 ? p.mat[1].s_off : p.mat[2].s_off);
+    if constexpr (ASYM) zo[0] = sg == 0 ? p.mat[0].z_off : (sg == 1 ? p.mat[1].z_off : p.mat[2].z_off);
+    else zo[0] = 0;
+    tl = T - (sg == 0 ? 0u : (sg == 1 ? p.tb1 : p.tb2));
   } else {
     rw[0] = make_rsrc(p.wbase0, 0x80000000u);
     so[0] = p.s_off0;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   // zero points}; slot i holds the record of item i (mod PF)
   constexpr uint32_t SLOT = 1024u + 16u * SBYTES + (ASYM ? 16u * SPS : 0u);
   constexpr int OPS = ASYM ? 3 : 2;  // requests per record
-  static_assert(OPS * PF <= 63, "vmcnt is a 6-bit counter");
+  static_assert(OPS * PF + kGvMaxRows * 2 <= 63, "vmcnt is a 6-bit counter (ring + the carried norm's pieces)");
   const LdsPtr ring = (LdsPtr)(smem) + p.ring_off + w * p.ring_stride;
   const uint32_t ring_lane = uint32_t(reinterpret_cast<uintptr_t>(ring)) + uint32_t(l) * 16u;  // LDS byte address
   const uint32_t ring_corr = uint32_t(reinterpret_cast<uintptr_t>(ring)) + 1024u + uint32_t(nn) * SBYTES;
@@ -288,8 +294,9 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 
   // ---- 2b. carried norm (consumer side): the rows' partial sums of squares, in_parts floats per row, go to LDS as
   //      1 KiB pieces too — requested AFTER the ring so that nothing is added in front of the first weight request
-  //      (its arguments are fetched here, late); only the epilogue reads them.  A wave that requests a piece waits
-  //      a little more strictly for its first records (the piece counts as one more request in flight), that is all.
+  //      (its arguments are fetched here, late); only the epilogue reads them.  The requesting wave waits a little
+  //      more strictly for its first records (a piece counts as one more request in flight), that is all.  With up
+  //      to 16 rows x pieces the 6-bit request counter cannot overflow: PF x OPS + 16 <= 63 is asserted below.
   const float* in_ssq = nullptr;
   uint32_t in_parts = 0, ssq_off = 0;
   if constexpr (EXT) {
@@ -298,12 +305,12 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
     in_parts = mid->in_parts;
     ssq_off = mid->ssq_off;
   }
-  if (EXT && in_ssq) {
+  if (EXT && in_ssq && w == 0) {  // wave 0 finishes the tile: it fetches them itself and needs no barrier to read them
     const uint32_t in_stride = late_args()->in_stride;
     const uint32_t spieces = (in_parts * 4u + 1023u) >> 10;
     const Rsrc rs = make_rsrc(in_ssq, (uint32_t(rows - 1) * in_stride + in_parts) * 4u);
     const LdsPtr al = (LdsPtr)(smem);
-    for (uint32_t u = NW - 1u - w; u < uint32_t(rows) * spieces; u += NW) {  // last wave first: it has the fewest A pieces
+    for (uint32_t u = 0; u < uint32_t(rows) * spieces; u++) {
       const uint32_t r = u / spieces, c = u - r * spieces;
       const uint32_t left = in_parts * 4u - (c << 10);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -425,6 +432,65 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
     ossq = cold->out_ssq;
     ostride = cold->out_stride;
   }
+  // Wave 0 finishes the tile.  Everything its epilogue has to FETCH (the epilogue operand, the next norm's weight, the
+  // RoPE table entry) is requested before the workgroup barrier, so the round trips overlap the wait for the slowest
+  // wave instead of following it (each is 1-2 us at the tail of a 5-12 us launch).
+  const int col = int(tl) * 16 + nn;
+  const bool col_ok = col < ncols;
+  float dvp[4] = {0.f, 0.f, 0.f, 0.f};
+  float gam = 1.f;
+  float2 cs[4];
+  int rope_head = 0, rope_e = 0;
+  bool rope_on = false;
+  _Float16* rope_cache = nullptr;
+  long long rope_sl = 0;
+  // carried norm, consumer side: A was gamma * x, not yet normalised; the row's 1 / rms scales the finished dot
+  // products (ne_compute_forward_rms_norm_f32, ne_layers.c: scale = 1 / sqrtf(mean + eps)).  Per row the 64 lanes add
+  // the staged partial sums in a fixed order (lane-strided, then a butterfly).
+  float rscale[4] = {1.f, 1.f, 1.f, 1.f};
+  if (w == 0) {
+    if constexpr (!DUAL) {
+      if (dptr && col_ok) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+          if (4 * g + rr < p.m) dvp[rr] = dptr[size_t(4 * g + rr) * ldd + col];
+      }
+    }
+    if constexpr (EXT) {
+      if (ogamma && col_ok) gam = ogamma[col];
+      if constexpr (MSEG) {
+        rope_on = cold->rope.on != 0;
+        if (rope_on) {
+          const int hs = cold->rope.head_size;
+          rope_head = col / hs;
+          rope_e = col - rope_head * hs;
+          if (sg < 2) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) cs[rr] = cold->rope.cos_sin[min(4 * g + rr, rows - 1) * (hs >> 1) + (rope_e >> 1)];
+          }
+          rope_sl = cold->rope.c_sl;
+          rope_cache = (sg == 1 ? cold->rope.kc : cold->rope.vc) + (long long)cold->rope.n_past * rope_sl +
+                       (long long)rope_head * cold->rope.c_head + rope_e;
+        }
+      }
+      if (in_ssq) {  // wave 0 requested the pieces itself and has waited for all its requests (last record: vmcnt 0)
+        const uint32_t ssq_ld = ((in_parts * 4u + 1023u) >> 10) << 8;  // floats per staged row
+        const float* sl = reinterpret_cast<const float*>(smem + ssq_off);
+        for (int row = 0; row < rows; row++) {
+          float t = 0.f;
+          for (uint32_t j = uint32_t(l); j < in_parts; j += 64u) t += sl[uint32_t(row) * ssq_ld + j];
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+          const float r = 1.0f / sqrtf(t * in_inv + in_eps);
+          if ((row >> 2) == g) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+              if ((row & 3) == rr) rscale[rr] = r;
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
   if (w == 0) {
     floatx4 sum[NQ];
@@ -434,50 +500,22 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
       for (uint32_t ww = 0; ww < NW; ww++) sum[q] += red[ww * kRedWave + q * 64 + l];
     }
     // ---- 6. epilogue: lane (nn, g) holds rows 4g .. 4g+3 of column nn ----
-    // carried norm, consumer side: A was gamma * x, not yet normalised; the row's 1 / rms scales the finished dot
-    // products (ne_compute_forward_rms_norm_f32, ne_layers.c: scale = 1 / sqrtf(mean + eps)).  The 16 lanes of a
-    // row group add the staged partial sums in a fixed order.
-    float rscale[4] = {1.f, 1.f, 1.f, 1.f};
-    if (EXT && in_ssq) {
-      const uint32_t ssq_ld = ((in_parts * 4u + 1023u) >> 10) << 8;  // floats per staged row
-      const float* sl = reinterpret_cast<const float*>(smem + ssq_off);
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int row = min(4 * g + rr, rows - 1);
-        float t = 0.f;
-        for (uint32_t j = uint32_t(nn); j < in_parts; j += 16u) t += sl[uint32_t(row) * ssq_ld + j];
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
-        rscale[rr] = 1.0f / sqrtf(t * in_inv + in_eps);
-      }
-    }
-    const int col = int(tl) * 16 + nn;
-    const bool col_ok = col < ncols;
-    const float gam = (EXT && ogamma && col_ok) ? ogamma[col] : 1.f;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       const int row = 4 * g + rr;
       const bool ok = col_ok && row < p.m;
       float v = sum[0][rr] * rscale[rr];
       if constexpr (MSEG && EXT) {
-        if (cold->rope.on) {
+        if (rope_on) {
           // ne_rope (mode 0) on q and k, then the kv-cache append (models/llama/llama.cpp:232-262): the arithmetic of
-          // rope_qkv_append_kernel (ns_quant.hip) — theta by sequential fp32 products, separately rounded multiplies
+          // rope_qkv_append_kernel (ns_quant.hip), separately rounded multiplies; (cos, sin) from the per-token table
+          // (evaluating cosf / sinf here — argument reduction for angles up to the context length — cost 12 us per
+          // launch, profiles/r02n)
           const float vp = __shfl_xor(v, 1, 64);  // the pair's other element (same tile: 16 | even head_size)
-          const int hs = cold->rope.head_size;
-          const int head = col / hs, e = col - head * hs;
-          if (sg < 2) {
-            // (cos, sin) come from the per-token table: evaluating cosf / sinf here (argument reduction for angles up to
-            // the context length) cost 12 us per launch (profiles/r02n)
-            const float2 cs = cold->rope.cos_sin[min(row, rows - 1) * (hs >> 1) + (e >> 1)];
-            v = (e & 1) ? __fadd_rn(__fmul_rn(vp, cs.y), __fmul_rn(v, cs.x)) : __fsub_rn(__fmul_rn(v, cs.x), __fmul_rn(vp, cs.y));
-          }
-          if (ok && sg > 0) {
-            _Float16* cache = sg == 1 ? cold->rope.kc : cold->rope.vc;
-            cache[(long long)(cold->rope.n_past + row) * cold->rope.c_sl + (long long)head * cold->rope.c_head + e] = (_Float16)v;
-          }
+          if (sg < 2)
+            v = (rope_e & 1) ? __fadd_rn(__fmul_rn(vp, cs[rr].y), __fmul_rn(v, cs[rr].x))
+                             : __fsub_rn(__fmul_rn(v, cs[rr].x), __fmul_rn(vp, cs[rr].y));
+          if (ok && sg > 0) rope_cache[(long long)row * rope_sl] = (_Float16)v;
         }
       }
       if (ok) {
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
           if (c2) c2[size_t(row) * ldc + col] = t1;
           v = sum[1][rr] * rscale[rr] * t1;
         } else {
-          const float dv = dptr ? dptr[size_t(row) * ldd + col] : 0.f;
+          const float dv = dvp[rr];
           switch (epi) {
             case 1: v = v + dv; break;            // custom::epilogue::Add
             case 2: v = v * dv; break;            // custom::epilogue::Mul
@@ -655,6 +693,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
           k.norm_size < 1)
         return hipErrorInvalidValue;
       ssq_bytes = size_t(rows) * ((size_t(k.in_parts) * 4 + 1023) >> 10 << 10);
+      if (ssq_bytes > 32 * 1024) return hipErrorNotSupported;  // at most 32 one-KiB pieces (request counter budget)
       p.in_ssq = k.in_ssq;
       p.in_parts = uint32_t(k.in_parts), p.in_stride = uint32_t(k.in_stride);
       p.in_eps = k.eps, p.in_inv_size = 1.0f / float(k.norm_size);

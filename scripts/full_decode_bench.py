@@ -12,8 +12,12 @@ pkg = ge.load_package()
 torch.cuda.set_device(0)
 chain = bench.Chain(pkg, bench.CFG["n_layer"], 0, 1)
 res = {}
+only_fused = os.environ.get("NS_FULL_ONLY_FUSED") == "1"  # profiling: nothing but the fused graph's kernels
 for ctx in [int(a) for a in sys.argv[1:]] or [128, 512, 2048]:
     f, lf = bench.full_token(chain, pkg, ctx, fused=True)
+    if only_fused:
+        res["ctx_%d" % ctx] = {"fused": f}
+        continue
     u, lu = bench.full_token(chain, pkg, ctx, fused=False)
     rel = float((lf.double() - lu.double()).norm() / lu.double().norm())
     res["ctx_%d" % ctx] = {"fused": f, "one_launch_per_operator": u, "logits_rel_l2": round(rel, 6)}
