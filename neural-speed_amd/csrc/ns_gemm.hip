@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -267,6 +268,324 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
     }
 }
 
+// ================================================================================================================
+// gemm3_kernel — third generation.  What bounded gemm2_kernel was the LDS pipe, not the matrix cores
+// (profiles/r01i: SQ_VALU_MFMA_BUSY 0.39): every chunk the workgroup WROTE 16 KiB of A and 16 KiB of dequantised B
+// with ds_write_b128 (~79 B/clk, MI355X_MICROARCH.md LDS table) and read both back.  Here
+//   * A (fp16) goes HBM/L2 -> LDS by DMA (buffer_load ... lds, 16 B per lane): no staging registers, no ds_write.  The
+//     image is row-major [256 rows][64 halves] with the 16-byte pieces of a row XOR-ed by (row >> 1) & 7 — applied on
+//     the SOURCE address of the DMA (the LDS side of a DMA is lane-linear) and on the fragment reads — so every
+//     ds_read_b128 lane group covers all 64 banks once;
+//   * B never touches LDS: each wave loads the raw records of ITS four column tiles straight into registers (16 B per
+//     lane = one record = 128 deep for 4-bit codes) and dequantises them into MFMA B fragments itself.  A record is
+//     shared by the two waves that split the rows (one extra L1/L2 hit), in exchange the workgroup moves 1/4 of the
+//     LDS bytes and no LDS writes at all;
+//   * workgroup tile 256 x 128, four waves of 128 x 64 (8 x 4 accumulator tiles: 12 fragment reads feed 32 MFMAs per
+//     32-deep slice), two 32 KiB A stages -> two workgroups per CU, whose waves fill each other's dequantisation
+//     and barrier bubbles.
+// Synchronisation per 64-deep chunk: s_waitcnt vmcnt(0) (the wave's own DMA of this chunk, issued one chunk ago, has
+// landed) -> s_barrier (everybody's has, and everybody is done reading the other stage) -> issue the DMA of the next
+// chunk into the other stage -> multiply this chunk.
+constexpr int kG3BM = 256, kG3KC = 64, kG3Tiles = 8;
+constexpr int kG3StageBytes = kG3BM * kG3KC * 2;  // 32 KiB
+constexpr int kG3Stages = 2;
+constexpr int kG3BStageMax = 8 * 2 * 1024 + 8 * 2 * 16 * 16 + 8 * 2 * 16 * 4;  // B stage upper bound: codes + scale rows + zero points
+
+template <int KIND, int SPS, int SK, bool ASYM>
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
+  constexpr bool B8 = KIND == WK_INT8;          // 8-bit codes: a record is 64 deep, two per 128-deep superstep
+  constexpr int NJ = B8 ? 2 : 4;                // 32-deep slices per record
+  constexpr int RPS = B8 ? 2 : 1;               // records per superstep (128 deep = chunks 2u, 2u + 1)
+  constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
+  using Corr = CorrRaw<SPS, SK, ASYM>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char* LdsPtr;
+
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, nn = l & 15, g = l >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int bn = xcd * p.cpx + local % p.cpx, bm = local / p.cpx;
+  if (bn >= p.nbn) return;
+  const int tile0 = bn * kG3Tiles + wn * 4, row0 = bm * kG3BM;
+
+  const Rsrc rq = make_rsrc(p.codes, p.codes_bytes);
+  const Rsrc rs = make_rsrc(p.scales, p.scales_bytes);
+  const Rsrc rz = make_rsrc(p.zps, p.zps_bytes);
+  const Rsrc ra = make_rsrc(p.a16, uint32_t(p.m) * uint32_t(p.lda16) * 2u);  // rows >= m read as zeros
+  const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
+
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- A: DMA of chunk c into a stage.  Wave w, request i covers rows (8 w + i) * 8 .. + 7; lane l writes LDS piece
+  //      l & 7 of row l >> 3 of them and therefore FETCHES piece (l & 7) ^ ((row >> 1) & 7) ----
+  const uint32_t lrow = uint32_t(l >> 3);
+  uint32_t a_voff[2];  // (row >> 1) & 7 = 4 * (i & 1) + (l >> 4): two per-lane source offsets, for even and odd i
+#pragma unroll
+  for (int par = 0; par < 2; par++)
+    a_voff[par] = (uint32_t(row0) + uint32_t(w) * 64u + lrow) * uint32_t(p.lda16) * 2u +
+                  ((uint32_t(l & 7) ^ (uint32_t(4 * par) + uint32_t(l >> 4))) << 4);
+  const uint32_t a_istride = 8u * uint32_t(p.lda16) * 2u;  // source bytes between consecutive requests of a wave
+  auto issue_a = [&](int c, int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const LdsPtr dst = (LdsPtr)(smem) + stage * kG3StageBytes + (w * 8 + i) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16,
+                                               a_voff[i & 1], uint32_t(c) * (kG3KC * 2) + uint32_t(i) * a_istride, 0, 0);
+    }
+#endif
+  };
+  // fragment read offsets of this lane: row wm * 128 + mi * 16 + nn, piece (4 jj + g) ^ ((nn >> 1) & 7)
+  uint32_t a_roff[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; jj++)
+    a_roff[jj] = uint32_t(wm * 128 + nn) * 128u + ((uint32_t(4 * jj + g) ^ uint32_t((nn >> 1) & 7)) << 4);
+
+  // ---- B: raw records + their scale / zero-point rows of the workgroup's 8 column tiles for one 128-deep superstep,
+  //      HBM -> LDS by DMA as well (an ordinary load in this loop would make hipcc drain every DMA in flight at its
+  //      first use — measured: s_waitcnt vmcnt(0) right behind the issue).  ONE B stage: the waves copy their records
+  //      into registers at the start of the superstep, the DMA of the next superstep refills the stage one chunk later.
+  //      Wave w fetches tiles 2w, 2w + 1. ----
+  constexpr uint32_t kBCodes = kG3Tiles * RPS * 1024u;         // [tile][record][64 lanes x 16 B]
+  constexpr uint32_t kBScal = kG3Tiles * RPS * 16u * SBYTES;   // [record][tile][16 columns x SBYTES]
+  constexpr uint32_t kBZp = ASYM ? kG3Tiles * RPS * 16u * SPS : 0u;
+  unsigned char* const b_lds = smem + kG3Stages * kG3StageBytes;
+  const uint32_t btile0 = uint32_t(bn * kG3Tiles + 2 * w);
+  // scale rows: 16 * SBYTES bytes per (tile, row) = SBYTES lanes of 16 B; lanes [0, 2 * SBYTES) cover the wave's two tiles
+  const uint32_t s_lane_tile = uint32_t(l) / uint32_t(SBYTES), s_lane_piece = uint32_t(l) % uint32_t(SBYTES);
+  const uint32_t s_voff = (btile0 + s_lane_tile) * uint32_t(p.srows) * p.sstride + s_lane_piece * 16u;
+  const uint32_t z_lane_tile = uint32_t(l) / uint32_t(SPS), z_lane_piece = uint32_t(l) % uint32_t(SPS);
+  const uint32_t z_voff = (btile0 + z_lane_tile) * uint32_t(p.srows) * p.zstride + z_lane_piece * 16u;
+  auto issue_b = [&](int u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int r = 0; r < RPS; r++) {
+      const uint32_t s = uint32_t(min(u * RPS + r, p.ksteps - 1));
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const LdsPtr dst = (LdsPtr)(b_lds) + ((2 * w + t) * RPS + r) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, uint32_t(l) * 16u,
+                                                 ((btile0 + t) * uint32_t(p.ksteps) + s) * p.qstride, 0, 0);
+      }
+      const uint32_t srow = (s * uint32_t(p.srow_mul)) >> p.srow_shift;
+      if (l < 2 * SBYTES) {
+        const LdsPtr dst = (LdsPtr)(b_lds) + kBCodes + (r * kG3Tiles + 2 * w) * (16 * SBYTES);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, s_voff,
+                                                 srow * p.sstride, 0, 0);
+      }
+      if constexpr (ASYM) {
+        if (l < 2 * SPS) {
+          const LdsPtr dst = (LdsPtr)(b_lds) + kBCodes + kBScal + (r * kG3Tiles + 2 * w) * (16 * SPS);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, z_voff,
+                                                   srow * p.zstride, 0, 0);
+        }
+      }
+    }
+#endif
+  };
+  struct BRec {
+    uint32_t q[4][4 * RPS];
+    Corr c[4][RPS];
+  };
+  // LDS -> registers: this wave's four column tiles (wn * 4 + ni)
+  auto read_b = [&](BRec& b) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      const int t = wn * 4 + ni;
+#pragma unroll
+      for (int r = 0; r < RPS; r++) {
+        const uint4v v = *reinterpret_cast<const uint4v*>(b_lds + (t * RPS + r) * 1024 + l * 16);
+        b.q[ni][4 * r + 0] = v.x, b.q[ni][4 * r + 1] = v.y, b.q[ni][4 * r + 2] = v.z, b.q[ni][4 * r + 3] = v.w;
+        const unsigned char* sp = b_lds + kBCodes + ((r * kG3Tiles + t) * 16 + nn) * SBYTES;
+        if constexpr (SBYTES == 16) {
+          const uint4v sv = *reinterpret_cast<const uint4v*>(sp);
+          b.c[ni][r].s[0] = sv.x, b.c[ni][r].s[1] = sv.y, b.c[ni][r].s[2] = sv.z, b.c[ni][r].s[3] = sv.w;
+        } else if constexpr (SBYTES == 8) {
+          b.c[ni][r].s[0] = reinterpret_cast<const uint32_t*>(sp)[0];
+          b.c[ni][r].s[1] = reinterpret_cast<const uint32_t*>(sp)[1];
+        } else if constexpr (SBYTES == 4) {
+          b.c[ni][r].s[0] = *reinterpret_cast<const uint32_t*>(sp);
+        } else {
+          b.c[ni][r].s[0] = *reinterpret_cast<const uint16_t*>(sp);
+        }
+        if constexpr (ASYM) {
+          const unsigned char* zp = b_lds + kBCodes + kBScal + ((r * kG3Tiles + t) * 16 + nn) * SPS;
+          if constexpr (SPS == 4)
+            b.c[ni][r].z[0] = *reinterpret_cast<const uint32_t*>(zp);
+          else if constexpr (SPS == 2)
+            b.c[ni][r].z[0] = *reinterpret_cast<const uint16_t*>(zp);
+          else
+            b.c[ni][r].z[0] = *zp;
+        }
+      }
+    }
+  };
+
+  // B fragments of 32-deep slice t (0..3) of the superstep held in `b`: codes -> fp16 (code - zp) * scale
+  auto dequant = [&](const BRec& b, auto tc, half8_t (&bf)[4]) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int h = t >> 1, jj = t & 1;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      // 4-bit: word t of the one record; 8-bit: record h, words 2 jj, 2 jj + 1
+      float sc[4], zp[4];
+      corr_decode<SPS, SK, ASYM, NJ>(b.c[ni][B8 ? h : 0], sc, zp);
+      constexpr int js = B8 ? jj : t;  // slice inside its record
+      half8_t v;
+      if constexpr (KIND == WK_INT4) {
+        const _Float16 zl = (_Float16)(-1032.f - zp[js]), zh = (_Float16)(-72.f - zp[js]);
+        v = cvt_i4x8(b.q[ni][js], i4c, half2_t{zl, zl}, half2_t{zh, zh});
+      } else if constexpr (KIND == WK_INT8) {
+        const _Float16 zo = (_Float16)(-1152.f - zp[js]);
+        v = cvt_i8x8(b.q[ni][4 * h + 2 * jj], b.q[ni][4 * h + 2 * jj + 1], half2_t{zo, zo});
+      } else {
+        v = cvt_f4x8(b.q[ni][js], p.lut);
+      }
+      const _Float16 sh = (_Float16)(sc[js] * p.spre);
+      bf[ni] = v * half8_t{sh, sh, sh, sh, sh, sh, sh, sh};
+    }
+  };
+  auto load_af = [&](int stage, int jj, half8_t (&af)[8]) {
+    const unsigned char* a_lds = smem + stage * kG3StageBytes + a_roff[jj];
+#pragma unroll
+    for (int mi = 0; mi < 8; mi++) af[mi] = *reinterpret_cast<const half8_t*>(a_lds + mi * (16 * 128));
+  };
+  // one slice: 32 MFMAs; each A fragment is reloaded for the NEXT slice (stage / jj given) as soon as its four MFMAs are
+  // issued — in place, so the next slice's fragments cost no registers beyond this slice's
+  auto mma = [&](half8_t (&af)[8], const half8_t (&bf)[4], auto reload, int stage, int jj) {
+    const unsigned char* nxt = smem + stage * kG3StageBytes + a_roff[jj];
+#pragma unroll
+    for (int mi = 0; mi < 8; mi++) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      if constexpr (decltype(reload)::value) af[mi] = *reinterpret_cast<const half8_t*>(nxt + mi * (16 * 128));
+    }
+  };
+  // ask the scheduler to spread the preparation of the NEXT slice (8 fragment reads, ~60 VALU of dequantisation) between
+  // this slice's 32 MFMAs instead of in front of them: one wave then keeps its matrix pipe busy on its own
+  auto interleave = [&](auto vpm, auto ds) {
+    constexpr int valu_per_mfma = decltype(vpm)::value;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            // 1 MFMA
+      if (decltype(ds)::value && (i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
+      if (valu_per_mfma) __builtin_amdgcn_sched_group_barrier(0x002, valu_per_mfma, 0);             // VALU
+    }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+  // chunk range of this workgroup (split-K: an even number of chunks per split, so supersteps never straddle)
+  const int cbeg = p.ksplit > 1 ? int(blockIdx.y) * p.cps : 0;
+  const int cend = p.ksplit > 1 ? min(p.nchunks, cbeg + p.cps) : p.nchunks;
+  const int ubeg = cbeg >> 1, uend = (cend + 1) >> 1;
+
+  BRec breg;
+  half8_t af[8], bf0[4], bf1[4];
+  issue_a(cbeg, 0);
+  issue_b(ubeg);
+  for (int u = ubeg; u < uend; u++) {
+    const int c0 = 2 * u;
+    // ---- chunk 2u (A stage 0): this superstep's records move to registers ----
+    // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier here (hipcc drains the DMAs in flight before a
+    // barrier): the wave's own DMAs — A(2u), B(u) — have landed, then everybody's have, and everybody is done with A
+    // stage 1.  (An asm barrier with a "memory" clobber made hipcc keep a memory copy of the 128 accumulator registers
+    // up to date: a scratch store behind every MFMA.)
+    __syncthreads();
+    if (c0 + 1 < cend) issue_a(c0 + 1, 1);
+    read_b(breg);
+    load_af(0, 0, af);
+    dequant(breg, std::integral_constant<int, 0>{}, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+    // slice 0 multiplies while slice 1 is prepared
+    dequant(breg, std::integral_constant<int, 1>{}, bf1);
+    mma(af, bf0, T_{}, 0, 1);
+    interleave(std::integral_constant<int, 2>{}, T_{});
+    __builtin_amdgcn_sched_barrier(0);
+    // slice 1 multiplies while slice 2's B fragments are prepared (its A image is behind the next barrier)
+    dequant(breg, std::integral_constant<int, 2>{}, bf0);
+    mma(af, bf1, F_{}, 0, 0);
+    interleave(std::integral_constant<int, 2>{}, F_{});
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chunk 2u + 1 (A stage 1) ----
+    if (c0 + 1 < cend) {
+      __syncthreads();  // A(2u + 1) has landed; everybody has copied B(u) and left A stage 0
+      if (c0 + 2 < cend) issue_a(c0 + 2, 0);
+      if (u + 1 < uend) issue_b(u + 1);
+      load_af(1, 0, af);
+      __builtin_amdgcn_sched_barrier(0);
+      dequant(breg, std::integral_constant<int, 3>{}, bf1);
+      mma(af, bf0, T_{}, 1, 1);
+      interleave(std::integral_constant<int, 2>{}, T_{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(af, bf1, F_{}, 0, 0);
+    }
+  }
+
+  // ---- epilogue ----  (the operator is selected OUTSIDE the unrolled 128-element loops: with the switch inside them
+  // hipcc kept the accumulators in scratch memory — a store behind every MFMA of the main loop)
+  auto store_all = [&](auto ec) {
+    constexpr int E = decltype(ec)::value;  // -1: raw split-K partial
+#pragma unroll
+    for (int mi = 0; mi < 8; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++) {
+        const int col = (tile0 + ni) * 16 + nn;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = row0 + wm * 128 + mi * 16 + 4 * g + r;
+          if (row < p.m && col < p.n) {
+            float v = acc[mi][ni][r] * p.spost;
+            if constexpr (E < 0) {
+              p.part[(size_t(blockIdx.y) * p.m + row) * p.n + col] = v;
+            } else {
+              float dv = 0.f;
+              if constexpr (E == 1 || E == 2 || E == 3) dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
+              if constexpr (E == 1) v = v + dv;            // custom::epilogue::Add
+              if constexpr (E == 2) v = v * dv;            // custom::epilogue::Mul
+              if constexpr (E == 3) v = epi_gelu(v + dv);  // custom::epilogue::Add_Gelu
+              if constexpr (E == 4) v = epi_gelu(v);
+              if constexpr (E == 5) v = epi_silu(v);
+              p.c[size_t(row) * p.ldc + col] = v;
+              if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
+            }
+          }
+        }
+      }
+  };
+  if (p.ksplit > 1) {
+    store_all(std::integral_constant<int, -1>{});
+  } else if (p.epilogue == 1) {
+    store_all(std::integral_constant<int, 1>{});
+  } else if (p.epilogue == 5) {
+    store_all(std::integral_constant<int, 5>{});
+  } else {
+    store_all(std::integral_constant<int, 0>{});
+    if (p.epilogue >= 2 && p.epilogue <= 4) {
+      // the rarely used operators (Mul, Add_Gelu, Gelu) run as a second pass of the SAME thread over what it just stored
+      // (program order on its own addresses; no accumulator access, so these loops need not be unrolled)
+      for (int e = 0; e < 8 * 4 * 4; e++) {
+        const int mi = e >> 4, ni = (e >> 2) & 3, r = e & 3;
+        const int col = (tile0 + ni) * 16 + nn, row = row0 + wm * 128 + mi * 16 + 4 * g + r;
+        if (row < p.m && col < p.n) {
+          float v = p.c[size_t(row) * p.ldc + col];
+          const float dv = (p.epilogue != 4 && p.d) ? p.d[size_t(row) * p.ldd + col] : 0.f;
+          v = p.epilogue == 2 ? v * dv : epi_gelu(p.epilogue == 3 ? v + dv : v);
+          p.c[size_t(row) * p.ldc + col] = v;
+          if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
+        }
+      }
+    }
+  }
+}
+
 // split-K tail: C = epilogue(sum over the K splits, in split order -> deterministic)
 __global__ void gemm2_reduce_kernel(const Gemm2Params p) {
   const size_t idx = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -398,6 +717,40 @@ static hipError_t launch_gemm2_k(const Gemm2Params& p, bool asym, dim3 grid, siz
     return go(gemm2_kernel<KIND, SPS, SK, false>);
   }
 }
+template <int KIND, int SPS, int SK>
+static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hipStream_t st) {
+  // A stages + the B stage of this format: records, scale rows, zero-point rows of 8 column tiles for one superstep
+  constexpr int rps = KIND == WK_INT8 ? 2 : 1;
+  constexpr int sbytes = SPS * (SK == SK_F32 ? 4 : 2);
+  const size_t lds3 = size_t(kG3Stages) * kG3StageBytes + size_t(kG3Tiles) * rps * (1024 + 16 * sbytes + (asym ? 16 * SPS : 0));
+  auto go = [&](auto kern) {
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(kG3Stages * kG3StageBytes + kG3BStageMax));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds3, st, p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && p.ksplit > 1) {
+      const size_t total = size_t(p.m) * p.n;
+      hipLaunchKernelGGL(gemm2_reduce_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, p);
+      e = hipGetLastError();
+    }
+    return e;
+  };
+  if constexpr (KIND == WK_F4) {
+    (void)asym;
+    return go(gemm3_kernel<KIND, SPS, SK, false>);
+  } else {
+    if (asym) return go(gemm3_kernel<KIND, SPS, SK, true>);
+    return go(gemm3_kernel<KIND, SPS, SK, false>);
+  }
+}
+template <int KIND, int SPS>
+static hipError_t launch_gemm3_s(const Gemm2Params& p, uint32_t scale_dt, bool asym, dim3 grid, hipStream_t st) {
+  if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32>(p, asym, grid, st);
+  if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16>(p, asym, grid, st);
+  return launch_gemm3_k<KIND, SPS, SK_BF16>(p, asym, grid, st);
+}
+
 template <int KIND, int SPS>
 static hipError_t launch_gemm2_s(const Gemm2Params& p, uint32_t scale_dt, bool asym, dim3 grid, size_t lds,
                                  hipStream_t st) {
@@ -462,6 +815,45 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   p.spost = w0->g2_post;
   p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
   p.cpx = (p.nbn + 7) / 8;
+  // third-generation kernel (256-row tiles, A by LDS DMA, B dequantised in registers): from 192 rows up; below that
+  // its row tile would be mostly padding.  NS_GEMM3=0 keeps the second generation (diagnostics / A-B runs).
+  static const bool g3_off = getenv("NS_GEMM3") != nullptr && atoi(getenv("NS_GEMM3")) == 0;
+  if (!g3_off && a.m >= 192 && (p.lda16 & 7) == 0) {
+    const int nbm3 = (a.m + kG3BM - 1) / kG3BM;
+    p.ksplit = 1;
+    p.cps = p.nchunks;
+    {
+      static const bool no_splitk = getenv("NS_NO_SPLITK") != nullptr;  // diagnostics
+      const int tiles = p.nbn * nbm3;
+      int ks = 1;
+      while (ks < 8 && tiles * ks * 2 <= 512 && p.nchunks / (ks * 2) >= 8) ks *= 2;
+      if (ks > 1 && !no_splitk) {
+        const size_t bytes = size_t(ks) * a.m * w0->n * 4;
+        float* part = static_cast<float*>(stream_scratch(st, bytes, 2));
+        if (part) {
+          p.ksplit = ks;
+          p.cps = ((p.nchunks + ks - 1) / ks + 1) & ~1;  // even: a 128-deep superstep never straddles two splits
+          p.part = part;
+        }
+      }
+    }
+    const dim3 grid3(unsigned(8 * p.cpx * nbm3), unsigned(p.ksplit));
+#define NS_G3DISPATCH(KIND)                                                           \
+  switch (w0->sps) {                                                                  \
+    case 4: return launch_gemm3_s<KIND, 4>(p, w0->scale_dt, w0->asym, grid3, st);     \
+    case 2: return launch_gemm3_s<KIND, 2>(p, w0->scale_dt, w0->asym, grid3, st);     \
+    default: return launch_gemm3_s<KIND, 1>(p, w0->scale_dt, w0->asym, grid3, st);    \
+  }
+    if (w0->kind == WK_INT4) {
+      NS_G3DISPATCH(WK_INT4)
+    } else if (w0->kind == WK_INT8) {
+      if (w0->sps == 2) return launch_gemm3_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, grid3, st);
+      return launch_gemm3_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, grid3, st);
+    } else {
+      NS_G3DISPATCH(WK_F4)
+    }
+#undef NS_G3DISPATCH
+  }
   const int nbm = (a.m + kG2BM - 1) / kG2BM;
   // few output tiles (M up to a few hundred rows): split K so that the launch still fills the chip
   p.ksplit = 1;

@@ -2,13 +2,13 @@
 # SQ counters of the prefill GEMM (own --pmc pass): where the wave cycles go
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcg
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d gpurun_out/pmcg -o g -- python scripts/prefill_bench.py > gpurun_out/pmcg_bench.json 2>gpurun_out/pmcg_err.log
+timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmcg -o g -- python scripts/prefill_bench.py > gpurun_out/pmcg_bench.json 2>gpurun_out/pmcg_err.log
 python - <<'PY'
 import csv, collections
 rows = list(csv.DictReader(open("gpurun_out/pmcg/g_counter_collection.csv")))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    if "gemm2" not in r["Kernel_Name"]:
+    if "gemm2_kernel" not in r["Kernel_Name"] and "gemm3_kernel" not in r["Kernel_Name"]:
         continue
     key = (r["Kernel_Name"].split("(")[0].replace("void ns::", ""), r["Grid_Size"])
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
