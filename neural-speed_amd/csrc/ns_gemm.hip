@@ -68,6 +68,7 @@ struct Gemm2Params {
                       // to fp16 and the accumulators by spost on the way out, so that weights with very small or very
                       // large magnitudes stay inside fp16's normal range (1, 1 for ordinary LLM weights)
   F4Lut lut;
+  int diag;  // NS_G3_DIAG (diagnostics): 1 = skip the output stores, 2 = skip the main loop
 };
 
 template <int KIND, int SPS, int SK, bool ASYM>
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   half8_t af[8], bf0[4], bf1[4];
   issue_a(cbeg, 0);
   issue_b(ubeg);
-  for (int u = ubeg; u < uend; u++) {
+  for (int u = ubeg; u < (p.diag == 2 ? ubeg + 1 : uend); u++) {
     const int c0 = 2 * u;
     // ---- chunk 2u (A stage 0): this superstep's records move to registers ----
     // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier here (hipcc drains the DMAs in flight before a
@@ -529,58 +530,75 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
     }
   }
 
-  // ---- epilogue ----  (the operator is selected OUTSIDE the unrolled 128-element loops: with the switch inside them
-  // hipcc kept the accumulators in scratch memory — a store behind every MFMA of the main loop)
-  auto store_all = [&](auto ec) {
-    constexpr int E = decltype(ec)::value;  // -1: raw split-K partial
+  // ---- epilogue: through LDS, so that C leaves in whole rows.  A lane of the MFMA layout holds column nn of rows
+  //      4g .. 4g + 3: storing from there writes 64-byte (fp32) and 32-byte (fp16 shadow) pieces — 50 MB per 2048 x 4096
+  //      output at a fraction of the HBM write rate, a third of the whole GEMM's time at K = 4096.  Each wave parks half
+  //      of its 128 x 64 tile (64 rows, padded to 68 floats: conflict-free ds_write_b32) in the stage memory, reads it
+  //      back as float4 along the rows and stores 256-byte runs; the operator is applied on the way out, in a plain loop
+  //      (nothing below indexes the accumulators dynamically — with the switch inside the unrolled accumulator loops hipcc
+  //      kept all 128 accumulator registers in scratch memory, a store behind every MFMA of the main loop). ----
+  constexpr int kRowF = 68;  // floats per parked row
+  float* park = reinterpret_cast<float*>(smem) + w * (64 * kRowF);
+  const int colw = tile0 * 16;  // first column of this wave's 64
+  const bool vec4 = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.c) & 15) == 0 && colw + 64 <= p.n &&
+                    (p.ksplit > 1 ? (p.n & 3) == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 : true) &&
+                    (!p.d || ((p.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(p.d) & 15) == 0)) &&
+                    (!p.c16 || (reinterpret_cast<uintptr_t>(p.c16) & 7) == 0);
+  const int epi = p.epilogue;
+  auto finish = [&](float v, float dv) {
+    switch (epi) {
+      case 1: return v + dv;            // custom::epilogue::Add
+      case 2: return v * dv;            // custom::epilogue::Mul
+      case 3: return epi_gelu(v + dv);  // custom::epilogue::Add_Gelu
+      case 4: return epi_gelu(v);
+      case 5: return epi_silu(v);
+      default: return v;
+    }
+  };
+  __syncthreads();  // every wave is done with the A stages
 #pragma unroll
-    for (int mi = 0; mi < 8; mi++)
+  for (int hh = 0; hh < 2; hh++) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ni++) {
-        const int col = (tile0 + ni) * 16 + nn;
+    for (int mi = 0; mi < 4; mi++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = row0 + wm * 128 + mi * 16 + 4 * g + r;
-          if (row < p.m && col < p.n) {
-            float v = acc[mi][ni][r] * p.spost;
-            if constexpr (E < 0) {
-              p.part[(size_t(blockIdx.y) * p.m + row) * p.n + col] = v;
-            } else {
-              float dv = 0.f;
-              if constexpr (E == 1 || E == 2 || E == 3) dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
-              if constexpr (E == 1) v = v + dv;            // custom::epilogue::Add
-              if constexpr (E == 2) v = v * dv;            // custom::epilogue::Mul
-              if constexpr (E == 3) v = epi_gelu(v + dv);  // custom::epilogue::Add_Gelu
-              if constexpr (E == 4) v = epi_gelu(v);
-              if constexpr (E == 5) v = epi_silu(v);
-              p.c[size_t(row) * p.ldc + col] = v;
-              if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
-            }
-          }
+      for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) park[(mi * 16 + 4 * g + r) * kRowF + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * p.spost;
+    // (LDS operations of one wave complete in order: no barrier between its own writes and reads)
+    const int rbase = row0 + wm * 128 + hh * 64;
+    if (p.diag == 1) continue;
+    if (vec4) {
+      for (int it = 0; it < 16; it++) {
+        const int rl = it * 4 + (l >> 4), row = rbase + rl, col = colw + (l & 15) * 4;
+        if (row >= p.m) continue;
+        float4 v = *reinterpret_cast<const float4*>(park + rl * kRowF + (l & 15) * 4);
+        if (p.ksplit > 1) {  // raw partial; the operator is applied by gemm2_reduce_kernel
+          *reinterpret_cast<float4*>(p.part + (size_t(blockIdx.y) * p.m + row) * p.n + col) = v;
+          continue;
+        }
+        float4 dv = {0.f, 0.f, 0.f, 0.f};
+        if (p.d && epi >= 1 && epi <= 3) dv = *reinterpret_cast<const float4*>(p.d + size_t(row) * p.ldd + col);
+        v = float4{finish(v.x, dv.x), finish(v.y, dv.y), finish(v.z, dv.z), finish(v.w, dv.w)};
+        *reinterpret_cast<float4*>(p.c + size_t(row) * p.ldc + col) = v;
+        if (p.c16) {
+          typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<half4_t*>(p.c16 + size_t(row) * p.ldc + col) =
+              half4_t{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         }
       }
-  };
-  if (p.ksplit > 1) {
-    store_all(std::integral_constant<int, -1>{});
-  } else if (p.epilogue == 1) {
-    store_all(std::integral_constant<int, 1>{});
-  } else if (p.epilogue == 5) {
-    store_all(std::integral_constant<int, 5>{});
-  } else {
-    store_all(std::integral_constant<int, 0>{});
-    if (p.epilogue >= 2 && p.epilogue <= 4) {
-      // the rarely used operators (Mul, Add_Gelu, Gelu) run as a second pass of the SAME thread over what it just stored
-      // (program order on its own addresses; no accumulator access, so these loops need not be unrolled)
-      for (int e = 0; e < 8 * 4 * 4; e++) {
-        const int mi = e >> 4, ni = (e >> 2) & 3, r = e & 3;
-        const int col = (tile0 + ni) * 16 + nn, row = row0 + wm * 128 + mi * 16 + 4 * g + r;
-        if (row < p.m && col < p.n) {
-          float v = p.c[size_t(row) * p.ldc + col];
-          const float dv = (p.epilogue != 4 && p.d) ? p.d[size_t(row) * p.ldd + col] : 0.f;
-          v = p.epilogue == 2 ? v * dv : epi_gelu(p.epilogue == 3 ? v + dv : v);
-          p.c[size_t(row) * p.ldc + col] = v;
-          if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
+    } else {
+      for (int it = 0; it < 64; it++) {  // one row per step, lane = column
+        const int row = rbase + it, col = colw + l;
+        if (row >= p.m || col >= p.n) continue;
+        float v = park[it * kRowF + l];
+        if (p.ksplit > 1) {
+          p.part[(size_t(blockIdx.y) * p.m + row) * p.n + col] = v;
+          continue;
         }
+        const float dv = (p.d && epi >= 1 && epi <= 3) ? p.d[size_t(row) * p.ldd + col] : 0.f;
+        v = finish(v, dv);
+        p.c[size_t(row) * p.ldc + col] = v;
+        if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
       }
     }
   }
@@ -813,6 +831,8 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   if (w0->kind == WK_F4) f4_lut_planes(w0->lut, &p.lut);
   p.spre = w0->g2_pre;
   p.spost = w0->g2_post;
+  static const int g3_diag = getenv("NS_G3_DIAG") ? atoi(getenv("NS_G3_DIAG")) : 0;
+  p.diag = g3_diag;
   p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
   p.cpx = (p.nbn + 7) / 8;
   // third-generation kernel (256-row tiles, A by LDS DMA, B dequantised in registers): from 192 rows up; below that
