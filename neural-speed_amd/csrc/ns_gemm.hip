@@ -68,7 +68,7 @@ struct Gemm2Params {
                       // to fp16 and the accumulators by spost on the way out, so that weights with very small or very
                       // large magnitudes stay inside fp16's normal range (1, 1 for ordinary LLM weights)
   F4Lut lut;
-  int diag;  // NS_G3_DIAG (diagnostics): 1 = skip the output stores, 2 = skip the main loop
+  int diag;  // NS_G3_DIAG (diagnostics): 1 = skip the output stores, 2 = skip the main loop, 3 = DMA and barriers only, 4 = no DMA
 };
 
 template <int KIND, int SPS, int SK, bool ASYM>
@@ -332,15 +332,16 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
     a_voff[par] = (uint32_t(row0) + uint32_t(w) * 64u + lrow) * uint32_t(p.lda16) * 2u +
                   ((uint32_t(l & 7) ^ (uint32_t(4 * par) + uint32_t(l >> 4))) << 4);
   const uint32_t a_istride = 8u * uint32_t(p.lda16) * 2u;  // source bytes between consecutive requests of a wave
-  auto issue_a = [&](int c, int stage) {
+  auto issue_a_piece = [&](int c, int stage, int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const LdsPtr dst = (LdsPtr)(smem) + stage * kG3StageBytes + (w * 8 + i) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16,
-                                               a_voff[i & 1], uint32_t(c) * (kG3KC * 2) + uint32_t(i) * a_istride, 0, 0);
-    }
+    const LdsPtr dst = (LdsPtr)(smem) + stage * kG3StageBytes + (w * 8 + i) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16,
+                                             a_voff[i & 1], uint32_t(c) * (kG3KC * 2) + uint32_t(i) * a_istride, 0, 0);
 #endif
+  };
+  auto issue_a = [&](int c, int stage) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) issue_a_piece(c, stage, i);
   };
   // fragment read offsets of this lane: row wm * 128 + mi * 16 + nn, piece (4 jj + g) ^ ((nn >> 1) & 7)
   uint32_t a_roff[2];
@@ -459,7 +460,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   };
   // one slice: 32 MFMAs; each A fragment is reloaded for the NEXT slice (stage / jj given) as soon as its four MFMAs are
   // issued — in place, so the next slice's fragments cost no registers beyond this slice's
-  auto mma = [&](half8_t (&af)[8], const half8_t (&bf)[4], auto reload, int stage, int jj) {
+  // `after(mi)`: hook behind the four MFMAs of fragment row mi — the DMA requests of the next chunk are issued there,
+  // one per row, instead of in a burst behind the barrier (a request costs ~60 cycles of issue among MFMAs, 100-185 in a
+  // phase that already carries fragment reads, MI355X_MICROARCH.md; 8 of them in front of the MFMAs stall every wave)
+  auto mma = [&](half8_t (&af)[8], const half8_t (&bf)[4], auto reload, int stage, int jj, auto&& after) {
     const unsigned char* nxt = smem + stage * kG3StageBytes + a_roff[jj];
 #pragma unroll
     for (int mi = 0; mi < 8; mi++) {
@@ -467,16 +471,19 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
       for (int ni = 0; ni < 4; ni++)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
       if constexpr (decltype(reload)::value) af[mi] = *reinterpret_cast<const half8_t*>(nxt + mi * (16 * 128));
+      after(mi);
     }
   };
+  auto nothing = [](int) {};
   // ask the scheduler to spread the preparation of the NEXT slice (8 fragment reads, ~60 VALU of dequantisation) between
   // this slice's 32 MFMAs instead of in front of them: one wave then keeps its matrix pipe busy on its own
-  auto interleave = [&](auto vpm, auto ds) {
+  auto interleave = [&](auto vpm, auto ds, auto dma) {
     constexpr int valu_per_mfma = decltype(vpm)::value;
 #pragma unroll
     for (int i = 0; i < 32; i++) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            // 1 MFMA
       if (decltype(ds)::value && (i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
+      if (decltype(dma)::value && (i & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 DMA request
       if (valu_per_mfma) __builtin_amdgcn_sched_group_barrier(0x002, valu_per_mfma, 0);             // VALU
     }
   };
@@ -497,36 +504,36 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
     // ---- chunk 2u (A stage 0): this superstep's records move to registers ----
     // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier here (hipcc drains the DMAs in flight before a
     // barrier): the wave's own DMAs — A(2u), B(u) — have landed, then everybody's have, and everybody is done with A
-    // stage 1.  (An asm barrier with a "memory" clobber made hipcc keep a memory copy of the 128 accumulator registers
-    // up to date: a scratch store behind every MFMA.)
+    // stage 1.
     __syncthreads();
-    if (c0 + 1 < cend) issue_a(c0 + 1, 1);
     read_b(breg);
     load_af(0, 0, af);
     dequant(breg, std::integral_constant<int, 0>{}, bf0);
     __builtin_amdgcn_sched_barrier(0);
-    // slice 0 multiplies while slice 1 is prepared
+    // slice 0 multiplies while slice 1 is prepared and the next chunk's A image is requested piece by piece
+    // (requested unconditionally: past the last chunk the pieces land in a stage nobody reads — the source offsets stay
+    // inside the buffer descriptor or read as zeros — and the loop body stays one straight-line block to schedule)
+    const bool more1 = c0 + 1 < cend;
     dequant(breg, std::integral_constant<int, 1>{}, bf1);
-    mma(af, bf0, T_{}, 0, 1);
-    interleave(std::integral_constant<int, 2>{}, T_{});
+    mma(af, bf0, T_{}, 0, 1, [&](int mi) { issue_a_piece(c0 + 1, 1, mi); });
+    interleave(std::integral_constant<int, 2>{}, T_{}, T_{});
     __builtin_amdgcn_sched_barrier(0);
     // slice 1 multiplies while slice 2's B fragments are prepared (its A image is behind the next barrier)
     dequant(breg, std::integral_constant<int, 2>{}, bf0);
-    mma(af, bf1, F_{}, 0, 0);
-    interleave(std::integral_constant<int, 2>{}, F_{});
+    mma(af, bf1, F_{}, 0, 0, nothing);
+    interleave(std::integral_constant<int, 2>{}, F_{}, F_{});
     __builtin_amdgcn_sched_barrier(0);
     // ---- chunk 2u + 1 (A stage 1) ----
-    if (c0 + 1 < cend) {
+    if (more1) {
       __syncthreads();  // A(2u + 1) has landed; everybody has copied B(u) and left A stage 0
-      if (c0 + 2 < cend) issue_a(c0 + 2, 0);
       if (u + 1 < uend) issue_b(u + 1);
       load_af(1, 0, af);
       __builtin_amdgcn_sched_barrier(0);
       dequant(breg, std::integral_constant<int, 3>{}, bf1);
-      mma(af, bf0, T_{}, 1, 1);
-      interleave(std::integral_constant<int, 2>{}, T_{});
+      mma(af, bf0, T_{}, 1, 1, [&](int mi) { issue_a_piece(c0 + 2, 0, mi); });
+      interleave(std::integral_constant<int, 2>{}, T_{}, T_{});
       __builtin_amdgcn_sched_barrier(0);
-      mma(af, bf1, F_{}, 0, 0);
+      mma(af, bf1, F_{}, 0, 0, nothing);
     }
   }
 
@@ -603,6 +610,356 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
     }
   }
 }
+
+#ifdef NS_WITH_GEMM3D  // measured slower than gemm3_kernel on every int4 shape (profiles/r02q_gemm3_vs_gemm3d.txt): not built by default
+// ================================================================================================================
+// gemm3d_kernel — gemm3_kernel with a DEEP pipeline, for one workgroup per CU.  gemm3_kernel relies on a second
+// workgroup on the CU to cover its memory latency (each chunk's DMA is issued one chunk ahead): with 256 output tiles
+// on 256 CUs (every 4096-wide GEMM at 2048 rows) a chunk took 1.4 us, 30 % matrix-core utilisation, and splitting K to
+// get the second workgroup costs a reduction pass as long as a third of the GEMM (profiles/r02q).  Here
+//   * eight waves: the four 128 x 64 wave tiles twice, wave group wk multiplying 32-deep slice wk of every 64-deep
+//     chunk (two waves per SIMD from ONE workgroup; the halves are added through LDS at the end);
+//   * four A stages (three for 8-bit codes, whose B stages are twice as large): the DMA of chunk c + 3 is issued while
+//     chunk c is multiplied; two B stages, a superstep's records arrive a chunk before they are needed;
+//   * counted waits: s_waitcnt vmcnt(n) leaves the younger chunks' DMAs in flight across the barrier (raw s_barrier —
+//     __syncthreads() would drain them).  Per wave a chunk's batch is 4 A requests, an odd chunk's batch also the NB
+//     requests of the next superstep's B records; requests retire in order, so before chunk c only the batches younger
+//     than the one that carried A(c) — and, before an odd chunk, B(u + 1) — may still be in flight.
+constexpr int kG3dThreads = 512;
+template <int KIND, int SPS, int SK, bool ASYM>
+__global__ __launch_bounds__(kG3dThreads, 1) void gemm3d_kernel(const Gemm2Params p) {
+  constexpr bool B8 = KIND == WK_INT8;
+  constexpr int NJ = B8 ? 2 : 4;
+  constexpr int RPS = B8 ? 2 : 1;
+  constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
+  constexpr int NS = B8 ? 3 : 4;   // A stages
+  constexpr int D = NS - 1;        // chunks of A in flight ahead of the one being multiplied
+  constexpr int NB = RPS * (2 + (ASYM ? 1 : 0));  // B requests per wave and superstep
+  using Corr = CorrRaw<SPS, SK, ASYM>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char* LdsPtr;
+
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63, nn = l & 15, g = l >> 4;
+  const int wk = w >> 2, wm = (w >> 1) & 1, wn = w & 1;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int bn = xcd * p.cpx + local % p.cpx, bm = local / p.cpx;
+  if (bn >= p.nbn) return;
+  const int tile0 = bn * kG3Tiles + wn * 4, row0 = bm * kG3BM;
+
+  const Rsrc rq = make_rsrc(p.codes, p.codes_bytes);
+  const Rsrc rs = make_rsrc(p.scales, p.scales_bytes);
+  const Rsrc rz = make_rsrc(p.zps, p.zps_bytes);
+  const Rsrc ra = make_rsrc(p.a16, uint32_t(p.m) * uint32_t(p.lda16) * 2u);  // rows >= m read as zeros
+  const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
+
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- A: wave w, request i (0..3) covers rows (4 w + i) * 8 .. + 7 of the 256; same XOR image as gemm3_kernel ----
+  const uint32_t lrow = uint32_t(l >> 3);
+  uint32_t a_voff[2];
+#pragma unroll
+  for (int par = 0; par < 2; par++)
+    a_voff[par] = (uint32_t(row0) + uint32_t(w) * 32u + lrow) * uint32_t(p.lda16) * 2u +
+                  ((uint32_t(l & 7) ^ (uint32_t(4 * par) + uint32_t(l >> 4))) << 4);
+  const uint32_t a_istride = 8u * uint32_t(p.lda16) * 2u;
+  auto issue_a = [&](int c, int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const LdsPtr dst = (LdsPtr)(smem) + stage * kG3StageBytes + (w * 4 + i) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16,
+                                               a_voff[i & 1], uint32_t(c) * (kG3KC * 2) + uint32_t(i) * a_istride, 0, 0);
+    }
+#endif
+  };
+  // this wave multiplies slice wk of a chunk: fragment of row wm * 128 + mi * 16 + nn, piece (4 wk + g) ^ ((nn >> 1) & 7)
+  const uint32_t a_roff = uint32_t(wm * 128 + nn) * 128u + ((uint32_t(4 * wk + g) ^ uint32_t((nn >> 1) & 7)) << 4);
+
+  // ---- B: two stages of {records, scale rows, zero-point rows} of the 8 column tiles; wave w fetches tile w ----
+  constexpr uint32_t kBCodes = kG3Tiles * RPS * 1024u;
+  constexpr uint32_t kBScal = kG3Tiles * RPS * 16u * SBYTES;
+  constexpr uint32_t kBZp = ASYM ? kG3Tiles * RPS * 16u * SPS : 0u;
+  constexpr uint32_t kBStage = kBCodes + kBScal + kBZp;
+  unsigned char* const b_lds0 = smem + NS * kG3StageBytes;
+  const uint32_t btile = uint32_t(bn * kG3Tiles + w);
+  const uint32_t s_voff = btile * uint32_t(p.srows) * p.sstride + uint32_t(l) * 16u;  // lanes < SBYTES
+  const uint32_t z_voff = btile * uint32_t(p.srows) * p.zstride + uint32_t(l) * 16u;  // lanes < SPS
+  auto issue_b = [&](int u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const LdsPtr bs = (LdsPtr)(b_lds0) + (u & 1) * kBStage;
+#pragma unroll
+    for (int r = 0; r < RPS; r++) {
+      const uint32_t s = uint32_t(min(u * RPS + r, p.ksteps - 1));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, reinterpret_cast<__attribute__((address_space(3))) void*>(bs + (w * RPS + r) * 1024), 16,
+                                               uint32_t(l) * 16u, (btile * uint32_t(p.ksteps) + s) * p.qstride, 0, 0);
+      const uint32_t srow = (s * uint32_t(p.srow_mul)) >> p.srow_shift;
+      if (l < SBYTES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, reinterpret_cast<__attribute__((address_space(3))) void*>(bs + kBCodes + (r * kG3Tiles + w) * (16 * SBYTES)),
+                                                 16, s_voff, srow * p.sstride, 0, 0);
+      if constexpr (ASYM) {
+        if (l < SPS)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, reinterpret_cast<__attribute__((address_space(3))) void*>(bs + kBCodes + kBScal + (r * kG3Tiles + w) * (16 * SPS)),
+                                                   16, z_voff, srow * p.zstride, 0, 0);
+      }
+    }
+#endif
+  };
+  // a wave keeps, per column tile, only the words of ITS two slices of the superstep (t = wk and 2 + wk)
+  struct BRec {
+    uint32_t q[4][B8 ? 4 : 2];  // 4-bit: words wk, 2 + wk of the record; 8-bit: words 2 wk, 2 wk + 1 of records 0 and 1
+    Corr c[4][RPS];
+  };
+  auto read_b = [&](int u, BRec& b) {
+    const unsigned char* bs = b_lds0 + (u & 1) * kBStage;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      const int t = wn * 4 + ni;
+#pragma unroll
+      for (int r = 0; r < RPS; r++) {
+        const unsigned char* rec = bs + (t * RPS + r) * 1024 + l * 16;
+        if constexpr (B8) {
+          b.q[ni][2 * r + 0] = reinterpret_cast<const uint32_t*>(rec)[2 * wk];
+          b.q[ni][2 * r + 1] = reinterpret_cast<const uint32_t*>(rec)[2 * wk + 1];
+        } else {
+          b.q[ni][0] = reinterpret_cast<const uint32_t*>(rec)[wk];
+          b.q[ni][1] = reinterpret_cast<const uint32_t*>(rec)[2 + wk];
+        }
+        const unsigned char* sp = bs + kBCodes + ((r * kG3Tiles + t) * 16 + nn) * SBYTES;
+        if constexpr (SBYTES == 16) {
+          const uint4v sv = *reinterpret_cast<const uint4v*>(sp);
+          b.c[ni][r].s[0] = sv.x, b.c[ni][r].s[1] = sv.y, b.c[ni][r].s[2] = sv.z, b.c[ni][r].s[3] = sv.w;
+        } else if constexpr (SBYTES == 8) {
+          b.c[ni][r].s[0] = reinterpret_cast<const uint32_t*>(sp)[0];
+          b.c[ni][r].s[1] = reinterpret_cast<const uint32_t*>(sp)[1];
+        } else if constexpr (SBYTES == 4) {
+          b.c[ni][r].s[0] = *reinterpret_cast<const uint32_t*>(sp);
+        } else {
+          b.c[ni][r].s[0] = *reinterpret_cast<const uint16_t*>(sp);
+        }
+        if constexpr (ASYM) {
+          const unsigned char* zp = bs + kBCodes + kBScal + ((r * kG3Tiles + t) * 16 + nn) * SPS;
+          if constexpr (SPS == 4)
+            b.c[ni][r].z[0] = *reinterpret_cast<const uint32_t*>(zp);
+          else if constexpr (SPS == 2)
+            b.c[ni][r].z[0] = *reinterpret_cast<const uint16_t*>(zp);
+          else
+            b.c[ni][r].z[0] = *zp;
+        }
+      }
+    }
+  };
+  // B fragments of this wave's slice of chunk h (0 / 1) of the superstep in `b`
+  auto dequant = [&](const BRec& b, auto hc, half8_t (&bf)[4]) {
+    constexpr int h = decltype(hc)::value;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      float sc[4], zp[4];
+      corr_decode<SPS, SK, ASYM, NJ>(b.c[ni][B8 ? h : 0], sc, zp);
+      // slice inside its record: 4-bit t = 2 h + wk; 8-bit wk.  wk is wave-uniform but not a compile-time constant:
+      // select with it instead of indexing
+      const float s_sel = B8 ? (wk ? sc[1] : sc[0]) : (wk ? sc[2 * h + 1] : sc[2 * h]);
+      const float z_sel = B8 ? (wk ? zp[1] : zp[0]) : (wk ? zp[2 * h + 1] : zp[2 * h]);
+      half8_t v;
+      if constexpr (KIND == WK_INT4) {
+        const _Float16 zl = (_Float16)(-1032.f - z_sel), zh = (_Float16)(-72.f - z_sel);
+        v = cvt_i4x8(b.q[ni][h], i4c, half2_t{zl, zl}, half2_t{zh, zh});
+      } else if constexpr (KIND == WK_INT8) {
+        const _Float16 zo = (_Float16)(-1152.f - z_sel);
+        v = cvt_i8x8(b.q[ni][2 * h], b.q[ni][2 * h + 1], half2_t{zo, zo});
+      } else {
+        v = cvt_f4x8(b.q[ni][h], p.lut);
+      }
+      const _Float16 sh = (_Float16)(s_sel * p.spre);
+      bf[ni] = v * half8_t{sh, sh, sh, sh, sh, sh, sh, sh};
+    }
+  };
+  auto load_af = [&](int stage, half8_t (&af)[8]) {
+    const unsigned char* a_lds = smem + stage * kG3StageBytes + a_roff;
+#pragma unroll
+    for (int mi = 0; mi < 8; mi++) af[mi] = *reinterpret_cast<const half8_t*>(a_lds + mi * (16 * 128));
+  };
+  auto mma = [&](const half8_t (&af)[8], const half8_t (&bf)[4]) {
+#pragma unroll
+    for (int mi = 0; mi < 8; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+  };
+  auto wait_vm = [&](auto nc) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(nc)::value) : "memory"); };
+  using IC0 = std::integral_constant<int, 0>;
+  using IC1 = std::integral_constant<int, 1>;
+
+  // chunk range (split-K: an even number of chunks per split)
+  const int cbeg = p.ksplit > 1 ? int(blockIdx.y) * p.cps : 0;
+  const int cend = p.ksplit > 1 ? min(p.nchunks, cbeg + p.cps) : p.nchunks;
+  const int ubeg = cbeg >> 1, uend = (cend + 1) >> 1;
+
+  // ---- prologue: B(first), A(first D chunks); then the first superstep's B is read after a full drain ----
+  issue_b(ubeg);
+#pragma unroll
+  for (int d = 0; d < D; d++)
+    if (cbeg + d < cend) issue_a(cbeg + d, d % NS);
+  BRec bcur, bnxt;
+  half8_t af[8], bfa[4], bfb[4];
+  wait_vm(IC0{});
+  asm volatile("s_barrier" ::: "memory");
+  read_b(ubeg, bcur);
+  if (ubeg + 1 < uend) issue_b(ubeg + 1);  // in the steady state B(u + 1) is issued at the top of chunk 2u - 1
+  dequant(bcur, IC0{}, bfa);
+  if (p.diag >= 5) {  // diagnostics: operands that no longer come from LDS / the dequantiser
+    dequant(bcur, IC1{}, bfb);
+    load_af(0, af);
+  }
+  // The B fragments of a chunk are always prepared during the MFMAs of the chunk before it (bfa: even chunks, bfb: odd
+  // chunks), so that behind a barrier only the A fragment reads stand in front of the matrix cores; the scheduler is
+  // asked to put the fragment reads first and then to alternate MFMAs with the dequantisation's VALU work.
+  auto interleave = [&]() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the 8 A fragment reads
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // up to 3 VALU
+    }
+  };
+  // from here on, at the top of chunk c the batches in flight are those issued at the tops of chunks c - 1, c - 2, ...
+  for (int u = ubeg; u < uend; u++) {
+    const int c0 = 2 * u;
+    // ================= even chunk c0 =================
+    {
+      const int c = c0;
+      if (c > cbeg) {
+        // A(c) came with the batch of chunk c - D; younger batches: chunk c - 1 (odd: 4 + NB) [and c - 2 (even: 4) when D = 3]
+        if (c + D + 2 >= cend) wait_vm(IC0{});  // the last chunks: the younger batches are no longer full ones
+        else if constexpr (D == 3) wait_vm(std::integral_constant<int, 8 + NB>{});
+        else wait_vm(std::integral_constant<int, 4 + NB>{});
+        if (p.diag != 7) asm volatile("s_barrier" ::: "memory");
+      }
+      if (c + D < cend && p.diag < 4) issue_a(c + D, (c - cbeg + D) % NS);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p.diag != 3) {
+        if (p.diag < 6) load_af((c - cbeg) % NS, af);
+        if (p.diag < 5) dequant(bcur, IC1{}, bfb);  // for the odd chunk of this superstep
+        mma(af, bfa);
+        interleave();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ================= odd chunk c0 + 1 =================
+    if (c0 + 1 < cend) {
+      const int c = c0 + 1;
+      // A(c) and B(u + 1) (batch of chunk c - 2) must have landed; younger: the batch of chunk c - 1 (even: 4 requests)
+      if (c + D + 2 >= cend) wait_vm(IC0{});
+      else wait_vm(std::integral_constant<int, 4>{});
+      if (p.diag != 7) asm volatile("s_barrier" ::: "memory");
+      if (c + D < cend && p.diag < 4) issue_a(c + D, (c - cbeg + D) % NS);
+      if (u + 2 < uend && p.diag < 4) issue_b(u + 2);
+      if (u + 1 < uend) read_b(u + 1, bnxt);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p.diag != 3) {
+        if (p.diag < 6) load_af((c - cbeg) % NS, af);
+        if (u + 1 < uend && p.diag < 5) dequant(bnxt, IC0{}, bfa);  // for the even chunk of the next superstep
+        mma(af, bfb);
+        interleave();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bcur = bnxt;
+    }
+  }
+
+  // ---- the two slice halves are added through LDS: wave group 1 parks its accumulators, group 0 adds them ----
+  __syncthreads();
+  {
+    floatx4* park4 = reinterpret_cast<floatx4*>(smem) + (w & 3) * (32 * 64) + l;
+    if (wk == 1) {
+#pragma unroll
+      for (int mi = 0; mi < 8; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) park4[(mi * 4 + ni) * 64] = acc[mi][ni];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 8; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) acc[mi][ni] += park4[(mi * 4 + ni) * 64];
+    }
+    __syncthreads();
+  }
+  if (wk != 0) return;
+
+  // ---- epilogue of wave group 0: through LDS in whole rows (see gemm3_kernel) ----
+  constexpr int kRowF = 68;
+  float* park = reinterpret_cast<float*>(smem) + w * (64 * kRowF);
+  const int colw = tile0 * 16;
+  const bool vec4 = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.c) & 15) == 0 && colw + 64 <= p.n &&
+                    (p.ksplit > 1 ? (p.n & 3) == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 : true) &&
+                    (!p.d || ((p.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(p.d) & 15) == 0)) &&
+                    (!p.c16 || (reinterpret_cast<uintptr_t>(p.c16) & 7) == 0);
+  const int epi = p.epilogue;
+  auto finish = [&](float v, float dv) {
+    switch (epi) {
+      case 1: return v + dv;
+      case 2: return v * dv;
+      case 3: return epi_gelu(v + dv);
+      case 4: return epi_gelu(v);
+      case 5: return epi_silu(v);
+      default: return v;
+    }
+  };
+#pragma unroll
+  for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+      for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) park[(mi * 16 + 4 * g + r) * kRowF + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * p.spost;
+    const int rbase = row0 + wm * 128 + hh * 64;
+    if (p.diag == 1) continue;
+    if (vec4) {
+      for (int it = 0; it < 16; it++) {
+        const int rl = it * 4 + (l >> 4), row = rbase + rl, col = colw + (l & 15) * 4;
+        if (row >= p.m) continue;
+        float4 v = *reinterpret_cast<const float4*>(park + rl * kRowF + (l & 15) * 4);
+        if (p.ksplit > 1) {
+          *reinterpret_cast<float4*>(p.part + (size_t(blockIdx.y) * p.m + row) * p.n + col) = v;
+          continue;
+        }
+        float4 dv = {0.f, 0.f, 0.f, 0.f};
+        if (p.d && epi >= 1 && epi <= 3) dv = *reinterpret_cast<const float4*>(p.d + size_t(row) * p.ldd + col);
+        v = float4{finish(v.x, dv.x), finish(v.y, dv.y), finish(v.z, dv.z), finish(v.w, dv.w)};
+        *reinterpret_cast<float4*>(p.c + size_t(row) * p.ldc + col) = v;
+        if (p.c16) {
+          typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<half4_t*>(p.c16 + size_t(row) * p.ldc + col) =
+              half4_t{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        }
+      }
+    } else {
+      for (int it = 0; it < 64; it++) {
+        const int row = rbase + it, col = colw + l;
+        if (row >= p.m || col >= p.n) continue;
+        float v = park[it * kRowF + l];
+        if (p.ksplit > 1) {
+          p.part[(size_t(blockIdx.y) * p.m + row) * p.n + col] = v;
+          continue;
+        }
+        const float dv = (p.d && epi >= 1 && epi <= 3) ? p.d[size_t(row) * p.ldd + col] : 0.f;
+        v = finish(v, dv);
+        p.c[size_t(row) * p.ldc + col] = v;
+        if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
+      }
+    }
+  }
+}
+
+#endif  // NS_WITH_GEMM3D
 
 // split-K tail: C = epilogue(sum over the K splits, in split order -> deterministic)
 __global__ void gemm2_reduce_kernel(const Gemm2Params p) {
@@ -762,8 +1119,46 @@ static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hip
     return go(gemm3_kernel<KIND, SPS, SK, false>);
   }
 }
+#ifdef NS_WITH_GEMM3D
+template <int KIND, int SPS, int SK>
+static hipError_t launch_gemm3d_k(const Gemm2Params& p, bool asym, dim3 grid, hipStream_t st) {
+  constexpr int rps = KIND == WK_INT8 ? 2 : 1;
+  constexpr int ns = KIND == WK_INT8 ? 3 : 4;
+  constexpr int sbytes = SPS * (SK == SK_F32 ? 4 : 2);
+  const size_t ldsd = size_t(ns) * kG3StageBytes + 2 * size_t(kG3Tiles) * rps * (1024 + 16 * sbytes + (asym ? 16 * SPS : 0));
+  auto go = [&](auto kern) {
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(kern, grid, dim3(kG3dThreads), ldsd, st, p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && p.ksplit > 1) {
+      const size_t total = size_t(p.m) * p.n;
+      hipLaunchKernelGGL(gemm2_reduce_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, p);
+      e = hipGetLastError();
+    }
+    return e;
+  };
+  if constexpr (KIND == WK_F4) {
+    (void)asym;
+    return go(gemm3d_kernel<KIND, SPS, SK, false>);
+  } else {
+    if (asym) return go(gemm3d_kernel<KIND, SPS, SK, true>);
+    return go(gemm3d_kernel<KIND, SPS, SK, false>);
+  }
+}
+#endif
 template <int KIND, int SPS>
-static hipError_t launch_gemm3_s(const Gemm2Params& p, uint32_t scale_dt, bool asym, dim3 grid, hipStream_t st) {
+static hipError_t launch_gemm3_s(const Gemm2Params& p, uint32_t scale_dt, bool asym, dim3 grid, hipStream_t st, bool deep) {
+#ifdef NS_WITH_GEMM3D
+  if (deep) {
+    if (scale_dt == DT_F32) return launch_gemm3d_k<KIND, SPS, SK_F32>(p, asym, grid, st);
+    if (scale_dt == DT_F16) return launch_gemm3d_k<KIND, SPS, SK_F16>(p, asym, grid, st);
+    return launch_gemm3d_k<KIND, SPS, SK_BF16>(p, asym, grid, st);
+  }
+#else
+  (void)deep;
+#endif
   if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32>(p, asym, grid, st);
   if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16>(p, asym, grid, st);
   return launch_gemm3_k<KIND, SPS, SK_BF16>(p, asym, grid, st);
@@ -837,7 +1232,9 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   p.cpx = (p.nbn + 7) / 8;
   // third-generation kernel (256-row tiles, A by LDS DMA, B dequantised in registers): from 192 rows up; below that
   // its row tile would be mostly padding.  NS_GEMM3=0 keeps the second generation (diagnostics / A-B runs).
-  static const bool g3_off = getenv("NS_GEMM3") != nullptr && atoi(getenv("NS_GEMM3")) == 0;
+  static const int g3_mode = getenv("NS_GEMM3") ? atoi(getenv("NS_GEMM3")) : 1;  // 0: gemm2, 1: gemm3, 2: gemm3d (NS_WITH_GEMM3D builds)
+  const bool g3_off = g3_mode == 0;
+  const bool deep = g3_mode == 2;
   if (!g3_off && a.m >= 192 && (p.lda16 & 7) == 0) {
     const int nbm3 = (a.m + kG3BM - 1) / kG3BM;
     p.ksplit = 1;
@@ -846,7 +1243,8 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
       static const bool no_splitk = getenv("NS_NO_SPLITK") != nullptr;  // diagnostics
       const int tiles = p.nbn * nbm3;
       int ks = 1;
-      while (ks < 8 && tiles * ks * 2 <= 512 && p.nchunks / (ks * 2) >= 8) ks *= 2;
+      // gemm3_kernel wants two workgroups per CU, the deep kernel one
+      while (ks < 8 && tiles * ks * 2 <= (deep ? 256 : 512) && p.nchunks / (ks * 2) >= 8) ks *= 2;
       if (ks > 1 && !no_splitk) {
         const size_t bytes = size_t(ks) * a.m * w0->n * 4;
         float* part = static_cast<float*>(stream_scratch(st, bytes, 2));
@@ -860,15 +1258,15 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
     const dim3 grid3(unsigned(8 * p.cpx * nbm3), unsigned(p.ksplit));
 #define NS_G3DISPATCH(KIND)                                                           \
   switch (w0->sps) {                                                                  \
-    case 4: return launch_gemm3_s<KIND, 4>(p, w0->scale_dt, w0->asym, grid3, st);     \
-    case 2: return launch_gemm3_s<KIND, 2>(p, w0->scale_dt, w0->asym, grid3, st);     \
-    default: return launch_gemm3_s<KIND, 1>(p, w0->scale_dt, w0->asym, grid3, st);    \
+    case 4: return launch_gemm3_s<KIND, 4>(p, w0->scale_dt, w0->asym, grid3, st, deep);     \
+    case 2: return launch_gemm3_s<KIND, 2>(p, w0->scale_dt, w0->asym, grid3, st, deep);     \
+    default: return launch_gemm3_s<KIND, 1>(p, w0->scale_dt, w0->asym, grid3, st, deep);    \
   }
     if (w0->kind == WK_INT4) {
       NS_G3DISPATCH(WK_INT4)
     } else if (w0->kind == WK_INT8) {
-      if (w0->sps == 2) return launch_gemm3_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, grid3, st);
-      return launch_gemm3_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, grid3, st);
+      if (w0->sps == 2) return launch_gemm3_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, grid3, st, deep);
+      return launch_gemm3_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, grid3, st, deep);
     } else {
       NS_G3DISPATCH(WK_F4)
     }
