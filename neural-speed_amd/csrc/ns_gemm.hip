@@ -68,6 +68,7 @@ struct Gemm2Params {
                       // to fp16 and the accumulators by spost on the way out, so that weights with very small or very
                       // large magnitudes stay inside fp16's normal range (1, 1 for ordinary LLM weights)
   F4Lut lut;
+  int bm3;   // gemm3_kernel: rows of the workgroup tile (256 / 128)
   int diag;  // NS_G3_DIAG (diagnostics): 1 = skip the output stores, 2 = skip the main loop, 3 = DMA and barriers only, 4 = no DMA
 };
 
@@ -292,8 +293,14 @@ constexpr int kG3StageBytes = kG3BM * kG3KC * 2;  // 32 KiB
 constexpr int kG3Stages = 2;
 constexpr int kG3BStageMax = 8 * 2 * 1024 + 8 * 2 * 16 * 16 + 8 * 2 * 16 * 4;  // B stage upper bound: codes + scale rows + zero points
 
-template <int KIND, int SPS, int SK, bool ASYM>
+// BM: rows of the workgroup tile.  256: waves 2 (rows) x 2 (columns), wave tile 128 x 64.  128: waves 1 x 4, wave tile 128 x 32
+// — the same MFMA : dequantisation ratio, half the A stage (three workgroups per CU), twice the tiles: for outputs with
+// few tiles (4096 wide at 2048 rows: 256 of the tall tiles, one per CU) instead of a K split and its reduction pass.
+template <int KIND, int SPS, int SK, bool ASYM, int BM>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
+  constexpr int NIW = BM == 256 ? 4 : 2;        // column tiles (16 wide) per wave
+  constexpr int APW = BM / 32;                   // A DMA pieces (8 rows each) per wave and chunk
+  constexpr int kStage = BM * kG3KC * 2;         // bytes of one A stage
   constexpr bool B8 = KIND == WK_INT8;          // 8-bit codes: a record is 64 deep, two per 128-deep superstep
   constexpr int NJ = B8 ? 2 : 4;                // 32-deep slices per record
   constexpr int RPS = B8 ? 2 : 1;               // records per superstep (128 deep = chunks 2u, 2u + 1)
@@ -305,11 +312,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, nn = l & 15, g = l >> 4;
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = BM == 256 ? (w >> 1) : 0, wn = BM == 256 ? (w & 1) : w;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int bn = xcd * p.cpx + local % p.cpx, bm = local / p.cpx;
   if (bn >= p.nbn) return;
-  const int tile0 = bn * kG3Tiles + wn * 4, row0 = bm * kG3BM;
+  const int tile0 = bn * kG3Tiles + wn * NIW, row0 = bm * BM;
 
   const Rsrc rq = make_rsrc(p.codes, p.codes_bytes);
   const Rsrc rs = make_rsrc(p.scales, p.scales_bytes);
@@ -317,11 +324,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const Rsrc ra = make_rsrc(p.a16, uint32_t(p.m) * uint32_t(p.lda16) * 2u);  // rows >= m read as zeros
   const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
-  floatx4 acc[8][4];
+  floatx4 acc[8][NIW];
 #pragma unroll
   for (int mi = 0; mi < 8; mi++)
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NIW; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   // ---- A: DMA of chunk c into a stage.  Wave w, request i covers rows (8 w + i) * 8 .. + 7; lane l writes LDS piece
   //      l & 7 of row l >> 3 of them and therefore FETCHES piece (l & 7) ^ ((row >> 1) & 7) ----
@@ -329,19 +336,19 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   uint32_t a_voff[2];  // (row >> 1) & 7 = 4 * (i & 1) + (l >> 4): two per-lane source offsets, for even and odd i
 #pragma unroll
   for (int par = 0; par < 2; par++)
-    a_voff[par] = (uint32_t(row0) + uint32_t(w) * 64u + lrow) * uint32_t(p.lda16) * 2u +
+    a_voff[par] = (uint32_t(row0) + uint32_t(w) * uint32_t(APW * 8) + lrow) * uint32_t(p.lda16) * 2u +
                   ((uint32_t(l & 7) ^ (uint32_t(4 * par) + uint32_t(l >> 4))) << 4);
   const uint32_t a_istride = 8u * uint32_t(p.lda16) * 2u;  // source bytes between consecutive requests of a wave
   auto issue_a_piece = [&](int c, int stage, int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const LdsPtr dst = (LdsPtr)(smem) + stage * kG3StageBytes + (w * 8 + i) * 1024;
+    const LdsPtr dst = (LdsPtr)(smem) + stage * kStage + (w * APW + i) * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16,
                                              a_voff[i & 1], uint32_t(c) * (kG3KC * 2) + uint32_t(i) * a_istride, 0, 0);
 #endif
   };
   auto issue_a = [&](int c, int stage) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) issue_a_piece(c, stage, i);
+    for (int i = 0; i < APW; i++) issue_a_piece(c, stage, i);
   };
   // fragment read offsets of this lane: row wm * 128 + mi * 16 + nn, piece (4 jj + g) ^ ((nn >> 1) & 7)
   uint32_t a_roff[2];
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   constexpr uint32_t kBCodes = kG3Tiles * RPS * 1024u;         // [tile][record][64 lanes x 16 B]
   constexpr uint32_t kBScal = kG3Tiles * RPS * 16u * SBYTES;   // [record][tile][16 columns x SBYTES]
   constexpr uint32_t kBZp = ASYM ? kG3Tiles * RPS * 16u * SPS : 0u;
-  unsigned char* const b_lds = smem + kG3Stages * kG3StageBytes;
+  unsigned char* const b_lds = smem + kG3Stages * kStage;
   const uint32_t btile0 = uint32_t(bn * kG3Tiles + 2 * w);
   // scale rows: 16 * SBYTES bytes per (tile, row) = SBYTES lanes of 16 B; lanes [0, 2 * SBYTES) cover the wave's two tiles
   const uint32_t s_lane_tile = uint32_t(l) / uint32_t(SBYTES), s_lane_piece = uint32_t(l) % uint32_t(SBYTES);
@@ -392,14 +399,14 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
 #endif
   };
   struct BRec {
-    uint32_t q[4][4 * RPS];
-    Corr c[4][RPS];
+    uint32_t q[NIW][4 * RPS];
+    Corr c[NIW][RPS];
   };
   // LDS -> registers: this wave's four column tiles (wn * 4 + ni)
   auto read_b = [&](BRec& b) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++) {
-      const int t = wn * 4 + ni;
+    for (int ni = 0; ni < NIW; ni++) {
+      const int t = wn * NIW + ni;
 #pragma unroll
       for (int r = 0; r < RPS; r++) {
         const uint4v v = *reinterpret_cast<const uint4v*>(b_lds + (t * RPS + r) * 1024 + l * 16);
@@ -430,11 +437,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   };
 
   // B fragments of 32-deep slice t (0..3) of the superstep held in `b`: codes -> fp16 (code - zp) * scale
-  auto dequant = [&](const BRec& b, auto tc, half8_t (&bf)[4]) {
+  auto dequant = [&](const BRec& b, auto tc, half8_t (&bf)[NIW]) {
     constexpr int t = decltype(tc)::value;
     constexpr int h = t >> 1, jj = t & 1;
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++) {
+    for (int ni = 0; ni < NIW; ni++) {
       // 4-bit: word t of the one record; 8-bit: record h, words 2 jj, 2 jj + 1
       float sc[4], zp[4];
       corr_decode<SPS, SK, ASYM, NJ>(b.c[ni][B8 ? h : 0], sc, zp);
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
     }
   };
   auto load_af = [&](int stage, int jj, half8_t (&af)[8]) {
-    const unsigned char* a_lds = smem + stage * kG3StageBytes + a_roff[jj];
+    const unsigned char* a_lds = smem + stage * kStage + a_roff[jj];
 #pragma unroll
     for (int mi = 0; mi < 8; mi++) af[mi] = *reinterpret_cast<const half8_t*>(a_lds + mi * (16 * 128));
   };
@@ -463,12 +470,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   // `after(mi)`: hook behind the four MFMAs of fragment row mi — the DMA requests of the next chunk are issued there,
   // one per row, instead of in a burst behind the barrier (a request costs ~60 cycles of issue among MFMAs, 100-185 in a
   // phase that already carries fragment reads, MI355X_MICROARCH.md; 8 of them in front of the MFMAs stall every wave)
-  auto mma = [&](half8_t (&af)[8], const half8_t (&bf)[4], auto reload, int stage, int jj, auto&& after) {
-    const unsigned char* nxt = smem + stage * kG3StageBytes + a_roff[jj];
+  auto mma = [&](half8_t (&af)[8], const half8_t (&bf)[NIW], auto reload, int stage, int jj, auto&& after) {
+    const unsigned char* nxt = smem + stage * kStage + a_roff[jj];
 #pragma unroll
     for (int mi = 0; mi < 8; mi++) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ni++)
+      for (int ni = 0; ni < NIW; ni++)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
       if constexpr (decltype(reload)::value) af[mi] = *reinterpret_cast<const half8_t*>(nxt + mi * (16 * 128));
       after(mi);
@@ -480,10 +487,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   auto interleave = [&](auto vpm, auto ds, auto dma) {
     constexpr int valu_per_mfma = decltype(vpm)::value;
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
+    for (int i = 0; i < 8 * NIW; i++) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            // 1 MFMA
-      if (decltype(ds)::value && (i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
-      if (decltype(dma)::value && (i & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 DMA request
+      if (decltype(ds)::value && (i & (NIW - 1)) == NIW - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
+      if (decltype(dma)::value && (i & (NIW - 1)) == 1 && i / NIW < APW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 DMA request
       if (valu_per_mfma) __builtin_amdgcn_sched_group_barrier(0x002, valu_per_mfma, 0);             // VALU
     }
   };
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const int ubeg = cbeg >> 1, uend = (cend + 1) >> 1;
 
   BRec breg;
-  half8_t af[8], bf0[4], bf1[4];
+  half8_t af[8], bf0[NIW], bf1[NIW];
   issue_a(cbeg, 0);
   issue_b(ubeg);
   for (int u = ubeg; u < (p.diag == 2 ? ubeg + 1 : uend); u++) {
@@ -515,7 +522,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
     // inside the buffer descriptor or read as zeros — and the loop body stays one straight-line block to schedule)
     const bool more1 = c0 + 1 < cend;
     dequant(breg, std::integral_constant<int, 1>{}, bf1);
-    mma(af, bf0, T_{}, 0, 1, [&](int mi) { issue_a_piece(c0 + 1, 1, mi); });
+    mma(af, bf0, T_{}, 0, 1, [&](int mi) {
+      if (mi < APW) issue_a_piece(c0 + 1, 1, mi);
+    });
     interleave(std::integral_constant<int, 2>{}, T_{}, T_{});
     __builtin_amdgcn_sched_barrier(0);
     // slice 1 multiplies while slice 2's B fragments are prepared (its A image is behind the next barrier)
@@ -530,7 +539,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
       load_af(1, 0, af);
       __builtin_amdgcn_sched_barrier(0);
       dequant(breg, std::integral_constant<int, 3>{}, bf1);
-      mma(af, bf0, T_{}, 1, 1, [&](int mi) { issue_a_piece(c0 + 2, 0, mi); });
+      mma(af, bf0, T_{}, 1, 1, [&](int mi) {
+        if (mi < APW) issue_a_piece(c0 + 2, 0, mi);
+      });
       interleave(std::integral_constant<int, 2>{}, T_{}, T_{});
       __builtin_amdgcn_sched_barrier(0);
       mma(af, bf1, F_{}, 0, 0, nothing);
@@ -544,10 +555,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   //      back as float4 along the rows and stores 256-byte runs; the operator is applied on the way out, in a plain loop
   //      (nothing below indexes the accumulators dynamically — with the switch inside the unrolled accumulator loops hipcc
   //      kept all 128 accumulator registers in scratch memory, a store behind every MFMA of the main loop). ----
-  constexpr int kRowF = 68;  // floats per parked row
+  constexpr int kCols = NIW * 16;     // columns of the wave tile
+  constexpr int kRowF = kCols + 4;    // floats per parked row
+  constexpr int kLpr = kCols / 4;     // lanes per row in the float4 read-back
   float* park = reinterpret_cast<float*>(smem) + w * (64 * kRowF);
   const int colw = tile0 * 16;  // first column of this wave's 64
-  const bool vec4 = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.c) & 15) == 0 && colw + 64 <= p.n &&
+  const bool vec4 = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.c) & 15) == 0 && colw + kCols <= p.n &&
                     (p.ksplit > 1 ? (p.n & 3) == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 : true) &&
                     (!p.d || ((p.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(p.d) & 15) == 0)) &&
                     (!p.c16 || (reinterpret_cast<uintptr_t>(p.c16) & 7) == 0);
@@ -568,17 +581,17 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
 #pragma unroll
     for (int mi = 0; mi < 4; mi++)
 #pragma unroll
-      for (int ni = 0; ni < 4; ni++)
+      for (int ni = 0; ni < NIW; ni++)
 #pragma unroll
         for (int r = 0; r < 4; r++) park[(mi * 16 + 4 * g + r) * kRowF + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * p.spost;
     // (LDS operations of one wave complete in order: no barrier between its own writes and reads)
     const int rbase = row0 + wm * 128 + hh * 64;
     if (p.diag == 1) continue;
     if (vec4) {
-      for (int it = 0; it < 16; it++) {
-        const int rl = it * 4 + (l >> 4), row = rbase + rl, col = colw + (l & 15) * 4;
+      for (int it = 0; it < kLpr; it++) {
+        const int rl = it * (64 / kLpr) + l / kLpr, row = rbase + rl, col = colw + (l % kLpr) * 4;
         if (row >= p.m) continue;
-        float4 v = *reinterpret_cast<const float4*>(park + rl * kRowF + (l & 15) * 4);
+        float4 v = *reinterpret_cast<const float4*>(park + rl * kRowF + (l % kLpr) * 4);
         if (p.ksplit > 1) {  // raw partial; the operator is applied by gemm2_reduce_kernel
           *reinterpret_cast<float4*>(p.part + (size_t(blockIdx.y) * p.m + row) * p.n + col) = v;
           continue;
@@ -594,10 +607,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
         }
       }
     } else {
-      for (int it = 0; it < 64; it++) {  // one row per step, lane = column
-        const int row = rbase + it, col = colw + l;
+      for (int it = 0; it < 64 * kCols / 64; it++) {  // 64 elements per step, row-major over the 64 x kCols half tile
+        const int e = it * 64 + l, rl = e / kCols, cl = e % kCols;
+        const int row = rbase + rl, col = colw + cl;
         if (row >= p.m || col >= p.n) continue;
-        float v = park[it * kRowF + l];
+        float v = park[rl * kRowF + cl];
         if (p.ksplit > 1) {
           p.part[(size_t(blockIdx.y) * p.m + row) * p.n + col] = v;
           continue;
@@ -1092,12 +1106,12 @@ static hipError_t launch_gemm2_k(const Gemm2Params& p, bool asym, dim3 grid, siz
     return go(gemm2_kernel<KIND, SPS, SK, false>);
   }
 }
-template <int KIND, int SPS, int SK>
+template <int KIND, int SPS, int SK, int BM>
 static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hipStream_t st) {
   // A stages + the B stage of this format: records, scale rows, zero-point rows of 8 column tiles for one superstep
   constexpr int rps = KIND == WK_INT8 ? 2 : 1;
   constexpr int sbytes = SPS * (SK == SK_F32 ? 4 : 2);
-  const size_t lds3 = size_t(kG3Stages) * kG3StageBytes + size_t(kG3Tiles) * rps * (1024 + 16 * sbytes + (asym ? 16 * SPS : 0));
+  const size_t lds3 = size_t(kG3Stages) * BM * kG3KC * 2 + size_t(kG3Tiles) * rps * (1024 + 16 * sbytes + (asym ? 16 * SPS : 0));
   auto go = [&](auto kern) {
     static const hipError_t attr =
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(kG3Stages * kG3StageBytes + kG3BStageMax));
@@ -1113,10 +1127,10 @@ static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hip
   };
   if constexpr (KIND == WK_F4) {
     (void)asym;
-    return go(gemm3_kernel<KIND, SPS, SK, false>);
+    return go(gemm3_kernel<KIND, SPS, SK, false, BM>);
   } else {
-    if (asym) return go(gemm3_kernel<KIND, SPS, SK, true>);
-    return go(gemm3_kernel<KIND, SPS, SK, false>);
+    if (asym) return go(gemm3_kernel<KIND, SPS, SK, true, BM>);
+    return go(gemm3_kernel<KIND, SPS, SK, false, BM>);
   }
 }
 #ifdef NS_WITH_GEMM3D
@@ -1159,9 +1173,14 @@ static hipError_t launch_gemm3_s(const Gemm2Params& p, uint32_t scale_dt, bool a
 #else
   (void)deep;
 #endif
-  if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32>(p, asym, grid, st);
-  if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16>(p, asym, grid, st);
-  return launch_gemm3_k<KIND, SPS, SK_BF16>(p, asym, grid, st);
+  if (p.bm3 == 128) {
+    if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 128>(p, asym, grid, st);
+    if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 128>(p, asym, grid, st);
+    return launch_gemm3_k<KIND, SPS, SK_BF16, 128>(p, asym, grid, st);
+  }
+  if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 256>(p, asym, grid, st);
+  if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 256>(p, asym, grid, st);
+  return launch_gemm3_k<KIND, SPS, SK_BF16, 256>(p, asym, grid, st);
 }
 
 template <int KIND, int SPS>
@@ -1236,7 +1255,14 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   const bool g3_off = g3_mode == 0;
   const bool deep = g3_mode == 2;
   if (!g3_off && a.m >= 192 && (p.lda16 & 7) == 0) {
-    const int nbm3 = (a.m + kG3BM - 1) / kG3BM;
+    // 128-row tiles (three workgroups per CU hide each other's barrier / dequantisation / output phases) unless the
+    // output has so many tiles that the tall ones' halved A traffic wins (profiles/r02r_gemm3_bm.txt: at 2048 rows equal
+    // or better up to 11008 columns, 7 % worse at 32000)
+    static const int bm_env = getenv("NS_G3_BM") ? atoi(getenv("NS_G3_BM")) : 0;  // diagnostics
+    const int tall_tiles = p.nbn * ((a.m + 255) / 256);
+    p.bm3 = bm_env == 128 || bm_env == 256 ? bm_env : (tall_tiles >= 1024 && w0->kind != WK_INT8 ? 256 : 128);  // 8-bit codes: the tall tile's LDS
+                                                                                            // footprint (81 KiB) leaves one workgroup per CU
+    const int nbm3 = (a.m + p.bm3 - 1) / p.bm3;
     p.ksplit = 1;
     p.cps = p.nchunks;
     {
