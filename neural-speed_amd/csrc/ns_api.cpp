@@ -39,8 +39,11 @@ int g_pack_core = NS_CORE_AUTO;
 struct CacheEntry {
   ns_weight* w;
   uint64_t fingerprint;
+  uint64_t last_use;  // g_cache_tick at the last hit: the eviction order when NS_CACHE_MAX_BYTES caps the cache
 };
 std::unordered_map<const void*, CacheEntry> g_cache;  // host blob pointer -> device weight (part-1 API)
+uint64_t g_cache_tick = 0;
+size_t g_cache_bytes = 0;
 
 struct Scratch {  // growable device scratch for the host-pointer API
   void* p = nullptr;
@@ -361,12 +364,29 @@ ns_weight* cached_weight(const void* blob) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_cache.find(blob);
   if (it != g_cache.end()) {
-    if (it->second.fingerprint == fp) return it->second.w;
+    if (it->second.fingerprint == fp) {
+      it->second.last_use = ++g_cache_tick;
+      return it->second.w;
+    }
+    g_cache_bytes -= std::min(g_cache_bytes, it->second.w->alloc_bytes);
     ns_hip_weight_free(it->second.w);  // the address now holds a different blob
     g_cache.erase(it);
   }
   ns_weight* w = ns_hip_weight_from_blob(blob, nullptr);
-  if (w) g_cache[blob] = CacheEntry{w, fp};
+  if (!w) return nullptr;
+  // optional cap (NS_CACHE_MAX_BYTES, default unlimited: a model's weights are a fixed set): least recently used
+  // device copies go first.  Host entry points are serialised (g_host_mu), so no evicted weight is in use.
+  static const size_t cap = getenv("NS_CACHE_MAX_BYTES") ? strtoull(getenv("NS_CACHE_MAX_BYTES"), nullptr, 10) : 0;
+  g_cache_bytes += w->alloc_bytes;
+  while (cap && g_cache_bytes > cap && !g_cache.empty()) {
+    auto victim = g_cache.begin();
+    for (auto jt = g_cache.begin(); jt != g_cache.end(); ++jt)
+      if (jt->second.last_use < victim->second.last_use) victim = jt;
+    g_cache_bytes -= std::min(g_cache_bytes, victim->second.w->alloc_bytes);
+    ns_hip_weight_free(victim->second.w);
+    g_cache.erase(victim);
+  }
+  g_cache[blob] = CacheEntry{w, fp, ++g_cache_tick};
   return w;
 }
 
@@ -500,6 +520,7 @@ void ns_hip_cache_clear(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_cache) ns_hip_weight_free(kv.second.w);
   g_cache.clear();
+  g_cache_bytes = 0;
 }
 
 int ns_hip_device_count(void) {

@@ -119,6 +119,59 @@ int neref_ffn_silu(const float* a, void* b1, size_t s1, void* b2, size_t s2, voi
   return 0;
 }
 
+/* out[m][n] = A[m] . W[ids[m][id]] through the reference's expert-indexed node: ne_mul_mat_id -> NE_OP_MUL_MAT_ID ->
+ * ne_compute_forward_mul_mat_id_q_f32_bestla (ne_layers.c:7783-7916: token rows are grouped per expert in the INIT task,
+ * then ONE bestla_f32f32_forward per (expert, token row)).  ids [m][n_ids] int32. */
+int neref_mul_mat_id(const float* a, void* const* blobs, const size_t* blob_bytes, int n_as, const int32_t* ids, int n_ids,
+                     int id, float* out, int m, int n, int k) {
+  struct ne_init_params ip = {(size_t)m * (k + n + n_ids) * 4 + (64u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  struct ne_init_params ipw = {1u << 20, NULL, true};
+  struct ne_context* wctx = ne_init(ipw);
+  if (!ctx || !wctx || n_as > 8) return -1;
+  struct ne_tensor* as[8];
+  for (int i = 0; i < n_as; i++) as[i] = btla_tensor(wctx, blobs[i], blob_bytes[i], k, n);
+  struct ne_tensor* x = ne_new_tensor_2d(ctx, NE_TYPE_F32, k, m, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(x->data, a, (size_t)m * k * 4);
+  struct ne_tensor* idt = ne_new_tensor_2d(ctx, NE_TYPE_I32, n_ids, m, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(idt->data, ids, (size_t)m * n_ids * 4);
+  struct ne_tensor* y = ne_mul_mat_id(ctx, as, n_as, idt, id, x);
+  run_graph(ctx, y);
+  memcpy(out, y->data, (size_t)m * n * 4);
+  ne_free(ctx);
+  ne_free(wctx);
+  return 0;
+}
+
+/* out[m][d] = FFN(A; gate / down / up of expert ids[0][id]) through ne_mul_id_ffn_silu / _gelu -> NE_OP_MUL_ID_FFN_* ->
+ * ne_compute_forward_ffn_id_* (ne_layers.c:8053-8170): the expert of the FIRST token row serves all rows, the three
+ * weights go to bestla_fusion_FFN_{SiLu,Gelu_Mul}_f32f32_forward.  blobs = gate[0..n_as) , down[..], up[..]. */
+int neref_ffn_id(int gelu, const float* a, void* const* blobs, const size_t* blob_bytes, int n_as, const int32_t* ids,
+                 int n_ids, int id, float* out, int m, int d, int ff) {
+  struct ne_init_params ip = {(size_t)m * (2 * d + 2 * ff + n_ids) * 4 + (64u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  struct ne_init_params ipw = {1u << 20, NULL, true};
+  struct ne_context* wctx = ne_init(ipw);
+  if (!ctx || !wctx || n_as > 8) return -1;
+  struct ne_tensor *gate[8], *down[8], *up[8];
+  for (int i = 0; i < n_as; i++) {
+    gate[i] = btla_tensor(wctx, blobs[i], blob_bytes[i], d, ff);
+    down[i] = btla_tensor(wctx, blobs[n_as + i], blob_bytes[n_as + i], ff, d);
+    up[i] = btla_tensor(wctx, blobs[2 * n_as + i], blob_bytes[2 * n_as + i], d, ff);
+  }
+  struct ne_tensor* x = ne_new_tensor_2d(ctx, NE_TYPE_F32, d, m, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(x->data, a, (size_t)m * d * 4);
+  struct ne_tensor* idt = ne_new_tensor_2d(ctx, NE_TYPE_I32, n_ids, m, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(idt->data, ids, (size_t)m * n_ids * 4);
+  struct ne_tensor* y = gelu ? ne_mul_id_ffn_gelu(ctx, down, gate, up, n_as, idt, id, x)
+                             : ne_mul_id_ffn_silu(ctx, down, gate, up, n_as, idt, id, x);
+  run_graph(ctx, y);
+  memcpy(out, y->data, (size_t)m * d * 4);
+  ne_free(ctx);
+  ne_free(wctx);
+  return 0;
+}
+
 /* Attention as the reference's model graphs spell it when the fused kernel is not used (models/llama/llama.cpp non-fused
  * branch): KQ = mul_mat(K, Q) -> scale -> diag_mask_inf(n_past) -> soft_max -> mul_mat(V^T, P).  fp32 tensors throughout
  * (the caller passes fp16-representable K / V values), GQA through mul_mat's broadcast (head / (heads / heads_kv)).

@@ -177,6 +177,8 @@ def neref(product_lib_path=None):
         _neref.neref_flash_attn.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, f, C.c_uint]
         _neref.neref_fused.argtypes = [i, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, i, i, i]
         _neref.neref_decoder_layer.argtypes = [vp, vp, i, i, i, i, f, f, vp, vp] + [vp, C.c_size_t] * 7
+        _neref.neref_mul_mat_id.argtypes = [vp, vp, vp, i, vp, i, i, vp, i, i, i]
+        _neref.neref_ffn_id.argtypes = [i, vp, vp, vp, i, vp, i, i, vp, i, i, i]
         _neref.neref_attn_unfused.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, i]
     elif product_lib_path and _neref.provider != product_lib_path:
         raise RuntimeError("libne_ref.so is already loaded without (or with another) bestla_* provider")
@@ -387,6 +389,36 @@ def gemv_u8s8(a, blob, nthreads=0):
     c = np.zeros((m, bi.n), np.float32)
     assert lib().nso_gemv_u8s8_f32(ptr(a), a.shape[1], ptr(blob), ptr(c), bi.n, m, nthreads) == 0
     return c
+
+
+def _blob_table(blobs):
+    ptrs = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
+    sizes = (C.c_size_t * len(blobs))(*[b.size for b in blobs])
+    return ptrs, sizes
+
+
+def neref_mul_mat_id(a, blobs, ids, id_):
+    """the reference's ne_mul_mat_id node over BTLA expert weights; a [m][k] fp32, ids [m][n_ids] int32"""
+    a = np.ascontiguousarray(a, np.float32)
+    ids = np.ascontiguousarray(ids, np.int32)
+    bi = parse(blobs[0])
+    out = np.zeros((a.shape[0], bi.n), np.float32)
+    ptrs, sizes = _blob_table(blobs)
+    assert neref().neref_mul_mat_id(ptr(a), ptrs, sizes, len(blobs), ptr(ids), ids.shape[1], id_, ptr(out), a.shape[0], bi.n,
+                                    a.shape[1]) == 0
+    return out
+
+
+def neref_ffn_id(a, gate, down, up, ids, id_, gelu=False):
+    """ne_mul_id_ffn_silu / _gelu over BTLA expert weights (the expert of token row 0 serves every row)"""
+    a = np.ascontiguousarray(a, np.float32)
+    ids = np.ascontiguousarray(ids, np.int32)
+    d, ff = a.shape[1], parse(gate[0]).n
+    out = np.zeros((a.shape[0], d), np.float32)
+    ptrs, sizes = _blob_table(list(gate) + list(down) + list(up))
+    assert neref().neref_ffn_id(int(gelu), ptr(a), ptrs, sizes, len(gate), ptr(ids), ids.shape[1], id_, ptr(out), a.shape[0],
+                                d, ff) == 0
+    return out
 
 
 class AttnArgs(C.Structure):

@@ -52,6 +52,18 @@ void bestla_fusion_FFN_SiLu_f32f32_forward(float* a, void* w1, void* w2, void* w
   for (size_t i = 0; i < (size_t)seq * fmid; i++) t2[i] = t2[i] * nso_silu(t1[i]);
   gemm(t2, fmid, w2, out, fout, seq, fout);
 }
+/* tmp1 = gelu(A*W1), tmp2 = (A*W3) * tmp1, out = tmp2 * W2 (ip_fusion_ffn.cpp, Gelu_Mul form) */
+void bestla_fusion_FFN_Gelu_Mul_f32f32_forward(float* a, void* w1, void* w2, void* w3, float* t1, float* t2, float* out, int seq,
+                                               int fin, int fmid, int fout, void* ws) {
+  (void)ws;
+  gemm(a, fin, w1, t1, fmid, seq, fmid);
+  gemm(a, fin, w3, t2, fmid, seq, fmid);
+  for (size_t i = 0; i < (size_t)seq * fmid; i++) {
+    const float x = t1[i];
+    t2[i] = t2[i] * (0.5f * x * (1.f + tanhf(0.7978845834732056f * (x + 0.044714998453855515f * x * x * x))));
+  }
+  gemm(t2, fmid, w2, out, fout, seq, fout);
+}
 void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* p) {
   nso_attn_args a;
   memset(&a, 0, sizeof(a));

@@ -172,6 +172,30 @@ def gpt2_small_greedy(ne, n_new=4):
     return t_graph[len(prompt):], margins
 
 
+def expert_nodes_case(rng, d, ff):
+    """expert-indexed nodes (MoE): ne_mul_mat_id groups the token rows per expert and issues one forward per row
+    (ne_layers.c:7783-7916); ne_mul_id_ffn_silu / _gelu run the fused FFN of the expert the first row selects (:8053-8170)"""
+    def gelu(x):
+        return 0.5 * x * (1 + np.tanh(0.7978845834732056 * (x + 0.044714998453855515 * x ** 3)))
+    n_as, n_ids, me = 4, 2, 5
+    experts = blobs(rng, [(ff, d)] * n_as)
+    ids = rng.integers(0, n_as, size=(me, n_ids)).astype(np.int32)
+    am = rng.standard_normal((me, d)).astype(np.float32)
+    for id_ in range(n_ids):
+        y = nso.neref_mul_mat_id(am, experts, ids, id_)
+        ref = np.stack([nso.gemm_f64(am[t:t + 1], experts[ids[t, id_]])[0] for t in range(me)])
+        assert nso.rel_l2(y, ref) < 1e-3, ("mul_mat_id", id_)
+    gate, down, up = blobs(rng, [(ff, d)] * n_as), blobs(rng, [(d, ff)] * n_as), blobs(rng, [(ff, d)] * n_as)
+    a1 = am[:1].copy()
+    for use_gelu in (False, True):
+        y = nso.neref_ffn_id(a1, gate, down, up, ids[:1], 1, gelu=use_gelu)
+        e = ids[0, 1]
+        g_ = nso.gemm_f64(a1, gate[e])
+        act = gelu(g_) if use_gelu else g_ / (1 + np.exp(-g_))
+        ref = nso.gemm_f64((act * nso.gemm_f64(a1, up[e])).astype(np.float32), down[e])
+        assert nso.rel_l2(y, ref) < 2e-3, ("ffn_id", use_gelu)
+
+
 def main(kind):
     rng = np.random.default_rng(21)
     m, d, ff = 3, 256, 512
@@ -183,6 +207,7 @@ def main(kind):
                                "-L" + os.path.join(ROOT, "oracle"), "-lns_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lm"])
         ne = nso.neref(so)
         assert ne is not None, "oracle/_ref/libne_ref.so missing"
+        expert_nodes_case(rng, d, ff)
         print("decoder layer through the reference graph, oracle provider: rel l2 %.2e" % decoder_layer_case(ne, rng))
         if os.environ.get("NS_REF_GRAPH_GPT2", "1") != "0":
             toks, margins = gpt2_small_greedy(ne)
@@ -296,8 +321,9 @@ def main(kind):
     xd = x.astype(np.float64)
     assert nso.rel_l2(nso.neref_norm(x, 1e-6, True), xd / np.sqrt((xd ** 2).mean(-1, keepdims=True) + 1e-6)) < 1e-6
     assert nso.rel_l2(nso.neref_norm(x, 1e-5, False), (xd - xd.mean(-1, keepdims=True)) / np.sqrt(xd.var(-1, keepdims=True) + 1e-5)) < 1e-5
+    expert_nodes_case(rng, d, ff)
     print("decoder layer through the reference graph on libns_hip.so: rel l2 %.2e" % decoder_layer_case(ne, rng))
-    if os.environ.get("NS_REF_GRAPH_GPT2_PRODUCT") == "1":   # opt-in until it has been run on a GPU box once
+    if os.environ.get("NS_REF_GRAPH_GPT2_PRODUCT", "1") != "0":
         toks, margins = gpt2_small_greedy(ne)
         print("config 1 on libns_hip.so: tokens", toks, "top-1 margins %s" % ["%.3f" % m_ for m_ in margins])
     print("REF_GRAPH_PRODUCT_OK")
