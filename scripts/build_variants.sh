@@ -8,7 +8,7 @@ for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   # FILES = which kernel sources get the flags (the others are linked from the regular build)
   objs=""
-  for f in ns_kernels ns_gemv ns_gemm; do
+  for f in ns_kernels ns_gemv ns_gemm ns_attn; do
     if [[ " ${FILES:-ns_kernels ns_gemv ns_gemm} " == *" $f "* ]]; then
       /opt/rocm/bin/hipcc -O3 -std=c++20 $flags -fPIC --offload-arch=gfx950 -c $f.hip -o /tmp/${f}_$name.o &
       objs="$objs /tmp/${f}_$name.o"
@@ -17,6 +17,6 @@ for spec in "$@"; do
     fi
   done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libns_hip_$name.so ns_api.o ns_blob.o $objs ns_attn.o ns_quant.o ns_p2p.o ns_i8ref.o ns_moe.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libns_hip_$name.so ns_api.o ns_blob.o ns_tp.o $objs ns_quant.o ns_p2p.o ns_i8ref.o ns_moe.o -ldl
   echo built variants/libns_hip_$name.so
 done
