@@ -184,9 +184,10 @@ enum ns_compute_mode { NS_COMPUTE_FP16 = 0, NS_COMPUTE_REF_INT8 = 1 };
 int ns_hip_set_compute_mode(int mode);
 int ns_hip_get_compute_mode(void);
 
-/* Diagnostics / A-B switches of the decode kernels (process-wide, take effect at the next launch or capture):
- *   "gemv2"  0 = first-generation streaming kernel only, 1 = second generation (default), 2 = second generation with
- *            whole-tile workgroups only (no stream-K part);  also NS_GEMV2 in the environment.
+/* Diagnostics / A-B switches of the kernels (process-wide, take effect at the next launch or capture):
+ *   "gemv2"           0 = first-generation decode kernel only, 1 = gemv_kernel (default); also NS_GEMV2 in the environment
+ *   "g3_bm"           row-tile height of the prefill GEMM (128 / 256), 0 = automatic
+ *   "attn_wg_target", "attn_min_keys"   context-split rule of the decode attention kernel (defaults 1024, 128)
  * Returns 0, or -1 for an unknown key. */
 int ns_hip_set_tuning(const char* key, int value);
 

@@ -728,6 +728,10 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_gemv_mode(value);
     return 0;
   }
+  if (key && !strcmp(key, "g3_bm")) {
+    set_gemm3_bm(value);
+    return 0;
+  }
   if (key && !strcmp(key, "attn_wg_target")) {
     set_attn_tuning(value, 0);
     return 0;

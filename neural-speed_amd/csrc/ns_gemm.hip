@@ -16,6 +16,7 @@
 // bestla_wrapper.h LauncherBase GEMM loop); A rounded to fp16 (north_star: fp16 activations).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -1191,6 +1192,9 @@ static hipError_t launch_gemm2_s(const Gemm2Params& p, uint32_t scale_dt, bool a
   return launch_gemm2_k<KIND, SPS, SK_BF16>(p, asym, grid, lds, st);
 }
 
+static std::atomic<int> g_g3_bm{0};
+void set_gemm3_bm(int bm) { g_g3_bm.store(bm == 128 || bm == 256 ? bm : 0); }
+
 // hipErrorNotSupported = use the first-generation kernel (scratch allocation failed, sizes beyond 32-bit offsets ...)
 hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   static const bool off = getenv("NS_GEMM_V1") != nullptr;  // diagnostics
@@ -1258,7 +1262,8 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
     // 128-row tiles (three workgroups per CU hide each other's barrier / dequantisation / output phases) unless the
     // output has so many tiles that the tall ones' halved A traffic wins (profiles/r02r_gemm3_bm.txt: at 2048 rows equal
     // or better up to 11008 columns, 7 % worse at 32000)
-    static const int bm_env = getenv("NS_G3_BM") ? atoi(getenv("NS_G3_BM")) : 0;  // diagnostics
+    static const int bm_env0 = getenv("NS_G3_BM") ? atoi(getenv("NS_G3_BM")) : 0;  // diagnostics
+    const int bm_env = g_g3_bm.load() ? g_g3_bm.load() : bm_env0;                  // ns_hip_set_tuning("g3_bm", 128 / 256 / 0)
     const int tall_tiles = p.nbn * ((a.m + 255) / 256);
     p.bm3 = bm_env == 128 || bm_env == 256 ? bm_env : (tall_tiles >= 1024 && w0->kind != WK_INT8 ? 256 : 128);  // 8-bit codes: the tall tile's LDS
                                                                                             // footprint (81 KiB) leaves one workgroup per CU
