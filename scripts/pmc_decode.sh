@@ -2,13 +2,13 @@
 # SQ counters of the decode (weight-streaming) kernels, own --pmc pass: where the wave cycles go
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcd
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d gpurun_out/pmcd -o d -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmcd_bench.json 2>gpurun_out/pmcd_err.log
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d gpurun_out/pmcd -o d -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --chain-only > gpurun_out/pmcd_bench.json 2>gpurun_out/pmcd_err.log
 python - <<'PY'
 import csv, collections
 rows = list(csv.DictReader(open("gpurun_out/pmcd/d_counter_collection.csv")))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    if "smallm" not in r["Kernel_Name"]:
+    if "gemv_kernel" not in r["Kernel_Name"] and "attn_" not in r["Kernel_Name"]:
         continue
     key = (r["Kernel_Name"].split("(")[0].replace("void ns::", ""), r["Grid_Size"], r["Workgroup_Size"])
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
