@@ -434,7 +434,7 @@ static bool attn_shape_ok(int head_num, int heads_kv, int head_size, int sl_q, i
 // attn_mfma_kernel — prefill / multi-row attention on the matrix cores (head size 64 or 128, contiguous head dim)
 //
 // One 256-thread workgroup = 64 query rows of one (batch, head); wave w owns rows 16w .. 16w+15.  KV positions are
-// walked in blocks of 32 with the online-softmax recurrence:
+// walked in blocks of 64 (four score tiles, two 32-deep P.V slices) with the online-softmax recurrence:
 //   S^T = K . Q^T   v_mfma_f32_16x16x32_f16 with A = K rows (lane (nn, g): 16 B of K[pos0 + 16t + nn][32j + 8g ..]) and
 //                   B = Q rows (lane (nn, g): Q[q0 + nn][32j + 8g ..], converted to fp16 once): lane (nn, g) ends up
 //                   with the scores of query q0 + nn at positions pos0 + 16t + 4g + r (t = 0, 1; r = 0..3)
@@ -450,7 +450,7 @@ static bool attn_shape_ok(int head_num, int heads_kv, int head_size, int sl_q, i
 typedef _Float16 ahalf8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 ahalf4_t __attribute__((ext_vector_type(4)));
 typedef float afloatx4 __attribute__((ext_vector_type(4)));
-constexpr int kAttnKB = 32;           // kv positions per block
+constexpr int kAttnKB = 64;           // kv positions per block (32: two barriers and one softmax update per 32 keys)
 constexpr int kAttnVStr = kAttnKB + 4;  // halves per V^T row in LDS: keeps the 8-byte reads aligned, skews banks
 
 template <int HS>
@@ -458,9 +458,13 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
   constexpr int NJ = HS / 32, NDT = HS / 16, CH = HS / 8;  // k-slices of QK^T, output column tiles, V halves per thread
   __shared__ __attribute__((aligned(16))) _Float16 vt[HS * kAttnVStr];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nn = l & 15, g = l >> 4;
-  const int qblk = blockIdx.x, ihn = blockIdx.y, ibs = blockIdx.z;
+  const int ihn = blockIdx.y, ibs = blockIdx.z;
   const int ihkv = ihn / (p.head_num / p.heads_kv);
   const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
+  // causal: the LAST query block sees the most keys — dispatch it first, so that the light blocks fill the tail of the
+  // launch (in natural order the 32-block tiles of a 2048-token prompt started last and the kernel took twice its
+  // average workgroup time, profiles/r02t_attn_prefill.txt)
+  const int qblk = causal ? int(gridDim.x) - 1 - int(blockIdx.x) : int(blockIdx.x);
   const int off = p.sl_kv - p.sl_q;
   const int q0 = qblk * 64 + w * 16;
   const float* qb = p.q + ibs * p.step_q_bs + ihn * p.step_q_head_num;
@@ -484,23 +488,90 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
   const int q_last = min(qblk * 64 + 63, p.sl_q - 1);
   const int kv_end = causal ? min(p.sl_kv, q_last + off + 1) : p.sl_kv;            // workgroup-uniform
   const int visible = min(p.sl_kv, causal ? q0 + nn + off + 1 : p.sl_kv);          // mha_dense_wrapper.h:1440-1441
+  const int vis_wave = min(p.sl_kv, causal ? q0 + off + 1 : p.sl_kv);              // what the wave's FIRST row sees
 
-  for (int pos0 = 0; pos0 < kv_end; pos0 += kAttnKB) {
-    afloatx4 sv[2];
+  constexpr int NT = kAttnKB / 16, NH = kAttnKB / 32;  // score tiles, 32-deep P.V slices per block
+  // The K fragments and the V rows of block b + 1 are requested BEFORE block b is multiplied: without that every block
+  // paid two exposed global round trips (K in front of the score MFMAs, V behind the first barrier) — 10 us per 64-key
+  // block and workgroup, 110 TFLOPS at 2048 tokens, whatever the block size (profiles/r02t_attn_prefill.txt).
+  typedef _Float16 ahalf2_t __attribute__((ext_vector_type(2)));
+  const int vp = (tid >> 3) * 2, vc = tid & 7;  // V^T staging: this thread's two neighbouring positions, its CH head dims
+  ahalf8_t kn[NT][NJ], vn[2][CH / 8];
+  // (one register set each: the next K fragments are requested right behind the score MFMAs that consumed the current
+  // ones, the next V rows right behind the LDS stores of the current ones)
+  // row pointers advance by a uniform stride per block; only a block that reaches past the last key clamps its rows
+  // (64-bit multiplies per row and block were a fifth of this loop's VALU work)
+  const long long kstep_blk = (long long)kAttnKB * p.step_k_sl, vstep_blk = (long long)kAttnKB * p.step_v_sl;
+  const _Float16* kp[NT];
+  const _Float16* vpp[2];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-      sv[t] = afloatx4{0.f, 0.f, 0.f, 0.f};
-      const _Float16* kr = kb + (long long)min(pos0 + 16 * t + nn, p.sl_kv - 1) * p.step_k_sl + 8 * g;
+  for (int t = 0; t < NT; t++) kp[t] = kb + (long long)(16 * t + nn) * p.step_k_sl + 8 * g;
 #pragma unroll
-      for (int j = 0; j < NJ; j++)
-        sv[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const ahalf8_t*>(kr + 32 * j), qf[j], sv[t], 0, 0, 0);
+  for (int q2 = 0; q2 < 2; q2++) vpp[q2] = vb + (long long)(vp + q2) * p.step_v_sl + vc * CH;
+  auto fetch_k = [&](int pos0) {
+    if (pos0 + kAttnKB <= p.sl_kv) {  // workgroup-uniform
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) kn[t][j] = *reinterpret_cast<const ahalf8_t*>(kp[t] + 32 * j);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const _Float16* kr = kb + (long long)min(pos0 + 16 * t + nn, p.sl_kv - 1) * p.step_k_sl + 8 * g;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) kn[t][j] = *reinterpret_cast<const ahalf8_t*>(kr + 32 * j);
+      }
     }
-    float x[8], mx = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const int pos = pos0 + 16 * (e >> 2) + 4 * g + (e & 3);
-      x[e] = pos < visible ? sv[e >> 2][e & 3] * sc : -INFINITY;
-      mx = fmaxf(mx, x[e]);
+    for (int t = 0; t < NT; t++) kp[t] += kstep_blk;
+  };
+  auto fetch_v = [&](int pos0) {
+    if (pos0 + kAttnKB <= p.sl_kv) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; q2++)
+#pragma unroll
+        for (int u = 0; u < CH / 8; u++) vn[q2][u] = *reinterpret_cast<const ahalf8_t*>(vpp[q2] + 8 * u);
+    } else {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; q2++) {
+        const _Float16* vr = vb + (long long)min(pos0 + vp + q2, p.sl_kv - 1) * p.step_v_sl + vc * CH;
+#pragma unroll
+        for (int u = 0; u < CH / 8; u++) vn[q2][u] = *reinterpret_cast<const ahalf8_t*>(vr + 8 * u);
+      }
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < 2; q2++) vpp[q2] += vstep_blk;
+  };
+  if (kv_end > 0) {
+    fetch_k(0);
+    fetch_v(0);
+  }
+  for (int pos0 = 0; pos0 < kv_end; pos0 += kAttnKB) {
+    const bool more = pos0 + kAttnKB < kv_end;
+    afloatx4 sv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      sv[t] = afloatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; j++) sv[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kn[t][j], qf[j], sv[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch_k(pos0 + kAttnKB);
+    __builtin_amdgcn_sched_barrier(0);
+    float x[4 * NT], mx = -INFINITY;
+    if (pos0 + kAttnKB <= vis_wave) {  // wave-uniform: every row of this wave sees the whole block (all but the diagonal)
+#pragma unroll
+      for (int e = 0; e < 4 * NT; e++) {
+        x[e] = sv[e >> 2][e & 3] * sc;
+        mx = fmaxf(mx, x[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4 * NT; e++) {
+        const int pos = pos0 + 16 * (e >> 2) + 4 * g + (e & 3);
+        x[e] = pos < visible ? sv[e >> 2][e & 3] * sc : -INFINITY;
+        mx = fmaxf(mx, x[e]);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -508,12 +579,12 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
     const float m_use = m_new == -INFINITY ? 0.f : m_new;  // nothing visible yet: every exp2 below is exp2(-inf) = 0
     const float alpha = exp2f(m_run - m_use);
     float ps = 0.f;
-    ahalf8_t pf;
+    ahalf8_t pf[NH];  // slice h covers positions pos0 + 32 h ..: k-slot 8g + i <-> position 32 h + 16 (i >> 2) + 4g + (i & 3)
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
+    for (int e = 0; e < 4 * NT; e++) {
       const float pe = exp2f(x[e] - m_use);
       ps += pe;
-      pf[e] = (_Float16)pe;
+      pf[e >> 3][e & 7] = (_Float16)pe;
     }
     ps += __shfl_xor(ps, 16, 64);
     ps += __shfl_xor(ps, 32, 64);
@@ -525,32 +596,36 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 
     __syncthreads();  // the previous block's V^T reads are done
     {
-      const int vp = tid >> 3, c = tid & 7, vpos = pos0 + vp;
-      _Float16 vals[CH];
-      if (vpos < p.sl_kv) {
-        const _Float16* vr = vb + (long long)vpos * p.step_v_sl + c * CH;
+      // V^T[d][pos] for the block: (pos, pos + 1) pairs as 4-byte LDS stores; positions past the end hold zeros (P is zero
+      // there; keeps 0 * x away from inf / nan bits)
+      if (pos0 + kAttnKB <= p.sl_kv) {
 #pragma unroll
-        for (int u = 0; u < CH / 8; u++) {
-          const ahalf8_t v8 = *reinterpret_cast<const ahalf8_t*>(vr + 8 * u);
-#pragma unroll
-          for (int i = 0; i < 8; i++) vals[8 * u + i] = v8[i];
-        }
+        for (int i = 0; i < CH; i++)
+          *reinterpret_cast<ahalf2_t*>(vt + (vc * CH + i) * kAttnVStr + vp) = ahalf2_t{vn[0][i >> 3][i & 7], vn[1][i >> 3][i & 7]};
       } else {
+        const bool ok0 = pos0 + vp < p.sl_kv, ok1 = pos0 + vp + 1 < p.sl_kv;
 #pragma unroll
-        for (int i = 0; i < CH; i++) vals[i] = (_Float16)0.f;  // P is zero there; keep 0 * x away from inf / nan bits
+        for (int i = 0; i < CH; i++) {
+          const _Float16 a0 = ok0 ? vn[0][i >> 3][i & 7] : (_Float16)0.f, a1 = ok1 ? vn[1][i >> 3][i & 7] : (_Float16)0.f;
+          *reinterpret_cast<ahalf2_t*>(vt + (vc * CH + i) * kAttnVStr + vp) = ahalf2_t{a0, a1};
+        }
       }
-#pragma unroll
-      for (int i = 0; i < CH; i++) vt[(c * CH + i) * kAttnVStr + vp] = vals[i];
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) fetch_v(pos0 + kAttnKB);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
 #pragma unroll
     for (int dt = 0; dt < NDT; dt++) {
-      const _Float16* vr = vt + (16 * dt + nn) * kAttnVStr + 4 * g;
-      const ahalf4_t lo = *reinterpret_cast<const ahalf4_t*>(vr), hi = *reinterpret_cast<const ahalf4_t*>(vr + 16);
-      const ahalf8_t vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int r = 0; r < 4; r++) o[dt][r] *= ar[r];
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[dt], 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        const _Float16* vr = vt + (16 * dt + nn) * kAttnVStr + 32 * h + 4 * g;
+        const ahalf4_t lo = *reinterpret_cast<const ahalf4_t*>(vr), hi = *reinterpret_cast<const ahalf4_t*>(vr + 16);
+        const ahalf8_t vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[h], vf, o[dt], 0, 0, 0);
+      }
     }
   }
   const float inv = l_run > 0.f ? p.out_scale / l_run : 0.f;

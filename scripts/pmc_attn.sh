@@ -1,0 +1,21 @@
+#!/bin/bash
+# SQ counters of the prefill attention kernel (own --pmc pass)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/pmca
+timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d gpurun_out/pmca -o a -- python scripts/attn_prefill_bench.py 2048 > /dev/null 2>&1
+python - <<'PY'
+import csv, collections
+rows = list(csv.DictReader(open("gpurun_out/pmca/a_counter_collection.csv")))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    if "attn_" not in r["Kernel_Name"]:
+        continue
+    key = (r["Kernel_Name"].split("(")[0].replace("void ns::", ""), r["Grid_Size"], r["Workgroup_Size"], r.get("VGPR_Count",""), r.get("LDS_Block_Size",""))
+    agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for key, c in agg.items():
+    m = {k: sum(v) / len(v) for k, v in c.items()}
+    print(key, "dispatches", len(next(iter(c.values()))))
+    wc = m.get("SQ_WAVE_CYCLES", 1)
+    for k, v in sorted(m.items()):
+        print("   %-28s %14.0f  %6.3f of WAVE_CYCLES" % (k, v, v / wc))
+PY
