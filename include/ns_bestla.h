@@ -362,8 +362,7 @@ int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, s
  *   S[i][j] = (q_i . k_j) * QK_scale * Q_sc * K_sc  [tanh30: 30*tanh(S/30)]  + j * alibi_slope(head)
  *   causal: j <= i + (sl_kv - sl_q);  P = softmax_j(S);  dst[i] = (P . V) * V_sc / dst_sc
  * GQA: kv head = head / (head_num / heads_kv).  Only ATTN_FWD_LAYOUT_PLAIN tensors with arbitrary element strides
- * (incl. transposed K) are taken; the CPU-specific reordered kv-cache (NTILE48/24 row packs) is declined through
- * bestla_reordered_attn_fp32_support() == false, the reference's graceful path (llama.cpp:160-165).
+ * (incl. transposed K) are taken by the fp16 entries; the library-managed kv-cache entries below use their own layout.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct attn_shape_t {
   int batch_size, head_num, heads_kv, head_size, sl_q, sl_kv;
@@ -408,8 +407,60 @@ size_t bestla_fusion_attn_workspace_size(const attn_shape_t* params);
 /* mha_dense.h:85-86.  Host pointers: Q/K/V are uploaded, dst downloaded, synchronous (reference semantics). */
 bool bestla_fusion_attn_fp32_fp16_fp16_fp32_support(const attn_shape_t* params);
 void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* params);
-/* mha_dense.h:123: the reordered (CPU tile-packed) kv-cache path is not offered: graphs fall back to the plain cache */
-bool bestla_reordered_attn_fp32_support(const attn_shape_t* params);
+/* The library-managed ("reordered") kv-cache, mha_dense.h:124-172.  The reference hands the cache to BesTLA as an opaque
+ * buffer — sizes and view strides from batch_kv_info, contents only through update_k / update_v / shift_rope_k /
+ * batch_cpy / forward — and packs it in AMX / AVX tile order.  Nothing else looks inside, so the MI355X form is the layout
+ * its attention kernels stream best: plain fp16 [batch][head][seq_max][head_size] (k_layout = v_layout = PLAIN, byte
+ * strides as the graph code expects them for its views, llama.cpp:544-560).  Host pointers, synchronous, like the
+ * reference; a device-resident backend uses ns_hip_rope_qkv_append / ns_qkv_rope and the device attention entry. */
+typedef struct kv_shape_t {
+  uint32_t heads_kv, head_size, sl_kv_max;
+} kv_shape_t; /* mha_dense.h:29-33 */
+typedef struct kv_cache_info_t {
+  size_t k_bytes, v_bytes;
+  ATTN_FWD_LAYOUT k_layout, v_layout;
+  int stride_k_head_num, stride_k_sl, stride_k_head_size;
+  int stride_v_head_num, stride_v_sl, stride_v_head_size;
+} kv_cache_info_t; /* mha_dense.h:49-54 */
+typedef struct bestla_fusion_attn_fp32_update_kv_args_t {
+  float* src;
+  char* cache;
+  int batch_size, heads_kv, head_size, seq_off, seq_size, seq_max;
+  int step_bs, step_head_num, step_seq, step_head_size;
+  bool no_zeroing;
+} bestla_fusion_attn_fp32_update_kv_args_t; /* mha_dense.h:130-136 */
+typedef struct bestla_fusion_attn_fp32_batch_cpy_kv_args_t {
+  char* src;
+  char* dst;
+  int heads_kv, head_size, seq_off, seq_size, seq_max;
+  bool no_zeroing;
+} bestla_fusion_attn_fp32_batch_cpy_kv_args_t; /* mha_dense.h:145-150 */
+typedef struct bestla_reordered_attn_fp32_fp32_fwd_args_t {
+  float* Q;
+  char* K;
+  char* V;
+  float* dst;
+  float Q_sc, K_sc, V_sc, dst_sc;
+  char* tmp;
+  float QK_scale;
+  ns_attn_flags_t attn_flags;
+  int batch_size, head_num, heads_kv, head_size, sl_q, sl_kv;
+  ATTN_FWD_LAYOUT Q_layout, K_layout, V_layout, dst_layout;
+  int step_q_bs, step_q_head_num, step_q_sl;
+  int stride_k_bs, stride_k_head_num, stride_k_sl, stride_k_head_size;
+  int stride_v_bs, stride_v_head_num, stride_v_sl, stride_v_head_size;
+  int step_dst_bs, step_dst_head_num, step_dst_sl;
+} bestla_reordered_attn_fp32_fp32_fwd_args_t; /* mha_dense.h:156-171 */
+bool bestla_reordered_attn_fp32_support(const attn_shape_t* params);                          /* mha_dense.h:125 */
+void bestla_reordered_attn_fp32_batch_kv_info(const kv_shape_t* params, kv_cache_info_t* out); /* :128 */
+void bestla_reordered_attn_fp32_update_k(const bestla_fusion_attn_fp32_update_kv_args_t* params); /* :138 */
+void bestla_reordered_attn_fp32_update_v(const bestla_fusion_attn_fp32_update_kv_args_t* params); /* :140 */
+/* :142-143: rows [seq_keep, seq_max) of every (batch, head) rotated by the one angle set cossin = {cos_0, sin_0, ...} (fp16) */
+void bestla_reordered_attn_fp32_shift_rope_k(char* cache, const uint16_t* cossin, int batch_size, int heads_kv, int head_size,
+                                             int seq_max, int seq_keep);
+void bestla_fusion_attn_fp32_batch_cpy_k(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* params); /* :152 */
+void bestla_fusion_attn_fp32_batch_cpy_v(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* params); /* :154 */
+void bestla_reordered_attn_fp32_forward(const bestla_reordered_attn_fp32_fp32_fwd_args_t* params);   /* :172 */
 /* same operator on DEVICE pointers, asynchronous on `stream`; returns 0 on success */
 int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* dparams, void* stream);
 /* same, also writing the fp16 shadow of dst (dst16: same element strides as dst; may be NULL) that the "_h" / "_x" GEMM

@@ -55,6 +55,46 @@ class AttnShape(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("batch_size", "head_num", "heads_kv", "head_size", "sl_q", "sl_kv")]
 
 
+class KvShape(C.Structure):
+    """kv_shape_t (mha_dense.h:29-33)"""
+    _fields_ = [(n, C.c_uint32) for n in ("heads_kv", "head_size", "sl_kv_max")]
+
+
+class KvCacheInfo(C.Structure):
+    """kv_cache_info_t (mha_dense.h:49-54): byte sizes per batch entry and BYTE strides of the library's cache layout"""
+    _fields_ = ([("k_bytes", C.c_size_t), ("v_bytes", C.c_size_t), ("k_layout", C.c_int), ("v_layout", C.c_int)] +
+                [(n, C.c_int) for n in ("stride_k_head_num", "stride_k_sl", "stride_k_head_size",
+                                        "stride_v_head_num", "stride_v_sl", "stride_v_head_size")])
+
+
+class KvUpdateArgs(C.Structure):
+    """bestla_fusion_attn_fp32_update_kv_args_t (mha_dense.h:130-136); steps of src in ELEMENTS"""
+    _fields_ = ([("src", C.c_void_p), ("cache", C.c_void_p)] +
+                [(n, C.c_int) for n in ("batch_size", "heads_kv", "head_size", "seq_off", "seq_size", "seq_max",
+                                        "step_bs", "step_head_num", "step_seq", "step_head_size")] +
+                [("no_zeroing", C.c_bool)])
+
+
+class KvBatchCpyArgs(C.Structure):
+    """bestla_fusion_attn_fp32_batch_cpy_kv_args_t (mha_dense.h:145-150)"""
+    _fields_ = ([("src", C.c_void_p), ("dst", C.c_void_p)] +
+                [(n, C.c_int) for n in ("heads_kv", "head_size", "seq_off", "seq_size", "seq_max")] +
+                [("no_zeroing", C.c_bool)])
+
+
+class ReorderedAttnArgs(C.Structure):
+    """bestla_reordered_attn_fp32_fp32_fwd_args_t (mha_dense.h:156-171): Q / dst steps in elements, K / V strides in BYTES"""
+    _fields_ = ([("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("dst", C.c_void_p),
+                 ("Q_sc", C.c_float), ("K_sc", C.c_float), ("V_sc", C.c_float), ("dst_sc", C.c_float),
+                 ("tmp", C.c_void_p), ("QK_scale", C.c_float), ("attn_flags", C.c_uint32)] +
+                [(n, C.c_int) for n in ("batch_size", "head_num", "heads_kv", "head_size", "sl_q", "sl_kv",
+                                        "Q_layout", "K_layout", "V_layout", "dst_layout",
+                                        "step_q_bs", "step_q_head_num", "step_q_sl",
+                                        "stride_k_bs", "stride_k_head_num", "stride_k_sl", "stride_k_head_size",
+                                        "stride_v_bs", "stride_v_head_num", "stride_v_sl", "stride_v_head_size",
+                                        "step_dst_bs", "step_dst_head_num", "step_dst_sl")])
+
+
 class AttnArgs(C.Structure):
     """attn_fp32_fp16_fp16_fp32_fwd_args_t (mha_dense.h:66-81)"""
     _fields_ = ([("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("dst", C.c_void_p),
@@ -190,6 +230,15 @@ def lib():
         L.bestla_fusion_attn_fp32_fp16_fp16_fp32_support.argtypes = [vp]
         L.bestla_reordered_attn_fp32_support.restype = b
         L.bestla_reordered_attn_fp32_support.argtypes = [vp]
+        for fn in ("bestla_reordered_attn_fp32_update_k", "bestla_reordered_attn_fp32_update_v",
+                   "bestla_fusion_attn_fp32_batch_cpy_k", "bestla_fusion_attn_fp32_batch_cpy_v",
+                   "bestla_reordered_attn_fp32_forward"):
+            getattr(L, fn).restype = None
+            getattr(L, fn).argtypes = [vp]
+        L.bestla_reordered_attn_fp32_batch_kv_info.restype = None
+        L.bestla_reordered_attn_fp32_batch_kv_info.argtypes = [vp, vp]
+        L.bestla_reordered_attn_fp32_shift_rope_k.restype = None
+        L.bestla_reordered_attn_fp32_shift_rope_k.argtypes = [vp, vp, i, i, i, i, i]
         L.bestla_fusion_attn_fp32_fp16_fp16_fp32_forward.restype = None
         L.bestla_fusion_attn_fp32_fp16_fp16_fp32_forward.argtypes = [vp]
         L.ns_hip_attn_fp32_fp16_fp16_fp32_forward.argtypes = [vp, vp]

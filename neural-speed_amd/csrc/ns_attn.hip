@@ -754,6 +754,37 @@ static size_t span4(int n0, long long s0, int n1, long long s1, int n2, long lon
   return size_t((n0 - 1) * s0 + (n1 - 1) * s1 + (n2 - 1) * s2 + (n3 - 1) * s3 + 1);
 }
 
+
+// ---- library-managed ("reordered") kv-cache, MI355X form: plain fp16 [batch][head][seq_max][head_size] -----------------
+// The reference hands the cache to BesTLA as an opaque buffer (sizes / strides from bestla_reordered_attn_fp32_batch_kv_info,
+// contents only through the update / shift / copy / forward entries, mha_dense.h:124-172) and packs it for AMX / AVX tiles.
+// Nothing but this module looks inside, so the layout here is the one the attention kernels stream best.
+__global__ void kv_update_kernel(const float* __restrict__ src, _Float16* __restrict__ out, int batch, int heads, int hs,
+                                 int seq, long long step_bs, long long step_head, long long step_seq, long long step_hs) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t total = size_t(batch) * heads * seq * hs;
+  if (gid >= total) return;
+  const int j = int(gid % hs);
+  const int i = int((gid / hs) % seq);
+  const int h = int((gid / (size_t(hs) * seq)) % heads);
+  const int b = int(gid / (size_t(hs) * seq * heads));
+  out[gid] = (_Float16)src[b * step_bs + h * step_head + i * step_seq + j * step_hs];  // out: [batch][head][seq][hs]
+}
+// rows [seq_keep, seq_max) of every (batch, head): adjacent pairs rotated by the one angle set in cossin = {cos_0, sin_0,
+// cos_1, sin_1, ...} (fp16), as ne_compute_forward_rope_bestla prepares it (ne_layers.c:9636-9651)
+__global__ void kv_shift_rope_kernel(_Float16* __restrict__ rows, const _Float16* __restrict__ cossin, size_t nrows, int hs) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int half = hs / 2;
+  if (gid >= nrows * half) return;
+  const size_t r = gid / half;
+  const int pr = int(gid % half);
+  _Float16* x = rows + r * hs + 2 * pr;
+  const float c = float(cossin[2 * pr]), sn = float(cossin[2 * pr + 1]);
+  const float x0 = float(x[0]), x1 = float(x[1]);
+  x[0] = (_Float16)(x0 * c - x1 * sn);
+  x[1] = (_Float16)(x0 * sn + x1 * c);
+}
+
 }  // namespace ns
 
 using namespace ns;  // NOLINT
@@ -782,8 +813,145 @@ bool bestla_fusion_attn_fp32_fp16_fp16_fp32_support(const attn_shape_t* s) {
 }
 
 bool bestla_reordered_attn_fp32_support(const attn_shape_t* params) {
-  (void)params;
+  // mha_dense.cpp:70-80 answers by CPU features; here: whatever the attention kernels take (fp16 cache, see below)
+  std::string why;
+  int count = 0;
+  if (!params || hipGetDeviceCount(&count) != hipSuccess || count <= 0) return false;
+  return attn_shape_ok(params->head_num, params->heads_kv, params->head_size, params->sl_q, params->sl_kv, false, &why);
+}
+
+void bestla_reordered_attn_fp32_batch_kv_info(const kv_shape_t* params, kv_cache_info_t* out) {
+  // mha_dense.cpp:82-112.  Byte strides, as the graph code uses them for its views (llama.cpp:544-560)
+  if (!params || !out) return;
+  const size_t row = size_t(params->head_size) * 2;
+  out->k_layout = ATTN_FWD_LAYOUT_PLAIN;
+  out->v_layout = ATTN_FWD_LAYOUT_PLAIN;
+  out->stride_k_head_size = 2;
+  out->stride_k_sl = int(row);
+  out->stride_k_head_num = int(row * params->sl_kv_max);
+  out->k_bytes = size_t(out->stride_k_head_num) * params->heads_kv;
+  out->stride_v_head_size = 2;
+  out->stride_v_sl = int(row);
+  out->stride_v_head_num = int(row * params->sl_kv_max);
+  out->v_bytes = size_t(out->stride_v_head_num) * params->heads_kv;
+}
+
+static bool kv_device() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) == hipSuccess && count > 0) return true;
+  (void)hipGetLastError();
+  set_error("no HIP device visible: libns_hip.so has no CPU fallback");
+  fprintf(stderr, "Err: invalid parameters (bestla_reordered_attn: no HIP device visible: libns_hip.so has no CPU fallback)\n");
   return false;
+}
+
+// update_k / update_v share one layout here: fp32 rows (any element steps) -> fp16 at [batch][head][seq_off + i][:]
+static void kv_update(const bestla_fusion_attn_fp32_update_kv_args_t* pp, const char* who) {
+  if (!kv_device()) return;
+  const auto& a = *pp;
+  if (!a.src || !a.cache || a.batch_size < 0 || a.heads_kv <= 0 || a.head_size <= 0 || a.seq_size < 0 || a.seq_off < 0 ||
+      a.seq_off + a.seq_size > a.seq_max) {
+    set_error(std::string(who) + ": invalid argument");
+    fprintf(stderr, "Err: invalid parameters (%s)\n", who);
+    return;
+  }
+  const size_t total = size_t(a.batch_size) * a.heads_kv * a.seq_size * a.head_size;
+  if (total == 0) return;
+  const size_t nsrc = span4(a.batch_size, a.step_bs, a.heads_kv, a.step_head_num, a.seq_size, a.step_seq, a.head_size, a.step_head_size);
+  float* dsrc = nullptr;
+  _Float16* dout = nullptr;
+  bool ok = hipMalloc((void**)&dsrc, nsrc * 4) == hipSuccess && hipMalloc((void**)&dout, total * 2) == hipSuccess &&
+            hipMemcpy(dsrc, a.src, nsrc * 4, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(kv_update_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, nullptr, dsrc, dout, a.batch_size,
+                       a.heads_kv, a.head_size, a.seq_size, (long long)a.step_bs, (long long)a.step_head_num, (long long)a.step_seq,
+                       (long long)a.step_head_size);
+    // [batch x head] chunks of seq_size rows land at row seq_off of their seq_max-row slab
+    const size_t row = size_t(a.head_size) * 2;
+    ok = hipGetLastError() == hipSuccess &&
+         hipMemcpy2D(a.cache + size_t(a.seq_off) * row, size_t(a.seq_max) * row, dout, size_t(a.seq_size) * row,
+                     size_t(a.seq_size) * row, size_t(a.batch_size) * a.heads_kv, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  if (dsrc) (void)hipFree(dsrc);
+  if (dout) (void)hipFree(dout);
+  if (!ok) {
+    (void)hipGetLastError();
+    set_error(std::string(who) + ": device copy / launch failed");
+    fprintf(stderr, "Err: invalid parameters (%s: device copy / launch failed)\n", who);
+  }
+}
+void bestla_reordered_attn_fp32_update_k(const bestla_fusion_attn_fp32_update_kv_args_t* params) {
+  kv_update(params, "bestla_reordered_attn_fp32_update_k");
+}
+void bestla_reordered_attn_fp32_update_v(const bestla_fusion_attn_fp32_update_kv_args_t* params) {
+  kv_update(params, "bestla_reordered_attn_fp32_update_v");
+}
+
+void bestla_reordered_attn_fp32_shift_rope_k(char* cache, const uint16_t* cossin, int batch_size, int heads_kv, int head_size,
+                                             int seq_max, int seq_keep) {
+  if (!kv_device()) return;
+  if (!cache || !cossin || batch_size < 0 || heads_kv <= 0 || head_size <= 0 || (head_size & 1) || seq_keep < 0 || seq_keep > seq_max) {
+    set_error("bestla_reordered_attn_fp32_shift_rope_k: invalid argument");
+    fprintf(stderr, "Err: invalid parameters (bestla_reordered_attn_fp32_shift_rope_k)\n");
+    return;
+  }
+  const size_t row = size_t(head_size) * 2, slabs = size_t(batch_size) * heads_kv, n = size_t(seq_max - seq_keep);
+  if (slabs == 0 || n == 0) return;
+  _Float16 *drows = nullptr, *dcs = nullptr;
+  bool ok = hipMalloc((void**)&drows, slabs * n * row) == hipSuccess && hipMalloc((void**)&dcs, row) == hipSuccess &&
+            hipMemcpy(dcs, cossin, row, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy2D(drows, n * row, cache + size_t(seq_keep) * row, size_t(seq_max) * row, n * row, slabs, hipMemcpyHostToDevice) ==
+                hipSuccess;
+  if (ok) {
+    const size_t work = slabs * n * (head_size / 2);
+    hipLaunchKernelGGL(kv_shift_rope_kernel, dim3(unsigned((work + 255) / 256)), dim3(256), 0, nullptr, drows, dcs, slabs * n, head_size);
+    ok = hipGetLastError() == hipSuccess &&
+         hipMemcpy2D(cache + size_t(seq_keep) * row, size_t(seq_max) * row, drows, n * row, n * row, slabs, hipMemcpyDeviceToHost) ==
+             hipSuccess;
+  }
+  if (drows) (void)hipFree(drows);
+  if (dcs) (void)hipFree(dcs);
+  if (!ok) {
+    (void)hipGetLastError();
+    set_error("bestla_reordered_attn_fp32_shift_rope_k: device copy / launch failed");
+    fprintf(stderr, "Err: invalid parameters (bestla_reordered_attn_fp32_shift_rope_k: device copy / launch failed)\n");
+  }
+}
+
+// beam search: rows [seq_off, seq_off + seq_size) of every head from one sequence's cache to another's (both in host
+// memory, as the graph allocates them): a plain copy in this layout — data movement, no arithmetic
+static void kv_batch_cpy(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* pp) {
+  const auto& a = *pp;
+  if (!a.src || !a.dst || a.heads_kv <= 0 || a.head_size <= 0 || a.seq_size <= 0 || a.seq_off < 0 || a.seq_off + a.seq_size > a.seq_max) return;
+  const size_t row = size_t(a.head_size) * 2;
+  for (int h = 0; h < a.heads_kv; h++)
+    memcpy(a.dst + (size_t(h) * a.seq_max + a.seq_off) * row, a.src + (size_t(h) * a.seq_max + a.seq_off) * row, size_t(a.seq_size) * row);
+}
+void bestla_fusion_attn_fp32_batch_cpy_k(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* params) { kv_batch_cpy(params); }
+void bestla_fusion_attn_fp32_batch_cpy_v(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* params) { kv_batch_cpy(params); }
+
+void bestla_reordered_attn_fp32_forward(const bestla_reordered_attn_fp32_fp32_fwd_args_t* rp) {
+  // the graph passes BYTE strides of its K / V views (ne_layers.c:10238-10279; the sequence stride of V is not passed at
+  // all: every layout knows its own) — here they are plain fp16 rows, so this is the fp16 attention entry
+  attn_fp32_fp16_fp16_fp32_fwd_args_t a;
+  memset(&a, 0, sizeof(a));
+  a.Q = rp->Q, a.K = reinterpret_cast<uint16_t*>(rp->K), a.V = reinterpret_cast<uint16_t*>(rp->V), a.dst = rp->dst;
+  a.Q_sc = rp->Q_sc, a.K_sc = rp->K_sc, a.V_sc = rp->V_sc, a.dst_sc = rp->dst_sc;
+  a.tmp = rp->tmp, a.QK_scale = rp->QK_scale, a.attn_flags = rp->attn_flags;
+  a.batch_size = rp->batch_size, a.head_num = rp->head_num, a.heads_kv = rp->heads_kv, a.head_size = rp->head_size;
+  a.sl_q = rp->sl_q, a.sl_kv = rp->sl_kv;
+  a.Q_layout = a.K_layout = a.V_layout = a.dst_layout = ATTN_FWD_LAYOUT_PLAIN;
+  a.step_q_bs = rp->step_q_bs, a.step_q_head_num = rp->step_q_head_num, a.step_q_sl = rp->step_q_sl;
+  a.step_k_bs = rp->stride_k_bs / 2, a.step_k_head_num = rp->stride_k_head_num / 2;
+  a.step_k_sl = rp->stride_k_sl ? rp->stride_k_sl / 2 : rp->head_size, a.step_k_head_size = 1;
+  a.step_v_bs = rp->stride_v_bs / 2, a.step_v_head_num = rp->stride_v_head_num / 2, a.step_v_sl = rp->head_size, a.step_v_head_size = 1;
+  a.step_dst_bs = rp->step_dst_bs, a.step_dst_head_num = rp->step_dst_head_num, a.step_dst_sl = rp->step_dst_sl;
+  if (rp->K_layout != ATTN_FWD_LAYOUT_PLAIN || rp->V_layout != ATTN_FWD_LAYOUT_PLAIN) {
+    set_error("bestla_reordered_attn_fp32_forward: the cache was not laid out by this library (bestla_reordered_attn_fp32_batch_kv_info)");
+    fprintf(stderr, "Err: invalid parameters (bestla_reordered_attn_fp32_forward: foreign cache layout)\n");
+    return;
+  }
+  bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(&a);
 }
 
 int ns_hip_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* a, void* stream) {

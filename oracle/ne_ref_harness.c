@@ -24,6 +24,7 @@
 #include "ne.h"
 #include "ne_bestla.h"
 #include "ne_layers.h"
+#include "layers/mha_dense.h"
 
 /* the three graph-struct entry points live in glue/ne_bestla_hip_glue.c (product glue, compiled into this library by
  * oracle/Makefile) */
@@ -235,6 +236,66 @@ int neref_norm(const float* x, float* y, int rows, int cols, float eps, int is_r
   struct ne_tensor* r = is_rms ? ne_rms_norm(ctx, a, eps) : ne_norm(ctx, a, eps);
   run_graph(ctx, r);
   memcpy(y, r->data, n * 4);
+  ne_free(ctx);
+  return 0;
+}
+
+/* Library-managed kv-cache through the reference's graph nodes, built the way models/llama/llama.cpp:496-571 builds them:
+ * bestla_reordered_attn_fp32_batch_kv_info sizes two NE_TYPE_BTLA cache tensors, ne_flash_attn_update_k / _v append fp32
+ * K / V rows (NE_OP_FLASH_ATTN_KV_UPDATE -> bestla_reordered_attn_fp32_update_k / _v, ne_layers.c:10529-10558), then ne_flash_attn over views whose strides come from the
+ * info struct (-> ne_compute_forward_flash_attn_reordered -> bestla_reordered_attn_fp32_forward, :10216-10280).
+ * q [bs][sl_q][heads][hs]; kall / vall [bs][sl_kv][heads_kv][hs]: with split != 0 the first sl_kv - sl_q rows are appended
+ * by one update pair and the last sl_q rows by a second one (seq_off > 0).
+ * The ring-full branch (ne_rope_shift_inplace over the K view, llama.cpp:551-558) is NOT driven: ne_rope_impl builds its
+ * parameter tensor with 5 + batch elements (ne_layers.c:3402) while ne_compute_forward_rope_bestla and _rope_f16 assert
+ * exactly 5 (:9437, :9619) and _rope_f32 refuses a shift (:9311) — no shift-RoPE node of the reference can execute as
+ * shipped.  bestla_reordered_attn_fp32_shift_rope_k is tested by direct calls against the restated arithmetic instead. */
+int neref_reordered_attn(const float* q, const float* kall, const float* vall, float* out, int bs, int heads, int heads_kv,
+                         int hs, int sl_q, int sl_kv, int n_ctx, float scale, unsigned flags, int split) {
+  kv_shape_t ks = {(uint32_t)heads_kv, (uint32_t)hs, (uint32_t)n_ctx};
+  kv_cache_info_t info;
+  memset(&info, 0, sizeof(info));
+  bestla_reordered_attn_fp32_batch_kv_info(&ks, &info);
+  if (!info.k_bytes || !info.v_bytes) return -2;
+  const size_t fl = (size_t)bs * ((size_t)sl_q * heads * 2 + (size_t)sl_kv * heads_kv * 4) * hs * 4;
+  struct ne_init_params ip = {(size_t)bs * (info.k_bytes + info.v_bytes) + fl + (128u << 20), NULL, false};
+  struct ne_context* ctx = ne_init(ip);
+  if (!ctx) return -1;
+  struct ne_tensor* kc = ne_new_tensor_1d(ctx, NE_TYPE_BTLA, (int64_t)bs * info.k_bytes, (size_t)bs * info.k_bytes, NE_BACKEND_CPU);
+  struct ne_tensor* vc = ne_new_tensor_1d(ctx, NE_TYPE_BTLA, (int64_t)bs * info.v_bytes, (size_t)bs * info.v_bytes, NE_BACKEND_CPU);
+  memset(kc->data, 0x7f, (size_t)bs * info.k_bytes); /* garbage: rows past what was appended must never be read */
+  memset(vc->data, 0x7f, (size_t)bs * info.v_bytes);
+  memset(&g_graph, 0, sizeof(g_graph));
+  g_graph.n_threads = 1;
+  const int past = sl_kv - sl_q;
+  const int nupd = (split && past > 0) ? 2 : 1;
+  for (int u = 0; u < nupd; u++) {
+    const int off = (nupd == 2 && u == 1) ? past : 0;
+    const int len = nupd == 2 ? (u == 0 ? past : sl_q) : sl_kv;
+    /* cur tensors ne = (head_size, heads_kv, len, bs): contiguous copies of the rows [off, off + len) */
+    struct ne_tensor* kcur = ne_new_tensor_4d(ctx, NE_TYPE_F32, hs, heads_kv, len, bs, NE_SIZE_CALC, NE_BACKEND_CPU);
+    struct ne_tensor* vcur = ne_new_tensor_4d(ctx, NE_TYPE_F32, hs, heads_kv, len, bs, NE_SIZE_CALC, NE_BACKEND_CPU);
+    const size_t rows = (size_t)len * heads_kv * hs;
+    for (int b = 0; b < bs; b++) {
+      memcpy((float*)kcur->data + b * rows, kall + ((size_t)b * sl_kv + off) * heads_kv * hs, rows * 4);
+      memcpy((float*)vcur->data + b * rows, vall + ((size_t)b * sl_kv + off) * heads_kv * hs, rows * 4);
+    }
+    struct ne_tensor* kcg = ne_view_4d(ctx, kc, hs, n_ctx, heads_kv, bs, 0, 0, info.k_bytes, 0);
+    struct ne_tensor* vcg = ne_view_4d(ctx, vc, hs, n_ctx, heads_kv, bs, 0, 0, info.v_bytes, 0);
+    ne_build_forward_expand(&g_graph, ne_flash_attn_update_k(ctx, kcg, kcur, off, false));
+    ne_build_forward_expand(&g_graph, ne_flash_attn_update_v(ctx, vcg, vcur, off, false));
+  }
+  struct ne_tensor* qcur = ne_new_tensor_4d(ctx, NE_TYPE_F32, hs, heads, sl_q, bs, NE_SIZE_CALC, NE_BACKEND_CPU);
+  memcpy(qcur->data, q, (size_t)bs * sl_q * heads * hs * 4);
+  struct ne_tensor* Q = ne_permute(ctx, qcur, 0, 2, 1, 3);
+  struct ne_tensor* K = ne_view_4d(ctx, kc, hs, sl_kv, heads_kv, bs, info.stride_k_sl, info.stride_k_head_num, info.k_bytes, 0);
+  *(ATTN_FWD_LAYOUT*)(&K->nb[0]) = info.k_layout; /* nb0 carries the layout (llama.cpp:550) */
+  struct ne_tensor* V = ne_view_4d(ctx, vc, sl_kv, hs, heads_kv, bs, info.stride_v_head_size, info.stride_v_head_num, info.v_bytes, 0);
+  *(ATTN_FWD_LAYOUT*)(&V->nb[0]) = info.v_layout;
+  struct ne_tensor* o = ne_flash_attn(ctx, Q, K, V, scale, (ne_attn_flags_t)flags);
+  ne_build_forward_expand(&g_graph, o);
+  ne_graph_compute(ctx, &g_graph);
+  memcpy(out, o->data, (size_t)bs * sl_q * heads * hs * 4);
   ne_free(ctx);
   return 0;
 }

@@ -28,7 +28,8 @@ NE_REF_STUB(bestla_fusion_attn_fp32_fp16_fp16_fp32_forward)
 NE_REF_STUB(bestla_layernormalization)
 NE_REF_STUB(bestla_mul)
 NE_REF_STUB(bestla_add)
-/* the CPU tile-packed kv-cache entries are not offered by the product (support() == false): never reached */
+/* the library-managed kv-cache entries (mha_dense.h:124-172) */
+NE_REF_STUB(bestla_reordered_attn_fp32_batch_kv_info)
 NE_REF_STUB(bestla_reordered_attn_fp32_forward)
 NE_REF_STUB(bestla_reordered_attn_fp32_shift_rope_k)
 NE_REF_STUB(bestla_reordered_attn_fp32_update_k)

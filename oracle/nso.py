@@ -220,6 +220,44 @@ def neref_flash_attn(q, k, v, qk_scale, flags):
     return out
 
 
+def neref_reordered_attn(q, kall, vall, n_ctx, qk_scale, flags, split=False):
+    """the reference graph's library-managed kv-cache nodes (update_k / update_v / flash_attn over
+    NE_TYPE_BTLA caches, llama.cpp:496-571); needs a bestla_* provider.  q [bs][sl_q][heads][hs] fp32;
+    kall / vall [bs][sl_kv][heads_kv][hs] fp32 (what the graph appends)."""
+    q = np.ascontiguousarray(q, np.float32)
+    kall = np.ascontiguousarray(kall, np.float32)
+    vall = np.ascontiguousarray(vall, np.float32)
+    bs, sl_q, hn, hs = q.shape
+    sl_kv, hkv = vall.shape[1], vall.shape[2]
+    out = np.zeros_like(q)
+    f = neref().neref_reordered_attn
+    f.argtypes = [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_float, C.c_uint, C.c_int]
+    rc = f(ptr(q), ptr(kall), ptr(vall), ptr(out), bs, hn, hkv, hs, sl_q, sl_kv, n_ctx, qk_scale, flags, int(split))
+    assert rc == 0, rc
+    return out
+
+
+def rope_shift_f16_ref(k16, shift_n, n_keep, freq_base=10000.0):
+    """restatement of the shift-RoPE of a K cache (ne_compute_forward_rope_f16's is_shift branch, ne_layers.c:9494-9530; the
+    BTLA-cache twin computes the same cos / sin table, :9640-9650, and hands it to bestla_reordered_attn_fp32_shift_rope_k).
+    PARITY UNPINNED: the reference cannot execute either branch (parameter-tensor size assert, see ne_ref_harness.c).
+    k16 fp16 [bs][seq][heads][hs] -> (rotated copy, the fp16 {cos, sin} table).  One angle set for -shift_n positions, cos / sin ROUNDED TO
+    FP16, fp32 arithmetic on adjacent pairs, result rounded to fp16; rows < n_keep untouched."""
+    k = np.asarray(k16, np.float16).copy()
+    hs = k.shape[-1]
+    theta_scale = np.float32(np.power(np.float32(freq_base), np.float32(-2.0) / np.float32(hs)))
+    theta = np.float32(-shift_n)
+    cs = np.zeros(hs, np.float16)
+    for i0 in range(0, hs, 2):
+        cs[i0], cs[i0 + 1] = np.float16(np.cos(theta, dtype=np.float32)), np.float16(np.sin(theta, dtype=np.float32))
+        theta = np.float32(theta * theta_scale)
+    c, s = cs[0::2].astype(np.float32), cs[1::2].astype(np.float32)
+    x0, x1 = k[:, n_keep:, :, 0::2].astype(np.float32), k[:, n_keep:, :, 1::2].astype(np.float32)
+    k[:, n_keep:, :, 0::2] = (x0 * c - x1 * s).astype(np.float16)
+    k[:, n_keep:, :, 1::2] = (x1 * c + x0 * s).astype(np.float16)
+    return k, cs
+
+
 def neref_attn_unfused(q, k, v, qk_scale, causal):
     """attention through the reference's UNFUSED graph (mul_mat -> scale -> diag_mask_inf -> soft_max -> mul_mat), fp32.
     q [1][sl_q][heads][hs], k / v fp16 [1][sl_kv][heads_kv][hs] (attn_ref's layouts) -> dst [1][sl_q][heads][hs]"""

@@ -95,6 +95,15 @@ def test_no_device_fails_loudly(L, pkg, nso):
     L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), 1, 16, 128, 128, 16, None)  # prints Err, as the reference
     assert np.all(out == 7.0)  # output untouched: nothing computed on the CPU
     assert not L.bestla_fusion_QKV_f32f32_support(nso.ptr(blob), nso.ptr(blob), nso.ptr(blob), 1, 16, 128)
+    # library-managed kv cache: support() is what makes the graph builder choose it — false without a device; an update
+    # that is called anyway leaves the cache untouched
+    import ctypes as C
+    assert not L.bestla_reordered_attn_fp32_support(C.byref(pkg.AttnShape(1, 4, 4, 64, 1, 8)))
+    cache = np.full(4 * 8 * 64 * 2, 0x55, np.uint8)
+    cur = np.ones((1, 2, 4, 64), np.float32)
+    u = pkg.KvUpdateArgs(cur.ctypes.data, cache.ctypes.data, 1, 4, 64, 0, 2, 8, 2 * 4 * 64, 64, 4 * 64, 1, False)
+    L.bestla_reordered_attn_fp32_update_k(C.byref(u))
+    assert np.all(cache == 0x55) and "no HIP device" in pkg.last_error()
 
 
 def test_header_is_plain_c(tmp_path):

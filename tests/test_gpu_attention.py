@@ -43,7 +43,7 @@ def test_attention_host_api(L, pkg, nso, bs, hn, hkv, hs, sl_q, sl_kv, flags, k_
     ref = nso.attn_ref(q, kk, v, scale, flags, k_trans=k_trans)
     shape = pkg.AttnShape(bs, hn, hkv, hs, sl_q, sl_kv)
     assert L.bestla_fusion_attn_fp32_fp16_fp16_fp32_support(C.byref(shape))
-    assert not L.bestla_reordered_attn_fp32_support(C.byref(shape))  # CPU tile-packed kv cache: declined
+    assert L.bestla_reordered_attn_fp32_support(C.byref(shape))  # library-managed fp16 cache: tests/test_gpu_kvcache.py
     out = np.full(q.shape, 7.0, np.float32)
     a = pkg.attn_args(q.ctypes.data, kk.ctypes.data, v.ctypes.data, out.ctypes.data, bs, hn, hkv, hs, sl_q, sl_kv, scale,
                       flags, k_trans)

@@ -316,6 +316,15 @@ def main(kind):
     for flags in (1, 0):
         o = nso.neref_flash_attn(qa, ka, va, hs ** -0.5, flags)
         assert nso.rel_l2(o, nso.attn_ref(qa, ka, va, hs ** -0.5, flags)) < 1e-3
+    # library-managed kv cache (llama.cpp:496-571): NE_TYPE_BTLA cache tensors sized by batch_kv_info, fp32 K / V appended by
+    # the update nodes (one call, or past rows then current rows at seq_off > 0), attention over views with the info strides
+    n_ctx = 16
+    kf = rng.standard_normal((bs_, slkv, hkv, hs)).astype(np.float32)
+    vf = rng.standard_normal((bs_, slkv, hkv, hs)).astype(np.float32)
+    want = nso.attn_ref(qa, kf.astype(np.float16), vf.astype(np.float16), hs ** -0.5, 1)
+    for split in (False, True):
+        o = nso.neref_reordered_attn(qa, kf, vf, n_ctx, hs ** -0.5, 1, split=split)
+        assert nso.rel_l2(o, want) < 1e-3, (split, nso.rel_l2(o, want))
     # ne_rms_norm / ne_norm nodes: their forwards call bestla_layernormalization unconditionally (ne_layers.c:4622)
     x = rng.standard_normal((5, 300)).astype(np.float32)
     xd = x.astype(np.float64)
