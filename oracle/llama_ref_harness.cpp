@@ -1,0 +1,105 @@
+/*
+ * llama_ref_harness.cpp — TEST INFRASTRUCTURE.  Flat C entry points over the reference's UNCHANGED model code:
+ *   /root/reference/neural_speed/models/llama/llama.cpp        (the graph builder, model_eval_internal :83-790)
+ *   /root/reference/neural_speed/models/llama/llama_utils.cpp  (Llama::init / ::load, the llama quant-layer rules)
+ *   /root/reference/neural_speed/models/model_utils/model_utils.cpp, model_files.h (context, kv-cache allocation, the NE
+ *       file reader incl. BTLA tensors :1177-1235, :1564-1571), quant_utils.cpp (model_quantize -> bestla_quantize
+ *       :269-354 -> BTLAGemmQuantPackB), application/common.cpp (quant_params helpers)
+ *   /root/reference/neural_speed/core/ne_layers.c              (the graph executor)
+ * all compiled from where they lie into oracle/_ref/libne_llama_ref.so (oracle/Makefile target nellama) with
+ * glue/shim in front of the include path (two shim headers replace the xbyak-dependent bestla_common.hpp /
+ * bestla_parallel.h) and the product's glue files (glue/ne_bestla_hip_glue.c, glue/bestla_gemm_hip.cpp) in place of
+ * core/layers/*.cpp.  Every bestla_* / ns_BTLAGemm* symbol binds at run time to whichever provider was loaded
+ * RTLD_GLOBAL first: libns_hip.so (the product, GPU) or tests/tools/oracle_bestla_provider.c (the CPU oracle).
+ *
+ * This is SURVEY section 8 (b)'s claim made executable: "existing model graphs ... keep working unchanged".
+ */
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "application/common.h"
+#include "models/model_utils/model_config.h"
+#include "models/model_utils/model_types.h"
+#include "models/model_utils/model_utils.h"
+#include "models/model_utils/quant_utils.h"
+
+extern "C" {
+
+/* what application/quant_model.cpp:37-72 does: f32 NE file -> BTLA-quantized NE file through the reference's quantizer
+ * driver.  Returns 0 on success. */
+int nellama_quantize(const char* in_path, const char* out_path, const char* weight_dtype, const char* alg, int group_size,
+                     const char* scale_dtype, const char* compute_dtype) {
+  model_init_backend();
+  quant_params q;
+  q.model_file = in_path;
+  q.out_file = out_path;
+  q.weight_dtype = weight_dtype;
+  q.alg = alg;
+  q.group_size = group_size;
+  q.scale_dtype = scale_dtype;
+  q.compute_dtype = compute_dtype;
+  q.model_name = "llama";
+  q.model_arch = model_name_to_arch::init().find(q.model_name);
+  q.nthread = 1;
+  auto ql = ql_registry::create_ql(q.model_name);
+  return model_quantize(q, ql);
+}
+
+/* Greedy generation the way application/main_run.cpp / main_pybind.cpp drive the model: one model_eval over the prompt,
+ * then one per new token with n_past advanced.  kv_type: 0 auto (the library-managed cache when
+ * bestla_reordered_attn_fp32_support says yes), 1 fp16, 2 fp32 (KV_MEM_TYPE, model_types.h:96-100).  out_tokens[n_new]; out_logits
+ * [(n_new) x n_vocab] = the logits each token was picked from (may be NULL).  Returns the number of tokens generated, < 0
+ * on failure. */
+int nellama_generate(const char* model_path, const int* prompt, int n_prompt, int n_new, int n_ctx, int kv_type,
+                     int* out_tokens, float* out_logits) {
+  model_init_backend();
+  model_context_params p = model_context_default_params();
+  p.arch = MODEL_LLAMA;
+  p.n_ctx = n_ctx;
+  p.seed = 1;
+  p.kv_type = static_cast<KV_MEM_TYPE>(kv_type);
+  p.use_mmap = false;
+  p.batch_size = 1;
+  p.max_request_num = 1;
+  p.beam_size = 1;
+  p.beam_search = false;
+  p.cont_batching = false;
+  p.scratch_size_ratio = 0.125f; /* llama_mem_req sizes its scratch for 7B+ models (llama.h:30-80) */
+  model_context* ctx = model_init_from_file(model_path, p);
+  if (!ctx) return -1;
+  const int n_vocab = model_n_vocab(ctx);
+  std::vector<model_token> toks(prompt, prompt + n_prompt);
+  int n_past = 0, n_total = 0, made = 0;
+  std::vector<model_token> cur = toks;
+  for (int step = 0; step < n_new; step++) {
+    model_input in;
+    in.tokens = cur.data();
+    in.n_tokens = static_cast<uint32_t>(cur.size());
+    in.n_prompt_tokens = static_cast<uint32_t>(n_prompt);
+    in.n_past = static_cast<uint32_t>(n_past);
+    in.n_total = static_cast<uint32_t>(n_total);
+    in.request_idx = 0;
+    in.beam_idx = 0;
+    fprintf(stderr, "nellama_generate: step %d, %zu token(s) at n_past %d\n", step, cur.size(), n_past);
+    if (model_eval(ctx, &in, 1, 1) != 0) {
+      model_free(ctx);
+      return -2;
+    }
+    n_past += static_cast<int>(cur.size());
+    n_total += static_cast<int>(cur.size());
+    const float* logits = model_get_logits(ctx);
+    int best = 0;
+    for (int i = 1; i < n_vocab; i++)
+      if (logits[i] > logits[best]) best = i;
+    if (out_logits) memcpy(out_logits + static_cast<size_t>(step) * n_vocab, logits, sizeof(float) * n_vocab);
+    out_tokens[made++] = best;
+    cur.assign(1, best);
+  }
+  model_free(ctx);
+  return made;
+}
+
+}  // extern "C"

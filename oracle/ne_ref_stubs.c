@@ -34,6 +34,16 @@ NE_REF_STUB(bestla_reordered_attn_fp32_forward)
 NE_REF_STUB(bestla_reordered_attn_fp32_shift_rope_k)
 NE_REF_STUB(bestla_reordered_attn_fp32_update_k)
 NE_REF_STUB(bestla_reordered_attn_fp32_update_v)
+NE_REF_STUB(bestla_reordered_attn_fp32_support)
+NE_REF_STUB(bestla_fusion_attn_fp32_batch_cpy_k)
+NE_REF_STUB(bestla_fusion_attn_fp32_batch_cpy_v)
+/* asked by the model graph builders (llama.cpp:212, :600) and the quantizer driver (through glue/bestla_gemm_hip.cpp) */
+NE_REF_STUB(bestla_fusion_QKV_f32f32_support)
+NE_REF_STUB(bestla_fusion_FFN_SiLu_f32f32_support)
+NE_REF_STUB(ns_BTLAGemmPackBSize)
+NE_REF_STUB(ns_BTLAGemmQuantPackB)
+NE_REF_STUB(ns_BTLAGemmPackB)
+NE_REF_STUB(ns_BTLAGemmUnPackB)
 /* operators of other reference source files, outside the path */
 NE_REF_STUB(ne_attention_padding_mask_f32_forward)
 NE_REF_STUB(ne_compute_forward_argsort)
@@ -43,6 +53,7 @@ NE_REF_STUB(ne_compute_forward_conv_1d_2s)
 
 /* size / set-up functions must be callable without a provider (graphs without BTLA nodes never need a workspace) */
 void bestla_init(void) {}
+void* bestla_get_thread_handle(void) { return 0; }
 int bestla_set_threads(int n) {
   (void)n;
   return 1;

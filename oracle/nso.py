@@ -57,6 +57,15 @@ def build(force=False):
         srcs = [os.path.join(HERE, f) for f in ("ne_ref_harness.c", "ne_ref_stubs.c")]
         if force or not os.path.exists(nref) or os.path.getmtime(nref) < max(os.path.getmtime(f) for f in srcs):
             subprocess.check_call(["make", "-C", HERE, "neref"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/neural_speed/models/llama/llama.cpp"):
+        lref = os.path.join(HERE, "_ref", "libne_llama_ref.so")
+        root = os.path.dirname(HERE)
+        srcs = [os.path.join(HERE, "llama_ref_harness.cpp"), os.path.join(HERE, "ne_ref_stubs.c"),
+                os.path.join(root, "glue", "ne_bestla_hip_glue.c"), os.path.join(root, "glue", "bestla_gemm_hip.cpp"),
+                os.path.join(root, "glue", "shim", "core", "layers", "bestla_common.hpp"),
+                os.path.join(root, "glue", "shim", "bestla", "bestla_parallel.h")]
+        if force or not os.path.exists(lref) or os.path.getmtime(lref) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", HERE, "nellama"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/bestla/bestla/bestla_storage.h"):
         sref = os.path.join(HERE, "_ref", "libstor_ref.so")
         if force or not os.path.exists(sref) or os.path.getmtime(sref) < os.path.getmtime(os.path.join(HERE, "stor_shim.cpp")):

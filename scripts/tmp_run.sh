@@ -1,7 +1,7 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_fuzz.py tests/test_gpu_decoder_layer.py -q -x 2>&1 | tail -4
-timeout 300 python scripts/config_bench.py 2>/dev/null > gpurun_out/cfg.json; python -c "
-import json; d=json.load(open('gpurun_out/cfg.json'))
-for k in ('config4_mistral7b_nf4_g128_batch8',):
-    v=d[k]; print(k, {a:b for a,b in v.items() if a!='per_shape'}); print('   ', {a:(b['us'], b.get('GBps')) for a,b in v['per_shape'].items()})
-"
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null
+time (NS_WORKER_WATCHDOG_S=60 timeout 90 python tests/tools/llama_model_worker.py oracle /tmp/llw f16 2 tmp_llama_q.bin > gpurun_out/llw2.out 2> gpurun_out/llw2.err)
+echo "rc=$?"
+grep "^llama\|OK\|Timeout" gpurun_out/llw2.out gpurun_out/llw2.err | tail

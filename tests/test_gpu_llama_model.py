@@ -1,0 +1,23 @@
+"""The reference's UNCHANGED llama model code (see tests/test_llama_model.py) on libns_hip.so: an fp32 NE file goes through
+the reference's quantizer driver with the product's quantizer underneath (blobs equal to the oracle's), the
+reference's loader reads it back, and its llama graph — fused QKV / FFN nodes, the library-managed kv cache
+(NE_TYPE_BTLA cache tensors, update_k / update_v, reordered attention) because bestla_reordered_attn_fp32_support answers
+true — generates greedily.  Pass = same tokens as the fp64 model AND as the same code on the CPU oracle provider."""
+import numpy as np
+import pytest
+
+from test_llama_model import run_worker
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("heads_kv", [4, 2])
+def test_reference_llama_generates_on_the_hip_library(tmp_path, nso, heads_kv):
+    out = run_worker("product", tmp_path, "auto", heads_kv)
+    assert "BTLA blobs equal to the oracle's" in out
+    # the same code and the same file with the CPU oracle answering (its own fp16 cache and unfused attention)
+    run_worker("oracle", tmp_path, "f16", heads_kv, given=tmp_path / ("llama_q_product_%d.bin" % heads_kv))
+    p = np.load(tmp_path / ("product_auto_%d.npz" % heads_kv))
+    o = np.load(tmp_path / ("oracle_f16_%d.npz" % heads_kv))
+    assert list(p["tokens"]) == list(o["tokens"])
+    assert nso.rel_l2(p["logits"], o["logits"]) < 5e-3

@@ -1,0 +1,49 @@
+"""The reference's UNCHANGED llama model code — graph builder models/llama/llama.cpp, loader llama_utils.cpp +
+model_utils/model_files.h (NE file reader, BTLA tensors), context / kv-cache set-up model_utils.cpp, graph executor
+core/ne_layers.c — compiled from where it lies into oracle/_ref/libne_llama_ref.so with glue/shim in front of the include
+path (oracle/Makefile target nellama) and run on a synthetic 22-layer int4 llama.  Here (no GPU) the CPU oracle answers the
+bestla_* calls; tests/test_gpu_llama_model.py runs the same code on libns_hip.so.  Pass = greedy tokens and logits of an
+independent fp64 model of the network."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_worker(mode, workdir, kv, heads_kv, given=None, timeout=900):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libne_llama_ref.so")) and not os.path.exists(
+            "/root/reference/neural_speed/models/llama/llama.cpp"):
+        pytest.skip("oracle/_ref/libne_llama_ref.so not built (reference tree absent)")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "llama_model_worker.py"), mode, str(workdir), kv,
+                        str(heads_kv)] + ([str(given)] if given else []), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "LLAMA_MODEL_%s_OK" % mode.upper() in r.stdout
+    return r.stdout
+
+
+@pytest.mark.parametrize("kv,heads_kv", [("f32", 4), ("f16", 2)])
+def test_reference_llama_on_the_oracle_provider(tmp_path, kv, heads_kv):
+    """heads_kv == heads takes the fused QKV node (ne_mul_qkv), heads_kv < heads three ne_mul_mat; both the fused FFN node;
+    lm_head through ne_mul_mat over a BTLA tensor; the model's own fp32 / fp16 kv cache and unfused attention"""
+    run_worker("oracle", tmp_path, kv, heads_kv)
+
+
+def test_glue_shim_headers_are_all_the_model_code_needs(tmp_path):
+    """models/llama/llama.cpp compiles against glue/shim + the reference's own headers (no xbyak, no JIT headers)"""
+    src = "/root/reference/neural_speed/models/llama/llama.cpp"
+    if not os.path.exists(src) or shutil.which("g++") is None:
+        pytest.skip("reference tree absent")
+    ref = "/root/reference"
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "glue", "shim"), "-I" + ref,
+                           "-I" + ref + "/neural_speed", "-I" + ref + "/neural_speed/core", "-I" + ref + "/bestla",
+                           "-I" + ref + "/bestla/bestla", "-H", src], stderr=open(tmp_path / "inc.txt", "w"))
+    included = open(tmp_path / "inc.txt").read()
+    assert "glue/shim/core/layers/bestla_common.hpp" in included and "glue/shim/bestla/bestla_parallel.h" in included
+    for banned in ("xbyak", "bestla_jit", "bestla_device", "bestla_prologue_b"):
+        assert banned not in included, banned

@@ -1,0 +1,223 @@
+"""Worker of tests/test_llama_model.py / tests/test_gpu_llama_model.py (fresh interpreter: the bestla_* provider must be
+loaded RTLD_GLOBAL before oracle/_ref/libne_llama_ref.so = the reference's UNCHANGED llama model code + graph executor,
+see oracle/llama_ref_harness.cpp).
+
+  llama_model_worker.py oracle  <workdir> <kv: auto|f16|f32> <heads_kv> [existing quantized file]
+      the CPU oracle answers the bestla_* calls; the quantized NE file is written here (nso.quant_pack blobs) unless one
+      is given (the GPU test hands over the file the product run produced)
+  llama_model_worker.py product <workdir> <kv> <heads_kv>
+      libns_hip.so answers them (GPU): an fp32 NE file goes through the reference's quantizer driver
+      (model_quantize -> bestla_quantize -> BTLAGemmQuantPackB -> glue/bestla_gemm_hip.cpp -> ns_BTLAGemmQuantPackB), the
+      resulting file's blobs must equal the oracle's byte for byte, then the reference's loader + llama graph generate
+Both: greedy generation, token ids and logits compared with an independent fp64 model of the network built from the
+dequantized weights; results saved to <workdir>/<mode>_<kv>_<heads_kv>.npz for the cross-provider comparison."""
+import ctypes as C
+import os
+
+# the CPU oracle's GEMMs are OpenMP loops over small matrices: a team as wide as a GPU host (hundreds of hardware threads,
+# possibly behind a CPU quota) spends its time in barriers — 40 s for one prompt step on the GPU box vs 1 s with 8 threads
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+import ne_file  # noqa: E402
+import nso  # noqa: E402
+
+V, D, HEADS, FF, LAYERS, N_CTX, EPS, BASE = 384, 256, 4, 704, 22, 64, 1e-5, 10000.0
+PROMPT = [1, 17, 200, 3, 99, 42, 311]   # bos first (llama.cpp:80-85 warns otherwise)
+N_NEW = 6
+KV = {"auto": 0, "f16": 1, "f32": 2}
+
+
+def make_model(heads_kv):
+    rng = np.random.default_rng(77)
+    hs = D // HEADS
+    dkv = hs * heads_kv
+    t = [("tok_embeddings.weight", (rng.standard_normal((V, D)) * 0.5).astype(np.float32)),
+         ("norm.weight", (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
+         ("output.weight", (rng.standard_normal((V, D)) * D ** -0.5).astype(np.float32))]
+    for i in range(LAYERS):
+        p = "layers.%d." % i
+        t += [(p + "attention_norm.weight", (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
+              (p + "attention.wq.weight", (rng.standard_normal((D, D)) * D ** -0.5).astype(np.float32)),
+              (p + "attention.wk.weight", (rng.standard_normal((dkv, D)) * D ** -0.5).astype(np.float32)),
+              (p + "attention.wv.weight", (rng.standard_normal((dkv, D)) * D ** -0.5).astype(np.float32)),
+              (p + "attention.wo.weight", (rng.standard_normal((D, D)) * 0.5 * D ** -0.5).astype(np.float32)),
+              (p + "ffn_norm.weight", (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
+              (p + "feed_forward.w1.weight", (rng.standard_normal((FF, D)) * D ** -0.5).astype(np.float32)),
+              (p + "feed_forward.w2.weight", (rng.standard_normal((D, FF)) * 0.5 * FF ** -0.5).astype(np.float32)),
+              (p + "feed_forward.w3.weight", (rng.standard_normal((FF, D)) * D ** -0.5).astype(np.float32))]
+    hp = dict(n_vocab=V, n_embd=D, n_mult=256, n_head=HEADS, n_head_kv=heads_kv, n_layer=LAYERS, n_rot=hs, ftype=0,
+              max_seq_len=N_CTX, ffn_hidden_size=FF, norm_eps=EPS, freq_base=BASE, freq_scale=1.0, rope_scaling_factor=0.0)
+    return hp, t
+
+
+def quantized(name, a):
+    """the llama quant-layer rule (llama_utils.cpp:259-295): 2-D '*weight' tensors except the token embedding"""
+    return a.ndim == 2 and name.endswith("weight") and name != "tok_embeddings.weight"
+
+
+def quantize_tensors(tensors):
+    out = []
+    for name, a in tensors:
+        if quantized(name, a):
+            blob = nso.quant_pack(a, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)  # int4 sym g32, bf16 scales, int8 compute
+            out.append((name, (blob, a.shape[0], a.shape[1])))
+        else:
+            out.append((name, a))
+    return out
+
+
+def same_blob(data, a):
+    """the blob of the file equals the oracle's in every byte a packer WRITES.  The alignment gaps between sections and the
+    tail of the reduce section are written by neither side (bestla_storage.h:85-109), and the quantizer driver packs into an
+    uninitialised buffer (quant_utils.cpp:411-413), so those hold whatever the allocator left: the written bytes are the
+    ones two oracle packs over differently pre-filled buffers agree on."""
+    b0 = nso.quant_pack(a, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB, fill=0x00)
+    b1 = nso.quant_pack(a, 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB, fill=0xFF)
+    got = np.frombuffer(data, np.uint8)
+    if got.size != b0.size:
+        return "size %d != %d" % (got.size, b0.size)
+    written = b0 == b1
+    bad = written & (got != b0)
+    return None if not bad.any() else "%d of %d written bytes differ, first at %d" % (int(bad.sum()), int(written.sum()), int(np.argmax(bad)))
+
+
+def weights_from_file(path):
+    """fp64 weights of the model the reference's loader will see: 2-D GEMM weights as [K][N], the embedding as [V][D]"""
+    _, tensors = ne_file.read(path)
+    deq = {}
+    for name, (typ, ne, data) in tensors.items():
+        if typ == ne_file.NE_TYPE_BTLA:
+            blob = nso.aligned_bytes(len(data))
+            blob[:] = np.frombuffer(data, np.uint8)
+            deq[name] = nso.unpack_fp32(blob).astype(np.float64)
+        elif typ == ne_file.NE_TYPE_Q4_0:
+            deq[name] = ne_file.dequant_q4_0(data, ne)
+        else:
+            deq[name] = np.frombuffer(data, np.float32).reshape(tuple(reversed(ne))).astype(np.float64)
+    return deq
+
+
+def model_fp64(deq, heads_kv, tokens, kv_fp16):
+    """logits of the LAST position"""
+    hs, T, grp = D // HEADS, len(tokens), HEADS // heads_kv
+
+    def rms(v, g):
+        return v / np.sqrt((v * v).mean(-1, keepdims=True) + EPS) * g
+
+    def rope(v):   # [T][h][hs], mode 0: adjacent pairs, positions 0..T-1
+        o = v.copy()
+        ts = BASE ** (-2.0 / hs)
+        for i in range(T):
+            th = i * ts ** np.arange(hs // 2)
+            c, s_ = np.cos(th), np.sin(th)
+            x0, x1 = v[i, :, 0::2], v[i, :, 1::2]
+            o[i, :, 0::2] = x0 * c - x1 * s_
+            o[i, :, 1::2] = x0 * s_ + x1 * c
+        return o
+    x = deq["tok_embeddings.weight"][tokens]
+    for i in range(LAYERS):
+        p = "layers.%d." % i
+        h = rms(x, deq[p + "attention_norm.weight"])
+        q = rope((h @ deq[p + "attention.wq.weight"]).reshape(T, HEADS, hs))
+        k = rope((h @ deq[p + "attention.wk.weight"]).reshape(T, heads_kv, hs))
+        v = (h @ deq[p + "attention.wv.weight"]).reshape(T, heads_kv, hs)
+        if kv_fp16:
+            k, v = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
+        att = np.zeros((T, HEADS, hs))
+        for hd in range(HEADS):
+            sc = (q[:, hd] @ k[:, hd // grp].T) / np.sqrt(hs)
+            sc = np.where(np.tril(np.ones((T, T), bool)), sc, -np.inf)
+            pr = np.exp(sc - sc.max(-1, keepdims=True))
+            att[:, hd] = (pr / pr.sum(-1, keepdims=True)) @ v[:, hd // grp]
+        x = x + att.reshape(T, D) @ deq[p + "attention.wo.weight"]
+        h2 = rms(x, deq[p + "ffn_norm.weight"])
+        g = h2 @ deq[p + "feed_forward.w1.weight"]
+        x = x + (g / (1 + np.exp(-g)) * (h2 @ deq[p + "feed_forward.w3.weight"])) @ deq[p + "feed_forward.w2.weight"]
+    return rms(x[-1:], deq["norm.weight"]) @ deq["output.weight"]
+
+
+def main(mode, workdir, kv, heads_kv, given=None):
+    heads_kv = int(heads_kv)
+    os.makedirs(workdir, exist_ok=True)
+    hp, tensors = make_model(heads_kv)
+    qt = quantize_tensors(tensors)
+    qpath = given or os.path.join(workdir, "llama_q_%s_%d.bin" % (mode, heads_kv))
+    if mode == "oracle":
+        so = os.path.join(tempfile.mkdtemp(), "liboracle_bestla.so")
+        nso.build()
+        subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "tools", "oracle_bestla_provider.c"),
+                               "-L" + os.path.join(ROOT, "oracle"), "-lns_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lm"])
+        provider = so
+    else:
+        import torch  # noqa: F401  (torch's HIP runtime first, as neural_speed_amd.lib() does)
+        provider = os.path.join(ROOT, "neural-speed_amd", "libns_hip.so")
+    C.CDLL(provider, mode=C.RTLD_GLOBAL)
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libne_llama_ref.so")
+    if not os.path.exists(lib_path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "nellama"], stdout=subprocess.DEVNULL)
+    ref = C.CDLL(lib_path)
+    if mode == "oracle":
+        if not given:
+            ne_file.write(qpath, dict(hp, ftype=ne_file.NE_FTYPE_MOSTLY_Q_BTLA), qt)
+    else:
+        # the reference's quantizer driver on the product's quantizer
+        fpath = os.path.join(workdir, "llama_f32_%d.bin" % heads_kv)
+        ne_file.write(fpath, hp, tensors)
+        ref.nellama_quantize.argtypes = [C.c_char_p] * 4 + [C.c_int] + [C.c_char_p] * 2
+        assert ref.nellama_quantize(fpath.encode(), qpath.encode(), b"int4", b"sym", 32, b"bf16", b"int8") == 0
+        hq, got = ne_file.read(qpath)
+        # (the saver writes the INPUT file's ftype: write_hparams ignores its new_ftype argument, model_files.h:1248-1257)
+        assert len(got) == len(qt), (len(got), len(qt))
+        n_blobs = 0
+        for name, t in qt:
+            typ, ne, data = got[name]
+            if isinstance(t, tuple):
+                assert typ == ne_file.NE_TYPE_BTLA and ne == (t[2], t[1]), name
+                why = same_blob(data, dict(tensors)[name])
+                assert why is None, "blob of %s differs from the oracle's: %s" % (name, why)
+                n_blobs += 1
+            elif name == "tok_embeddings.weight":
+                assert typ == ne_file.NE_TYPE_Q4_0   # the reference's own ggml quantizer (llama_utils.cpp:261-265)
+            else:
+                assert typ == ne_file.NE_TYPE_F32 and data == np.ascontiguousarray(t, np.float32).tobytes(), name
+        print("reference quantizer driver on libns_hip.so: %d BTLA blobs equal to the oracle's in every written byte" % n_blobs)
+    toks = (C.c_int * N_NEW)()
+    logits = np.zeros((N_NEW, V), np.float32)
+    prompt = (C.c_int * len(PROMPT))(*PROMPT)
+    ref.nellama_generate.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    sys.stdout.flush()
+    n = ref.nellama_generate(qpath.encode(), prompt, len(PROMPT), N_NEW, N_CTX, KV[kv], toks, logits.ctypes.data)
+    assert n == N_NEW, n
+    toks = list(toks)
+    deq = weights_from_file(qpath)
+    # independent fp64 model: same greedy tokens wherever its own top-1 margin is clear of the path's tolerance
+    seq, errs, margins = list(PROMPT), [], []
+    for i in range(N_NEW):
+        want = model_fp64(deq, heads_kv, seq, kv != "f32")[0]
+        errs.append(nso.rel_l2(logits[i], want))
+        top = np.sort(want)[-2:]
+        margins.append(float(top[1] - top[0]))
+        if margins[-1] > 0.05:
+            assert toks[i] == int(np.argmax(want)), (i, toks[i], int(np.argmax(want)), margins[-1])
+        seq.append(toks[i])
+    print("llama (%d layers, heads %d/%d, kv %s) through the reference's model code, %s provider: tokens %s, logits rel l2 vs fp64 "
+          "model max %.2e, top-1 margins %s" % (LAYERS, HEADS, heads_kv, kv, mode, toks, max(errs), ["%.2f" % m for m in margins]))
+    assert max(errs) < 1e-2, errs
+    np.savez(os.path.join(workdir, "%s_%s_%d.npz" % (mode, kv, heads_kv)), tokens=np.array(toks), logits=logits)
+    print("LLAMA_MODEL_%s_OK" % mode.upper())
+
+
+if __name__ == "__main__":
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("NS_WORKER_WATCHDOG_S", "150")), exit=True)   # a hang must not eat the box
+    main(*sys.argv[1:6])

@@ -10,6 +10,28 @@
 #include "../../oracle/ns_oracle.h"
 
 void bestla_init(void) {}
+void* bestla_get_thread_handle(void) {
+  static int handle;
+  return &handle;
+}
+/* the model graph builders ask before choosing the fused nodes (llama.cpp:212-215, :600-603) */
+static bool parses(void* w) {
+  nso_blob_info info;
+  return w && nso_blob_parse(w, &info) == 0;
+}
+bool bestla_fusion_QKV_f32f32_support(void* wq, void* wk, void* wv, int m, int n, int k) {
+  (void)m, (void)n, (void)k;
+  return parses(wq) && parses(wk) && parses(wv);
+}
+bool bestla_fusion_FFN_SiLu_f32f32_support(void* w1, void* w2, void* w3, int seq, int fin, int fmid, int fout) {
+  (void)seq, (void)fin, (void)fmid, (void)fout;
+  return parses(w1) && parses(w2) && parses(w3);
+}
+/* no library-managed kv cache on the CPU side: the model falls back to its own fp16 / fp32 cache and unfused attention */
+bool bestla_reordered_attn_fp32_support(const attn_shape_t* p) {
+  (void)p;
+  return false;
+}
 void bestla_timer(bool m) { (void)m; }
 int bestla_set_threads(int n) { return n > 0 ? n : 1; }
 unsigned long long bestla_f32f32_get_workspace_size(int m, int n, int k, void* w) {
