@@ -238,6 +238,209 @@ __global__ __launch_bounds__(kI8Threads) void i8ref_kernel(const I8RefParams p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same semantics on the matrix cores, for GEMM-sized calls (prefill): v_mfma_i32_16x16x32_i8 per 32-deep slice.
+//   sum_k (a - za)(q - zb) with  a' = a - 128 (the u8 code as an s8: a ^ 0x80),  u = stored code (nibble 0..15, i.e.
+//   q + 8; bytes: the raw s8 q), zbb = zb + 8 (nibbles) or zb (bytes):
+//       = [sum a' u]  +  (128 - za) * [sum u]  +  zbb * (32 za - [sum a])          every term an exact integer
+//   [sum a' u]  : one MFMA per (16 rows, 16 columns, slice); the 8 bytes a lane holds are exactly its record's codes
+//   [sum u]     : one more MFMA per slice with an all-ones A — every accumulator of a lane then holds its column's sum
+//   [sum a], za, scale_a : per (row, slice), computed once while the activation codes are staged into LDS
+// The fp32 side is the reference's: float(integer sum) * (scale_a * scale_b) accumulated per slice (ref_kblock_int8,
+// bestla/ut/bestla_gemm.cpp:159-190, accumulates per k-block; a k-block of 64 / 128 is two / four slices here — fp32
+// summation order is the only difference, as in the kernel above).
+// Workgroup = 4 waves = 64 rows x 64 columns: wave w owns column tile 4 bx + w and all four 16-row tiles; A is staged per
+// 512-deep chunk: [64 rows][512 + 16 pad] s8 (row stride shifted by four banks: ds_read_b64 of 16 rows x 2 k-groups is
+// conflict-free) + three [16 slices][64 rows] fp32 planes: 128 - za, 32 za - sum a, scale_a.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kGM = 64, kGChunk = 512, kGRowStride = kGChunk + 16, kGSlices = kGChunk / 32;
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+template <bool FOUR>
+__global__ __launch_bounds__(256) void i8mfma_kernel(const I8RefParams p) {
+  constexpr int NJ = FOUR ? 4 : 2;            // slices per k-step record
+  constexpr int CS = kGChunk / (32 * NJ);     // k-step records per chunk: 4 (128-deep) or 8 (64-deep)
+  extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+  unsigned char* a_lds = g_smem;                                                         // [kGM][kGRowStride]
+  int4v* meta = reinterpret_cast<int4v*>(g_smem + size_t(kGM) * kGRowStride);            // 3 planes [kGSlices][kGM] fp32
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nn = l & 15, g = l >> 4;
+  const int tile = blockIdx.x * 4 + w;
+  const bool tile_on = tile < (p.n + 15) / 16;
+  const int r0 = blockIdx.y * kGM;
+  const int zbias = FOUR ? 8 : 0;
+  const int sbytes = p.scale_dt == DT_F32 ? 4 : 2;
+  const int rec_sbytes = p.sps * sbytes;
+  const bool vec_ok = (p.k & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aq) & 7) == 0;
+  float acc[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[rt][i] = 0.f;
+  const long ones = 0x0101010101010101L;
+
+  for (int c0 = 0; c0 < p.ksteps; c0 += CS) {
+    // ---- this wave's weight records of the chunk: requested before the staging so that their latency hides behind it
+    uint4v rec[CS];
+    uint32_t sw[CS][4], zw[CS];
+#pragma unroll
+    for (int t = 0; t < CS; t++) {
+      const int s = c0 + t;
+      const bool on = tile_on && s < p.ksteps;
+      rec[t] = uint4v{0, 0, 0, 0};
+      sw[t][0] = sw[t][1] = sw[t][2] = sw[t][3] = 0, zw[t] = 0;
+      if (on) {
+        rec[t] = *reinterpret_cast<const uint4v*>(p.codes + (size_t(tile) * p.ksteps + s) * p.qstride + l * 16);
+        const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
+        const size_t crow = size_t(tile) * p.srows + srow;
+        const uint8_t* sp = p.scales + crow * p.sstride + size_t(nn) * rec_sbytes;
+        if (rec_sbytes == 16) {
+          const uint4v v = *reinterpret_cast<const uint4v*>(sp);
+          sw[t][0] = v.x, sw[t][1] = v.y, sw[t][2] = v.z, sw[t][3] = v.w;
+        } else if (rec_sbytes == 8) {
+          const uint2 v = *reinterpret_cast<const uint2*>(sp);
+          sw[t][0] = v.x, sw[t][1] = v.y;
+        } else if (rec_sbytes == 4) {
+          sw[t][0] = *reinterpret_cast<const uint32_t*>(sp);
+        } else {
+          sw[t][0] = *reinterpret_cast<const uint16_t*>(sp);
+        }
+        if (p.asym) {
+          const int8_t* zp = p.zps + crow * p.zstride + nn * p.sps;
+          for (int e = 0; e < p.sps; e++) zw[t] |= uint32_t(uint8_t(zp[e])) << (8 * e);
+        }
+      }
+    }
+    __syncthreads();  // the previous chunk is consumed
+    // ---- stage: one (row, slice) per thread and pass: 32 codes -> s8, permuted for the nibble container; the slice's
+    //      integer corrections and activation scale next to them
+    for (int idx = tid; idx < kGM * kGSlices; idx += 256) {
+      const int r = idx & (kGM - 1), q = idx / kGM;
+      const int k0 = c0 * (32 * NJ) + 32 * q;
+      const int row = r0 + r;
+      int4v mt = {0, 0, 0, 0};
+      uint2 out[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+      if (row < p.m && k0 < p.k) {
+        const int kb = min(k0 / p.blocksize, p.nblk - 1);
+        const int za = int(p.azp[size_t(row) * p.nblk + kb]);
+        const uint32_t zpad = p.azp[size_t(row) * p.nblk + (p.nblk - 1)];
+        const uint8_t* src = p.aq + size_t(row) * p.k + k0;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+          uint32_t lo, hi;
+          if (vec_ok && k0 + 8 * gq + 8 <= p.k) {
+            const uint2 v = *reinterpret_cast<const uint2*>(src + 8 * gq);
+            lo = v.x, hi = v.y;
+          } else {
+            uint32_t b[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) b[i] = (k0 + 8 * gq + i < p.k) ? uint32_t(src[8 * gq + i]) : zpad;
+            lo = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            hi = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+          }
+          sum = __builtin_amdgcn_udot4(lo, 0x01010101u, __builtin_amdgcn_udot4(hi, 0x01010101u, sum, false), false);
+          uint32_t d0 = lo, d1 = hi;
+          if (FOUR) {  // (a0,a4,a1,a5) and (a2,a6,a3,a7): the byte order of the nibble unpack
+            d0 = __builtin_amdgcn_perm(hi, lo, 0x05010400u);
+            d1 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+          }
+          out[gq] = uint2{d0 ^ 0x80808080u, d1 ^ 0x80808080u};
+        }
+        // a tail slice is padded with the row's last zero point: (a - za) vanishes there because kb is the last block
+        // (small integers: exact in fp32, and so is every sum of them the compute loop forms — all below 2^24)
+        mt.x = __builtin_bit_cast(int, float(128 - za));
+        mt.y = __builtin_bit_cast(int, float(32 * za - int(sum)));
+        mt.z = __builtin_bit_cast(int, p.ascale[size_t(row) * p.nblk + kb]);
+      }
+      unsigned char* dst = a_lds + size_t(r) * kGRowStride + 32 * q;
+#pragma unroll
+      for (int gq = 0; gq < 4; gq++) *reinterpret_cast<uint2*>(dst + 8 * gq) = out[gq];
+      // three planes [c1 | e | scale_a][slice][row]: a lane's four consecutive rows of one plane are one 16-byte read
+      float* mf = reinterpret_cast<float*>(meta);
+      mf[(0 * kGSlices + q) * kGM + r] = __builtin_bit_cast(float, int(mt.x));
+      mf[(1 * kGSlices + q) * kGM + r] = __builtin_bit_cast(float, int(mt.y));
+      mf[(2 * kGSlices + q) * kGM + r] = __builtin_bit_cast(float, int(mt.z));
+    }
+    __syncthreads();
+    if (!tile_on) continue;
+    // ---- compute
+#pragma unroll
+    for (int t = 0; t < CS; t++) {
+      const int s = c0 + t;
+      if (s >= p.ksteps) break;
+      const uint32_t xw[4] = {rec[t].x, rec[t].y, rec[t].z, rec[t].w};
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int k0 = s * (32 * NJ) + 32 * j;
+        if (k0 >= p.k) continue;
+        const int q = t * NJ + j;
+        const int e = (j * p.sps) / NJ;
+        auto pick = [&](int i) { return i == 0 ? sw[t][0] : (i == 1 ? sw[t][1] : (i == 2 ? sw[t][2] : sw[t][3])); };
+        float sb;
+        if (p.scale_dt == DT_F32) {
+          sb = __builtin_bit_cast(float, pick(e));
+        } else {
+          const uint32_t h = (pick(e >> 1) >> (16 * (e & 1))) & 0xffffu;
+          sb = p.scale_dt == DT_BF16 ? __builtin_bit_cast(float, h << 16) : f16_bits_to_f32(h);
+        }
+        const int zbb = (p.asym ? int(int8_t((zw[t] >> (8 * e)) & 0xffu)) : 0) + zbias;
+        uint32_t u0, u1;
+        if (FOUR) {
+          u0 = xw[j] & 0x0f0f0f0fu, u1 = (xw[j] >> 4) & 0x0f0f0f0fu;
+        } else {
+          u0 = xw[2 * j], u1 = xw[2 * j + 1];  // the raw s8 codes
+        }
+        const long b = long(uint64_t(u0) | (uint64_t(u1) << 32));
+        const int4v zero = {0, 0, 0, 0};
+        const int4v sv = __builtin_amdgcn_mfma_i32_16x16x32_i8(ones, b, zero, 0, 0, 0);  // column sum of the stored codes
+        int4v d[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) {  // the four row tiles back to back: their latency overlaps
+          const long a = *reinterpret_cast<const long*>(a_lds + size_t(rt * 16 + nn) * kGRowStride + 32 * q + 8 * g);
+          d[rt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, zero, 0, 0, 0);
+        }
+        const float suf = float(int(sv.x)), zbf = float(zbb);
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) {
+          const float* mf = reinterpret_cast<const float*>(meta) + q * kGM + rt * 16 + 4 * g;
+          const float4 c1 = *reinterpret_cast<const float4*>(mf);                         // 128 - za      of rows 4g .. 4g+3
+          const float4 ee = *reinterpret_cast<const float4*>(mf + kGSlices * kGM);        // 32 za - sum a
+          const float4 sa = *reinterpret_cast<const float4*>(mf + 2 * kGSlices * kGM);    // scale_a
+          const int dd[4] = {d[rt].x, d[rt].y, d[rt].z, d[rt].w};
+          const float c1v[4] = {c1.x, c1.y, c1.z, c1.w}, eev[4] = {ee.x, ee.y, ee.z, ee.w}, sav[4] = {sa.x, sa.y, sa.z, sa.w};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float isum = __builtin_fmaf(suf, c1v[i], __builtin_fmaf(zbf, eev[i], float(dd[i])));  // exact integer
+            acc[rt][i] = __builtin_fmaf(isum, sav[i] * sb, acc[rt][i]);
+          }
+        }
+      }
+    }
+  }
+  if (!tile_on) return;
+  const int col = tile * 16 + nn;
+  if (col >= p.n) return;
+#pragma unroll
+  for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = r0 + rt * 16 + 4 * g + i;
+      if (row >= p.m) continue;
+      float v = acc[rt][i];
+      const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
+      switch (p.epilogue) {
+        case 1: v = v + dv; break;
+        case 2: v = v * dv; break;
+        case 3: v = epi_gelu(v + dv); break;
+        case 4: v = epi_gelu(v); break;
+        case 5: v = epi_silu(v); break;
+        default: break;
+      }
+      p.c[size_t(row) * p.ldc + col] = v;
+      if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
+    }
+}
+
 }  // namespace
 
 bool i8ref_supported(const ns_weight* w) {
@@ -289,6 +492,20 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   p.epilogue = epilogue;
   p.d = d;
   p.ldd = ldd;
+  // GEMM-sized calls take the matrix-core kernel (NS_I8_MFMA_MIN_M rows and up, default 16; 0 disables it)
+  static const int mfma_min_m = [] {
+    const char* e = getenv("NS_I8_MFMA_MIN_M");
+    return e ? atoi(e) : 16;
+  }();
+  if (mfma_min_m > 0 && m >= mfma_min_m && (w->kstep_len == (p.nj == 4 ? 128 : 64))) {
+    const size_t lds = size_t(kGM) * kGRowStride + size_t(3) * kGSlices * kGM * 4;
+    const dim3 grid(unsigned((w->ntiles + 3) / 4), unsigned((m + kGM - 1) / kGM));
+    if (p.nj == 4)
+      hipLaunchKernelGGL(i8mfma_kernel<true>, grid, dim3(256), lds, st, p);
+    else
+      hipLaunchKernelGGL(i8mfma_kernel<false>, grid, dim3(256), lds, st, p);
+    return hipGetLastError();
+  }
   // LDS (<= 60 KiB): the row group's activation scales / zero points, then up to four rows of u8 codes per chunk
   const size_t corr_bytes = size_t(kI8Rows) * nblk * 8;
   if (corr_bytes > 40 * 1024) return hipErrorNotSupported;

@@ -43,6 +43,26 @@ def test_int8_mode_matches_reference_int8_semantics(L, pkg, nso, int8_mode, qt, 
     assert nso.rel_l2(out, ref) < 2e-6, nso.rel_l2(out, ref)
 
 
+@pytest.mark.parametrize("qt,st,asym,bs,n,k,core", CASES)
+@pytest.mark.parametrize("m", [16, 77, 200])
+def test_int8_mode_gemm_sized_calls_run_on_the_matrix_cores(L, pkg, nso, int8_mode, qt, st, asym, bs, n, k, core, m):
+    """16 rows and up take i8mfma_kernel (v_mfma_i32_16x16x32_i8 per 32-deep slice, exact integer corrections): the same
+    numbers as the decode-sized kernel — ragged M (row tiles of 16 inside workgroups of 64), ragged N, K tails, asymmetric
+    weights, byte containers, per-channel blocks"""
+    rng = np.random.default_rng(n * 7 + k * 3 + m)
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    a[m // 2] *= 30.0   # one row with a very different activation scale
+    blob = nso.quant_pack(w, bs, getattr(nso, qt), getattr(nso, st), asym, getattr(nso, core))
+    out = np.full((m, n), 7.0, np.float32)
+    L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(out), m, n, k, k, n, None)
+    ref = nso.gemm_u8s8(a, blob)
+    assert nso.rel_l2(out, ref) < 2e-6, nso.rel_l2(out, ref)
+    # row by row as well: a wrong row tile must not hide behind the large row
+    per_row = np.sqrt(((out - ref) ** 2).sum(-1) / np.maximum((ref.astype(np.float64) ** 2).sum(-1), 1e-30))
+    assert per_row.max() < 1e-5, (int(per_row.argmax()), per_row.max())
+
+
 def test_int8_mode_device_entries_and_epilogues(L, pkg, nso, int8_mode):
     import torch
     rng = np.random.default_rng(5)
