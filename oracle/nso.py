@@ -66,6 +66,12 @@ def build(force=False):
                 os.path.join(root, "glue", "shim", "bestla", "bestla_parallel.h")]
         if force or not os.path.exists(lref) or os.path.getmtime(lref) < max(os.path.getmtime(f) for f in srcs):
             subprocess.check_call(["make", "-C", HERE, "nellama"], stdout=subprocess.DEVNULL)
+        pref = os.path.join(HERE, "_ref", "llama_cpp.so")   # the reference's pybind module (needs pybind11's headers)
+        if force or not os.path.exists(pref) or os.path.getmtime(pref) < max(os.path.getmtime(f) for f in srcs[1:]):
+            try:
+                subprocess.check_call(["make", "-C", HERE, "nepy"], stdout=subprocess.DEVNULL)
+            except subprocess.CalledProcessError:
+                pass
     if os.path.exists("/root/reference/bestla/bestla/bestla_storage.h"):
         sref = os.path.join(HERE, "_ref", "libstor_ref.so")
         if force or not os.path.exists(sref) or os.path.getmtime(sref) < os.path.getmtime(os.path.join(HERE, "stor_shim.cpp")):
