@@ -76,6 +76,57 @@ def chain_time(shapes, qt, st_dt, bs, comp, m, nrep=3):
     return out, total_us, total_bytes
 
 
+def layer_chain(d_in, qn, kvn, o_k, ff_n, qt, st_dt, bs, comp, m, n_layers, min_bytes=700e6):
+    """The configuration's decode step the way bench.py times the headline chain: L DIFFERENT layers (enough of them to
+    exceed the 256 MB Infinity Cache several times) captured into ONE graph of fused launches — QKV (one launch, GQA
+    shapes included), attention-output projection, gate/up + down (the three-matrix FFN entry) — so that no launch pays a
+    graph-replay of its own and no weight is re-read from a cache.  The per-shape table above times every shape in
+    isolation (3 launches per replay: +2..3 us each) and is kept as the breakdown.
+    d_in: model width (K of q/k/v/w1/w3, N of wo/w2); qn / kvn: this rank's q and k/v widths; o_k: K of wo; ff_n: this
+    rank's FFN width.  Returns (us per layer, weight bytes per layer)."""
+    per_layer = None
+    layers = []
+    while True:
+        i = len(layers)
+        lw = {"q": make(qn, d_in, qt, st_dt, bs, comp, 100 + 8 * i)[0], "k": make(kvn, d_in, qt, st_dt, bs, comp, 101 + 8 * i)[0],
+              "v": make(kvn, d_in, qt, st_dt, bs, comp, 102 + 8 * i)[0], "o": make(d_in, o_k, qt, st_dt, bs, comp, 103 + 8 * i)[0],
+              "w1": make(ff_n, d_in, qt, st_dt, bs, comp, 104 + 8 * i)[0], "w3": make(ff_n, d_in, qt, st_dt, bs, comp, 105 + 8 * i)[0],
+              "w2": make(d_in, ff_n, qt, st_dt, bs, comp, 106 + 8 * i)[0]}
+        layers.append(lw)
+        per_layer = sum(w.stream_bytes for w in lw.values())
+        if per_layer * len(layers) >= min_bytes or len(layers) >= n_layers:
+            break
+    ldq = max(qn, kvn)
+    x = torch.randn((m, d_in), device="cuda")
+    xh = x.half()
+    qkv = torch.empty((3, m, ldq), device="cuda")
+    qkvh = torch.empty((3, m, ldq), device="cuda", dtype=torch.float16)
+    att = torch.empty((m, d_in), device="cuda")
+    atth = torch.empty((m, d_in), device="cuda", dtype=torch.float16)
+    t2 = torch.empty((m, ff_n), device="cuda")
+    t2h = torch.empty((m, ff_n), device="cuda", dtype=torch.float16)
+    y = torch.empty((m, d_in), device="cuda")
+    yh = torch.empty((m, d_in), device="cuda", dtype=torch.float16)
+
+    def fn(s=None):
+        s = s or C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        xi, xih = x, xh
+        for lw in layers:
+            pkg.check(L.ns_hip_fusion_qkv_forward_h(xi.data_ptr(), xih.data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h, qkv.data_ptr(),
+                                                    qkvh.data_ptr(), m, d_in, ldq, s))
+            # attention is its own operator; the first o_k columns of the q slice stand in for its output
+            pkg.check(L.ns_hip_f32f32_forward_h(qkv.data_ptr(), qkvh.data_ptr(), lw["o"].h, att.data_ptr(), atth.data_ptr(), m, ldq,
+                                                d_in, pkg.EPI_NONE, None, 0, s))
+            pkg.check(L.ns_hip_fusion_ffn3_forward_h(att.data_ptr(), atth.data_ptr(), lw["w1"].h, lw["w2"].h, lw["w3"].h, None,
+                                                     t2.data_ptr(), t2h.data_ptr(), y.data_ptr(), yh.data_ptr(), m, pkg.EPI_SILU, s))
+            xi, xih = y, yh
+    us = time_us(fn, reps=20) / len(layers)
+    for lw in layers:
+        for w in lw.values():
+            w.free()
+    return us, per_layer, len(layers)
+
+
 res = {}
 # ---- config 4: Mistral-7B NF4 g128 batch 8 (wk/wv are 1024 wide: GQA, QKV not fused — llama.cpp:215) ----
 nl = 32
@@ -85,6 +136,13 @@ per, us, byt = chain_time(shapes, pkg.F4_NF4, pkg.BF16, 128, pkg.COMP_BF16, 8)
 res["config4_mistral7b_nf4_g128_batch8"] = {"per_shape": per, "ms_per_step": round(us / 1e3, 4),
                                             "tokens_per_s": round(8 * 1e6 / us, 1), "weight_bytes": byt,
                                             "chain_GBps": round(byt / us / 1e3, 1)}
+lus, lbyt, nlay = layer_chain(4096, 4096, 1024, 4096, 14336, pkg.F4_NF4, pkg.BF16, 128, pkg.COMP_BF16, 8, nl)
+head = per["lm_head"]
+tot_us = lus * nl + head["us"]
+tot_b = lbyt * nl + head["GBps"] * 1e3 * head["us"]
+res["config4_mistral7b_nf4_g128_batch8"]["graph_chain"] = {
+    "layers_in_graph": nlay, "us_per_layer": round(lus, 2), "launches_per_layer": 4, "ms_per_step": round(tot_us / 1e3, 4),
+    "tokens_per_s": round(8 * 1e6 / tot_us, 1), "chain_GBps": round(tot_b / tot_us / 1e3, 1), "frac_of_8TBps": round(tot_b / tot_us / 8e6, 3)}
 # ---- config 5: Llama-2-70B Q4_0, one rank of TP = 8 (N or K divided by 8, model_files.h:145-190) ----
 nl = 80
 d, ff, kvd = 8192, 28672, 1024
@@ -94,6 +152,13 @@ per, us, byt = chain_time(shapes, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, 1)
 res["config5_llama70b_q4_0_rank_of_tp8"] = {"per_shape": per, "gemm_ms_per_token_per_rank": round(us / 1e3, 4),
                                             "weight_bytes_per_rank": byt, "chain_GBps": round(byt / us / 1e3, 1),
                                             "note": "GEMMs of one rank only; 160 all-reduces of 32 KB per token come on top"}
+lus, lbyt, nlay = layer_chain(d, d // 8, kvd // 8, d // 8, ff // 8, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, 1, nl)
+head = per["lm_head"]
+tot_us = lus * nl + head["us"]
+tot_b = lbyt * nl + head["GBps"] * 1e3 * head["us"]
+res["config5_llama70b_q4_0_rank_of_tp8"]["graph_chain"] = {
+    "layers_in_graph": nlay, "us_per_layer": round(lus, 2), "launches_per_layer": 4, "gemm_ms_per_token_per_rank": round(tot_us / 1e3, 4),
+    "chain_GBps": round(tot_b / tot_us / 1e3, 1), "frac_of_8TBps": round(tot_b / tot_us / 8e6, 3)}
 # ---- extra: Llama-2-7B fp8 weights (E4M3, shared-exponent E8M0 scales, g32), batch 1 decode and M = 2048 prefill ----
 nl = 32
 shapes = [("wq", 4096, 4096, 3 * nl), ("wo", 4096, 4096, nl), ("w1", 11008, 4096, 2 * nl), ("w2", 4096, 11008, nl),

@@ -1,5 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_attention.py tests/test_gpu_kvcache.py tests/test_gpu_decoder_layer.py tests/test_gpu_int8_mode.py -x -q 2>&1 | tail -4
-timeout 120 python scripts/attn_prefill_bench.py 2>&1 | tail -1 | tee gpurun_out/attn_prefill_vgprform.json
+timeout 400 python scripts/config_bench.py > gpurun_out/config_bench.json 2> gpurun_out/config_bench.err
+echo rc=$?; tail -5 gpurun_out/config_bench.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/config_bench.json"))
+for k in ("config4_mistral7b_nf4_g128_batch8", "config5_llama70b_q4_0_rank_of_tp8"):
+    print(k, {a: b for a, b in d[k].items() if a != "per_shape"})
+PY
