@@ -6,6 +6,7 @@
  *       file reader incl. BTLA tensors :1177-1235, :1564-1571), quant_utils.cpp (model_quantize -> bestla_quantize
  *       :269-354 -> BTLAGemmQuantPackB), application/common.cpp (quant_params helpers)
  *   /root/reference/neural_speed/core/ne_layers.c              (the graph executor)
+ * (and, built a second time with -DNS_FAMILY_NAME / _ARCH, models/gptj/gptj.cpp + gptj_utils.cpp -> libne_gptj_ref.so)
  * all compiled from where they lie into oracle/_ref/libne_llama_ref.so (oracle/Makefile target nellama) with
  * glue/shim in front of the include path (two shim headers replace the xbyak-dependent bestla_common.hpp /
  * bestla_parallel.h) and the product's glue files (glue/ne_bestla_hip_glue.c, glue/bestla_gemm_hip.cpp) in place of
@@ -26,6 +27,11 @@
 #include "models/model_utils/model_utils.h"
 #include "models/model_utils/quant_utils.h"
 
+#ifndef NS_FAMILY_NAME  /* oracle/Makefile builds this file once per model family: llama (default), gptj */
+#define NS_FAMILY_NAME "llama"
+#define NS_FAMILY_ARCH MODEL_LLAMA
+#endif
+
 extern "C" {
 
 /* what application/quant_model.cpp:37-72 does: f32 NE file -> BTLA-quantized NE file through the reference's quantizer
@@ -41,7 +47,7 @@ int nellama_quantize(const char* in_path, const char* out_path, const char* weig
   q.group_size = group_size;
   q.scale_dtype = scale_dtype;
   q.compute_dtype = compute_dtype;
-  q.model_name = "llama";
+  q.model_name = NS_FAMILY_NAME;
   q.model_arch = model_name_to_arch::init().find(q.model_name);
   q.nthread = 1;
   auto ql = ql_registry::create_ql(q.model_name);
@@ -57,7 +63,7 @@ int nellama_generate(const char* model_path, const int* prompt, int n_prompt, in
                      int* out_tokens, float* out_logits) {
   model_init_backend();
   model_context_params p = model_context_default_params();
-  p.arch = MODEL_LLAMA;
+  p.arch = NS_FAMILY_ARCH;
   p.n_ctx = n_ctx;
   p.seed = 1;
   p.kv_type = static_cast<KV_MEM_TYPE>(kv_type);

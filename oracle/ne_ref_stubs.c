@@ -40,6 +40,13 @@ NE_REF_STUB(bestla_fusion_attn_fp32_batch_cpy_v)
 /* asked by the model graph builders (llama.cpp:212, :600) and the quantizer driver (through glue/bestla_gemm_hip.cpp) */
 NE_REF_STUB(bestla_fusion_QKV_f32f32_support)
 NE_REF_STUB(bestla_fusion_FFN_SiLu_f32f32_support)
+NE_REF_STUB(bestla_fusion_FFN_GeLu_f32f32_support)
+NE_REF_STUB(bestla_fusion_FFN_Add_GeLu_f32f32_support)
+NE_REF_STUB(bestla_fusion_FFN_Gelu_Mul_f32f32_support)
+NE_REF_STUB(bestla_fusion_add_f32f32_support)
+NE_REF_STUB(bestla_fusion_attn_fp32_fp16_fp16_fp32_support)
+NE_REF_STUB(bestla_fusion_attn_fp16_support)
+NE_REF_STUB(bestla_fusion_attn_bf16_support)
 NE_REF_STUB(ns_BTLAGemmPackBSize)
 NE_REF_STUB(ns_BTLAGemmQuantPackB)
 NE_REF_STUB(ns_BTLAGemmPackB)

@@ -21,3 +21,16 @@ def test_reference_llama_generates_on_the_hip_library(tmp_path, nso, heads_kv):
     o = np.load(tmp_path / ("oracle_f16_%d.npz" % heads_kv))
     assert list(p["tokens"]) == list(o["tokens"])
     assert nso.rel_l2(p["logits"], o["logits"]) < 5e-3
+
+
+def test_reference_gptj_generates_on_the_hip_library(tmp_path, nso):
+    """models/gptj/gptj.cpp on libns_hip.so: fused QKV, the library-managed kv cache, ne_ffn_add_gelu
+    (bestla_fusion_FFN_Add_GeLu_f32f32_forward) and ne_mul_mat_with_bias (bestla_fusion_add_f32f32_forward) from a real
+    model graph; same tokens as the fp64 model and as the CPU oracle provider on the file the product's quantizer wrote"""
+    out = run_worker("product", tmp_path, "auto", 4, family="gptj")
+    assert "BTLA blobs equal to the oracle's" in out
+    run_worker("oracle", tmp_path, "f16", 4, given=tmp_path / "gptj_q_product_gptj.bin", family="gptj")
+    p = np.load(tmp_path / "product_auto_gptj.npz")
+    o = np.load(tmp_path / "oracle_f16_gptj.npz")
+    assert list(p["tokens"]) == list(o["tokens"])
+    assert nso.rel_l2(p["logits"], o["logits"]) < 5e-3

@@ -14,14 +14,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_worker(mode, workdir, kv, heads_kv, given=None, timeout=900):
+def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", timeout=900):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libne_llama_ref.so")) and not os.path.exists(
             "/root/reference/neural_speed/models/llama/llama.cpp"):
         pytest.skip("oracle/_ref/libne_llama_ref.so not built (reference tree absent)")
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "llama_model_worker.py"), mode, str(workdir), kv,
-                        str(heads_kv)] + ([str(given)] if given else []), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+                        str(heads_kv), str(given) if given else "-", family], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "LLAMA_MODEL_%s_OK" % mode.upper() in r.stdout
     return r.stdout
@@ -32,6 +32,13 @@ def test_reference_llama_on_the_oracle_provider(tmp_path, kv, heads_kv):
     """heads_kv == heads takes the fused QKV node (ne_mul_qkv), heads_kv < heads three ne_mul_mat; both the fused FFN node;
     lm_head through ne_mul_mat over a BTLA tensor; the model's own fp32 / fp16 kv cache and unfused attention"""
     run_worker("oracle", tmp_path, kv, heads_kv)
+
+
+@pytest.mark.parametrize("kv", ["f32", "f16"])
+def test_reference_gptj_on_the_oracle_provider(tmp_path, kv):
+    """a second family through its own unchanged graph builder (models/gptj/gptj.cpp): LayerNorm with bias, partial rotary,
+    parallel residual, the fused gelu(x W + b) W + b node (ne_ffn_add_gelu), lm_head through ne_mul_mat_with_bias"""
+    run_worker("oracle", tmp_path, kv, 4, family="gptj")
 
 
 def test_glue_shim_headers_are_all_the_model_code_needs(tmp_path):

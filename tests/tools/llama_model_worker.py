@@ -2,10 +2,10 @@
 loaded RTLD_GLOBAL before oracle/_ref/libne_llama_ref.so = the reference's UNCHANGED llama model code + graph executor,
 see oracle/llama_ref_harness.cpp).
 
-  llama_model_worker.py oracle  <workdir> <kv: auto|f16|f32> <heads_kv> [existing quantized file]
+  llama_model_worker.py oracle  <workdir> <kv: auto|f16|f32> <heads_kv> [existing quantized file | -] [family: llama | gptj]
       the CPU oracle answers the bestla_* calls; the quantized NE file is written here (nso.quant_pack blobs) unless one
       is given (the GPU test hands over the file the product run produced)
-  llama_model_worker.py product <workdir> <kv> <heads_kv>
+  llama_model_worker.py product <workdir> <kv> <heads_kv> [-] [family]
       libns_hip.so answers them (GPU): an fp32 NE file goes through the reference's quantizer driver
       (model_quantize -> bestla_quantize -> BTLAGemmQuantPackB -> glue/bestla_gemm_hip.cpp -> ns_BTLAGemmQuantPackB), the
       resulting file's blobs must equal the oracle's byte for byte, then the reference's loader + llama graph generate
@@ -60,9 +60,73 @@ def make_model(heads_kv):
     return hp, t
 
 
+GJ_LAYERS, GJ_ROT, GJ_FF = 28, 32, 4 * D   # gptj_mem_req knows 28 layers only (gptj.h:29-41); n_ff = 4 n_embd (gptj_utils.cpp:66)
+
+
+def make_model_gptj():
+    """GPT-J: LayerNorm with bias, rotary on the first n_rot dims of every head, attention and FFN both fed by ln_1(x) and
+    added to x (parallel residual), gelu(x W_in + b_in) W_out + b_out, lm_head with bias (tensor names of gptj_utils.cpp:113-144)"""
+    rng = np.random.default_rng(78)
+    vec = lambda n, s=0.1, m=0.0: (m + s * rng.standard_normal(n)).astype(np.float32)
+    t = [("transformer.wte.weight", (rng.standard_normal((V, D)) * 0.5).astype(np.float32)),
+         ("transformer.ln_f.weight", vec(D, 0.1, 1.0)), ("transformer.ln_f.bias", vec(D)),
+         ("lm_head.weight", (rng.standard_normal((V, D)) * D ** -0.5).astype(np.float32)), ("lm_head.bias", vec(V))]
+    for i in range(GJ_LAYERS):
+        p = "transformer.h.%d." % i
+        t += [(p + "ln_1.weight", vec(D, 0.1, 1.0)), (p + "ln_1.bias", vec(D)),
+              (p + "attn.q_proj.weight", (rng.standard_normal((D, D)) * D ** -0.5).astype(np.float32)),
+              (p + "attn.k_proj.weight", (rng.standard_normal((D, D)) * D ** -0.5).astype(np.float32)),
+              (p + "attn.v_proj.weight", (rng.standard_normal((D, D)) * D ** -0.5).astype(np.float32)),
+              (p + "attn.out_proj.weight", (rng.standard_normal((D, D)) * 0.4 * D ** -0.5).astype(np.float32)),
+              (p + "mlp.fc_in.weight", (rng.standard_normal((GJ_FF, D)) * D ** -0.5).astype(np.float32)), (p + "mlp.fc_in.bias", vec(GJ_FF)),
+              (p + "mlp.fc_out.weight", (rng.standard_normal((D, GJ_FF)) * 0.4 * GJ_FF ** -0.5).astype(np.float32)),
+              (p + "mlp.fc_out.bias", vec(D))]
+    hp = dict(n_vocab=V, n_embd=D, n_mult=256, n_head=HEADS, n_head_kv=HEADS, n_layer=GJ_LAYERS, n_rot=GJ_ROT, ftype=0,
+              max_seq_len=N_CTX, norm_eps=EPS, freq_base=BASE, freq_scale=1.0, rope_scaling_factor=0.0)
+    return hp, t
+
+
+def model_fp64_gptj(deq, tokens, kv_fp16):
+    hs, T = D // HEADS, len(tokens)
+
+    def ln(v, g, b):
+        mu = v.mean(-1, keepdims=True)
+        return (v - mu) / np.sqrt(((v - mu) ** 2).mean(-1, keepdims=True) + EPS) * g + b
+
+    def rope(v):   # [T][h][hs]: adjacent pairs of the first GJ_ROT dims only, positions 0..T-1
+        o = v.copy()
+        ts = BASE ** (-2.0 / GJ_ROT)
+        for i in range(T):
+            th = i * ts ** np.arange(GJ_ROT // 2)
+            c, s_ = np.cos(th), np.sin(th)
+            x0, x1 = v[i, :, 0:GJ_ROT:2], v[i, :, 1:GJ_ROT:2]
+            o[i, :, 0:GJ_ROT:2] = x0 * c - x1 * s_
+            o[i, :, 1:GJ_ROT:2] = x0 * s_ + x1 * c
+        return o
+    gelu = lambda x: 0.5 * x * (1 + np.tanh(0.7978845834732056 * (x + 0.044714998453855515 * x ** 3)))
+    x = deq["transformer.wte.weight"][tokens]
+    for i in range(GJ_LAYERS):
+        p = "transformer.h.%d." % i
+        h = ln(x, deq[p + "ln_1.weight"], deq[p + "ln_1.bias"])
+        q = rope((h @ deq[p + "attn.q_proj.weight"]).reshape(T, HEADS, hs))
+        k = rope((h @ deq[p + "attn.k_proj.weight"]).reshape(T, HEADS, hs))
+        v = (h @ deq[p + "attn.v_proj.weight"]).reshape(T, HEADS, hs)
+        if kv_fp16:
+            k, v = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
+        att = np.zeros((T, HEADS, hs))
+        for hd in range(HEADS):
+            sc = (q[:, hd] @ k[:, hd].T) / np.sqrt(hs)
+            sc = np.where(np.tril(np.ones((T, T), bool)), sc, -np.inf)
+            pr = np.exp(sc - sc.max(-1, keepdims=True))
+            att[:, hd] = (pr / pr.sum(-1, keepdims=True)) @ v[:, hd]
+        ffn = gelu(h @ deq[p + "mlp.fc_in.weight"] + deq[p + "mlp.fc_in.bias"]) @ deq[p + "mlp.fc_out.weight"] + deq[p + "mlp.fc_out.bias"]
+        x = x + att.reshape(T, D) @ deq[p + "attn.out_proj.weight"] + ffn
+    return ln(x[-1:], deq["transformer.ln_f.weight"], deq["transformer.ln_f.bias"]) @ deq["lm_head.weight"] + deq["lm_head.bias"]
+
+
 def quantized(name, a):
     """the llama quant-layer rule (llama_utils.cpp:259-295): 2-D '*weight' tensors except the token embedding"""
-    return a.ndim == 2 and name.endswith("weight") and name != "tok_embeddings.weight"
+    return a.ndim == 2 and name.endswith("weight") and name not in ("tok_embeddings.weight", "transformer.wte.weight")
 
 
 def quantize_tensors(tensors):
@@ -146,12 +210,14 @@ def model_fp64(deq, heads_kv, tokens, kv_fp16):
     return rms(x[-1:], deq["norm.weight"]) @ deq["output.weight"]
 
 
-def main(mode, workdir, kv, heads_kv, given=None):
+def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     heads_kv = int(heads_kv)
+    given = None if given in (None, "-") else given
     os.makedirs(workdir, exist_ok=True)
-    hp, tensors = make_model(heads_kv)
+    hp, tensors = make_model(heads_kv) if family == "llama" else make_model_gptj()
     qt = quantize_tensors(tensors)
-    qpath = given or os.path.join(workdir, "llama_q_%s_%d.bin" % (mode, heads_kv))
+    tag = "%d" % heads_kv if family == "llama" else family
+    qpath = given or os.path.join(workdir, "%s_q_%s_%s.bin" % (family, mode, tag))
     if mode == "oracle":
         so = os.path.join(tempfile.mkdtemp(), "liboracle_bestla.so")
         nso.build()
@@ -162,7 +228,7 @@ def main(mode, workdir, kv, heads_kv, given=None):
         import torch  # noqa: F401  (torch's HIP runtime first, as neural_speed_amd.lib() does)
         provider = os.path.join(ROOT, "neural-speed_amd", "libns_hip.so")
     C.CDLL(provider, mode=C.RTLD_GLOBAL)
-    lib_path = os.path.join(ROOT, "oracle", "_ref", "libne_llama_ref.so")
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libne_%s_ref.so" % family)
     if not os.path.exists(lib_path):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "nellama"], stdout=subprocess.DEVNULL)
     ref = C.CDLL(lib_path)
@@ -171,7 +237,7 @@ def main(mode, workdir, kv, heads_kv, given=None):
             ne_file.write(qpath, dict(hp, ftype=ne_file.NE_FTYPE_MOSTLY_Q_BTLA), qt)
     else:
         # the reference's quantizer driver on the product's quantizer
-        fpath = os.path.join(workdir, "llama_f32_%d.bin" % heads_kv)
+        fpath = os.path.join(workdir, "%s_f32_%s.bin" % (family, tag))
         ne_file.write(fpath, hp, tensors)
         ref.nellama_quantize.argtypes = [C.c_char_p] * 4 + [C.c_int] + [C.c_char_p] * 2
         assert ref.nellama_quantize(fpath.encode(), qpath.encode(), b"int4", b"sym", 32, b"bf16", b"int8") == 0
@@ -186,7 +252,7 @@ def main(mode, workdir, kv, heads_kv, given=None):
                 why = same_blob(data, dict(tensors)[name])
                 assert why is None, "blob of %s differs from the oracle's: %s" % (name, why)
                 n_blobs += 1
-            elif name == "tok_embeddings.weight":
+            elif name in ("tok_embeddings.weight", "transformer.wte.weight"):
                 assert typ == ne_file.NE_TYPE_Q4_0   # the reference's own ggml quantizer (llama_utils.cpp:261-265)
             else:
                 assert typ == ne_file.NE_TYPE_F32 and data == np.ascontiguousarray(t, np.float32).tobytes(), name
@@ -203,21 +269,22 @@ def main(mode, workdir, kv, heads_kv, given=None):
     # independent fp64 model: same greedy tokens wherever its own top-1 margin is clear of the path's tolerance
     seq, errs, margins = list(PROMPT), [], []
     for i in range(N_NEW):
-        want = model_fp64(deq, heads_kv, seq, kv != "f32")[0]
+        want = (model_fp64(deq, heads_kv, seq, kv != "f32") if family == "llama" else model_fp64_gptj(deq, seq, kv != "f32"))[0]
         errs.append(nso.rel_l2(logits[i], want))
         top = np.sort(want)[-2:]
         margins.append(float(top[1] - top[0]))
         if margins[-1] > 0.05:
             assert toks[i] == int(np.argmax(want)), (i, toks[i], int(np.argmax(want)), margins[-1])
         seq.append(toks[i])
-    print("llama (%d layers, heads %d/%d, kv %s) through the reference's model code, %s provider: tokens %s, logits rel l2 vs fp64 "
-          "model max %.2e, top-1 margins %s" % (LAYERS, HEADS, heads_kv, kv, mode, toks, max(errs), ["%.2f" % m for m in margins]))
+    print("%s (%d layers, heads %d/%d, kv %s) through the reference's model code, %s provider: tokens %s, logits rel l2 vs fp64 "
+          "model max %.2e, top-1 margins %s" % (family, LAYERS if family == "llama" else GJ_LAYERS, HEADS, heads_kv, kv, mode, toks,
+                                                max(errs), ["%.2f" % m for m in margins]))
     assert max(errs) < 1e-2, errs
-    np.savez(os.path.join(workdir, "%s_%s_%d.npz" % (mode, kv, heads_kv)), tokens=np.array(toks), logits=logits)
+    np.savez(os.path.join(workdir, "%s_%s_%s.npz" % (mode, kv, tag)), tokens=np.array(toks), logits=logits)
     print("LLAMA_MODEL_%s_OK" % mode.upper())
 
 
 if __name__ == "__main__":
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("NS_WORKER_WATCHDOG_S", "150")), exit=True)   # a hang must not eat the box
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])

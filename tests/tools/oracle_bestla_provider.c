@@ -27,6 +27,18 @@ bool bestla_fusion_FFN_SiLu_f32f32_support(void* w1, void* w2, void* w3, int seq
   (void)seq, (void)fin, (void)fmid, (void)fout;
   return parses(w1) && parses(w2) && parses(w3);
 }
+bool bestla_fusion_FFN_Add_GeLu_f32f32_support(void* w1, void* w2, int seq, int fin, int fmid, int fout) {
+  (void)seq, (void)fin, (void)fmid, (void)fout;
+  return parses(w1) && parses(w2);
+}
+bool bestla_fusion_add_f32f32_support(void* w, int m, int n, int k) {
+  (void)m, (void)n, (void)k;
+  return parses(w);
+}
+bool bestla_fusion_attn_fp32_fp16_fp16_fp32_support(const attn_shape_t* p) {
+  (void)p;
+  return true;
+}
 /* no library-managed kv cache on the CPU side: the model falls back to its own fp16 / fp32 cache and unfused attention */
 bool bestla_reordered_attn_fp32_support(const attn_shape_t* p) {
   (void)p;
@@ -75,6 +87,27 @@ void bestla_fusion_FFN_SiLu_f32f32_forward(float* a, void* w1, void* w2, void* w
   gemm(t2, fmid, w2, out, fout, seq, fout);
 }
 /* tmp1 = gelu(A*W1), tmp2 = (A*W3) * tmp1, out = tmp2 * W2 (ip_fusion_ffn.cpp, Gelu_Mul form) */
+static float gelu_tanh(float x) { return 0.5f * x * (1.f + tanhf(0.7978845834732056f * (x + 0.044714998453855515f * x * x * x))); }
+/* ne_bestla.h:36-38 / inner_product.cpp: output = A W + bias (bias row 0 for every row when boardcast_bias) */
+void bestla_fusion_add_f32f32_forward(float* a, void* w, float* bias, float* out, int m, int n, int k, int lda, int ldo,
+                                      bool boardcast_bias, void* ws) {
+  (void)k, (void)ws;
+  gemm(a, lda, w, out, ldo, m, n);
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < n; j++) out[(size_t)i * ldo + j] += bias[(boardcast_bias ? 0 : (size_t)i * n) + j];
+}
+/* ip_fusion_ffn.cpp: out = gelu(A W1 + b1) W2 + b2 */
+void bestla_fusion_FFN_Add_GeLu_f32f32_forward(float* a, void* w1, void* w2, float* b1, float* b2, float* t1, float* out, int seq,
+                                               int fin, int fmid, int fout, bool boardcast_bias, void* ws) {
+  (void)ws;
+  gemm(a, fin, w1, t1, fmid, seq, fmid);
+  for (int i = 0; i < seq; i++)
+    for (int j = 0; j < fmid; j++)
+      t1[(size_t)i * fmid + j] = gelu_tanh(t1[(size_t)i * fmid + j] + b1[(boardcast_bias ? 0 : (size_t)i * fmid) + j]);
+  gemm(t1, fmid, w2, out, fout, seq, fout);
+  for (int i = 0; i < seq; i++)
+    for (int j = 0; j < fout; j++) out[(size_t)i * fout + j] += b2[(boardcast_bias ? 0 : (size_t)i * fout) + j];
+}
 void bestla_fusion_FFN_Gelu_Mul_f32f32_forward(float* a, void* w1, void* w2, void* w3, float* t1, float* t2, float* out, int seq,
                                                int fin, int fmid, int fout, void* ws) {
   (void)ws;

@@ -49,7 +49,7 @@ def main(mode, workdir):
     # static quant-layer registry, which refuses a second registration: quant_config.h:206-211); that worker checks the
     # tokens and logits against the fp64 model
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "llama_model_worker.py"), mode, workdir, "auto",
-                        str(heads_kv), qpath], capture_output=True, text=True, timeout=300)
+                        str(heads_kv), qpath, "llama"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     want = [int(t) for t in np.load(os.path.join(workdir, "%s_auto_%d.npz" % (mode, heads_kv)))["tokens"]]
     C.CDLL(provider, mode=C.RTLD_GLOBAL)
