@@ -406,6 +406,9 @@ typedef struct attn_fp32_fp16_fp16_fp32_fwd_args_t {
 size_t bestla_fusion_attn_workspace_size(const attn_shape_t* params);
 /* mha_dense.h:85-86.  Host pointers: Q/K/V are uploaded, dst downloaded, synchronous (reference semantics). */
 bool bestla_fusion_attn_fp32_fp16_fp16_fp32_support(const attn_shape_t* params);
+/* mha_dense.h:106 — the all-fp16 variant (fp16 Q and dst) has one caller, compiled out by its own switch
+ * (models/gptj/gptj.cpp:42-43, :141); declined, so that such a build still links: Q and dst are fp32 in every graph */
+bool bestla_fusion_attn_fp16_support(const attn_shape_t* params);
 void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp32_fwd_args_t* params);
 /* The library-managed ("reordered") kv-cache, mha_dense.h:124-172.  The reference hands the cache to BesTLA as an opaque
  * buffer — sizes and view strides from batch_kv_info, contents only through update_k / update_v / shift_rope_k /

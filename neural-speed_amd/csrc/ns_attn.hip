@@ -812,6 +812,8 @@ bool bestla_fusion_attn_fp32_fp16_fp16_fp32_support(const attn_shape_t* s) {
   return attn_shape_ok(s->head_num, s->heads_kv, s->head_size, s->sl_q, s->sl_kv, false, &why);
 }
 
+bool bestla_fusion_attn_fp16_support(const attn_shape_t*) { return false; }  // mha_dense.h:106: fp16 Q / dst form, not offered
+
 bool bestla_reordered_attn_fp32_support(const attn_shape_t* params) {
   // mha_dense.cpp:70-80 answers by CPU features; here: whatever the attention kernels take (fp16 cache, see below)
   std::string why;
