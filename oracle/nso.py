@@ -76,6 +76,13 @@ def build(force=False):
         sref = os.path.join(HERE, "_ref", "libstor_ref.so")
         if force or not os.path.exists(sref) or os.path.getmtime(sref) < os.path.getmtime(os.path.join(HERE, "stor_shim.cpp")):
             subprocess.check_call(["make", "-C", HERE, "storref"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/bestla/bestla/kernel_avx512f.h"):
+        aref = os.path.join(HERE, "_ref", "libkernel_avx_ref.so")
+        if force or not os.path.exists(aref) or os.path.getmtime(aref) < os.path.getmtime(os.path.join(HERE, "avx_shim.cpp")):
+            try:
+                subprocess.check_call(["make", "-C", HERE, "avxref"], stdout=subprocess.DEVNULL)
+            except subprocess.CalledProcessError:
+                pass   # a compiler without the AVX512 intrinsics: the comparison test skips
     if os.path.exists("/root/reference/bestla/bestla/kernel_ref.h"):
         ref = os.path.join(HERE, "_ref", "libkernel_ref.so")
         if force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(os.path.join(HERE, "ref_shim.cpp")):

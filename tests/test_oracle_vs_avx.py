@@ -1,0 +1,93 @@
+"""The oracle (= the reference's SCALAR kernels, bit for bit: tests/test_oracle_vs_ref.py) against the reference's VECTOR
+kernels — kernel_avx512f.h / kernel_avx2.h compiled from where they lie into oracle/_ref/libkernel_avx_ref.so
+(oracle/Makefile avxref) — for the two quantizers that kernel_wrapper.h:546-603 sends to the vector ISA on an AVX512 / AVX2
+host: the F4 weight quantizer and the u8 activation quantizer of the int8-compute path.  (The integer weight quantizer
+always runs the scalar kernel, :540-543.)  The product follows the scalar kernels; this file records how far the
+vector kernels are from them, so that "bit-exact with the reference" is a statement about a named kernel."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def avx(nso):
+    flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
+    if "avx512f" not in flags or "avx512bw" not in flags:
+        pytest.skip("no AVX512 on this host")
+    so = os.path.join(HERE, "..", "oracle", "_ref", "libkernel_avx_ref.so")
+    if not os.path.exists(so):
+        if not os.path.exists("/root/reference/bestla/bestla/kernel_avx512f.h"):
+            pytest.skip("oracle/_ref/libkernel_avx_ref.so not built (reference tree absent)")
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "..", "oracle"), "avxref"], stdout=subprocess.DEVNULL)
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("f4", ["F4_NF4", "F4_BNB", "F4_E2M1"])
+def test_f4_weight_quantizer_avx512_is_a_different_encoder(nso, avx, f4):
+    """What an AVX512 host writes for an F4 weight is NOT the scalar kernel's bits, by construction
+    (kernel_avx512f.h:1189-1196, :1082-1148 vs kernel_ref.h:1802-1822):
+      * the block scale keeps the SIGN of the largest-magnitude element (vrangeps imm 7: absolute max, sign of the selected
+        operand, the later element on a tie) where the scalar kernel stores |max| — same magnitude bit for bit;
+      * x / scale is x * rcp14(scale), a 14-bit table reciprocal, where the scalar kernel multiplies by the exact 1.f / absmax;
+      * codes come from sixteen (eight) sequential `<=` threshold tests instead of the scalar decision tree.
+    Both are valid encodings of the same format — the dequantizer is LUT[code] * scale either way — and the product (like the
+    oracle) reproduces the scalar one, the only one defined without an ISA-specific approximation table.  What must hold for
+    a drop-in: blobs from EITHER encoder load and compute correctly (negative scales: tests/test_gpu_parity.py), and the two
+    encodings reconstruct the weights equally well — checked here."""
+    qt = getattr(nso, f4)
+    rng = np.random.default_rng(3)
+    k, n, bs = 256, 64, 32
+    nf = nso.lib().nso_f4_unpack
+    nf.restype = C.c_float
+    lut = np.array([nf(C.c_uint32(qt), c) for c in range(16)], np.float32)
+    for w in ((rng.standard_normal((k, n)) * 0.02).astype(np.float32), rng.uniform(-0.5, 0.5, (k, n)).astype(np.float32)):
+        q, sc, _ = nso.quantize(w, bs, qt)
+        q2, sc2 = np.zeros_like(q), np.zeros_like(sc)
+        assert avx.avx512_quantize_f4(nso.ptr(w), nso.ptr(q2), k, n, n, n, nso.ptr(sc2), bs, C.c_uint32(qt)) == 0
+        # same magnitude, sign of the block's largest element
+        assert np.array_equal(np.abs(sc2).view(np.uint32), sc.view(np.uint32))
+        wb = w.reshape(k // bs, bs, n)
+        big = np.take_along_axis(wb, np.abs(wb).argmax(1)[:, None, :], 1)[:, 0, :]
+        assert np.array_equal(np.signbit(sc2), np.signbit(big))
+        assert np.signbit(sc2).mean() > 0.3          # i.e. about half of the blocks
+        # reconstruction: both encodings are equally close to the weights (the signed one a little closer: its largest element
+        # always lands on the exact code 1.0)
+        deq = lambda qq, ss: lut[qq.astype(np.int64) & 15] * np.repeat(ss, bs, axis=0)
+        e_scalar = np.linalg.norm(deq(q, sc) - w) / np.linalg.norm(w)
+        e_avx = np.linalg.norm(deq(q2, sc2) - w) / np.linalg.norm(w)
+        print("%s: rel. reconstruction error scalar %.4f, avx512 %.4f; codes equal on %.1f %% of the positive-scale blocks" % (
+            f4, e_scalar, e_avx, 100 * (q == q2)[np.repeat(~np.signbit(sc2), bs, axis=0)].mean()))
+        assert e_avx < e_scalar * 1.02 and e_scalar < e_avx * 1.10
+        # where the scale came out positive the two encoders see the same normalised values up to rcp14's 2^-14: codes agree
+        # except next to a threshold
+        pos = np.repeat(~np.signbit(sc2), bs, axis=0)
+        assert (q == q2)[pos].mean() > 0.995
+
+
+@pytest.mark.parametrize("isa", ["avx512", "avx2"])
+def test_u8_activation_quantizer_vector_kernels_vs_scalar(nso, avx, isa):
+    """quantize_fp_u8_colblock: scales and zero points of the vector kernels == scalar (same min / max reductions); the
+    CODES may differ by one where (x - min) / scale lands within an ulp of .5 (the vector kernels multiply by a reciprocal
+    and round to nearest-even in the cvt instruction, the scalar kernel divides and uses roundf) — measured and bounded."""
+    rng = np.random.default_rng(8)
+    m, k, bs = 64, 4096, 32
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    nb = k // bs
+    f = getattr(avx, "%s_quantize_fp_u8_colblock" % isa)
+    outs = []
+    for fn in (nso.lib().nso_quantize_fp_u8_colblock, f):
+        aq, asc, azp, red = np.zeros((m, k), np.uint8), np.zeros((m, nb), np.float32), np.zeros((m, nb), np.uint8), np.zeros((m, nb), np.float32)
+        fn(m, k, nso.ptr(a), k, nso.ptr(aq), k, nso.ptr(asc), nb, nso.ptr(azp), bs, nso.ptr(red))
+        outs.append((aq, asc, azp, red))
+    (aq, asc, azp, red), (aq2, asc2, azp2, red2) = outs
+    assert np.array_equal(asc.view(np.uint32), asc2.view(np.uint32)), "scales differ"
+    assert np.array_equal(azp, azp2), "zero points differ"
+    d = np.abs(aq.astype(np.int32) - aq2.astype(np.int32))
+    frac = float((d != 0).mean())
+    print("%s u8 activation codes differing from the scalar kernel: %.4f %% (max |diff| %d)" % (isa, 100 * frac, d.max()))
+    assert d.max() <= 1 and frac < 5e-3
