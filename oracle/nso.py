@@ -451,6 +451,46 @@ def gemv_u8s8(a, blob, nthreads=0):
     return c
 
 
+_avx = None
+
+
+def avxref():
+    """oracle/_ref/libkernel_avx_ref.so (the reference's AVX512 / AVX2 kernels, oracle/avx_shim.cpp) or None when it is
+    not built or this CPU lacks AVX512-VNNI"""
+    global _avx
+    if _avx is None:
+        _avx = False
+        so = os.path.join(HERE, "_ref", "libkernel_avx_ref.so")
+        try:
+            flags = open("/proc/cpuinfo").read()
+        except OSError:
+            flags = ""
+        if os.path.exists(so) and all(f in flags for f in ("avx512f", "avx512bw", "avx512vl", "avx512dq", "avx512_vnni")):
+            _avx = C.CDLL(so)
+            _avx.avx512vnni_gemv_4bit_u8s8.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_void_p]
+    return _avx or None
+
+
+def gemv_u8s8_avx512vnni(a, blob, nthreads=0, _scratch={}):
+    """one row through the REFERENCE's own decode kernels on this CPU: avx512f::quantize_fp_u8_colblock +
+    avx512f::vnni::gemv_4bit_u8s8_fp32<ScaleT, 48, 1> per 48-column tile (int4 blobs of the AVX512_VNNI k-block core, fp32 or
+    bf16 scales), tiles over OpenMP threads.  -> [1][n] fp32"""
+    bi = parse(blob)
+    assert a.shape[0] == 1 and bi.ntile == 48 and bi.packrow == 4 and bi.scale_dtype in (F32, BF16)
+    c = _scratch.get(("c", bi.npad))
+    if c is None:
+        c = _scratch[("c", bi.npad)] = np.zeros((1, bi.npad), np.float32)
+    sc = _scratch.get(("s", bi.k))
+    if sc is None:
+        sc = _scratch[("s", bi.k)] = np.zeros(bi.k + 128 + 8 * nblk(bi.k, bi.blocksize), np.uint8)
+    base = blob.ctypes.data
+    rc = avxref().avx512vnni_gemv_4bit_u8s8(ptr(a), base + bi.q_off, base + bi.scale_off, int(bi.scale_dtype == BF16),
+                                            base + bi.zp_off if bi.is_asym else None, bi.cstep, bi.kpad, bi.n, bi.k, bi.blocksize,
+                                            ptr(c), nthreads, ptr(sc))
+    assert rc == 0
+    return c[:, :bi.n]
+
+
 def _blob_table(blobs):
     ptrs = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
     sizes = (C.c_size_t * len(blobs))(*[b.size for b in blobs])

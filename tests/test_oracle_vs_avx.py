@@ -91,3 +91,19 @@ def test_u8_activation_quantizer_vector_kernels_vs_scalar(nso, avx, isa):
     frac = float((d != 0).mean())
     print("%s u8 activation codes differing from the scalar kernel: %.4f %% (max |diff| %d)" % (isa, 100 * frac, d.max()))
     assert d.max() <= 1 and frac < 5e-3
+
+
+@pytest.mark.parametrize("n,k,bs,st,asym", [(4096, 4096, 32, "BF16", False), (200, 1024, 128, "F32", True), (688, 2048, 64, "BF16", True)])
+def test_reference_avx512_vnni_decode_gemv_equals_the_oracle(nso, avx, n, k, bs, st, asym):
+    """the reference's real decode hot loop (avx512f::vnni::gemv_4bit_u8s8_fp32 per 48-column tile, fed by its AVX512 activation
+    quantizer) on the oracle's blobs == the oracle's restatement of the scalar gemv_4bit_u8s8_fp32: the blob layout the
+    product packs is the one the reference's vector kernels read, and the int8-compute numbers the oracle defines are theirs
+    (1e-6: fp32 summation order + the activation codes that differ by one, see above)"""
+    if nso.avxref() is None:
+        pytest.skip("no AVX512-VNNI on this host")
+    rng = np.random.default_rng(n + k)
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    a = rng.standard_normal((1, k)).astype(np.float32)
+    blob = nso.quant_pack(w, bs, nso.S4, getattr(nso, st), asym, nso.CORE_AVX512_VNNI_KB)
+    got = nso.gemv_u8s8_avx512vnni(a, blob, 4).copy()
+    assert nso.rel_l2(got, nso.gemv_u8s8(a, blob, 4)) < 5e-6
