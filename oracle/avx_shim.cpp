@@ -44,6 +44,26 @@ int avx512_quantize_fp_u8_colblock(int row, int col, const float* src, int ld_sr
                                                                       blocksize, blkreduce);
 }
 
+/* fp8 weight tile -> fp32 with the scale applied (what the AVX512 product path dequantizes with, kernel_avx512f.h:653-720):
+ * ONE call over a whole tile, the kernel itself steps the scale row every `kblock` packed rows */
+int avx512_decompress_kblock_f8_fp(uint32_t f8type, int packrow, int8_t* src, float* dst, int row, int col, void* scales,
+                                   int scale_is_e8m0, int k_offset, int kblock, int npad) {
+  namespace k = bestla::kernel::avx512f;
+#define NS_F8(P)                                                                                                          \
+  do {                                                                                                                    \
+    if (scale_is_e8m0)                                                                                                    \
+      return (int)k::decompress_kblock_f8_fp<true, float, P, utils::f8>((utils::f8*)src, dst, row, col, col, col,          \
+                                                                        (utils::f8*)scales, k_offset, kblock, npad,        \
+                                                                        (BTLA_DTYPE)f8type);                               \
+    return (int)k::decompress_kblock_f8_fp<true, float, P, float>((utils::f8*)src, dst, row, col, col, col, (float*)scales, \
+                                                                  k_offset, kblock, npad, (BTLA_DTYPE)f8type);             \
+  } while (0)
+  if (packrow == 1) NS_F8(1);
+  if (packrow == 2) NS_F8(2);
+#undef NS_F8
+  return -1;
+}
+
 int avx2_quantize_fp_u8_colblock(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
                                  int ld_scale, uint8_t* zps, int blocksize, float* blkreduce) {
   return (int)bestla::kernel::avx2::quantize_fp_u8_colblock<float>(row, col, src, ld_src, dst, ld_dst, scales, ld_scale, zps,

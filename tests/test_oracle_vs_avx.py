@@ -107,3 +107,32 @@ def test_reference_avx512_vnni_decode_gemv_equals_the_oracle(nso, avx, n, k, bs,
     blob = nso.quant_pack(w, bs, nso.S4, getattr(nso, st), asym, nso.CORE_AVX512_VNNI_KB)
     got = nso.gemv_u8s8_avx512vnni(a, blob, 4).copy()
     assert nso.rel_l2(got, nso.gemv_u8s8(a, blob, 4)) < 5e-6
+
+
+@pytest.mark.parametrize("f8", ["F8_E4M3", "F8_E5M2"])
+@pytest.mark.parametrize("st", ["F8_E8M0", "F32"])
+@pytest.mark.parametrize("core,packrow", [("CORE_AVX512F", 1), ("CORE_AMX_BF16", 2)])
+def test_f8_unpack_equals_the_avx512_tile_dequant_in_one_call(nso, avx, f8, st, core, packrow):
+    """the oracle's (and the product's) fp8 unpack == avx512f::decompress_kblock_f8_fp over a WHOLE tile in one call: the
+    vector kernel advances the scale row per k-block itself (sptr = scales + kpos * NPad) for both scale types — the form the
+    scalar kernel only reproduces when it is called one k-block at a time (its fp32-scale branch drops the k-block offset,
+    kernel_ref.h:1017-1018; tests/test_oracle_vs_ref.py)"""
+    rng = np.random.default_rng(77)
+    n, k, bs = 96, 256, 32
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    blob = nso.quant_pack(w, bs, getattr(nso, f8), getattr(nso, st), False, getattr(nso, core))
+    bi = nso.parse(blob)
+    mine = nso.unpack_fp32(blob)
+    nt = bi.ntile
+    sbytes = 1 if st == "F8_E8M0" else 4
+    for t in range(bi.npad // nt):
+        tile = np.ascontiguousarray(blob[bi.q_off + t * nt * bi.kpad: bi.q_off + (t + 1) * nt * bi.kpad]).view(np.int8)
+        # this tile's scale columns with the blob's own row stride: the kernel is told NPad = cstep
+        sc = np.ascontiguousarray(blob[bi.scale_off + t * nt * sbytes: bi.scale_off + bi.scale_bytes])
+        dst = np.zeros((bi.kpad // packrow, nt * packrow), np.float32)
+        rc = avx.avx512_decompress_kblock_f8_fp(C.c_uint32(getattr(nso, f8)), packrow, nso.ptr(tile), nso.ptr(dst), bi.kpad // packrow,
+                                                nt * packrow, nso.ptr(sc), int(st == "F8_E8M0"), 0, bs // packrow, bi.cstep)
+        assert rc == 0
+        deq = dst.reshape(bi.kpad // packrow, nt, packrow).transpose(0, 2, 1).reshape(bi.kpad, nt)
+        cols = min(nt, bi.n - t * nt)
+        assert np.array_equal(mine[:, t * nt:t * nt + cols].view(np.uint32), deq[:bi.k, :cols].view(np.uint32))
