@@ -319,10 +319,14 @@ __global__ void pack_codes_kernel(TiledSrc src, uint8_t* __restrict__ out, size_
   }
 }
 
-// reduce[kb][n] = bf16( sum_k float(code - zp) * stored_scale ), sequential fp32 sum (row_reduce_sum)
+// reduce[kb][n] = bf16( sum_k float(code - zp) * stored_scale ), sequential fp32 sum (row_reduce_sum).
+// The reference's reduceWeight dequantises the blob it has just written (bestla_prologue_b.h:455-470), i.e. the codes as
+// the bit planes hold them: the canonical codes for every type except S1, where compress_1bit stores element 1's bit in
+// place of element 4's in every group of eight PACKED elements (kernel_ref.h:355).  `s1`: read position p - 3 of the tiled
+// image for a position p with p % 8 == 4 (`ts` maps tiled positions back to the canonical array).
 __global__ void reduce_kernel(const int8_t* __restrict__ q, size_t sk, size_t sn, const uint8_t* __restrict__ sblob,
                               const int8_t* __restrict__ zblob, uint16_t* __restrict__ rblob, size_t n, size_t k,
-                              int bs, size_t cstep, uint32_t stype) {
+                              int bs, size_t cstep, uint32_t stype, TiledSrc ts, bool s1) {
   const size_t nblk = (k + bs - 1) / bs;
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (gid >= nblk * n) return;
@@ -337,7 +341,15 @@ __global__ void reduce_kernel(const int8_t* __restrict__ q, size_t sk, size_t sn
   const int z = zblob ? zblob[kb * cstep + col] : 0;
   float tmp = 0.f;
   const size_t kend = min(k, (kb + 1) * size_t(bs));
-  for (size_t kk = kb * bs; kk < kend; kk++) tmp = __fadd_rn(tmp, __fmul_rn(float(int(q[kk * sk + col * sn]) - z), s));
+  for (size_t kk = kb * bs; kk < kend; kk++) {
+    int code = int(q[kk * sk + col * sn]);
+    if (s1) {
+      const size_t p = (col / ts.ntile) * size_t(ts.ntile) * ts.kpad + (kk / ts.packrow) * size_t(ts.ntile) * ts.packrow +
+                       (col % ts.ntile) * ts.packrow + kk % ts.packrow;
+      if ((p & 7) == 4) code = ts.at(p - 3);
+    }
+    tmp = __fadd_rn(tmp, __fmul_rn(float(code - z), s));
+  }
   rblob[kb * cstep + col] = f32_to_bf16_ref(tmp);
 }
 
@@ -362,7 +374,7 @@ hipError_t pack_sections(const int8_t* q, size_t sk, size_t sn, const float* sca
   hipLaunchKernelGGL(pack_codes_kernel, grid1d(elts / 8, 256), dim3(256), 0, st, ts, q_out, elts, qtype);
   if (has_reduce)
     hipLaunchKernelGGL(reduce_kernel, grid1d(rawnk * n, 256), dim3(256), 0, st, q, sk, sn, (const uint8_t*)s_out,
-                       (const int8_t*)z_out, r_out, n, k, bs, size_t(cstep), stype);
+                       (const int8_t*)z_out, r_out, n, k, bs, size_t(cstep), stype, ts, dt_is_int(qtype) && dt_bits(qtype) == 1);
   return hipGetLastError();
 }
 

@@ -729,7 +729,12 @@ static int pack_q_impl(void* blob, const int8_t* q, int ldq, const float* scales
   nso_compress(tiled.data(), base + bi.q_off, tiled.size(), qtype);
   // reduce[kb][n] = sum over the block's rows of the DEQUANTISED weight (stored-precision scale), fp32 sequential
   // sum (row_reduce_sum, kernel_ref.h:2132-2142) -> bf16.  Padded columns are left untouched, as in the reference.
+  // reduceWeight (:455-470) dequantises the blob it has just WRITTEN (unpackWeight), i.e. the codes as the bit planes hold
+  // them: identical to q for every type except S1, where compress_1bit stores element 1's bit in place of element 4's in
+  // every group of eight PACKED elements (kernel_ref.h:355) — so the codes are read back from the compressed image.
   if (bi.has_reduce) {
+    std::vector<int8_t> stored(tiled.size());
+    nso_decompress(base + bi.q_off, stored.data(), stored.size(), qtype);
     uint16_t* rp = (uint16_t*)(base + bi.red_off);
     for (int c = 0; c < n; c++)
       for (int kb = 0; kb < rawnk; kb++) {
@@ -737,7 +742,7 @@ static int pack_q_impl(void* blob, const int8_t* q, int ldq, const float* scales
         float s = scale_to_f32(sp, stype, size_t(kb) * bi.npad + c);
         int z = bi.is_asym ? zps[size_t(kb) * n + c] : 0;
         for (int kk = kb * bi.blocksize; kk < std::min(k, (kb + 1) * bi.blocksize); kk++)
-          tmp += float(int(q[size_t(kk) * ldq + c]) - z) * s;
+          tmp += float(int(stored[tiled_index(bi, kk, c)]) - z) * s;
         rp[size_t(kb) * bi.cstep + c] = nso_f32_to_bf16(tmp);
       }
   }

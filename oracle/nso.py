@@ -83,6 +83,14 @@ def build(force=False):
                 subprocess.check_call(["make", "-C", HERE, "avxref"], stdout=subprocess.DEVNULL)
             except subprocess.CalledProcessError:
                 pass   # a compiler without the AVX512 intrinsics: the comparison test skips
+    if os.path.exists("/root/reference/bestla/bestla/bestla_prologue_b.h"):
+        pref = os.path.join(HERE, "_ref", "libpack_ref.so")
+        srcs = [os.path.join(HERE, f) for f in ("pack_shim.cpp", "standins/kernel_jit.h", "standins/xbyak/xbyak_util.h")]
+        if force or not os.path.exists(pref) or os.path.getmtime(pref) < max(os.path.getmtime(f) for f in srcs):
+            try:
+                subprocess.check_call(["make", "-C", HERE, "packref"], stdout=subprocess.DEVNULL)
+            except subprocess.CalledProcessError:
+                pass   # a compiler without the AVX512 intrinsics: the comparison test skips
     if os.path.exists("/root/reference/bestla/bestla/kernel_ref.h"):
         ref = os.path.join(HERE, "_ref", "libkernel_ref.so")
         if force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(os.path.join(HERE, "ref_shim.cpp")):
