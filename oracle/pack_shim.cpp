@@ -70,6 +70,29 @@ int do_pack(void* blob, const float* w, int n, int k, int ldw, int bs, BTLA_DTYP
   return 0;
 }
 
+// BTLAGemmPackBImpl (bestla_gemm.cpp:400-422): pre-quantized codes [K][N], fp32 scales / zero points [nblk][N], optional
+// GPTQ act-order group indices (enableShuffle + setShuffleIndices), integer weights
+template <class CoreT>
+int do_pack_q(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k, int bs, BTLA_DTYPE qt,
+              BTLA_DTYPE st, bool asym, int* g_idx) {
+  parallel::SingleThread th;
+  using P = prologue_b::gemm::WeightKBlockNInteger<CoreT>;
+  auto stor = P::createStorage(n, k, bs, qt, st, BTLA_DTYPE::BF16, asym);
+  if (g_idx) P::enableShuffle(&stor);
+  stor.assign(reinterpret_cast<int8_t*>(blob));
+  if (g_idx) P::setShuffleIndices(g_idx, &stor, &th);
+  P::packQWeight(n, k, q, ldq, scales, asym ? zps : nullptr, &stor, &th);
+  return 0;
+}
+
+template <class CoreT>
+size_t do_size_gidx(int n, int k, int bs, BTLA_DTYPE q, BTLA_DTYPE s, bool asym) {
+  using P = prologue_b::gemm::WeightKBlockNInteger<CoreT>;
+  auto stor = P::createStorage(n, k, bs, q, s, BTLA_DTYPE::BF16, asym);
+  P::enableShuffle(&stor);
+  return stor.mSize;
+}
+
 template <class CoreT>
 int do_unpack(void* blob, float* out, int ld, bool is_float) {
   parallel::SingleThread th;
@@ -115,6 +138,18 @@ int packref_quant_pack(void* blob, const float* w, int n, int k, int ldw, int bl
                        int core, int is_trans) {
   NS_CORE_SWITCH(core, return do_pack<CT>(blob, w, n, k, ldw, blocksize, (BTLA_DTYPE)qtype, (BTLA_DTYPE)stype, asym != 0, is_trans != 0));
   return -1;
+}
+
+/* BTLAGemmPackB (integer weights): codes [K][N] (ld = ldq), scales / zps [nblk][N]; g_idx (may be NULL): group of input channel k */
+int packref_pack_q(void* blob, const int8_t* q, int ldq, const float* scales, const int8_t* zps, int n, int k, int blocksize,
+                   uint32_t qtype, uint32_t stype, int asym, int core, int* g_idx) {
+  NS_CORE_SWITCH(core, return do_pack_q<CT>(blob, q, ldq, scales, zps, n, k, blocksize, (BTLA_DTYPE)qtype, (BTLA_DTYPE)stype, asym != 0, g_idx));
+  return -1;
+}
+
+size_t packref_size_gidx(int n, int k, int blocksize, uint32_t qtype, uint32_t stype, int asym, int core) {
+  NS_CORE_SWITCH(core, return do_size_gidx<CT>(n, k, blocksize, (BTLA_DTYPE)qtype, (BTLA_DTYPE)stype, asym != 0));
+  return 0;
 }
 
 /* BTLAGemmUnPackB: blob -> fp32 [K][N] */

@@ -92,6 +92,34 @@ def worker(isa):
                     assert P.packref_unpack(nso.ptr(mine), nso.ptr(out), n, core, int(is_flt)) == 0
                     if not np.array_equal(out.view(np.uint32), nso.unpack_fp32(mine).view(np.uint32)):
                         bad.append((core, qn, sn, asym, bs, n, k, "unpack differs"))
+    # BTLAGemmPackB: pre-quantized codes, with and without GPTQ act-order group indices (ShuffleIndices section)
+    P.packref_pack_q.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_uint32] * 2 + [C.c_int] * 2 + [C.c_void_p]
+    P.packref_size_gidx.restype = C.c_size_t
+    P.packref_size_gidx.argtypes = [C.c_int] * 3 + [C.c_uint32] * 2 + [C.c_int] * 2
+    for core in (1, 2, 4, 7):
+        for qn, asym, bs in (("S4", False, 32), ("S4", True, 64), ("S8", False, 32), ("S3", False, 32), ("S2", True, 64)):
+            for use_gidx in (False, True):
+                n, k = 72, 256
+                qt = getattr(nso, qn)
+                if bs % [1, 1, 32, 32, 4, 4, 4, 4, 64][core]:
+                    continue
+                w = (rng.standard_normal((k, n)) * 0.02).astype(np.float32)
+                q, sc, zp = nso.quantize(w, bs, qt, asym)
+                g_idx = rng.permutation(np.repeat(np.arange(k // bs), bs)).astype(np.int32) if use_gidx else None
+                mine = nso.pack_q(q, sc, zp, bs, qt, nso.BF16, core, fill=0, g_idx=g_idx)
+                size = (P.packref_size_gidx if use_gidx else P.packref_size)(n, k, bs, qt, nso.BF16, int(asym), core)
+                if size != mine.size:
+                    bad.append((core, qn, "BF16", asym, bs, n, k, "pack_q size %d != %d" % (size, mine.size)))
+                    continue
+                n_cases += 1
+                b0, b1 = nso.aligned_bytes(size, fill=0), nso.aligned_bytes(size, fill=0xFF)
+                for buf in (b0, b1):
+                    assert P.packref_pack_q(nso.ptr(buf), nso.ptr(q), n, nso.ptr(sc), nso.ptr(zp), n, k, bs, qt, nso.BF16, int(asym), core,
+                                            nso.ptr(g_idx)) == 0
+                diff = (b0 == b1) & (b0 != mine)
+                if diff.any():
+                    bad.append((core, qn, "BF16", asym, bs, n, k, "pack_q%s: %d written bytes differ, first at %d" % (
+                        " + g_idx" if use_gidx else "", int(diff.sum()), int(np.argmax(diff)))))
     print("PACKREF_RESULT " + json.dumps({"cases": n_cases, "bad": bad}))
 
 
