@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_worker(mode, workdir, timeout=600):
+def run_worker(mode, workdir, extra=(), timeout=600):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "llama_cpp.so")) and not os.path.exists(
             "/root/reference/neural_speed/application/main_pybind.cpp"):
         pytest.skip("oracle/_ref/llama_cpp.so not built (reference tree absent)")
@@ -22,7 +22,7 @@ def run_worker(mode, workdir, timeout=600):
         pytest.skip("no gcc")
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "llama_cpp.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "nellama", "nepy"], stdout=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "python_api_worker.py"), mode, str(workdir)],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "python_api_worker.py"), mode, str(workdir)] + list(extra),
                        capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "PYTHON_API_%s_OK" % mode.upper() in r.stdout
@@ -34,3 +34,9 @@ def test_reference_python_model_generate_on_the_oracle_provider(tmp_path):
         pytest.skip("the reference's Python package is not on this box")
     out = run_worker("oracle", tmp_path)
     assert "neural_speed.Model.generate(): [[1, 17, 200, 3, 99, 42, 311," in out
+
+
+def test_reference_beam_search_on_the_oracle_provider(tmp_path):
+    """num_beams = 2 through the pybind Model (model_utils.cpp beam_search: batched evals, kv reorder between beams)"""
+    out = run_worker("oracle", tmp_path, extra=("beam",))
+    assert "BEAM_TOKENS [" in out

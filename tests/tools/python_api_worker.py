@@ -30,6 +30,35 @@ import ne_file  # noqa: E402
 import nso  # noqa: E402
 
 
+def beam(mode, workdir):
+    """beam search (2 beams) through the pybind Model: model_utils.cpp's beam_search drives batched evals of both beams, the
+    kv-cache reorder between beams (bestla_fusion_attn_fp32_batch_cpy_k / _v when the cache is the library's) and the batch-2
+    attention.  Prints BEAM_TOKENS; the GPU test compares the product's sequence with the oracle provider's."""
+    os.makedirs(workdir, exist_ok=True)
+    hp, tensors = lw.make_model(4)
+    qpath = os.path.join(workdir, "llama_q_beam.bin")
+    ne_file.write(qpath, dict(hp, ftype=ne_file.NE_FTYPE_MOSTLY_Q_BTLA), lw.quantize_tensors(tensors))
+    if mode == "oracle":
+        so = os.path.join(tempfile.mkdtemp(), "liboracle_bestla.so")
+        nso.build()
+        subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "tools", "oracle_bestla_provider.c"),
+                               "-L" + os.path.join(ROOT, "oracle"), "-lns_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lm"])
+        provider = so
+    else:
+        import torch  # noqa: F401
+        provider = os.path.join(ROOT, "neural-speed_amd", "libns_hip.so")
+    C.CDLL(provider, mode=C.RTLD_GLOBAL)
+    spec = importlib.util.spec_from_file_location("neural_speed.llama_cpp", os.path.join(ROOT, "oracle", "_ref", "llama_cpp.so"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    m = mod.Model()
+    m.init_model(qpath, max_new_tokens=lw.N_NEW, ctx_size=lw.N_CTX, threads=1, num_beams=2, do_sample=False, scratch_size_ratio=0.125,
+                 early_stopping=True)
+    r = m.generate(input_ids=[list(lw.PROMPT)])
+    print("BEAM_TOKENS %s" % list(r[0]))
+    print("PYTHON_API_%s_OK beam" % mode.upper())
+
+
 def main(mode, workdir):
     os.makedirs(workdir, exist_ok=True)
     heads_kv = 4
@@ -86,4 +115,4 @@ def main(mode, workdir):
 if __name__ == "__main__":
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("NS_WORKER_WATCHDOG_S", "150")), exit=True)
-    main(*sys.argv[1:3])
+    (beam if len(sys.argv) > 3 and sys.argv[3] == "beam" else main)(*sys.argv[1:3])
