@@ -497,6 +497,7 @@ def main():
                                            "logits_rel_l2_fused_vs_unfused": round(rel, 6)}
             out["config"]["prefill_m2048_tflops"] = prefill_tflops(chain, pkg)
             out["config"]["prefill_m2048_tflops_int8w"] = prefill_tflops_int8w(chain, pkg)
+            out["config"]["prefill_m2048_tflops_ref_int8_semantics"] = prefill_tflops_ref_int8(chain, pkg)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.layers)
         print(json.dumps(out))
@@ -742,6 +743,18 @@ def roofline(chain, pkg):
         "avg_launch_us": round(us, 3),
         "note": "avg over %d back-to-back graph launches incl. ~1.2us inter-kernel boundary each" % (reps * nl),
     }
+
+
+def prefill_tflops_ref_int8(chain, pkg, m=2048):
+    """the same seven GEMMs (int4 g32 weights) in the reference's DEFAULT int8-compute semantics (NS_COMPUTE_REF_INT8: u8
+    activation quantization per k-block + exact integer dots on the int8 matrix cores, ns_i8ref.hip i8mfma_kernel); the
+    activation quantizer is inside the timed region.  TFLOPS-equivalent (2 m n k)."""
+    L = pkg.lib()
+    prev = L.ns_hip_set_compute_mode(1)
+    try:
+        return prefill_tflops(chain, pkg, m)
+    finally:
+        L.ns_hip_set_compute_mode(prev if prev in (0, 1) else 0)
 
 
 def prefill_tflops(chain, pkg, m=2048):
