@@ -108,4 +108,61 @@ int nellama_generate(const char* model_path, const int* prompt, int n_prompt, in
   return made;
 }
 
+/* Continuous batching the way the reference's serving loop evaluates it (models/llama/llama.cpp:66-70, :330-350, :496-571:
+ * batch_size == n_input requests concatenated into ONE graph without padding, per-request RoPE offsets, kv-cache blocks per
+ * request, attention per group of requests that share (n_tokens, n_past)): two requests, greedy, every eval carries both —
+ * the two prompts first, then one token each at its own n_past.  out_tokens [2][n_new], out_logits [2][n_new][n_vocab] (or
+ * NULL).  Returns n_new, < 0 on failure. */
+int nellama_generate2(const char* model_path, const int* prompt0, int n0, const int* prompt1, int n1, int n_new, int n_ctx,
+                      int kv_type, int* out_tokens, float* out_logits) {
+  model_init_backend();
+  model_context_params p = model_context_default_params();
+  p.arch = NS_FAMILY_ARCH;
+  p.n_ctx = n_ctx;
+  p.seed = 1;
+  p.kv_type = static_cast<KV_MEM_TYPE>(kv_type);
+  p.use_mmap = false;
+  p.batch_size = 2;
+  p.max_request_num = 2;
+  p.beam_size = 1;
+  p.beam_search = false;
+  p.cont_batching = true;
+  p.scratch_size_ratio = 0.125f;
+  model_context* ctx = model_init_from_file(model_path, p);
+  if (!ctx) return -1;
+  const int n_vocab = model_n_vocab(ctx);
+  std::vector<model_token> cur[2] = {std::vector<model_token>(prompt0, prompt0 + n0), std::vector<model_token>(prompt1, prompt1 + n1)};
+  const int n_prompt[2] = {n0, n1};
+  int n_past[2] = {0, 0};
+  for (int step = 0; step < n_new; step++) {
+    model_input in[2];
+    for (int r = 0; r < 2; r++) {
+      in[r].tokens = cur[r].data();
+      in[r].n_tokens = static_cast<uint32_t>(cur[r].size());
+      in[r].n_prompt_tokens = static_cast<uint32_t>(n_prompt[r]);
+      in[r].n_past = static_cast<uint32_t>(n_past[r]);
+      in[r].n_total = static_cast<uint32_t>(n_past[r]);
+      in[r].request_idx = r;
+      in[r].beam_idx = 0;
+    }
+    if (model_eval(ctx, in, 2, 1) != 0) {
+      model_free(ctx);
+      return -2;
+    }
+    const float* logits = model_get_logits(ctx);  // [2][n_vocab]: the last position of every request
+    for (int r = 0; r < 2; r++) {
+      n_past[r] += static_cast<int>(cur[r].size());
+      const float* lr = logits + static_cast<size_t>(r) * n_vocab;
+      int best = 0;
+      for (int i = 1; i < n_vocab; i++)
+        if (lr[i] > lr[best]) best = i;
+      if (out_logits) memcpy(out_logits + (static_cast<size_t>(r) * n_new + step) * n_vocab, lr, sizeof(float) * n_vocab);
+      out_tokens[r * n_new + step] = best;
+      cur[r].assign(1, best);
+    }
+  }
+  model_free(ctx);
+  return n_new;
+}
+
 }  // extern "C"

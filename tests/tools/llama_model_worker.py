@@ -281,6 +281,29 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
                                                 max(errs), ["%.2f" % m for m in margins]))
     assert max(errs) < 1e-2, errs
     np.savez(os.path.join(workdir, "%s_%s_%s.npz" % (mode, kv, tag)), tokens=np.array(toks), logits=logits)
+    if family == "llama" and os.environ.get("NS_WORKER_CONT_BATCH", "1") != "0":
+        # continuous batching: two requests per eval (concatenated, no padding; llama.cpp:66-70, :330-350, :496-571) must
+        # reproduce what each request generates alone — prompts of different lengths (two attention groups of one request)
+        # and of equal length (one group of two: the kv update / attention entries see batch 2)
+        ref.nellama_generate2.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p]
+
+        def alone(p_):
+            tk = (C.c_int * N_NEW)()
+            lg = np.zeros((N_NEW, V), np.float32)
+            assert ref.nellama_generate(qpath.encode(), (C.c_int * len(p_))(*p_), len(p_), N_NEW, N_CTX, KV[kv], tk, lg.ctypes.data) == N_NEW
+            return list(tk), lg
+        for pb in ([1, 5, 77, 130, 9], [1, 300, 12, 250, 7, 64, 199]):
+            tk2 = (C.c_int * (2 * N_NEW))()
+            lg2 = np.zeros((2, N_NEW, V), np.float32)
+            assert ref.nellama_generate2(qpath.encode(), prompt, len(PROMPT), (C.c_int * len(pb))(*pb), len(pb), N_NEW, N_CTX, KV[kv],
+                                         tk2, lg2.ctypes.data) == N_NEW
+            tb, lb = alone(pb)
+            assert list(tk2)[:N_NEW] == toks and list(tk2)[N_NEW:] == tb, (list(tk2), toks, tb)
+            e0, e1 = nso.rel_l2(lg2[0], logits), nso.rel_l2(lg2[1], lb)
+            assert max(e0, e1) < 2e-3, (e0, e1)
+            print("continuous batching, prompts of %d and %d tokens: both requests generate what they generate alone "
+                  "(logits rel l2 %.1e / %.1e)" % (len(PROMPT), len(pb), e0, e1))
     print("LLAMA_MODEL_%s_OK" % mode.upper())
 
 
