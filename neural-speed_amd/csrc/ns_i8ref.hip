@@ -256,7 +256,9 @@ __global__ __launch_bounds__(kI8Threads) void i8ref_kernel(const I8RefParams p) 
 constexpr int kGM = 64, kGChunk = 512, kGRowStride = kGChunk + 16, kGSlices = kGChunk / 32;
 typedef int int4v __attribute__((ext_vector_type(4)));
 
-template <bool FOUR>
+// SDT: scale dtype of the weight (0 bf16, 1 f16, 2 f32), SPS: scales per k-step record and column, ASYM: zero points — compile
+// time, so that the per-slice scale selection costs no scalar branches (the kernel is issue-bound, profiles/r02z_*)
+template <bool FOUR, int SDT, int SPS, bool ASYM>
 __global__ __launch_bounds__(256) void i8mfma_kernel(const I8RefParams p) {
   constexpr int NJ = FOUR ? 4 : 2;            // slices per k-step record
   constexpr int CS = kGChunk / (32 * NJ);     // k-step records per chunk: 4 (128-deep) or 8 (64-deep)
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(256) void i8mfma_kernel(const I8RefParams p) {
   const bool tile_on = tile < (p.n + 15) / 16;
   const int r0 = blockIdx.y * kGM;
   const int zbias = FOUR ? 8 : 0;
-  const int sbytes = p.scale_dt == DT_F32 ? 4 : 2;
-  const int rec_sbytes = p.sps * sbytes;
+  constexpr int sbytes = SDT == 2 ? 4 : 2;
+  constexpr int rec_sbytes = SPS * sbytes;
   const bool vec_ok = (p.k & 7) == 0 && (reinterpret_cast<uintptr_t>(p.aq) & 7) == 0;
   float acc[4][4];
 #pragma unroll
@@ -293,20 +295,21 @@ __global__ __launch_bounds__(256) void i8mfma_kernel(const I8RefParams p) {
         const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
         const size_t crow = size_t(tile) * p.srows + srow;
         const uint8_t* sp = p.scales + crow * p.sstride + size_t(nn) * rec_sbytes;
-        if (rec_sbytes == 16) {
+        if constexpr (rec_sbytes == 16) {
           const uint4v v = *reinterpret_cast<const uint4v*>(sp);
           sw[t][0] = v.x, sw[t][1] = v.y, sw[t][2] = v.z, sw[t][3] = v.w;
-        } else if (rec_sbytes == 8) {
+        } else if constexpr (rec_sbytes == 8) {
           const uint2 v = *reinterpret_cast<const uint2*>(sp);
           sw[t][0] = v.x, sw[t][1] = v.y;
-        } else if (rec_sbytes == 4) {
+        } else if constexpr (rec_sbytes == 4) {
           sw[t][0] = *reinterpret_cast<const uint32_t*>(sp);
         } else {
           sw[t][0] = *reinterpret_cast<const uint16_t*>(sp);
         }
-        if (p.asym) {
-          const int8_t* zp = p.zps + crow * p.zstride + nn * p.sps;
-          for (int e = 0; e < p.sps; e++) zw[t] |= uint32_t(uint8_t(zp[e])) << (8 * e);
+        if constexpr (ASYM) {
+          const int8_t* zp = p.zps + crow * p.zstride + nn * SPS;
+#pragma unroll
+          for (int e = 0; e < SPS; e++) zw[t] |= uint32_t(uint8_t(zp[e])) << (8 * e);
         }
       }
     }
@@ -374,16 +377,15 @@ __global__ __launch_bounds__(256) void i8mfma_kernel(const I8RefParams p) {
         const int k0 = s * (32 * NJ) + 32 * j;
         if (k0 >= p.k) continue;
         const int q = t * NJ + j;
-        const int e = (j * p.sps) / NJ;
-        auto pick = [&](int i) { return i == 0 ? sw[t][0] : (i == 1 ? sw[t][1] : (i == 2 ? sw[t][2] : sw[t][3])); };
+        const int e = (j * SPS) / NJ;  // a constant once the loops are unrolled
         float sb;
-        if (p.scale_dt == DT_F32) {
-          sb = __builtin_bit_cast(float, pick(e));
+        if constexpr (SDT == 2) {
+          sb = __builtin_bit_cast(float, sw[t][e]);
         } else {
-          const uint32_t h = (pick(e >> 1) >> (16 * (e & 1))) & 0xffffu;
-          sb = p.scale_dt == DT_BF16 ? __builtin_bit_cast(float, h << 16) : f16_bits_to_f32(h);
+          const uint32_t h = (sw[t][e >> 1] >> (16 * (e & 1))) & 0xffffu;
+          sb = SDT == 0 ? __builtin_bit_cast(float, h << 16) : f16_bits_to_f32(h);
         }
-        const int zbb = (p.asym ? int(int8_t((zw[t] >> (8 * e)) & 0xffu)) : 0) + zbias;
+        const int zbb = (ASYM ? int(int8_t((zw[t] >> (8 * e)) & 0xffu)) : 0) + zbias;
         uint32_t u0, u1;
         if (FOUR) {
           u0 = xw[j] & 0x0f0f0f0fu, u1 = (xw[j] >> 4) & 0x0f0f0f0fu;
@@ -439,6 +441,23 @@ __global__ __launch_bounds__(256) void i8mfma_kernel(const I8RefParams p) {
       p.c[size_t(row) * p.ldc + col] = v;
       if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
     }
+}
+
+template <bool F, int S, int D>
+void launch_i8mfma_a(bool asym, dim3 grid, size_t lds, hipStream_t st, const I8RefParams& p) {
+  if (asym)
+    hipLaunchKernelGGL((i8mfma_kernel<F, D, S, true>), grid, dim3(256), lds, st, p);
+  else
+    hipLaunchKernelGGL((i8mfma_kernel<F, D, S, false>), grid, dim3(256), lds, st, p);
+}
+template <bool F, int S>
+void launch_i8mfma(int sdt, bool asym, dim3 grid, size_t lds, hipStream_t st, const I8RefParams& p) {
+  if (sdt == 0)
+    launch_i8mfma_a<F, S, 0>(asym, grid, lds, st, p);
+  else if (sdt == 1)
+    launch_i8mfma_a<F, S, 1>(asym, grid, lds, st, p);
+  else
+    launch_i8mfma_a<F, S, 2>(asym, grid, lds, st, p);
 }
 
 }  // namespace
@@ -500,10 +519,14 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   if (mfma_min_m > 0 && m >= mfma_min_m && (w->kstep_len == (p.nj == 4 ? 128 : 64))) {
     const size_t lds = size_t(kGM) * kGRowStride + size_t(3) * kGSlices * kGM * 4;
     const dim3 grid(unsigned((w->ntiles + 3) / 4), unsigned((m + kGM - 1) / kGM));
-    if (p.nj == 4)
-      hipLaunchKernelGGL(i8mfma_kernel<true>, grid, dim3(256), lds, st, p);
-    else
-      hipLaunchKernelGGL(i8mfma_kernel<false>, grid, dim3(256), lds, st, p);
+    const int sdt = w->scale_dt == DT_BF16 ? 0 : (w->scale_dt == DT_F32 ? 2 : 1);
+    const bool four = p.nj == 4;
+    if (four && w->sps == 4) launch_i8mfma<true, 4>(sdt, w->asym, grid, lds, st, p);
+    else if (four && w->sps == 2) launch_i8mfma<true, 2>(sdt, w->asym, grid, lds, st, p);
+    else if (four && w->sps == 1) launch_i8mfma<true, 1>(sdt, w->asym, grid, lds, st, p);
+    else if (!four && w->sps == 2) launch_i8mfma<false, 2>(sdt, w->asym, grid, lds, st, p);
+    else if (!four && w->sps == 1) launch_i8mfma<false, 1>(sdt, w->asym, grid, lds, st, p);
+    else return hipErrorNotSupported;
     return hipGetLastError();
   }
   // LDS (<= 60 KiB): the row group's activation scales / zero points, then up to four rows of u8 codes per chunk
