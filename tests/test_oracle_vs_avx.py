@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.fixture(scope="module")
 def avx(nso):
     flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
-    if "avx512f" not in flags or "avx512bw" not in flags:
-        pytest.skip("no AVX512 on this host")
+    if not all(f in flags for f in ("avx512f", "avx512bw", "avx512vl", "avx512dq", "avx512_vnni")):
+        pytest.skip("no AVX512 (F / BW / VL / DQ / VNNI: the code generation the library is compiled with) on this host")
     so = os.path.join(HERE, "..", "oracle", "_ref", "libkernel_avx_ref.so")
     if not os.path.exists(so):
         if not os.path.exists("/root/reference/bestla/bestla/kernel_avx512f.h"):
