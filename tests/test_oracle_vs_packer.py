@@ -159,5 +159,61 @@ def test_oracle_blobs_equal_the_reference_packer_on_this_hosts_isa():
     assert not res["bad"], res["bad"][:5]
 
 
+def golden_worker():
+    """runs in a subprocess (NS_PACKREF_ISA=nosimd): the real packer on the golden weights, against the golden blobs"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nso
+    G = np.load(os.path.join(ROOT, "tests", "golden", "btla_golden.npz"))
+    P = C.CDLL(SO)
+    P.packref_size.restype = C.c_size_t
+    P.packref_size.argtypes = [C.c_int] * 3 + [C.c_uint32] * 2 + [C.c_int] * 2
+    P.packref_quant_pack.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_uint32] * 2 + [C.c_int] * 3
+    bad, done = [], 0
+    for name in [str(x) for x in G["names"]]:
+        qt, st, asym, core, bs, n, k = [int(x) for x in G[name + "/meta"]]
+        gold = G[name + "/blob"]
+        w = np.ascontiguousarray(G[name + "/w"], np.float32)
+        size = P.packref_size(n, k, bs, qt, st, asym, core)
+        if size != gold.size:
+            bad.append((name, "size %d != %d" % (size, gold.size)))
+            continue
+        b0, b1 = nso.aligned_bytes(size, fill=0), nso.aligned_bytes(size, fill=0xFF)
+        for buf in (b0, b1):
+            assert P.packref_quant_pack(nso.ptr(buf), nso.ptr(w), n, k, k, bs, qt, st, asym, core, 1) == 0
+        written = b0 == b1
+        if st == nso.F16 and nso.is_int_type(qt):   # the scalar dispatch cannot unpack fp16 scales: its reduce section is garbage
+            bi = nso.parse(nso_aligned(nso, gold))
+            written[bi.red_off:bi.red_off + bi.red_bytes] = False
+        diff = written & (b0 != gold)
+        done += 1
+        if diff.any():
+            bad.append((name, "%d of %d written bytes differ" % (int(diff.sum()), int(written.sum()))))
+    print("PACKREF_RESULT " + json.dumps({"cases": done, "bad": bad}))
+
+
+def nso_aligned(nso, arr):
+    b = nso.aligned_bytes(arr.size)
+    b[:] = arr
+    return b
+
+
+def test_committed_golden_blobs_are_what_the_reference_packer_writes():
+    """tests/golden/btla_golden.npz (18 formats; checked against the GPU quantizer on the GPU box, where no reference tree
+    exists: tests/test_golden.py) == the real packer's output on the same weights, here: the chain GPU == golden == reference
+    packer closes through committed fixtures"""
+    if not os.path.exists(SO) and not os.path.exists("/root/reference/bestla/bestla/bestla_prologue_b.h"):
+        pytest.skip("oracle/_ref/libpack_ref.so not built (reference tree absent)")
+    flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
+    if not all(f in flags for f in ("avx512f", "avx512bw", "avx512vl", "avx512dq", "avx512_vnni")):
+        pytest.skip("libpack_ref.so is compiled with AVX512 code generation enabled")
+    if not os.path.exists(SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "packref"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, OMP_NUM_THREADS="4", NS_PACKREF_ISA="nosimd")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "golden"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("PACKREF_RESULT ")][-1][len("PACKREF_RESULT "):])
+    assert res["cases"] == 18 and not res["bad"], res
+
+
 if __name__ == "__main__":
-    worker(sys.argv[1])
+    golden_worker() if sys.argv[1] == "golden" else worker(sys.argv[1])
