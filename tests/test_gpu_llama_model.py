@@ -34,3 +34,11 @@ def test_reference_gptj_generates_on_the_hip_library(tmp_path, nso):
     o = np.load(tmp_path / "oracle_f16_gptj.npz")
     assert list(p["tokens"]) == list(o["tokens"])
     assert nso.rel_l2(p["logits"], o["logits"]) < 5e-3
+
+
+def test_reference_gguf_route_on_the_hip_library(tmp_path):
+    """fp32 GGUF file -> the reference's GGUF reader -> its quantizer driver on the PRODUCT's quantizer (blobs equal to the
+    oracle's) -> NE container with GGUF tensor names -> loader (GGUF branch) -> llama graph on libns_hip.so: tokens and logits of
+    the fp64 model built from the file"""
+    out = run_worker("product", tmp_path, "auto", 4, gguf=True)
+    assert "GGUF route:" in out

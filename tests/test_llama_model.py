@@ -14,14 +14,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", timeout=900):
+def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", gguf=False, timeout=900):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libne_llama_ref.so")) and not os.path.exists(
             "/root/reference/neural_speed/models/llama/llama.cpp"):
         pytest.skip("oracle/_ref/libne_llama_ref.so not built (reference tree absent)")
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "llama_model_worker.py"), mode, str(workdir), kv,
-                        str(heads_kv), str(given) if given else "-", family], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+                        str(heads_kv), str(given) if given else "-", family], capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                       env=dict(os.environ, NS_WORKER_GGUF="1") if gguf else None)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "LLAMA_MODEL_%s_OK" % mode.upper() in r.stdout
     return r.stdout
@@ -32,6 +33,14 @@ def test_reference_llama_on_the_oracle_provider(tmp_path, kv, heads_kv):
     """heads_kv == heads takes the fused QKV node (ne_mul_qkv), heads_kv < heads three ne_mul_mat; both the fused FFN node;
     lm_head through ne_mul_mat over a BTLA tensor; the model's own fp32 / fp16 kv cache and unfused attention"""
     run_worker("oracle", tmp_path, kv, heads_kv)
+
+
+def test_reference_gguf_route_on_the_oracle_provider(tmp_path):
+    """an fp32 GGUF file (tests/tools/gguf_file.py) through the reference's GGUF reader, its quantizer driver (here on the
+    oracle's packer: the blobs it writes are checked), the NE-container output with GGUF tensor names, the loader's GGUF
+    branch and the llama graph"""
+    out = run_worker("oracle", tmp_path, "f32", 4, gguf=True)
+    assert "GGUF route:" in out
 
 
 @pytest.mark.parametrize("kv", ["f32", "f16"])

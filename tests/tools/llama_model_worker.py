@@ -158,6 +158,9 @@ def same_blob(data, a):
 def weights_from_file(path):
     """fp64 weights of the model the reference's loader will see: 2-D GEMM weights as [K][N], the embedding as [V][D]"""
     _, tensors = ne_file.read(path)
+    if "token_embd.weight" in tensors:   # a file quantized from GGUF keeps the GGUF tensor names: back to the converter's
+        import gguf_file
+        tensors = {gguf_file.ne_name(k_): v_ for k_, v_ in tensors.items()}
     deq = {}
     for name, (typ, ne, data) in tensors.items():
         if typ == ne_file.NE_TYPE_BTLA:
@@ -232,7 +235,24 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     if not os.path.exists(lib_path):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "nellama"], stdout=subprocess.DEVNULL)
     ref = C.CDLL(lib_path)
-    if mode == "oracle":
+    use_gguf = os.environ.get("NS_WORKER_GGUF") == "1"
+    if use_gguf and not given:
+        # GGUF route: an fp32 GGUF file -> the reference's GGUF reader (model_files.h:643-986) -> its quantizer driver on this
+        # provider's quantizer -> an NE-container file with GGUF tensor names, which the llama loader takes by its GGUF branch
+        # (llama_utils.cpp:113-152)
+        import gguf_file
+        gpath = os.path.join(workdir, "%s_f32_%s.gguf" % (family, tag))
+        gguf_file.write_llama(gpath, hp, tensors)
+        ref.nellama_quantize.argtypes = [C.c_char_p] * 4 + [C.c_int] + [C.c_char_p] * 2
+        assert ref.nellama_quantize(gpath.encode(), qpath.encode(), b"int4", b"sym", 32, b"bf16", b"int8") == 0
+        _, got = ne_file.read(qpath)
+        for name, t in qt:
+            typ, ne, data = got[gguf_file.gguf_name(name)]
+            if isinstance(t, tuple):
+                why = same_blob(data, dict(tensors)[name])
+                assert typ == ne_file.NE_TYPE_BTLA and why is None, (name, why)
+        print("GGUF route: the reference's GGUF reader + quantizer driver on the %s provider wrote the oracle's blobs" % mode)
+    elif mode == "oracle":
         if not given:
             ne_file.write(qpath, dict(hp, ftype=ne_file.NE_FTYPE_MOSTLY_Q_BTLA), qt)
     else:

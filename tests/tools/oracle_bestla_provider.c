@@ -27,6 +27,30 @@ bool bestla_fusion_FFN_SiLu_f32f32_support(void* w1, void* w2, void* w3, int seq
   (void)seq, (void)fin, (void)fmid, (void)fout;
   return parses(w1) && parses(w2) && parses(w3);
 }
+/* the quantizer entries the reference's driver reaches through glue/bestla_gemm_hip.cpp, answered by the oracle's packer.  The
+ * core a new blob is laid out for follows the product's rule (csrc/ns_blob.cpp core_for_comp: the reference's walk on a
+ * Sapphire-Rapids class host) so that both providers write the same bytes. */
+static int core_for(int comp, uint32_t qt, bool asym, size_t bs) {
+  const bool is_int = ((qt >> 8) & 0xff) == 1;
+  if (comp == 4 && is_int && !(qt == NSO_S8 && asym)) {
+    if (bs % 64 == 0) return NSO_CORE_AMX_INT8_KB;
+    if (bs % 4 == 0) return NSO_CORE_AVX512_VNNI_KB;
+  }
+  if ((comp == 4 || comp == 2) && bs % 32 == 0) return NSO_CORE_AMX_BF16;
+  return NSO_CORE_AVX512F;
+}
+size_t ns_BTLAGemmPackBSize(size_t n, size_t k, size_t blk, uint32_t qt, uint32_t st, bool asym, int comp, int* shuf) {
+  const size_t bs = (long long)blk <= 0 ? k : blk;
+  if (shuf) return nso_pack_size_gidx((int)n, (int)k, (int)blk, qt, st, asym, core_for(comp, qt, asym, bs));
+  return nso_pack_size((int)n, (int)k, (int)blk, qt, st, asym, core_for(comp, qt, asym, bs));
+}
+bool ns_BTLAGemmQuantPackB(void* buf, const float* w, size_t n, size_t k, size_t ldb, size_t blk, uint32_t qt, uint32_t st, bool asym,
+                           int comp, bool is_trans, void* tp) {
+  (void)tp;
+  const size_t bs = (long long)blk <= 0 ? k : blk;
+  return nso_quant_pack(buf, w, (int)n, (int)k, (int)ldb, (int)blk, qt, st, asym, core_for(comp, qt, asym, bs), is_trans) == 0;
+}
+
 bool bestla_fusion_FFN_Add_GeLu_f32f32_support(void* w1, void* w2, int seq, int fin, int fmid, int fout) {
   (void)seq, (void)fin, (void)fmid, (void)fout;
   return parses(w1) && parses(w2);
