@@ -53,7 +53,9 @@ NE_REF_STUB(ns_BTLAGemmPackB)
 NE_REF_STUB(ns_BTLAGemmUnPackB)
 /* operators of other reference source files, outside the path */
 NE_REF_STUB(ne_attention_padding_mask_f32_forward)
+#ifndef NS_REF_HAVE_ARGSORT /* the model libraries compile the reference's core/layers/argsort.cpp (ne_top_k of the MoE router) */
 NE_REF_STUB(ne_compute_forward_argsort)
+#endif
 NE_REF_STUB(ne_compute_forward_conv_1d)
 NE_REF_STUB(ne_compute_forward_conv_1d_1s)
 NE_REF_STUB(ne_compute_forward_conv_1d_2s)

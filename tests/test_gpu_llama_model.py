@@ -42,3 +42,16 @@ def test_reference_gguf_route_on_the_hip_library(tmp_path):
     the fp64 model built from the file"""
     out = run_worker("product", tmp_path, "auto", 4, gguf=True)
     assert "GGUF route:" in out
+
+
+def test_reference_mixture_of_experts_llama_on_the_hip_library(tmp_path, nso):
+    """the mixture-of-experts llama graph on libns_hip.so: the reference's NE_OP_MUL_MAT_ID nodes (prompt: one
+    bestla_f32f32_forward per (token, expert), ne_layers.c:7783-7916) and NE_OP_MUL_ID_FFN_SILU nodes (single tokens: the fused
+    FFN entry on the routed expert) from the real model code; tokens / logits of the fp64 model and of the CPU oracle provider"""
+    out = run_worker("product", tmp_path, "auto", 4, gguf=True, experts=8)
+    assert "8 experts (2 used)" in out
+    run_worker("oracle", tmp_path, "f16", 4, given=tmp_path / "llama_q_product_4_moe8.bin", experts=8)
+    p = np.load(tmp_path / "product_auto_4_moe8.npz")
+    o = np.load(tmp_path / "oracle_f16_4_moe8.npz")
+    assert list(p["tokens"]) == list(o["tokens"])
+    assert nso.rel_l2(p["logits"], o["logits"]) < 5e-3

@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", gguf=False, timeout=900):
+def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", gguf=False, experts=0, timeout=900):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libne_llama_ref.so")) and not os.path.exists(
             "/root/reference/neural_speed/models/llama/llama.cpp"):
         pytest.skip("oracle/_ref/libne_llama_ref.so not built (reference tree absent)")
@@ -22,7 +22,7 @@ def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", gguf=Fal
         pytest.skip("no gcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "llama_model_worker.py"), mode, str(workdir), kv,
                         str(heads_kv), str(given) if given else "-", family], capture_output=True, text=True, timeout=timeout, cwd=ROOT,
-                       env=dict(os.environ, NS_WORKER_GGUF="1") if gguf else None)
+                       env=dict(os.environ, NS_WORKER_GGUF="1" if gguf else "0", NS_WORKER_EXPERTS=str(experts)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "LLAMA_MODEL_%s_OK" % mode.upper() in r.stdout
     return r.stdout
@@ -41,6 +41,15 @@ def test_reference_gguf_route_on_the_oracle_provider(tmp_path):
     branch and the llama graph"""
     out = run_worker("oracle", tmp_path, "f32", 4, gguf=True)
     assert "GGUF route:" in out
+
+
+def test_reference_mixture_of_experts_llama_on_the_oracle_provider(tmp_path):
+    """a Mixtral-style llama (8 experts, 2 per token) through models/llama/llama.cpp:619-683: router ne_mul_mat over a BTLA
+    weight 8 columns wide, soft_max, ne_top_k (the reference's argsort.cpp), renormalised weights, ne_mul_mat_id per expert for
+    the prompt and the fused ne_mul_id_ffn_silu for single tokens — against an fp64 model of the same routing.  Through the
+    GGUF route: the NE branch of the reference's loader cannot load such a model (llama_utils.cpp:228-230)."""
+    out = run_worker("oracle", tmp_path, "f32", 4, gguf=True, experts=8)
+    assert "8 experts (2 used)" in out
 
 
 @pytest.mark.parametrize("kv", ["f32", "f16"])

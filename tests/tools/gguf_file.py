@@ -18,7 +18,7 @@ NAMES = {  # NE-converter name -> GGUF name (llama_utils.cpp:113-152 vs :165-204
 def gguf_name(ne_name):
     if ne_name.startswith("layers."):
         _, i, rest = ne_name.split(".", 2)
-        return "blk.%s.%s" % (i, NAMES[rest])
+        return "blk.%s.%s" % (i, NAMES.get(rest, rest))   # the expert tensors (ffn_gate_inp, ffn_gate.N, ...) keep their names
     return NAMES[ne_name]
 
 
@@ -26,7 +26,7 @@ def ne_name(gname):
     inv = {v: k for k, v in NAMES.items()}
     if gname.startswith("blk."):
         _, i, rest = gname.split(".", 2)
-        return "layers.%s.%s" % (i, inv[rest])
+        return "layers.%s.%s" % (i, inv.get(rest, rest))
     return inv[gname]
 
 
@@ -42,7 +42,8 @@ def write_llama(path, hp, tensors):
           ("llama.attention.head_count_kv", U32, hp["n_head_kv"]), ("llama.block_count", U32, hp["n_layer"]),
           ("llama.rope.dimension_count", U32, hp["n_rot"]), ("llama.attention.layer_norm_rms_epsilon", F32, hp["norm_eps"]),
           ("llama.rope.freq_base", F32, hp["freq_base"]), ("ftype", U32, 0), ("llama.context_length", U32, hp["max_seq_len"]),
-          ("llama.feed_forward_length", U32, hp["ffn_hidden_size"]), ("tokenizer.ggml.bos_token_id", U32, 1),
+          ("llama.feed_forward_length", U32, hp["ffn_hidden_size"]), ("llama.expert_count", U32, hp.get("n_experts", 0)),
+          ("llama.expert_used_count", U32, hp.get("n_experts_used", 0)), ("tokenizer.ggml.bos_token_id", U32, 1),
           ("tokenizer.ggml.eos_token_id", U32, 2), ("tokenizer.ggml.pad_token_id", U32, 0), ("tokenizer.ggml.sep_token_id", U32, 0)]
     out = bytearray(b"GGUF" + struct.pack("<IQQ", 3, len(tensors), len(kv) + 2))
     for key, typ, val in kv:

@@ -37,10 +37,14 @@ N_NEW = 6
 KV = {"auto": 0, "f16": 1, "f32": 2}
 
 
-def make_model(heads_kv):
+def make_model(heads_kv, n_experts=0):
+    """n_experts > 0: a Mixtral-style mixture of experts (router ffn_gate_inp + n_experts SiLU FFNs per layer, two used per
+    token; llama_utils.cpp:141-152).  Such a model loads through the GGUF branch only: the NE branch of Llama::load sums
+    ne_nbytes(layer.ffn[0..2]), null for it (llama_utils.cpp:228-230)."""
     rng = np.random.default_rng(77)
     hs = D // HEADS
     dkv = hs * heads_kv
+    ff = 256 if n_experts else FF   # eight experts per layer: keep the file small
     t = [("tok_embeddings.weight", (rng.standard_normal((V, D)) * 0.5).astype(np.float32)),
          ("norm.weight", (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
          ("output.weight", (rng.standard_normal((V, D)) * D ** -0.5).astype(np.float32))]
@@ -51,12 +55,23 @@ def make_model(heads_kv):
               (p + "attention.wk.weight", (rng.standard_normal((dkv, D)) * D ** -0.5).astype(np.float32)),
               (p + "attention.wv.weight", (rng.standard_normal((dkv, D)) * D ** -0.5).astype(np.float32)),
               (p + "attention.wo.weight", (rng.standard_normal((D, D)) * 0.5 * D ** -0.5).astype(np.float32)),
-              (p + "ffn_norm.weight", (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
-              (p + "feed_forward.w1.weight", (rng.standard_normal((FF, D)) * D ** -0.5).astype(np.float32)),
-              (p + "feed_forward.w2.weight", (rng.standard_normal((D, FF)) * 0.5 * FF ** -0.5).astype(np.float32)),
-              (p + "feed_forward.w3.weight", (rng.standard_normal((FF, D)) * D ** -0.5).astype(np.float32))]
+              (p + "ffn_norm.weight", (1 + 0.1 * rng.standard_normal(D)).astype(np.float32))]
+        if n_experts:
+            # a wide router (logit gaps of order one: the choice of experts must not hang on the last bits of a softmax).  Eight
+            # experts: with fewer the reference's quantizer driver overruns its own output buffer on the router weight (it sizes
+            # the buffer as 4 bytes per element, quant_utils.cpp:411-412; a blob pads N to the 48-column tile: 8000 bytes here)
+            t += [(p + "ffn_gate_inp.weight", (rng.standard_normal((n_experts, D)) * 4.0 * D ** -0.5).astype(np.float32))]
+            for x in range(n_experts):
+                t += [(p + "ffn_gate.%d.weight" % x, (rng.standard_normal((ff, D)) * D ** -0.5).astype(np.float32)),
+                      (p + "ffn_down.%d.weight" % x, (rng.standard_normal((D, ff)) * 0.5 * ff ** -0.5).astype(np.float32)),
+                      (p + "ffn_up.%d.weight" % x, (rng.standard_normal((ff, D)) * D ** -0.5).astype(np.float32))]
+        else:
+            t += [(p + "feed_forward.w1.weight", (rng.standard_normal((FF, D)) * D ** -0.5).astype(np.float32)),
+                  (p + "feed_forward.w2.weight", (rng.standard_normal((D, FF)) * 0.5 * FF ** -0.5).astype(np.float32)),
+                  (p + "feed_forward.w3.weight", (rng.standard_normal((FF, D)) * D ** -0.5).astype(np.float32))]
     hp = dict(n_vocab=V, n_embd=D, n_mult=256, n_head=HEADS, n_head_kv=heads_kv, n_layer=LAYERS, n_rot=hs, ftype=0,
-              max_seq_len=N_CTX, ffn_hidden_size=FF, norm_eps=EPS, freq_base=BASE, freq_scale=1.0, rope_scaling_factor=0.0)
+              max_seq_len=N_CTX, ffn_hidden_size=ff, norm_eps=EPS, freq_base=BASE, freq_scale=1.0, rope_scaling_factor=0.0,
+              n_experts=n_experts, n_experts_used=2 if n_experts else 0)
     return hp, t
 
 
@@ -174,8 +189,9 @@ def weights_from_file(path):
     return deq
 
 
-def model_fp64(deq, heads_kv, tokens, kv_fp16):
-    """logits of the LAST position"""
+def model_fp64(deq, heads_kv, tokens, kv_fp16, n_experts=0, gaps=None):
+    """logits of the LAST position.  gaps (list): receives, per layer and position, the relative gap between the second and
+    the third router probability (how safely the two experts were chosen)"""
     hs, T, grp = D // HEADS, len(tokens), HEADS // heads_kv
 
     def rms(v, g):
@@ -208,8 +224,24 @@ def model_fp64(deq, heads_kv, tokens, kv_fp16):
             att[:, hd] = (pr / pr.sum(-1, keepdims=True)) @ v[:, hd // grp]
         x = x + att.reshape(T, D) @ deq[p + "attention.wo.weight"]
         h2 = rms(x, deq[p + "ffn_norm.weight"])
-        g = h2 @ deq[p + "feed_forward.w1.weight"]
-        x = x + (g / (1 + np.exp(-g)) * (h2 @ deq[p + "feed_forward.w3.weight"])) @ deq[p + "feed_forward.w2.weight"]
+        if n_experts:   # llama.cpp:619-683: softmax over the router logits, top 2, weights renormalised
+            lg = h2 @ deq[p + "ffn_gate_inp.weight"]
+            pr = np.exp(lg - lg.max(-1, keepdims=True))
+            pr /= pr.sum(-1, keepdims=True)
+            order = np.argsort(-pr, axis=-1)
+            moe = np.zeros_like(x)
+            for ti in range(T):
+                sel = order[ti, :2]
+                wsel = pr[ti, sel] / pr[ti, sel].sum()
+                if gaps is not None and n_experts > 2:
+                    gaps.append(float((pr[ti, order[ti, 1]] - pr[ti, order[ti, 2]]) / pr[ti, order[ti, 1]]))
+                for e_, w_ in zip(sel, wsel):
+                    g = h2[ti] @ deq[p + "ffn_gate.%d.weight" % e_]
+                    moe[ti] += w_ * ((g / (1 + np.exp(-g)) * (h2[ti] @ deq[p + "ffn_up.%d.weight" % e_])) @ deq[p + "ffn_down.%d.weight" % e_])
+            x = x + moe
+        else:
+            g = h2 @ deq[p + "feed_forward.w1.weight"]
+            x = x + (g / (1 + np.exp(-g)) * (h2 @ deq[p + "feed_forward.w3.weight"])) @ deq[p + "feed_forward.w2.weight"]
     return rms(x[-1:], deq["norm.weight"]) @ deq["output.weight"]
 
 
@@ -217,9 +249,10 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     heads_kv = int(heads_kv)
     given = None if given in (None, "-") else given
     os.makedirs(workdir, exist_ok=True)
-    hp, tensors = make_model(heads_kv) if family == "llama" else make_model_gptj()
+    n_experts = int(os.environ.get("NS_WORKER_EXPERTS", "0")) if family == "llama" else 0
+    hp, tensors = make_model(heads_kv, n_experts) if family == "llama" else make_model_gptj()
     qt = quantize_tensors(tensors)
-    tag = "%d" % heads_kv if family == "llama" else family
+    tag = ("%d%s" % (heads_kv, "_moe%d" % n_experts if n_experts else "")) if family == "llama" else family
     qpath = given or os.path.join(workdir, "%s_q_%s_%s.bin" % (family, mode, tag))
     if mode == "oracle":
         so = os.path.join(tempfile.mkdtemp(), "liboracle_bestla.so")
@@ -287,9 +320,9 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     toks = list(toks)
     deq = weights_from_file(qpath)
     # independent fp64 model: same greedy tokens wherever its own top-1 margin is clear of the path's tolerance
-    seq, errs, margins = list(PROMPT), [], []
+    seq, errs, margins, gaps = list(PROMPT), [], [], []
     for i in range(N_NEW):
-        want = (model_fp64(deq, heads_kv, seq, kv != "f32") if family == "llama" else model_fp64_gptj(deq, seq, kv != "f32"))[0]
+        want = (model_fp64(deq, heads_kv, seq, kv != "f32", n_experts, gaps) if family == "llama" else model_fp64_gptj(deq, seq, kv != "f32"))[0]
         errs.append(nso.rel_l2(logits[i], want))
         top = np.sort(want)[-2:]
         margins.append(float(top[1] - top[0]))
@@ -298,10 +331,11 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
         seq.append(toks[i])
     print("%s (%d layers, heads %d/%d, kv %s) through the reference's model code, %s provider: tokens %s, logits rel l2 vs fp64 "
           "model max %.2e, top-1 margins %s" % (family, LAYERS if family == "llama" else GJ_LAYERS, HEADS, heads_kv, kv, mode, toks,
-                                                max(errs), ["%.2f" % m for m in margins]))
+                                                max(errs), ["%.2f" % m for m in margins]) +
+          (", %d experts (2 used), smallest router gap %.3f" % (n_experts, min(gaps)) if gaps else ""))
     assert max(errs) < 1e-2, errs
     np.savez(os.path.join(workdir, "%s_%s_%s.npz" % (mode, kv, tag)), tokens=np.array(toks), logits=logits)
-    if family == "llama" and os.environ.get("NS_WORKER_CONT_BATCH", "1") != "0":
+    if family == "llama" and not n_experts and os.environ.get("NS_WORKER_CONT_BATCH", "1") != "0":
         # continuous batching: two requests per eval (concatenated, no padding; llama.cpp:66-70, :330-350, :496-571) must
         # reproduce what each request generates alone — prompts of different lengths (two attention groups of one request)
         # and of equal length (one group of two: the kv update / attention entries see batch 2)
