@@ -94,3 +94,30 @@ def test_every_model_family_compiles_against_the_shim():
         results = list(ex.map(check, srcs))
     failed = [(s_, e) for s_, rc, e in results if rc]
     assert len(srcs) >= 40 and not failed, failed[:3]
+
+
+def test_every_bestla_symbol_the_model_families_reference_is_provided(tmp_path, pkg):
+    """object files of all model sources (compiled against glue/shim): every `bestla_*` / `BTLAGemm*` symbol they leave
+    undefined is either exported by libns_hip.so or defined by glue/bestla_gemm_hip.cpp (the three C++-linkage quantizer
+    functions) — nothing a model family calls is missing from the drop-in"""
+    import glob
+    from concurrent.futures import ThreadPoolExecutor
+    ref = "/root/reference"
+    srcs = sorted(glob.glob(ref + "/neural_speed/models/*/*.cpp"))
+    if not srcs or shutil.which("g++") is None or shutil.which("nm") is None:
+        pytest.skip("reference tree absent")
+    inc = ["-I" + os.path.join(ROOT, "glue", "shim"), "-I" + ref, "-I" + ref + "/neural_speed", "-I" + ref + "/neural_speed/core",
+           "-I" + ref + "/bestla", "-I" + ref + "/bestla/bestla"]
+
+    def undefined(src):
+        obj = str(tmp_path / (src.replace("/", "_") + ".o"))
+        subprocess.check_call(["g++", "-std=c++17", "-O0", "-fPIC", "-w", '-DMODEL_NAME="x"'] + inc + ["-c", src, "-o", obj])
+        out = subprocess.check_output(["nm", "-u", obj], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if ln.split() and ("bestla_" in ln or "BTLA" in ln)}
+    with ThreadPoolExecutor(8) as ex:
+        need = set().union(*ex.map(undefined, srcs))
+    exported = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", pkg.LIB_PATH], text=True).splitlines() if ln.split()}
+    missing = sorted(need - exported)
+    assert len(need) >= 12
+    # what is left is C++-mangled: BTLAGemmPackBSize / BTLAGemmQuantPackB / BTLAGemmPackB, the forwarders of glue/bestla_gemm_hip.cpp
+    assert all(m.startswith("_Z") and "BTLAGemm" in m for m in missing) and len(missing) <= 4, missing
