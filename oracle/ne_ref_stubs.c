@@ -46,7 +46,6 @@ NE_REF_STUB(bestla_fusion_FFN_Gelu_Mul_f32f32_support)
 NE_REF_STUB(bestla_fusion_add_f32f32_support)
 NE_REF_STUB(bestla_fusion_attn_fp32_fp16_fp16_fp32_support)
 NE_REF_STUB(bestla_fusion_attn_fp16_support)
-NE_REF_STUB(bestla_fusion_attn_bf16_support)
 NE_REF_STUB(ns_BTLAGemmPackBSize)
 NE_REF_STUB(ns_BTLAGemmQuantPackB)
 NE_REF_STUB(ns_BTLAGemmPackB)

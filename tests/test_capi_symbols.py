@@ -119,3 +119,18 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                         "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_every_fallback_of_the_reference_harness_is_interposed_by_the_library(pkg):
+    """oracle/ne_ref_stubs.c holds an aborting fallback for every `bestla_*` / `ns_BTLAGemm*` symbol the reference's graph
+    executor and model code reference; libns_hip.so must export each of them (it is loaded RTLD_GLOBAL first and wins the
+    symbol resolution), otherwise a drop-in run would abort in the fallback"""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = re.findall(r"NE_REF_STUB\((bestla_\w+|ns_BTLA\w+)\)", open(os.path.join(root, "oracle", "ne_ref_stubs.c")).read())
+    assert len(names) >= 25
+    exported = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", pkg.LIB_PATH], text=True).splitlines() if ln.split()}
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
