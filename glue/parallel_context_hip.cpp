@@ -7,8 +7,10 @@
 //
 // Bootstrap without MPI (the launcher provides the usual variables, e.g. torchrun or `mpirun -x`):
 //   WORLD_SIZE / RANK / LOCAL_RANK  (or NS_TP_WORLD_SIZE / NS_TP_RANK / NS_TP_LOCAL_RANK)
-//   NS_TP_ID_FILE  path on a filesystem every rank sees (default /tmp/ns_tp_id.<uid>.<MASTER_PORT>): rank 0 writes the
-//                  128-byte RCCL unique id there (write + rename), the others wait for it (60 s)
+//   NS_TP_ID_FILE  path on a filesystem every rank sees (default /tmp/ns_tp_id.<uid>.<launch nonce>): rank 0 removes
+//                  whatever is there, writes {magic, launch nonce, 128-byte RCCL unique id} (O_EXCL, 0600, write +
+//                  rename) and the others wait up to 60 s for a file carrying THEIR launch's nonce
+//   NS_TP_RUN_ID / TORCHELASTIC_RUN_ID  the launcher's run id, part of the nonce (else MASTER_PORT + the parent pid)
 // With one rank nothing is initialised and every call is the identity.
 //
 // NOTE on `count`: parallel_context.cpp hands it to ccl::allreduce as an ELEMENT count, and so does this file; the
@@ -18,7 +20,11 @@
 
 #include "parallel_context.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <chrono>
 #include <cstdio>
@@ -40,46 +46,83 @@ int env_int(const char* a, const char* b, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
+// Per-launch nonce shared by the ranks of ONE launch and by nobody else: the launcher's run id when it exports one
+// (torchrun: TORCHELASTIC_RUN_ID; anything: NS_TP_RUN_ID), mixed with the parent pid on a single node (the ranks of a
+// torchrun / mpirun launch are siblings).  It names the id file and is written into it, so a file left behind by a
+// crashed earlier launch is neither opened by name nor accepted by content (a stale 128-byte id made
+// ncclCommInitRank hang with no time-out).
+uint64_t launch_nonce() {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const char* t) {
+    for (; t && *t; t++) h = (h ^ uint64_t(uint8_t(*t))) * 1099511628211ull;
+  };
+  const char* run = getenv("NS_TP_RUN_ID");
+  if (!run) run = getenv("TORCHELASTIC_RUN_ID");
+  mix(run);
+  mix(getenv("MASTER_PORT"));
+  if (!run || !strcmp(run, "none")) h = (h ^ uint64_t(getppid())) * 1099511628211ull;  // torchrun's default run id is "none"
+  return h ? h : 1;
+}
+
+struct IdFile {  // what rank 0 publishes
+  char magic[8];
+  uint64_t nonce;
+  unsigned char id[NS_TP_UNIQUE_ID_BYTES];
+};
+
 ns_tp* make_tp() {
   const int world = env_int("NS_TP_WORLD_SIZE", "WORLD_SIZE", 1);
   const int rank = env_int("NS_TP_RANK", "RANK", 0);
   const int local = env_int("NS_TP_LOCAL_RANK", "LOCAL_RANK", rank);
   if (world <= 1) return ns_tp_init(0, 1, nullptr, -1);
+  const uint64_t nonce = launch_nonce();
+  char hex[17];
+  snprintf(hex, sizeof(hex), "%016llx", static_cast<unsigned long long>(nonce));
   std::string path = getenv("NS_TP_ID_FILE") ? getenv("NS_TP_ID_FILE")
-                                              : "/tmp/ns_tp_id." + std::to_string(getuid()) + "." +
-                                                    (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
-  unsigned char id[NS_TP_UNIQUE_ID_BYTES];
+                                              : "/tmp/ns_tp_id." + std::to_string(getuid()) + "." + hex;
+  IdFile rec;
+  memset(&rec, 0, sizeof(rec));
   if (rank == 0) {
-    if (ns_tp_unique_id(id) != 0) return nullptr;
+    memcpy(rec.magic, "NSTPID1", 8);
+    rec.nonce = nonce;
     const std::string tmp = path + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) {
-      fprintf(stderr, "parallel_context: cannot write %s\n", tmp.c_str());
-      if (f) fclose(f);
+    unlink(path.c_str());  // whatever an earlier launch left under this name is gone before any reader can match it
+    unlink(tmp.c_str());
+    if (ns_tp_unique_id(rec.id) != 0) return nullptr;
+    // O_EXCL | O_NOFOLLOW, 0600: never write through a link or into a file somebody else created first
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    bool ok = fd >= 0 && write(fd, &rec, sizeof(rec)) == ssize_t(sizeof(rec)) && fsync(fd) == 0;
+    if (fd >= 0) ok = (close(fd) == 0) && ok;
+    ok = ok && rename(tmp.c_str(), path.c_str()) == 0;
+    if (!ok) {
+      fprintf(stderr, "parallel_context: cannot publish %s (%s)\n", path.c_str(), strerror(errno));
+      unlink(tmp.c_str());
+      unlink(path.c_str());
       return nullptr;
     }
-    fclose(f);
-    rename(tmp.c_str(), path.c_str());
   } else {
     bool got = false;
     for (int i = 0; i < 600 && !got; i++) {
-      FILE* f = fopen(path.c_str(), "rb");
-      if (f) {
-        got = fread(id, 1, sizeof(id), f) == sizeof(id);
-        fclose(f);
+      const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+      if (fd >= 0) {
+        struct stat sb;
+        IdFile in;
+        // a regular file of this user, not writable by anyone else, complete, carrying THIS launch's nonce
+        got = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_uid == getuid() && !(sb.st_mode & (S_IWGRP | S_IWOTH)) &&
+              read(fd, &in, sizeof(in)) == ssize_t(sizeof(in)) && !memcmp(in.magic, "NSTPID1", 8) && in.nonce == nonce;
+        if (got) rec = in;
+        close(fd);
       }
       if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
     if (!got) {
-      fprintf(stderr, "parallel_context: rank %d never saw %s\n", rank, path.c_str());
+      fprintf(stderr, "parallel_context: rank %d never saw a valid %s\n", rank, path.c_str());
       return nullptr;
     }
   }
-  ns_tp* tp = ns_tp_init(rank, world, id, local);
-  if (tp) {
-    ns_tp_barrier_host(tp);            // every rank has read the id
-    if (rank == 0) unlink(path.c_str());  // a later run must not pick up a stale id
-  }
+  ns_tp* tp = ns_tp_init(rank, world, rec.id, local);
+  if (tp) ns_tp_barrier_host(tp);            // every rank has read the id
+  if (rank == 0) unlink(path.c_str());       // success or failure: a later launch must not find it
   return tp;
 }
 

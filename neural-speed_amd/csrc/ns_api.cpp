@@ -43,6 +43,24 @@ struct CacheEntry {
 };
 std::unordered_map<const void*, CacheEntry> g_cache;  // host blob pointer -> device weight (part-1 API)
 uint64_t g_cache_tick = 0;
+// Pinning against the NS_CACHE_MAX_BYTES eviction: every host entry that looks weights up opens a CachePin for its
+// duration.  While any pin is open, entries touched since the OLDEST open pin began (last_use > g_pin_floor) are in
+// use by some call — a fused entry holds up to three of them at once — and are never evicted; if that leaves the
+// cache over its cap the cap is exceeded until the calls return (q was freed while k / v were loaded).
+int g_pin_count = 0;
+uint64_t g_pin_floor = 0;
+struct CachePin {
+  CachePin() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_pin_count++ == 0) g_pin_floor = g_cache_tick;
+  }
+  ~CachePin() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    --g_pin_count;
+  }
+  CachePin(const CachePin&) = delete;
+  CachePin& operator=(const CachePin&) = delete;
+};
 size_t g_cache_bytes = 0;
 
 struct Scratch {  // growable device scratch for the host-pointer API
@@ -375,13 +393,16 @@ ns_weight* cached_weight(const void* blob) {
   ns_weight* w = ns_hip_weight_from_blob(blob, nullptr);
   if (!w) return nullptr;
   // optional cap (NS_CACHE_MAX_BYTES, default unlimited: a model's weights are a fixed set): least recently used
-  // device copies go first.  Host entry points are serialised (g_host_mu), so no evicted weight is in use.
+  // device copies go first — except the ones a call in flight may hold (CachePin above).
   static const size_t cap = getenv("NS_CACHE_MAX_BYTES") ? strtoull(getenv("NS_CACHE_MAX_BYTES"), nullptr, 10) : 0;
   g_cache_bytes += w->alloc_bytes;
   while (cap && g_cache_bytes > cap && !g_cache.empty()) {
-    auto victim = g_cache.begin();
-    for (auto jt = g_cache.begin(); jt != g_cache.end(); ++jt)
-      if (jt->second.last_use < victim->second.last_use) victim = jt;
+    auto victim = g_cache.end();
+    for (auto jt = g_cache.begin(); jt != g_cache.end(); ++jt) {
+      if (g_pin_count > 0 && jt->second.last_use > g_pin_floor) continue;  // in use by a call in flight
+      if (victim == g_cache.end() || jt->second.last_use < victim->second.last_use) victim = jt;
+    }
+    if (victim == g_cache.end()) break;  // the working set of the calls in flight exceeds the cap: keep it
     g_cache_bytes -= std::min(g_cache_bytes, victim->second.w->alloc_bytes);
     ns_hip_weight_free(victim->second.w);
     g_cache.erase(victim);
@@ -1125,6 +1146,7 @@ bool ns_BTLAGemmPackB(void* PackedBuf, const int8_t* QData, const float* Scales,
 
 bool ns_BTLAGemmUnPackB(float* FpData, const void* PackedBuf, size_t N, size_t K, size_t ldb, void* ThreadPool) {
   (void)ThreadPool;
+  CachePin pin;
   ns_weight* w = cached_weight(PackedBuf);
   if (!w) return false;
   if (size_t(w->n) != N || size_t(w->k) != K) {
@@ -1174,6 +1196,7 @@ unsigned long long bestla_f32f32_get_workspace_size(int _m, int _n, int _k, void
 static bool host_forward(float* activation, void* weiptr, float* output, int m, int n, int k, int lda, int ldo,
                          int epi, const float* hostD, int ldd_rows, int ldd) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   ns_weight* w = cached_weight(weiptr);
   if (!w) return false;
   if (w->n != n || w->k != k) {
@@ -1233,6 +1256,8 @@ void bestla_f32f32_forward(float* activation, void* weiptr, float* output, int _
 bool bestla_fusion_add_f32f32_support(void* weiptr, int _m, int _n, int _k) {
   (void)_m;
   if (ns_hip_device_count() <= 0) return false;
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   ns_weight* w = cached_weight(weiptr);
   return w && w->n == _n && w->k == _k;
 }
@@ -1253,6 +1278,8 @@ unsigned long long bestla_fusion_QKV_f32f32_get_workspace_size(int _m, int _n, i
 bool bestla_fusion_QKV_f32f32_support(void* wqptr, void* wkptr, void* wvptr, int _m, int _n, int _k) {
   (void)_m;
   if (ns_hip_device_count() <= 0) return false;
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   ns_weight *q = cached_weight(wqptr), *k = cached_weight(wkptr), *v = cached_weight(wvptr);
   if (!q || !k || !v) return false;
   if (q->shuf || k->shuf || v->shuf) return false;  // ip_fusion_qkv.cpp:174-176: no QKV fusion with activation shuffle
@@ -1267,6 +1294,7 @@ bool bestla_fusion_QKV_f32f32_support(void* wqptr, void* wkptr, void* wvptr, int
 void bestla_fusion_QKV_f32f32_forward(float* activation, void* wqptr, void* wkptr, void* wvptr, float* output, int _m,
                                       int _n, int _k, int lda, int ldo, void* workspace) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   (void)workspace;
   bool ok = have_device();
   ns_weight *q = nullptr, *k = nullptr, *v = nullptr;
@@ -1313,6 +1341,8 @@ unsigned long long bestla_fusion_FFN_f32f32_get_workspace_size(int seq, int fin,
 
 static bool ffn3_support(void* w1ptr, void* w2ptr, void* w3ptr, int fin, int fmid, int fout) {
   if (ns_hip_device_count() <= 0) return false;
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   ns_weight *w1 = cached_weight(w1ptr), *w2 = cached_weight(w2ptr), *w3 = cached_weight(w3ptr);
   if (!w1 || !w2 || !w3) return false;
   return w1->k == fin && w1->n == fmid && w3->k == fin && w3->n == fmid && w2->k == fmid && w2->n == fout &&
@@ -1322,6 +1352,7 @@ static bool ffn3_support(void* w1ptr, void* w2ptr, void* w3ptr, int fin, int fmi
 static void ffn3_forward(const char* who, float* activation, void* w1ptr, void* w2ptr, void* w3ptr, float* tmp1,
                          float* tmp2, float* output, int seq, int fin, int fmid, int fout, int act) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   bool ok = have_device();
   ns_weight *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
   if (ok) {
@@ -1396,12 +1427,15 @@ void bestla_fusion_FFN_Gelu_Mul_f32f32_forward(float* activation, void* w1ptr, v
 
 static bool ffn2_support(void* w1ptr, void* w2ptr, int fin, int fmid, int fout) {
   if (ns_hip_device_count() <= 0) return false;
+  std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   ns_weight *w1 = cached_weight(w1ptr), *w2 = cached_weight(w2ptr);
   return w1 && w2 && w1->k == fin && w1->n == fmid && w2->k == fmid && w2->n == fout;
 }
 static void ffn2_forward(const char* who, float* activation, void* w1ptr, void* w2ptr, float* b1, float* b2,
                          float* tmp1, float* output, int seq, int fin, int fmid, int fout, bool bcast) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   bool ok = have_device();
   ns_weight *w1 = nullptr, *w2 = nullptr;
   if (ok) {
@@ -1653,6 +1687,7 @@ int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector,
 void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* FpIn,
                                float* FpOut) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   const size_t n = size_t(norm_count) * norm_size;
   if (!have_device() || !host_unary(n, n, FpIn, FpOut, [&](const float* i, float* o) {
         return launch_rmsnorm(norm_count, norm_size, isrms, epsilon, i, o, nullptr);
@@ -1663,6 +1698,7 @@ void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float 
 static void host_binary(const char* who, int batch, int vsize, const float* tensor, const float* vector, int vstep,
                         float* out, bool mul) {
   std::lock_guard<std::mutex> host_lock(g_host_mu);
+  CachePin pin;
   if (batch <= 0 || vsize <= 0) return;  // nothing to do (and batch - 1 below must not wrap)
   bool ok = have_device();
   if (ok) {

@@ -210,7 +210,8 @@ int ns_tp_reduce_add(ns_tp* t, const float* dSend, float* dRecv, size_t count, v
   }
   // NS_TP_FORCE_RCCL=1: a single rank still goes through its (one-rank) RCCL communicator — lets a one-GPU box
   // exercise library loading, communicator set-up and the collective calls themselves
-  static const bool force = getenv("NS_TP_FORCE_RCCL") != nullptr && t->comm != nullptr;
+  static const bool force_env = getenv("NS_TP_FORCE_RCCL") != nullptr;  // the environment only: contexts differ
+  const bool force = force_env && t->comm != nullptr;
   if (t->world == 1 && !force) {
     if (dSend != dRecv &&
         hipMemcpyAsync(dRecv, dSend, count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
@@ -247,6 +248,7 @@ int ns_tp_alltoall(ns_tp* t, const float* dSend, float* dRecv, size_t count, voi
 
 int ns_tp_barrier(ns_tp* t, void* stream) {
   if (!t) return -1;
+  if (t->device < 0) return 0;  // the solo context without a GPU: nothing to order
   if ((t->world > 1 || (getenv("NS_TP_FORCE_RCCL") && t->comm)) &&
       !nccl_ok(g_rccl.all_reduce(t->d_token, t->d_token, 1, kNcclInt32, kNcclSum, t->comm, (hipStream_t)stream), "barrier"))
     return -1;

@@ -833,6 +833,7 @@ int nso_unpack_fp32(const void* blob, float* out, int ldb) {
   zp.resize(size_t(nblk) * bi.n);
   nso_unpack_canonical(blob, q.data(), sc.data(), zp.data());
   const bool is_int = bi.prologue_id == 1;
+#pragma omp parallel for schedule(static)
   for (int kk = 0; kk < bi.k; kk++)
     for (int c = 0; c < bi.n; c++) {
       const size_t si = size_t(kk / bi.blocksize) * bi.n + c;
@@ -844,34 +845,60 @@ int nso_unpack_fp32(const void* blob, float* out, int ldb) {
   return 0;
 }
 
-static int gemm_f64_impl(const float* a, int lda, const void* blob, double* c, int ldc, int m, bool a16) {
+// fp64 GEMM over the unpacked weights; per output the products are added in ascending k — column blocks of 128 and row
+// blocks of 8 only change which outputs share a pass over W, not any output's summation order.  which: bit 0 = fp32
+// activations -> c, bit 1 = activations rounded through fp16 first -> c16 (one unpack serves both).
+static int gemm_f64_impl(const float* a, int lda, const void* blob, double* c, double* c16, int ldc, int m, int which) {
   nso_blob_info bi;
   if (nso_blob_parse(blob, &bi)) return -1;
   std::vector<float> w(size_t(bi.k) * bi.n);
   nso_unpack_fp32(blob, w.data(), bi.n);
   const int* shuf = bi.has_shuffle ? (const int*)((const uint8_t*)blob + bi.shuf_off) : nullptr;
-  std::vector<double> arow(bi.k);
-  for (int i = 0; i < m; i++) {
-    for (int kk = 0; kk < bi.k; kk++) {
-      // activation shuffle (g_idx blobs): A'[j] = A[indices[j]], kernel_ref.h:28-37 via prologue_a.h:322-330
-      float av = a[size_t(i) * lda + (shuf ? shuf[kk] : kk)];
-      if (a16) av = round_through_ieee_f16(av);  // what v_cvt_f16_f32 (RNE) does on the device
-      arow[kk] = av;
-    }
-#pragma omp parallel for schedule(static)
-    for (int j = 0; j < bi.n; j++) {
-      double acc = 0;
-      for (int kk = 0; kk < bi.k; kk++) acc += arow[kk] * double(w[size_t(kk) * bi.n + j]);
-      c[size_t(i) * ldc + j] = acc;
+  const int K = bi.k, N = bi.n;
+  for (int pass = 0; pass < 2; pass++) {
+    if (!(which & (1 << pass))) continue;
+    const bool a16 = pass == 1;
+    double* out = a16 ? c16 : c;
+    std::vector<double> arows(size_t(m) * K);
+    for (int i = 0; i < m; i++)
+      for (int kk = 0; kk < K; kk++) {
+        // activation shuffle (g_idx blobs): A'[j] = A[indices[j]], kernel_ref.h:28-37 via prologue_a.h:322-330
+        float av = a[size_t(i) * lda + (shuf ? shuf[kk] : kk)];
+        if (a16) av = round_through_ieee_f16(av);  // what v_cvt_f16_f32 (RNE) does on the device
+        arows[size_t(i) * K + kk] = av;
+      }
+    constexpr int JB = 128, IB = 8;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int jb = 0; jb < N; jb += JB) {
+      const int jn = std::min(JB, N - jb);
+      for (int ib = 0; ib < m; ib += IB) {
+        const int in = std::min(IB, m - ib);
+        double acc[IB][JB];
+        for (int i = 0; i < in; i++)
+          for (int j = 0; j < jn; j++) acc[i][j] = 0;
+        for (int kk = 0; kk < K; kk++) {
+          const float* wr = &w[size_t(kk) * N + jb];
+          for (int i = 0; i < in; i++) {
+            const double av = arows[size_t(ib + i) * K + kk];
+            for (int j = 0; j < jn; j++) acc[i][j] += av * double(wr[j]);
+          }
+        }
+        for (int i = 0; i < in; i++)
+          for (int j = 0; j < jn; j++) out[size_t(ib + i) * ldc + jb + j] = acc[i][j];
+      }
     }
   }
   return 0;
 }
 int nso_gemm_f64(const float* a, int lda, const void* blob, double* c, int ldc, int m) {
-  return gemm_f64_impl(a, lda, blob, c, ldc, m, false);
+  return gemm_f64_impl(a, lda, blob, c, nullptr, ldc, m, 1);
 }
 int nso_gemm_f64_a16(const float* a, int lda, const void* blob, double* c, int ldc, int m) {
-  return gemm_f64_impl(a, lda, blob, c, ldc, m, true);
+  return gemm_f64_impl(a, lda, blob, nullptr, c, ldc, m, 2);
+}
+// both forms from one unpack of the blob (full-size parity tests)
+int nso_gemm_f64_pair(const float* a, int lda, const void* blob, double* c, double* c16, int ldc, int m) {
+  return gemm_f64_impl(a, lda, blob, c, c16, ldc, m, 3);
 }
 
 // gemv_{N}bit_fp32_fp32 — kernel_ref.h:2489-2531: acc[n] += a[k] * (code - zp) * scale, fp32, k ascending.

@@ -135,6 +135,8 @@ int nso_gemm_f64(const float* a, int lda, const void* blob, double* c, int ldc, 
 /* same but A first rounded to fp16 (what the HIP kernels feed the MFMA/dot units) — used to separate
  * activation-rounding error from kernel error in tests */
 int nso_gemm_f64_a16(const float* a, int lda, const void* blob, double* c, int ldc, int m);
+/* both of the above from ONE unpack of the blob: c = fp32 activations, c16 = activations rounded through fp16 */
+int nso_gemm_f64_pair(const float* a, int lda, const void* blob, double* c, double* c16, int ldc, int m);
 /* sequential-k fp32 accumulation exactly as gemv_4bit_fp32_fp32 does it (kernel_ref.h:2489-2531), threaded over N
  * with OpenMP; used as the timed CPU baseline ("port") */
 int nso_gemv_f32(const float* a, int lda, const void* blob, float* c, int ldc, int m, int nthreads);

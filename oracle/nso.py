@@ -440,6 +440,17 @@ def gemm_f64(a, blob, a16=False):
     return c
 
 
+def gemm_f64_pair(a, blob):
+    """(gemm_f64(a, blob), gemm_f64(a, blob, a16=True)) from one unpack of the blob"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    bi = parse(blob)
+    m = a.shape[0]
+    c = np.zeros((m, bi.n), np.float64)
+    c16 = np.zeros((m, bi.n), np.float64)
+    assert lib().nso_gemm_f64_pair(ptr(a), a.shape[1], ptr(blob), ptr(c), ptr(c16), bi.n, m) == 0
+    return c, c16
+
+
 def gemv_f32(a, blob, nthreads=0):
     a = np.ascontiguousarray(a, dtype=np.float32)
     bi = parse(blob)
