@@ -188,6 +188,8 @@ int ns_hip_get_compute_mode(void);
  *   "gemv2"           0 = first-generation decode kernel only, 1 = gemv_kernel (default); also NS_GEMV2 in the environment
  *   "g3_bm"           row-tile height of the prefill GEMM (128 / 256), 0 = automatic
  *   "attn_wg_target", "attn_min_keys"   context-split rule of the decode attention kernel (defaults 1024, 128)
+ *   "gv_nw"           waves per 16-column tile of the decode kernels (2 / 4 / 8 / 16), 0 = by shape (default); the
+ *                     partial sums of a tile are added in wave order, so this selects the summation order
  * Returns 0, or -1 for an unknown key. */
 int ns_hip_set_tuning(const char* key, int value);
 
@@ -353,6 +355,32 @@ int ns_hip_quantize_fp_u8_colblock(int row, int col, const float* dSrc, int ld_s
 int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, size_t ldb, size_t BlkSize,
                              uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType, bool isTrans,
                              void* stream);
+
+/* ---- Part 3b — decode engine: a chain of batch-1 GEMV operators as ONE persistent launch (csrc/ns_engine.hip) ----
+ * What it replaces: the per-operator calls ne_graph_compute makes for a decode token (ne_layers.c:11918-11998 ->
+ * bestla_f32f32_forward / bestla_fusion_FFN_SiLu_f32f32_forward per node), when the caller can hand over the whole
+ * chain at once.  One workgroup per CU stays resident for the token: a loader wave streams the weights ahead across
+ * operator boundaries, consumer waves run gemv_kernel's arithmetic, outputs travel between workgroups as 8-byte tagged
+ * granules.  v0 envelope: one row, int4 symmetric group-32 bf16-scale weights, K a multiple of 128 and <= 11008.
+ * Results equal ns_hip_f32f32_forward_h's with 8 waves per tile (ns_hip_set_tuning("gv_nw", 8)) bit for bit. */
+typedef struct ns_engine ns_engine;
+typedef struct ns_engine_op {
+  const ns_weight* w0;
+  const ns_weight* w1; /* second matrix of a fused gate/up operator: out = (x*w1) * act(x*w0); NULL otherwise */
+  int input;           /* index of the operator whose fp16 output row feeds this one (its first K values);
+                          -1 = the external input row; -2 = the same input as the previous operator */
+  float* c;            /* fp32 output [n] in device memory, may be NULL when only later operators read it */
+  int epilogue;        /* enum ns_epilogue: NONE / SILU / GELU (fused operator: SILU or GELU) */
+} ns_engine_op;
+/* x16: fp16 [K of operator 0] in device memory, read at every launch.  NULL + ns_hip_last_error() on failure. */
+ns_engine* ns_hip_engine_create(const ns_engine_op* ops, int nops, const void* x16);
+/* one token; asynchronous on `stream`, capturable into a HIP graph */
+int ns_hip_engine_launch(ns_engine* e, void* stream);
+/* 0 = every launch so far ran to the end; else the first give-up code of a bounded wait (synchronises the device) */
+unsigned ns_hip_engine_status(ns_engine* e);
+void ns_hip_engine_destroy(ns_engine* e);
+/* diagnostics (library built with -DNS_ENG_TRACE): per workgroup and operator, eight 100 MHz time stamps */
+int ns_hip_engine_trace(ns_engine* e, unsigned long long* out, int nwg);
 
 /* ----------------------------------------------------------------------------------------------
  * Part 4 — fused attention: the C surface `ne_compute_forward_flash_attn_f32_f16_f16`

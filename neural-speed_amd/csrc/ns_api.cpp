@@ -753,6 +753,14 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_gemm3_bm(value);
     return 0;
   }
+  if (key && !strcmp(key, "gv_nw")) {
+    if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16) {
+      set_error("ns_hip_set_tuning: gv_nw must be 0, 2, 4, 8 or 16");
+      return -1;
+    }
+    set_decode_waves(value);
+    return 0;
+  }
   if (key && !strcmp(key, "attn_wg_target")) {
     set_attn_tuning(value, 0);
     return 0;

@@ -164,6 +164,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st);
 void set_gemv_mode(int mode);
 void set_attn_tuning(int wg_target, int min_keys);
 void set_gemm3_bm(int bm);  // ns_gemm.hip: force gemm3_kernel's row-tile height (tests / A-B runs); 0 = automatic  // ns_attn.hip: context-split rule of the decode attention kernel
+void set_decode_waves(int nw);  // 0 = by shape
 int decode_waves(int grid, int ks, bool dual);  // waves per workgroup of a decode launch (both kernel generations)  // 0 off, 1 on, 2 on without the stream-K part, -1 re-read NS_GEMV2
 void srow_rule(const ns_weight* w, int* num, int* den);          // scale row of k-step s = s * num / den
 // the same rule as a branch-free (s * mul) >> shift, verified for every k-step; false = not expressible

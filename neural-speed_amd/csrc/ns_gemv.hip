@@ -626,6 +626,8 @@ static int gemv_mode() {
 // waves per workgroup of a decode launch (one 16-column tile per workgroup, k-steps dealt round-robin to the waves).
 // Shared with smallm_kernel so that both kernels add a tile's partial sums in the same order: a caller that passes the
 // fp16 shadow of A (gemv_kernel) gets bit for bit what the fp32-only caller (smallm_kernel) gets.
+static std::atomic<int> g_decode_waves{0};  // ns_hip_set_tuning("gv_nw", n)
+void set_decode_waves(int nw) { g_decode_waves.store(nw); }
 int decode_waves(int grid, int ks, bool dual) {
   // measured on the 7B shapes (profiles/r02g_sweep.txt): 256 tiles x 32 k-steps (attention output) 16 waves, 256 tiles
   // x 86 k-steps (FFN down) 8 waves (7.5 vs 8.0 us at 16), 768 tiles 4 waves, 2000 tiles (lm_head) 2 waves
@@ -636,7 +638,9 @@ int decode_waves(int grid, int ks, bool dual) {
     const int target_waves = 2560;
     while (nw > 2 && grid * (nw / 2) >= target_waves) nw /= 2;
   }
-  static const int env_nw = getenv("NS_GV_NW") ? atoi(getenv("NS_GV_NW")) : 0;  // diagnostics
+  static const int env_nw0 = getenv("NS_GV_NW") ? atoi(getenv("NS_GV_NW")) : 0;  // diagnostics
+  const int forced = g_decode_waves.load();
+  const int env_nw = forced ? forced : env_nw0;
   if (env_nw == 2 || env_nw == 4 || env_nw == 8 || (env_nw == 16 && !dual)) nw = env_nw;
   while (nw > 1 && nw > ks) nw /= 2;
   return nw;
