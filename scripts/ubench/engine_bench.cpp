@@ -144,7 +144,12 @@ int main(int argc, char** argv) {
     NSCK(ns_hip_fusion_qkv_forward_h(in, inh, l.q, l.k, l.v, qkv, qkvh, 1, d, d, g_st));
   };
   auto op_wo = [&](const Layer& l) { NSCK(ns_hip_f32f32_forward_h(qkv, qkvh, l.o, attn, attnh, 1, d, d, NS_EPI_NONE, nullptr, 0, g_st)); };
-  auto op_gu = [&](const Layer& l) { NSCK(ns_hip_fusion_ffn3_gateup_h(attn, attnh, l.w1, l.w3, nullptr, t2, t2h, 1, NS_EPI_SILU, g_st)); };
+  int ref_nw = 0;  // 0: the launches' own choice; 16: the engine's summation order (fused gate/up: 8)
+  auto op_gu = [&](const Layer& l) {
+    if (ref_nw) ns_hip_set_tuning("gv_nw", 8);
+    NSCK(ns_hip_fusion_ffn3_gateup_h(attn, attnh, l.w1, l.w3, nullptr, t2, t2h, 1, NS_EPI_SILU, g_st));
+    if (ref_nw) ns_hip_set_tuning("gv_nw", ref_nw);
+  };
   auto op_dn = [&](const Layer& l) { NSCK(ns_hip_f32f32_forward_h(t2, t2h, l.w2, x, xh, 1, ff, d, NS_EPI_NONE, nullptr, 0, g_st)); };
   auto op_head = [&](const float* in, _Float16* inh) {
     NSCK(ns_hip_f32f32_forward_h(in, inh, head, logits, nullptr, 1, d, V, NS_EPI_NONE, nullptr, 0, g_st));
@@ -169,6 +174,7 @@ int main(int argc, char** argv) {
   };
 
   // ---- reference: the launches with the engine's summation order (8 waves per tile) ----
+  ref_nw = 8;
   ns_hip_set_tuning("gv_nw", 8);
   std::vector<std::vector<float>> ref;
   {
@@ -261,6 +267,7 @@ int main(int argc, char** argv) {
     hipGraphExec_t gc = capture(chain);
     const double tc8 = time_graph(gc, reps);
     CK(hipGraphExecDestroy(gc));
+    ref_nw = 0;
     ns_hip_set_tuning("gv_nw", 0);
     gc = capture(chain);
     const double tc = time_graph(gc, reps);
@@ -292,9 +299,9 @@ int main(int argc, char** argv) {
       for (int g = 0; g < nwg; g++)
         for (int k = 0; k < 8; k++) {
           const unsigned long long v = tr[(size_t(g) * 64 + 0) * 8 + k];
-          if (v && v < t0) t0 = v;
+          if (v && v < t0 && (k < 4 || k >= 6)) t0 = v;
         }
-      const char* nm[8] = {"ld0", "ld1", "g0", "g1", "cwait", "crdy", "cdone", "pub"};
+      const char* nm[8] = {"ld0", "ld1", "in0", "in1", "clk_wait", "clk_math", "c_done", "pub"};
       fprintf(stderr, "stamps in us since the first stamp of the launch; columns:");
       for (int k = 0; k < 8; k++) fprintf(stderr, " %s", nm[k]);
       fprintf(stderr, "\n");
@@ -303,7 +310,8 @@ int main(int argc, char** argv) {
           fprintf(stderr, "wg %3d op %2d:", g, op);
           for (int k = 0; k < 8; k++) {
             const unsigned long long v = tr[(size_t(g) * 64 + op) * 8 + k];
-            if (v) fprintf(stderr, " %8.2f", double(v - t0) / 100.0);
+            if (k >= 4 && k <= 5) fprintf(stderr, " %8llu", v);  // durations in shader clocks (wait / LDS + arithmetic / requests)
+            else if (v) fprintf(stderr, " %8.2f", double(v - t0) / 100.0);
             else fprintf(stderr, " %8s", "-");
           }
           fprintf(stderr, "\n");
@@ -314,10 +322,10 @@ int main(int argc, char** argv) {
         for (int g = 0; g < nwg; g++) {
           const unsigned long long* r = &tr[(size_t(g) * 64 + op) * 8];
           if (r[7]) pmax = std::max(pmax, r[7]), pmin = std::min(pmin, r[7]);
-          rmax = std::max(rmax, r[5]);
+          rmax = std::max(rmax, r[3]);
           dmax = std::max(dmax, r[6]);
         }
-        fprintf(stderr, "op %2d: first publish %8.2f last publish %8.2f | last input-ready %8.2f | last consumer-0 done %8.2f\n", op,
+        fprintf(stderr, "op %2d: first publish %8.2f last publish %8.2f | last input staged %8.2f | last wave-0 done %8.2f\n", op,
                 pmin == ~0ull ? 0.0 : double(pmin - t0) / 100.0, pmax ? double(pmax - t0) / 100.0 : 0.0, rmax ? double(rmax - t0) / 100.0 : 0.0,
                 dmax ? double(dmax - t0) / 100.0 : 0.0);
       }
