@@ -43,7 +43,9 @@ static int64_t tensor_rows(const struct ne_tensor* t) { return t->ne[1] * t->ne[
 bool bestla_support(struct ne_tensor* node, int n_threads, size_t* workspace, size_t* dev_workspace) {
   (void)n_threads;
   size_t ws = 0;
-  bool claimed = false;
+  /* every node that lives on the device is this backend's (ne_bestla.cpp:209-211: the generic executor asserts a CPU node,
+   * ne_layers.c:11900); its operator is one of bestla_device_* (glue/ne_bestla_hip_device.c, libns_hip.so) */
+  bool claimed = node->backend == NE_BACKEND_SYCL;
   const struct ne_tensor *a = node->src0, *b = node->src1;
   switch (node->op) {
     case NE_OP_MUL_MAT:
@@ -52,7 +54,8 @@ bool bestla_support(struct ne_tensor* node, int n_threads, size_t* workspace, si
       /* MUL_MAT_ID: src0 is the first expert, the n_as experts are opt[0..] (ne_layers.c:7783-7916) */
       const struct ne_tensor* wei = node->op == NE_OP_MUL_MAT_ID ? node->opt[0] : a;
       if (a->type == NE_TYPE_BTLA) {
-        ws = bestla_f32f32_get_workspace_size((int)b->ne[1], (int)wei->ne[1], (int)b->ne[0], wei->data);
+        if (a->backend == NE_BACKEND_CPU) /* a device-resident weight's data is a storage record, not a blob (ne_bestla.cpp:222-225) */
+          ws = bestla_f32f32_get_workspace_size((int)b->ne[1], (int)wei->ne[1], (int)b->ne[0], wei->data);
         claimed = true;
       }
     } break;
@@ -76,15 +79,15 @@ bool bestla_support(struct ne_tensor* node, int n_threads, size_t* workspace, si
       break;
     case NE_OP_ADD:
     case NE_OP_MUL: /* bestla_add / bestla_mul: contiguous fp32, src1 one row or as many rows as src0 */
-      claimed = tensor_is_dense(b) && tensor_is_dense(a) && (tensor_rows(b) == 1 || tensor_rows(b) == tensor_rows(a)) &&
-                a->ne[0] == b->ne[0] && node->nb[0] == sizeof(float);
+      claimed = claimed || (tensor_is_dense(b) && tensor_is_dense(a) && (tensor_rows(b) == 1 || tensor_rows(b) == tensor_rows(a)) &&
+                            a->ne[0] == b->ne[0] && node->nb[0] == sizeof(float));
       break;
     case NE_OP_NORM:
     case NE_OP_RMS_NORM: /* bestla_layernormalization */
-      claimed = tensor_is_dense(a);
+      claimed = claimed || tensor_is_dense(a);
       break;
     case NE_OP_ROPE: /* only the (CPU tile-packed) BTLA kv-cache form, which this backend never creates */
-      claimed = node->type == NE_TYPE_BTLA;
+      claimed = claimed || node->type == NE_TYPE_BTLA;
       break;
     default:
       break;
@@ -95,11 +98,30 @@ bool bestla_support(struct ne_tensor* node, int n_threads, size_t* workspace, si
   return claimed;
 }
 
-/* Tensors live in host memory on this path (the device-resident API is ns_hip_*): every node stays on NE_BACKEND_CPU,
- * as the reference answers without NS_SYCL (ne_bestla.cpp:176-203). */
+/* Where a new node lives (ne_bestla.cpp:176-203).  Without NS_SYCL every node stays in host memory (the library's
+ * host-pointer entries stage per call).  With NS_SYCL — the reference's own device switch; the device set it then calls
+ * is bestla_device_* of libns_hip.so + glue/ne_bestla_hip_device.c — a BTLA matmul and the fp32 RMS_NORM / SILU / ADD /
+ * MUL follow their inputs onto the device, exactly the reference's table. */
 enum ne_backend bestla_backend_support(struct ne_tensor* a, struct ne_tensor* b, enum ne_op op) {
+#ifdef NS_SYCL
+  const bool on_device = a->backend == NE_BACKEND_SYCL || (b && b->backend == NE_BACKEND_SYCL);
+  switch (op) {
+    case NE_OP_MUL_MAT:
+      if (a->type == NE_TYPE_BTLA) return on_device ? NE_BACKEND_SYCL : NE_BACKEND_CPU;
+      break;
+    case NE_OP_RMS_NORM:
+    case NE_OP_SILU:
+    case NE_OP_ADD:
+    case NE_OP_MUL:
+      if (a->type == NE_TYPE_F32) return on_device ? NE_BACKEND_SYCL : NE_BACKEND_CPU;
+      break;
+    default:
+      break;
+  }
+#else
   (void)a;
   (void)b;
   (void)op;
+#endif
   return NE_BACKEND_CPU;
 }

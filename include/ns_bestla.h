@@ -356,6 +356,35 @@ int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, s
                              uint32_t QuantType, uint32_t ScaleDtype, bool isAsym, int CompType, bool isTrans,
                              void* stream);
 
+/* ---- Part 3a — the reference's device-backend set under its own names (ne_bestla.h:85-112, guarded there by NS_SYCL;
+ * csrc/ns_device.hip).  The pointer-only functions are exported by libns_hip.so AS IS — a reference tree built with
+ * -DNS_SYCL binds to them — and the tensor-level ones (bestla_device_mul_f32 / _add_f32 / _elewise_f32 / _rms_norm_f32 /
+ * _rope_f32 / _dup_f32 / _mha_f32) are glue/ne_bestla_hip_device.c over the ns_hip_* entries.  "queue" = hipStream_t. ---- */
+void* bestla_create_device(bool profile);
+void* bestla_get_device_queue(void* device);
+void bestla_release_device(void* device);
+size_t bestla_device_gmem_size(void* device);
+void* bestla_device_malloc(size_t size, void* queue);
+void bestla_device_free(void* ptr, void* queue);
+void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue);
+void bestla_device_memcpy_sync(void* dstptr, const void* srcptr, size_t size, void* queue);
+void bestla_device_sync(void* queue);
+size_t bestla_device_storage_size(void);
+/* hoststor: BTLA blob in host memory; devstor: bestla_device_storage_size() bytes inside the tensor object
+ * (ne_layers.c:946-949); deviceptr: the device-pool slice the graph reserved (unused: the weight gets its own allocation
+ * in this library's streaming layout) */
+void bestla_device_load_storage(void* hoststor, void* devstor, void* deviceptr, void* queue);
+void bestla_device_f32f32_forward(float* activation, void* weiptr, float* output, int _m, int _n, int _k, int lda, int ldo,
+                                  void* workspace, void* queue);
+void ns_hip_device_storage_release(void* devstor);
+/* ne's broadcasting add (is_mul = 0) / mul over four strided dimensions: dst[i] = a[i] op b[i mod ne1]; strides in bytes */
+int ns_hip_binary_nd_f32(int is_mul, const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4],
+                         const long long ne1[4], const long long nb1[4], const long long nbd[4], void* stream);
+/* attention over the device prototype's fp32 kv cache (ne_bestla_sycl.cpp:592-880): q / o [batch][seq][heads][head_size],
+ * k [batch][heads_kv][n_ctx][head_size], v [batch][heads_kv][head_size][n_ctx]; masked: causal with n_past = seq_all - seq */
+int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* dV, float* dO, int batch, int seq, int seq_all, int heads,
+                                 int heads_kv, int head_size, int n_ctx, float scale, int masked, void* stream);
+
 /* ---- Part 3b — decode engine: a chain of batch-1 GEMV operators as ONE persistent launch (csrc/ns_engine.hip) ----
  * What it replaces: the per-operator calls ne_graph_compute makes for a decode token (ne_layers.c:11918-11998 ->
  * bestla_f32f32_forward / bestla_fusion_FFN_SiLu_f32f32_forward per node), when the caller can hand over the whole

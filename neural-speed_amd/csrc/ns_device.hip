@@ -1,0 +1,305 @@
+// ns_device.hip — the device-backend half of neural-speed's BesTLA surface
+// (/root/reference/neural_speed/core/ne_bestla.h:85-112, the set the reference guards with NS_SYCL; reference
+// implementation core/layers/ne_bestla_sycl.cpp) for MI355X.  With these symbols a reference tree built with -DNS_SYCL
+// runs its UNCHANGED graph device-resident: tensors of the offloaded layers live in HBM (ne_new_device_tensor_impl,
+// ne_layers.c:904-1050), BTLA weights are re-laid-out once at load (model_files.h:1515-1527), every operator of those
+// layers is a HIP launch on one stream and only the token ids go in and the logits come out over PCIe.
+//
+// This file holds the functions whose signatures are plain pointers — exported under the reference's own names, so
+// libns_hip.so is the drop-in for them — and two kernels the tensor-level functions need (the tensor-level functions
+// themselves take ne_tensor and live in glue/ne_bestla_hip_device.c, compiled against the reference's headers):
+//   * nd_binary_kernel: ne's broadcasting add / mul over four strided dimensions (ne_bestla_sycl.cpp:174-295)
+//   * mha_f32_kernel:   the device prototype's attention over its fp32 kv cache, K [batch][heads][n_ctx][head_size],
+//                       V [batch][heads][head_size][n_ctx] (ne_bestla_sycl.cpp:592-880; llama.cpp:241-285 lays the cache
+//                       out like that).  One workgroup per (head, query row, batch): scores, soft-max in LDS, P*V.
+//                       HBM-bound on the kv stream; written for correctness first — the tuned kernels of this library
+//                       (ns_attn.hip) read an fp16 cache, which the reference's device path does not create.
+// "queue" is a hipStream_t throughout.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ns_bestla.h"
+#include "ns_common.h"
+
+namespace ns {
+
+struct NdArgs {
+  long long ne0[4];      // extents of src0 / dst
+  long long nb0[4];      // byte strides of src0
+  long long ne1[4];      // extents of src1 (each 1 or ne0[i]: broadcast by modulo, as the reference does)
+  long long nb1[4];
+  long long nbd[4];
+};
+__global__ __launch_bounds__(256) void nd_binary_kernel(const char* a, const char* b, char* d, NdArgs g, long long total, int op) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long i0 = i % g.ne0[0];
+  i /= g.ne0[0];
+  const long long i1 = i % g.ne0[1];
+  i /= g.ne0[1];
+  const long long i2 = i % g.ne0[2];
+  const long long i3 = i / g.ne0[2];
+  const float x = *reinterpret_cast<const float*>(a + i3 * g.nb0[3] + i2 * g.nb0[2] + i1 * g.nb0[1] + i0 * g.nb0[0]);
+  const float y = *reinterpret_cast<const float*>(b + (i3 % g.ne1[3]) * g.nb1[3] + (i2 % g.ne1[2]) * g.nb1[2] + (i1 % g.ne1[1]) * g.nb1[1] +
+                                                  (i0 % g.ne1[0]) * g.nb1[0]);
+  *reinterpret_cast<float*>(d + i3 * g.nbd[3] + i2 * g.nbd[2] + i1 * g.nbd[1] + i0 * g.nbd[0]) = op ? x * y : x + y;
+}
+
+// q [batch][seq][heads][hs] (contiguous), k [batch][heads_kv][n_ctx][hs], v [batch][heads_kv][hs][n_ctx], o like q.
+// masked: key j is visible to query row iq when j <= iq + (seq_all - seq)  (ne_bestla_sycl.cpp:633-644)
+__global__ __launch_bounds__(256) void mha_f32_kernel(const float* q, const float* k, const float* v, float* o, int seq, int seq_all,
+                                                      int heads, int heads_kv, int hs, int n_ctx, float scale, int masked) {
+  extern __shared__ float sm[];  // [seq_all] scores, then [256] reduction scratch
+  float* sc = sm;
+  float* red = sm + ((seq_all + 3) & ~3);
+  const int ih = blockIdx.x, iq = blockIdx.y, ib = blockIdx.z;
+  const int hkv = ih / (heads / heads_kv);
+  const int t = threadIdx.x;
+  const float* qp = q + ((size_t(ib) * seq + iq) * heads + ih) * hs;
+  const float* kp = k + (size_t(ib) * heads_kv + hkv) * size_t(n_ctx) * hs;
+  const float* vp = v + (size_t(ib) * heads_kv + hkv) * size_t(hs) * n_ctx;
+  const int visible = masked ? min(seq_all, iq + (seq_all - seq) + 1) : seq_all;
+  // ---- scores: a quarter-wave (16 lanes) per key, lanes split the head dimension (coalesced 64-byte reads of K) ----
+  const int sub = t & 15, grp = t >> 4;  // 16 keys in flight per workgroup pass
+  float mx = -INFINITY;
+  for (int j0 = 0; j0 < visible; j0 += 16) {
+    const int j = j0 + grp;
+    float s = 0.f;
+    if (j < visible) {
+      const float* kr = kp + size_t(j) * hs;
+      for (int e = sub; e < hs; e += 16) s += qp[e] * kr[e];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s *= scale;
+    if (j < visible) {
+      if (sub == 0) sc[j] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  red[t] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) red[t] = fmaxf(red[t], red[t + w]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = t; j < visible; j += 256) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  red[t] = sum;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) red[t] += red[t + w];
+    __syncthreads();
+  }
+  const float inv = 1.f / red[0];
+  __syncthreads();
+  // ---- P * V: V is [hs][n_ctx]: a quarter-wave per output element walks the keys (coalesced reads along n_ctx) ----
+  for (int e0 = 0; e0 < hs; e0 += 16) {
+    const int e = e0 + grp;
+    float acc = 0.f;
+    if (e < hs) {
+      const float* vr = vp + size_t(e) * n_ctx;
+      for (int j = sub; j < visible; j += 16) acc += sc[j] * vr[j];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if (e < hs && sub == 0) o[((size_t(ib) * seq + iq) * heads + ih) * hs + e] = acc * inv;
+  }
+}
+
+// what bestla_device_load_storage leaves in the tensor object behind a device-resident BTLA weight
+// (ne_layers.c:946-949 reserves bestla_device_storage_size() bytes there).  It starts with a word no BTLA blob can start
+// with (a blob's first field is its size, bestla_storage.h:250-317): the host-pointer entry points (_support, forward)
+// recognise a blob by that field and refuse this struct instead of parsing it.
+struct DeviceStorage {
+  uint64_t not_a_blob;  // 0xffffffffffffffff
+  uint64_t magic;       // "NSHIPDEV"
+  ns_weight* w;
+  int n, k;
+  uint64_t reserved[4];
+};
+constexpr uint64_t kDevMagic = 0x564544504948534eull;
+
+struct Device {
+  hipStream_t stream;
+  int id;
+};
+
+}  // namespace ns
+
+extern "C" {
+
+/* ---- ne_bestla.h:86-96, ne_bestla_sycl.cpp:26-92 ---- */
+void* bestla_create_device(bool profile) {
+  (void)profile;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    ns::set_error("bestla_create_device: no HIP device visible");
+    return nullptr;
+  }
+  ns::Device* d = new ns::Device();
+  d->id = 0;
+  if (hipGetDevice(&d->id) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete d;
+    ns::set_error("bestla_create_device: stream creation failed");
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, d->id) == hipSuccess)
+    fprintf(stderr, "bestla device: %s, %d CUs, %.1f GB\n", prop.name, prop.multiProcessorCount, double(prop.totalGlobalMem) / 1e9);
+  return d;
+}
+void* bestla_get_device_queue(void* device) { return device ? static_cast<ns::Device*>(device)->stream : nullptr; }
+void bestla_release_device(void* device) {
+  if (!device) return;
+  ns::Device* d = static_cast<ns::Device*>(device);
+  (void)hipStreamSynchronize(d->stream);
+  (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+size_t bestla_device_gmem_size(void* device) {
+  (void)device;
+  size_t fr = 0, total = 0;
+  return hipMemGetInfo(&fr, &total) == hipSuccess ? total : 0;
+}
+void* bestla_device_malloc(size_t size, void* queue) {
+  (void)queue;
+  void* p = nullptr;
+  if (hipMalloc(&p, size ? size : 1) != hipSuccess) {
+    ns::set_error("bestla_device_malloc: out of device memory");
+    return nullptr;
+  }
+  return p;
+}
+void bestla_device_free(void* ptr, void* queue) {
+  (void)queue;
+  if (ptr) (void)hipFree(ptr);
+}
+void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {
+  if (!dstptr || !srcptr || !size) return;
+  if (hipMemcpyAsync(dstptr, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
+    ns::set_error("bestla_device_memcpy failed");
+}
+void bestla_device_sync(void* queue) { (void)hipStreamSynchronize(static_cast<hipStream_t>(queue)); }
+void bestla_device_memcpy_sync(void* dstptr, const void* srcptr, size_t size, void* queue) {
+  bestla_device_memcpy(dstptr, srcptr, size, queue);
+  bestla_device_sync(queue);
+}
+
+/* ---- ne_bestla.h:97-98, ne_bestla_sycl.cpp:92-141 ---- */
+size_t bestla_device_storage_size(void) { return sizeof(ns::DeviceStorage); }
+
+/* hoststor: the BTLA blob as read from the model file (host memory); devstor: the tensor's storage area; deviceptr: the
+ * slice of the device pool the graph reserved for this tensor (blob-sized).  The weight is re-laid-out into this
+ * library's streaming layout in ITS OWN allocation (alloc_weight): the layout's size differs from the blob's (other tile
+ * padding, no reduce section), so the reserved slice stays unused — 1x the model's size of HBM, out of 288 GB. */
+void bestla_device_load_storage(void* hoststor, void* devstor, void* deviceptr, void* queue) {
+  (void)deviceptr;
+  if (!hoststor || !devstor) return;
+  ns::DeviceStorage* s = static_cast<ns::DeviceStorage*>(devstor);
+  memset(s, 0, sizeof(*s));
+  s->not_a_blob = ~0ull;
+  ns_weight* w = ns_hip_weight_from_blob(hoststor, queue);
+  if (!w) {
+    fprintf(stderr, "bestla_device_load_storage: %s\n", ns_hip_last_error());
+    return;  // magic stays 0: the forward refuses the tensor loudly
+  }
+  (void)hipStreamSynchronize(static_cast<hipStream_t>(queue));  // the caller frees hoststor right after (model_files.h:1526)
+  s->magic = ns::kDevMagic;
+  s->w = w;
+  int bits = 0, bs = 0;
+  uint64_t db = 0;
+  ns_hip_weight_info(w, &s->n, &s->k, &bits, &bs, &db);
+}
+
+/* ---- ne_bestla.h:99-100, ne_bestla_sycl.cpp:149-171; called by ne_compute_forward_mul_mat_q_f32_bestla
+ *      (ne_layers.c:7305-7309) with device pointers ---- */
+void bestla_device_f32f32_forward(float* activation, void* weiptr, float* output, int _m, int _n, int _k, int lda, int ldo,
+                                  void* workspace, void* queue) {
+  (void)workspace;
+  const ns::DeviceStorage* s = static_cast<const ns::DeviceStorage*>(weiptr);
+  if (!s || s->magic != ns::kDevMagic || !s->w || s->n != _n || s->k != _k) {
+    ns::set_error("bestla_device_f32f32_forward: not a weight loaded by bestla_device_load_storage (or a shape mismatch)");
+    printf("Err: invalid parameters (bestla_device_f32f32_forward: %s)\n", ns_hip_last_error());
+    return;
+  }
+  if (ns_hip_f32f32_forward(activation, s->w, output, _m, lda, ldo, NS_EPI_NONE, nullptr, 0, queue) != 0)
+    printf("Err: invalid parameters (bestla_device_f32f32_forward: %s)\n", ns_hip_last_error());
+}
+
+/* releases the device copy behind a storage area (the reference never frees its device weights either; offered for
+ * callers that reload models in one process) */
+void ns_hip_device_storage_release(void* devstor) {
+  ns::DeviceStorage* s = static_cast<ns::DeviceStorage*>(devstor);
+  if (s && s->magic == ns::kDevMagic && s->w) {
+    ns_hip_weight_free(s->w);
+    s->w = nullptr;
+    s->magic = 0;
+  }
+}
+
+/* ---- kernels behind the tensor-level functions of glue/ne_bestla_hip_device.c ---- */
+int ns_hip_binary_nd_f32(int is_mul, const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4],
+                         const long long ne1[4], const long long nb1[4], const long long nbd[4], void* stream) {
+  if (!dA || !dB || !dDst) {
+    ns::set_error("binary_nd: null argument");
+    return -1;
+  }
+  ns::NdArgs g;
+  long long total = 1;
+  for (int i = 0; i < 4; i++) {
+    g.ne0[i] = ne0[i], g.nb0[i] = nb0[i], g.ne1[i] = ne1[i] > 0 ? ne1[i] : 1, g.nb1[i] = nb1[i], g.nbd[i] = nbd[i];
+    total *= ne0[i];
+  }
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(ns::nd_binary_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const char*>(dA), reinterpret_cast<const char*>(dB), reinterpret_cast<char*>(dDst), g, total,
+                     is_mul ? 1 : 0);
+  if (hipGetLastError() != hipSuccess) {
+    ns::set_error("binary_nd: launch failed");
+    return -1;
+  }
+  return 0;
+}
+
+int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* dV, float* dO, int batch, int seq, int seq_all, int heads,
+                                 int heads_kv, int head_size, int n_ctx, float scale, int masked, void* stream) {
+  if (!dQ || !dK || !dV || !dO || batch < 1 || seq < 1 || seq_all < seq || heads < 1 || heads_kv < 1 || heads % heads_kv || head_size < 1 ||
+      n_ctx < seq_all) {
+    ns::set_error("mha_f32: invalid argument");
+    return -1;
+  }
+  const size_t lds = (size_t((seq_all + 3) & ~3) + 256) * sizeof(float);
+  if (lds > 160 * 1024) {
+    ns::set_error("mha_f32: context too long for the device-layout attention kernel");
+    return -1;
+  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ns::mha_f32_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess && lds > 64 * 1024) {
+    ns::set_error("mha_f32: cannot raise the LDS limit");
+    return -1;
+  }
+  hipLaunchKernelGGL(ns::mha_f32_kernel, dim3(heads, seq, batch), dim3(256), lds, static_cast<hipStream_t>(stream), dQ, dK, dV, dO, seq,
+                     seq_all, heads, heads_kv, head_size, n_ctx, scale, masked);
+  if (hipGetLastError() != hipSuccess) {
+    ns::set_error("mha_f32: launch failed");
+    return -1;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -108,6 +108,70 @@ int nellama_generate(const char* model_path, const int* prompt, int n_prompt, in
   return made;
 }
 
+#ifdef NS_SYCL
+/* The same loop with the model OFFLOADED: the reference's own device switch (-DNS_SYCL) — model_init_sycl ->
+ * bestla_create_device, every layer's tensors on the device (n_gpu_layers = all: Llama::load, llama_utils.cpp:95-200;
+ * BTLA weights through bestla_device_load_storage, model_files.h:1515-1527), the fp32 device kv cache
+ * (model_utils.cpp:140-160) and the device branch of the graph builder (llama.cpp:190-330: ne_device_sync, device RoPE,
+ * ne_cpy into the cache, ne_flash_attn -> bestla_device_mha_f32).  libns_hip.so + glue/ne_bestla_hip_device.c answer the
+ * bestla_device_* calls.  out_us_per_token: wall time of the single-token evals (may be NULL). */
+int nellama_generate_dev(const char* model_path, const int* prompt, int n_prompt, int n_new, int n_ctx, int n_gpu_layers,
+                         int* out_tokens, float* out_logits, double* out_us_per_token) {
+  model_init_backend();
+  ne_sycl_context* dev = model_init_sycl(false);
+  if (!dev) return -3;
+  model_context_params p = model_context_default_params();
+  p.arch = NS_FAMILY_ARCH;
+  p.n_ctx = n_ctx;
+  p.seed = 1;
+  p.kv_type = KV_MEM_TYPE_F32; /* model_init_from_gpt_params does the same with a device context (model_utils.cpp:1420-1422) */
+  p.use_mmap = false;
+  p.batch_size = 1;
+  p.max_request_num = 1;
+  p.beam_size = 1;
+  p.beam_search = false;
+  p.cont_batching = false;
+  p.scratch_size_ratio = 0.125f;
+  p.n_gpu_layers = n_gpu_layers; /* = the model's layer count: every layer (the loader sizes the device pool by it) */
+  p.dev_ctx = dev;
+  model_context* ctx = model_init_from_file(model_path, p);
+  if (!ctx) return -1;
+  const int n_vocab = model_n_vocab(ctx);
+  int n_past = 0, made = 0;
+  std::vector<model_token> cur(prompt, prompt + n_prompt);
+  double us = 0;
+  int timed = 0;
+  for (int step = 0; step < n_new; step++) {
+    model_input in;
+    in.tokens = cur.data();
+    in.n_tokens = static_cast<uint32_t>(cur.size());
+    in.n_prompt_tokens = static_cast<uint32_t>(n_prompt);
+    in.n_past = static_cast<uint32_t>(n_past);
+    in.n_total = static_cast<uint32_t>(n_past);
+    in.request_idx = 0;
+    in.beam_idx = 0;
+    const int64_t t0 = ne_time_us();
+    if (model_eval(ctx, &in, 1, 1) != 0) {
+      model_free(ctx);
+      return -2;
+    }
+    if (cur.size() == 1 && step > 1) us += double(ne_time_us() - t0), timed++;
+    n_past += static_cast<int>(cur.size());
+    const float* logits = model_get_logits(ctx);
+    int best = 0;
+    for (int i = 1; i < n_vocab; i++)
+      if (logits[i] > logits[best]) best = i;
+    if (out_logits) memcpy(out_logits + static_cast<size_t>(step) * n_vocab, logits, sizeof(float) * n_vocab);
+    out_tokens[made++] = best;
+    cur.assign(1, best);
+  }
+  if (out_us_per_token) *out_us_per_token = timed ? us / timed : 0.0;
+  model_free(ctx);
+  model_release_sycl(dev);
+  return made;
+}
+#endif
+
 /* Continuous batching the way the reference's serving loop evaluates it (models/llama/llama.cpp:66-70, :330-350, :496-571:
  * batch_size == n_input requests concatenated into ONE graph without padding, per-request RoPE offsets, kv-cache blocks per
  * request, attention per group of requests that share (n_tokens, n_past)): two requests, greedy, every eval carries both —

@@ -55,3 +55,17 @@ def test_reference_mixture_of_experts_llama_on_the_hip_library(tmp_path, nso):
     o = np.load(tmp_path / "oracle_f16_4_moe8.npz")
     assert list(p["tokens"]) == list(o["tokens"])
     assert nso.rel_l2(p["logits"], o["logits"]) < 5e-3
+
+
+def test_reference_llama_runs_device_resident_through_its_own_device_switch(tmp_path, nso):
+    """The reference built with -DNS_SYCL (its device hooks: ne_layers.c:4252, :4568, :5633, :6405, :6592, :7292-7315, :9247,
+    :9912; loader model_files.h:1515-1527; graph builder llama.cpp:190-330) on libns_hip.so's bestla_device_* set
+    (ne_bestla.h:85-112): weights, activations and the kv cache stay in HBM, token ids go in and logits come out.  Same
+    tokens as the fp64 model and as the host-pointer route on the same file."""
+    run_worker("product", tmp_path, "auto", 4)
+    out = run_worker("device", tmp_path, "f32", 4, given=tmp_path / "llama_q_product_4.bin")
+    assert "device-resident graph" in out and "LLAMA_MODEL_DEVICE_OK" in out
+    p = np.load(tmp_path / "product_auto_4.npz")
+    d = np.load(tmp_path / "device_f32_4.npz")
+    assert list(p["tokens"]) == list(d["tokens"])
+    assert nso.rel_l2(d["logits"], p["logits"]) < 5e-3

@@ -9,7 +9,11 @@ see oracle/llama_ref_harness.cpp).
       libns_hip.so answers them (GPU): an fp32 NE file goes through the reference's quantizer driver
       (model_quantize -> bestla_quantize -> BTLAGemmQuantPackB -> glue/bestla_gemm_hip.cpp -> ns_BTLAGemmQuantPackB), the
       resulting file's blobs must equal the oracle's byte for byte, then the reference's loader + llama graph generate
-Both: greedy generation, token ids and logits compared with an independent fp64 model of the network built from the
+  llama_model_worker.py device  <workdir> f32 <heads_kv> <quantized file>
+      libns_hip.so again, but the reference built with ITS device switch (-DNS_SYCL -> oracle/_ref/libne_llama_dev_ref.so):
+      every layer offloaded, BTLA weights through bestla_device_load_storage, fp32 device kv cache, the device branch of
+      the graph builder — the unchanged graph runs device-resident (glue/ne_bestla_hip_device.c, csrc/ns_device.hip)
+All: greedy generation, token ids and logits compared with an independent fp64 model of the network built from the
 dequantized weights; results saved to <workdir>/<mode>_<kv>_<heads_kv>.npz for the cross-provider comparison."""
 import ctypes as C
 import os
@@ -254,6 +258,9 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     qt = quantize_tensors(tensors)
     tag = ("%d%s" % (heads_kv, "_moe%d" % n_experts if n_experts else "")) if family == "llama" else family
     qpath = given or os.path.join(workdir, "%s_q_%s_%s.bin" % (family, mode, tag))
+    device = mode == "device"
+    if device:
+        assert given and kv == "f32" and family == "llama" and not n_experts, "device mode: an existing quantized file, the fp32 cache"
     if mode == "oracle":
         so = os.path.join(tempfile.mkdtemp(), "liboracle_bestla.so")
         nso.build()
@@ -264,9 +271,9 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
         import torch  # noqa: F401  (torch's HIP runtime first, as neural_speed_amd.lib() does)
         provider = os.path.join(ROOT, "neural-speed_amd", "libns_hip.so")
     C.CDLL(provider, mode=C.RTLD_GLOBAL)
-    lib_path = os.path.join(ROOT, "oracle", "_ref", "libne_%s_ref.so" % family)
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libne_llama_dev_ref.so" if device else "libne_%s_ref.so" % family)
     if not os.path.exists(lib_path):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "nellama"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "nellamadev" if device else "nellama"], stdout=subprocess.DEVNULL)
     ref = C.CDLL(lib_path)
     use_gguf = os.environ.get("NS_WORKER_GGUF") == "1"
     if use_gguf and not given:
@@ -288,6 +295,8 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     elif mode == "oracle":
         if not given:
             ne_file.write(qpath, dict(hp, ftype=ne_file.NE_FTYPE_MOSTLY_Q_BTLA), qt)
+    elif device:
+        pass   # the file the product run wrote
     else:
         # the reference's quantizer driver on the product's quantizer
         fpath = os.path.join(workdir, "%s_f32_%s.bin" % (family, tag))
@@ -315,7 +324,13 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     prompt = (C.c_int * len(PROMPT))(*PROMPT)
     ref.nellama_generate.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     sys.stdout.flush()
-    n = ref.nellama_generate(qpath.encode(), prompt, len(PROMPT), N_NEW, N_CTX, KV[kv], toks, logits.ctypes.data)
+    if device:
+        us = C.c_double(0)
+        ref.nellama_generate_dev.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = ref.nellama_generate_dev(qpath.encode(), prompt, len(PROMPT), N_NEW, N_CTX, LAYERS, toks, logits.ctypes.data, C.byref(us))
+        print("device-resident graph: %.1f us per single-token eval (%d layers, d %d)" % (us.value, LAYERS, D))
+    else:
+        n = ref.nellama_generate(qpath.encode(), prompt, len(PROMPT), N_NEW, N_CTX, KV[kv], toks, logits.ctypes.data)
     assert n == N_NEW, n
     toks = list(toks)
     deq = weights_from_file(qpath)
@@ -335,7 +350,7 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
           (", %d experts (2 used), smallest router gap %.3f" % (n_experts, min(gaps)) if gaps else ""))
     assert max(errs) < 1e-2, errs
     np.savez(os.path.join(workdir, "%s_%s_%s.npz" % (mode, kv, tag)), tokens=np.array(toks), logits=logits)
-    if family == "llama" and not n_experts and os.environ.get("NS_WORKER_CONT_BATCH", "1") != "0":
+    if family == "llama" and not n_experts and not device and os.environ.get("NS_WORKER_CONT_BATCH", "1") != "0":
         # continuous batching: two requests per eval (concatenated, no padding; llama.cpp:66-70, :330-350, :496-571) must
         # reproduce what each request generates alone — prompts of different lengths (two attention groups of one request)
         # and of equal length (one group of two: the kv update / attention entries see batch 2)

@@ -32,7 +32,10 @@ def write(path, hparams, tensors, vocab_ids=(1, 2, 0, 0)):
             f.write(struct.pack("<I", len(word)) + word + struct.pack("<f", 0.0))
         for name, t in tensors:
             nb = name.encode()
-            if isinstance(t, tuple):
+            if isinstance(t, tuple) and isinstance(t[0], str) and t[0] == "q4_0":   # ("q4_0", fp32 [N][K] array): ggml Q4_0 blocks
+                a = np.ascontiguousarray(t[1], np.float32)
+                dims, typ, data = tuple(reversed(a.shape)), NE_TYPE_Q4_0, quant_q4_0(a)
+            elif isinstance(t, tuple):
                 blob, n, k = t
                 dims, typ, data = (k, n), NE_TYPE_BTLA, bytes(memoryview(np.ascontiguousarray(blob)))
             else:
@@ -79,6 +82,22 @@ def read(path):
         tensors[name] = (typ, ne, buf[off:off + size])
         off += size
     return hp, tensors
+
+
+def quant_q4_0(a):
+    """ggml's Q4_0 (the reference's own ne_quantize_q4_0, what its converter / quantizer makes of the token embedding):
+    blocks of 32 along a row: fp16 d = (value of largest magnitude) / -8, codes clamp(round(x / d) + 8, 0, 15), element j and
+    j + 16 share byte j"""
+    x = a.reshape(-1, 32)
+    idx = np.abs(x).argmax(1)
+    mx = x[np.arange(x.shape[0]), idx]
+    d = (mx / -8.0).astype(np.float32)
+    inv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1), 0).astype(np.float32)
+    q = np.clip(np.floor(x * inv[:, None] + 8.5), 0, 15).astype(np.uint8)
+    out = np.zeros((x.shape[0], 18), np.uint8)
+    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:] = q[:, :16] | (q[:, 16:] << 4)
+    return out.tobytes()
 
 
 def dequant_q4_0(data, ne):
