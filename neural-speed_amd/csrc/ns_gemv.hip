@@ -147,8 +147,14 @@ enum GemvMode { GV_PLAIN = 0, GV_DUAL = 1, GV_MSEG = 2 };
 // EXT: the launch carries an RMS norm (ns_norm_link) and / or the RoPE + kv-append epilogue (ns_qkv_rope).  A separate
 // instantiation, because even untaken these paths cost every launch 0.1-0.3 us (later argument fetch, longer cold
 // epilogue code: 1057 vs 1036 us on the 7B chain, profiles/r02o_ext_ab.txt).
-template <int KIND, int SPS, int SK, bool ASYM, int MODE, bool EXT>
+// XV: 0 plain; 1 = EXT; 2 = A32: the activations arrive as fp32 only (a caller without a producer shadow: the reference's
+// device graph hands bestla_device_f32f32_forward fp32 tensors).  The wave's share of A is loaded into registers in
+// front of the ring requests, converted (round to nearest even, as the shadow's producers do) and written to LDS once
+// only ring requests are left in flight — the weights are requested exactly as early as with a shadow.
+constexpr int kGvA32Regs = 8;  // 16-byte loads of fp32 activations a wave holds in registers
+template <int KIND, int SPS, int SK, bool ASYM, int MODE, int XV>
 __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
+  constexpr bool EXT = XV == 1, A32 = XV == 2;
   constexpr bool DUAL = MODE == GV_DUAL, MSEG = MODE == GV_MSEG;
   constexpr int NJ = kind_is_8bit(KIND) ? 2 : 4;
   constexpr int KSTEP = NJ * 32;
@@ -263,7 +269,36 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   //      HBM/L2 -> LDS directly in 1 KiB pieces, piece c of row r by wave (r * pieces + c) % NW; LDS row r holds
   //      ks * KSTEP halves (columns >= K read as zero through the descriptor: k-step padding) ----
   const int rows = min(p.m, kGvMaxRows);
-  {
+  floatx4 areg[A32 ? kGvA32Regs : 1];
+  if constexpr (A32) {
+    // fp32 rows: 1 KiB pieces (256 columns) by wave (r * pieces + c) % NW again, at most kGvA32Regs per wave (host)
+    // the descriptor make_rsrc() builds, as four words for the asm operand: base, stride 0, bytes, flags
+    const uint64_t abase = reinterpret_cast<uint64_t>(p.a);
+    const uint4v ra_words = {uint32_t(abase), uint32_t(abase >> 32) & 0xffffu,
+                             uint32_t(rows - 1) * uint32_t(p.lda) * 4u + uint32_t(p.k) * 4u, 0x00020000u};
+    const uint32_t row_bytes = ks * uint32_t(KSTEP) * 4u;
+    const uint32_t pieces = (row_bytes + 1023u) >> 10;
+    const uint32_t total = uint32_t(rows) * pieces;
+    uint32_t r = 0, c = w;  // piece u = w + i * NW is (row r, column piece c): stepped, not divided
+#pragma unroll
+    for (int i = 0; i < kGvA32Regs; i++) {
+      const uint32_t u = w + (uint32_t(i) << p.nw_log2);
+      areg[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (u < total) {
+        while (c >= pieces) c -= pieces, r++;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // columns >= K of the last k-step come back as zero through the descriptor
+        // by hand: hipcc does not count LDS-DMA requests, so for a load it knows of it waits for everything in flight
+        // (vmcnt(0): the whole ring) before the first use; wait_records() below is this load's wait
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"
+                     : "=v"(areg[i])
+                     : "v"(voff_q), "s"(ra_words), "s"(r * uint32_t(p.lda) * 4u + (c << 10))
+                     : "memory");
+#endif
+        c += NW;
+      }
+    }
+  } else {
     const Rsrc ra = make_rsrc(p.a, uint32_t(rows - 1) * uint32_t(p.lda) * 2u + uint32_t(p.k) * 2u);
     const uint32_t row_bytes = ks * uint32_t(KSTEP) * 2u;
     const uint32_t pieces = (row_bytes + 1023u) >> 10;
@@ -325,6 +360,29 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   // ---- 3. this wave's activation pieces (the oldest requests in its queue) have landed once only its ring
   //      requests are left in flight ----
   wait_records(min(nst * uint32_t(NQ), uint32_t(PF)));
+  if constexpr (A32) {
+#pragma unroll
+    for (int i = 0; i < kGvA32Regs; i++) asm volatile("" : "+v"(areg[i]));  // not to be read above the wait
+    const uint32_t row_bytes = ks * uint32_t(KSTEP) * 4u;
+    const uint32_t pieces = (row_bytes + 1023u) >> 10;
+    const uint32_t total = uint32_t(rows) * pieces;
+    uint32_t r = 0, c = w;
+#pragma unroll
+    for (int i = 0; i < kGvA32Regs; i++) {
+      const uint32_t u = w + (uint32_t(i) << p.nw_log2);
+      if (u < total) {
+        while (c >= pieces) c -= pieces, r++;
+        const half2_t lo = half2_t{(_Float16)areg[i][0], (_Float16)areg[i][1]};
+        const half2_t hi = half2_t{(_Float16)areg[i][2], (_Float16)areg[i][3]};
+        const uint32_t dst = uint32_t(reinterpret_cast<uintptr_t>((LdsPtr)(smem))) + r * p.row_stride * 2u + (c << 9) + uint32_t(l) * 8u;
+        // by hand: for a visible LDS store hipcc would first wait for every LDS-DMA request in flight (the whole ring)
+        if ((c << 10) + uint32_t(l) * 16u < row_bytes)
+          asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"((uint64_t(as_u32(hi)) << 32) | as_u32(lo)) : "memory");
+        c += NW;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   // workgroup barrier over the staged activations, written by hand: for __syncthreads() hipcc first waits for every
   // LDS-DMA request in flight (it cannot know that the rings are wave-private), i.e. for the whole ring to land
   asm volatile("s_barrier" ::: "memory");
@@ -562,13 +620,16 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 // ============================================================================================================
 // host side
 // ============================================================================================================
+constexpr int kGvModeA32 = 0x100;  // or-ed into the launch mode: fp32 activations (XV = 2)
 template <int KIND, int SPS, int SK, bool ASYM>
 static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw, size_t lds, hipStream_t st) {
   const dim3 g(grid), b(nw * 64);
   const bool ext = p.in_ssq || p.out_gamma || p.out_ssq || p.rope.on;
+  const bool a32 = (mode & kGvModeA32) != 0;  // never together with ext (launch_gemv)
+  mode &= ~kGvModeA32;
 #define NS_GV_LAUNCH(MODEV)                                                                                     \
   {                                                                                                             \
-    if (ext) NS_GV_LAUNCH_E(MODEV, true) else NS_GV_LAUNCH_E(MODEV, false)                                      \
+    if (ext) NS_GV_LAUNCH_E(MODEV, 1) else if (a32) NS_GV_LAUNCH_E(MODEV, 2) else NS_GV_LAUNCH_E(MODEV, 0)      \
   }
 #define NS_GV_LAUNCH_E(MODEV, EXTV)                                                                             \
   {                                                                                                             \
@@ -686,8 +747,12 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   // fp16 activations with 16-byte aligned rows; several rows need K to fill whole k-steps (a row's padding columns
   // would otherwise read the next row through the descriptor)
   const bool a16 = a.a16 != nullptr && (a.lda & 7) == 0 && (w0->k & 7) == 0 && (reinterpret_cast<uintptr_t>(a.a16) & 15) == 0;
-  if (!a16 || (rows > 1 && w0->k % kstep != 0)) return hipErrorNotSupported;
-  p.a = a.a16;
+  // fp32-only callers: converted while staging (XV = 2); not together with a carried norm / fused RoPE, whose producers
+  // always leave a shadow
+  const bool a32 = !a16 && a.a != nullptr && !a.link && !a.rope && (a.lda & 3) == 0 && (w0->k & 3) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.a) & 15) == 0;
+  if ((!a16 && !a32) || (rows > 1 && w0->k % kstep != 0)) return hipErrorNotSupported;
+  p.a = a16 ? a.a16 : static_cast<const void*>(a.a);
   // carried RMS norm (ns_norm_link): consumer side stages in_parts floats per row behind A
   size_t ssq_bytes = 0;
   if (a.link) {
@@ -738,6 +803,8 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   }
   uint32_t nw_log2 = 0;
   while ((1 << nw_log2) < nw) nw_log2++;
+  if (a32 && uint64_t(rows) * ((uint64_t(ks) * uint32_t(kstep) * 4u + 1023u) >> 10) > uint64_t(nw) * kGvA32Regs)
+    return hipErrorNotSupported;  // more fp32 pieces than the waves hold in registers: smallm_kernel stages those
 
   p.ks = ks;
   p.qstride = w0->qstride;
@@ -769,21 +836,22 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   p.ring_stride = uint32_t(ring_bytes(nw));
   const size_t lds = size_t(p.ring_off) + size_t(nw) * p.ring_stride;
   if (lds > kGvMaxLds) return hipErrorNotSupported;
+  const int mode_x = mode | (a32 ? kGvModeA32 : 0);
 
 #define NS_DISPATCH(KIND)                                                                       \
   switch (w0->sps) {                                                                            \
-    case 4: return launch_gemv_s<KIND, 4>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st);  \
-    case 2: return launch_gemv_s<KIND, 2>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st);  \
-    default: return launch_gemv_s<KIND, 1>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st); \
+    case 4: return launch_gemv_s<KIND, 4>(p, w0->scale_dt, w0->asym, mode_x, grid, nw, lds, st);  \
+    case 2: return launch_gemv_s<KIND, 2>(p, w0->scale_dt, w0->asym, mode_x, grid, nw, lds, st);  \
+    default: return launch_gemv_s<KIND, 1>(p, w0->scale_dt, w0->asym, mode_x, grid, nw, lds, st); \
   }
   if (w0->kind == WK_INT4) {
     NS_DISPATCH(WK_INT4)
   } else if (w0->kind == WK_INT8) {
-    if (w0->sps == 2) return launch_gemv_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st);
-    return launch_gemv_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, mode, grid, nw, lds, st);
+    if (w0->sps == 2) return launch_gemv_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, mode_x, grid, nw, lds, st);
+    return launch_gemv_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, mode_x, grid, nw, lds, st);
   } else if (w0->kind == WK_F8) {  // device scales are always fp32 (E8M0 shared exponents are expanded at load)
-    if (w0->sps == 2) return launch_gemv_a<WK_F8, 2, SK_F32>(p, false, mode, grid, nw, lds, st);
-    return launch_gemv_a<WK_F8, 1, SK_F32>(p, false, mode, grid, nw, lds, st);
+    if (w0->sps == 2) return launch_gemv_a<WK_F8, 2, SK_F32>(p, false, mode_x, grid, nw, lds, st);
+    return launch_gemv_a<WK_F8, 1, SK_F32>(p, false, mode_x, grid, nw, lds, st);
   } else {
     NS_DISPATCH(WK_F4)
   }

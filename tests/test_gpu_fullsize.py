@@ -170,3 +170,32 @@ def test_config4_mistral7b_nf4_g128_batch8_full_width(L, pkg, nso, n, k):
     assert nso.rel_l2(out2, ref) < TOL
     L.ns_hip_cache_clear()
     wt.free()
+
+
+A32_CASES = [(n, k, GEMV_FORMATS[0], m) for (n, k) in GEMV_SHAPES[:4] for m in (1, 2, 4)] + \
+            [(n, k, f, 1) for f in GEMV_FORMATS[1:] for (n, k) in GEMV_SHAPES[:3]] + \
+            [(4096, 4096 + 96, GEMV_FORMATS[0], 1), (1008, 4096, GEMV_FORMATS[0], 3)]  # ragged last k-step / last tile
+
+
+@pytest.mark.parametrize("n,k,fmt,m", A32_CASES, ids=["%s-%dx%d-m%d" % (c[2][0], c[0], c[1], c[3]) for c in A32_CASES])
+def test_gemv_kernel_fp32_activations_only_equals_the_shadow_path(L, pkg, nso, n, k, fmt, m):
+    """A caller without an fp16 shadow (the reference's device graph: bestla_device_f32f32_forward, ne_bestla.h:110-112)
+    is served by the same streaming kernel, converting its share of A on the way to LDS: BIT FOR BIT what the caller with
+    the round-to-nearest shadow gets, and the oracle's fp64 GEMM within the usual tolerance."""
+    import torch
+    name, qt, st_dt, bs, comp, asym = fmt
+    if not hasattr(pkg, qt):
+        pytest.skip("format constant %s not exported by the package" % qt)
+    blob, wt = _device_blob(L, pkg, nso, n, k, getattr(pkg, qt), getattr(pkg, st_dt), bs, getattr(pkg, comp), asym,
+                            seed=n * 5 + k + bs + m)
+    g = torch.Generator(device="cuda").manual_seed(m * 10 + 3)
+    dA = torch.randn((m, k), generator=g, device="cuda")
+    with_shadow = _forward_h(L, pkg, wt, dA, m, k, n, shadow=True)
+    fp32_only = _forward_h(L, pkg, wt, dA, m, k, n, shadow=False)
+    assert np.isfinite(fp32_only).all()
+    assert np.array_equal(with_shadow.view(np.int32), fp32_only.view(np.int32)), \
+        (name, n, k, m, float(np.max(np.abs(with_shadow - fp32_only))))
+    ref, ref16 = nso.gemm_f64_pair(dA.cpu().numpy(), blob)
+    assert nso.rel_l2(fp32_only, ref) < TOL, (name, n, k, m)
+    assert nso.rel_l2(fp32_only, ref16) < (6e-4 if qt.startswith("F4") else 3e-5), (name, n, k, m)
+    wt.free()
