@@ -356,7 +356,10 @@ def main():
     # the collectives themselves go through the library's native layer (ns_tp_*: RCCL / the peer-memory kernel behind a
     # C ABI); torch.distributed only bootstraps it (128-byte unique id) and carries the failure flags.  NS_TP_NATIVE=0
     # keeps torch's ProcessGroup all-reduce instead.
-    use_native = world > 1 and os.environ.get("NS_TP_NATIVE", "1") != "0" and backend == "nccl" and pctx.enable_native()
+    # (NS_TP_RCCL_LIB: a named collective library — with a non-RCCL process group that is the tests' shared-memory stand-in,
+    # which lets two ranks share one GPU; such a line is marked INVALID below)
+    use_native = (world > 1 and os.environ.get("NS_TP_NATIVE", "1") != "0" and
+                  (backend == "nccl" or bool(os.environ.get("NS_TP_RCCL_LIB"))) and pctx.enable_native())
     chain = Chain(pkg, args.layers, rank, world, keep_host_layer=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     # the chain object itself carries the captured stream handle; under graph capture torch switches the current
     # stream, so the stream pointer handed to the C ABI must be re-read inside the capture.
@@ -456,7 +459,9 @@ def main():
                 "all_reduce": (None if world == 1 else
                                ("ns_tp_reduce_add (native C ABI): " if pctx.native_enabled() else "") +
                                ("one-shot kernel over peer-mapped HBM (HIP IPC, xGMI)" if pctx.p2p_enabled() else
-                                "RCCL all-reduce" if pctx.native_enabled() else "torch.distributed all_reduce (%s)" % backend)),
+                                ("RCCL all-reduce" if not os.environ.get("NS_TP_RCCL_LIB") else
+                                 "collective library %s" % os.path.basename(os.environ["NS_TP_RCCL_LIB"]))
+                                if pctx.native_enabled() else "torch.distributed all_reduce (%s)" % backend)),
                 "event_ms_per_step": round(ev_ms / args.steps, 5),
             },
         }

@@ -62,8 +62,16 @@ bool load_rccl() {
   if (g_rccl.so) return true;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* so = nullptr;
-  for (const char* n : names)
-    if ((so = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+  // NS_TP_RCCL_LIB: the collective library to bind instead (a differently named RCCL build; the shared-memory stand-in
+  // of tests/tools/stub_rccl.cpp that lets several ranks share one GPU).  Bound privately: a process that already
+  // holds the real RCCL (torch) keeps using it for everything else.
+  const char* forced = getenv("NS_TP_RCCL_LIB");
+  if (forced && *forced) {
+    so = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+  } else {
+    for (const char* n : names)
+      if ((so = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+  }
   if (!so) {
     ns::set_error(std::string("ns_tp: cannot load RCCL: ") + (dlerror() ? dlerror() : "not found"));
     return false;

@@ -135,7 +135,10 @@ class ParallelContext:
         ok, raw = box[0]
         tp = None
         if ok:
-            tp = L.ns_tp_init(self.rank, self.world, raw, self.local_rank)
+            # the device this process already computes on (the launcher's LOCAL_RANK unless the caller chose another: several
+            # ranks of a test may share one GPU)
+            dev = torch.cuda.current_device() if torch.cuda.is_available() else self.local_rank
+            tp = L.ns_tp_init(self.rank, self.world, raw, dev)
         oks = [None] * self.world
         dist.all_gather_object(oks, bool(tp))
         if not all(oks):
