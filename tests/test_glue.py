@@ -87,3 +87,34 @@ def test_reference_tp_build_is_what_the_glue_replaces():
     src = os.path.join(REF, "neural_speed", "core", "ne_layers.c")
     r = subprocess.run(["gcc", "-fsyntax-only", "-w", "-DNS_TP_MODEL", *INC, src], capture_output=True, text=True)
     assert r.returncode != 0 and "too few arguments to function" in r.stderr
+
+
+def test_device_backend_glue_compiles_against_the_reference_headers_with_its_device_switch(tmp_path):
+    """glue/ne_bestla_hip_device.c defines the ne_tensor-level half of the reference's device backend (ne_bestla.h:98-109,
+    visible under -DNS_SYCL only) and leaves exactly the library's pointer-level functions undefined; the graph-struct glue
+    compiles with the switch too (its bestla_backend_support then carries the reference's placement table)."""
+    dev = str(tmp_path / "ne_bestla_hip_device.o")
+    subprocess.run(["gcc", "-std=c11", "-fPIC", "-Wall", "-Werror", "-Wno-unused-variable", "-Wno-unused-function", "-DNS_SYCL", "-c", *INC,
+                    os.path.join(ROOT, "glue", "ne_bestla_hip_device.c"), "-o", dev], check=True)
+    sym = _symbols(dev)
+    for name in ("bestla_device_mul_f32", "bestla_device_add_f32", "bestla_device_elewise_f32", "bestla_device_rms_norm_f32",
+                 "bestla_device_rope_f32", "bestla_device_dup_f32", "bestla_device_mha_f32"):
+        assert name in sym, name
+    und = subprocess.run(["nm", "--undefined-only", dev], capture_output=True, text=True, check=True).stdout
+    undefined = {ln.split()[-1] for ln in und.splitlines() if ln.strip()}
+    ours = {u for u in undefined if u.startswith("ns_hip_")}
+    assert ours, undefined
+    import ctypes as C2
+    import __graft_entry__ as ge
+    L = C2.CDLL(ge.load_package().LIB_PATH)
+    for u in ours:  # every ns_hip_* the glue calls is exported by the library
+        assert hasattr(L, u), u
+    glue = str(tmp_path / "ne_bestla_hip_glue_dev.o")
+    subprocess.run(["gcc", "-std=c11", "-fPIC", "-Wall", "-Werror", "-Wno-unused-variable", "-Wno-unused-function", "-DNS_SYCL", "-c", *INC,
+                    os.path.join(ROOT, "glue", "ne_bestla_hip_glue.c"), "-o", glue], check=True)
+    assert "bestla_backend_support" in _symbols(glue)
+    # the pointer-level half, by the reference's names, comes from the library itself
+    for name in ("bestla_create_device", "bestla_get_device_queue", "bestla_release_device", "bestla_device_gmem_size",
+                 "bestla_device_malloc", "bestla_device_free", "bestla_device_memcpy", "bestla_device_memcpy_sync", "bestla_device_sync",
+                 "bestla_device_storage_size", "bestla_device_load_storage", "bestla_device_f32f32_forward"):
+        assert hasattr(L, name), name
