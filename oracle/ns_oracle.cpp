@@ -1242,7 +1242,19 @@ int nso_rope_f32_glm(const float* src, float* dst, int batch, int seq, int heads
 
 // bestla_fusion_attn_forward_ref — mha_dense_wrapper.h:1371-1517 (PLAIN layouts; fp32 accumulation in the loop order
 // of the reference: scores j ascending / k ascending, then exp, then P.V k ascending)
-int nso_attn_ref(const nso_attn_args* a, int bf16_gemm) {
+/* mha_exp_ref with MHA_2ND_EXP = 1 (mha_dense_wrapper.h:41, :79-85) = kernel::ref::exp_ps_0_1 (kernel_ref.h:2253-2262): 2^z times a
+ * second-order polynomial in the fraction — the exp the reference's attention reference (and its kernels) use */
+static float nso_exp_ps_0_1(float x) {
+  static const float log2e = std::log2(std::exp(1.f));
+  const float x1 = x * log2e + .5f;
+  const float z = std::floor(x1);
+  const float f = x1 - z;
+  return ldexpf(0.240226507f * f * f + 0.452920674f * f + 0.713483036f, static_cast<int>(z));
+}
+
+int nso_attn_ref(const nso_attn_args* a, int mode) {
+  const int bf16_gemm = mode & 1;
+  const bool exp2nd = (mode & 2) != 0;
   const bool is_causal = (a->flags & 1u) != 0, is_alibi = (a->flags & 2u) != 0;
   if (is_causal && a->sl_q > a->sl_kv) return -1;
   if (a->heads_kv <= 0 || a->head_num % a->heads_kv) return -1;
@@ -1250,6 +1262,17 @@ int nso_attn_ref(const nso_attn_args* a, int bf16_gemm) {
   const int lf = 1 << int(floor(log2(double(a->head_num))));  // :1424-1426
   const float m0 = powf(2.0f, -(8.f) / lf), m1 = powf(2.0f, -(8.f / 2.0f) / lf);
   auto bf = [&](float x) { return bf16_gemm ? nso_bf16_to_f32(nso_f32_to_bf16(x)) : x; };
+  // K and V are fp16: static_cast<bf16>(fp16) is fp16::operator bf16() (bestla_utils.h:208-229) — the mantissa is TRUNCATED to
+  // seven bits, fp16 subnormals become zero, exponent 31 becomes sign | 0x7fff
+  auto bfh = [&](uint16_t h) -> float {
+    if (!bf16_gemm) return nso_f16_to_f32(h);
+    const int e = (h >> 10) & 0x1f, m = h & 0x3ff;
+    uint16_t b;
+    if (e == 0) b = 0;
+    else if (e == 31) b = uint16_t(h | 0x7fff);
+    else b = uint16_t((h & 0x8000) | ((e + 128 - 16) << 7) | (m >> 3));
+    return nso_bf16_to_f32(b);
+  };
   std::vector<float> row(size_t(a->sl_kv));
   for (int ibs = 0; ibs < a->batch_size; ibs++)
     for (int ihn = 0; ihn < a->head_num; ihn++)
@@ -1265,20 +1288,20 @@ int nso_attn_ref(const nso_attn_args* a, int bf16_gemm) {
         for (int j = 0; j < unmasked; j++) {  // :1451-1474
           float s = 0.f;
           for (int k = 0; k < a->head_size; k++)
-            s += bf(q[k]) * bf(nso_f16_to_f32(kc[j * a->step_k_sl + k * a->step_k_head_size]));
+            s += bf(q[k]) * bfh(kc[j * a->step_k_sl + k * a->step_k_head_size]);
           s = s * a->qk_scale * a->q_sc * a->k_sc + j * slope;
           row[size_t(j)] = s;
           row_max = std::max(row_max, s);
         }
         float exp_sum = 0.f;
         for (int j = 0; j < unmasked; j++) {  // :1477-1481
-          row[size_t(j)] = expf(row[size_t(j)] - row_max);
+          row[size_t(j)] = exp2nd ? nso_exp_ps_0_1(row[size_t(j)] - row_max) : expf(row[size_t(j)] - row_max);
           exp_sum += row[size_t(j)];
         }
         for (int j = 0; j < unmasked; j++) row[size_t(j)] = bf(row[size_t(j)] / exp_sum);  // :1487-1490
         for (int j = 0; j < a->head_size; j++) {  // :1494-1512
           float acc = 0.f;
-          for (int k = 0; k < unmasked; k++) acc += row[size_t(k)] * bf(nso_f16_to_f32(vc[k * a->step_v_sl + j]));
+          for (int k = 0; k < unmasked; k++) acc += row[size_t(k)] * bfh(vc[k * a->step_v_sl + j]);
           dst[j] = acc * a->v_sc / a->dst_sc;
         }
       }

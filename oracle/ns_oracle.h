@@ -157,11 +157,14 @@ float nso_silu(float x);
 /* fused attention — bestla_fusion_attn_forward_ref, neural_speed/core/layers/mha_dense_wrapper.h:1371-1517, for
  * Q fp32 / K,V fp16 / dst fp32 in ATTN_FWD_LAYOUT_PLAIN with element strides.  `bf16_gemm` != 0 reproduces the
  * reference's default rounding of Q, K and P to bf16 (IS_BF16_GEMM, :1389-1394); 0 = its NE_ATTN_FLAG_PREFER_FP32
- * form.  flags: 1 causal, 2 alibi8 (TANH30 is not part of forward_ref).  PARITY: mha_dense_wrapper.h needs the xbyak-
- * dependent BesTLA headers and cannot be compiled here, so forward_ref itself is unpinned; this line-by-line
- * restatement is checked against an independent fp64 softmax(QK^T)V and PINNED IN ITS SEMANTICS (mask placement, scale,
- * GQA mapping, normalisation) to the reference's own unfused attention graph executed by ne_layers.c
- * (oracle/_ref/libne_ref.so, tests/test_attention_oracle.py; tolerance = that graph's fp16-table soft_max). */
+ * form; `mode` bit 1 (value 2) uses the reference's own exp (MHA_2ND_EXP: exp_ps_0_1, a second-order polynomial, relative
+ * error up to 2e-3) instead of expf.  flags: 1 causal, 2 alibi8 (TANH30 is not part of forward_ref).  PARITY: PINNED
+ * to the function itself — bestla_fusion_attn_forward_ref<float, fp16, fp16, float> compiled from the reference file
+ * (oracle/Makefile attnref -> _ref/libattn_ref.so): with mode bit 1 set the restatement reproduces it to fp32 rounding on
+ * every case of mha_dense_tests.cpp:43-62, :92-112 (plain / transposed K, causal, alibi, GQA, PREFER_FP32 or the bf16
+ * default), tests/test_attention_oracle.py — and, in its semantics, to the reference's unfused attention graph executed
+ * by ne_layers.c (oracle/_ref/libne_ref.so; tolerance = that graph's fp16-table soft_max).  The PRODUCT evaluates the
+ * exact exp (mode bit 1 clear is its oracle); the distance between the two exps is measured in the same test. */
 typedef struct nso_attn_args {
   const float* q;
   const uint16_t* k;
@@ -175,7 +178,7 @@ typedef struct nso_attn_args {
   long long step_v_bs, step_v_head_num, step_v_sl;
   long long step_dst_bs, step_dst_head_num, step_dst_sl;
 } nso_attn_args;
-int nso_attn_ref(const nso_attn_args* a, int bf16_gemm);
+int nso_attn_ref(const nso_attn_args* a, int mode); /* mode: bit 0 bf16 GEMM rounding, bit 1 the reference's polynomial exp */
 
 /* RoPE — ne_compute_forward_rope_f32, neural_speed/core/ne_layers.c:9243-9428, for contiguous fp32 tensors
  * [batch][seq][heads][head_size], modes 0 (adjacent pairs over the whole row) and 2 (NeoX halves inside n_dims-wide

@@ -554,7 +554,59 @@ class AttnArgs(C.Structure):
                 ("step_dst_bs", C.c_longlong), ("step_dst_head_num", C.c_longlong), ("step_dst_sl", C.c_longlong)]
 
 
-def attn_ref(q, k, v, qk_scale, flags=0, k_trans=False, bf16_gemm=False, scales=(1.0, 1.0, 1.0, 1.0)):
+_attn = None
+
+
+def attnref():
+    """oracle/_ref/libattn_ref.so: the reference's OWN bestla_fusion_attn_forward_ref<float, fp16, fp16, float> (oracle/Makefile
+    attnref); None where it was never built"""
+    global _attn
+    if _attn is None:
+        so = os.path.join(HERE, "_ref", "libattn_ref.so")
+        if not os.path.exists(so) and os.path.isdir("/root/reference"):
+            subprocess.call(["make", "-C", HERE, "attnref"], stdout=subprocess.DEVNULL)
+        _attn = C.CDLL(so) if os.path.exists(so) else False
+        if _attn:
+            for f in ("attnref_flag_causal", "attnref_flag_alibi8", "attnref_flag_prefer_fp32"):
+                getattr(_attn, f).restype = C.c_uint
+    return _attn or None
+
+
+def _attn_args(q, k, v, dst, qk_scale, flags, k_trans, scales):
+    bs, sl_q, hn, hs = q.shape
+    sl_kv, hkv = v.shape[1], v.shape[2]
+    a = AttnArgs()
+    a.q, a.k, a.v, a.dst = q.ctypes.data, k.ctypes.data, v.ctypes.data, dst.ctypes.data
+    a.q_sc, a.k_sc, a.v_sc, a.dst_sc = scales
+    a.qk_scale, a.flags = qk_scale, flags
+    a.batch_size, a.head_num, a.heads_kv, a.head_size, a.sl_q, a.sl_kv = bs, hn, hkv, hs, sl_q, sl_kv
+    a.step_q_bs, a.step_q_head_num, a.step_q_sl = sl_q * hn * hs, hs, hn * hs
+    a.step_k_bs = sl_kv * hkv * hs
+    if k_trans:
+        a.step_k_head_num, a.step_k_sl, a.step_k_head_size = hs * sl_kv, 1, sl_kv
+    else:
+        a.step_k_head_num, a.step_k_sl, a.step_k_head_size = hs, hkv * hs, 1
+    a.step_v_bs, a.step_v_head_num, a.step_v_sl = sl_kv * hkv * hs, hs, hkv * hs
+    a.step_dst_bs, a.step_dst_head_num, a.step_dst_sl = sl_q * hn * hs, hs, hn * hs
+    return a
+
+
+def attn_reference(q, k, v, qk_scale, causal=False, alibi8=False, prefer_fp32=False, k_trans=False, scales=(1.0, 1.0, 1.0, 1.0)):
+    """The reference's own function (attnref()) on attn_ref's layouts.  Without prefer_fp32 it rounds Q, K, P and V to bf16
+    when K is not transposed (IS_BF16_GEMM, mha_dense_wrapper.h:1389-1394)."""
+    L = attnref()
+    q = np.ascontiguousarray(q, np.float32)
+    k = np.ascontiguousarray(k, np.float16)
+    v = np.ascontiguousarray(v, np.float16)
+    dst = np.zeros_like(q)
+    flags = (L.attnref_flag_causal() if causal else 0) | (L.attnref_flag_alibi8() if alibi8 else 0) | \
+            (L.attnref_flag_prefer_fp32() if prefer_fp32 else 0)
+    a = _attn_args(q, k, v, dst, qk_scale, flags, k_trans, scales)
+    assert L.attnref_forward_f32_f16_f16_f32(C.byref(a)) == 0
+    return dst
+
+
+def attn_ref(q, k, v, qk_scale, flags=0, k_trans=False, bf16_gemm=False, scales=(1.0, 1.0, 1.0, 1.0), ref_exp=False):
     """q fp32 [bs][sl_q][heads][hs]; k, v fp16 [bs][sl_kv][heads_kv][hs] (k_trans: k is [bs][heads_kv][hs][sl_kv]).
     Returns dst fp32 [bs][sl_q][heads][hs] — the tensor layouts of mha_dense_tests.cpp:232-262."""
     q = np.ascontiguousarray(q, np.float32)
@@ -576,7 +628,7 @@ def attn_ref(q, k, v, qk_scale, flags=0, k_trans=False, bf16_gemm=False, scales=
         a.step_k_head_num, a.step_k_sl, a.step_k_head_size = hs, hkv * hs, 1
     a.step_v_bs, a.step_v_head_num, a.step_v_sl = sl_kv * hkv * hs, hs, hkv * hs
     a.step_dst_bs, a.step_dst_head_num, a.step_dst_sl = sl_q * hn * hs, hs, hn * hs
-    assert lib().nso_attn_ref(C.byref(a), 1 if bf16_gemm else 0) == 0
+    assert lib().nso_attn_ref(C.byref(a), (1 if bf16_gemm else 0) | (2 if ref_exp else 0)) == 0
     return dst
 
 

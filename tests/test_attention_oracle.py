@@ -1,6 +1,9 @@
-"""CPU: the oracle's restatement of bestla_fusion_attn_forward_ref (mha_dense_wrapper.h:1371-1517) against an
-independent fp64 softmax(QK^T)V.  The reference itself cannot be compiled here (xbyak), so this is what pins the
-attention oracle — stated as "parity unpinned" in oracle/ns_oracle.h and DESIGN.md."""
+"""CPU: the oracle's restatement of bestla_fusion_attn_forward_ref (mha_dense_wrapper.h:1371-1517) against (1) an
+independent fp64 softmax(QK^T)V, (2) the reference's unfused attention graph run by its ne_layers.c, and (3) — round 3 —
+THE FUNCTION ITSELF: mha_dense_wrapper.h as a whole needs the JIT headers, the function does not, so oracle/Makefile
+attnref cuts it out of the reference file at build time and compiles it (oracle/_ref/libattn_ref.so).  With the
+reference's polynomial exp selected the restatement reproduces it BIT FOR BIT in every mode; golden rows minted from
+the function travel to the GPU box (tests/golden/attn_forward_ref.npz)."""
 import numpy as np
 import pytest
 
@@ -84,3 +87,52 @@ def test_attention_oracle_matches_reference_unfused_graph(nso, hn, hkv, hs, slq,
     if causal and slq > 1:
         wrong = nso.attn_ref(q, k, v, scale, 0)
         assert nso.rel_l2(wrong, ref) > 1e-2
+
+
+# ---- (3) the reference's own function ---------------------------------------------------------------------------------
+import importlib.util
+import os
+
+_spec = importlib.util.spec_from_file_location("make_attn_golden", os.path.join(os.path.dirname(__file__), "golden", "make_attn_golden.py"))
+_gold = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_gold)
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "attn_forward_ref.npz")
+
+
+@pytest.mark.parametrize("idx", range(len(_gold.CASES)))
+def test_restatement_equals_the_reference_function_bit_for_bit(nso, idx):
+    """every mode of bestla_fusion_attn_forward_ref<float, fp16, fp16, float>: PREFER_FP32 and the default (Q, P rounded to bf16
+    to nearest even; K, V through fp16::operator bf16 — truncation, subnormals flushed — when K is not transposed,
+    IS_BF16_GEMM :1389-1394), plain and transposed K, causal with sl_q < sl_kv, GQA, alibi"""
+    if nso.attnref() is None:
+        pytest.skip("oracle/_ref/libattn_ref.so absent (needs the reference tree)")
+    bs, hn, hkv, hs, slq, slkv, causal, alibi = _gold.CASES[idx]
+    q, k, v = _gold.case_inputs(idx)
+    sc = 1.0 / np.sqrt(hs)
+    flags = (1 if causal else 0) | (2 if alibi else 0)
+    for kt in (False, True):
+        kk = np.ascontiguousarray(k.transpose(0, 2, 3, 1)) if kt else k
+        for pf in (True, False):
+            ref = nso.attn_reference(q, kk, v, sc, causal=causal, alibi8=alibi, prefer_fp32=pf, k_trans=kt)
+            mine = nso.attn_ref(q, kk, v, sc, flags=flags, k_trans=kt, bf16_gemm=(not pf) and (not kt), ref_exp=True)
+            assert np.array_equal(ref.view(np.int32), mine.view(np.int32)), (idx, kt, pf, float(np.abs(ref - mine).max()))
+            # the exact exp (what the product evaluates and is checked against) stays within the polynomial's own error
+            exact = nso.attn_ref(q, kk, v, sc, flags=flags, k_trans=kt, bf16_gemm=(not pf) and (not kt), ref_exp=False)
+            assert nso.rel_l2(exact, ref) < 4e-3, (idx, kt, pf)
+
+
+@pytest.mark.parametrize("idx", range(len(_gold.CASES)))
+def test_restatement_equals_the_golden_rows_of_the_reference_function(nso, idx):
+    """the same pin where the reference tree (and oracle/_ref) is absent: rows minted by tests/golden/make_attn_golden.py"""
+    g = np.load(GOLDEN)
+    bs, hn, hkv, hs, slq, slkv, causal, alibi = _gold.CASES[idx]
+    q, k, v = _gold.case_inputs(idx)
+    rows = _gold.sample_rows(slq)
+    sc = 1.0 / np.sqrt(hs)
+    flags = (1 if causal else 0) | (2 if alibi else 0)
+    for kt in (False, True):
+        kk = np.ascontiguousarray(k.transpose(0, 2, 3, 1)) if kt else k
+        for pf in (True, False):
+            mine = nso.attn_ref(q, kk, v, sc, flags=flags, k_trans=kt, bf16_gemm=(not pf) and (not kt), ref_exp=True)
+            want = g["c%d_kt%d_fp32%d" % (idx, int(kt), int(pf))]
+            assert np.array_equal(want.view(np.int32), mine[:, rows].view(np.int32)), (idx, kt, pf)
