@@ -485,6 +485,22 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
     lda = w->k;
     dA16 = nullptr;  // the caller's fp16 shadow is in the unshuffled order
   }
+  if (ref_int8_for(w) && m <= 4) {  // decode-sized: the streaming kernel's int8-reference variant (gemv_kernel XV = 3)
+    I8Act q;
+    if (hip_ok(i8_quantize_for_decode(dA, lda, w, m, st, reuse_aq && !w->shuf, &q), "activation quantization")) {
+      SmallMArgs a{};
+      a.a = dA, a.lda = lda, a.m = m, a.ldc = ldc, a.nseg = 1;
+      a.seg[0] = {w, dC, dC16};
+      a.epilogue = epilogue, a.d = dD, a.ldd = ldd;
+      a.i8 = &q;
+      const hipError_t e = launch_gemv(a, st);
+      if (e == hipSuccess) return 0;
+      if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference decode launch") ? 0 : -1;
+      reuse_aq = false;  // outside that kernel's envelope: the general int8-reference kernel, with its own scratch
+    } else {
+      return -1;
+    }
+  }
   if (ref_int8_for(w))  // opt-in: quantize A to u8 per k-block and accumulate integer dots, like the CPU int8 cores
     return hip_ok(launch_i8ref(dA, lda, w, dC, dC16, m, ldc, epilogue, dD, ldd, st, reuse_aq && !w->shuf),
                   "int8-reference forward") ? 0 : -1;
@@ -886,6 +902,25 @@ int ns_hip_fusion_qkv_forward_x(const float* dA, const void* dA16, const ns_weig
     return -1;
   }
   if (link && !link_ok(link, wq, m, dA16)) return -1;
+  if (ref_int8_for(wq) && m <= 4 && !link) {  // int8-reference numerics, decode-sized: ONE activation quantization + one launch
+    bool same8 = true;
+    for (int i = 1; i < 3; i++)
+      same8 &= ref_int8_for(ws[i]) && ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize &&
+               ws[i]->scale_dt == wq->scale_dt && ws[i]->asym == wq->asym && ws[i]->qtype == wq->qtype;
+    same8 &= !wq->shuf && !wk->shuf && !wv->shuf;
+    I8Act q;
+    if (same8 && i8_quantize_for_decode(dA, lda, wq, m, st, false, &q) == hipSuccess) {
+      SmallMArgs a{};
+      a.a = dA, a.lda = lda, a.m = m, a.ldc = ldc, a.nseg = 3;
+      for (int i = 0; i < 3; i++)
+        a.seg[i] = {ws[i], dC + size_t(i) * m * ldc, dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr};
+      a.epilogue = NS_EPI_NONE;
+      a.i8 = &q;
+      const hipError_t e = launch_gemv(a, st);
+      if (e == hipSuccess) return 0;
+      if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference qkv launch") ? 0 : -1;
+    }
+  }
   if (!same || m > 64) {  // fall back to three launches (still on the GPU)
     // int8-reference mode: the three weights share one activation quantization when K and the group size agree
     auto same_aq = [&](int i) {
@@ -959,6 +994,22 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
   if (link) {
     set_error("ffn gate/up: a norm link needs the fused launch (matching formats, seq <= 16)");
     return -1;
+  }
+  if (ref8 && same && seq <= 4 && ref_int8_for(w3)) {  // int8-reference numerics, decode-sized: one quantization, one launch
+    I8Act q;
+    if (i8_quantize_for_decode(dA, fin, w1, seq, st, false, &q) == hipSuccess) {
+      SmallMArgs a{};
+      a.a = dA, a.lda = fin, a.m = seq, a.ldc = fmid, a.nseg = 2;
+      a.seg[0] = {w1, dTmp2, dTmp2_16};
+      a.seg[1] = {w3, dTmp2, nullptr};
+      a.epilogue = act;
+      a.dual = true;
+      a.c2 = dTmp1;
+      a.i8 = &q;
+      const hipError_t e = launch_gemv(a, st);
+      if (e == hipSuccess) return 0;
+      if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference gate/up launch") ? 0 : -1;
+    }
   }
   if (!dTmp1 && ref8) dTmp1 = static_cast<float*>(stream_scratch(st, size_t(seq) * fmid * 4, 5));
   if (!dTmp1) {

@@ -133,6 +133,13 @@ struct GemmSeg {
   float* c;       // output base of this segment
   void* c16;      // optional fp16 shadow of the output (same shape / ldc), consumed as `a16` by the next GEMM
 };
+// int8-reference numerics for a decode launch (gemv_kernel XV = 3): the activations as quantize_fp_u8_colblock leaves them
+struct I8Act {
+  const uint8_t* aq;    // [m][ldq] u8 codes (ldq >= K)
+  int ldq;
+  const uint8_t* corr;  // [m][nblk] fp32 scales immediately followed by [m][nblk] u8 zero points, 16-byte aligned
+  int nblk, blocksize;
+};
 struct SmallMArgs {
   const float* a;
   const void* a16;  // optional fp16 copy of A (same shape / lda): skips the fp32->fp16 staging conversion
@@ -147,6 +154,7 @@ struct SmallMArgs {
   float* c2;       // optional tmp1 output in dual mode
   const ns_norm_link* link = nullptr;  // carried RMS norm (include/ns_bestla.h); gemv_kernel only
   const ns_qkv_rope* rope = nullptr;   // RoPE(q, k) + kv-cache append as the QKV epilogue; gemv_kernel only
+  const I8Act* i8 = nullptr;           // int8-reference numerics (m <= 4); gemv_kernel only: launch_gemv() directly
 };
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
 // ns_gemm.hip: second-generation prefill GEMM; hipErrorNotSupported = use the first-generation gemm_kernel
@@ -230,6 +238,7 @@ hipError_t launch_gather_cols(const float* a, int lda, const int* idx, float* ou
 hipError_t launch_prefetch(const ns_weight* w, size_t offset, size_t bytes, int grid, hipStream_t st);
 // ns_i8ref.hip: the reference's int8-compute semantics (u8 activation quantization + integer dot per k-block)
 bool i8ref_supported(const ns_weight* w);
+hipError_t i8_quantize_for_decode(const float* a, int lda, const ns_weight* w, int m, hipStream_t st, bool reuse, I8Act* out);
 hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, void* c16, int m, int ldc, int epilogue,
                         const float* d, int ldd, hipStream_t st, bool reuse_aq = false);
 hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t st);

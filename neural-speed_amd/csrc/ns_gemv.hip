@@ -93,6 +93,10 @@ struct GemvParams {
   uint32_t ring_off;        // byte offset of the per-wave rings in LDS (the reduction scratch reuses them)
   uint32_t ring_stride;     // bytes of one wave's ring = slots x slot size
   uint32_t z_off0, z_off1, zstride;  // asymmetric formats only: last, so that the rest is one contiguous run of words
+  // int8-reference numerics (XV = 3): a = u8 activation codes [m][lda]; i8_corr = [m][nblk] fp32 scales followed by
+  // [m][nblk] u8 zero points (one span, staged at ssq_off); k-block of column kk = kk >> i8_bshift
+  const uint8_t* i8_corr;
+  uint32_t i8_span, i8_nblk, i8_bshift;
   // ---- cold: read late, through the kernel-argument pointer (keeps them out of the streaming loop's SGPRs) ----
   GemvMat mat[3];
   float* c2;
@@ -152,9 +156,16 @@ enum GemvMode { GV_PLAIN = 0, GV_DUAL = 1, GV_MSEG = 2 };
 // front of the ring requests, converted (round to nearest even, as the shadow's producers do) and written to LDS once
 // only ring requests are left in flight — the weights are requested exactly as early as with a shadow.
 constexpr int kGvA32Regs = 8;  // 16-byte loads of fp32 activations a wave holds in registers
+// XV = 3 (I8S): the REFERENCE'S int8-compute numerics (its default for Q4_0: gemv_4bit_u8s8_fp32, kernel_ref.h:2371-2429) on the
+// same streaming skeleton: A arrives as the u8 codes / scales / zero points of quantize_fp_u8_colblock (aquant_u8_kernel,
+// bit-exact), a lane (column nn, k-slot g) takes exact integer dots of its eight codes per 32-deep slice with v_dot4 on the
+// stored codes,  sum (a - za)(q - zb) = sum a u - (zb + bias) sum a - za sum u + 8 za (zb + bias)  (u = q + bias), and adds
+// float(sum) * (scale_a * scale_b) per slice; up to four rows.  Reduction, epilogues, fused QKV / gate-up modes are shared.
 template <int KIND, int SPS, int SK, bool ASYM, int MODE, int XV>
 __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
-  constexpr bool EXT = XV == 1, A32 = XV == 2;
+  constexpr bool EXT = XV == 1, A32 = XV == 2, I8S = XV == 3;
+  static_assert(!I8S || KIND == WK_INT4 || KIND == WK_INT8, "integer weights only");
+  constexpr uint32_t AEL = I8S ? 1u : 2u;  // bytes per staged activation element
   constexpr bool DUAL = MODE == GV_DUAL, MSEG = MODE == GV_MSEG;
   constexpr int NJ = kind_is_8bit(KIND) ? 2 : 4;
   constexpr int KSTEP = NJ * 32;
@@ -299,8 +310,8 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
       }
     }
   } else {
-    const Rsrc ra = make_rsrc(p.a, uint32_t(rows - 1) * uint32_t(p.lda) * 2u + uint32_t(p.k) * 2u);
-    const uint32_t row_bytes = ks * uint32_t(KSTEP) * 2u;
+    const Rsrc ra = make_rsrc(p.a, uint32_t(rows - 1) * uint32_t(p.lda) * AEL + uint32_t(p.k) * AEL);
+    const uint32_t row_bytes = ks * uint32_t(KSTEP) * AEL;
     const uint32_t pieces = (row_bytes + 1023u) >> 10;
     const uint32_t total = uint32_t(rows) * pieces;
     const LdsPtr al = (LdsPtr)(smem);
@@ -314,8 +325,17 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
       if (uint32_t(l) * 16u < left)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(al + r * p.row_stride * 2u + (c << 10)),
-                                                 16, voff_q, r * uint32_t(p.lda) * 2u + (c << 10), 0, 0);
+                                                 16, voff_q, r * uint32_t(p.lda) * AEL + (c << 10), 0, 0);
 #endif
+    }
+    if constexpr (I8S) {  // the rows' activation scales + zero points: one span, 1 KiB pieces, read zero past its end
+      const Rsrc rc = make_rsrc(p.i8_corr, p.i8_span);
+      for (uint32_t u = w; u < ((p.i8_span + 1023u) >> 10); u += NW) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, reinterpret_cast<__attribute__((address_space(3))) void*>(al + p.ssq_off + (u << 10)), 16,
+                                                 voff_q, u << 10, 0, 0);
+#endif
+      }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -394,9 +414,103 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+  float accr[NQ][4];  // I8S: rows 0..3 of column nn, this lane's k-slots
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) accr[q][r] = 0.f;
+  const uint32_t i8_rsb = p.row_stride * 2u;  // I8S: bytes per staged row of codes
   auto compute = [&](auto slot_c, uint32_t s) {
     constexpr int slot = decltype(slot_c)::value;
     constexpr int q = slot % NQ;
+    if constexpr (I8S) {
+      Corr cr;
+      {
+        typedef __attribute__((address_space(3))) const uint32_t* L32;
+        const uint32_t ca = ring_corr + uint32_t(slot) * SLOT;
+        if constexpr (SBYTES == 2) {
+          cr.s[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(ca);
+        } else {
+#pragma unroll
+          for (int t = 0; t < Corr::NW32; t++) cr.s[t] = reinterpret_cast<L32>(ca)[t];
+        }
+        if constexpr (ASYM) {
+          const uint32_t za = uint32_t(reinterpret_cast<uintptr_t>(ring)) + uint32_t(slot) * SLOT + 1024u + 16u * SBYTES + uint32_t(nn) * SPS;
+          if constexpr (SPS == 4)
+            cr.z[0] = *reinterpret_cast<L32>(za);
+          else if constexpr (SPS == 2)
+            cr.z[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(za);
+          else
+            cr.z[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint8_t*>(za);
+        }
+      }
+      float sc[4], zp[4];
+      corr_decode<SPS, SK, ASYM, NJ>(cr, sc, zp);
+      const uint4v qvv = *reinterpret_cast<const __attribute__((address_space(3))) uint4v*>(ring_lane + uint32_t(slot) * SLOT);
+      const uint32_t xw[4] = {qvv.x, qvv.y, qvv.z, qvv.w};
+      constexpr int BIAS = KIND == WK_INT4 ? 8 : 128;
+      const uint32_t lds0 = uint32_t(reinterpret_cast<uintptr_t>((LdsPtr)(smem)));
+      const uint32_t kbase = s * uint32_t(KSTEP);
+      const uint32_t i8_sbase = lds0 + p.ssq_off;                            // [rows][nblk] fp32 scales
+      const uint32_t i8_zbase = i8_sbase + uint32_t(rows) * p.i8_nblk * 4u;  // [rows][nblk] u8 zero points
+      // the record's weight side, once for all rows: codes as bytes (k ascending), their sums, zero points + bias, k-blocks
+      uint32_t u0[NJ], u1[NJ], kb[NJ];
+      int su[NJ], zbq[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        if constexpr (KIND == WK_INT4) {
+          const uint32_t t0 = xw[j] & 0x0f0f0f0fu, t1 = (xw[j] >> 4) & 0x0f0f0f0fu;  // codes 0,4,1,5 and 2,6,3,7
+          u0[j] = __builtin_amdgcn_perm(t1, t0, 0x06040200u);
+          u1[j] = __builtin_amdgcn_perm(t1, t0, 0x07050301u);
+        } else {
+          u0[j] = xw[2 * j] ^ 0x80808080u, u1[j] = xw[2 * j + 1] ^ 0x80808080u;  // raw int8 -> q + 128
+        }
+        su[j] = int(__builtin_amdgcn_udot4(u0[j], 0x01010101u, __builtin_amdgcn_udot4(u1[j], 0x01010101u, 0u, false), false));
+        zbq[j] = (ASYM ? int(zp[j]) : 0) + BIAS;
+        kb[j] = min((kbase + 32u * uint32_t(j)) >> p.i8_bshift, p.i8_nblk - 1u);  // (slices past K: clamped, never used)
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (r < rows) {
+          // LDS reads by hand, one batch per row and record: for a visible LDS read hipcc waits for EVERY LDS-DMA request in
+          // flight (vmcnt(0): the whole ring) — it cannot know that the rings and the staged activations do not overlap
+          uint64_t av[4] = {0, 0, 0, 0};
+          uint32_t zau[4] = {0, 0, 0, 0}, asu[4] = {0, 0, 0, 0};
+          const uint32_t aaddr = lds0 + uint32_t(r) * i8_rsb + kbase + 8u * uint32_t(g);
+          const uint32_t zrow = i8_zbase + uint32_t(r) * p.i8_nblk, srow = i8_sbase + uint32_t(r) * p.i8_nblk * 4u;
+          if constexpr (NJ == 4) {
+            asm volatile(
+                "ds_read_b64 %0, %12\n\tds_read_b64 %1, %12 offset:32\n\tds_read_b64 %2, %12 offset:64\n\tds_read_b64 %3, %12 offset:96\n\t"
+                "ds_read_u8 %4, %13\n\tds_read_u8 %5, %14\n\tds_read_u8 %6, %15\n\tds_read_u8 %7, %16\n\t"
+                "ds_read_b32 %8, %17\n\tds_read_b32 %9, %18\n\tds_read_b32 %10, %19\n\tds_read_b32 %11, %20\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(av[0]), "=&v"(av[1]), "=&v"(av[2]), "=&v"(av[3]), "=&v"(zau[0]), "=&v"(zau[1]), "=&v"(zau[2]), "=&v"(zau[3]),
+                  "=&v"(asu[0]), "=&v"(asu[1]), "=&v"(asu[2]), "=&v"(asu[3])
+                : "v"(aaddr), "v"(zrow + kb[0]), "v"(zrow + kb[1]), "v"(zrow + kb[2]), "v"(zrow + kb[3]), "v"(srow + kb[0] * 4u),
+                  "v"(srow + kb[1] * 4u), "v"(srow + kb[2] * 4u), "v"(srow + kb[3] * 4u)
+                : "memory");
+          } else {
+            asm volatile(
+                "ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:32\n\tds_read_u8 %2, %7\n\tds_read_u8 %3, %8\n\t"
+                "ds_read_b32 %4, %9\n\tds_read_b32 %5, %10\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(av[0]), "=&v"(av[1]), "=&v"(zau[0]), "=&v"(zau[1]), "=&v"(asu[0]), "=&v"(asu[1])
+                : "v"(aaddr), "v"(zrow + kb[0]), "v"(zrow + kb[1]), "v"(srow + kb[0] * 4u), "v"(srow + kb[1] * 4u)
+                : "memory");
+          }
+#pragma unroll
+          for (int j = 0; j < NJ; j++) {
+            if (kbase + 32u * uint32_t(j) < uint32_t(p.k)) {  // wave-uniform: a 32-deep slice lies inside K or outside
+              const uint32_t avx = uint32_t(av[j]), avy = uint32_t(av[j] >> 32);
+              const int za = int(zau[j]);
+              const int dot = int(__builtin_amdgcn_udot4(avx, u0[j], __builtin_amdgcn_udot4(avy, u1[j], 0u, false), false));
+              const int sa = int(__builtin_amdgcn_udot4(avx, 0x01010101u, __builtin_amdgcn_udot4(avy, 0x01010101u, 0u, false), false));
+              const int isum = dot - zbq[j] * sa - za * su[j] + 8 * za * zbq[j];
+              accr[q][r] += float(isum) * (__builtin_bit_cast(float, asu[j]) * sc[j]);
+            }
+          }
+        }
+      }
+      return;
+    }
     const _Float16* abase = a_lds + s * KSTEP + aoff;
     // the record's scales / zero points of column nn and the lane's 16 B of codes, out of the ring slot
     Corr cr;
@@ -467,6 +581,20 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   }
   NS_GSTAMP(4);
 
+  if constexpr (I8S) {  // the four k-slots of a column live in lanes nn, nn + 16, nn + 32, nn + 48; rows 0..3 = lane group 0's
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      float t[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float v = accr[q][r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        t[r] = v;
+      }
+      acc[q] = g == 0 ? floatx4{t[0], t[1], t[2], t[3]} : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   // ---- 5. cross-wave reduction: every wave writes its partial sums over ITS OWN ring, wave 0 adds them in wave order ----
   floatx4* red = reinterpret_cast<floatx4*>(smem + p.ring_off);
   const uint32_t kRedWave = p.ring_stride / 16;  // floatx4 per wave region (>= NQ KiB, checked by the host)
@@ -621,15 +749,24 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 // host side
 // ============================================================================================================
 constexpr int kGvModeA32 = 0x100;  // or-ed into the launch mode: fp32 activations (XV = 2)
+constexpr int kGvModeI8 = 0x200;   // int8-reference numerics (XV = 3)
 template <int KIND, int SPS, int SK, bool ASYM>
 static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw, size_t lds, hipStream_t st) {
   const dim3 g(grid), b(nw * 64);
   const bool ext = p.in_ssq || p.out_gamma || p.out_ssq || p.rope.on;
   const bool a32 = (mode & kGvModeA32) != 0;  // never together with ext (launch_gemv)
-  mode &= ~kGvModeA32;
+  const bool i8s = (mode & kGvModeI8) != 0;
+  mode &= ~(kGvModeA32 | kGvModeI8);
+  if constexpr (KIND != WK_INT4 && KIND != WK_INT8)
+    if (i8s) return hipErrorNotSupported;
 #define NS_GV_LAUNCH(MODEV)                                                                                     \
   {                                                                                                             \
-    if (ext) NS_GV_LAUNCH_E(MODEV, 1) else if (a32) NS_GV_LAUNCH_E(MODEV, 2) else NS_GV_LAUNCH_E(MODEV, 0)      \
+    if (ext) NS_GV_LAUNCH_E(MODEV, 1) else if (a32) NS_GV_LAUNCH_E(MODEV, 2) else if (i8s) NS_GV_LAUNCH_I8(MODEV)    \
+    else NS_GV_LAUNCH_E(MODEV, 0)                                                                               \
+  }
+#define NS_GV_LAUNCH_I8(MODEV)                                                                                   \
+  {                                                                                                             \
+    if constexpr (KIND == WK_INT4 || KIND == WK_INT8) NS_GV_LAUNCH_E(MODEV, 3)                                  \
   }
 #define NS_GV_LAUNCH_E(MODEV, EXTV)                                                                             \
   {                                                                                                             \
@@ -647,6 +784,7 @@ static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw,
     NS_GV_LAUNCH(GV_PLAIN)
 #undef NS_GV_LAUNCH
 #undef NS_GV_LAUNCH_E
+#undef NS_GV_LAUNCH_I8
   return hipGetLastError();
 }
 template <int KIND, int SPS, int SK>
@@ -739,22 +877,41 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   const int kstep = w0->kstep_len;
   if (tiles == 0 || ks == 0) return hipErrorNotSupported;
 
-  // staged activations: [rows][ks * KSTEP + 8] halves
+  // staged activations: [rows][ks * KSTEP + 8] halves (int8-reference numerics: [rows][ks * KSTEP + 16] bytes)
   const int rows = a.m;
-  const uint32_t row_stride = ks * uint32_t(kstep) + 8;
+  const bool i8s = a.i8 != nullptr;
+  const uint32_t row_stride = i8s ? (ks * uint32_t(kstep) + 16) / 2 : ks * uint32_t(kstep) + 8;
   const size_t a_bytes = size_t(rows) * row_stride * 2;
   if (a_bytes > kGvMaxALds) return hipErrorNotSupported;
+  uint32_t i8_shift = 0;
+  if (i8s) {
+    const I8Act& q = *a.i8;
+    const bool int_w = w0->kind == WK_INT4 || w0->kind == WK_INT8;
+    // a 32-deep slice must lie inside one k-block and inside or outside K; block index by shift (one block: any shift >= 31)
+    const bool one_block = q.nblk == 1;
+    while (!one_block && (1u << i8_shift) < uint32_t(q.blocksize)) i8_shift++;
+    if (!int_w || rows > 4 || a.link || a.rope || (w0->k & 31) || !q.aq || !q.corr || (reinterpret_cast<uintptr_t>(q.aq) & 15) ||
+        (reinterpret_cast<uintptr_t>(q.corr) & 15) || (q.ldq & 15) || q.ldq < w0->k ||
+        (!one_block && ((1u << i8_shift) != uint32_t(q.blocksize) || q.blocksize < 32)))
+      return hipErrorNotSupported;
+    if (one_block) i8_shift = 31;
+    p.i8_corr = q.corr;
+    p.i8_nblk = uint32_t(q.nblk);
+    p.i8_span = (uint32_t(rows) * uint32_t(q.nblk) * 5u + 3u) & ~3u;  // whole words: a buffer load drops a word that straddles the bound (the scratch has the slack)
+    p.i8_bshift = i8_shift;
+  }
   // fp16 activations with 16-byte aligned rows; several rows need K to fill whole k-steps (a row's padding columns
   // would otherwise read the next row through the descriptor)
-  const bool a16 = a.a16 != nullptr && (a.lda & 7) == 0 && (w0->k & 7) == 0 && (reinterpret_cast<uintptr_t>(a.a16) & 15) == 0;
+  const bool a16 = i8s || (a.a16 != nullptr && (a.lda & 7) == 0 && (w0->k & 7) == 0 && (reinterpret_cast<uintptr_t>(a.a16) & 15) == 0);
   // fp32-only callers: converted while staging (XV = 2); not together with a carried norm / fused RoPE, whose producers
   // always leave a shadow
   const bool a32 = !a16 && a.a != nullptr && !a.link && !a.rope && (a.lda & 3) == 0 && (w0->k & 3) == 0 &&
                    (reinterpret_cast<uintptr_t>(a.a) & 15) == 0;
   if ((!a16 && !a32) || (rows > 1 && w0->k % kstep != 0)) return hipErrorNotSupported;
-  p.a = a16 ? a.a16 : static_cast<const void*>(a.a);
+  p.a = i8s ? static_cast<const void*>(a.i8->aq) : (a16 ? a.a16 : static_cast<const void*>(a.a));
   // carried RMS norm (ns_norm_link): consumer side stages in_parts floats per row behind A
   size_t ssq_bytes = 0;
+  if (i8s) ssq_bytes = (size_t(p.i8_span) + 1023) >> 10 << 10;  // the scales / zero points span sits where a carried norm's sums would
   if (a.link) {
     const ns_norm_link& k = *a.link;
     if (k.in_ssq) {
@@ -819,7 +976,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   }
   p.m = a.m;
   p.k = w0->k;
-  p.lda = a.lda;
+  p.lda = i8s ? a.i8->ldq : a.lda;
   p.row_stride = row_stride;
   p.ssq_off = uint32_t((a_bytes + 15) & ~size_t(15));
   p.ring_off = p.ssq_off + uint32_t(ssq_bytes);
@@ -836,7 +993,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   p.ring_stride = uint32_t(ring_bytes(nw));
   const size_t lds = size_t(p.ring_off) + size_t(nw) * p.ring_stride;
   if (lds > kGvMaxLds) return hipErrorNotSupported;
-  const int mode_x = mode | (a32 ? kGvModeA32 : 0);
+  const int mode_x = mode | (a32 ? kGvModeA32 : 0) | (i8s ? kGvModeI8 : 0);
 
 #define NS_DISPATCH(KIND)                                                                       \
   switch (w0->sps) {                                                                            \

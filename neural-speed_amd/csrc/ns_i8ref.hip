@@ -462,6 +462,28 @@ void launch_i8mfma(int sdt, bool asym, dim3 grid, size_t lds, hipStream_t st, co
 
 }  // namespace
 
+// quantize_fp_u8_colblock(A) into the stream's scratch (slot 6) in the layout gemv_kernel's int8-reference variant stages:
+// codes [m][ldq] (ldq = K rounded up to 16) | [m][nblk] fp32 scales | [m][nblk] u8 zero points.  reuse: the scratch already
+// holds it for this (A, m, K, blocksize) — the previous call of a fused QKV / gate-up group
+hipError_t i8_quantize_for_decode(const float* a, int lda, const ns_weight* w, int m, hipStream_t st, bool reuse, I8Act* out) {
+  const int bs = w->blocksize >= w->k ? w->k : w->blocksize;
+  const int nblk = (w->k + bs - 1) / bs;
+  const int ldq = (w->k + 15) & ~15;
+  const size_t aq_bytes = size_t(m) * ldq;
+  uint8_t* base = static_cast<uint8_t*>(stream_scratch(st, aq_bytes + size_t(m) * nblk * 5 + 16, 6));
+  if (!base) return hipErrorOutOfMemory;
+  float* as = reinterpret_cast<float*>(base + aq_bytes);
+  uint8_t* az = base + aq_bytes + size_t(m) * nblk * 4;
+  if (!reuse) {
+    const hipError_t e = launch_aquant_u8(m, w->k, a, lda, base, ldq, as, nblk, az, bs, nullptr, st);
+    if (e != hipSuccess) return e;
+  }
+  out->aq = base, out->ldq = ldq;
+  out->corr = base + aq_bytes;
+  out->nblk = nblk, out->blocksize = bs;
+  return hipSuccess;
+}
+
 bool i8ref_supported(const ns_weight* w) {
   return (w->kind == WK_INT4 || w->kind == WK_INT8) && w->blocksize > 0 && (w->blocksize % 32 == 0 || w->blocksize >= w->k);
 }
