@@ -503,6 +503,7 @@ def main():
             out["config"]["prefill_m2048_tflops"] = prefill_tflops(chain, pkg)
             out["config"]["prefill_m2048_tflops_int8w"] = prefill_tflops_int8w(chain, pkg)
             out["config"]["prefill_m2048_tflops_ref_int8_semantics"] = prefill_tflops_ref_int8(chain, pkg)
+            out["config"]["decode_tokens_per_s_ref_int8_semantics"] = decode_ref_int8(step, pkg)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.layers)
         print(json.dumps(out))
@@ -748,6 +749,20 @@ def roofline(chain, pkg):
         "avg_launch_us": round(us, 3),
         "note": "avg over %d back-to-back graph launches incl. ~1.2us inter-kernel boundary each" % (reps * nl),
     }
+
+
+def decode_ref_int8(step, pkg, steps=60, warmup=10):
+    """the SAME decode chain in the reference's DEFAULT numerics for this model (Q4_0: compute_dtype = int8 —
+    quantize_fp_u8_colblock on every GEMV input + gemv_4bit_u8s8_fp32's integer dots, kernel_ref.h:1824-1883, :2371-2429):
+    NS_COMPUTE_REF_INT8 routes the same entry points to the streaming kernel's int8 variant (one activation quantization
+    launch per distinct input + the fused QKV / gate-up / plain launches); one HIP graph, tokens/s"""
+    L = pkg.lib()
+    prev = L.ns_hip_set_compute_mode(1)
+    try:
+        wall_ms, _ = time_graph(step, steps, warmup, True, 1)
+        return round(1000.0 / (wall_ms / steps), 2)
+    finally:
+        L.ns_hip_set_compute_mode(prev if prev in (0, 1) else 0)
 
 
 def prefill_tflops_ref_int8(chain, pkg, m=2048):
