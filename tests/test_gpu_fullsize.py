@@ -199,3 +199,41 @@ def test_gemv_kernel_fp32_activations_only_equals_the_shadow_path(L, pkg, nso, n
     assert nso.rel_l2(fp32_only, ref) < TOL, (name, n, k, m)
     assert nso.rel_l2(fp32_only, ref16) < (6e-4 if qt.startswith("F4") else 3e-5), (name, n, k, m)
     wt.free()
+
+
+I8_SHAPES = [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096)]
+
+
+@pytest.mark.parametrize("m", [1, 4])
+@pytest.mark.parametrize("n,k", I8_SHAPES)
+def test_int8_reference_numerics_decode_full_size(L, pkg, nso, n, k, m):
+    """NS_COMPUTE_REF_INT8 at decode size on the 7B shapes: the streaming kernel's int8 variant (gemv_kernel XV = 3) against the
+    oracle's restatement of quantize_fp_u8_colblock + gemv_4bit_u8s8_fp32 on the same blob — exact integer dots, so only the
+    fp32 summation order differs (2e-6); the plain entry and, for the square shape, the fused QKV and gate/up entries"""
+    import torch
+    blob, wt = _device_blob(L, pkg, nso, n, k, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, False, seed=n + 3 * k + m)
+    g = torch.Generator(device="cuda").manual_seed(m * 7 + 1)
+    dA = torch.randn((m, k), generator=g, device="cuda")
+    prev = L.ns_hip_set_compute_mode(1)
+    try:
+        out = _forward_h(L, pkg, wt, dA, m, k, n, shadow=False)
+        ref = nso.gemm_u8s8(dA.cpu().numpy(), blob)
+        assert nso.rel_l2(out, ref) < 2e-6, (n, k, m, nso.rel_l2(out, ref))
+        if n == k:  # fused entries: three / two weights, one activation quantization, one launch
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            blob2, wt2 = _device_blob(L, pkg, nso, n, k, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, False, seed=n + 5 * k + m)
+            qkv = torch.full((3, m, n), 7.0, dtype=torch.float32, device="cuda")
+            pkg.check(L.ns_hip_fusion_qkv_forward_h(dA.data_ptr(), None, wt.h, wt2.h, wt.h, qkv.data_ptr(), None, m, k, n, st))
+            t1 = torch.empty((m, n), dtype=torch.float32, device="cuda")
+            t2 = torch.full((m, n), 7.0, dtype=torch.float32, device="cuda")
+            pkg.check(L.ns_hip_fusion_ffn3_gateup_h(dA.data_ptr(), None, wt.h, wt2.h, t1.data_ptr(), t2.data_ptr(), None, m, pkg.EPI_SILU, st))
+            torch.cuda.synchronize()
+            ref2 = nso.gemm_u8s8(dA.cpu().numpy(), blob2)
+            q = qkv.cpu().numpy()
+            assert nso.rel_l2(q[0], ref) < 2e-6 and nso.rel_l2(q[1], ref2) < 2e-6 and nso.rel_l2(q[2], ref) < 2e-6
+            silu = ref.astype(np.float64) / (1.0 + np.exp(-ref.astype(np.float64)))
+            assert nso.rel_l2(t2.cpu().numpy(), (silu * ref2).astype(np.float32)) < 5e-6
+            wt2.free()
+    finally:
+        L.ns_hip_set_compute_mode(prev)
+    wt.free()
