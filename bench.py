@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-only", action="store_true", help="diagnostics: skip the roofline / prefill / CPU legs")
+    ap.add_argument("--full-token-only", action="store_true", help="diagnostics: print the whole-token leg alone and exit")
     return ap.parse_args()
 
 
@@ -394,6 +395,10 @@ def main():
         full = fg == "force" or (fg == "1" and (backend == "nccl" or p2p_on))
         return ([True] if full else []) + ["segments", False]
 
+    if args.full_token_only and world == 1:
+        ft, _ = full_token(chain, pkg, 2048, fused=True)
+        print(json.dumps({"full_token": ft}))
+        return
     attempts = ([(m, True) for m in launch_modes(True)] if use_p2p else []) + [(m, False) for m in launch_modes(False)]
     wall_ms = ev_ms = None
     p2p_dead = False
