@@ -246,7 +246,12 @@ int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_wei
  *                  (16-byte aligned, in_stride a multiple of 4); eps, norm_size of the norm
  *   producer side (out_gamma and/or out_ssq != NULL; single-matrix forward only): dC16 <- fp16(v * out_gamma[col]),
  *                  out_ssq[row * out_stride + tile] <- sum over the tile's columns of v^2 (tiles = ceil(N / 16))
- * ns_hip_norm_prep does the producer side for a tensor that no GEMM produced (the embedding row of layer 0). */
+ * ns_hip_norm_prep does the producer side for a tensor that no GEMM produced (the embedding row of layer 0).
+ * RANGE: the shadow holds gamma . x BEFORE normalisation in fp16: |gamma[col] * x[col]| must stay below 65504 (an
+ * un-carried norm's shadow holds the normalised value and has no such limit).  Residual streams of the model families the
+ * reference ships stay orders of magnitude below that; a caller whose residual stream can exceed it keeps the norm as a
+ * launch of its own (ns_hip_norm_mul_h) — an overflowed element reads as inf and the consumer's output row as inf / nan,
+ * never as a silently wrong finite value. */
 typedef struct ns_norm_link {
   const float* in_ssq;
   int in_parts, in_stride;

@@ -20,6 +20,8 @@
 //   per XCD on MI355X).  HBM-bound on K and V: 2 * sl_kv * heads_kv * head_size * 2 B per query row.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -838,6 +840,9 @@ void bestla_reordered_attn_fp32_batch_kv_info(const kv_shape_t* params, kv_cache
   out->v_bytes = size_t(out->stride_v_head_num) * params->heads_kv;
 }
 
+// the host-tensor entries stage through slots of the null stream's scratch; one call at a time
+static std::mutex g_attn_host_mu;
+constexpr int kScratchHostA = 10, kScratchHostB = 11, kScratchHostC = 12, kScratchHostD = 13;
 static bool kv_device() {
   int count = 0;
   if (hipGetDeviceCount(&count) == hipSuccess && count > 0) return true;
@@ -860,10 +865,11 @@ static void kv_update(const bestla_fusion_attn_fp32_update_kv_args_t* pp, const 
   const size_t total = size_t(a.batch_size) * a.heads_kv * a.seq_size * a.head_size;
   if (total == 0) return;
   const size_t nsrc = span4(a.batch_size, a.step_bs, a.heads_kv, a.step_head_num, a.seq_size, a.step_seq, a.head_size, a.step_head_size);
-  float* dsrc = nullptr;
-  _Float16* dout = nullptr;
-  bool ok = hipMalloc((void**)&dsrc, nsrc * 4) == hipSuccess && hipMalloc((void**)&dout, total * 2) == hipSuccess &&
-            hipMemcpy(dsrc, a.src, nsrc * 4, hipMemcpyHostToDevice) == hipSuccess;
+  // staging in the grow-only per-stream scratch (a hipMalloc / hipFree pair per call synchronises the whole device twice)
+  std::lock_guard<std::mutex> host_lock(g_attn_host_mu);
+  float* dsrc = static_cast<float*>(stream_scratch(nullptr, nsrc * 4, kScratchHostA));
+  _Float16* dout = static_cast<_Float16*>(stream_scratch(nullptr, total * 2, kScratchHostB));
+  bool ok = dsrc && dout && hipMemcpy(dsrc, a.src, nsrc * 4, hipMemcpyHostToDevice) == hipSuccess;
   if (ok) {
     hipLaunchKernelGGL(kv_update_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, nullptr, dsrc, dout, a.batch_size,
                        a.heads_kv, a.head_size, a.seq_size, (long long)a.step_bs, (long long)a.step_head_num, (long long)a.step_seq,
@@ -874,8 +880,6 @@ static void kv_update(const bestla_fusion_attn_fp32_update_kv_args_t* pp, const 
          hipMemcpy2D(a.cache + size_t(a.seq_off) * row, size_t(a.seq_max) * row, dout, size_t(a.seq_size) * row,
                      size_t(a.seq_size) * row, size_t(a.batch_size) * a.heads_kv, hipMemcpyDeviceToHost) == hipSuccess;
   }
-  if (dsrc) (void)hipFree(dsrc);
-  if (dout) (void)hipFree(dout);
   if (!ok) {
     (void)hipGetLastError();
     set_error(std::string(who) + ": device copy / launch failed");
@@ -899,9 +903,10 @@ void bestla_reordered_attn_fp32_shift_rope_k(char* cache, const uint16_t* cossin
   }
   const size_t row = size_t(head_size) * 2, slabs = size_t(batch_size) * heads_kv, n = size_t(seq_max - seq_keep);
   if (slabs == 0 || n == 0) return;
-  _Float16 *drows = nullptr, *dcs = nullptr;
-  bool ok = hipMalloc((void**)&drows, slabs * n * row) == hipSuccess && hipMalloc((void**)&dcs, row) == hipSuccess &&
-            hipMemcpy(dcs, cossin, row, hipMemcpyHostToDevice) == hipSuccess &&
+  std::lock_guard<std::mutex> host_lock(g_attn_host_mu);
+  _Float16* drows = static_cast<_Float16*>(stream_scratch(nullptr, slabs * n * row, kScratchHostA));
+  _Float16* dcs = static_cast<_Float16*>(stream_scratch(nullptr, row, kScratchHostB));
+  bool ok = drows && dcs && hipMemcpy(dcs, cossin, row, hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy2D(drows, n * row, cache + size_t(seq_keep) * row, size_t(seq_max) * row, n * row, slabs, hipMemcpyHostToDevice) ==
                 hipSuccess;
   if (ok) {
@@ -911,8 +916,6 @@ void bestla_reordered_attn_fp32_shift_rope_k(char* cache, const uint16_t* cossin
          hipMemcpy2D(cache + size_t(seq_keep) * row, size_t(seq_max) * row, drows, n * row, n * row, slabs, hipMemcpyDeviceToHost) ==
              hipSuccess;
   }
-  if (drows) (void)hipFree(drows);
-  if (dcs) (void)hipFree(dcs);
   if (!ok) {
     (void)hipGetLastError();
     set_error("bestla_reordered_attn_fp32_shift_rope_k: device copy / launch failed");
@@ -988,9 +991,13 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
                           a.step_v_head_size);
   const size_t nd = span4(a.batch_size, a.step_dst_bs, a.head_num, a.step_dst_head_num, a.sl_q, a.step_dst_sl,
                           a.head_size, 1);
-  void *dq = nullptr, *dk = nullptr, *dv = nullptr, *dd = nullptr;
-  bool ok = hipMalloc(&dq, nq * 4) == hipSuccess && hipMalloc(&dk, nk * 2) == hipSuccess &&
-            hipMalloc(&dv, nv * 2) == hipSuccess && hipMalloc(&dd, nd * 4) == hipSuccess;
+  // staging in the grow-only per-stream scratch (four hipMalloc / hipFree pairs per call synchronised the device eight times)
+  std::lock_guard<std::mutex> host_lock(g_attn_host_mu);
+  void* dq = stream_scratch(nullptr, nq * 4, kScratchHostA);
+  void* dk = stream_scratch(nullptr, nk * 2, kScratchHostB);
+  void* dv = stream_scratch(nullptr, nv * 2, kScratchHostC);
+  void* dd = stream_scratch(nullptr, nd * 4, kScratchHostD);
+  bool ok = dq && dk && dv && dd;
   ok = ok && hipMemcpy(dq, hp->Q, nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(dk, hp->K, nk * 2, hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(dv, hp->V, nv * 2, hipMemcpyHostToDevice) == hipSuccess &&
@@ -1006,10 +1013,6 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
   } else {
     set_error("attention: device allocation / upload failed");
   }
-  if (dq) hipFree(dq);
-  if (dk) hipFree(dk);
-  if (dv) hipFree(dv);
-  if (dd) hipFree(dd);
   if (!ok) fprintf(stderr, "Err: invalid parameters (bestla_fusion_attn_fp32_fp16_fp16_fp32_forward: %s)\n", ns_hip_last_error());
 }
 

@@ -166,14 +166,14 @@ void gemm_scratch_release();  // frees the per-stream scratch buffers
 void* stream_scratch(hipStream_t st, size_t bytes, int slot);
 // fp32 [m][lda] -> fp16 [m][ld16] (ld16 a multiple of 8, columns k..ld16-1 zero)
 hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, int ld16, hipStream_t st);
-// ns_gemv.hip: second-generation decode kernel (m <= 16): lean prologue, whole-tile + stream-K hybrid grid;
+// ns_gemv.hip: second-generation decode kernel (m <= 16): lean prologue, one 16-column tile per workgroup;
 // hipErrorNotSupported = outside its envelope (use smallm_kernel)
 hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st);
-void set_gemv_mode(int mode);
+void set_gemv_mode(int mode);  // 0 off (first-generation kernel), 1 on, -1 re-read NS_GEMV2
 void set_attn_tuning(int wg_target, int min_keys);
 void set_gemm3_bm(int bm);  // ns_gemm.hip: force gemm3_kernel's row-tile height (tests / A-B runs); 0 = automatic  // ns_attn.hip: context-split rule of the decode attention kernel
 void set_decode_waves(int nw);  // 0 = by shape
-int decode_waves(int grid, int ks, bool dual);  // waves per workgroup of a decode launch (both kernel generations)  // 0 off, 1 on, 2 on without the stream-K part, -1 re-read NS_GEMV2
+int decode_waves(int grid, int ks, bool dual);  // waves per workgroup of a decode launch (both kernel generations)
 void srow_rule(const ns_weight* w, int* num, int* den);          // scale row of k-step s = s * num / den
 // the same rule as a branch-free (s * mul) >> shift, verified for every k-step; false = not expressible
 bool srow_params(const ns_weight* w, int* mul, int* shift);

@@ -823,8 +823,11 @@ static int gemv_mode() {
 }
 
 // waves per workgroup of a decode launch (one 16-column tile per workgroup, k-steps dealt round-robin to the waves).
-// Shared with smallm_kernel so that both kernels add a tile's partial sums in the same order: a caller that passes the
-// fp16 shadow of A (gemv_kernel) gets bit for bit what the fp32-only caller (smallm_kernel) gets.
+// Shared with smallm_kernel so that both kernels split K the same way — bit-identical sums between a caller that passes
+// the fp16 shadow of A and an fp32-only caller — wherever this rule alone decides: launch_gemv additionally halves the
+// wave count until activations + rings fit in LDS (several rows of a large K), where smallm_kernel keeps the rule's value;
+// the two then differ in fp32 summation order only (fp32-only callers of decode shapes are served by gemv_kernel itself
+// since round 3, bit-equal to the shadow path: tests/test_gpu_fullsize.py).
 static std::atomic<int> g_decode_waves{0};  // ns_hip_set_tuning("gv_nw", n)
 void set_decode_waves(int nw) { g_decode_waves.store(nw); }
 int decode_waves(int grid, int ks, bool dual) {

@@ -744,7 +744,7 @@ hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
   // cover bandwidth x latency (~3-4k waves) and (b) as many k-steps per wave as possible so that dequant/MFMA of one
   // step overlaps the loads of the next ones.  Measured on MI355X (profiles/r01*): many tiles -> few waves each.
   int nw = 8;
-  if (mb == 1) nw = decode_waves(grid, w0->ksteps, a.dual);  // the same split of K as gemv_kernel: bit-identical sums
+  if (mb == 1) nw = decode_waves(grid, w0->ksteps, a.dual);  // the same split of K as gemv_kernel's rule (ns_gemv.hip: decode_waves)
   if (env_nw == 8 || env_nw == 4 || env_nw == 2 || (env_nw == 16 && mb == 1)) nw = env_nw;
   static const int env_nw_plain = getenv("NS_NW_PLAIN") ? atoi(getenv("NS_NW_PLAIN")) : 0;  // diagnostics
   if (!a.dual && mb == 1 && (env_nw_plain == 2 || env_nw_plain == 4 || env_nw_plain == 8 || env_nw_plain == 16))
