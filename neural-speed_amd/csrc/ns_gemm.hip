@@ -70,6 +70,7 @@ struct Gemm2Params {
                       // large magnitudes stay inside fp16's normal range (1, 1 for ordinary LLM weights)
   F4Lut lut;
   int bm3;   // gemm3_kernel: rows of the workgroup tile (256 / 128)
+  int tall3; // gemm3_kernel, bm3 = 256: waves 1 x 4 of 256 x 32 instead of 2 x 2 of 128 x 64
   int diag;  // NS_G3_DIAG (diagnostics): 1 = skip the output stores, 2 = skip the main loop, 3 = DMA and barriers only, 4 = no DMA
 };
 
@@ -297,9 +298,14 @@ constexpr int kG3BStageMax = 8 * 2 * 1024 + 8 * 2 * 16 * 16 + 8 * 2 * 16 * 4;  /
 // BM: rows of the workgroup tile.  256: waves 2 (rows) x 2 (columns), wave tile 128 x 64.  128: waves 1 x 4, wave tile 128 x 32
 // — the same MFMA : dequantisation ratio, half the A stage (three workgroups per CU), twice the tiles: for outputs with
 // few tiles (4096 wide at 2048 rows: 256 of the tall tiles, one per CU) instead of a K split and its reduction pass.
-template <int KIND, int SPS, int SK, bool ASYM, int BM>
+// TALL (BM = 256 only): waves 1 x 4 like BM = 128, but 256 rows each — wave tile 256 x 32: the dequantisation of a B fragment
+// (the VALU work of the loop) is shared by 16 row fragments instead of 8, the same 128 accumulator registers per lane
+template <int KIND, int SPS, int SK, bool ASYM, int BM, bool TALL = false>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
-  constexpr int NIW = BM == 256 ? 4 : 2;        // column tiles (16 wide) per wave
+  static_assert(!TALL || BM == 256, "the tall wave tile is a 256-row workgroup tile");
+  constexpr bool SQ = BM == 256 && !TALL;       // waves 2 x 2
+  constexpr int MI = (SQ ? 128 : BM) / 16;      // row fragments (16 rows) per wave
+  constexpr int NIW = SQ ? 4 : 2;               // column tiles (16 wide) per wave
   constexpr int APW = BM / 32;                   // A DMA pieces (8 rows each) per wave and chunk
   constexpr int kStage = BM * kG3KC * 2;         // bytes of one A stage
   constexpr bool B8 = KIND == WK_INT8;          // 8-bit codes: a record is 64 deep, two per 128-deep superstep
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63, nn = l & 15, g = l >> 4;
-  const int wm = BM == 256 ? (w >> 1) : 0, wn = BM == 256 ? (w & 1) : w;
+  const int wm = SQ ? (w >> 1) : 0, wn = SQ ? (w & 1) : w;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int bn = xcd * p.cpx + local % p.cpx, bm = local / p.cpx;
   if (bn >= p.nbn) return;
@@ -325,9 +331,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const Rsrc ra = make_rsrc(p.a16, uint32_t(p.m) * uint32_t(p.lda16) * 2u);  // rows >= m read as zeros
   const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
-  floatx4 acc[8][NIW];
+  floatx4 acc[MI][NIW];
 #pragma unroll
-  for (int mi = 0; mi < 8; mi++)
+  for (int mi = 0; mi < MI; mi++)
 #pragma unroll
     for (int ni = 0; ni < NIW; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
 
@@ -461,20 +467,20 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
       bf[ni] = v * half8_t{sh, sh, sh, sh, sh, sh, sh, sh};
     }
   };
-  auto load_af = [&](int stage, int jj, half8_t (&af)[8]) {
+  auto load_af = [&](int stage, int jj, half8_t (&af)[MI]) {
     const unsigned char* a_lds = smem + stage * kStage + a_roff[jj];
 #pragma unroll
-    for (int mi = 0; mi < 8; mi++) af[mi] = *reinterpret_cast<const half8_t*>(a_lds + mi * (16 * 128));
+    for (int mi = 0; mi < MI; mi++) af[mi] = *reinterpret_cast<const half8_t*>(a_lds + mi * (16 * 128));
   };
   // one slice: 32 MFMAs; each A fragment is reloaded for the NEXT slice (stage / jj given) as soon as its four MFMAs are
   // issued — in place, so the next slice's fragments cost no registers beyond this slice's
   // `after(mi)`: hook behind the four MFMAs of fragment row mi — the DMA requests of the next chunk are issued there,
   // one per row, instead of in a burst behind the barrier (a request costs ~60 cycles of issue among MFMAs, 100-185 in a
   // phase that already carries fragment reads, MI355X_MICROARCH.md; 8 of them in front of the MFMAs stall every wave)
-  auto mma = [&](half8_t (&af)[8], const half8_t (&bf)[NIW], auto reload, int stage, int jj, auto&& after) {
+  auto mma = [&](half8_t (&af)[MI], const half8_t (&bf)[NIW], auto reload, int stage, int jj, auto&& after) {
     const unsigned char* nxt = smem + stage * kStage + a_roff[jj];
 #pragma unroll
-    for (int mi = 0; mi < 8; mi++) {
+    for (int mi = 0; mi < MI; mi++) {
 #pragma unroll
       for (int ni = 0; ni < NIW; ni++)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   auto interleave = [&](auto vpm, auto ds, auto dma) {
     constexpr int valu_per_mfma = decltype(vpm)::value;
 #pragma unroll
-    for (int i = 0; i < 8 * NIW; i++) {
+    for (int i = 0; i < MI * NIW; i++) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            // 1 MFMA
       if (decltype(ds)::value && (i & (NIW - 1)) == NIW - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
       if (decltype(dma)::value && (i & (NIW - 1)) == 1 && i / NIW < APW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 DMA request
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const int ubeg = cbeg >> 1, uend = (cend + 1) >> 1;
 
   BRec breg;
-  half8_t af[8], bf0[NIW], bf1[NIW];
+  half8_t af[MI], bf0[NIW], bf1[NIW];
   issue_a(cbeg, 0);
   issue_b(ubeg);
   for (int u = ubeg; u < (p.diag == 2 ? ubeg + 1 : uend); u++) {
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   };
   __syncthreads();  // every wave is done with the A stages
 #pragma unroll
-  for (int hh = 0; hh < 2; hh++) {
+  for (int hh = 0; hh < MI / 4; hh++) {
 #pragma unroll
     for (int mi = 0; mi < 4; mi++)
 #pragma unroll
@@ -1107,7 +1113,7 @@ static hipError_t launch_gemm2_k(const Gemm2Params& p, bool asym, dim3 grid, siz
     return go(gemm2_kernel<KIND, SPS, SK, false>);
   }
 }
-template <int KIND, int SPS, int SK, int BM>
+template <int KIND, int SPS, int SK, int BM, bool TALL = false>
 static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hipStream_t st) {
   // A stages + the B stage of this format: records, scale rows, zero-point rows of 8 column tiles for one superstep
   constexpr int rps = KIND == WK_INT8 ? 2 : 1;
@@ -1128,10 +1134,10 @@ static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hip
   };
   if constexpr (KIND == WK_F4) {
     (void)asym;
-    return go(gemm3_kernel<KIND, SPS, SK, false, BM>);
+    return go(gemm3_kernel<KIND, SPS, SK, false, BM, TALL>);
   } else {
-    if (asym) return go(gemm3_kernel<KIND, SPS, SK, true, BM>);
-    return go(gemm3_kernel<KIND, SPS, SK, false, BM>);
+    if (asym) return go(gemm3_kernel<KIND, SPS, SK, true, BM, TALL>);
+    return go(gemm3_kernel<KIND, SPS, SK, false, BM, TALL>);
   }
 }
 #ifdef NS_WITH_GEMM3D
@@ -1179,6 +1185,13 @@ static hipError_t launch_gemm3_s(const Gemm2Params& p, uint32_t scale_dt, bool a
     if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 128>(p, asym, grid, st);
     return launch_gemm3_k<KIND, SPS, SK_BF16, 128>(p, asym, grid, st);
   }
+  if constexpr (KIND == WK_INT4) {
+    if (p.tall3) {
+      if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 256, true>(p, asym, grid, st);
+      if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 256, true>(p, asym, grid, st);
+      return launch_gemm3_k<KIND, SPS, SK_BF16, 256, true>(p, asym, grid, st);
+    }
+  }
   if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 256>(p, asym, grid, st);
   if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 256>(p, asym, grid, st);
   return launch_gemm3_k<KIND, SPS, SK_BF16, 256>(p, asym, grid, st);
@@ -1193,7 +1206,7 @@ static hipError_t launch_gemm2_s(const Gemm2Params& p, uint32_t scale_dt, bool a
 }
 
 static std::atomic<int> g_g3_bm{0};
-void set_gemm3_bm(int bm) { g_g3_bm.store(bm == 128 || bm == 256 ? bm : 0); }
+void set_gemm3_bm(int bm) { g_g3_bm.store(bm == 128 || bm == 256 || bm == 257 || bm == 258 ? bm : 0); }  // 257: 256-row tile, tall wave tiles; 258: the automatic choice without them (A-B runs)
 
 // hipErrorNotSupported = use the first-generation kernel (scratch allocation failed, sizes beyond 32-bit offsets ...)
 hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
@@ -1265,7 +1278,12 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
     static const int bm_env0 = getenv("NS_G3_BM") ? atoi(getenv("NS_G3_BM")) : 0;  // diagnostics
     const int bm_env = g_g3_bm.load() ? g_g3_bm.load() : bm_env0;                  // ns_hip_set_tuning("g3_bm", 128 / 256 / 0)
     const int tall_tiles = p.nbn * ((a.m + 255) / 256);
-    p.bm3 = bm_env == 128 || bm_env == 256 ? bm_env : (tall_tiles >= 1024 && w0->kind != WK_INT8 ? 256 : 128);  // 8-bit codes: the tall tile's LDS
+    // tall wave tiles (256 x 32, TALL; ns_hip_set_tuning("g3_bm", 257)): shape by shape at 2048 rows they gain 2-4 % where a
+    // workgroup runs long (11008 x 4096, 4096 x 11008, 32000 x 4096) and lose 14 % on 4096 x 4096 (profiles/r03v_gemm3_tall.txt);
+    // in a layer's sequence of GEMMs, steady state, choosing them by that rule gained nothing (986 vs 993 TFLOPS,
+    // profiles/r03w_prefill_ab.txt) — not selected automatically
+    p.tall3 = bm_env == 257 && w0->kind == WK_INT4;
+    p.bm3 = p.tall3 ? 256 : bm_env == 128 || bm_env == 256 ? bm_env : (tall_tiles >= 1024 && w0->kind != WK_INT8 ? 256 : 128);  // 8-bit codes: the tall tile's LDS
                                                                                             // footprint (81 KiB) leaves one workgroup per CU
     const int nbm3 = (a.m + p.bm3 - 1) / p.bm3;
     p.ksplit = 1;

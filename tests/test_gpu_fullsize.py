@@ -51,7 +51,7 @@ def _forward_h(L, pkg, wt, dA, m, k, n, shadow=True):
 PREFILL_SHAPES = [(4096, 4096), (11008, 4096), (4096, 11008)]  # (n, k)
 
 
-@pytest.mark.parametrize("bm", [128, 256])
+@pytest.mark.parametrize("bm", [128, 256, 257])  # 257: 256-row tiles with tall (256 x 32) wave tiles, int4 only
 @pytest.mark.parametrize("fmt", ["s8_g32_bf16", "s4_g32_bf16"])
 @pytest.mark.parametrize("n,k", PREFILL_SHAPES)
 def test_config3_prefill_m2048_full_size(L, pkg, nso, n, k, fmt, bm):
