@@ -726,10 +726,10 @@ def roofline(chain, pkg):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         body()
-    for _ in range(5):
+    for _ in range(40):  # steady state, like every other leg: ~15 ms under this load before the timed region
         g.replay()
     torch.cuda.synchronize()
-    reps = 20
+    reps = 100
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
