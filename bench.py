@@ -804,9 +804,15 @@ def prefill_tflops(chain, pkg, m=2048):
     a_d16, a_ff16 = a_d.half(), a_ff.half()
     out_big = torch.empty((m, max(d, ff)), device="cuda", dtype=torch.float32)
     out_big16 = torch.empty((m, max(d, ff)), device="cuda", dtype=torch.float16)
-    gemms = [(a_d, a_d16, lw[k]) for k in ("q", "k", "v", "o", "w1", "w3")] + [(a_ff, a_ff16, lw["w2"])]
+    gemms = [(a_d, a_d16, lw[k]) for k in ("o", "w1", "w3")] + [(a_ff, a_ff16, lw["w2"])]
+    qkv_out = torch.empty((3, m, d), device="cuda", dtype=torch.float32)
+    qkv_out16 = torch.empty((3, m, d), device="cuda", dtype=torch.float16)
 
     def run():
+        # Q, K, V through the fused entry, as the reference's graphs run them (bestla_fusion_QKV_f32f32_forward,
+        # ip_fusion_qkv.cpp:84-86): at this size one launch of the tiled kernel with the three matrices side by side
+        pkg.check(L.ns_hip_fusion_qkv_forward_h(a_d.data_ptr(), a_d16.data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h, qkv_out.data_ptr(),
+                                                qkv_out16.data_ptr(), m, d, chain.dl, st))
         for a, a16, wt in gemms:
             pkg.check(L.ns_hip_f32f32_forward_h(a.data_ptr(), a16.data_ptr(), wt.h, out_big.data_ptr(),
                                                 out_big16.data_ptr(), m, wt.k, wt.n, pkg.EPI_NONE, None, 0, st))
@@ -822,7 +828,7 @@ def prefill_tflops(chain, pkg, m=2048):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    flops = sum(2.0 * m * wt.n * wt.k for _, _, wt in gemms)
+    flops = sum(2.0 * m * wt.n * wt.k for _, _, wt in gemms) + sum(2.0 * m * lw[k].n * lw[k].k for k in ("q", "k", "v"))
     return round(flops / ms / 1e9, 1)
 
 

@@ -921,6 +921,21 @@ int ns_hip_fusion_qkv_forward_x(const float* dA, const void* dA16, const ns_weig
       if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference qkv launch") ? 0 : -1;
     }
   }
+  if (same && m >= 192 && !link) {  // GEMM size: the three matrices side by side in ONE launch of the tiled kernel
+    SmallMArgs a{};
+    a.a = dA;
+    a.a16 = dA16;
+    a.lda = lda;
+    a.m = m;
+    a.ldc = ldc;
+    a.nseg = 3;
+    for (int i = 0; i < 3; i++)
+      a.seg[i] = {ws[i], dC + size_t(i) * m * ldc, dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr};
+    a.epilogue = NS_EPI_NONE;
+    const hipError_t e = launch_gemm2(a, st);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotSupported) return hip_ok(e, "qkv GEMM launch") ? 0 : -1;
+  }
   if (!same || m > 64) {  // fall back to three launches (still on the GPU)
     // int8-reference mode: the three weights share one activation quantization when K and the group size agree
     auto same_aq = [&](int i) {

@@ -69,6 +69,17 @@ struct Gemm2Params {
                       // to fp16 and the accumulators by spost on the way out, so that weights with very small or very
                       // large magnitudes stay inside fp16's normal range (1, 1 for ordinary LLM weights)
   F4Lut lut;
+  // gemm3_kernel, fused QKV (ip_fusion_qkv.cpp:84-86 at GEMM size): up to three matrices of one K and one format side by
+  // side along the column blocks; nseg <= 1: the single matrix above
+  int nseg;
+  int seg_bn0[3];   // first column block of matrix s
+  int seg_n[3];
+  const void* seg_codes[3];
+  const void* seg_scales[3];
+  const int8_t* seg_zps[3];
+  uint32_t seg_codes_bytes[3], seg_scales_bytes[3], seg_zps_bytes[3];
+  float* seg_c[3];
+  _Float16* seg_c16[3];
   int bm3;   // gemm3_kernel: rows of the workgroup tile (256 / 128)
   int tall3; // gemm3_kernel, bm3 = 256: waves 1 x 4 of 256 x 32 instead of 2 x 2 of 128 x 64
   int diag;  // NS_G3_DIAG (diagnostics): 1 = skip the output stores, 2 = skip the main loop, 3 = DMA and barriers only, 4 = no DMA
@@ -323,11 +334,18 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int bn = xcd * p.cpx + local % p.cpx, bm = local / p.cpx;
   if (bn >= p.nbn) return;
-  const int tile0 = bn * kG3Tiles + wn * NIW, row0 = bm * BM;
+  // fused QKV: the column block belongs to one of up to three matrices (indexed scalar loads of its pointers)
+  int sg = 0;
+  if (p.nseg > 1) sg = int(bn >= p.seg_bn0[1]) + int(p.nseg > 2 && bn >= p.seg_bn0[2]);
+  const int bnl = p.nseg > 1 ? bn - p.seg_bn0[sg] : bn;  // column block inside its matrix
+  const int n_cols = p.nseg > 1 ? p.seg_n[sg] : p.n;
+  float* const c_out = p.nseg > 1 ? p.seg_c[sg] : p.c;
+  _Float16* const c16_out = p.nseg > 1 ? p.seg_c16[sg] : p.c16;
+  const int tile0 = bnl * kG3Tiles + wn * NIW, row0 = bm * BM;
 
-  const Rsrc rq = make_rsrc(p.codes, p.codes_bytes);
-  const Rsrc rs = make_rsrc(p.scales, p.scales_bytes);
-  const Rsrc rz = make_rsrc(p.zps, p.zps_bytes);
+  const Rsrc rq = p.nseg > 1 ? make_rsrc(p.seg_codes[sg], p.seg_codes_bytes[sg]) : make_rsrc(p.codes, p.codes_bytes);
+  const Rsrc rs = p.nseg > 1 ? make_rsrc(p.seg_scales[sg], p.seg_scales_bytes[sg]) : make_rsrc(p.scales, p.scales_bytes);
+  const Rsrc rz = p.nseg > 1 ? make_rsrc(p.seg_zps[sg], p.seg_zps_bytes[sg]) : make_rsrc(p.zps, p.zps_bytes);
   const Rsrc ra = make_rsrc(p.a16, uint32_t(p.m) * uint32_t(p.lda16) * 2u);  // rows >= m read as zeros
   const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   constexpr uint32_t kBScal = kG3Tiles * RPS * 16u * SBYTES;   // [record][tile][16 columns x SBYTES]
   constexpr uint32_t kBZp = ASYM ? kG3Tiles * RPS * 16u * SPS : 0u;
   unsigned char* const b_lds = smem + kG3Stages * kStage;
-  const uint32_t btile0 = uint32_t(bn * kG3Tiles + 2 * w);
+  const uint32_t btile0 = uint32_t(bnl * kG3Tiles + 2 * w);
   // scale rows: 16 * SBYTES bytes per (tile, row) = SBYTES lanes of 16 B; lanes [0, 2 * SBYTES) cover the wave's two tiles
   const uint32_t s_lane_tile = uint32_t(l) / uint32_t(SBYTES), s_lane_piece = uint32_t(l) % uint32_t(SBYTES);
   const uint32_t s_voff = (btile0 + s_lane_tile) * uint32_t(p.srows) * p.sstride + s_lane_piece * 16u;
@@ -567,10 +585,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   constexpr int kLpr = kCols / 4;     // lanes per row in the float4 read-back
   float* park = reinterpret_cast<float*>(smem) + w * (64 * kRowF);
   const int colw = tile0 * 16;  // first column of this wave's 64
-  const bool vec4 = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.c) & 15) == 0 && colw + kCols <= p.n &&
+  const bool vec4 = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(c_out) & 15) == 0 && colw + kCols <= n_cols &&
                     (p.ksplit > 1 ? (p.n & 3) == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 : true) &&
                     (!p.d || ((p.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(p.d) & 15) == 0)) &&
-                    (!p.c16 || (reinterpret_cast<uintptr_t>(p.c16) & 7) == 0);
+                    (!c16_out || (reinterpret_cast<uintptr_t>(c16_out) & 7) == 0);
   const int epi = p.epilogue;
   auto finish = [&](float v, float dv) {
     switch (epi) {
@@ -606,10 +624,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
         float4 dv = {0.f, 0.f, 0.f, 0.f};
         if (p.d && epi >= 1 && epi <= 3) dv = *reinterpret_cast<const float4*>(p.d + size_t(row) * p.ldd + col);
         v = float4{finish(v.x, dv.x), finish(v.y, dv.y), finish(v.z, dv.z), finish(v.w, dv.w)};
-        *reinterpret_cast<float4*>(p.c + size_t(row) * p.ldc + col) = v;
-        if (p.c16) {
+        *reinterpret_cast<float4*>(c_out + size_t(row) * p.ldc + col) = v;
+        if (c16_out) {
           typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-          *reinterpret_cast<half4_t*>(p.c16 + size_t(row) * p.ldc + col) =
+          *reinterpret_cast<half4_t*>(c16_out + size_t(row) * p.ldc + col) =
               half4_t{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         }
       }
@@ -617,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
       for (int it = 0; it < 64 * kCols / 64; it++) {  // 64 elements per step, row-major over the 64 x kCols half tile
         const int e = it * 64 + l, rl = e / kCols, cl = e % kCols;
         const int row = rbase + rl, col = colw + cl;
-        if (row >= p.m || col >= p.n) continue;
+        if (row >= p.m || col >= n_cols) continue;
         float v = park[rl * kRowF + cl];
         if (p.ksplit > 1) {
           p.part[(size_t(blockIdx.y) * p.m + row) * p.n + col] = v;
@@ -625,8 +643,8 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
         }
         const float dv = (p.d && epi >= 1 && epi <= 3) ? p.d[size_t(row) * p.ldd + col] : 0.f;
         v = finish(v, dv);
-        p.c[size_t(row) * p.ldc + col] = v;
-        if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
+        c_out[size_t(row) * p.ldc + col] = v;
+        if (c16_out) c16_out[size_t(row) * p.ldc + col] = (_Float16)v;
       }
     }
   }
@@ -1265,6 +1283,28 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   static const int g3_diag = getenv("NS_G3_DIAG") ? atoi(getenv("NS_G3_DIAG")) : 0;
   p.diag = g3_diag;
   p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
+  if (a.nseg > 1) {  // fused QKV at GEMM size: gemm3_kernel only (192 rows and up), whole column blocks per matrix
+    static const bool g3_off_env = getenv("NS_GEMM3") && atoi(getenv("NS_GEMM3")) != 1;
+    if (a.nseg > 3 || a.dual || a.m < 192 || (p.lda16 & 7) != 0 || g3_off_env) return hipErrorNotSupported;
+    p.nseg = a.nseg;
+    int bn0 = 0;
+    for (int i = 0; i < a.nseg; i++) {
+      const ns_weight* w = a.seg[i].w;
+      if (w->k != w0->k || w->kind != w0->kind || w->sps != w0->sps || w->scale_dt != w0->scale_dt || w->asym != w0->asym ||
+          w->ksteps != w0->ksteps || w->qstride != w0->qstride || w->sstride != w0->sstride || w->zstride != w0->zstride ||
+          w->srows != w0->srows || w->g2_pre != w0->g2_pre || w->g2_post != w0->g2_post || w->qtype != w0->qtype)
+        return hipErrorNotSupported;
+      p.seg_bn0[i] = bn0;
+      p.seg_n[i] = w->n;
+      p.seg_codes[i] = w->codes, p.seg_scales[i] = w->scales, p.seg_zps[i] = w->zps;
+      p.seg_codes_bytes[i] = uint32_t(w->codes_bytes), p.seg_scales_bytes[i] = uint32_t(w->scales_bytes);
+      p.seg_zps_bytes[i] = uint32_t(w->zps_bytes);
+      p.seg_c[i] = a.seg[i].c;
+      p.seg_c16[i] = static_cast<_Float16*>(a.seg[i].c16);
+      bn0 += (w->ntiles + kG2Tiles - 1) / kG2Tiles;
+    }
+    p.nbn = bn0;
+  }
   p.cpx = (p.nbn + 7) / 8;
   // third-generation kernel (256-row tiles, A by LDS DMA, B dequantised in registers): from 192 rows up; below that
   // its row tile would be mostly padding.  NS_GEMM3=0 keeps the second generation (diagnostics / A-B runs).
@@ -1294,7 +1334,7 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
       int ks = 1;
       // gemm3_kernel wants two workgroups per CU, the deep kernel one
       while (ks < 8 && tiles * ks * 2 <= (deep ? 256 : 512) && p.nchunks / (ks * 2) >= 8) ks *= 2;
-      if (ks > 1 && !no_splitk) {
+      if (ks > 1 && !no_splitk && p.nseg <= 1) {
         const size_t bytes = size_t(ks) * a.m * w0->n * 4;
         float* part = static_cast<float*>(stream_scratch(st, bytes, 2));
         if (part) {

@@ -237,3 +237,47 @@ def test_int8_reference_numerics_decode_full_size(L, pkg, nso, n, k, m):
     finally:
         L.ns_hip_set_compute_mode(prev)
     wt.free()
+
+
+@pytest.mark.parametrize("bm", [128, 256])
+@pytest.mark.parametrize("ns,k,m", [((4096, 4096, 4096), 4096, 2048), ((4096, 1024, 1024), 4096, 2048), ((1000, 200, 136), 1024, 300)],
+                         ids=["mha-4096", "gqa-4096-1024", "ragged-n"])
+def test_fused_qkv_at_gemm_size_is_one_launch_of_the_tiled_kernel(L, pkg, nso, ns, k, m, bm):
+    """bestla_fusion_QKV_f32f32_forward's GEMM-sized form (ip_fusion_qkv.cpp:84-86): the three weights side by side along the
+    column blocks of ONE gemm3_kernel launch — equal, GQA-sized and ragged widths (matrices that end inside a column block);
+    every output of sampled rows against the oracle's fp64 GEMM per weight, and the three separate launches to fp32 rounding"""
+    import torch
+    blobs, wts = [], []
+    for i, n in enumerate(ns):
+        b, w = _device_blob(L, pkg, nso, n, k, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, False, seed=n * 3 + k + i)
+        blobs.append(b), wts.append(w)
+    g = torch.Generator(device="cuda").manual_seed(13)
+    dA = torch.randn((m, k), generator=g, device="cuda")
+    dA16 = dA.half()
+    ldc = max(ns)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fused = torch.full((3, m, ldc), 7.0, dtype=torch.float32, device="cuda")
+    fused16 = torch.zeros((3, m, ldc), dtype=torch.float16, device="cuda")
+    assert L.ns_hip_set_tuning(b"g3_bm", bm) == 0
+    try:
+        pkg.check(L.ns_hip_fusion_qkv_forward_h(dA.data_ptr(), dA16.data_ptr(), wts[0].h, wts[1].h, wts[2].h, fused.data_ptr(),
+                                                fused16.data_ptr(), m, k, ldc, st))
+        sep = torch.full((3, m, ldc), 7.0, dtype=torch.float32, device="cuda")
+        for i, n in enumerate(ns):
+            pkg.check(L.ns_hip_f32f32_forward_h(dA.data_ptr(), dA16.data_ptr(), wts[i].h, sep[i].data_ptr(), None, m, k, ldc, 0, None, 0, st))
+        torch.cuda.synchronize()
+    finally:
+        L.ns_hip_set_tuning(b"g3_bm", 0)
+    rng = np.random.default_rng(k + m + bm)
+    rows = np.unique(np.concatenate([[0, m - 1, min(255, m - 1), min(256, m - 1)], rng.integers(0, m, 10)]))
+    a = dA[torch.from_numpy(rows).cuda()].cpu().numpy()
+    f, s16, sp = fused.cpu().numpy(), fused16.cpu().numpy(), sep.cpu().numpy()
+    for i, n in enumerate(ns):
+        ref = nso.gemm_f64(a, blobs[i])
+        assert nso.rel_l2(f[i][rows][:, :n], ref) < TOL, (i, n)
+        # the separate launches K-split a matrix with few tiles (another fp32 summation order), the fused launch never does
+        assert nso.rel_l2(f[i][:, :n], sp[i][:, :n]) < 1e-6, (i, n)
+        assert np.array_equal(s16[i][:, :n], f[i][:, :n].astype(np.float16)), (i, n)
+        assert (f[i][:, n:] == 7.0).all(), (i, n)  # nothing written beyond a matrix's own columns
+    for w in wts:
+        w.free()
