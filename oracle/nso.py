@@ -72,6 +72,26 @@ def build(force=False):
                 subprocess.check_call(["make", "-C", HERE, "nepy"], stdout=subprocess.DEVNULL)
             except subprocess.CalledProcessError:
                 pass
+    if os.path.exists("/root/reference/neural_speed/models/llama/llama.cpp"):
+        # the same model code with the reference's device switch (-DNS_SYCL) on the product's bestla_device_* set
+        dref = os.path.join(HERE, "_ref", "libne_llama_dev_ref.so")
+        root = os.path.dirname(HERE)
+        srcs = [os.path.join(HERE, "llama_ref_harness.cpp"), os.path.join(HERE, "ne_ref_stubs.c"),
+                os.path.join(root, "glue", "ne_bestla_hip_glue.c"), os.path.join(root, "glue", "ne_bestla_hip_device.c"),
+                os.path.join(root, "glue", "bestla_gemm_hip.cpp")]
+        if force or not os.path.exists(dref) or os.path.getmtime(dref) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", HERE, "nellamadev"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/neural_speed/core/layers/mha_dense_wrapper.h"):
+        # the reference's own bestla_fusion_attn_forward_ref, cut out of its header at build time
+        aref = os.path.join(HERE, "_ref", "libattn_ref.so")
+        if force or not os.path.exists(aref) or os.path.getmtime(aref) < os.path.getmtime(os.path.join(HERE, "attn_shim.cpp")):
+            subprocess.check_call(["make", "-C", HERE, "attnref"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/neural_speed/core/parallel_context.h"):
+        # glue/parallel_context_hip.cpp against the reference header, for the multi-rank GPU test
+        gref = os.path.join(HERE, "_ref", "libpc_glue.so")
+        src = os.path.join(os.path.dirname(HERE), "glue", "parallel_context_hip.cpp")
+        if force or not os.path.exists(gref) or os.path.getmtime(gref) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", HERE, "pcglue"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/bestla/bestla/bestla_storage.h"):
         sref = os.path.join(HERE, "_ref", "libstor_ref.so")
         if force or not os.path.exists(sref) or os.path.getmtime(sref) < os.path.getmtime(os.path.join(HERE, "stor_shim.cpp")):
