@@ -689,8 +689,10 @@ def pmc_traffic(chain):
     (scripts/pmc_traffic.sh; the driver runs bench.py bare), so the measured per-launch figure is read back from the
     committed summary — only when that summary was taken on the SAME kernel and grid this run launches (the file records
     both; a kernel or launch-geometry change makes the figure null until the counters are collected again)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_fetch_size.json")
-    if chain.world != 1 or not os.path.exists(path):
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((p for p in (os.path.join(prof, "r03_pmc_fetch_size.json"), os.path.join(prof, "r02_pmc_fetch_size.json"))
+                 if os.path.exists(p)), None)
+    if chain.world != 1 or path is None:
         return None
     try:
         d = json.load(open(path))
@@ -749,7 +751,7 @@ def roofline(chain, pkg):
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": pmc_traffic(chain),
         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (own pass, scripts/pmc_traffic.sh), x2 gfx950 correction, "
-                          "bytes per gate/up launch at tp=1: profiles/r02_pmc_fetch_size.json",
+                          "bytes per gate/up launch at tp=1: profiles/r03_pmc_fetch_size.json",
         "bytes_per_launch": bytes_per_launch,
         "avg_launch_us": round(us, 3),
         "note": "avg over %d back-to-back graph launches incl. ~1.2us inter-kernel boundary each" % (reps * nl),
