@@ -554,10 +554,13 @@ void ns_hip_reset_error(void) {
 }
 
 void ns_hip_cache_clear(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  for (auto& kv : g_cache) ns_hip_weight_free(kv.second.w);
-  g_cache.clear();
-  g_cache_bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_cache) ns_hip_weight_free(kv.second.w);
+    g_cache.clear();
+    g_cache_bytes = 0;
+  }
+  kv_mirrors_clear();  // ns_attn.hip: device mirrors of library-managed kv caches
 }
 
 int ns_hip_device_count(void) {

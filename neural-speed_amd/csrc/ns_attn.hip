@@ -20,6 +20,7 @@
 //   per XCD on MI355X).  HBM-bound on K and V: 2 * sl_kv * heads_kv * head_size * 2 B per query row.
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <mutex>
 
 #include <algorithm>
@@ -840,8 +841,64 @@ void bestla_reordered_attn_fp32_batch_kv_info(const kv_shape_t* params, kv_cache
   out->v_bytes = size_t(out->stride_v_head_num) * params->heads_kv;
 }
 
+// ---- device mirrors of the library-managed kv caches -----------------------------------------------------------------------
+// The graph keeps a library-managed cache (NE_TYPE_BTLA tensors, llama.cpp:544-560) in HOST memory and hands its address to every
+// entry below; nothing but these entries ever reads or writes its bytes (the layout is this library's own).  Uploading the
+// visible K / V rows for every attention call (32 MB per layer and token at 2048 positions) made the default, host-pointer
+// route PCIe-bound.  So every cache the update entries see gets a DEVICE MIRROR, keyed by its host address range: updates,
+// shifts and beam copies are applied to both copies (the host copy stays authoritative and complete), the attention entry
+// reads the mirror.  A range that is not (wholly) mirrored falls back to the upload path; a new range that overlaps an old
+// one replaces it (the tensor was re-created); ns_hip_cache_clear() and NS_KV_MIRROR=0 drop / disable the mirrors — needed
+// only by a caller that writes cache bytes behind the library's back (restoring a saved session with memcpy).
+static std::mutex& g_attn_host_mu_ref();
+struct KvMirror {
+  char* dev = nullptr;
+  size_t bytes = 0;
+};
+static std::map<const char*, KvMirror> g_kv_mirrors;  // host base -> mirror; guarded by g_attn_host_mu
+static bool kv_mirror_enabled() {
+  static const bool on = !(getenv("NS_KV_MIRROR") && atoi(getenv("NS_KV_MIRROR")) == 0);
+  return on;
+}
+// device address of host range [p, p + bytes) when a mirror covers it, else nullptr
+static char* kv_mirror_find(const char* p, size_t bytes) {
+  auto it = g_kv_mirrors.upper_bound(p);
+  if (it == g_kv_mirrors.begin()) return nullptr;
+  --it;
+  if (p >= it->first && p + bytes <= it->first + it->second.bytes) return it->second.dev + (p - it->first);
+  return nullptr;
+}
+// mirror of exactly [p, p + bytes): the covering one, or a new one filled from the host copy (overlapping older ones go)
+static char* kv_mirror_get(const char* p, size_t bytes) {
+  if (!kv_mirror_enabled() || bytes == 0) return nullptr;
+  if (char* d = kv_mirror_find(p, bytes)) return d;
+  for (auto it = g_kv_mirrors.begin(); it != g_kv_mirrors.end();) {
+    if (it->first < p + bytes && p < it->first + it->second.bytes) {
+      (void)hipFree(it->second.dev);
+      it = g_kv_mirrors.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  KvMirror m;
+  if (hipMalloc(reinterpret_cast<void**>(&m.dev), bytes) != hipSuccess || hipMemcpy(m.dev, p, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    if (m.dev) (void)hipFree(m.dev);
+    return nullptr;  // no mirror: the upload path serves this cache
+  }
+  m.bytes = bytes;
+  g_kv_mirrors[p] = m;
+  return m.dev;
+}
+static void kv_mirrors_clear_impl() {
+  std::lock_guard<std::mutex> lock(g_attn_host_mu_ref());
+  for (auto& kv : g_kv_mirrors) (void)hipFree(kv.second.dev);
+  g_kv_mirrors.clear();
+}
+
 // the host-tensor entries stage through slots of the null stream's scratch; one call at a time
 static std::mutex g_attn_host_mu;
+static std::mutex& g_attn_host_mu_ref() { return g_attn_host_mu; }
 constexpr int kScratchHostA = 10, kScratchHostB = 11, kScratchHostC = 12, kScratchHostD = 13;
 static bool kv_device() {
   int count = 0;
@@ -879,6 +936,15 @@ static void kv_update(const bestla_fusion_attn_fp32_update_kv_args_t* pp, const 
     ok = hipGetLastError() == hipSuccess &&
          hipMemcpy2D(a.cache + size_t(a.seq_off) * row, size_t(a.seq_max) * row, dout, size_t(a.seq_size) * row,
                      size_t(a.seq_size) * row, size_t(a.batch_size) * a.heads_kv, hipMemcpyDeviceToHost) == hipSuccess;
+    // the device mirror of this cache (created from the host copy — which the line above just completed — on first sight)
+    if (ok) {
+      const size_t slab = size_t(a.batch_size) * a.heads_kv * a.seq_max * row;
+      const bool fresh = kv_mirror_find(a.cache, slab) == nullptr;
+      char* mir = kv_mirror_get(a.cache, slab);
+      if (mir && !fresh)
+        ok = hipMemcpy2D(mir + size_t(a.seq_off) * row, size_t(a.seq_max) * row, dout, size_t(a.seq_size) * row, size_t(a.seq_size) * row,
+                         size_t(a.batch_size) * a.heads_kv, hipMemcpyDeviceToDevice) == hipSuccess;
+    }
   }
   if (!ok) {
     (void)hipGetLastError();
@@ -915,6 +981,10 @@ void bestla_reordered_attn_fp32_shift_rope_k(char* cache, const uint16_t* cossin
     ok = hipGetLastError() == hipSuccess &&
          hipMemcpy2D(cache + size_t(seq_keep) * row, size_t(seq_max) * row, drows, n * row, n * row, slabs, hipMemcpyDeviceToHost) ==
              hipSuccess;
+    if (ok)
+      if (char* mir = kv_mirror_find(cache, slabs * size_t(seq_max) * row))
+        ok = hipMemcpy2D(mir + size_t(seq_keep) * row, size_t(seq_max) * row, drows, n * row, n * row, slabs, hipMemcpyDeviceToDevice) ==
+             hipSuccess;
   }
   if (!ok) {
     (void)hipGetLastError();
@@ -931,6 +1001,21 @@ static void kv_batch_cpy(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* pp) 
   const size_t row = size_t(a.head_size) * 2;
   for (int h = 0; h < a.heads_kv; h++)
     memcpy(a.dst + (size_t(h) * a.seq_max + a.seq_off) * row, a.src + (size_t(h) * a.seq_max + a.seq_off) * row, size_t(a.seq_size) * row);
+  // the destination's device mirror takes the same rows (from the host copy just written: a beam copy is a few rows)
+  std::lock_guard<std::mutex> host_lock(g_attn_host_mu);
+  const size_t slab = size_t(a.heads_kv) * a.seq_max * row;
+  if (char* mir = kv_mirror_find(a.dst, slab)) {
+    if (hipMemcpy2D(mir + size_t(a.seq_off) * row, size_t(a.seq_max) * row, a.dst + size_t(a.seq_off) * row, size_t(a.seq_max) * row,
+                    size_t(a.seq_size) * row, size_t(a.heads_kv), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      for (auto it = g_kv_mirrors.begin(); it != g_kv_mirrors.end(); ++it)  // cannot keep it current: drop it, the upload path takes over
+        if (a.dst >= it->first && a.dst < it->first + it->second.bytes) {
+          (void)hipFree(it->second.dev);
+          g_kv_mirrors.erase(it);
+          break;
+        }
+    }
+  }
 }
 void bestla_fusion_attn_fp32_batch_cpy_k(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* params) { kv_batch_cpy(params); }
 void bestla_fusion_attn_fp32_batch_cpy_v(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* params) { kv_batch_cpy(params); }
@@ -994,13 +1079,16 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
   // staging in the grow-only per-stream scratch (four hipMalloc / hipFree pairs per call synchronised the device eight times)
   std::lock_guard<std::mutex> host_lock(g_attn_host_mu);
   void* dq = stream_scratch(nullptr, nq * 4, kScratchHostA);
-  void* dk = stream_scratch(nullptr, nk * 2, kScratchHostB);
-  void* dv = stream_scratch(nullptr, nv * 2, kScratchHostC);
+  // K / V of a library-managed cache are already on the device (kv mirrors above): nothing to upload
+  void* mk = kv_mirror_find(reinterpret_cast<const char*>(hp->K), nk * 2);
+  void* mv = kv_mirror_find(reinterpret_cast<const char*>(hp->V), nv * 2);
+  void* dk = mk ? mk : stream_scratch(nullptr, nk * 2, kScratchHostB);
+  void* dv = mv ? mv : stream_scratch(nullptr, nv * 2, kScratchHostC);
   void* dd = stream_scratch(nullptr, nd * 4, kScratchHostD);
   bool ok = dq && dk && dv && dd;
   ok = ok && hipMemcpy(dq, hp->Q, nq * 4, hipMemcpyHostToDevice) == hipSuccess &&
-       hipMemcpy(dk, hp->K, nk * 2, hipMemcpyHostToDevice) == hipSuccess &&
-       hipMemcpy(dv, hp->V, nv * 2, hipMemcpyHostToDevice) == hipSuccess &&
+       (mk || hipMemcpy(dk, hp->K, nk * 2, hipMemcpyHostToDevice) == hipSuccess) &&
+       (mv || hipMemcpy(dv, hp->V, nv * 2, hipMemcpyHostToDevice) == hipSuccess) &&
        hipMemcpy(dd, hp->dst, nd * 4, hipMemcpyHostToDevice) == hipSuccess;  // keeps bytes between strided rows
   if (ok) {
     a.Q = static_cast<float*>(dq);
@@ -1017,3 +1105,7 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
 }
 
 }  // extern "C"
+
+namespace ns {
+void kv_mirrors_clear() { kv_mirrors_clear_impl(); }
+}  // namespace ns

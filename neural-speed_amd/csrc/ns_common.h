@@ -171,6 +171,7 @@ hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, in
 hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st);
 void set_gemv_mode(int mode);  // 0 off (first-generation kernel), 1 on, -1 re-read NS_GEMV2
 void set_attn_tuning(int wg_target, int min_keys);
+void kv_mirrors_clear();  // ns_attn.hip: drops the device mirrors of library-managed kv caches (ns_hip_cache_clear)
 void set_gemm3_bm(int bm);  // ns_gemm.hip: force gemm3_kernel's row-tile height (tests / A-B runs); 0 = automatic  // ns_attn.hip: context-split rule of the decode attention kernel
 void set_decode_waves(int nw);  // 0 = by shape
 int decode_waves(int grid, int ks, bool dual);  // waves per workgroup of a decode launch (both kernel generations)

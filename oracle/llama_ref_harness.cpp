@@ -59,9 +59,15 @@ int nellama_quantize(const char* in_path, const char* out_path, const char* weig
  * bestla_reordered_attn_fp32_support says yes), 1 fp16, 2 fp32 (KV_MEM_TYPE, model_types.h:96-100).  out_tokens[n_new]; out_logits
  * [(n_new) x n_vocab] = the logits each token was picked from (may be NULL).  Returns the number of tokens generated, < 0
  * on failure. */
+static double g_last_us_per_token = 0.0;
+/* wall time per single-token eval of the last nellama_generate call (evals after the second one) */
+double nellama_last_us_per_token(void) { return g_last_us_per_token; }
+
 int nellama_generate(const char* model_path, const int* prompt, int n_prompt, int n_new, int n_ctx, int kv_type,
                      int* out_tokens, float* out_logits) {
   model_init_backend();
+  double us_sum = 0;
+  int us_n = 0;
   model_context_params p = model_context_default_params();
   p.arch = NS_FAMILY_ARCH;
   p.n_ctx = n_ctx;
@@ -90,10 +96,12 @@ int nellama_generate(const char* model_path, const int* prompt, int n_prompt, in
     in.request_idx = 0;
     in.beam_idx = 0;
     fprintf(stderr, "nellama_generate: step %d, %zu token(s) at n_past %d\n", step, cur.size(), n_past);
+    const int64_t t0 = ne_time_us();
     if (model_eval(ctx, &in, 1, 1) != 0) {
       model_free(ctx);
       return -2;
     }
+    if (cur.size() == 1 && step > 1) us_sum += double(ne_time_us() - t0), us_n++;
     n_past += static_cast<int>(cur.size());
     n_total += static_cast<int>(cur.size());
     const float* logits = model_get_logits(ctx);
@@ -104,6 +112,7 @@ int nellama_generate(const char* model_path, const int* prompt, int n_prompt, in
     out_tokens[made++] = best;
     cur.assign(1, best);
   }
+  g_last_us_per_token = us_n ? us_sum / us_n : 0.0;
   model_free(ctx);
   return made;
 }

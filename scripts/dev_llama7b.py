@@ -68,6 +68,9 @@ def main(mode="device", n_new="24", n_ctx="512"):
     import torch  # noqa: F401
     C.CDLL(os.path.join(ROOT, "neural-speed_amd", "libns_hip.so"), mode=C.RTLD_GLOBAL)
     prompt = [1, 17, 200, 3, 99, 42, 311, 2048]
+    n_prompt = int(os.environ.get("NS_DEV7B_PROMPT", "8"))  # longer prompts: the decode steps attend over that many cached positions
+    if n_prompt > len(prompt):
+        prompt = prompt + [int(t) for t in np.random.default_rng(1).integers(3, V, n_prompt - len(prompt))]
     toks = (C.c_int * n_new)()
     pr = (C.c_int * len(prompt))(*prompt)
     t0 = time.time()
@@ -83,9 +86,13 @@ def main(mode="device", n_new="24", n_ctx="512"):
         ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libne_llama_ref.so"))
         ref.nellama_generate.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         t1 = time.time()
-        n = ref.nellama_generate(path.encode(), pr, len(prompt), n_new, n_ctx, 2, toks, None)
+        kv = int(os.environ.get("NS_DEV7B_KV", "0"))  # 0: the library-managed cache (bestla_reordered_attn_*), 1 fp16, 2 fp32 tensors
+        n = ref.nellama_generate(path.encode(), pr, len(prompt), n_new, n_ctx, kv, toks, None)
         assert n == n_new, n
-        print('{"route": "host-pointer entries (PCIe per call)", "wall_s_incl_load": %.1f, "tokens": %s}' % (time.time() - t1, list(toks)[:8]))
+        ref.nellama_last_us_per_token.restype = C.c_double
+        us = ref.nellama_last_us_per_token()
+        print('{"route": "host-pointer entries (activations cross PCIe per call)", "kv_type": %d, "n_prompt": %d, "us_per_token": %.1f, '
+              '"tokens_per_s": %.1f, "wall_s_incl_load": %.1f, "tokens": %s}' % (kv, len(prompt), us, 1e6 / us if us else 0.0, time.time() - t1, list(toks)[:8]))
 
 
 if __name__ == "__main__":

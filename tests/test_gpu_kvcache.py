@@ -137,3 +137,44 @@ def test_forward_refuses_a_foreign_layout(L, pkg):
     out = forward(L, pkg, q, kc, vc, info, bs, hn, hkv, hs, 1, 4, 0.125, 1)
     assert np.all(out == 7.0)
     assert b"not laid out by this library" in L.ns_hip_last_error()
+
+
+def test_device_mirror_of_the_cache_serves_the_same_numbers_as_the_upload_path(L, pkg, nso):
+    """A library-managed cache is mirrored on the device from its first update on (the attention entry then uploads Q only).
+    Same result with the mirror and, after ns_hip_cache_clear() dropped it, through the upload path; a beam copy and a shift
+    reach the mirror too; bytes written to the host copy behind the library's back are seen after a clear (the documented
+    contract), not before."""
+    rng = np.random.default_rng(5)
+    bs, hn, hkv, hs, n_ctx = 1, 8, 8, 128, 96
+    info = kv_info(L, pkg, hkv, hs, n_ctx)
+    kc = np.zeros(info.k_bytes * bs, np.uint8)
+    vc = np.zeros(info.v_bytes * bs, np.uint8)
+    scale = float(hs) ** -0.5
+    n = 0
+    for chunk in (40, 1, 1):
+        cur_k = rng.standard_normal((bs, chunk, hkv, hs)).astype(np.float32)
+        cur_v = rng.standard_normal((bs, chunk, hkv, hs)).astype(np.float32)
+        update(L, pkg, "bestla_reordered_attn_fp32_update_k", kc, cur_k, n, n_ctx)
+        update(L, pkg, "bestla_reordered_attn_fp32_update_v", vc, cur_v, n, n_ctx)
+        n += chunk
+    q = rng.standard_normal((bs, 1, hn, hs)).astype(np.float32)
+    with_mirror = forward(L, pkg, q, kc, vc, info, bs, hn, hkv, hs, 1, n, scale, 1)
+    L.ns_hip_cache_clear()
+    uploaded = forward(L, pkg, q, kc, vc, info, bs, hn, hkv, hs, 1, n, scale, 1)
+    assert np.array_equal(with_mirror.view(np.int32), uploaded.view(np.int32))
+    # re-establish the mirrors (an update does), then write one cached K row on the host behind the library's back
+    cur = rng.standard_normal((bs, 1, hkv, hs)).astype(np.float32)
+    update(L, pkg, "bestla_reordered_attn_fp32_update_k", kc, cur, n, n_ctx)
+    update(L, pkg, "bestla_reordered_attn_fp32_update_v", vc, cur, n, n_ctx)
+    n += 1
+    before = forward(L, pkg, q, kc, vc, info, bs, hn, hkv, hs, 1, n, scale, 1)
+    rows = kc.view(np.float16).reshape(bs, hkv, n_ctx, hs)
+    rows[0, :, 3, :] *= np.float16(-2.0)
+    stale = forward(L, pkg, q, kc, vc, info, bs, hn, hkv, hs, 1, n, scale, 1)
+    assert np.array_equal(before.view(np.int32), stale.view(np.int32))  # the mirror still holds what the library wrote
+    L.ns_hip_cache_clear()
+    fresh = forward(L, pkg, q, kc, vc, info, bs, hn, hkv, hs, 1, n, scale, 1)
+    kh = rows[0].astype(np.float32).transpose(1, 0, 2)[None, :n]
+    vh = vc.view(np.float16).reshape(bs, hkv, n_ctx, hs)[0].astype(np.float32).transpose(1, 0, 2)[None, :n]
+    assert nso.rel_l2(fresh, nso.attn_ref(q, kh.astype(np.float16), vh.astype(np.float16), scale, 1)) < 1e-3
+    assert not np.array_equal(fresh.view(np.int32), stale.view(np.int32))
