@@ -14,11 +14,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -552,6 +555,42 @@ void ns_hip_reset_error(void) {
   }
   set_error("");
 }
+
+}  // extern "C"  (reopened below)
+namespace ns {
+namespace {
+struct HostProf {
+  std::mutex mu;
+  std::map<std::string, std::pair<long long, long long>> acc;  // name -> (calls, ns)
+  ~HostProf() {
+    if (acc.empty()) return;
+    long long total = 0;
+    for (auto& kv : acc) total += kv.second.second;
+    fprintf(stderr, "NS_HOST_PROFILE: host-tensor entries, %.3f ms in total\n", total * 1e-6);
+    for (auto& kv : acc)
+      fprintf(stderr, "  %-46s calls %7lld  total %10.3f ms  avg %8.1f us\n", kv.first.c_str(), kv.second.first, kv.second.second * 1e-6,
+              kv.second.first ? kv.second.second * 1e-3 / kv.second.first : 0.0);
+  }
+};
+HostProf g_host_prof;
+bool host_prof_on() {
+  static const bool on = getenv("NS_HOST_PROFILE") != nullptr;
+  return on;
+}
+long long now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+HostScope::HostScope(const char* n) : name(n), t0(host_prof_on() ? now_ns() : 0) {}
+HostScope::~HostScope() {
+  if (!t0) return;
+  const long long dt = now_ns() - t0;
+  std::lock_guard<std::mutex> lk(g_host_prof.mu);
+  auto& e = g_host_prof.acc[name];
+  e.first++, e.second += dt;
+}
+}  // namespace ns
+extern "C" {
 
 void ns_hip_cache_clear(void) {
   {
@@ -1325,6 +1364,7 @@ static bool host_forward(float* activation, void* weiptr, float* output, int m, 
 
 void bestla_f32f32_forward(float* activation, void* weiptr, float* output, int _m, int _n, int _k, int lda, int ldo,
                            void* workspace) {
+  ns::HostScope host_scope("bestla_f32f32_forward");
   (void)workspace;
   if (!have_device() || !host_forward(activation, weiptr, output, _m, _n, _k, lda, ldo, NS_EPI_NONE, nullptr, 0, 0))
     invalid_parameters("bestla_f32f32_forward");
@@ -1341,6 +1381,7 @@ bool bestla_fusion_add_f32f32_support(void* weiptr, int _m, int _n, int _k) {
 
 void bestla_fusion_add_f32f32_forward(float* activation, void* weiptr, float* bias, float* output, int _m, int _n,
                                       int _k, int lda, int ldo, bool boardcast_bias, void* workspace) {
+  ns::HostScope host_scope("bestla_fusion_add_f32f32_forward");
   (void)workspace;
   // custom::epilogue::Add with ldd = broadcast ? 0 : ldo (inner_product.cpp:113-244)
   if (!have_device() || !host_forward(activation, weiptr, output, _m, _n, _k, lda, ldo, NS_EPI_ADD, bias,
@@ -1370,6 +1411,7 @@ bool bestla_fusion_QKV_f32f32_support(void* wqptr, void* wkptr, void* wvptr, int
 
 void bestla_fusion_QKV_f32f32_forward(float* activation, void* wqptr, void* wkptr, void* wvptr, float* output, int _m,
                                       int _n, int _k, int lda, int ldo, void* workspace) {
+  ns::HostScope host_scope("bestla_fusion_QKV_f32f32_forward");
   std::lock_guard<std::mutex> host_lock(g_host_mu);
   CachePin pin;
   (void)workspace;
@@ -1485,6 +1527,7 @@ bool bestla_fusion_FFN_SiLu_f32f32_support(void* w1ptr, void* w2ptr, void* w3ptr
 void bestla_fusion_FFN_SiLu_f32f32_forward(float* activation, void* w1ptr, void* w2ptr, void* w3ptr, float* tmp1,
                                            float* tmp2, float* output, int seq, int fin, int fmid, int fout,
                                            void* workspace) {
+  ns::HostScope host_scope("bestla_fusion_FFN_SiLu_f32f32_forward");
   (void)workspace;
   ffn3_forward("bestla_fusion_FFN_SiLu_f32f32_forward", activation, w1ptr, w2ptr, w3ptr, tmp1, tmp2, output, seq, fin,
                fmid, fout, NS_EPI_SILU);
@@ -1497,6 +1540,7 @@ bool bestla_fusion_FFN_Gelu_Mul_f32f32_support(void* w1ptr, void* w2ptr, void* w
 void bestla_fusion_FFN_Gelu_Mul_f32f32_forward(float* activation, void* w1ptr, void* w2ptr, void* w3ptr, float* tmp1,
                                                float* tmp2, float* output, int seq, int fin, int fmid, int fout,
                                                void* workspace) {
+  ns::HostScope host_scope("bestla_fusion_FFN_Gelu_Mul_f32f32_forward");
   (void)workspace;
   ffn3_forward("bestla_fusion_FFN_Gelu_Mul_f32f32_forward", activation, w1ptr, w2ptr, w3ptr, tmp1, tmp2, output, seq,
                fin, fmid, fout, NS_EPI_GELU);
@@ -1545,6 +1589,7 @@ bool bestla_fusion_FFN_GeLu_f32f32_support(void* w1ptr, void* w2ptr, int seq, in
 }
 void bestla_fusion_FFN_GeLu_f32f32_forward(float* activation, void* w1ptr, void* w2ptr, float* tmp1, float* output,
                                            int seq, int fin, int fmid, int fout, void* workspace) {
+  ns::HostScope host_scope("bestla_fusion_FFN_GeLu_f32f32_forward");
   (void)workspace;
   ffn2_forward("bestla_fusion_FFN_GeLu_f32f32_forward", activation, w1ptr, w2ptr, nullptr, nullptr, tmp1, output, seq,
                fin, fmid, fout, false);
@@ -1556,6 +1601,7 @@ bool bestla_fusion_FFN_Add_GeLu_f32f32_support(void* w1ptr, void* w2ptr, int seq
 void bestla_fusion_FFN_Add_GeLu_f32f32_forward(float* activation, void* w1ptr, void* w2ptr, float* b1ptr, float* b2ptr,
                                                float* tmp1, float* output, int seq, int fin, int fmid, int fout,
                                                bool boardcast_bias, void* workspace) {
+  ns::HostScope host_scope("bestla_fusion_FFN_Add_GeLu_f32f32_forward");
   (void)workspace;
   ffn2_forward("bestla_fusion_FFN_Add_GeLu_f32f32_forward", activation, w1ptr, w2ptr, b1ptr, b2ptr, tmp1, output, seq,
                fin, fmid, fout, boardcast_bias);
@@ -1590,6 +1636,20 @@ void bestla_packweight_copyattr(const float* f32ptr, void* dstpr, int n, int k, 
 
 static bool host_unary(size_t in_elems, size_t out_elems, const float* in, float* out,
                        const std::function<hipError_t(const float*, float*)>& fn) {
+  // decode-sized tensors: pinned, device-mapped staging — memcpy, ONE launch that reads / writes host memory over PCIe, ONE
+  // synchronisation (three blocking hipMemcpy round trips cost 36-53 us per call; the graph issues six such calls per layer)
+  if (zero_copy_enabled() && (in_elems + out_elems) * 4 <= kZeroCopyMaxBytes) {
+    float *hI = nullptr, *hO = nullptr;
+    float* dI = mapped(g_ha, in_elems * 4, &hI);
+    float* dO = mapped(g_hc, out_elems * 4, &hO);
+    if (dI && dO) {
+      memcpy(hI, in, in_elems * 4);
+      if (!hip_ok(fn(dI, dO), "launch") || !hip_ok(hipStreamSynchronize(nullptr), "synchronize")) return false;
+      memcpy(out, hO, out_elems * 4);
+      return true;
+    }
+    (void)hipGetLastError();  // pinned allocation refused: staged copies
+  }
   float* dI = (float*)g_sa.get(in_elems * 4);
   float* dO = (float*)g_sc.get(out_elems * 4);
   return dI && dO && hip_ok(hipMemcpy(dI, in, in_elems * 4, hipMemcpyHostToDevice), "H2D") && hip_ok(fn(dI, dO), "launch") &&
@@ -1763,6 +1823,7 @@ int ns_hip_add(int batch, int vsize, const float* dTensor, const float* dVector,
 
 void bestla_layernormalization(int norm_count, int norm_size, bool isrms, float epsilon, const float* FpIn,
                                float* FpOut) {
+  ns::HostScope host_scope("bestla_layernormalization");
   std::lock_guard<std::mutex> host_lock(g_host_mu);
   CachePin pin;
   const size_t n = size_t(norm_count) * norm_size;
@@ -1781,6 +1842,22 @@ static void host_binary(const char* who, int batch, int vsize, const float* tens
   if (ok) {
     const size_t n = size_t(batch) * vsize;
     const size_t vn = size_t(batch - 1) * vstep + vsize;
+    if (zero_copy_enabled() && (2 * n + vn) * 4 <= kZeroCopyMaxBytes) {  // decode-sized: see host_unary
+      float *hT = nullptr, *hV = nullptr, *hO = nullptr;
+      float* zT = mapped(g_ha, n * 4, &hT);
+      float* zV = mapped(g_hd, vn * 4, &hV);
+      float* zO = mapped(g_hc, n * 4, &hO);
+      if (zT && zV && zO) {
+        memcpy(hT, tensor, n * 4);
+        memcpy(hV, vector, vn * 4);
+        ok = hip_ok(launch_bcast_binary(batch, vsize, zT, zV, vstep, zO, mul, nullptr), "launch") &&
+             hip_ok(hipStreamSynchronize(nullptr), "synchronize");
+        if (ok) memcpy(out, hO, n * 4);
+        if (!ok) invalid_parameters(who);
+        return;
+      }
+      (void)hipGetLastError();
+    }
     float* dT = (float*)g_sa.get(n * 4);
     float* dV = (float*)g_sd.get(vn * 4);
     float* dO = (float*)g_sc.get(n * 4);
@@ -1792,9 +1869,11 @@ static void host_binary(const char* who, int batch, int vsize, const float* tens
   if (!ok) invalid_parameters(who);
 }
 void bestla_mul(int batch, int vsize, const float* tensor, const float* vector, int vstep, float* out) {
+  ns::HostScope host_scope("bestla_mul");
   host_binary("bestla_mul", batch, vsize, tensor, vector, vstep, out, true);
 }
 void bestla_add(int batch, int vsize, const float* tensor, const float* vector, int vstep, float* out) {
+  ns::HostScope host_scope("bestla_add");
   host_binary("bestla_add", batch, vsize, tensor, vector, vstep, out, false);
 }
 

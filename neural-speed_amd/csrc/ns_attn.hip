@@ -762,8 +762,10 @@ static size_t span4(int n0, long long s0, int n1, long long s1, int n2, long lon
 // The reference hands the cache to BesTLA as an opaque buffer (sizes / strides from bestla_reordered_attn_fp32_batch_kv_info,
 // contents only through the update / shift / copy / forward entries, mha_dense.h:124-172) and packs it for AMX / AVX tiles.
 // Nothing but this module looks inside, so the layout here is the one the attention kernels stream best.
+// slab (optional): the device mirror of the cache, rows seq_off .. of every (batch, head) slab of seq_max rows
 __global__ void kv_update_kernel(const float* __restrict__ src, _Float16* __restrict__ out, int batch, int heads, int hs,
-                                 int seq, long long step_bs, long long step_head, long long step_seq, long long step_hs) {
+                                 int seq, long long step_bs, long long step_head, long long step_seq, long long step_hs,
+                                 _Float16* __restrict__ slab = nullptr, int seq_max = 0, int seq_off = 0) {
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t total = size_t(batch) * heads * seq * hs;
   if (gid >= total) return;
@@ -771,7 +773,9 @@ __global__ void kv_update_kernel(const float* __restrict__ src, _Float16* __rest
   const int i = int((gid / hs) % seq);
   const int h = int((gid / (size_t(hs) * seq)) % heads);
   const int b = int(gid / (size_t(hs) * seq * heads));
-  out[gid] = (_Float16)src[b * step_bs + h * step_head + i * step_seq + j * step_hs];  // out: [batch][head][seq][hs]
+  const _Float16 v = (_Float16)src[b * step_bs + h * step_head + i * step_seq + j * step_hs];
+  out[gid] = v;  // out: [batch][head][seq][hs]
+  if (slab) slab[((size_t(b) * heads + h) * seq_max + seq_off + i) * hs + j] = v;
 }
 // rows [seq_keep, seq_max) of every (batch, head): adjacent pairs rotated by the one angle set in cossin = {cos_0, sin_0,
 // cos_1, sin_1, ...} (fp16), as ne_compute_forward_rope_bestla prepares it (ne_layers.c:9636-9651)
@@ -900,6 +904,36 @@ static void kv_mirrors_clear_impl() {
 static std::mutex g_attn_host_mu;
 static std::mutex& g_attn_host_mu_ref() { return g_attn_host_mu; }
 constexpr int kScratchHostA = 10, kScratchHostB = 11, kScratchHostC = 12, kScratchHostD = 13;
+// pinned, device-mapped staging for the decode-sized host calls (guarded by g_attn_host_mu): the kernels read / write host
+// memory over PCIe, a call is memcpy + launches + ONE synchronisation instead of blocking hipMemcpy round trips
+struct AttnPinned {
+  void* host = nullptr;
+  void* dev = nullptr;
+  size_t cap = 0;
+};
+static AttnPinned g_attn_pin[4];
+constexpr size_t kAttnZeroCopyMax = size_t(2) << 20;
+static bool attn_zero_copy() {
+  static const bool off = getenv("NS_NO_ZERO_COPY") != nullptr;  // diagnostics
+  return !off;
+}
+static void* attn_pinned(int slot, size_t bytes, void** dev) {
+  AttnPinned& e = g_attn_pin[slot];
+  if (bytes > e.cap) {
+    if (e.host) (void)hipHostFree(e.host);
+    e = AttnPinned{};
+    const size_t want = bytes < (size_t(1) << 16) ? (size_t(1) << 16) : bytes;
+    if (hipHostMalloc(&e.host, want, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&e.dev, e.host, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (e.host) (void)hipHostFree(e.host);
+      e = AttnPinned{};
+      return nullptr;
+    }
+    e.cap = want;
+  }
+  *dev = e.dev;
+  return e.host;
+}
 static bool kv_device() {
   int count = 0;
   if (hipGetDeviceCount(&count) == hipSuccess && count > 0) return true;
@@ -911,6 +945,7 @@ static bool kv_device() {
 
 // update_k / update_v share one layout here: fp32 rows (any element steps) -> fp16 at [batch][head][seq_off + i][:]
 static void kv_update(const bestla_fusion_attn_fp32_update_kv_args_t* pp, const char* who) {
+  ns::HostScope host_scope("bestla_reordered_attn_fp32_update_k/v");
   if (!kv_device()) return;
   const auto& a = *pp;
   if (!a.src || !a.cache || a.batch_size < 0 || a.heads_kv <= 0 || a.head_size <= 0 || a.seq_size < 0 || a.seq_off < 0 ||
@@ -922,8 +957,35 @@ static void kv_update(const bestla_fusion_attn_fp32_update_kv_args_t* pp, const 
   const size_t total = size_t(a.batch_size) * a.heads_kv * a.seq_size * a.head_size;
   if (total == 0) return;
   const size_t nsrc = span4(a.batch_size, a.step_bs, a.heads_kv, a.step_head_num, a.seq_size, a.step_seq, a.head_size, a.step_head_size);
-  // staging in the grow-only per-stream scratch (a hipMalloc / hipFree pair per call synchronises the whole device twice)
   std::lock_guard<std::mutex> host_lock(g_attn_host_mu);
+  const size_t row_b = size_t(a.head_size) * 2;
+  if (attn_zero_copy() && nsrc * 4 + total * 2 <= kAttnZeroCopyMax) {  // a token's rows: pinned staging, one launch, one synchronisation
+    void *zsrc = nullptr, *zout = nullptr;
+    float* hsrc = static_cast<float*>(attn_pinned(0, nsrc * 4, &zsrc));
+    _Float16* hout = static_cast<_Float16*>(attn_pinned(1, total * 2, &zout));
+    if (hsrc && hout) {
+      const size_t slab = size_t(a.batch_size) * a.heads_kv * a.seq_max * row_b;
+      const bool had = kv_mirror_find(a.cache, slab) != nullptr;  // (a mirror created now is filled from the host copy below)
+      _Float16* mir = had ? reinterpret_cast<_Float16*>(kv_mirror_find(a.cache, slab)) : nullptr;
+      memcpy(hsrc, a.src, nsrc * 4);
+      hipLaunchKernelGGL(kv_update_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, nullptr, static_cast<const float*>(zsrc),
+                         static_cast<_Float16*>(zout), a.batch_size, a.heads_kv, a.head_size, a.seq_size, (long long)a.step_bs,
+                         (long long)a.step_head_num, (long long)a.step_seq, (long long)a.step_head_size, mir, a.seq_max, a.seq_off);
+      bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+      if (ok) {
+        const size_t chunk = size_t(a.seq_size) * row_b;
+        for (size_t bh = 0; bh < size_t(a.batch_size) * a.heads_kv; bh++)
+          memcpy(a.cache + (bh * a.seq_max + a.seq_off) * row_b, reinterpret_cast<const char*>(hout) + bh * chunk, chunk);
+        if (!had) (void)kv_mirror_get(a.cache, slab);  // first sight of this cache: mirror = the (now complete) host copy
+      } else {
+        (void)hipGetLastError();
+        set_error(std::string(who) + ": device launch failed");
+        fprintf(stderr, "Err: invalid parameters (%s: device launch failed)\n", who);
+      }
+      return;
+    }
+  }
+  // staging in the grow-only per-stream scratch (a hipMalloc / hipFree pair per call synchronises the whole device twice)
   float* dsrc = static_cast<float*>(stream_scratch(nullptr, nsrc * 4, kScratchHostA));
   _Float16* dout = static_cast<_Float16*>(stream_scratch(nullptr, total * 2, kScratchHostB));
   bool ok = dsrc && dout && hipMemcpy(dsrc, a.src, nsrc * 4, hipMemcpyHostToDevice) == hipSuccess;
@@ -996,6 +1058,7 @@ void bestla_reordered_attn_fp32_shift_rope_k(char* cache, const uint16_t* cossin
 // beam search: rows [seq_off, seq_off + seq_size) of every head from one sequence's cache to another's (both in host
 // memory, as the graph allocates them): a plain copy in this layout — data movement, no arithmetic
 static void kv_batch_cpy(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* pp) {
+  ns::HostScope host_scope("bestla_fusion_attn_fp32_batch_cpy_k/v");
   const auto& a = *pp;
   if (!a.src || !a.dst || a.heads_kv <= 0 || a.head_size <= 0 || a.seq_size <= 0 || a.seq_off < 0 || a.seq_off + a.seq_size > a.seq_max) return;
   const size_t row = size_t(a.head_size) * 2;
@@ -1021,6 +1084,7 @@ void bestla_fusion_attn_fp32_batch_cpy_k(const bestla_fusion_attn_fp32_batch_cpy
 void bestla_fusion_attn_fp32_batch_cpy_v(const bestla_fusion_attn_fp32_batch_cpy_kv_args_t* params) { kv_batch_cpy(params); }
 
 void bestla_reordered_attn_fp32_forward(const bestla_reordered_attn_fp32_fp32_fwd_args_t* rp) {
+  ns::HostScope host_scope("bestla_reordered_attn_fp32_forward");
   // the graph passes BYTE strides of its K / V views (ne_layers.c:10238-10279; the sequence stride of V is not passed at
   // all: every layout knows its own) — here they are plain fp16 rows, so this is the fp16 attention entry
   attn_fp32_fp16_fp16_fp32_fwd_args_t a;
@@ -1078,10 +1142,28 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
                           a.head_size, 1);
   // staging in the grow-only per-stream scratch (four hipMalloc / hipFree pairs per call synchronised the device eight times)
   std::lock_guard<std::mutex> host_lock(g_attn_host_mu);
-  void* dq = stream_scratch(nullptr, nq * 4, kScratchHostA);
   // K / V of a library-managed cache are already on the device (kv mirrors above): nothing to upload
   void* mk = kv_mirror_find(reinterpret_cast<const char*>(hp->K), nk * 2);
   void* mv = kv_mirror_find(reinterpret_cast<const char*>(hp->V), nv * 2);
+  if (mk && mv && attn_zero_copy() && (nq + nd) * 4 <= kAttnZeroCopyMax) {  // decode over a mirrored cache: Q and dst through pinned memory
+    void *zq = nullptr, *zd = nullptr;
+    float* hq = static_cast<float*>(attn_pinned(2, nq * 4, &zq));
+    float* hd = static_cast<float*>(attn_pinned(3, nd * 4, &zd));
+    if (hq && hd) {
+      memcpy(hq, hp->Q, nq * 4);
+      memcpy(hd, hp->dst, nd * 4);  // keeps the bytes between strided rows
+      a.Q = static_cast<float*>(zq);
+      a.K = static_cast<uint16_t*>(mk);
+      a.V = static_cast<uint16_t*>(mv);
+      a.dst = static_cast<float*>(zd);
+      a.tmp = nullptr;
+      const bool okz = ns_hip_attn_fp32_fp16_fp16_fp32_forward(&a, nullptr) == 0 && hipStreamSynchronize(nullptr) == hipSuccess;
+      if (okz) memcpy(hp->dst, hd, nd * 4);
+      else fprintf(stderr, "Err: invalid parameters (bestla_fusion_attn_fp32_fp16_fp16_fp32_forward: %s)\n", ns_hip_last_error());
+      return;
+    }
+  }
+  void* dq = stream_scratch(nullptr, nq * 4, kScratchHostA);
   void* dk = mk ? mk : stream_scratch(nullptr, nk * 2, kScratchHostB);
   void* dv = mv ? mv : stream_scratch(nullptr, nv * 2, kScratchHostC);
   void* dd = stream_scratch(nullptr, nd * 4, kScratchHostD);

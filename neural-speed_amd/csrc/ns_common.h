@@ -171,6 +171,14 @@ hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, in
 hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st);
 void set_gemv_mode(int mode);  // 0 off (first-generation kernel), 1 on, -1 re-read NS_GEMV2
 void set_attn_tuning(int wg_target, int min_keys);
+// NS_HOST_PROFILE=1: wall time and call count of every host-tensor entry, printed at exit (diagnostics of the default,
+// host-pointer route: where a token's milliseconds go between the graph executor and the GPU)
+struct HostScope {
+  const char* name;
+  long long t0;
+  explicit HostScope(const char* n);
+  ~HostScope();
+};
 void kv_mirrors_clear();  // ns_attn.hip: drops the device mirrors of library-managed kv caches (ns_hip_cache_clear)
 void set_gemm3_bm(int bm);  // ns_gemm.hip: force gemm3_kernel's row-tile height (tests / A-B runs); 0 = automatic  // ns_attn.hip: context-split rule of the decode attention kernel
 void set_decode_waves(int nw);  // 0 = by shape
