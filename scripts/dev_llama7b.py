@@ -65,6 +65,9 @@ def main(mode="device", n_new="24", n_ctx="512"):
     if not os.path.exists(path):
         build_file(path)
     print("quantized NE file: %.2f GB, written in %.0f s" % (os.path.getsize(path) / 1e9, time.time() - t0), flush=True)
+    if os.environ.get("NS_DEV7B_SCHED"):  # experiment: the runtime's wait mode (1 spin, 2 yield, 4 blocking sync) before the context exists
+        hip = C.CDLL("libamdhip64.so")
+        print("hipSetDeviceFlags ->", hip.hipSetDeviceFlags(C.c_uint(int(os.environ["NS_DEV7B_SCHED"]))), flush=True)
     import torch  # noqa: F401
     C.CDLL(os.path.join(ROOT, "neural-speed_amd", "libns_hip.so"), mode=C.RTLD_GLOBAL)
     prompt = [1, 17, 200, 3, 99, 42, 311, 2048]
