@@ -529,7 +529,12 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   // on the streaming kernel up to 64 rows with an fp16 shadow (21 vs 25 us), 14336 x 4096 leaves it at 17 (53 vs 44 us
   // at 32 rows), fp32 activations leave earlier.
   double staging = double(w->ntiles) * m * w->k * (dA16 ? 2.0 : 4.0);
-  const bool small = m <= 16 || (m <= small_max && (staging <= 140e6 || getenv("NS_SMALLM_MAX") != nullptr));
+  // 17..64 rows on a wide output (>= 256 column tiles): the tiled kernel's 128-row tile wins although most of it is padding
+  // (round 3, scripts/m_sweep.py: 11008 x 4096 at 32 rows 23.7 vs 41.3 us, 4096 x 4096 at 48 rows 16.3 vs 18.2; below 33 rows
+  // on a 4096-wide output the streaming kernel is still level or ahead).  fp8 weights stay (first-generation GEMM only).
+  const bool wide_tiled = m >= 17 && w->kind != WK_F8 && !getenv("NS_SMALLM_MAX") &&
+                          (w->ntiles >= 512 || (w->ntiles >= 256 && m >= 33));
+  const bool small = m <= 16 || (!wide_tiled && m <= small_max && (staging <= 140e6 || getenv("NS_SMALLM_MAX") != nullptr));
   // fp32 activations, several rows, many column tiles: one conversion pass to fp16 (about 2 us) halves what every
   // workgroup of the streaming kernel stages (14336 x 4096 at 16 rows: 39 -> 24 us; at 8 rows: 25 -> 18 us)
   if (small && !dA16 && m >= 6 && staging > 60e6 && lda == w->k && w->k % 8 == 0) {
@@ -807,6 +812,10 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_gemv_mode(value);
     return 0;
   }
+  if (key && !strcmp(key, "g3_min_m")) {
+    set_gemm3_min_m(value);
+    return 0;
+  }
   if (key && !strcmp(key, "g3_bm")) {
     set_gemm3_bm(value);
     return 0;
@@ -963,7 +972,7 @@ int ns_hip_fusion_qkv_forward_x(const float* dA, const void* dA16, const ns_weig
       if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference qkv launch") ? 0 : -1;
     }
   }
-  if (same && m >= 192 && !link) {  // GEMM size: the three matrices side by side in ONE launch of the tiled kernel
+  if (same && m > 64 && !link) {  // GEMM size: the three matrices side by side in ONE launch of the tiled kernel
     SmallMArgs a{};
     a.a = dA;
     a.a16 = dA16;

@@ -180,6 +180,7 @@ struct HostScope {
   ~HostScope();
 };
 void kv_mirrors_clear();  // ns_attn.hip: drops the device mirrors of library-managed kv caches (ns_hip_cache_clear)
+void set_gemm3_min_m(int m);  // ns_gemm.hip: rows from which gemm3_kernel is used (0 = default)
 void set_gemm3_bm(int bm);  // ns_gemm.hip: force gemm3_kernel's row-tile height (tests / A-B runs); 0 = automatic  // ns_attn.hip: context-split rule of the decode attention kernel
 void set_decode_waves(int nw);  // 0 = by shape
 int decode_waves(int grid, int ks, bool dual);  // waves per workgroup of a decode launch (both kernel generations)

@@ -302,6 +302,11 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
 // landed) -> s_barrier (everybody's has, and everybody is done reading the other stage) -> issue the DMA of the next
 // chunk into the other stage -> multiply this chunk.
 constexpr int kG3BM = 256, kG3KC = 64, kG3Tiles = 8;
+// rows from which the third-generation kernel is used (tuning: g3_min_m).  Round 3 (scripts/m_sweep.py, profiles/r03_m_sweep.txt):
+// with its 128-row tile it beats gemm2_kernel everywhere below the old threshold of 192 — 4096 x 4096: 17.5 vs 24.2 us at 65
+// rows, 21.7 vs 34.2 at 128, 25.0 vs 36.4 at 191; 11008 x 4096: 26.0 vs 44.6, 29.0 vs 49.6, 40.5 vs 71.0 — and the streaming
+// kernel from 17 rows on wide outputs (11008 x 4096: 22.5 vs 33.0 us at 17 rows, 25.9 vs 44.8 at 64; ns_api.cpp decides)
+constexpr int kG3MinM = 17;
 constexpr int kG3StageBytes = kG3BM * kG3KC * 2;  // 32 KiB
 constexpr int kG3Stages = 2;
 constexpr int kG3BStageMax = 8 * 2 * 1024 + 8 * 2 * 16 * 16 + 8 * 2 * 16 * 4;  // B stage upper bound: codes + scale rows + zero points
@@ -1224,6 +1229,12 @@ static hipError_t launch_gemm2_s(const Gemm2Params& p, uint32_t scale_dt, bool a
 }
 
 static std::atomic<int> g_g3_bm{0};
+static std::atomic<int> g_g3_min_m{0};  // ns_hip_set_tuning("g3_min_m", rows): 0 = the default below
+void set_gemm3_min_m(int m) { g_g3_min_m.store(m > 0 ? m : 0); }
+static int gemm3_min_m() {
+  const int v = g_g3_min_m.load();
+  return v > 0 ? v : kG3MinM;
+}
 void set_gemm3_bm(int bm) { g_g3_bm.store(bm == 128 || bm == 256 || bm == 257 || bm == 258 ? bm : 0); }  // 257: 256-row tile, tall wave tiles; 258: the automatic choice without them (A-B runs)
 
 // hipErrorNotSupported = use the first-generation kernel (scratch allocation failed, sizes beyond 32-bit offsets ...)
@@ -1283,9 +1294,9 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   static const int g3_diag = getenv("NS_G3_DIAG") ? atoi(getenv("NS_G3_DIAG")) : 0;
   p.diag = g3_diag;
   p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
-  if (a.nseg > 1) {  // fused QKV at GEMM size: gemm3_kernel only (192 rows and up), whole column blocks per matrix
+  if (a.nseg > 1) {  // fused QKV at GEMM size: gemm3_kernel only, whole column blocks per matrix
     static const bool g3_off_env = getenv("NS_GEMM3") && atoi(getenv("NS_GEMM3")) != 1;
-    if (a.nseg > 3 || a.dual || a.m < 192 || (p.lda16 & 7) != 0 || g3_off_env) return hipErrorNotSupported;
+    if (a.nseg > 3 || a.dual || a.m < gemm3_min_m() || (p.lda16 & 7) != 0 || g3_off_env) return hipErrorNotSupported;
     p.nseg = a.nseg;
     int bn0 = 0;
     for (int i = 0; i < a.nseg; i++) {
@@ -1311,7 +1322,7 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   static const int g3_mode = getenv("NS_GEMM3") ? atoi(getenv("NS_GEMM3")) : 1;  // 0: gemm2, 1: gemm3, 2: gemm3d (NS_WITH_GEMM3D builds)
   const bool g3_off = g3_mode == 0;
   const bool deep = g3_mode == 2;
-  if (!g3_off && a.m >= 192 && (p.lda16 & 7) == 0) {
+  if (!g3_off && a.m >= gemm3_min_m() && (p.lda16 & 7) == 0) {
     // 128-row tiles (three workgroups per CU hide each other's barrier / dequantisation / output phases) unless the
     // output has so many tiles that the tall ones' halved A traffic wins (profiles/r02r_gemm3_bm.txt: at 2048 rows equal
     // or better up to 11008 columns, 7 % worse at 32000)

@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package(); L = pkg.lib()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("NS_SWEEP_G3MIN"):  # A-B: the third-generation tiled kernel from this many rows (default 192)
+    L.ns_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    L.ns_hip_set_tuning(b"g3_min_m", int(os.environ["NS_SWEEP_G3MIN"]))
 res = {}
 for n, k in ((4096, 4096), (11008, 4096)):
     ws = []
@@ -17,7 +20,7 @@ for n, k in ((4096, 4096), (11008, 4096)):
         pkg.check(L.ns_hip_quant_pack_device(blob.data_ptr(), w.data_ptr(), n, k, k, 32, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, True, st))
         ws.append(pkg.Weight.from_device_blob(blob.data_ptr(), size, st))
     torch.cuda.synchronize()
-    for m in (8, 16, 17, 32, 33, 48, 64, 65, 96, 128):
+    for m in (8, 16, 17, 32, 33, 48, 64, 65, 96, 128, 160, 191, 192, 256, 384, 512):
         a = torch.randn((m, k), device="cuda"); a16 = a.half()
         c = torch.empty((m, n), device="cuda")
         def f():

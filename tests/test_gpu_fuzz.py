@@ -105,13 +105,13 @@ def _qkv_cases(count, seed):
         if bs > 0 and k % bs:
             k = (k // bs + 1) * bs
         ns = tuple(int(rng.integers(1, 30)) * 16 + int(rng.choice([0, 0, 3, 9])) for _ in range(3))
-        out.append((i, qt, st, asym, core, bs, ns, k, int(rng.choice([192, 200, 256, 300, 513]))))
+        out.append((i, qt, st, asym, core, bs, ns, k, int(rng.choice([65, 100, 150, 191, 192, 256, 300, 513]))))
     return out
 
 
 @pytest.mark.parametrize("i,qt,st,asym,core,bs,ns,k,m", _qkv_cases(16, 57))
 def test_random_fused_qkv_at_gemm_size(L, pkg, nso, i, qt, st, asym, core, bs, ns, k, m):
-    """bestla_fusion_QKV_f32f32_forward with 192+ rows: three weights of a random ragged width (the host entry has ONE n) in one launch of the
+    """bestla_fusion_QKV_f32f32_forward with 65+ rows: three weights of a random ragged width (the host entry has ONE n) in one launch of the
     tiled kernel, host pointers; each output block against the oracle's fp64 GEMM of its weight"""
     rng = np.random.default_rng(5000 + i)
     n = max(ns)
