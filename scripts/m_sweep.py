@@ -20,7 +20,7 @@ for n, k in ((4096, 4096), (11008, 4096)):
         pkg.check(L.ns_hip_quant_pack_device(blob.data_ptr(), w.data_ptr(), n, k, k, 32, pkg.S4, pkg.BF16, False, pkg.COMP_INT8, True, st))
         ws.append(pkg.Weight.from_device_blob(blob.data_ptr(), size, st))
     torch.cuda.synchronize()
-    for m in (8, 16, 17, 32, 33, 48, 64, 65, 96, 128, 160, 191, 192, 256, 384, 512):
+    for m in [int(x) for x in os.environ.get("NS_SWEEP_MS", "8,16,17,32,33,48,64,65,96,128,160,191,192,256,384,512").split(",")]:
         a = torch.randn((m, k), device="cuda"); a16 = a.half()
         c = torch.empty((m, n), device="cuda")
         def f():
