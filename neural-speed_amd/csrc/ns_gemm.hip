@@ -1141,7 +1141,10 @@ static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hip
   // A stages + the B stage of this format: records, scale rows, zero-point rows of 8 column tiles for one superstep
   constexpr int rps = KIND == WK_INT8 ? 2 : 1;
   constexpr int sbytes = SPS * (SK == SK_F32 ? 4 : 2);
-  const size_t lds3 = size_t(kG3Stages) * BM * kG3KC * 2 + size_t(kG3Tiles) * rps * (1024 + 16 * sbytes + (asym ? 16 * SPS : 0));
+  // (the epilogue parks 64 rows x (wave columns + 4) floats per wave over the stage memory: the 64-row tile's stages alone are
+  // smaller than that)
+  constexpr size_t park_bytes = size_t(4) * 64 * (((BM == 256 && !TALL) ? 64 : 32) + 4) * 4;
+  const size_t lds3 = std::max(size_t(kG3Stages) * BM * kG3KC * 2 + size_t(kG3Tiles) * rps * (1024 + 16 * sbytes + (asym ? 16 * SPS : 0)), park_bytes);
   auto go = [&](auto kern) {
     static const hipError_t attr =
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(kG3Stages * kG3StageBytes + kG3BStageMax));
@@ -1203,6 +1206,11 @@ static hipError_t launch_gemm3_s(const Gemm2Params& p, uint32_t scale_dt, bool a
 #else
   (void)deep;
 #endif
+  if (p.bm3 == 64) {  // calls of at most 64 rows: a quarter / half of the 128-row tile's MFMA work is padding otherwise
+    if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 64>(p, asym, grid, st);
+    if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 64>(p, asym, grid, st);
+    return launch_gemm3_k<KIND, SPS, SK_BF16, 64>(p, asym, grid, st);
+  }
   if (p.bm3 == 128) {
     if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 128>(p, asym, grid, st);
     if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 128>(p, asym, grid, st);
@@ -1235,7 +1243,7 @@ static int gemm3_min_m() {
   const int v = g_g3_min_m.load();
   return v > 0 ? v : kG3MinM;
 }
-void set_gemm3_bm(int bm) { g_g3_bm.store(bm == 128 || bm == 256 || bm == 257 || bm == 258 ? bm : 0); }  // 257: 256-row tile, tall wave tiles; 258: the automatic choice without them (A-B runs)
+void set_gemm3_bm(int bm) { g_g3_bm.store(bm == 64 || bm == 128 || bm == 256 || bm == 257 || bm == 258 ? bm : 0); }  // 257: 256-row tile, tall wave tiles; 258: the automatic choice without them (A-B runs)
 
 // hipErrorNotSupported = use the first-generation kernel (scratch allocation failed, sizes beyond 32-bit offsets ...)
 hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
@@ -1334,7 +1342,7 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
     // in a layer's sequence of GEMMs, steady state, choosing them by that rule gained nothing (986 vs 993 TFLOPS,
     // profiles/r03w_prefill_ab.txt) — not selected automatically
     p.tall3 = bm_env == 257 && w0->kind == WK_INT4;
-    p.bm3 = p.tall3 ? 256 : bm_env == 128 || bm_env == 256 ? bm_env : (tall_tiles >= 1024 && w0->kind != WK_INT8 ? 256 : 128);  // 8-bit codes: the tall tile's LDS
+    p.bm3 = p.tall3 ? 256 : bm_env == 64 || bm_env == 128 || bm_env == 256 ? bm_env : a.m <= 64 ? 64 : (tall_tiles >= 1024 && w0->kind != WK_INT8 ? 256 : 128);  // 8-bit codes: the tall tile's LDS
                                                                                             // footprint (81 KiB) leaves one workgroup per CU
     const int nbm3 = (a.m + p.bm3 - 1) / p.bm3;
     p.ksplit = 1;
