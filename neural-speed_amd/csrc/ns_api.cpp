@@ -529,12 +529,23 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   // on the streaming kernel up to 64 rows with an fp16 shadow (21 vs 25 us), 14336 x 4096 leaves it at 17 (53 vs 44 us
   // at 32 rows), fp32 activations leave earlier.
   double staging = double(w->ntiles) * m * w->k * (dA16 ? 2.0 : 4.0);
-  // 17..64 rows on a wide output (>= 256 column tiles): the tiled kernel's 128-row tile wins although most of it is padding
-  // (round 3, scripts/m_sweep.py: 11008 x 4096 at 32 rows 23.7 vs 41.3 us, 4096 x 4096 at 48 rows 16.3 vs 18.2; below 33 rows
-  // on a 4096-wide output the streaming kernel is still level or ahead).  fp8 weights stay (first-generation GEMM only).
-  const bool wide_tiled = m >= 17 && w->kind != WK_F8 && !getenv("NS_SMALLM_MAX") &&
-                          (w->ntiles >= 512 || (w->ntiles >= 256 && m >= 33));
-  const bool small = m <= 16 || (!wide_tiled && m <= small_max && (staging <= 140e6 || getenv("NS_SMALLM_MAX") != nullptr));
+  // Where the TILED kernel (64-row tile up to 64 rows) beats the streaming one although most of its tile is padding — every
+  // 16-column workgroup of the streaming kernel stages all rows of A, the tiled kernel's 128-column workgroups share them
+  // (round 3, scripts/m_sweep.py, profiles/r03_m_sweep.txt; us, streaming -> tiled):
+  //   32000 x 4096 (lm_head)   8 rows 39.8 -> 32.1, 16 rows 53.4 -> 32.6   (4 rows: 28.9 vs 32.1, stays)
+  //   11008 x 4096             16 rows 17.2 -> 16.7, 17 rows 33.0 -> 17.5, 64 rows 44.8 -> 20.8
+  //   4096 x 11008             16 rows 24.1 -> 19.7 (12 rows level),  4096 x 4096: 33 rows 15.8 -> 13.4 (below: level or behind)
+  // fp8 weights stay on the old rule (first-generation GEMM only).  NS_TILED_MIN_M: diagnostics (A-B runs).
+  static const int tiled_env = getenv("NS_TILED_MIN_M") ? atoi(getenv("NS_TILED_MIN_M")) : 0;
+  // Up to 16 rows every call stays on the streaming kernels all the same: their accumulation is exact in fp32 (3e-5 from the
+  // fp64 product of the fp16-rounded activations, tests/test_gpu_fullsize.py), the tiled kernel rounds scaled weights to fp16
+  // (2e-4), and a decode step's numerics should not depend on the shape of the matrix.
+  const int tiled_from = tiled_env > 0 ? tiled_env
+                         : w->ntiles >= 512 ? 17
+                         : w->ntiles >= 256 ? (w->k >= 8192 ? 17 : 33)
+                                            : 1 << 30;
+  const bool wide_tiled = m >= tiled_from && w->kind != WK_F8 && !getenv("NS_SMALLM_MAX");
+  const bool small = !wide_tiled && (m <= 16 || (m <= small_max && (staging <= 140e6 || getenv("NS_SMALLM_MAX") != nullptr)));
   // fp32 activations, several rows, many column tiles: one conversion pass to fp16 (about 2 us) halves what every
   // workgroup of the streaming kernel stages (14336 x 4096 at 16 rows: 39 -> 24 us; at 8 rows: 25 -> 18 us)
   if (small && !dA16 && m >= 6 && staging > 60e6 && lda == w->k && w->k % 8 == 0) {

@@ -306,7 +306,7 @@ constexpr int kG3BM = 256, kG3KC = 64, kG3Tiles = 8;
 // with its 128-row tile it beats gemm2_kernel everywhere below the old threshold of 192 — 4096 x 4096: 17.5 vs 24.2 us at 65
 // rows, 21.7 vs 34.2 at 128, 25.0 vs 36.4 at 191; 11008 x 4096: 26.0 vs 44.6, 29.0 vs 49.6, 40.5 vs 71.0 — and the streaming
 // kernel from 17 rows on wide outputs (11008 x 4096: 22.5 vs 33.0 us at 17 rows, 25.9 vs 44.8 at 64; ns_api.cpp decides)
-constexpr int kG3MinM = 17;
+constexpr int kG3MinM = 2;  // (the caller decides from where on: ns_api.cpp forward_impl)
 constexpr int kG3StageBytes = kG3BM * kG3KC * 2;  // 32 KiB
 constexpr int kG3Stages = 2;
 constexpr int kG3BStageMax = 8 * 2 * 1024 + 8 * 2 * 16 * 16 + 8 * 2 * 16 * 4;  // B stage upper bound: codes + scale rows + zero points

@@ -11,7 +11,7 @@ if os.environ.get("NS_SWEEP_G3MIN"):  # A-B: the third-generation tiled kernel f
     L.ns_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
     L.ns_hip_set_tuning(b"g3_min_m", int(os.environ["NS_SWEEP_G3MIN"]))
 res = {}
-for n, k in ((4096, 4096), (11008, 4096)):
+for n, k in [tuple(int(v) for v in sh.split('x')) for sh in os.environ.get("NS_SWEEP_SHAPES", "4096x4096,11008x4096").split(',')]:
     ws = []
     for i in range(4):
         w = torch.randn((n, k), device="cuda") * 0.02
