@@ -827,6 +827,14 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_gemm3_min_m(value);
     return 0;
   }
+  if (key && !strcmp(key, "i8_tile")) {
+    set_i8_tile(value);
+    return 0;
+  }
+  if (key && !strcmp(key, "i8_mfma")) {
+    set_i8_mfma_gen(value);
+    return 0;
+  }
   if (key && !strcmp(key, "g3_bm")) {
     set_gemm3_bm(value);
     return 0;

@@ -180,6 +180,8 @@ struct HostScope {
   ~HostScope();
 };
 void kv_mirrors_clear();  // ns_attn.hip: drops the device mirrors of library-managed kv caches (ns_hip_cache_clear)
+void set_i8_tile(int tile);     // ns_i8ref.hip: workgroup tile of i8mfma2_kernel (0 = by size)
+void set_i8_mfma_gen(int gen);  // ns_i8ref.hip: 2 = i8mfma2_kernel for nibble containers (default), 1 = i8mfma_kernel everywhere
 void set_gemm3_min_m(int m);  // ns_gemm.hip: rows from which gemm3_kernel is used (0 = default)
 void set_gemm3_bm(int bm);  // ns_gemm.hip: force gemm3_kernel's row-tile height (tests / A-B runs); 0 = automatic  // ns_attn.hip: context-split rule of the decode attention kernel
 void set_decode_waves(int nw);  // 0 = by shape
@@ -241,6 +243,9 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
                                   float freq_scale, float attn_factor, long long c_sl, long long c_head, hipStream_t st);
 hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
                             int ld_scale, uint8_t* zps, int blocksize, float* blkreduce, hipStream_t st);
+// GEMM-sized form (16-byte loads, dword stores; bit-identical codes), optionally with the fp16 operand of the int8-reference GEMM
+hipError_t launch_aquant_u8_vec(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
+                                int ld_scale, uint8_t* zps, int blocksize, void* ap, int ld_ap, hipStream_t st);
 // A'[r][j] = A[r][idx[j]] (kernel_ref.h:28-37 shuffle_activation), fp32 [m][k] with leading dimension k
 hipError_t launch_gather_cols(const float* a, int lda, const int* idx, float* out, int m, int k, hipStream_t st);
 // default-policy read of [offset, offset + bytes) of the weight's stream (codes, scales, zero points) into the cache

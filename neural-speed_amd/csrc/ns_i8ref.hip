@@ -19,13 +19,24 @@
 // kernel).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "ns_common.h"
 #include "ns_dev.h"
 
 namespace ns {
 namespace {
+
+// which matrix-core kernel GEMM-sized calls on nibble containers take: 2 = i8mfma2_kernel (default), 1 = i8mfma_kernel
+std::atomic<int> g_i8_mfma_gen{[] {
+  const char* e = getenv("NS_I8_MFMA");
+  return e && atoi(e) == 1 ? 1 : 2;
+}()};
+
+std::atomic<int> g_i8_tile{0};  // workgroup tile of i8mfma2_kernel: 0 = by size, 1 = 64 x 64, 2 = 64 x 256, 3 = 128 x 128 (tests / A-B runs)
 
 constexpr int kI8Rows = 4;
 constexpr int kI8Waves = 8, kI8Threads = kI8Waves * 64;  // wave w takes k-steps w, w + 8, ...; four records in flight each
@@ -460,6 +471,374 @@ void launch_i8mfma(int sdt, bool asym, dim3 grid, size_t lds, hipStream_t st, co
     launch_i8mfma_a<F, S, 2>(asym, grid, lds, st, p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second matrix-core kernel (nibble containers, the Q4_0 case): the whole integer sum of a 32-deep slice out of ONE
+// MFMA, already an fp32 number, nothing to correct or convert per accumulator.  i8mfma_kernel above spends five VALU
+// instructions and three 16-byte LDS reads per accumulator and slice on the zero-point terms and the int -> float
+// conversion; its VALU pipe is the bound (profiles/r03_pmc_i8mfma_sq_counters.txt).  Here both zero points are folded into
+// the operands and the operands are small integers held in fp16:
+//       A' = a - za  in [-255, 255],      B' = u - zbb  in [-15, 15]     (u the stored nibble = q + 8, zbb = zb + 8)
+// every product (<= 3825) and every partial sum of a slice (<= 122400) is an integer below 2^24, so
+// v_mfma_f32_16x16x32_f16 returns float(sum_k (a - za)(q - zb)) EXACTLY — the integer dot of the reference, computed on the
+// fp16 matrix pipe.  A' depends on the activation alone: i8prep_kernel writes it once per call as [m][K'] fp16 and every
+// workgroup stages it with plain 16-byte copies; B' costs the lane that holds the record eleven VALU instructions per
+// slice (0x6400 | nibble = 1024 + u as fp16, minus 1024 + zbb: exact).  What is left per accumulator and slice is the
+// reference's fp32 side, float(isum) * (scale_a * scale_b) added in slice order — the same expression on the same numbers
+// as i8mfma_kernel, bit for bit (tests/test_gpu_int8_mode.py compares the two) — as packed fp32 instructions, two
+// accumulators each.
+// Workgroup = 4 waves = 64 rows x (64 or 256) columns; A' per 256-deep chunk in four planes [g][64 rows][8 slices x 16 B]
+// (row stride 144 B: the sixteen lanes of every ds_read_b128 group hold sixteen different rows, conflict-free) + the
+// activation scales [8 slices][64 + 4 rows]; the next chunk's A' pieces and scales and the next k-step's weight records are
+// in flight in registers while the current ones are consumed.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float float2v __attribute__((ext_vector_type(2)));
+// Tile geometry of i8mfma2_kernel: RH 64-row halves per workgroup (and per wave), kSL slices per staged chunk
+template <int RH>
+struct I8G2Geom {
+  static constexpr int kRows = 64 * RH;
+  static constexpr int kSL = 8 / RH;             // 256-deep chunks of 64 rows, 128-deep chunks of 128 rows
+  static constexpr int kRow = kSL * 16 + 16;     // 144 / 80 B = 9 / 5 sixteen-byte slots: rows 0 .. 15 land in sixteen different slots
+  static constexpr int kPlane = kRows * kRow;    // 9216 / 10240: multiples of 256 B, so the plane does not move the bank
+  static constexpr int kSaStride = kRows + 4;    // floats per slice row of the scale plane
+  static constexpr size_t kBuf = size_t(4) * kPlane + size_t(kSL) * kSaStride * 4;   // one staged chunk: 39040 / 43072 B
+  // 64-row workgroups double-buffer the chunk (two workgroups per CU: 2 x 2 x 39040 B <= 160 KiB): one barrier per chunk and
+  // the staging writes of the next chunk sit between the two k-steps of the current one
+  static constexpr int kBufs = RH == 1 ? 2 : 1;
+  static constexpr size_t kLds = kBuf * kBufs;
+};
+
+struct I8PrepParams {
+  const uint8_t* aq;   // [m][k]
+  const uint8_t* azp;  // [m][nblk]
+  uint8_t* out;        // [m][kp] fp16, kp = 32 nsl
+  int m, k, nsl, blocksize, nblk;
+};
+
+// A'[row][k] = fp16(a - za(row, k-block)) (/ 16 for k mod 8 in {2, 3, 6, 7}), zero beyond K: eight codes per thread
+__global__ __launch_bounds__(256) void i8prep_kernel(const I8PrepParams p) {
+  const size_t idx = size_t(blockIdx.x) * 256 + threadIdx.x;
+  const size_t per_row = size_t(p.nsl) * 4;
+  if (idx >= size_t(p.m) * per_row) return;
+  const int row = int(idx / per_row);
+  const int piece = int(idx - size_t(row) * per_row);
+  const int k0 = piece * 8;  // = 32 * slice + 8 * g
+  uint32_t lo = 0, hi = 0, za = 0;
+  if (k0 < p.k) {
+    za = p.azp[size_t(row) * p.nblk + min(k0 / p.blocksize, p.nblk - 1)];
+    const uint8_t* src = p.aq + size_t(row) * p.k + k0;
+    if (k0 + 8 <= p.k && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
+      const uint2 v = *reinterpret_cast<const uint2*>(src);
+      lo = v.x, hi = v.y;
+    } else {  // beyond K: the zero point itself, a - za = 0
+      uint32_t b[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) b[i] = (k0 + i < p.k) ? uint32_t(src[i]) : za;
+      lo = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+      hi = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+    }
+  }
+  // 0x6400 | byte = 1024 + a as fp16 (ulp 1 there); minus 1024 + za: exact
+  const half2_t zc = __builtin_bit_cast(half2_t, (0x6400u + za) * 0x00010001u);
+  const uint32_t src2[4] = {__builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u),
+                            __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u)};
+  // codes 2, 3, 6, 7 of the eight are stored as (a - za) / 16 (exact: eight significant bits): the GEMM builds their B' as
+  // 16 (u - zbb) straight from the nibbles' position in the dword, one shift less per pair
+  const half2_t sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    half2_t v = __builtin_bit_cast(half2_t, src2[i]) - zc;
+    if (i & 1) v = v * sixteenth;
+    o[i] = __builtin_bit_cast(uint32_t, v);
+  }
+  *reinterpret_cast<uint4v*>(p.out + idx * 16) = uint4v{o[0], o[1], o[2], o[3]};
+}
+
+struct I8Gemm2Params {
+  I8RefParams b;
+  const uint8_t* pa;  // i8prep_kernel's output
+  int nsl;            // slices per row of it
+};
+
+// Tile: a workgroup covers 64 RH rows x 64 CT columns, each of its four waves all the rows and CT 16-column tiles.
+//   (2, 2)  128 x 128: the large-problem shape.  Every B' fragment (VALU work) feeds eight MFMAs, every byte of A' staged two per
+//           wave; L2 / fabric traffic per flop is half of the 64 x 64 workgroup's, which bounded the first version of this kernel
+//           at 6 TB/s of cache traffic.  One 128-deep chunk in LDS (43 KB; two would not fit twice per CU)
+//   (1, 4)  64 x 256: mid-size problems.  Double-buffered 256-deep chunks: one barrier per chunk, staging writes between its two
+//           k-steps.  5 - 10 % behind (2, 2) at 2048 x 4096 x 4096 (profiles/r03_i8_prefill_kernels.txt)
+//   (1, 1)  64 x 64, double-buffered: small problems (four times the workgroups)
+template <int SDT, int SPS, bool ASYM, int RH, int CT>
+__global__ __launch_bounds__(256, 2) void i8mfma2_kernel(const I8Gemm2Params pp) {
+  using G = I8G2Geom<RH>;
+  const I8RefParams& p = pp.b;
+  constexpr int NJ = 4, CS = G::kSL / NJ;             // four 32-deep slices per k-step record; k-steps per chunk: 2 / 1
+  constexpr int kPieces = G::kRows * G::kSL * 4 / 256;  // 16-byte A' pieces per thread and chunk: 8
+  constexpr int kRowPieces = G::kSL * 4;                // pieces per row and chunk: 32 / 16
+  constexpr int kInstrRows = 64 / kRowPieces;           // rows one wave-instruction of the staging covers: 2 / 4
+  constexpr int kSaPer = G::kRows * G::kSL / 256;       // activation scales per thread and chunk: 2
+  extern __shared__ __attribute__((aligned(16))) unsigned char g2_smem[];
+  constexpr size_t kSaOff = size_t(4) * G::kPlane;  // the scale plane behind the four A' planes of a buffer
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nn = l & 15, g = l >> 4;
+  const int tile0 = (blockIdx.x * 4 + w) * CT;
+  const int ntiles = (p.n + 15) / 16;
+  const bool active = tile0 < ntiles;
+  const int r0 = blockIdx.y * G::kRows;
+  constexpr int sbytes = SDT == 2 ? 4 : 2;
+  constexpr int rec_sbytes = SPS * sbytes;
+  float2v acc[RH][CT][4][2];
+#pragma unroll
+  for (int h = 0; h < RH; h++)
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+      for (int rt = 0; rt < 4; rt++) acc[h][ct][rt][0] = acc[h][ct][rt][1] = float2v{0.f, 0.f};
+  uint32_t magic = 0x64006400u;  // held in a register: (x & mask) | magic is then one v_and_or_b32
+  asm volatile("" : "+v"(magic));
+
+  struct KRec {  // the records of one k-step: codes, scale words, zero points of the wave's CT tiles
+    uint4v rec[CT];
+    uint32_t sw[CT][4], zw[CT];
+  };
+  auto fetch_w = [&](int s, KRec& r) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+      const int tile = tile0 + ct;
+      r.rec[ct] = uint4v{0, 0, 0, 0};
+      r.sw[ct][0] = r.sw[ct][1] = r.sw[ct][2] = r.sw[ct][3] = 0, r.zw[ct] = 0;
+      if (tile < ntiles && s < p.ksteps) {
+        r.rec[ct] = *reinterpret_cast<const uint4v*>(p.codes + (size_t(tile) * p.ksteps + s) * p.qstride + l * 16);
+        const uint32_t srow = uint32_t(s * p.srow_mul) >> p.srow_shift;
+        const size_t crow = size_t(tile) * p.srows + srow;
+        const uint8_t* sp = p.scales + crow * p.sstride + size_t(nn) * rec_sbytes;
+        if constexpr (rec_sbytes == 16) {
+          const uint4v v = *reinterpret_cast<const uint4v*>(sp);
+          r.sw[ct][0] = v.x, r.sw[ct][1] = v.y, r.sw[ct][2] = v.z, r.sw[ct][3] = v.w;
+        } else if constexpr (rec_sbytes == 8) {
+          const uint2 v = *reinterpret_cast<const uint2*>(sp);
+          r.sw[ct][0] = v.x, r.sw[ct][1] = v.y;
+        } else if constexpr (rec_sbytes == 4) {
+          r.sw[ct][0] = *reinterpret_cast<const uint32_t*>(sp);
+        } else {
+          r.sw[ct][0] = *reinterpret_cast<const uint16_t*>(sp);
+        }
+        if constexpr (ASYM) {
+          const int8_t* zp = p.zps + crow * p.zstride + nn * SPS;
+#pragma unroll
+          for (int e = 0; e < SPS; e++) r.zw[ct] |= uint32_t(uint8_t(zp[e])) << (8 * e);
+        }
+      }
+    }
+  };
+  uint4v pa[kPieces];
+  float psa[kSaPer];
+  // staging lane map: wave-instruction i of wave w covers kInstrRows whole rows of the chunk (1 KiB of A', contiguous per row);
+  // lane -> (row l / kRowPieces, slice l % kSL, k-group (l / kSL) % 4): eight consecutive lanes write eight consecutive 16-byte slots
+  const int st_row = (l / kRowPieces), st_sl = l % G::kSL, st_g = (l / G::kSL) & 3;
+  auto fetch_a = [&](int c0) {  // this thread's share of the chunk that starts at k-step c0
+#pragma unroll
+    for (int i = 0; i < kPieces; i++) {
+      const int row = r0 + (w + 4 * i) * kInstrRows + st_row, sl = c0 * NJ + st_sl;
+      pa[i] = uint4v{0, 0, 0, 0};
+      if (row < p.m && sl < pp.nsl) pa[i] = *reinterpret_cast<const uint4v*>(pp.pa + ((size_t(row) * pp.nsl + sl) * 4 + st_g) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < kSaPer; i++) {  // activation scales: idx -> (slice idx % kSL, row idx / kSL)
+      const int idx = tid + 256 * i;
+      const int row = r0 + idx / G::kSL, k0 = (c0 * NJ + idx % G::kSL) * 32;
+      psa[i] = 0.f;
+      if (row < p.m && k0 < p.k) psa[i] = p.ascale[size_t(row) * p.nblk + min(k0 / p.blocksize, p.nblk - 1)];
+    }
+  };
+  auto write_chunk = [&](unsigned char* buf) {  // registers -> LDS
+    float* sa_lds = reinterpret_cast<float*>(buf + kSaOff);
+#pragma unroll
+    for (int i = 0; i < kPieces; i++)
+      *reinterpret_cast<uint4v*>(buf + size_t(st_g) * G::kPlane + size_t((w + 4 * i) * kInstrRows + st_row) * G::kRow + st_sl * 16) = pa[i];
+#pragma unroll
+    for (int i = 0; i < kSaPer; i++) {
+      const int idx = tid + 256 * i;
+      sa_lds[(idx % G::kSL) * G::kSaStride + idx / G::kSL] = psa[i];
+    }
+  };
+  auto stage = [&](int c0) {  // single buffer: registers -> LDS for chunk c0 between two barriers, then the next chunk's loads
+    __syncthreads();          // the previous chunk is consumed
+    write_chunk(g2_smem);
+    __syncthreads();
+    if (c0 + CS < p.ksteps) fetch_a(c0 + CS);
+  };
+  // one k-step (four slices) of the staged chunk against the records in wc; t = its position in the chunk
+  auto kstep = [&](const KRec& wc, int s, int t, const unsigned char* a_lds) {
+    const float* sa_lds = reinterpret_cast<const float*>(a_lds + kSaOff);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int k0 = s * 128 + 32 * j;
+      if (k0 >= p.k) continue;
+      const int q = t * NJ + j;
+      const int e = (j * SPS) / NJ;  // a constant once the loops are unrolled
+      half8_t b[CT];
+      float sb[CT];
+      auto make_b = [&](int ct) {
+        if constexpr (SDT == 2) {
+          sb[ct] = __builtin_bit_cast(float, wc.sw[ct][e]);
+        } else {
+          const uint32_t h = (wc.sw[ct][e >> 1] >> (16 * (e & 1))) & 0xffffu;
+          sb[ct] = SDT == 0 ? __builtin_bit_cast(float, h << 16) : f16_bits_to_f32(h);
+        }
+        // B' as fp16.  The dword's nibbles 4s and 4s + 4 (s = 0 .. 3) are codes 2s and 2s + 1 of the lane's eight.
+        //   s = 0, 2:  (x >> 4s & 0x000f000f) | 0x6400 twice = 1024 + u;        minus 1024 + zbb     = u - zbb
+        //   s = 1, 3:  (x >> 4(s-1) & 0x00f000f0) | 0x6400 twice = 1024 + 16 u; minus 1024 + 16 zbb  = 16 (u - zbb), against A' / 16
+        uint32_t zbb = 8;
+        if constexpr (ASYM) zbb = uint32_t(8 + int(int8_t((wc.zw[ct] >> (8 * e)) & 0xffu)));
+        const half2_t z1 = __builtin_bit_cast(half2_t, (0x6400u + zbb) * 0x00010001u);
+        const half2_t z16 = __builtin_bit_cast(half2_t, (0x6400u + (zbb << 4)) * 0x00010001u);
+        const uint32_t x = j == 0 ? wc.rec[ct].x : (j == 1 ? wc.rec[ct].y : (j == 2 ? wc.rec[ct].z : wc.rec[ct].w));
+        const uint32_t y = x >> 8;
+        const uint32_t bw0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (x & 0x000f000fu) | magic) - z1);
+        const uint32_t bw1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (x & 0x00f000f0u) | magic) - z16);
+        const uint32_t bw2 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (y & 0x000f000fu) | magic) - z1);
+        const uint32_t bw3 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (y & 0x00f000f0u) | magic) - z16);
+        b[ct] = __builtin_bit_cast(half8_t, uint4v{bw0, bw1, bw2, bw3});
+      };
+      if constexpr (RH > 1) {  // shared by the row halves: all of them first
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) make_b(ct);
+      }
+#pragma unroll
+      for (int h = 0; h < RH; h++) {
+        half8_t a[4];
+        floatx4 sa[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) {
+          a[rt] = *reinterpret_cast<const half8_t*>(a_lds + size_t(g) * G::kPlane + size_t(h * 64 + rt * 16 + nn) * G::kRow + q * 16);
+          sa[rt] = *reinterpret_cast<const floatx4*>(sa_lds + q * G::kSaStride + h * 64 + rt * 16 + 4 * g);  // rows 4g .. 4g+3
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+          if constexpr (RH == 1) make_b(ct);  // one use: built right before it (registers)
+          const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+          floatx4 d[4];
+#pragma unroll
+          for (int rt = 0; rt < 4; rt++) d[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b[ct], zero, 0, 0, 0);
+          const float2v sb2 = {sb[ct], sb[ct]};
+#pragma unroll
+          for (int rt = 0; rt < 4; rt++) {
+            // fma(float(isum), scale_a * scale_b, acc), two accumulators per instruction (v_pk_mul_f32, v_pk_fma_f32)
+            acc[h][ct][rt][0] = __builtin_elementwise_fma(float2v{d[rt].x, d[rt].y}, float2v{sa[rt].x, sa[rt].y} * sb2, acc[h][ct][rt][0]);
+            acc[h][ct][rt][1] = __builtin_elementwise_fma(float2v{d[rt].z, d[rt].w}, float2v{sa[rt].z, sa[rt].w} * sb2, acc[h][ct][rt][1]);
+          }
+        }
+      }
+    }
+  };
+  KRec w0, w1;  // even and odd k-steps: each is refilled one k-step ahead of its use, across chunk boundaries as well
+  if (active) fetch_w(0, w0);
+  fetch_a(0);
+  if constexpr (G::kBufs == 2) {
+    static_assert(CS == 2, "two k-steps per chunk: the next chunk is written between them");
+    write_chunk(g2_smem);
+    if (CS < p.ksteps) fetch_a(CS);
+    for (int s = 0; s < p.ksteps; s += 2) {
+      unsigned char* cur = g2_smem + ((s >> 1) & 1) * G::kBuf;
+      unsigned char* nxt = g2_smem + (((s >> 1) & 1) ^ 1) * G::kBuf;
+      __syncthreads();  // chunk s / 2 is written by everyone, chunk s / 2 - 1 (the buffer written next) is consumed by everyone
+      if (active) {
+        fetch_w(s + 1, w1);  // (all zero beyond the last k-step)
+        kstep(w0, s, 0, cur);
+      }
+      if (s + 2 < p.ksteps) {
+        write_chunk(nxt);
+        if (s + 4 < p.ksteps) fetch_a(s + 4);
+      }
+      if (s + 1 < p.ksteps && active) {
+        fetch_w(s + 2, w0);
+        kstep(w1, s + 1, 1, cur);
+      }
+    }
+  } else {
+    for (int s = 0; s < p.ksteps; s += 2) {
+      stage(s);  // (CS = 2: the pair is one chunk)
+      if (active) {
+        fetch_w(s + 1, w1);  // (all zero beyond the last k-step)
+        kstep(w0, s, 0, g2_smem);
+      }
+      if (s + 1 >= p.ksteps) break;
+      if constexpr (CS == 1) stage(s + 1);
+      if (active) {
+        fetch_w(s + 2, w0);
+        kstep(w1, s + 1, CS == 1 ? 0 : 1, g2_smem);
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+    const int col = (tile0 + ct) * 16 + nn;
+    if (tile0 + ct >= ntiles || col >= p.n) continue;
+#pragma unroll
+    for (int h = 0; h < RH; h++)
+#pragma unroll
+      for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int row = r0 + h * 64 + rt * 16 + 4 * g + i;
+          if (row >= p.m) continue;
+          float v = (i & 1) ? acc[h][ct][rt][i >> 1].y : acc[h][ct][rt][i >> 1].x;
+          const float dv = p.d ? p.d[size_t(row) * p.ldd + col] : 0.f;
+          switch (p.epilogue) {
+            case 1: v = v + dv; break;
+            case 2: v = v * dv; break;
+            case 3: v = epi_gelu(v + dv); break;
+            case 4: v = epi_gelu(v); break;
+            case 5: v = epi_silu(v); break;
+            default: break;
+          }
+          p.c[size_t(row) * p.ldc + col] = v;
+          if (p.c16) p.c16[size_t(row) * p.ldc + col] = (_Float16)v;
+        }
+  }
+}
+
+template <int S, int D, int RH, int CT>
+hipError_t launch_i8mfma2_a(bool asym, dim3 grid, hipStream_t st, const I8Gemm2Params& p) {
+  auto go = [&](auto kern) {
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(I8G2Geom<RH>::kLds));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(kern, grid, dim3(256), I8G2Geom<RH>::kLds, st, p);
+    return hipGetLastError();
+  };
+  return asym ? go(i8mfma2_kernel<D, S, true, RH, CT>) : go(i8mfma2_kernel<D, S, false, RH, CT>);
+}
+template <int S, int RH, int CT>
+hipError_t launch_i8mfma2_t(int sdt, bool asym, int m, int ntiles, hipStream_t st, const I8Gemm2Params& p) {
+  const dim3 grid(unsigned((ntiles + 4 * CT - 1) / (4 * CT)), unsigned((m + 64 * RH - 1) / (64 * RH)));
+  if (sdt == 0) return launch_i8mfma2_a<S, 0, RH, CT>(asym, grid, st, p);
+  if (sdt == 1) return launch_i8mfma2_a<S, 1, RH, CT>(asym, grid, st, p);
+  return launch_i8mfma2_a<S, 2, RH, CT>(asym, grid, st, p);
+}
+template <int S>
+hipError_t launch_i8mfma2(int sdt, bool asym, int m, int ntiles, hipStream_t st, const I8Gemm2Params& p) {
+  // tile: "i8_tile" 0 = by size (128 x 128, else 64 x 256 workgroups once they still give every CU one), 1 = 64 x 64, 2 = 64 x 256,
+  // 3 = 128 x 128
+  const int force = g_i8_tile.load(std::memory_order_relaxed);
+  const bool big = size_t((ntiles + 7) / 8) * size_t((m + 127) / 128) >= 256;
+  const bool wide = size_t((ntiles + 15) / 16) * size_t((m + 63) / 64) >= 256;
+  const int tile = force ? force : (big ? 3 : (wide ? 2 : 1));
+  if (tile == 3) return launch_i8mfma2_t<S, 2, 2>(sdt, asym, m, ntiles, st, p);
+  if (tile == 2) return launch_i8mfma2_t<S, 1, 4>(sdt, asym, m, ntiles, st, p);
+  return launch_i8mfma2_t<S, 1, 1>(sdt, asym, m, ntiles, st, p);
+}
+
+// does the stream's A' scratch (slot 7) belong to its current activation codes (slot 4)?
+bool prep_valid(hipStream_t st, bool set, bool value = false) {
+  static std::mutex mu;
+  static std::map<hipStream_t, bool> valid;
+  std::lock_guard<std::mutex> lock(mu);
+  if (set) valid[st] = value;
+  auto it = valid.find(st);
+  return it != valid.end() && it->second;
+}
+
 }  // namespace
 
 // quantize_fp_u8_colblock(A) into the stream's scratch (slot 6) in the layout gemv_kernel's int8-reference variant stages:
@@ -484,6 +863,9 @@ hipError_t i8_quantize_for_decode(const float* a, int lda, const ns_weight* w, i
   return hipSuccess;
 }
 
+void set_i8_mfma_gen(int gen) { g_i8_mfma_gen.store(gen == 1 ? 1 : 2); }
+void set_i8_tile(int tile) { g_i8_tile.store(tile >= 1 && tile <= 3 ? tile : 0); }
+
 bool i8ref_supported(const ns_weight* w) {
   return (w->kind == WK_INT4 || w->kind == WK_INT8) && w->blocksize > 0 && (w->blocksize % 32 == 0 || w->blocksize >= w->k);
 }
@@ -504,9 +886,35 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   uint8_t* aq = base;
   float* as = reinterpret_cast<float*>(base + aq_bytes);
   uint8_t* az = base + aq_bytes + sc_bytes;
+  // GEMM-sized calls take the matrix-core kernels (NS_I8_MFMA_MIN_M rows and up, default 16; 0 disables them); nibble
+  // containers the second one: one exact fp16 MFMA per slice on operands with the zero points folded in ("i8_mfma" 1 /
+  // NS_I8_MFMA=1: the first kernel everywhere)
+  static const int mfma_min_m = [] {
+    const char* e = getenv("NS_I8_MFMA_MIN_M");
+    return e ? atoi(e) : 16;
+  }();
+  const bool four = w->kind != WK_INT8;
+  const bool mfma = mfma_min_m > 0 && m >= mfma_min_m && w->kstep_len == (four ? 128 : 64);
+  const bool v2 = mfma && four && g_i8_mfma_gen.load(std::memory_order_relaxed) != 1 && (w->sps == 4 || w->sps == 2 || w->sps == 1);
+  const int nsl = w->ksteps * 4;  // 32-deep slices per row of A'
+  uint8_t* pa = nullptr;
+  if (v2) {
+    pa = static_cast<uint8_t*>(stream_scratch(st, size_t(m) * nsl * 64, 7));
+    if (!pa) return hipErrorOutOfMemory;
+  }
   if (!reuse_aq) {
-    const hipError_t e = launch_aquant_u8(m, w->k, a, lda, aq, w->k, as, nblk, az, bs, nullptr, st);
+    hipError_t e = hipErrorNotSupported;
+    bool with_ap = false;
+    if (mfma) {  // the vector form of the quantizer; it writes A' as well when the rows need no padding (K a multiple of 128)
+      with_ap = v2 && w->k == nsl * 32;
+      e = launch_aquant_u8_vec(m, w->k, a, lda, aq, w->k, as, nblk, az, bs, with_ap ? pa : nullptr, nsl * 32, st);
+    }
+    if (e == hipErrorNotSupported) {
+      with_ap = false;
+      e = launch_aquant_u8(m, w->k, a, lda, aq, w->k, as, nblk, az, bs, nullptr, st);
+    }
     if (e != hipSuccess) return e;
+    prep_valid(st, true, with_ap);  // does slot 7 match slot 4?
   }
   I8RefParams p{};
   p.codes = reinterpret_cast<const uint8_t*>(w->codes);
@@ -517,7 +925,7 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   p.zstride = w->zstride;
   p.ksteps = w->ksteps;
   p.kstep_len = w->kstep_len;
-  p.nj = w->kind == WK_INT8 ? 2 : 4;
+  p.nj = four ? 4 : 2;
   p.sps = w->sps;
   p.srows = w->srows;
   if (!srow_params(w, &p.srow_mul, &p.srow_shift)) return hipErrorNotSupported;
@@ -533,16 +941,26 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   p.epilogue = epilogue;
   p.d = d;
   p.ldd = ldd;
-  // GEMM-sized calls take the matrix-core kernel (NS_I8_MFMA_MIN_M rows and up, default 16; 0 disables it)
-  static const int mfma_min_m = [] {
-    const char* e = getenv("NS_I8_MFMA_MIN_M");
-    return e ? atoi(e) : 16;
-  }();
-  if (mfma_min_m > 0 && m >= mfma_min_m && (w->kstep_len == (p.nj == 4 ? 128 : 64))) {
+  if (mfma) {
     const size_t lds = size_t(kGM) * kGRowStride + size_t(3) * kGSlices * kGM * 4;
     const dim3 grid(unsigned((w->ntiles + 3) / 4), unsigned((m + kGM - 1) / kGM));
     const int sdt = w->scale_dt == DT_BF16 ? 0 : (w->scale_dt == DT_F32 ? 2 : 1);
-    const bool four = p.nj == 4;
+    if (v2) {
+      I8Gemm2Params g2{};
+      g2.b = p;
+      g2.nsl = nsl;
+      g2.pa = pa;
+      if (!prep_valid(st, false)) {  // (a reused quantization consumed by other kernels so far, or rows that need padding)
+        const I8PrepParams pr{aq, az, pa, m, w->k, nsl, bs, nblk};
+        hipLaunchKernelGGL(i8prep_kernel, dim3(unsigned((size_t(m) * nsl * 4 + 255) / 256)), dim3(256), 0, st, pr);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        prep_valid(st, true, true);
+      }
+      if (w->sps == 4) return launch_i8mfma2<4>(sdt, w->asym, m, w->ntiles, st, g2);
+      if (w->sps == 2) return launch_i8mfma2<2>(sdt, w->asym, m, w->ntiles, st, g2);
+      return launch_i8mfma2<1>(sdt, w->asym, m, w->ntiles, st, g2);
+    }
     if (four && w->sps == 4) launch_i8mfma<true, 4>(sdt, w->asym, grid, lds, st, p);
     else if (four && w->sps == 2) launch_i8mfma<true, 2>(sdt, w->asym, grid, lds, st, p);
     else if (four && w->sps == 1) launch_i8mfma<true, 1>(sdt, w->asym, grid, lds, st, p);

@@ -630,6 +630,84 @@ __global__ void aquant_u8_coop_kernel(int row, int col, const float* __restrict_
     if (blkreduce) blkreduce[size_t(i) * ld_scale + kb] = __fmul_rn(float(sum), scale);
   }
 }
+// GEMM-sized calls: eight lanes per (row, k-block) again, but lane e takes the block's elements [e bs/8, (e + 1) bs/8) as
+// 16-byte loads and writes its codes as dwords (the form above stores single bytes).  The same per-element operations and
+// order-independent reductions: bit-identical.  Optionally the operand the int8-reference GEMM multiplies
+// (ns_i8ref.hip i8mfma2_kernel) next to the codes: ap[r][k] = fp16(code - zp), / 16 for k mod 8 in {2, 3, 6, 7}
+// (i8prep_kernel's output), so that kernel is not launched.
+// Needs blocksize % 32 == 0, col % blocksize == 0 and 16-byte / 4-byte aligned rows.
+typedef _Float16 aq_half2 __attribute__((ext_vector_type(2)));
+template <bool AP>
+__global__ __launch_bounds__(256) void aquant_u8_vec_kernel(int row, int col, const float* __restrict__ src, int ld_src,
+                                                            uint8_t* __restrict__ dst, int ld_dst, float* __restrict__ scales, int ld_scale,
+                                                            uint8_t* __restrict__ zps, int blocksize, uint16_t* __restrict__ ap, int ld_ap) {
+  const int nblk = col / blocksize;
+  const size_t gid = (size_t(blockIdx.x) * 256 + threadIdx.x) >> 3;
+  const int e = threadIdx.x & 7;
+  const bool live = gid < size_t(row) * nblk;  // whole lane groups are live or dead together
+  const int i = live ? int(gid / nblk) : 0, kb = live ? int(gid % nblk) : 0;
+  const int per = blocksize >> 3;  // elements of this lane: a multiple of four
+  const int j = kb * blocksize + e * per;
+  const float* s = src + size_t(i) * ld_src + j;
+  float maxval = FLT_MIN, minval = 0.f;
+  if (live)
+    for (int ij = 0; ij < per; ij += 4) {
+      const float4 f = *reinterpret_cast<const float4*>(s + ij);
+      const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        maxval = fv[t] > maxval ? fv[t] : maxval;  // std::max(f, maxval): NaN in f keeps maxval
+        minval = fv[t] < minval ? fv[t] : minval;
+      }
+    }
+#pragma unroll
+  for (int d = 1; d < 8; d <<= 1) {
+    const float om = __shfl_xor(maxval, d), on = __shfl_xor(minval, d);
+    maxval = om > maxval ? om : maxval;
+    minval = on < minval ? on : minval;
+  }
+  if (!live) return;
+  const float scale = __fdiv_rn(__fsub_rn(maxval, minval), 255.f);
+  const int zp = cast_f32_u8_x86(__fdiv_rn(__fsub_rn(0.f, minval), scale));
+  const float rscale = __fdiv_rn(1.f, scale);
+  const float zpf = float(zp);
+  uint8_t* d = dst + size_t(i) * ld_dst + j;
+  for (int ij = 0; ij < per; ij += 4) {
+    const float4 f = *reinterpret_cast<const float4*>(s + ij);  // (L1 / L2: the block was just read)
+    const float fv[4] = {f.x, f.y, f.z, f.w};
+    int c[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = cast_f32_u8_x86(__fadd_rn(zpf, float(cvt_round_int_x86(__fmul_rn(fv[t], rscale)))));
+    *reinterpret_cast<uint32_t*>(d + ij) = uint32_t(c[0]) | (uint32_t(c[1]) << 8) | (uint32_t(c[2]) << 16) | (uint32_t(c[3]) << 24);
+    if constexpr (AP) {  // small integers: exact in fp16, and so is the division by 16
+      const aq_half2 lo = {(_Float16)float(c[0] - zp), (_Float16)float(c[1] - zp)};
+      const aq_half2 hi = {(_Float16)(float(c[2] - zp) * 0.0625f), (_Float16)(float(c[3] - zp) * 0.0625f)};
+      *reinterpret_cast<uint2*>(ap + size_t(i) * ld_ap + j + ij) = uint2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+    }
+  }
+  if (e == 0) {
+    scales[size_t(i) * ld_scale + kb] = scale;
+    zps[size_t(i) * ld_scale + kb] = uint8_t(zp);
+  }
+}
+// codes + scales + zero points, and (ap != nullptr) the fp16 operand of i8mfma2_kernel with row stride ld_ap halves;
+// hipErrorNotSupported when the shape is outside the vector kernel's envelope (the caller then takes launch_aquant_u8)
+hipError_t launch_aquant_u8_vec(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
+                                int ld_scale, uint8_t* zps, int blocksize, void* ap, int ld_ap, hipStream_t st) {
+  if (blocksize <= 0 || blocksize % 32 != 0 || col % blocksize != 0 || (ld_src & 3) || (reinterpret_cast<uintptr_t>(src) & 15) ||
+      (ld_dst & 3) || (reinterpret_cast<uintptr_t>(dst) & 3) || (ap && ((ld_ap & 3) || (reinterpret_cast<uintptr_t>(ap) & 7))))
+    return hipErrorNotSupported;
+  const size_t total = size_t(row) * (col / blocksize);
+  if (total == 0) return hipSuccess;
+  if (ap)
+    hipLaunchKernelGGL(aquant_u8_vec_kernel<true>, grid1d(total * 8, 256), dim3(256), 0, st, row, col, src, ld_src, dst, ld_dst, scales,
+                       ld_scale, zps, blocksize, static_cast<uint16_t*>(ap), ld_ap);
+  else
+    hipLaunchKernelGGL(aquant_u8_vec_kernel<false>, grid1d(total * 8, 256), dim3(256), 0, st, row, col, src, ld_src, dst, ld_dst, scales,
+                       ld_scale, zps, blocksize, static_cast<uint16_t*>(nullptr), 0);
+  return hipGetLastError();
+}
+
 hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
                             int ld_scale, uint8_t* zps, int blocksize, float* blkreduce, hipStream_t st) {
   const int nblk = (col + blocksize - 1) / blocksize;

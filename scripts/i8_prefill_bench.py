@@ -1,5 +1,5 @@
 """NS_COMPUTE_REF_INT8 at prefill size: M = 2048 rows through a Llama-2-7B weight in the reference's int8-compute
-semantics (activation quantizer + i8mfma_kernel), graph-timed.  Prints one JSON line."""
+semantics (activation quantizer + the matrix-core kernels of ns_i8ref.hip: "i8_mfma" 1 and 2), event-timed.  Prints one JSON line."""
 import ctypes as C
 import json
 import os
@@ -26,23 +26,31 @@ for name, (n, k, qt, bs) in {"int4_g32_4096x4096": (4096, 4096, pkg.S4, 32), "in
     a = torch.randn((m, k), device="cuda")
     c = torch.zeros((m, n), device="cuda")
     res = {}
-    for mode in (1, 0):
+    for mode, gen, tile in ((1, 1, 0), (1, 2, 2), (1, 2, 3), (0, 0, 0)):
         L.ns_hip_set_compute_mode(mode)
+        if gen:
+            L.ns_hip_set_tuning(b"i8_mfma", gen)
+            L.ns_hip_set_tuning(b"i8_tile", tile)
 
         def run():
             pkg.check(L.ns_hip_f32f32_forward(a.data_ptr(), wt.h, c.data_ptr(), m, k, n, pkg.EPI_NONE, None, 0, st))
-        for _ in range(3):
+        for _ in range(25):
             run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 10
+        iters = 25
         e0.record()
         for _ in range(iters):
             run()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        res["int8_semantics" if mode else "fp16_default"] = {"ms": round(ms, 4), "tflops": round(2.0 * m * n * k / ms / 1e9, 1)}
+        key = ("int8_semantics_kernel%d" % gen + ("_tile%d" % tile if tile else "")) if mode else "fp16_default"
+        res[key] = {"ms": round(ms, 4), "tflops": round(2.0 * m * n * k / ms / 1e9, 1)}
+        if gen:
+            res[key]["checksum"] = float(c.double().abs().sum().item())
+    L.ns_hip_set_tuning(b"i8_mfma", 2)
+    L.ns_hip_set_tuning(b"i8_tile", 0)
     L.ns_hip_set_compute_mode(0)
     out[name] = res
 print(json.dumps({"m": 2048, "results": out}))

@@ -46,7 +46,8 @@ def test_int8_mode_matches_reference_int8_semantics(L, pkg, nso, int8_mode, qt, 
 @pytest.mark.parametrize("qt,st,asym,bs,n,k,core", CASES)
 @pytest.mark.parametrize("m", [16, 77, 200])
 def test_int8_mode_gemm_sized_calls_run_on_the_matrix_cores(L, pkg, nso, int8_mode, qt, st, asym, bs, n, k, core, m):
-    """16 rows and up take i8mfma_kernel (v_mfma_i32_16x16x32_i8 per 32-deep slice, exact integer corrections): the same
+    """16 rows and up take the matrix-core kernels (nibble containers: i8mfma2_kernel, one v_mfma_i32_16x16x64_i8 per 32-deep
+    slice on zero-point-folded operands; byte containers: i8mfma_kernel, v_mfma_i32_16x16x32_i8 + exact integer corrections): the same
     numbers as the decode-sized kernel — ragged M (row tiles of 16 inside workgroups of 64), ragged N, K tails, asymmetric
     weights, byte containers, per-channel blocks"""
     rng = np.random.default_rng(n * 7 + k * 3 + m)
@@ -61,6 +62,61 @@ def test_int8_mode_gemm_sized_calls_run_on_the_matrix_cores(L, pkg, nso, int8_mo
     # row by row as well: a wrong row tile must not hide behind the large row
     per_row = np.sqrt(((out - ref) ** 2).sum(-1) / np.maximum((ref.astype(np.float64) ** 2).sum(-1), 1e-30))
     assert per_row.max() < 1e-5, (int(per_row.argmax()), per_row.max())
+
+
+NIBBLE_CASES = [c for c in CASES if c[0] in ("S4", "S3")]
+
+
+@pytest.mark.parametrize("qt,st,asym,bs,n,k,core", NIBBLE_CASES)
+@pytest.mark.parametrize("m", [16, 77, 200])
+def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, int8_mode, qt, st, asym, bs, n, k, core, m):
+    """i8mfma2_kernel (one fp16 MFMA per slice on operands with both zero points folded in: fp16(a - za) against fp16(u - zbb),
+    every product and partial sum an integer below 2^24, so the MFMA returns float(isum) exactly) and i8mfma_kernel (integer MFMA
+    + integer corrections per accumulator) form the same exact integer per slice and the same fp32 expression in the same
+    order: equal bit for bit, in every workgroup tile of the second kernel.  Rows that drive the folding to its corners included:
+    all-positive / all-negative rows (zero point 0 / 255, a - za = +-255) and a constant row."""
+    rng = np.random.default_rng(n * 5 + k + m)
+    w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    a[0] = np.abs(a[0]) + 0.5
+    a[1] = -np.abs(a[1]) - 0.5
+    a[2] = 3.0
+    a[3, ::2] = 0.0
+    blob = nso.quant_pack(w, bs, getattr(nso, qt), getattr(nso, st), asym, getattr(nso, core))
+    outs = {}
+    try:
+        for gen, tile in ((1, 0), (2, 1), (2, 2), (2, 3)):  # the second kernel in each of its workgroup tiles
+            assert L.ns_hip_set_tuning(b"i8_mfma", gen) == 0
+            assert L.ns_hip_set_tuning(b"i8_tile", tile) == 0
+            o = np.full((m, n), 7.0, np.float32)
+            L.bestla_f32f32_forward(nso.ptr(a), nso.ptr(blob), nso.ptr(o), m, n, k, k, n, None)
+            outs[(gen, tile)] = o
+    finally:
+        L.ns_hip_set_tuning(b"i8_mfma", 2)
+        L.ns_hip_set_tuning(b"i8_tile", 0)
+    for tile in (1, 2, 3):
+        assert np.array_equal(outs[(1, 0)].view(np.uint32), outs[(2, tile)].view(np.uint32)), (tile, np.abs(outs[(1, 0)] - outs[(2, tile)]).max())
+    assert nso.rel_l2(outs[(2, 2)], nso.gemm_u8s8(a, blob)) < 2e-6
+
+
+def test_int8_mode_fused_qkv_at_gemm_size_prepares_the_activations_once(L, pkg, nso, int8_mode):
+    """the fused QKV entry at GEMM size: one activation quantization and one operand preparation ([p | r], i8prep_kernel)
+    for the three weights, as the reference quantizes A once (ip_fusion_qkv.cpp:84-86)"""
+    import torch
+    rng = np.random.default_rng(17)
+    n, k, m, bs = 192, 640, 70, 32
+    mk = lambda: nso.quant_pack((rng.standard_normal((n, k)) * 0.05).astype(np.float32), bs, nso.S4, nso.BF16, False,
+                                nso.CORE_AVX512_VNNI_KB)
+    blobs = [mk(), mk(), mk()]
+    ws = [pkg.Weight.from_host_blob(nso.ptr(b)) for b in blobs]
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    dA = torch.from_numpy(a).cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dC = torch.zeros((3, m, n), device="cuda")
+    pkg.check(L.ns_hip_fusion_qkv_forward(dA.data_ptr(), ws[0].h, ws[1].h, ws[2].h, dC.data_ptr(), m, k, n, st))
+    torch.cuda.synchronize()
+    for i, b in enumerate(blobs):
+        assert nso.rel_l2(dC[i].cpu().numpy(), nso.gemm_u8s8(a, b)) < 2e-6
 
 
 def test_int8_mode_device_entries_and_epilogues(L, pkg, nso, int8_mode):
