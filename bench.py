@@ -782,7 +782,8 @@ PREFILL_WARMUP, PREFILL_REPS = 80, 60
 
 def prefill_tflops_ref_int8(chain, pkg, m=2048):
     """the same seven GEMMs (int4 g32 weights) in the reference's DEFAULT int8-compute semantics (NS_COMPUTE_REF_INT8: u8
-    activation quantization per k-block + exact integer dots on the int8 matrix cores, ns_i8ref.hip i8mfma_kernel); the
+    activation quantization per k-block + exact integer dots per 32-deep slice on the matrix cores — ns_i8ref.hip
+    i8mfma2_kernel: fp16 operands holding the integers a - za and u - zb, so one MFMA returns float(isum) exactly); the
     activation quantizer is inside the timed region.  TFLOPS-equivalent (2 m n k)."""
     L = pkg.lib()
     prev = L.ns_hip_set_compute_mode(1)
