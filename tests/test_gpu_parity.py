@@ -278,6 +278,39 @@ def test_activation_u8_quantize_bit_exact(L, pkg, nso, m, k, bs):
     assert np.array_equal(dred.cpu().numpy().view(np.uint32), red.view(np.uint32))
 
 
+@pytest.mark.parametrize("m,k,bs,pad", [(64, 4096, 32, 4), (33, 1024, 128, 8), (16, 512, 64, 0), (40, 256, 256, 12)])
+def test_activation_u8_quantize_gemm_sized_form_bit_exact(L, pkg, nso, m, k, bs, pad):
+    """a9 at GEMM size (16 rows and up, no block sums): the vector form of the quantizer (aquant_u8_vec_kernel: 16-byte loads,
+    dword stores, eight lanes per k-block) == the oracle byte for byte: codes, scales, zero points; all-zero, one-sided and
+    constant blocks included."""
+    import torch
+    import ctypes as C
+    rng = np.random.default_rng(m * 17 + k)
+    a = (rng.standard_normal((m, k + pad)) * rng.uniform(0.01, 30.0, (m, 1))).astype(np.float32)
+    a[0, :bs] = 0.0
+    a[1, :bs] = np.abs(a[1, :bs])
+    a[2, :bs] = -np.abs(a[2, :bs])
+    a[3, :bs] = 2.5
+    nblk = k // bs
+    q = np.zeros((m, k), np.uint8)
+    sc = np.zeros((m, nblk), np.float32)
+    zp = np.zeros((m, nblk), np.uint8)
+    red = np.zeros((m, nblk), np.float32)
+    assert nso.lib().nso_quantize_fp_u8_colblock(m, k, nso.ptr(a), k + pad, nso.ptr(q), k, nso.ptr(sc), nblk, nso.ptr(zp), bs,
+                                                 nso.ptr(red)) == 0
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    da = torch.from_numpy(a).cuda()
+    dq = torch.zeros((m, k), dtype=torch.uint8, device="cuda")
+    dsc = torch.zeros((m, nblk), device="cuda")
+    dzp = torch.zeros((m, nblk), dtype=torch.uint8, device="cuda")
+    pkg.check(L.ns_hip_quantize_fp_u8_colblock(m, k, da.data_ptr(), k + pad, dq.data_ptr(), k, dsc.data_ptr(), nblk,
+                                               dzp.data_ptr(), bs, None, st))
+    torch.cuda.synchronize()
+    assert np.array_equal(dq.cpu().numpy(), q)
+    assert np.array_equal(dsc.cpu().numpy().view(np.uint32), sc.view(np.uint32))
+    assert np.array_equal(dzp.cpu().numpy(), zp)
+
+
 def test_forward_lda_and_uniform_distribution(L, pkg, nso):
     rng = np.random.default_rng(77)
     n, k, bs, m = 128, 768, 32, 3
