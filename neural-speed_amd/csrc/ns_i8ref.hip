@@ -567,19 +567,21 @@ struct I8Gemm2Params {
 //   (1, 4)  64 x 256: mid-size problems.  Double-buffered 256-deep chunks: one barrier per chunk, staging writes between its two
 //           k-steps.  5 - 10 % behind (2, 2) at 2048 x 4096 x 4096 (profiles/r03_i8_prefill_kernels.txt)
 //   (1, 1)  64 x 64, double-buffered: small problems (four times the workgroups)
-template <int SDT, int SPS, bool ASYM, int RH, int CT>
-__global__ __launch_bounds__(256, 2) void i8mfma2_kernel(const I8Gemm2Params pp) {
+template <int SDT, int SPS, bool ASYM, int RH, int CT, int WV>
+__global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const I8Gemm2Params pp) {
   using G = I8G2Geom<RH>;
   const I8RefParams& p = pp.b;
   constexpr int NJ = 4, CS = G::kSL / NJ;             // four 32-deep slices per k-step record; k-steps per chunk: 2 / 1
-  constexpr int kPieces = G::kRows * G::kSL * 4 / 256;  // 16-byte A' pieces per thread and chunk: 8
+  constexpr int kThreads = 64 * WV;
+  constexpr int kPieces = G::kRows * G::kSL * 4 / kThreads;  // 16-byte A' pieces per thread and chunk: 8 (2 with sixteen waves)
   constexpr int kRowPieces = G::kSL * 4;                // pieces per row and chunk: 32 / 16
   constexpr int kInstrRows = 64 / kRowPieces;           // rows one wave-instruction of the staging covers: 2 / 4
-  constexpr int kSaPer = G::kRows * G::kSL / 256;       // activation scales per thread and chunk: 2
+  constexpr int kSaAll = G::kRows * G::kSL;             // activation scales per chunk: 512
+  constexpr int kSaPer = (kSaAll + kThreads - 1) / kThreads;  // per thread: 2 (1 for the first half of sixteen waves)
   extern __shared__ __attribute__((aligned(16))) unsigned char g2_smem[];
   constexpr size_t kSaOff = size_t(4) * G::kPlane;  // the scale plane behind the four A' planes of a buffer
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nn = l & 15, g = l >> 4;
-  const int tile0 = (blockIdx.x * 4 + w) * CT;
+  const int tile0 = (blockIdx.x * WV + w) * CT;
   const int ntiles = (p.n + 15) / 16;
   const bool active = tile0 < ntiles;
   const int r0 = blockIdx.y * G::kRows;
@@ -637,27 +639,27 @@ __global__ __launch_bounds__(256, 2) void i8mfma2_kernel(const I8Gemm2Params pp)
   auto fetch_a = [&](int c0) {  // this thread's share of the chunk that starts at k-step c0
 #pragma unroll
     for (int i = 0; i < kPieces; i++) {
-      const int row = r0 + (w + 4 * i) * kInstrRows + st_row, sl = c0 * NJ + st_sl;
+      const int row = r0 + (w + WV * i) * kInstrRows + st_row, sl = c0 * NJ + st_sl;
       pa[i] = uint4v{0, 0, 0, 0};
       if (row < p.m && sl < pp.nsl) pa[i] = *reinterpret_cast<const uint4v*>(pp.pa + ((size_t(row) * pp.nsl + sl) * 4 + st_g) * 16);
     }
 #pragma unroll
     for (int i = 0; i < kSaPer; i++) {  // activation scales: idx -> (slice idx % kSL, row idx / kSL)
-      const int idx = tid + 256 * i;
+      const int idx = tid + kThreads * i;
       const int row = r0 + idx / G::kSL, k0 = (c0 * NJ + idx % G::kSL) * 32;
       psa[i] = 0.f;
-      if (row < p.m && k0 < p.k) psa[i] = p.ascale[size_t(row) * p.nblk + min(k0 / p.blocksize, p.nblk - 1)];
+      if (idx < kSaAll && row < p.m && k0 < p.k) psa[i] = p.ascale[size_t(row) * p.nblk + min(k0 / p.blocksize, p.nblk - 1)];
     }
   };
   auto write_chunk = [&](unsigned char* buf) {  // registers -> LDS
     float* sa_lds = reinterpret_cast<float*>(buf + kSaOff);
 #pragma unroll
     for (int i = 0; i < kPieces; i++)
-      *reinterpret_cast<uint4v*>(buf + size_t(st_g) * G::kPlane + size_t((w + 4 * i) * kInstrRows + st_row) * G::kRow + st_sl * 16) = pa[i];
+      *reinterpret_cast<uint4v*>(buf + size_t(st_g) * G::kPlane + size_t((w + WV * i) * kInstrRows + st_row) * G::kRow + st_sl * 16) = pa[i];
 #pragma unroll
     for (int i = 0; i < kSaPer; i++) {
-      const int idx = tid + 256 * i;
-      sa_lds[(idx % G::kSL) * G::kSaStride + idx / G::kSL] = psa[i];
+      const int idx = tid + kThreads * i;
+      if (idx < kSaAll) sa_lds[(idx % G::kSL) * G::kSaStride + idx / G::kSL] = psa[i];
     }
   };
   auto stage = [&](int c0) {  // single buffer: registers -> LDS for chunk c0 between two barriers, then the next chunk's loads
@@ -798,35 +800,36 @@ __global__ __launch_bounds__(256, 2) void i8mfma2_kernel(const I8Gemm2Params pp)
   }
 }
 
-template <int S, int D, int RH, int CT>
+template <int S, int D, int RH, int CT, int WV>
 hipError_t launch_i8mfma2_a(bool asym, dim3 grid, hipStream_t st, const I8Gemm2Params& p) {
   auto go = [&](auto kern) {
     static const hipError_t attr =
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(I8G2Geom<RH>::kLds));
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(kern, grid, dim3(256), I8G2Geom<RH>::kLds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WV), I8G2Geom<RH>::kLds, st, p);
     return hipGetLastError();
   };
-  return asym ? go(i8mfma2_kernel<D, S, true, RH, CT>) : go(i8mfma2_kernel<D, S, false, RH, CT>);
+  return asym ? go(i8mfma2_kernel<D, S, true, RH, CT, WV>) : go(i8mfma2_kernel<D, S, false, RH, CT, WV>);
 }
-template <int S, int RH, int CT>
+template <int S, int RH, int CT, int WV>
 hipError_t launch_i8mfma2_t(int sdt, bool asym, int m, int ntiles, hipStream_t st, const I8Gemm2Params& p) {
-  const dim3 grid(unsigned((ntiles + 4 * CT - 1) / (4 * CT)), unsigned((m + 64 * RH - 1) / (64 * RH)));
-  if (sdt == 0) return launch_i8mfma2_a<S, 0, RH, CT>(asym, grid, st, p);
-  if (sdt == 1) return launch_i8mfma2_a<S, 1, RH, CT>(asym, grid, st, p);
-  return launch_i8mfma2_a<S, 2, RH, CT>(asym, grid, st, p);
+  const dim3 grid(unsigned((ntiles + WV * CT - 1) / (WV * CT)), unsigned((m + 64 * RH - 1) / (64 * RH)));
+  if (sdt == 0) return launch_i8mfma2_a<S, 0, RH, CT, WV>(asym, grid, st, p);
+  if (sdt == 1) return launch_i8mfma2_a<S, 1, RH, CT, WV>(asym, grid, st, p);
+  return launch_i8mfma2_a<S, 2, RH, CT, WV>(asym, grid, st, p);
 }
 template <int S>
 hipError_t launch_i8mfma2(int sdt, bool asym, int m, int ntiles, hipStream_t st, const I8Gemm2Params& p) {
   // tile: "i8_tile" 0 = by size (128 x 128, else 64 x 256 workgroups once they still give every CU one), 1 = 64 x 64, 2 = 64 x 256,
-  // 3 = 128 x 128
+  // 3 = 128 x 128, 4 = 64 x 256 as sixteen waves of one 16-column tile each
   const int force = g_i8_tile.load(std::memory_order_relaxed);
   const bool big = size_t((ntiles + 7) / 8) * size_t((m + 127) / 128) >= 256;
   const bool wide = size_t((ntiles + 15) / 16) * size_t((m + 63) / 64) >= 256;
   const int tile = force ? force : (big ? 3 : (wide ? 2 : 1));
-  if (tile == 3) return launch_i8mfma2_t<S, 2, 2>(sdt, asym, m, ntiles, st, p);
-  if (tile == 2) return launch_i8mfma2_t<S, 1, 4>(sdt, asym, m, ntiles, st, p);
-  return launch_i8mfma2_t<S, 1, 1>(sdt, asym, m, ntiles, st, p);
+  if (tile == 4) return launch_i8mfma2_t<S, 1, 1, 16>(sdt, asym, m, ntiles, st, p);
+  if (tile == 3) return launch_i8mfma2_t<S, 2, 2, 4>(sdt, asym, m, ntiles, st, p);
+  if (tile == 2) return launch_i8mfma2_t<S, 1, 4, 4>(sdt, asym, m, ntiles, st, p);
+  return launch_i8mfma2_t<S, 1, 1, 4>(sdt, asym, m, ntiles, st, p);
 }
 
 // does the stream's A' scratch (slot 7) belong to its current activation codes (slot 4)?
@@ -864,7 +867,7 @@ hipError_t i8_quantize_for_decode(const float* a, int lda, const ns_weight* w, i
 }
 
 void set_i8_mfma_gen(int gen) { g_i8_mfma_gen.store(gen == 1 ? 1 : 2); }
-void set_i8_tile(int tile) { g_i8_tile.store(tile >= 1 && tile <= 3 ? tile : 0); }
+void set_i8_tile(int tile) { g_i8_tile.store(tile >= 1 && tile <= 4 ? tile : 0); }
 
 bool i8ref_supported(const ns_weight* w) {
   return (w->kind == WK_INT4 || w->kind == WK_INT8) && w->blocksize > 0 && (w->blocksize % 32 == 0 || w->blocksize >= w->k);

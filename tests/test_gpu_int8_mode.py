@@ -85,7 +85,7 @@ def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, in
     blob = nso.quant_pack(w, bs, getattr(nso, qt), getattr(nso, st), asym, getattr(nso, core))
     outs = {}
     try:
-        for gen, tile in ((1, 0), (2, 1), (2, 2), (2, 3)):  # the second kernel in each of its workgroup tiles
+        for gen, tile in ((1, 0), (2, 1), (2, 2), (2, 3), (2, 4)):  # the second kernel in each of its workgroup tiles
             assert L.ns_hip_set_tuning(b"i8_mfma", gen) == 0
             assert L.ns_hip_set_tuning(b"i8_tile", tile) == 0
             o = np.full((m, n), 7.0, np.float32)
@@ -94,7 +94,7 @@ def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, in
     finally:
         L.ns_hip_set_tuning(b"i8_mfma", 2)
         L.ns_hip_set_tuning(b"i8_tile", 0)
-    for tile in (1, 2, 3):
+    for tile in (1, 2, 3, 4):
         assert np.array_equal(outs[(1, 0)].view(np.uint32), outs[(2, tile)].view(np.uint32)), (tile, np.abs(outs[(1, 0)] - outs[(2, tile)]).max())
     assert nso.rel_l2(outs[(2, 2)], nso.gemm_u8s8(a, blob)) < 2e-6
 
