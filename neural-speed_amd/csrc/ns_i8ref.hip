@@ -560,13 +560,16 @@ struct I8Gemm2Params {
   int nsl;            // slices per row of it
 };
 
-// Tile: a workgroup covers 64 RH rows x 64 CT columns, each of its four waves all the rows and CT 16-column tiles.
-//   (2, 2)  128 x 128: the large-problem shape.  Every B' fragment (VALU work) feeds eight MFMAs, every byte of A' staged two per
-//           wave; L2 / fabric traffic per flop is half of the 64 x 64 workgroup's, which bounded the first version of this kernel
-//           at 6 TB/s of cache traffic.  One 128-deep chunk in LDS (43 KB; two would not fit twice per CU)
-//   (1, 4)  64 x 256: mid-size problems.  Double-buffered 256-deep chunks: one barrier per chunk, staging writes between its two
-//           k-steps.  5 - 10 % behind (2, 2) at 2048 x 4096 x 4096 (profiles/r03_i8_prefill_kernels.txt)
-//   (1, 1)  64 x 64, double-buffered: small problems (four times the workgroups)
+// Tile: a workgroup of WV waves covers 64 RH rows x 16 CT WV columns; each wave all the rows and CT 16-column tiles.
+//   (1, 1, 16)  64 x 256 as sixteen waves: the large-problem shape.  112 VGPRs: four waves per SIMD, which is what this
+//               kernel needs — its MFMA, LDS and VALU work per slice are each a third of the time and do not overlap inside
+//               one wave.  Every byte of A' staged feeds sixteen waves; L2 / fabric traffic per flop is 40 % of the
+//               64 x 64 workgroup's (the first version of this kernel sat at 6 TB/s of cache traffic).  Chunks
+//               double-buffered in LDS: one barrier per 256-deep chunk, staging writes between its two k-steps
+//   (2, 2, 4)   128 x 128, four waves of 128 x 32: every B' fragment (VALU work) feeds eight MFMAs, but 248 VGPRs (two waves
+//               per SIMD): 10 - 12 % behind at 2048 x 4096 x 4096.  (1, 4, 4): 64 x 256 as four waves: 20 % behind.  Both kept
+//               for A-B runs ("i8_tile" 3 / 2; profiles/r03_i8_prefill_kernels.json)
+//   (1, 1, 4)   64 x 64, double-buffered: small problems (four times the workgroups)
 template <int SDT, int SPS, bool ASYM, int RH, int CT, int WV>
 __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const I8Gemm2Params pp) {
   using G = I8G2Geom<RH>;
@@ -820,12 +823,11 @@ hipError_t launch_i8mfma2_t(int sdt, bool asym, int m, int ntiles, hipStream_t s
 }
 template <int S>
 hipError_t launch_i8mfma2(int sdt, bool asym, int m, int ntiles, hipStream_t st, const I8Gemm2Params& p) {
-  // tile: "i8_tile" 0 = by size (128 x 128, else 64 x 256 workgroups once they still give every CU one), 1 = 64 x 64, 2 = 64 x 256,
-  // 3 = 128 x 128, 4 = 64 x 256 as sixteen waves of one 16-column tile each
+  // tile: "i8_tile" 0 = by size (4 once 64 x 256 workgroups give every CU one, else 1), 1 = 64 x 64, 2 = 64 x 256 as four waves of four
+  // column tiles, 3 = 128 x 128, 4 = 64 x 256 as sixteen waves of one column tile each
   const int force = g_i8_tile.load(std::memory_order_relaxed);
-  const bool big = size_t((ntiles + 7) / 8) * size_t((m + 127) / 128) >= 256;
   const bool wide = size_t((ntiles + 15) / 16) * size_t((m + 63) / 64) >= 256;
-  const int tile = force ? force : (big ? 3 : (wide ? 2 : 1));
+  const int tile = force ? force : (wide ? 4 : 1);
   if (tile == 4) return launch_i8mfma2_t<S, 1, 1, 16>(sdt, asym, m, ntiles, st, p);
   if (tile == 3) return launch_i8mfma2_t<S, 2, 2, 4>(sdt, asym, m, ntiles, st, p);
   if (tile == 2) return launch_i8mfma2_t<S, 1, 4, 4>(sdt, asym, m, ntiles, st, p);

@@ -26,7 +26,7 @@ for name, (n, k, qt, bs) in {"int4_g32_4096x4096": (4096, 4096, pkg.S4, 32), "in
     a = torch.randn((m, k), device="cuda")
     c = torch.zeros((m, n), device="cuda")
     res = {}
-    for mode, gen, tile in ((1, 1, 0), (1, 2, 2), (1, 2, 3), (1, 2, 4), (0, 0, 0)):
+    for mode, gen, tile in ((1, 1, 0), (1, 2, 2), (1, 2, 3), (1, 2, 4), (1, 2, 0), (0, 0, 0)):
         L.ns_hip_set_compute_mode(mode)
         if gen:
             L.ns_hip_set_tuning(b"i8_mfma", gen)
@@ -45,7 +45,7 @@ for name, (n, k, qt, bs) in {"int4_g32_4096x4096": (4096, 4096, pkg.S4, 32), "in
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        key = ("int8_semantics_kernel%d" % gen + ("_tile%d" % tile if tile else "")) if mode else "fp16_default"
+        key = ("int8_semantics_kernel%d" % gen + ("_tile%d" % tile if tile else ("_default" if gen == 2 else ""))) if mode else "fp16_default"
         res[key] = {"ms": round(ms, 4), "tflops": round(2.0 * m * n * k / ms / 1e9, 1)}
         if gen:
             res[key]["checksum"] = float(c.double().abs().sum().item())
