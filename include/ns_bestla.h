@@ -187,11 +187,11 @@ int ns_hip_get_compute_mode(void);
 /* Diagnostics / A-B switches of the kernels (process-wide, take effect at the next launch or capture):
  *   "gemv2"           0 = first-generation decode kernel only, 1 = gemv_kernel (default); also NS_GEMV2 in the environment
  *   "g3_bm"           row-tile height of the prefill GEMM (128 / 256), 0 = automatic
- *   "i8_mfma"         NS_COMPUTE_REF_INT8 at 16 rows and up, nibble containers: 2 = one exact fp16 MFMA per 32-deep slice on
+ *   "i8_mfma"         NS_COMPUTE_REF_INT8 at 16 rows and up: 2 = one exact fp16 MFMA per 32-deep slice on
  *                     operands with both zero points folded in (default), 1 = the first kernel (integer MFMA + corrections
  *                     per accumulator); bit-identical results; also NS_I8_MFMA in the environment
  *   "i8_tile"         workgroup tile of that kernel: 0 = by problem size (default), 1 = 64 x 64, 2 = 64 x 256 (four waves),
- *                     3 = 128 x 128, 4 = 64 x 256 (sixteen waves; what large problems take)
+ *                     3 = 128 x 128, 4 = 64 x 256 (sixteen waves; what large problems take); 2 and 3 exist for nibble containers only
  *   "attn_wg_target", "attn_min_keys"   context-split rule of the decode attention kernel (defaults 1024, 128)
  *   "gv_nw"           waves per 16-column tile of the decode kernels (2 / 4 / 8 / 16), 0 = by shape (default); the
  *                     partial sums of a tile are added in wave order, so this selects the summation order

@@ -1157,7 +1157,7 @@ int ns_hip_quantize_fp_u8_colblock(int row, int col, const float* dSrc, int ld_s
   }
   if (!dBlkReduce && row >= 16) {  // GEMM-sized, no block sums wanted: the vector form (bit-identical codes, scales, zero points)
     const hipError_t e = launch_aquant_u8_vec(row, col, dSrc, ld_src, dDst, ld_dst, dScales, ld_scale, dZps, blocksize, nullptr, 0,
-                                              (hipStream_t)stream);
+                                              false, (hipStream_t)stream);
     if (e != hipErrorNotSupported) return hip_ok(e, "activation quantize launch") ? 0 : -1;
   }
   return hip_ok(launch_aquant_u8(row, col, dSrc, ld_src, dDst, ld_dst, dScales, ld_scale, dZps, blocksize, dBlkReduce,

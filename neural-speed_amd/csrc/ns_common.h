@@ -245,7 +245,7 @@ hipError_t launch_aquant_u8(int row, int col, const float* src, int ld_src, uint
                             int ld_scale, uint8_t* zps, int blocksize, float* blkreduce, hipStream_t st);
 // GEMM-sized form (16-byte loads, dword stores; bit-identical codes), optionally with the fp16 operand of the int8-reference GEMM
 hipError_t launch_aquant_u8_vec(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
-                                int ld_scale, uint8_t* zps, int blocksize, void* ap, int ld_ap, hipStream_t st);
+                                int ld_scale, uint8_t* zps, int blocksize, void* ap, int ld_ap, bool ap_scale16, hipStream_t st);
 // A'[r][j] = A[r][idx[j]] (kernel_ref.h:28-37 shuffle_activation), fp32 [m][k] with leading dimension k
 hipError_t launch_gather_cols(const float* a, int lda, const int* idx, float* out, int m, int k, hipStream_t st);
 // default-policy read of [offset, offset + bytes) of the weight's stream (codes, scales, zero points) into the cache

@@ -472,13 +472,14 @@ void launch_i8mfma(int sdt, bool asym, dim3 grid, size_t lds, hipStream_t st, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Second matrix-core kernel (nibble containers, the Q4_0 case): the whole integer sum of a 32-deep slice out of ONE
+// Second matrix-core kernel (nibble containers — the Q4_0 case — and byte containers): the whole integer sum of a 32-deep slice out of ONE
 // MFMA, already an fp32 number, nothing to correct or convert per accumulator.  i8mfma_kernel above spends five VALU
 // instructions and three 16-byte LDS reads per accumulator and slice on the zero-point terms and the int -> float
 // conversion; its VALU pipe is the bound (profiles/r03_pmc_i8mfma_sq_counters.txt).  Here both zero points are folded into
 // the operands and the operands are small integers held in fp16:
 //       A' = a - za  in [-255, 255],      B' = u - zbb  in [-15, 15]     (u the stored nibble = q + 8, zbb = zb + 8)
-// every product (<= 3825) and every partial sum of a slice (<= 122400) is an integer below 2^24, so
+//                                         B' = q - zb   in [-255, 255]   (byte containers)
+// every product (<= 3825; bytes 65025) and every partial sum of a slice (<= 122400; bytes 2.1 M) is an integer below 2^24, so
 // v_mfma_f32_16x16x32_f16 returns float(sum_k (a - za)(q - zb)) EXACTLY — the integer dot of the reference, computed on the
 // fp16 matrix pipe.  A' depends on the activation alone: i8prep_kernel writes it once per call as [m][K'] fp16 and every
 // workgroup stages it with plain 16-byte copies; B' costs the lane that holds the record eleven VALU instructions per
@@ -512,9 +513,10 @@ struct I8PrepParams {
   const uint8_t* azp;  // [m][nblk]
   uint8_t* out;        // [m][kp] fp16, kp = 32 nsl
   int m, k, nsl, blocksize, nblk;
+  int scale16;         // nibble containers: codes 2, 3, 6, 7 of every eight stored / 16
 };
 
-// A'[row][k] = fp16(a - za(row, k-block)) (/ 16 for k mod 8 in {2, 3, 6, 7}), zero beyond K: eight codes per thread
+// A'[row][k] = fp16(a - za(row, k-block)) (nibble containers: / 16 for k mod 8 in {2, 3, 6, 7}), zero beyond K: eight codes per thread
 __global__ __launch_bounds__(256) void i8prep_kernel(const I8PrepParams p) {
   const size_t idx = size_t(blockIdx.x) * 256 + threadIdx.x;
   const size_t per_row = size_t(p.nsl) * 4;
@@ -541,14 +543,14 @@ __global__ __launch_bounds__(256) void i8prep_kernel(const I8PrepParams p) {
   const half2_t zc = __builtin_bit_cast(half2_t, (0x6400u + za) * 0x00010001u);
   const uint32_t src2[4] = {__builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u),
                             __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u)};
-  // codes 2, 3, 6, 7 of the eight are stored as (a - za) / 16 (exact: eight significant bits): the GEMM builds their B' as
-  // 16 (u - zbb) straight from the nibbles' position in the dword, one shift less per pair
+  // nibble containers: codes 2, 3, 6, 7 of the eight are stored as (a - za) / 16 (exact: eight significant bits): the GEMM builds
+  // their B' as 16 (u - zbb) straight from the nibbles' position in the dword, one shift less per pair
   const half2_t sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
   uint32_t o[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     half2_t v = __builtin_bit_cast(half2_t, src2[i]) - zc;
-    if (i & 1) v = v * sixteenth;
+    if ((i & 1) && p.scale16) v = v * sixteenth;
     o[i] = __builtin_bit_cast(uint32_t, v);
   }
   *reinterpret_cast<uint4v*>(p.out + idx * 16) = uint4v{o[0], o[1], o[2], o[3]};
@@ -570,11 +572,13 @@ struct I8Gemm2Params {
 //               per SIMD): 10 - 12 % behind at 2048 x 4096 x 4096.  (1, 4, 4): 64 x 256 as four waves: 20 % behind.  Both kept
 //               for A-B runs ("i8_tile" 3 / 2; profiles/r03_i8_prefill_kernels.json)
 //   (1, 1, 4)   64 x 64, double-buffered: small problems (four times the workgroups)
-template <int SDT, int SPS, bool ASYM, int RH, int CT, int WV>
+template <bool FOUR, int SDT, int SPS, bool ASYM, int RH, int CT, int WV>
 __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const I8Gemm2Params pp) {
   using G = I8G2Geom<RH>;
   const I8RefParams& p = pp.b;
-  constexpr int NJ = 4, CS = G::kSL / NJ;             // four 32-deep slices per k-step record; k-steps per chunk: 2 / 1
+  constexpr int NJ = FOUR ? 4 : 2;   // 32-deep slices per k-step record (128-deep nibble / 64-deep byte containers)
+  constexpr int KS = 32 * NJ;
+  constexpr int CS = G::kSL / NJ;    // k-steps per chunk: 2 / 1 (nibbles), 4 / 2 (bytes)
   constexpr int kThreads = 64 * WV;
   constexpr int kPieces = G::kRows * G::kSL * 4 / kThreads;  // 16-byte A' pieces per thread and chunk: 8 (2 with sixteen waves)
   constexpr int kRowPieces = G::kSL * 4;                // pieces per row and chunk: 32 / 16
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const
     const float* sa_lds = reinterpret_cast<const float*>(a_lds + kSaOff);
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      const int k0 = s * 128 + 32 * j;
+      const int k0 = s * KS + 32 * j;
       if (k0 >= p.k) continue;
       const int q = t * NJ + j;
       const int e = (j * SPS) / NJ;  // a constant once the loops are unrolled
@@ -689,20 +693,35 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const
           const uint32_t h = (wc.sw[ct][e >> 1] >> (16 * (e & 1))) & 0xffffu;
           sb[ct] = SDT == 0 ? __builtin_bit_cast(float, h << 16) : f16_bits_to_f32(h);
         }
-        // B' as fp16.  The dword's nibbles 4s and 4s + 4 (s = 0 .. 3) are codes 2s and 2s + 1 of the lane's eight.
-        //   s = 0, 2:  (x >> 4s & 0x000f000f) | 0x6400 twice = 1024 + u;        minus 1024 + zbb     = u - zbb
-        //   s = 1, 3:  (x >> 4(s-1) & 0x00f000f0) | 0x6400 twice = 1024 + 16 u; minus 1024 + 16 zbb  = 16 (u - zbb), against A' / 16
-        uint32_t zbb = 8;
-        if constexpr (ASYM) zbb = uint32_t(8 + int(int8_t((wc.zw[ct] >> (8 * e)) & 0xffu)));
-        const half2_t z1 = __builtin_bit_cast(half2_t, (0x6400u + zbb) * 0x00010001u);
-        const half2_t z16 = __builtin_bit_cast(half2_t, (0x6400u + (zbb << 4)) * 0x00010001u);
-        const uint32_t x = j == 0 ? wc.rec[ct].x : (j == 1 ? wc.rec[ct].y : (j == 2 ? wc.rec[ct].z : wc.rec[ct].w));
-        const uint32_t y = x >> 8;
-        const uint32_t bw0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (x & 0x000f000fu) | magic) - z1);
-        const uint32_t bw1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (x & 0x00f000f0u) | magic) - z16);
-        const uint32_t bw2 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (y & 0x000f000fu) | magic) - z1);
-        const uint32_t bw3 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (y & 0x00f000f0u) | magic) - z16);
-        b[ct] = __builtin_bit_cast(half8_t, uint4v{bw0, bw1, bw2, bw3});
+        if constexpr (FOUR) {
+          // B' as fp16.  The dword's nibbles 4s and 4s + 4 (s = 0 .. 3) are codes 2s and 2s + 1 of the lane's eight.
+          //   s = 0, 2:  (x >> 4s & 0x000f000f) | 0x6400 twice = 1024 + u;        minus 1024 + zbb     = u - zbb
+          //   s = 1, 3:  (x >> 4(s-1) & 0x00f000f0) | 0x6400 twice = 1024 + 16 u; minus 1024 + 16 zbb  = 16 (u - zbb), against A' / 16
+          uint32_t zbb = 8;
+          if constexpr (ASYM) zbb = uint32_t(8 + int(int8_t((wc.zw[ct] >> (8 * e)) & 0xffu)));
+          const half2_t z1 = __builtin_bit_cast(half2_t, (0x6400u + zbb) * 0x00010001u);
+          const half2_t z16 = __builtin_bit_cast(half2_t, (0x6400u + (zbb << 4)) * 0x00010001u);
+          const uint32_t x = j == 0 ? wc.rec[ct].x : (j == 1 ? wc.rec[ct].y : (j == 2 ? wc.rec[ct].z : wc.rec[ct].w));
+          const uint32_t y = x >> 8;
+          const uint32_t bw0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (x & 0x000f000fu) | magic) - z1);
+          const uint32_t bw1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (x & 0x00f000f0u) | magic) - z16);
+          const uint32_t bw2 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (y & 0x000f000fu) | magic) - z1);
+          const uint32_t bw3 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, (y & 0x00f000f0u) | magic) - z16);
+          b[ct] = __builtin_bit_cast(half8_t, uint4v{bw0, bw1, bw2, bw3});
+        } else {
+          // byte containers: the slice's eight s8 codes are two dwords in k order.  q ^ 0x80 = q + 128 as a u8 under the high
+          // byte 0x64 = 1024 + 128 + q as fp16; minus 1024 + 128 + zb: q - zb in [-255, 255], exact (products < 2^16, a slice's
+          // sum < 2^21)
+          int zb = 0;
+          if constexpr (ASYM) zb = int(int8_t((wc.zw[ct] >> (8 * e)) & 0xffu));
+          const half2_t zc = __builtin_bit_cast(half2_t, uint32_t(0x6480 + zb) * 0x00010001u);
+          const uint32_t x0 = (j == 0 ? wc.rec[ct].x : wc.rec[ct].z) ^ 0x80808080u, x1 = (j == 0 ? wc.rec[ct].y : wc.rec[ct].w) ^ 0x80808080u;
+          const uint32_t bw0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, x0, 0x04010400u)) - zc);
+          const uint32_t bw1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, x0, 0x04030402u)) - zc);
+          const uint32_t bw2 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, x1, 0x04010400u)) - zc);
+          const uint32_t bw3 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(0x64646464u, x1, 0x04030402u)) - zc);
+          b[ct] = __builtin_bit_cast(half8_t, uint4v{bw0, bw1, bw2, bw3});
+        }
       };
       if constexpr (RH > 1) {  // shared by the row halves: all of them first
 #pragma unroll
@@ -738,39 +757,41 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const
   KRec w0, w1;  // even and odd k-steps: each is refilled one k-step ahead of its use, across chunk boundaries as well
   if (active) fetch_w(0, w0);
   fetch_a(0);
+  static_assert(CS == 1 || CS % 2 == 0, "the two record buffers alternate by k-step parity inside a chunk");
   if constexpr (G::kBufs == 2) {
-    static_assert(CS == 2, "two k-steps per chunk: the next chunk is written between them");
+    static_assert(CS % 2 == 0, "the next chunk is written in the middle of the current one");
     write_chunk(g2_smem);
     if (CS < p.ksteps) fetch_a(CS);
-    for (int s = 0; s < p.ksteps; s += 2) {
-      unsigned char* cur = g2_smem + ((s >> 1) & 1) * G::kBuf;
-      unsigned char* nxt = g2_smem + (((s >> 1) & 1) ^ 1) * G::kBuf;
-      __syncthreads();  // chunk s / 2 is written by everyone, chunk s / 2 - 1 (the buffer written next) is consumed by everyone
-      if (active) {
-        fetch_w(s + 1, w1);  // (all zero beyond the last k-step)
-        kstep(w0, s, 0, cur);
-      }
-      if (s + 2 < p.ksteps) {
-        write_chunk(nxt);
-        if (s + 4 < p.ksteps) fetch_a(s + 4);
-      }
-      if (s + 1 < p.ksteps && active) {
-        fetch_w(s + 2, w0);
-        kstep(w1, s + 1, 1, cur);
+    for (int s0 = 0; s0 < p.ksteps; s0 += CS) {
+      unsigned char* cur = g2_smem + ((s0 / CS) & 1) * G::kBuf;
+      unsigned char* nxt = g2_smem + (((s0 / CS) & 1) ^ 1) * G::kBuf;
+      __syncthreads();  // this chunk is written by everyone, the previous one (the buffer written next) is consumed by everyone
+#pragma unroll
+      for (int t = 0; t < CS; t++) {
+        const int s = s0 + t;
+        if (s >= p.ksteps) break;
+        if (active) {
+          fetch_w(s + 1, (t & 1) ? w0 : w1);  // (all zero beyond the last k-step)
+          kstep((t & 1) ? w1 : w0, s, t, cur);
+        }
+        if (t == CS / 2 - 1 && s0 + CS < p.ksteps) {
+          write_chunk(nxt);
+          if (s0 + 2 * CS < p.ksteps) fetch_a(s0 + 2 * CS);
+        }
       }
     }
   } else {
     for (int s = 0; s < p.ksteps; s += 2) {
-      stage(s);  // (CS = 2: the pair is one chunk)
+      if (s % CS == 0) stage(s);
       if (active) {
         fetch_w(s + 1, w1);  // (all zero beyond the last k-step)
-        kstep(w0, s, 0, g2_smem);
+        kstep(w0, s, s % CS, g2_smem);
       }
       if (s + 1 >= p.ksteps) break;
-      if constexpr (CS == 1) stage(s + 1);
+      if ((s + 1) % CS == 0) stage(s + 1);
       if (active) {
         fetch_w(s + 2, w0);
-        kstep(w1, s + 1, CS == 1 ? 0 : 1, g2_smem);
+        kstep(w1, s + 1, (s + 1) % CS, g2_smem);
       }
     }
   }
@@ -803,7 +824,7 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const
   }
 }
 
-template <int S, int D, int RH, int CT, int WV>
+template <bool F, int S, int D, int RH, int CT, int WV>
 hipError_t launch_i8mfma2_a(bool asym, dim3 grid, hipStream_t st, const I8Gemm2Params& p) {
   auto go = [&](auto kern) {
     static const hipError_t attr =
@@ -812,36 +833,41 @@ hipError_t launch_i8mfma2_a(bool asym, dim3 grid, hipStream_t st, const I8Gemm2P
     hipLaunchKernelGGL(kern, grid, dim3(64 * WV), I8G2Geom<RH>::kLds, st, p);
     return hipGetLastError();
   };
-  return asym ? go(i8mfma2_kernel<D, S, true, RH, CT, WV>) : go(i8mfma2_kernel<D, S, false, RH, CT, WV>);
+  return asym ? go(i8mfma2_kernel<F, D, S, true, RH, CT, WV>) : go(i8mfma2_kernel<F, D, S, false, RH, CT, WV>);
 }
-template <int S, int RH, int CT, int WV>
+template <bool F, int S, int RH, int CT, int WV>
 hipError_t launch_i8mfma2_t(int sdt, bool asym, int m, int ntiles, hipStream_t st, const I8Gemm2Params& p) {
   const dim3 grid(unsigned((ntiles + WV * CT - 1) / (WV * CT)), unsigned((m + 64 * RH - 1) / (64 * RH)));
-  if (sdt == 0) return launch_i8mfma2_a<S, 0, RH, CT, WV>(asym, grid, st, p);
-  if (sdt == 1) return launch_i8mfma2_a<S, 1, RH, CT, WV>(asym, grid, st, p);
-  return launch_i8mfma2_a<S, 2, RH, CT, WV>(asym, grid, st, p);
+  if (sdt == 0) return launch_i8mfma2_a<F, S, 0, RH, CT, WV>(asym, grid, st, p);
+  if (sdt == 1) return launch_i8mfma2_a<F, S, 1, RH, CT, WV>(asym, grid, st, p);
+  return launch_i8mfma2_a<F, S, 2, RH, CT, WV>(asym, grid, st, p);
 }
-template <int S>
+template <bool F, int S>
 hipError_t launch_i8mfma2(int sdt, bool asym, int m, int ntiles, hipStream_t st, const I8Gemm2Params& p) {
   // tile: "i8_tile" 0 = by size (4 once 64 x 256 workgroups give every CU one, else 1), 1 = 64 x 64, 2 = 64 x 256 as four waves of four
-  // column tiles, 3 = 128 x 128, 4 = 64 x 256 as sixteen waves of one column tile each
+  // column tiles, 3 = 128 x 128, 4 = 64 x 256 as sixteen waves of one column tile each (2 and 3: nibble containers only)
   const int force = g_i8_tile.load(std::memory_order_relaxed);
   const bool wide = size_t((ntiles + 15) / 16) * size_t((m + 63) / 64) >= 256;
-  const int tile = force ? force : (wide ? 4 : 1);
-  if (tile == 4) return launch_i8mfma2_t<S, 1, 1, 16>(sdt, asym, m, ntiles, st, p);
-  if (tile == 3) return launch_i8mfma2_t<S, 2, 2, 4>(sdt, asym, m, ntiles, st, p);
-  if (tile == 2) return launch_i8mfma2_t<S, 1, 4, 4>(sdt, asym, m, ntiles, st, p);
-  return launch_i8mfma2_t<S, 1, 1, 4>(sdt, asym, m, ntiles, st, p);
+  int tile = force ? force : (wide ? 4 : 1);
+  if constexpr (F) {
+    if (tile == 3) return launch_i8mfma2_t<F, S, 2, 2, 4>(sdt, asym, m, ntiles, st, p);
+    if (tile == 2) return launch_i8mfma2_t<F, S, 1, 4, 4>(sdt, asym, m, ntiles, st, p);
+  } else if (tile == 2 || tile == 3) {
+    tile = wide ? 4 : 1;
+  }
+  if (tile == 4) return launch_i8mfma2_t<F, S, 1, 1, 16>(sdt, asym, m, ntiles, st, p);
+  return launch_i8mfma2_t<F, S, 1, 1, 4>(sdt, asym, m, ntiles, st, p);
 }
 
-// does the stream's A' scratch (slot 7) belong to its current activation codes (slot 4)?
-bool prep_valid(hipStream_t st, bool set, bool value = false) {
+// which form of A' the stream's scratch (slot 7) holds for its current activation codes (slot 4): 0 none, 1 the nibble
+// containers' (odd pairs / 16), 2 the byte containers'
+int prep_state(hipStream_t st, bool set, int value = 0) {
   static std::mutex mu;
-  static std::map<hipStream_t, bool> valid;
+  static std::map<hipStream_t, int> state;
   std::lock_guard<std::mutex> lock(mu);
-  if (set) valid[st] = value;
-  auto it = valid.find(st);
-  return it != valid.end() && it->second;
+  if (set) state[st] = value;
+  auto it = state.find(st);
+  return it == state.end() ? 0 : it->second;
 }
 
 }  // namespace
@@ -900,8 +926,10 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   }();
   const bool four = w->kind != WK_INT8;
   const bool mfma = mfma_min_m > 0 && m >= mfma_min_m && w->kstep_len == (four ? 128 : 64);
-  const bool v2 = mfma && four && g_i8_mfma_gen.load(std::memory_order_relaxed) != 1 && (w->sps == 4 || w->sps == 2 || w->sps == 1);
-  const int nsl = w->ksteps * 4;  // 32-deep slices per row of A'
+  const bool v2 = mfma && g_i8_mfma_gen.load(std::memory_order_relaxed) != 1 &&
+                  (four ? (w->sps == 4 || w->sps == 2 || w->sps == 1) : (w->sps == 2 || w->sps == 1));
+  const int nsl = w->ksteps * (four ? 4 : 2);  // 32-deep slices per row of A'
+  const int want = four ? 1 : 2;               // the form of A' this weight multiplies
   uint8_t* pa = nullptr;
   if (v2) {
     pa = static_cast<uint8_t*>(stream_scratch(st, size_t(m) * nsl * 64, 7));
@@ -910,16 +938,16 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
   if (!reuse_aq) {
     hipError_t e = hipErrorNotSupported;
     bool with_ap = false;
-    if (mfma) {  // the vector form of the quantizer; it writes A' as well when the rows need no padding (K a multiple of 128)
+    if (mfma) {  // the vector form of the quantizer; it writes A' as well when the rows need no padding (K a multiple of the k-step)
       with_ap = v2 && w->k == nsl * 32;
-      e = launch_aquant_u8_vec(m, w->k, a, lda, aq, w->k, as, nblk, az, bs, with_ap ? pa : nullptr, nsl * 32, st);
+      e = launch_aquant_u8_vec(m, w->k, a, lda, aq, w->k, as, nblk, az, bs, with_ap ? pa : nullptr, nsl * 32, four, st);
     }
     if (e == hipErrorNotSupported) {
       with_ap = false;
       e = launch_aquant_u8(m, w->k, a, lda, aq, w->k, as, nblk, az, bs, nullptr, st);
     }
     if (e != hipSuccess) return e;
-    prep_valid(st, true, with_ap);  // does slot 7 match slot 4?
+    prep_state(st, true, with_ap ? want : 0);  // does slot 7 match slot 4?
   }
   I8RefParams p{};
   p.codes = reinterpret_cast<const uint8_t*>(w->codes);
@@ -955,16 +983,20 @@ hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, v
       g2.b = p;
       g2.nsl = nsl;
       g2.pa = pa;
-      if (!prep_valid(st, false)) {  // (a reused quantization consumed by other kernels so far, or rows that need padding)
-        const I8PrepParams pr{aq, az, pa, m, w->k, nsl, bs, nblk};
+      if (prep_state(st, false) != want) {  // (a reused quantization consumed by other kernels so far, or rows that need padding)
+        const I8PrepParams pr{aq, az, pa, m, w->k, nsl, bs, nblk, four ? 1 : 0};
         hipLaunchKernelGGL(i8prep_kernel, dim3(unsigned((size_t(m) * nsl * 4 + 255) / 256)), dim3(256), 0, st, pr);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        prep_valid(st, true, true);
+        prep_state(st, true, want);
       }
-      if (w->sps == 4) return launch_i8mfma2<4>(sdt, w->asym, m, w->ntiles, st, g2);
-      if (w->sps == 2) return launch_i8mfma2<2>(sdt, w->asym, m, w->ntiles, st, g2);
-      return launch_i8mfma2<1>(sdt, w->asym, m, w->ntiles, st, g2);
+      if (four) {
+        if (w->sps == 4) return launch_i8mfma2<true, 4>(sdt, w->asym, m, w->ntiles, st, g2);
+        if (w->sps == 2) return launch_i8mfma2<true, 2>(sdt, w->asym, m, w->ntiles, st, g2);
+        return launch_i8mfma2<true, 1>(sdt, w->asym, m, w->ntiles, st, g2);
+      }
+      if (w->sps == 2) return launch_i8mfma2<false, 2>(sdt, w->asym, m, w->ntiles, st, g2);
+      return launch_i8mfma2<false, 1>(sdt, w->asym, m, w->ntiles, st, g2);
     }
     if (four && w->sps == 4) launch_i8mfma<true, 4>(sdt, w->asym, grid, lds, st, p);
     else if (four && w->sps == 2) launch_i8mfma<true, 2>(sdt, w->asym, grid, lds, st, p);

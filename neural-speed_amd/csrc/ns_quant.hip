@@ -633,14 +633,15 @@ __global__ void aquant_u8_coop_kernel(int row, int col, const float* __restrict_
 // GEMM-sized calls: eight lanes per (row, k-block) again, but lane e takes the block's elements [e bs/8, (e + 1) bs/8) as
 // 16-byte loads and writes its codes as dwords (the form above stores single bytes).  The same per-element operations and
 // order-independent reductions: bit-identical.  Optionally the operand the int8-reference GEMM multiplies
-// (ns_i8ref.hip i8mfma2_kernel) next to the codes: ap[r][k] = fp16(code - zp), / 16 for k mod 8 in {2, 3, 6, 7}
-// (i8prep_kernel's output), so that kernel is not launched.
+// (ns_i8ref.hip i8mfma2_kernel) next to the codes: ap[r][k] = fp16(code - zp), with ap_scale16 (nibble containers) / 16 for
+// k mod 8 in {2, 3, 6, 7} (i8prep_kernel's output), so that kernel is not launched.
 // Needs blocksize % 32 == 0, col % blocksize == 0 and 16-byte / 4-byte aligned rows.
 typedef _Float16 aq_half2 __attribute__((ext_vector_type(2)));
 template <bool AP>
 __global__ __launch_bounds__(256) void aquant_u8_vec_kernel(int row, int col, const float* __restrict__ src, int ld_src,
                                                             uint8_t* __restrict__ dst, int ld_dst, float* __restrict__ scales, int ld_scale,
-                                                            uint8_t* __restrict__ zps, int blocksize, uint16_t* __restrict__ ap, int ld_ap) {
+                                                            uint8_t* __restrict__ zps, int blocksize, uint16_t* __restrict__ ap, int ld_ap,
+                                                            int ap_scale16) {
   const int nblk = col / blocksize;
   const size_t gid = (size_t(blockIdx.x) * 256 + threadIdx.x) >> 3;
   const int e = threadIdx.x & 7;
@@ -681,7 +682,8 @@ __global__ __launch_bounds__(256) void aquant_u8_vec_kernel(int row, int col, co
     *reinterpret_cast<uint32_t*>(d + ij) = uint32_t(c[0]) | (uint32_t(c[1]) << 8) | (uint32_t(c[2]) << 16) | (uint32_t(c[3]) << 24);
     if constexpr (AP) {  // small integers: exact in fp16, and so is the division by 16
       const aq_half2 lo = {(_Float16)float(c[0] - zp), (_Float16)float(c[1] - zp)};
-      const aq_half2 hi = {(_Float16)(float(c[2] - zp) * 0.0625f), (_Float16)(float(c[3] - zp) * 0.0625f)};
+      const float hs = ap_scale16 ? 0.0625f : 1.f;
+      const aq_half2 hi = {(_Float16)(float(c[2] - zp) * hs), (_Float16)(float(c[3] - zp) * hs)};
       *reinterpret_cast<uint2*>(ap + size_t(i) * ld_ap + j + ij) = uint2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
     }
   }
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(256) void aquant_u8_vec_kernel(int row, int col, co
 // codes + scales + zero points, and (ap != nullptr) the fp16 operand of i8mfma2_kernel with row stride ld_ap halves;
 // hipErrorNotSupported when the shape is outside the vector kernel's envelope (the caller then takes launch_aquant_u8)
 hipError_t launch_aquant_u8_vec(int row, int col, const float* src, int ld_src, uint8_t* dst, int ld_dst, float* scales,
-                                int ld_scale, uint8_t* zps, int blocksize, void* ap, int ld_ap, hipStream_t st) {
+                                int ld_scale, uint8_t* zps, int blocksize, void* ap, int ld_ap, bool ap_scale16, hipStream_t st) {
   if (blocksize <= 0 || blocksize % 32 != 0 || col % blocksize != 0 || (ld_src & 3) || (reinterpret_cast<uintptr_t>(src) & 15) ||
       (ld_dst & 3) || (reinterpret_cast<uintptr_t>(dst) & 3) || (ap && ((ld_ap & 3) || (reinterpret_cast<uintptr_t>(ap) & 7))))
     return hipErrorNotSupported;
@@ -701,10 +703,10 @@ hipError_t launch_aquant_u8_vec(int row, int col, const float* src, int ld_src, 
   if (total == 0) return hipSuccess;
   if (ap)
     hipLaunchKernelGGL(aquant_u8_vec_kernel<true>, grid1d(total * 8, 256), dim3(256), 0, st, row, col, src, ld_src, dst, ld_dst, scales,
-                       ld_scale, zps, blocksize, static_cast<uint16_t*>(ap), ld_ap);
+                       ld_scale, zps, blocksize, static_cast<uint16_t*>(ap), ld_ap, ap_scale16 ? 1 : 0);
   else
     hipLaunchKernelGGL(aquant_u8_vec_kernel<false>, grid1d(total * 8, 256), dim3(256), 0, st, row, col, src, ld_src, dst, ld_dst, scales,
-                       ld_scale, zps, blocksize, static_cast<uint16_t*>(nullptr), 0);
+                       ld_scale, zps, blocksize, static_cast<uint16_t*>(nullptr), 0, 0);
   return hipGetLastError();
 }
 

@@ -64,16 +64,14 @@ def test_int8_mode_gemm_sized_calls_run_on_the_matrix_cores(L, pkg, nso, int8_mo
     assert per_row.max() < 1e-5, (int(per_row.argmax()), per_row.max())
 
 
-NIBBLE_CASES = [c for c in CASES if c[0] in ("S4", "S3")]
-
-
-@pytest.mark.parametrize("qt,st,asym,bs,n,k,core", NIBBLE_CASES)
+@pytest.mark.parametrize("qt,st,asym,bs,n,k,core", CASES)
 @pytest.mark.parametrize("m", [16, 77, 200])
 def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, int8_mode, qt, st, asym, bs, n, k, core, m):
     """i8mfma2_kernel (one fp16 MFMA per slice on operands with both zero points folded in: fp16(a - za) against fp16(u - zbb),
     every product and partial sum an integer below 2^24, so the MFMA returns float(isum) exactly) and i8mfma_kernel (integer MFMA
     + integer corrections per accumulator) form the same exact integer per slice and the same fp32 expression in the same
-    order: equal bit for bit, in every workgroup tile of the second kernel.  Rows that drive the folding to its corners included:
+    order: equal bit for bit, in every workgroup tile of the second kernel — nibble and byte containers alike (bytes:
+    fp16(q - zb) in [-255, 255], a slice's sum below 2^21; tiles 2 and 3 exist for nibbles only and fall back to 4 / 1).  Rows that drive the folding to its corners included:
     all-positive / all-negative rows (zero point 0 / 255, a - za = +-255) and a constant row."""
     rng = np.random.default_rng(n * 5 + k + m)
     w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
