@@ -190,11 +190,8 @@ int ns_hip_get_compute_mode(void);
  *   "i8_mfma"         NS_COMPUTE_REF_INT8 at 16 rows and up: 2 = one exact fp16 MFMA per 32-deep slice on
  *                     operands with both zero points folded in (default), 1 = the first kernel (integer MFMA + corrections
  *                     per accumulator); bit-identical results; also NS_I8_MFMA in the environment
- *   "i8_tile"         workgroup tile of that kernel: 0 = by problem size (default), 1 = 64 x 64, 2 = 64 x 256 (four waves),
- *                     3 = 128 x 128, 4 = 64 x 256 (sixteen waves; what large problems take); 2 and 3 exist for nibble containers only
- *   "attn_wg_target", "attn_min_keys"   context-split rule of the decode attention kernel (defaults 1024, 128)
- *   "gv_nw"           waves per 16-column tile of the decode kernels (2 / 4 / 8 / 16), 0 = by shape (default); the
- *                     partial sums of a tile are added in wave order, so this selects the summation order
+ *   "i8_tile"         workgroup tile of that kernel: 0 = by problem size (default), 1 = 64 x 64 (four waves), 4 = 64 x 256
+ *                     (sixteen waves; what large problems take); other values = default
  * Returns 0, or -1 for an unknown key. */
 int ns_hip_set_tuning(const char* key, int value);
 

@@ -71,7 +71,7 @@ def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, in
     every product and partial sum an integer below 2^24, so the MFMA returns float(isum) exactly) and i8mfma_kernel (integer MFMA
     + integer corrections per accumulator) form the same exact integer per slice and the same fp32 expression in the same
     order: equal bit for bit, in every workgroup tile of the second kernel — nibble and byte containers alike (bytes:
-    fp16(q - zb) in [-255, 255], a slice's sum below 2^21; tiles 2 and 3 exist for nibbles only and fall back to 4 / 1).  Rows that drive the folding to its corners included:
+    fp16(q - zb) in [-255, 255], a slice's sum below 2^21).  Rows that drive the folding to its corners included:
     all-positive / all-negative rows (zero point 0 / 255, a - za = +-255) and a constant row."""
     rng = np.random.default_rng(n * 5 + k + m)
     w = (rng.standard_normal((n, k)) * 0.02).astype(np.float32)
@@ -83,7 +83,7 @@ def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, in
     blob = nso.quant_pack(w, bs, getattr(nso, qt), getattr(nso, st), asym, getattr(nso, core))
     outs = {}
     try:
-        for gen, tile in ((1, 0), (2, 1), (2, 2), (2, 3), (2, 4)):  # the second kernel in each of its workgroup tiles
+        for gen, tile in ((1, 0), (2, 1), (2, 4)):  # the second kernel in each of its workgroup tiles
             assert L.ns_hip_set_tuning(b"i8_mfma", gen) == 0
             assert L.ns_hip_set_tuning(b"i8_tile", tile) == 0
             o = np.full((m, n), 7.0, np.float32)
@@ -92,9 +92,9 @@ def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, in
     finally:
         L.ns_hip_set_tuning(b"i8_mfma", 2)
         L.ns_hip_set_tuning(b"i8_tile", 0)
-    for tile in (1, 2, 3, 4):
+    for tile in (1, 4):
         assert np.array_equal(outs[(1, 0)].view(np.uint32), outs[(2, tile)].view(np.uint32)), (tile, np.abs(outs[(1, 0)] - outs[(2, tile)]).max())
-    assert nso.rel_l2(outs[(2, 2)], nso.gemm_u8s8(a, blob)) < 2e-6
+    assert nso.rel_l2(outs[(2, 4)], nso.gemm_u8s8(a, blob)) < 2e-6
 
 
 def test_int8_mode_fused_qkv_at_gemm_size_prepares_the_activations_once(L, pkg, nso, int8_mode):
