@@ -29,6 +29,12 @@
 #include "ns_dev.h"
 #include "ns_i8g2.h"
 
+#ifndef NS_I8G2_NAME  // a bare `hipcc -c ns_i8g2.hip` builds the Q4_0 variant
+#define NS_I8G2_NAME launch_i8g2_n4
+#define NS_I8G2_FOUR true
+#define NS_I8G2_SPS 4
+#endif
+
 namespace ns {
 namespace {
 
