@@ -192,6 +192,10 @@ int ns_hip_get_compute_mode(void);
  *                     per accumulator); bit-identical results; also NS_I8_MFMA in the environment
  *   "i8_tile"         workgroup tile of that kernel: 0 = by problem size (default), 1 = 64 x 64 (four waves), 4 = 64 x 256
  *                     (sixteen waves; what large problems take); other values = default
+ *   "attn_wg_target", "attn_min_keys"   context-split rule of the decode attention kernel (defaults 1024, 128)
+ *   "gv_nw"           waves per 16-column tile of the decode kernels (2 / 4 / 8 / 16), 0 = by shape (default); the
+ *                     partial sums of a tile are added in wave order, so this selects the summation order
+ *   "g3_min_m"        rows from which the tiled prefill GEMM is used inside its envelope (0 = default)
  * Returns 0, or -1 for an unknown key. */
 int ns_hip_set_tuning(const char* key, int value);
 

@@ -134,3 +134,17 @@ def test_every_fallback_of_the_reference_harness_is_interposed_by_the_library(pk
     exported = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", pkg.LIB_PATH], text=True).splitlines() if ln.split()}
     missing = [n for n in names if n not in exported]
     assert not missing, missing
+
+
+def test_tuning_keys_documented_in_the_header_are_accepted_without_a_device(L):
+    """ns_hip_set_tuning: every key the header documents is known (process-wide switches: no device needed), unknown keys are
+    refused; the values are put back to their defaults"""
+    src = open(os.path.join(ROOT, "include", "ns_bestla.h")).read()
+    block = src[src.index("Diagnostics / A-B switches of the kernels"):src.index("int ns_hip_set_tuning")]
+    keys = re.findall(r'^\s*\*\s+"([a-z0-9_]+)"', block, flags=re.M) + re.findall(r'",\s*"([a-z0-9_]+)"', block)
+    assert {"gemv2", "g3_bm", "g3_min_m", "i8_mfma", "i8_tile", "gv_nw", "attn_wg_target", "attn_min_keys"} <= set(keys), keys
+    defaults = {"gemv2": 1, "i8_mfma": 2}
+    for k in sorted(set(keys)):
+        assert L.ns_hip_set_tuning(k.encode(), defaults.get(k, 0)) == 0, k
+    assert L.ns_hip_set_tuning(b"no_such_key", 1) == -1
+    L.ns_hip_reset_error()
