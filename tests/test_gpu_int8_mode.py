@@ -98,7 +98,7 @@ def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, in
 
 
 def test_int8_mode_fused_qkv_at_gemm_size_prepares_the_activations_once(L, pkg, nso, int8_mode):
-    """the fused QKV entry at GEMM size: one activation quantization and one operand preparation ([p | r], i8prep_kernel)
+    """the fused QKV entry at GEMM size: one activation quantization and one operand preparation (the fp16 A', by the quantizer itself or i8prep_kernel)
     for the three weights, as the reference quantizes A once (ip_fusion_qkv.cpp:84-86)"""
     import torch
     rng = np.random.default_rng(17)
