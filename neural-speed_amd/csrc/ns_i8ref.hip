@@ -17,6 +17,12 @@
 // the MFMA kernels read; integer dots with v_dot4_u32_u8 on the stored codes, activation codes staged in LDS.  Up to
 // four rows of A per pass (weights are re-read for more rows: a numerics mode for decode-sized calls, not a prefill
 // kernel).
+//
+// Who runs what (launch_i8ref below):   1 - 4 rows: the streaming decode kernel's int8 variant (ns_gemv.hip, XV = 3; ns_api.cpp)
+//   5 - 15 rows, k-steps the matrix-core kernels do not take: i8ref_kernel (this file)
+//   16 rows and up: i8mfma2_kernel (ns_i8g2.hip: one exact fp16 MFMA per slice on zero-point-folded operands; its fp16 A'
+//   comes from the quantizer's GEMM-sized form, ns_quant.hip aquant_u8_vec_kernel, or from i8prep_kernel here), or the
+//   first matrix-core kernel i8mfma_kernel (this file: integer MFMA + corrections) when "i8_mfma" = 1.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -31,7 +37,7 @@
 namespace ns {
 namespace {
 
-// which matrix-core kernel GEMM-sized calls on nibble containers take: 2 = i8mfma2_kernel (default), 1 = i8mfma_kernel
+// which matrix-core kernel GEMM-sized calls take: 2 = i8mfma2_kernel (default), 1 = i8mfma_kernel
 std::atomic<int> g_i8_mfma_gen{[] {
   const char* e = getenv("NS_I8_MFMA");
   return e && atoi(e) == 1 ? 1 : 2;
