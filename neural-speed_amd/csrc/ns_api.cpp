@@ -823,6 +823,10 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_gemv_mode(value);
     return 0;
   }
+  if (key && (!strcmp(key, "gvs") || !strcmp(key, "gvs_slices") || !strcmp(key, "gvs_waves") || !strcmp(key, "gvs_grid"))) {
+    set_gemvs_tuning(!strcmp(key, "gvs") ? 0 : !strcmp(key, "gvs_slices") ? 1 : !strcmp(key, "gvs_waves") ? 2 : 3, value);
+    return 0;
+  }
   if (key && !strcmp(key, "g3_min_m")) {
     set_gemm3_min_m(value);
     return 0;

@@ -170,6 +170,10 @@ hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, in
 // hipErrorNotSupported = outside its envelope (use smallm_kernel)
 hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st);
 void set_gemv_mode(int mode);  // 0 off (first-generation kernel), 1 on, -1 re-read NS_GEMV2
+// ns_gemvs.hip: small-batch / narrow-output decode kernel (2 .. 16 rows; activations staged once per workgroup and shared
+// by the tiles it streams, split-K across workgroups); hipErrorNotSupported = outside its envelope (use gemv_kernel)
+hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st);
+void set_gemvs_tuning(int what, int value);  // what: 0 mode (0 off, 1 from 2 rows, 2 from 1 row), 1 slices, 2 waves, 3 workgroups
 void set_attn_tuning(int wg_target, int min_keys);
 // NS_HOST_PROFILE=1: wall time and call count of every host-tensor entry, printed at exit (diagnostics of the default,
 // host-pointer route: where a token's milliseconds go between the graph executor and the GPU)

@@ -98,18 +98,21 @@ inline F8Consts f8_consts(uint32_t qtype) {
 struct F4Lut {
   uint32_t lo[4], hi[4];
 };
-__device__ __forceinline__ uint32_t lut_bytes(uint32_t codes, const uint32_t* t) {
-  const uint32_t sel = codes & 0x07070707u;
-  const uint32_t mask = ((codes >> 3) & 0x01010101u) * 0xffu;
+// byte-plane lookup of four codes (one per byte, 0..15): entries 0..7 and 8..15 through one v_perm_b32 each on the code's
+// low three bits, then a third v_perm_b32 picks per byte by bit 3 (sel2 = 0x03020100 + 4 * bit3: bytes 0..3 of the first
+// result, 4..7 of the second).  sel / sel2 are shared by the low- and the high-byte plane.
+__device__ __forceinline__ uint32_t lut_bytes2(uint32_t sel, uint32_t sel2, const uint32_t* t) {
   const uint32_t a = __builtin_amdgcn_perm(t[1], t[0], sel);
   const uint32_t b = __builtin_amdgcn_perm(t[3], t[2], sel);
-  return (mask & b) | (~mask & a);
+  return __builtin_amdgcn_perm(b, a, sel2);
 }
 __device__ __forceinline__ half8_t cvt_f4x8(uint32_t x, const F4Lut& lut) {
-  const uint32_t t0 = x & 0x0f0f0f0fu;         // bytes: i0 i4 i1 i5
-  const uint32_t t1 = (x >> 4) & 0x0f0f0f0fu;  // bytes: i2 i6 i3 i7
-  const uint32_t lo0 = lut_bytes(t0, lut.lo), hi0 = lut_bytes(t0, lut.hi);
-  const uint32_t lo1 = lut_bytes(t1, lut.lo), hi1 = lut_bytes(t1, lut.hi);
+  // nibbles of x by byte: low nibbles = codes i0 i4 i1 i5, high nibbles = codes i2 i6 i3 i7
+  const uint32_t xs = x >> 4;
+  const uint32_t s0 = x & 0x07070707u, s1 = xs & 0x07070707u;
+  const uint32_t p0 = and_or(x >> 1, 0x04040404u, 0x03020100u), p1 = and_or(xs >> 1, 0x04040404u, 0x03020100u);
+  const uint32_t lo0 = lut_bytes2(s0, p0, lut.lo), hi0 = lut_bytes2(s0, p0, lut.hi);
+  const uint32_t lo1 = lut_bytes2(s1, p1, lut.lo), hi1 = lut_bytes2(s1, p1, lut.hi);
   uint4v r = {__builtin_amdgcn_perm(hi0, lo0, 0x06020400u), __builtin_amdgcn_perm(hi1, lo1, 0x06020400u),
               __builtin_amdgcn_perm(hi0, lo0, 0x07030501u), __builtin_amdgcn_perm(hi1, lo1, 0x07030501u)};
   return __builtin_bit_cast(half8_t, r);

@@ -1,0 +1,891 @@
+// ns_gemvs.hip — gemvs_kernel: the small-batch (2 .. 16 rows) and narrow-output member of libns_hip.so's weight-streaming
+// family.  Same arithmetic as gemv_kernel (ns_gemv.hip): per 1 KiB weight record NJ x v_mfma_f32_16x16x32_f16 on the raw
+// codes, the group scale applied to the fp32 MFMA result, fp16 activations — w = (code - zp) * scale exactly, fp32
+// accumulation (reference: bestla/bestla/kernel_ref.h:2489-2531 gemv_4bit_fp32_fp32 and the M <= 4 envelope of
+// bestla_wrapper.h:643-688; the batched decode step is models/llama/llama.cpp:65-71).  What differs is the DECOMPOSITION.
+//
+// gemv_kernel gives every 16-column tile its own workgroup, and every workgroup stages all rows of A over the whole K.
+// At one row that is 8 KB beside 32 KB of weights; at 8 rows of a 4096-deep matrix it is 64 KB of activations from L2
+// for 32 KB of weights from HBM — a 2:1 activation-to-weight ratio per workgroup, one workgroup of 4 waves per CU
+// (LDS), staging and streaming serialised by the barrier between them: 0.19 of the HBM roofline on BASELINE config 4
+// (profiles/r03y_config_bench.json).  Here:
+//
+//   * ONE workgroup per CU, persistent over its share of the launch's tiles: the activations are staged ONCE per
+//     workgroup and shared by every tile it streams (FFN gate/up at 8 rows: 64 KB of A per 230 KB of weights instead
+//     of per 64 KB); the prologue, the A wait and the barrier are paid once per launch, not once per tile.
+//   * split-K across workgroups where the rows x K slice does not fit LDS (FFN down: 8 x 14336 fp16 = 229 KB) or the
+//     output is too narrow to give every CU a tile: workgroup (slice s, tile group t) stages only A[:, slice s] and
+//     streams slice s of its tiles; the per-slice partial sums go to a slab in HBM and a finalize launch adds them in
+//     slice order (deterministic: no atomics on values) and applies the epilogue.
+//   * NS streaming waves + ONE service wave per workgroup.  The streaming waves split a tile's k-steps as in
+//     gemv_kernel (private LDS-DMA rings, hand-counted vmcnt) and run straight on into the next tile: at the end of a
+//     tile each writes its partial sums to an LDS slot and bumps an LDS counter — no workgroup barrier.  The service
+//     wave polls the counter, adds the partials in wave order, applies the epilogue and stores — so reduction,
+//     epilogue-operand fetch and the output stores of tile j overlap the stream of tile j + 1.
+//   * f4 weights (NF4 / FP4: a 16-entry value table, kernel_ref.h:1456-1478) are decoded through LDS, not the VALU: a
+//     table of all 256 code PAIRS (byte -> two fp16), replicated once per LDS bank (32 KB) so that 64 lanes read it
+//     conflict-free; a lane's 16 B of codes cost 16 ds_read_b32 + 32 address operations instead of ~100 v_perm / v_bfi
+//     (profiles/r04b_ablation.txt: the VALU decode was 9-10 of the gate/up launch's 26 us).  A byte of the streaming
+//     layout holds codes (i0, i2) of a lane's eight, not an MFMA k-pair, so the staged activations are shuffled once in
+//     LDS to the matching order (a0 a2 a4 a6 a1 a3 a5 a7 per 16-byte fragment) instead of shuffling every weight.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+
+#include "../../include/ns_bestla.h"
+#include "ns_common.h"
+#include "ns_dev.h"
+
+namespace ns {
+
+#ifndef NS_GVS_PF
+#define NS_GVS_PF 4
+#endif
+// diagnostic builds (scripts/build_variants.sh): 1 = no code -> fp16 conversion (raw bits as operands), 2 = no activation
+// fragment reads, 3 = records are waited for and refilled but not read or multiplied (the structure's streaming rate)
+#ifndef NS_GVS_ABL
+#define NS_GVS_ABL 0
+#endif
+constexpr int kGsPF = NS_GVS_PF;        // records each streaming wave keeps in flight
+constexpr int kGsR = 2;                 // reduction slots (tiles whose partial sums may be pending in LDS)
+constexpr int kGsMaxRows = 16;
+constexpr int kGsMaxNS = 15;            // streaming waves (+ the service wave = 16 waves = 1024 threads)
+constexpr size_t kGsMaxLds = 160 * 1024;
+constexpr uint32_t kGsCtlBytes = 32;    // LDS control words: cnt[kGsR] at 0, done at 16
+constexpr uint32_t kGsTblBytes = 32 * 1024;  // f4 pair table: 256 entries x 32 bank copies x 4 B, at LDS offset 0
+constexpr uint32_t kGsSpinLimit = 1u << 22;  // polls of an LDS word before a wave gives up (about 0.2 s)
+
+struct GvsMat {
+  const uint8_t* wbase;  // ONE allocation: records at 0, scales at s_off, zero points at z_off
+  uint32_t s_off, z_off;
+  uint32_t tile_begin;
+  int n;
+  float* c;
+  _Float16* c16;
+};
+
+struct GvsParams {
+  // ---- hot: the prologue's words ----
+  const uint8_t* wb0;
+  const uint8_t* wb1;
+  const uint8_t* wb2;
+  const void* a;            // activations, fp16 [m][lda]
+  uint32_t so0, so1, so2;   // scale offsets of the matrices
+  uint32_t zo0, zo1, zo2;   // zero-point offsets (asymmetric only)
+  uint32_t ks;              // k-steps per tile (whole K)
+  uint32_t ksl;             // k-steps per slice
+  uint32_t s_log2;          // log2(slices): workgroup b streams slice b & (S - 1) of tile group b >> s_log2
+  uint32_t qstride, sstride, zstride;
+  uint32_t srows, srow_mul, srow_shift;
+  uint32_t tb1, tb2;        // first tile of matrices 1 and 2 of a fused QKV launch (2^32 - 1: absent)
+  uint32_t ntiles;          // tile units of the launch (dual: tile pairs)
+  uint32_t tg_count;        // tile groups = workgroups per slice; group t streams tiles t, t + tg_count, ...
+  uint32_t tiles_base, tiles_rem;  // ntiles = tiles_base * tg_count + tiles_rem
+  uint32_t ns;              // streaming waves
+  int m, k, lda;
+  uint32_t row_stride;      // halves per staged row
+  uint32_t ctl_off, red_off, ring_off, ring_stride;
+  uint32_t red_wave, red_slot;  // bytes of partial sums per wave / per slot
+  uint32_t a_off;           // LDS offset of the staged activations (behind the f4 pair table when there is one)
+  uint32_t a_bytes;         // bytes of the staged activations (rows x row_stride halves)
+  uint32_t lut16[8];        // f4: the 16 table values as fp16, two per word
+  // ---- cold ----
+  GvsMat mat[3];
+  float* c2;
+  const float* d;
+  int ldc, ldd, epilogue;
+  float* slab;              // split-K: [slice][tile unit][q][64 lanes][4] fp32 partial sums
+  F4Lut lut;
+  F8Consts f8;
+};
+using GvsKArgs = const __attribute__((address_space(4))) GvsParams*;
+__device__ __forceinline__ GvsKArgs gvs_late_args() {
+  uint64_t v = reinterpret_cast<uint64_t>(__builtin_amdgcn_kernarg_segment_ptr());
+  asm volatile("" : "+s"(v));
+  return reinterpret_cast<GvsKArgs>(v);
+}
+
+template <int N>
+__device__ __forceinline__ void gvs_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+enum GvsMode { GS_PLAIN = 0, GS_DUAL = 1, GS_MSEG = 2 };
+
+// epilogue of one tile: lane (nn, g) holds rows 4g .. 4g+3 of column `col` (custom::epilogue::*, bestla_f32f32_forward;
+// dual: tmp1 = act(A*W1), out = (A*W3) * tmp1, neural_speed/core/layers/ip_fusion_ffn.cpp:364-406)
+template <bool DUAL>
+__device__ __forceinline__ void gvs_epilogue(const floatx4* sum, int m, int col, bool col_ok, int g, float* cbase, _Float16* c16,
+                                             int ldc, const float* dvp, float* c2, int epi) {
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) {
+    const int row = 4 * g + rr;
+    if (!(col_ok && row < m)) continue;
+    float v = sum[0][rr];
+    if constexpr (DUAL) {
+      const float t1 = (epi == 5) ? epi_silu(v) : epi_gelu(v);
+      if (c2) c2[size_t(row) * ldc + col] = t1;
+      v = sum[DUAL ? 1 : 0][rr] * t1;
+    } else {
+      const float dv = dvp[rr];
+      switch (epi) {
+        case 1: v = v + dv; break;
+        case 2: v = v * dv; break;
+        case 3: v = epi_gelu(v + dv); break;
+        case 4: v = epi_gelu(v); break;
+        case 5: v = epi_silu(v); break;
+        default: break;
+      }
+    }
+    cbase[size_t(row) * ldc + col] = v;
+    if (c16) c16[size_t(row) * ldc + col] = (_Float16)v;
+  }
+}
+
+template <int KIND, int SPS, int SK, bool ASYM, int MODE>
+__global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
+  constexpr bool DUAL = MODE == GS_DUAL, MSEG = MODE == GS_MSEG;
+  constexpr int NJ = kind_is_8bit(KIND) ? 2 : 4;
+  constexpr int KSTEP = NJ * 32;
+  constexpr int NQ = DUAL ? 2 : 1;
+  constexpr int PF = kGsPF;
+  static_assert(PF % NQ == 0, "ring slots alternate between the two matrices");
+  constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
+  constexpr bool TBL = KIND == WK_F4 && NS_GVS_ABL != 1;  // f4 codes are decoded through the LDS pair table
+  using Corr = CorrRaw<SPS, SK, ASYM>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char* LdsPtr;
+
+  // one batch of scalar loads for everything the prologue needs (hipcc would otherwise sink each load to its first use)
+  asm volatile("" ::"s"(p.wb0), "s"(p.a), "s"(p.so0), "s"(p.ks), "s"(p.ksl), "s"(p.s_log2), "s"(p.qstride), "s"(p.sstride),
+               "s"(p.srows), "s"(p.srow_mul), "s"(p.srow_shift), "s"(p.ntiles), "s"(p.tg_count), "s"(p.tiles_base), "s"(p.tiles_rem),
+               "s"(p.ns));
+  asm volatile("" ::"s"(p.m), "s"(p.k), "s"(p.lda), "s"(p.row_stride), "s"(p.ctl_off), "s"(p.red_off), "s"(p.ring_off),
+               "s"(p.ring_stride), "s"(p.red_wave), "s"(p.red_slot), "s"(p.a_off));
+  if constexpr (DUAL || MSEG) asm volatile("" ::"s"(p.wb1), "s"(p.so1));
+  if constexpr (MSEG) asm volatile("" ::"s"(p.wb2), "s"(p.so2), "s"(p.tb1), "s"(p.tb2));
+  if constexpr (ASYM) asm volatile("" ::"s"(p.zo0), "s"(p.zo1), "s"(p.zo2), "s"(p.zstride));
+
+  const int tid = threadIdx.x;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nn = l & 15, g = l >> 4;
+  const uint32_t NS = p.ns;
+  const uint32_t sl = blockIdx.x & ((1u << p.s_log2) - 1u);   // K slice of this workgroup
+  const uint32_t tg = blockIdx.x >> p.s_log2;                 // tile group
+  const uint32_t kb = sl * p.ksl;                             // first k-step of the slice
+  const uint32_t nks = min(p.ks - kb, p.ksl);                 // k-steps of the slice (host: kb < ks)
+  const uint32_t ntw = p.tiles_base + (tg < p.tiles_rem ? 1u : 0u);  // tiles of this workgroup
+  const int rows = min(p.m, kGsMaxRows);
+  const int rows_q = (rows + 3) >> 2;                         // lane groups g that hold live output rows
+  const uint32_t lds0 = uint32_t(reinterpret_cast<uintptr_t>((LdsPtr)(smem)));
+  const uint32_t voff_q = uint32_t(l) * 16u;
+
+  // ---- 1. the slice of the activations: fp16 rows, HBM/L2 -> LDS by DMA in 1 KiB pieces, dealt to ALL waves ----
+  uint32_t a_reqs = 0;
+  {
+    const Rsrc ra = make_rsrc(p.a, uint32_t(rows - 1) * uint32_t(p.lda) * 2u + uint32_t(p.k) * 2u);
+    const uint32_t row_bytes = nks * uint32_t(KSTEP) * 2u;
+    const uint32_t pieces = (row_bytes + 1023u) >> 10;
+    const uint32_t total = uint32_t(rows) * pieces;
+    const LdsPtr al = (LdsPtr)(smem) + p.a_off;
+    uint32_t r = 0, c = w;  // piece u = w + i * (NS + 1) is (row r, piece c): stepped, not divided
+    for (uint32_t u = w; u < total; u += NS + 1u) {
+      while (c >= pieces) c -= pieces, r++;
+      const uint32_t left = row_bytes - (c << 10);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (uint32_t(l) * 16u < left)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(al + r * p.row_stride * 2u + (c << 10)),
+                                                 16, voff_q, r * uint32_t(p.lda) * 2u + kb * uint32_t(KSTEP) * 2u + (c << 10), 0, 0);
+#endif
+      a_reqs++;
+      c += NS + 1u;
+    }
+  }
+  (void)a_reqs;
+  __builtin_amdgcn_sched_barrier(0);
+  // f4: every wave writes its share of the pair table while the requests above are in flight.  Lane l < 16 holds table
+  // value l (picked out of the eight argument words); entry e = {value[e & 15], value[e >> 4]} is fetched from those lanes
+  // by ds_bpermute.  Stores by hand: for a visible LDS store hipcc would first wait for every LDS-DMA request in flight.
+  if constexpr (TBL) {
+    uint32_t lv = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) lv = ((l >> 1) == i) ? p.lut16[i] : lv;
+    lv = (l & 1) ? (lv >> 16) : (lv & 0xffffu);
+    const uint32_t nthreads = (NS + 1u) * 64u;
+    for (uint32_t idx = uint32_t(tid); idx < kGsTblBytes / 4u; idx += nthreads) {
+      const uint32_t e = idx >> 5;  // 32 consecutive words = the 32 bank copies of entry e
+      const uint32_t v0 = uint32_t(__builtin_amdgcn_ds_bpermute(int((e & 15u) << 2), int(lv)));
+      const uint32_t v1 = uint32_t(__builtin_amdgcn_ds_bpermute(int((e >> 4) << 2), int(lv)));
+      asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + idx * 4u), "v"(v0 | (v1 << 16)) : "memory");
+    }
+  }
+  // f4: once the activations have landed (first barrier), shuffle every 16-byte fragment a0..a7 -> a0 a2 a4 a6 a1 a3 a5 a7, the
+  // order in which a lane's code bytes pair its eight weights; second barrier behind it
+  auto shuffle_a = [&]() {
+    if constexpr (TBL) {
+      const uint32_t nthreads = (NS + 1u) * 64u;
+      const uint32_t abase = lds0 + p.a_off;
+      for (uint32_t off = uint32_t(tid) * 16u; off < p.a_bytes; off += nthreads * 16u) {
+        uint4v d;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(abase + off) : "memory");
+        const uint4v o = {__builtin_amdgcn_perm(d.y, d.x, 0x05040100u), __builtin_amdgcn_perm(d.w, d.z, 0x05040100u),
+                          __builtin_amdgcn_perm(d.y, d.x, 0x07060302u), __builtin_amdgcn_perm(d.w, d.z, 0x07060302u)};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(abase + off), "v"(o) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+
+  if (w < NS) {
+    // =========================================== streaming wave ===========================================
+    const uint32_t nst = w < nks ? (nks - w + NS - 1u) / NS : 0u;  // k-steps of a tile's slice that are this wave's
+    const uint32_t total = ntw * nst * uint32_t(NQ);               // items (records) this wave consumes
+
+    const uint8_t* wbs[3] = {p.wb0, p.wb1, p.wb2};
+    const uint32_t sos[3] = {p.so0, p.so1, p.so2};
+    const uint32_t zos[3] = {p.zo0, p.zo1, p.zo2};
+    // issue-side tile context
+    Rsrc irw[NQ];
+    uint32_t iso[NQ], izo[NQ];
+    uint32_t itile_q = 0, itile_c = 0;
+    auto tile_ctx = [&](uint32_t T) {
+      uint32_t tl = T;
+      if constexpr (MSEG) {
+        const int sg = int(T >= p.tb1) + int(T >= p.tb2);
+        const uint8_t* wbp = sg == 0 ? wbs[0] : (sg == 1 ? wbs[1] : wbs[2]);
+        irw[0] = make_rsrc(wbp, 0x80000000u);
+        iso[0] = sg == 0 ? sos[0] : (sg == 1 ? sos[1] : sos[2]);
+        izo[0] = ASYM ? (sg == 0 ? zos[0] : (sg == 1 ? zos[1] : zos[2])) : 0u;
+        tl = T - (sg == 0 ? 0u : (sg == 1 ? p.tb1 : p.tb2));
+      }
+      itile_q = tl * p.ks * p.qstride;
+      itile_c = tl * p.srows;
+    };
+    if constexpr (!MSEG) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        irw[q] = make_rsrc(wbs[q], 0x80000000u);
+        iso[q] = sos[q];
+        izo[q] = zos[q];
+      }
+    }
+    tile_ctx(tg);
+
+    constexpr uint32_t SLOT = 1024u + 16u * SBYTES + (ASYM ? 16u * SPS : 0u);
+    constexpr int OPS = ASYM ? 3 : 2;
+    static_assert(OPS * PF <= 48, "vmcnt is a 6-bit counter: the ring and a few activation pieces must fit");
+    const LdsPtr ring = (LdsPtr)(smem) + p.ring_off + w * p.ring_stride;
+    const uint32_t ring_lane = uint32_t(reinterpret_cast<uintptr_t>(ring)) + uint32_t(l) * 16u;
+    const uint32_t ring_corr = uint32_t(reinterpret_cast<uintptr_t>(ring)) + 1024u + uint32_t(nn) * SBYTES;
+    const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
+
+    uint32_t ji = 0, ki = 0;  // issue side: tile ordinal, k ordinal
+    auto issue = [&](auto slot_c) {
+      constexpr int slot = decltype(slot_c)::value;
+      constexpr int q = slot % NQ;
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint32_t s = kb + w + ki * NS;
+      const uint32_t crow = itile_c + ((s * p.srow_mul) >> p.srow_shift);
+      const LdsPtr dst = ring + slot * SLOT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(irw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, voff_q,
+                                               itile_q + s * p.qstride, 0, 2);
+      if (l < SBYTES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(irw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst + 1024), 16,
+                                                 voff_q, iso[q] + crow * p.sstride, 0, 2);
+      if constexpr (ASYM) {
+        if (l < SPS)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(irw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst + 1024 + 16 * SBYTES),
+                                                   16, voff_q, izo[q] + crow * p.zstride, 0, 2);
+      }
+#endif
+      if constexpr (q == NQ - 1) {
+        ki++;
+        if (ki == nst) {
+          ki = 0;
+          ji++;
+          if (ji < ntw) tile_ctx(tg + ji * p.tg_count);
+        }
+      }
+    };
+    auto wait_records = [&](uint32_t younger) {
+      if (younger == uint32_t(PF - 1)) {
+        gvs_wait_vmcnt<OPS * (PF - 1)>();
+        return;
+      }
+      [&]<int... K>(std::integer_sequence<int, K...>) {
+        (void)((younger == uint32_t(K) ? (gvs_wait_vmcnt<OPS * K>(), true) : false) || ...);
+      }(std::make_integer_sequence<int, PF + 1>{});
+    };
+#define NS_FOR_SLOTS(BODY)                                        \
+  {                                                               \
+    [&]<int... I>(std::integer_sequence<int, I...>) {             \
+      (([&] { constexpr int i = I; std::integral_constant<int, I> ic; (void)i; (void)ic; BODY }()), ...); \
+    }(std::make_integer_sequence<int, PF>{});                     \
+  }
+
+    // ---- 2. fill the ring ----
+    NS_FOR_SLOTS({ if (uint32_t(i) < total) issue(ic); })
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3. this wave's activation pieces are the oldest requests in its queue ----
+    wait_records(min(total, uint32_t(PF)));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    shuffle_a();
+
+    const uint32_t aoff = uint32_t(min(nn, rows - 1)) * p.row_stride + 8 * g;
+    const _Float16* a_lds = reinterpret_cast<const _Float16*>(smem + p.a_off);
+    const uint32_t tbl_lane = lds0 + uint32_t(l & 31) * 4u;  // this lane's bank copy of the f4 pair table
+    floatx4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](auto slot_c, uint32_t srel) {  // srel: k-step inside the slice
+      constexpr int slot = decltype(slot_c)::value;
+      constexpr int q = slot % NQ;
+      if constexpr (NS_GVS_ABL == 3) return;
+      const _Float16* abase = a_lds + srel * KSTEP + aoff;
+      Corr cr;
+      {
+        typedef __attribute__((address_space(3))) const uint32_t* L32;
+        const uint32_t ca = ring_corr + uint32_t(slot) * SLOT;
+        if constexpr (SBYTES == 2) {
+          cr.s[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(ca);
+        } else {
+#pragma unroll
+          for (int t = 0; t < Corr::NW32; t++) cr.s[t] = reinterpret_cast<L32>(ca)[t];
+        }
+        if constexpr (ASYM) {
+          const uint32_t za = uint32_t(reinterpret_cast<uintptr_t>(ring)) + uint32_t(slot) * SLOT + 1024u + 16u * SBYTES + uint32_t(nn) * SPS;
+          if constexpr (SPS == 4)
+            cr.z[0] = *reinterpret_cast<L32>(za);
+          else if constexpr (SPS == 2)
+            cr.z[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(za);
+          else
+            cr.z[0] = *reinterpret_cast<__attribute__((address_space(3))) const uint8_t*>(za);
+        }
+      }
+      float sc[4], zp[4];
+      corr_decode<SPS, SK, ASYM, NJ>(cr, sc, zp);
+      const uint4v qvv = *reinterpret_cast<const __attribute__((address_space(3))) uint4v*>(ring_lane + uint32_t(slot) * SLOT);
+      const uint32_t xw[4] = {qvv.x, qvv.y, qvv.z, qvv.w};
+      half8_t bq[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        if constexpr (NS_GVS_ABL == 1) {
+          const uint4v raw = {xw[j], xw[(j + 1) & 3], xw[(j + 2) & 3], xw[(j + 3) & 3]};
+          bq[j] = __builtin_bit_cast(half8_t, raw);
+        } else if constexpr (KIND == WK_INT4) {
+          const _Float16 zl = (_Float16)(-1032.f - zp[j]), zh = (_Float16)(-72.f - zp[j]);
+          bq[j] = cvt_i4x8(xw[j], i4c, half2_t{zl, zl}, half2_t{zh, zh});
+        } else if constexpr (KIND == WK_INT8) {
+          const _Float16 zo8 = (_Float16)(-1152.f - zp[j]);
+          bq[j] = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo8, zo8});
+        } else if constexpr (KIND == WK_F8) {
+          bq[j] = cvt_f8x8(xw[2 * j], xw[2 * j + 1], p.f8);
+        } else if constexpr (TBL) {
+          // byte b of the word = codes (i0,i2) (i4,i6) (i1,i3) (i5,i7): entry b of this lane's table copy = their two values
+          typedef __attribute__((address_space(3))) const uint32_t* L32;
+          uint4v r;
+          r.x = *reinterpret_cast<L32>(__builtin_amdgcn_ubfe(xw[j], 0, 8) * 128u + tbl_lane);
+          r.y = *reinterpret_cast<L32>(__builtin_amdgcn_ubfe(xw[j], 8, 8) * 128u + tbl_lane);
+          r.z = *reinterpret_cast<L32>(__builtin_amdgcn_ubfe(xw[j], 16, 8) * 128u + tbl_lane);
+          r.w = *reinterpret_cast<L32>((xw[j] >> 24) * 128u + tbl_lane);
+          bq[j] = __builtin_bit_cast(half8_t, r);
+        } else {
+          bq[j] = cvt_f4x8(xw[j], p.lut);
+        }
+      }
+      if constexpr (SPS == 1 && NS_GVS_ABL == 0) {
+        // one scale for the whole record: the NJ products are chained through the accumulator, one scaling per record
+        floatx4 dsum = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const half8_t afrag = *reinterpret_cast<const half8_t*>(abase + 32 * j);
+          dsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bq[j], dsum, 0, 0, 0);
+        }
+        acc[q] += dsum * sc[0];
+        return;
+      }
+      floatx4 dd[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        half8_t afrag;
+        if constexpr (NS_GVS_ABL == 2) {
+          const uint4v raw = {uint32_t(srel) | 0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+          afrag = __builtin_bit_cast(half8_t, raw);
+        } else {
+          afrag = *reinterpret_cast<const half8_t*>(abase + 32 * j);
+        }
+        dd[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bq[j], floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[q] += dd[j] * sc[j];
+    };
+
+    // end of a tile: this wave's partial sums -> LDS slot, counter + 1.  All by hand: for a visible LDS store hipcc would
+    // first wait for every LDS-DMA request in flight (the whole ring)
+    const uint32_t ctl = lds0 + p.ctl_off;
+    const uint32_t red_lane = lds0 + p.red_off + w * p.red_wave + uint32_t(l) * 16u;
+    uint32_t jc = 0, kc = 0;  // compute side: tile ordinal, k ordinal
+    auto flush = [&]() {
+      const uint32_t slot_r = jc & uint32_t(kGsR - 1);
+      if (jc >= uint32_t(kGsR)) {  // the slot's previous tile (jc - kGsR) must have been taken by the service wave
+        uint32_t dv, spins = 0;
+        do {  // (bounded: a broken hand-back must end as a wrong result the tests see, not as a hung GPU)
+          asm volatile("ds_read_b32 %0, %1 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(dv) : "v"(ctl) : "memory");
+          dv = __builtin_amdgcn_readfirstlane(dv);
+          if (dv + uint32_t(kGsR) <= jc) __builtin_amdgcn_s_sleep(1);
+        } while (dv + uint32_t(kGsR) <= jc && ++spins < kGsSpinLimit);
+      }
+      if (g < rows_q) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+          asm volatile("ds_write_b128 %0, %1" ::"v"(red_lane + slot_r * p.red_slot + uint32_t(q) * uint32_t(rows_q) * 256u), "v"(acc[q])
+                       : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (l == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(ctl + slot_r * 4u), "v"(1u) : "memory");
+#pragma unroll
+      for (int q = 0; q < NQ; q++) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- 4. stream: consume the oldest record, refill its slot with the record PF items ahead; tiles follow each
+    //      other without a pause ----
+    for (uint32_t t0 = 0; t0 < total; t0 += PF) {
+      NS_FOR_SLOTS({
+        const uint32_t t = t0 + i;
+        if (t < total) {
+          wait_records(min(total - t - 1u, uint32_t(PF - 1)));
+          compute(ic, w + kc * NS);
+          if constexpr (i % NQ == NQ - 1) {
+            kc++;
+            if (kc == nst) {
+              flush();
+              kc = 0;
+              jc++;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + PF < total) issue(ic);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      })
+    }
+#undef NS_FOR_SLOTS
+  } else {
+    // =========================================== service wave ===========================================
+    // the LDS control words start at zero: written here, in front of the barrier every streaming wave passes before its
+    // first flush
+    if (l < int(kGsCtlBytes / 4)) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + p.ctl_off + uint32_t(l) * 4u), "v"(0u) : "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    shuffle_a();
+    const uint32_t active = min(NS, nks);  // streaming waves that own k-steps (the others never flush)
+    const GvsKArgs cold = gvs_late_args();
+    const int ldc = cold->ldc, ldd = cold->ldd, epi = cold->epilogue;
+    const float* dptr = cold->d;
+    float* c2 = cold->c2;
+    float* slab = cold->slab;
+    const uint32_t ctl = lds0 + p.ctl_off;
+    const uint32_t red0 = lds0 + p.red_off + uint32_t(l) * 16u;
+    typedef const volatile __attribute__((address_space(3))) floatx4* LdsF4;
+    for (uint32_t jt = 0; jt < ntw; jt++) {
+      const uint32_t T = tg + jt * p.tg_count;
+      uint32_t tl = T;
+      int sg = 0;
+      if constexpr (MSEG) {
+        sg = int(T >= p.tb1) + int(T >= p.tb2);
+        tl = T - (sg == 0 ? 0u : (sg == 1 ? p.tb1 : p.tb2));
+      }
+      const auto* mp = &cold->mat[MSEG ? sg : 0];
+      const int ncols = mp->n;
+      float* cbase = mp->c;
+      _Float16* c16 = mp->c16;
+      const int col = int(tl) * 16 + nn;
+      const bool col_ok = col < ncols;
+      // what the epilogue has to fetch is requested before the wait for the tile's partial sums
+      float dvp[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (!DUAL) {
+        if (dptr && col_ok && !slab) {
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++)
+            if (4 * g + rr < p.m) dvp[rr] = dptr[size_t(4 * g + rr) * ldd + col];
+        }
+      }
+      const uint32_t slot_r = jt & uint32_t(kGsR - 1);
+      {
+        uint32_t cv, spins = 0;
+        do {
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(ctl + slot_r * 4u) : "memory");
+          cv = __builtin_amdgcn_readfirstlane(cv);
+          if (cv < active) __builtin_amdgcn_s_sleep(1);
+        } while (cv < active && ++spins < kGsSpinLimit);
+      }
+      floatx4 sum[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) sum[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (g < rows_q) {
+        for (uint32_t ww = 0; ww < active; ww++) {
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const floatx4 v = *reinterpret_cast<LdsF4>(red0 + slot_r * p.red_slot + ww * p.red_wave + uint32_t(q) * uint32_t(rows_q) * 256u);
+            sum[q] += v;
+          }
+        }
+      }
+      // hand the slot back: counter to zero first, then the "done" ordinal the streaming waves wait for
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (l == 0) {
+        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %2, %3 offset:16" ::"v"(ctl + slot_r * 4u), "v"(0u), "v"(ctl),
+                     "v"(jt + 1u)
+                     : "memory");
+      }
+      if (slab) {
+        // split-K: the raw partial sums of (slice, tile) — summed over the slices, in slice order, by gemvs_finalize_kernel
+        if (g < rows_q) {
+#pragma unroll
+          for (int q = 0; q < NQ; q++)
+            *reinterpret_cast<floatx4*>(slab + ((size_t(sl) * p.ntiles + T) * NQ + q) * 256 + size_t(l) * 4) = sum[q];
+        }
+      } else {
+        gvs_epilogue<DUAL>(sum, p.m, col, col_ok, g, cbase, c16, ldc, dvp, c2, epi);
+      }
+    }
+  }
+}
+
+// split-K, second pass: one wave per tile unit adds the slices' partial sums in slice order and applies the epilogue
+struct GvsFinParams {
+  const float* slab;
+  uint32_t slices, ntiles, nq;
+  uint32_t tb1, tb2;
+  int m;
+  GvsMat mat[3];
+  float* c2;
+  const float* d;
+  int ldc, ldd, epilogue;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void gemvs_finalize_kernel(const GvsFinParams p) {
+  constexpr bool DUAL = MODE == GS_DUAL, MSEG = MODE == GS_MSEG;
+  constexpr int NQ = DUAL ? 2 : 1;
+  const int l = threadIdx.x & 63;
+  const uint32_t T = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (T >= p.ntiles) return;
+  const int nn = l & 15, g = l >> 4;
+  if (4 * g >= p.m) return;
+  uint32_t tl = T;
+  int sg = 0;
+  if constexpr (MSEG) {
+    sg = int(T >= p.tb1) + int(T >= p.tb2);
+    tl = T - (sg == 0 ? 0u : (sg == 1 ? p.tb1 : p.tb2));
+  }
+  const GvsMat& mp = p.mat[MSEG ? sg : 0];
+  const int col = int(tl) * 16 + nn;
+  const bool col_ok = col < mp.n;
+  float dvp[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (!DUAL) {
+    if (p.d && col_ok) {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        if (4 * g + rr < p.m) dvp[rr] = p.d[size_t(4 * g + rr) * p.ldd + col];
+    }
+  }
+  floatx4 sum[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    sum[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (uint32_t s = 0; s < p.slices; s++)
+      sum[q] += *reinterpret_cast<const floatx4*>(p.slab + ((size_t(s) * p.ntiles + T) * NQ + q) * 256 + size_t(l) * 4);
+  }
+  gvs_epilogue<DUAL>(sum, p.m, col, col_ok, g, mp.c, mp.c16, p.ldc, dvp, p.c2, p.epilogue);
+}
+
+// ============================================================================================================
+// host side
+// ============================================================================================================
+template <int KIND, int SPS, int SK, bool ASYM>
+static hipError_t launch_gvs_k(const GvsParams& p, int mode, int grid, int nwaves, size_t lds, hipStream_t st) {
+  const dim3 g(grid), b(nwaves * 64);
+#define NS_GS_LAUNCH(MODEV)                                                                                     \
+  {                                                                                                             \
+    auto k = gemvs_kernel<KIND, SPS, SK, ASYM, MODEV>;                                                          \
+    static const hipError_t attr =                                                                              \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kGsMaxLds)); \
+    if (attr != hipSuccess && lds > 64 * 1024) return attr;                                                     \
+    hipLaunchKernelGGL(k, g, b, lds, st, p);                                                                    \
+  }
+  if (mode == GS_DUAL)
+    NS_GS_LAUNCH(GS_DUAL)
+  else if (mode == GS_MSEG)
+    NS_GS_LAUNCH(GS_MSEG)
+  else
+    NS_GS_LAUNCH(GS_PLAIN)
+#undef NS_GS_LAUNCH
+  return hipGetLastError();
+}
+template <int KIND, int SPS, int SK>
+static hipError_t launch_gvs_a(const GvsParams& p, bool asym, int mode, int grid, int nwaves, size_t lds, hipStream_t st) {
+  if constexpr (KIND == WK_F4 || KIND == WK_F8) {
+    (void)asym;
+    return launch_gvs_k<KIND, SPS, SK, false>(p, mode, grid, nwaves, lds, st);
+  } else {
+    if (asym) return launch_gvs_k<KIND, SPS, SK, true>(p, mode, grid, nwaves, lds, st);
+    return launch_gvs_k<KIND, SPS, SK, false>(p, mode, grid, nwaves, lds, st);
+  }
+}
+template <int KIND, int SPS>
+static hipError_t launch_gvs_s(const GvsParams& p, uint32_t scale_dt, bool asym, int mode, int grid, int nwaves, size_t lds,
+                               hipStream_t st) {
+  if (scale_dt == DT_F32) return launch_gvs_a<KIND, SPS, SK_F32>(p, asym, mode, grid, nwaves, lds, st);
+  if (scale_dt == DT_F16) return launch_gvs_a<KIND, SPS, SK_F16>(p, asym, mode, grid, nwaves, lds, st);
+  return launch_gvs_a<KIND, SPS, SK_BF16>(p, asym, mode, grid, nwaves, lds, st);
+}
+
+// tuning / diagnostics (ns_hip_set_tuning): "gvs" 0 = off, 1 = from 2 rows (default), 2 = from 1 row;
+// "gvs_slices" / "gvs_waves" / "gvs_grid" force the decomposition (0 = by shape)
+static std::atomic<int> g_gvs_mode{-1};
+static std::atomic<int> g_gvs_slices{-1}, g_gvs_waves{-1}, g_gvs_grid{-1};
+static int env_or(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+void set_gemvs_tuning(int what, int value) {
+  (what == 0 ? g_gvs_mode : what == 1 ? g_gvs_slices : what == 2 ? g_gvs_waves : g_gvs_grid).store(value);
+}
+static int gvs_knob(std::atomic<int>& k, const char* env, int dflt) {
+  int v = k.load();
+  if (v < 0) {
+    v = env_or(env, dflt);
+    k.store(v);
+  }
+  return v;
+}
+static int gvs_cus() {
+  static const int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return cus;
+}
+
+struct GvsPlan {
+  int slices_log2 = 0, ns = 8, tg = 0;
+  size_t a_bytes = 0, lds = 0;
+  uint32_t ksl = 0, row_stride = 0, red_wave = 0, red_slot = 0, ring_stride = 0;
+  double cost = 0;
+};
+
+// hipErrorNotSupported: outside the kernel's envelope or not the better decomposition — the caller goes on to gemv_kernel
+hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
+  const int mode_knob = gvs_knob(g_gvs_mode, "NS_GVS", 1);
+  if (mode_knob == 0 || a.m < (mode_knob >= 2 ? 1 : 2) || a.m > kGsMaxRows) return hipErrorNotSupported;
+  if (a.link || a.rope || a.i8) return hipErrorNotSupported;  // carried norm / fused RoPE / int8-reference numerics: gemv_kernel
+  const ns_weight* w0 = a.seg[0].w;
+  const int nmat = a.nseg;
+  if (nmat < 1 || nmat > 3 || (a.dual && nmat != 2)) return hipErrorNotSupported;
+  // fp16 activations with 16-byte aligned rows; several rows need K to fill whole k-steps (a row's padding columns
+  // would otherwise read the next row through the descriptor).  A caller without the fp16 shadow (the reference's device
+  // graph hands over fp32 tensors) gets one conversion pass into scratch first (round to nearest even, what the shadow's
+  // producers do: bit-identical results either way, tests/test_gpu_fullsize.py)
+  const int kstep = w0->kstep_len;
+  const bool shadow = a.a16 != nullptr;
+  if (shadow ? ((a.lda & 7) || (reinterpret_cast<uintptr_t>(a.a16) & 15)) : (a.a == nullptr)) return hipErrorNotSupported;
+  if ((w0->k & 7) || (a.m > 1 && w0->k % kstep != 0)) return hipErrorNotSupported;
+  const int lda16 = shadow ? a.lda : w0->k;
+  if (uint64_t(a.m) * uint64_t(lda16) * 2 >= (uint64_t(1) << 30)) return hipErrorNotSupported;
+
+  GvsParams p;
+  memset(&p, 0, sizeof(p));
+  uint32_t tiles = 0;
+  uint32_t tbeg[3] = {0, 0xffffffffu, 0xffffffffu};
+  const uint8_t* wb[3] = {nullptr, nullptr, nullptr};
+  uint32_t soff[3] = {0, 0, 0}, zoff[3] = {0, 0, 0};
+  for (int i = 0; i < nmat; i++) {
+    const ns_weight* w = a.seg[i].w;
+    if (!w->single_span || w->alloc_bytes >= (size_t(1) << 31)) return hipErrorNotSupported;
+    if (w->kind != w0->kind || w->sps != w0->sps || w->scale_dt != w0->scale_dt || w->asym != w0->asym || w->k != w0->k ||
+        w->ksteps != w0->ksteps || w->qstride != w0->qstride || w->sstride != w0->sstride || w->zstride != w0->zstride ||
+        w->srows != w0->srows || w->blocksize != w0->blocksize)
+      return hipErrorNotSupported;
+    if (a.dual && w->ntiles != w0->ntiles) return hipErrorNotSupported;
+    wb[i] = reinterpret_cast<const uint8_t*>(w->codes);
+    soff[i] = uint32_t(reinterpret_cast<const uint8_t*>(w->scales) - wb[i]);
+    zoff[i] = w->zps ? uint32_t(reinterpret_cast<const uint8_t*>(w->zps) - wb[i]) : 0u;
+    tbeg[i] = a.dual ? 0u : tiles;
+    if (!a.dual || i == 0) tiles += uint32_t(w->ntiles);
+    p.mat[i] = GvsMat{wb[i], soff[i], zoff[i], tbeg[i], w->n, a.seg[i].c, static_cast<_Float16*>(a.seg[i].c16)};
+  }
+  const bool mseg = !a.dual && nmat > 1;
+  const int mode = a.dual ? GS_DUAL : (mseg ? GS_MSEG : GS_PLAIN);
+  const uint32_t ks = uint32_t(w0->ksteps);
+  if (tiles == 0 || ks == 0) return hipErrorNotSupported;
+
+  const int rows = a.m;
+  const int rows_q = (rows + 3) / 4;
+  const int nq = a.dual ? 2 : 1;
+  const uint32_t sbytes = uint32_t(w0->sps) * (w0->scale_dt == DT_F32 ? 4u : 2u);
+  const uint32_t slot = 1024u + 16u * sbytes + (w0->asym ? 16u * uint32_t(w0->sps) : 0u);
+  const int cus = gvs_cus();
+  const int force_s = gvs_knob(g_gvs_slices, "NS_GVS_SLICES", 0);
+  const int force_ns = gvs_knob(g_gvs_waves, "NS_GVS_WAVES", 0);
+  const int force_grid = gvs_knob(g_gvs_grid, "NS_GVS_GRID", 0);
+  const int max_wg = force_grid > 0 ? force_grid : cus;
+
+  // ---- the decomposition: slices S (power of two), tile groups, streaming waves ----
+  // cost of a candidate, in bytes a workgroup moves (the launch ends with its slowest workgroup): its weight records +
+  // half its activation slice (L2, about twice the HBM stream's rate per CU) + what the finalize launch of a split costs
+  auto plan_for = [&](int s_log2, GvsPlan* out) -> bool {
+    const uint32_t S = 1u << s_log2;
+    if (S > ks || int(S) > max_wg) return false;
+    GvsPlan pl;
+    pl.slices_log2 = s_log2;
+    pl.ksl = (ks + S - 1) / S;
+    if (uint64_t(pl.ksl) * (S - 1) >= ks) return false;  // an empty last slice
+    pl.row_stride = pl.ksl * uint32_t(kstep) + 8;
+    pl.a_bytes = (size_t(rows) * pl.row_stride * 2 + 15) & ~size_t(15);
+    const size_t tbl = w0->kind == WK_F4 ? size_t(kGsTblBytes) : 0;
+    pl.tg = int(std::min<uint32_t>(tiles, uint32_t(max_wg) / S));
+    if (pl.tg < 1) return false;
+    pl.red_wave = uint32_t(nq) * uint32_t(rows_q) * 256u;
+    // streaming waves: a count LDS holds that splits the slice's k-steps evenly, preferring ten or more waves in flight
+    // (latency hiding); t = k-steps of the busiest wave x waves x that preference
+    const uint32_t tiles_max = (tiles + uint32_t(pl.tg) - 1) / uint32_t(pl.tg);
+    auto ring_of = [&](int ns) {
+      const size_t items = size_t((pl.ksl + ns - 1) / ns) * nq * tiles_max;
+      return (std::min<size_t>(items, size_t(kGsPF)) * slot + 15) & ~size_t(15);
+    };
+    int best_ns = 0;
+    double best_t = 1e30;
+    for (int ns = 1; ns <= kGsMaxNS; ns++) {
+      if (force_ns > 0 && ns != std::min(force_ns, kGsMaxNS)) continue;
+      const size_t need = tbl + pl.a_bytes + kGsCtlBytes + size_t(kGsR) * ns * pl.red_wave + size_t(ns) * ring_of(ns);
+      if (need > kGsMaxLds) continue;
+      const double t = double((pl.ksl + ns - 1) / ns) * ns * (1.0 + 0.35 * std::max(0, 10 - ns) / 10.0);
+      if (t < best_t - 1e-9 || (t < best_t + 1e-9 && ns > best_ns)) best_t = t, best_ns = ns;
+    }
+    if (best_ns == 0) return false;
+    pl.ns = best_ns;
+    pl.ring_stride = uint32_t(ring_of(pl.ns));
+    pl.red_slot = uint32_t(pl.ns) * pl.red_wave;
+    pl.lds = tbl + pl.a_bytes + kGsCtlBytes + size_t(kGsR) * pl.red_slot + size_t(pl.ns) * pl.ring_stride;
+    pl.cost = double(tiles_max) * best_t * nq * slot + 0.5 * double(pl.a_bytes) + (S > 1 ? 75e3 : 0.0);
+    *out = pl;
+    return true;
+  };
+  GvsPlan best;
+  bool have = false;
+  for (int s_log2 = 0; s_log2 <= 5; s_log2++) {
+    if (force_s > 0 && (1 << s_log2) != force_s) continue;
+    GvsPlan pl;
+    if (!plan_for(s_log2, &pl)) continue;
+    if (!have || pl.cost < best.cost) best = pl, have = true;
+  }
+  if (!have) return hipErrorNotSupported;
+  const uint32_t S = 1u << best.slices_log2;
+
+  float* slab = nullptr;
+  if (S > 1) {
+    slab = static_cast<float*>(stream_scratch(st, size_t(S) * tiles * nq * 256 * sizeof(float), 2));
+    if (!slab) return hipErrorNotSupported;
+  }
+
+  const void* a16 = a.a16;
+  if (!shadow) {
+    void* sc = stream_scratch(st, size_t(a.m) * w0->k * 2, 0);
+    if (!sc) return hipErrorNotSupported;
+    const hipError_t ce = launch_cvt_a16(a.a, sc, a.m, w0->k, a.lda, w0->k, st);
+    if (ce != hipSuccess) return ce;
+    a16 = sc;
+  }
+  p.wb0 = wb[0], p.wb1 = wb[1], p.wb2 = wb[2];
+  p.a = a16;
+  p.so0 = soff[0], p.so1 = soff[1], p.so2 = soff[2];
+  p.zo0 = zoff[0], p.zo1 = zoff[1], p.zo2 = zoff[2];
+  p.ks = ks;
+  p.ksl = best.ksl;
+  p.s_log2 = uint32_t(best.slices_log2);
+  p.qstride = w0->qstride, p.sstride = w0->sstride, p.zstride = w0->zstride;
+  p.srows = uint32_t(w0->srows);
+  {
+    int mul, shift;
+    if (!srow_params(w0, &mul, &shift)) return hipErrorNotSupported;
+    p.srow_mul = uint32_t(mul), p.srow_shift = uint32_t(shift);
+  }
+  p.tb1 = mseg ? tbeg[1] : 0xffffffffu;
+  p.tb2 = (mseg && nmat > 2) ? tbeg[2] : 0xffffffffu;
+  p.ntiles = tiles;
+  p.tg_count = uint32_t(best.tg);
+  p.tiles_base = tiles / uint32_t(best.tg);
+  p.tiles_rem = tiles % uint32_t(best.tg);
+  p.ns = uint32_t(best.ns);
+  p.m = a.m, p.k = w0->k, p.lda = lda16;
+  p.row_stride = best.row_stride;
+  p.a_off = w0->kind == WK_F4 ? kGsTblBytes : 0u;
+  p.a_bytes = uint32_t(best.a_bytes);
+  p.ctl_off = p.a_off + uint32_t(best.a_bytes);
+  p.red_off = p.ctl_off + kGsCtlBytes;
+  p.ring_off = p.red_off + uint32_t(kGsR) * best.red_slot;
+  p.ring_stride = best.ring_stride;
+  p.red_wave = best.red_wave, p.red_slot = best.red_slot;
+  p.c2 = a.c2, p.d = a.d, p.ldc = a.ldc, p.ldd = a.ldd, p.epilogue = a.epilogue;
+  p.slab = slab;
+  if (w0->kind == WK_F4) {
+    f4_lut_planes(w0->lut, &p.lut);
+    for (int i = 0; i < 8; i++)
+      p.lut16[i] = uint32_t(__builtin_bit_cast(unsigned short, w0->lut[2 * i])) | (uint32_t(__builtin_bit_cast(unsigned short, w0->lut[2 * i + 1])) << 16);
+  }
+  p.f8 = f8_consts(w0->qtype);
+  const size_t lds = best.lds;
+  if (lds > kGsMaxLds) return hipErrorNotSupported;
+  const int grid = best.tg * int(S);
+  const int nwaves = best.ns + 1;
+
+  hipError_t e = hipSuccess;
+#define NS_DISPATCH(KIND)                                                                          \
+  switch (w0->sps) {                                                                               \
+    case 4: e = launch_gvs_s<KIND, 4>(p, w0->scale_dt, w0->asym, mode, grid, nwaves, lds, st); break;  \
+    case 2: e = launch_gvs_s<KIND, 2>(p, w0->scale_dt, w0->asym, mode, grid, nwaves, lds, st); break;  \
+    default: e = launch_gvs_s<KIND, 1>(p, w0->scale_dt, w0->asym, mode, grid, nwaves, lds, st); break; \
+  }
+  if (w0->kind == WK_INT4) {
+    NS_DISPATCH(WK_INT4)
+  } else if (w0->kind == WK_INT8) {
+    if (w0->sps == 2) e = launch_gvs_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, mode, grid, nwaves, lds, st);
+    else e = launch_gvs_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, mode, grid, nwaves, lds, st);
+  } else if (w0->kind == WK_F8) {
+    if (w0->sps == 2) e = launch_gvs_a<WK_F8, 2, SK_F32>(p, false, mode, grid, nwaves, lds, st);
+    else e = launch_gvs_a<WK_F8, 1, SK_F32>(p, false, mode, grid, nwaves, lds, st);
+  } else {
+    NS_DISPATCH(WK_F4)
+  }
+#undef NS_DISPATCH
+  if (e != hipSuccess || S == 1) return e;
+
+  GvsFinParams f;
+  memset(&f, 0, sizeof(f));
+  f.slab = slab;
+  f.slices = S, f.ntiles = tiles, f.nq = uint32_t(nq);
+  f.tb1 = p.tb1, f.tb2 = p.tb2;
+  f.m = a.m;
+  for (int i = 0; i < 3; i++) f.mat[i] = p.mat[i];
+  f.c2 = a.c2, f.d = a.d, f.ldc = a.ldc, f.ldd = a.ldd, f.epilogue = a.epilogue;
+  const dim3 fg((tiles + 3) / 4), fb(256);
+  if (mode == GS_DUAL)
+    hipLaunchKernelGGL(gemvs_finalize_kernel<GS_DUAL>, fg, fb, 0, st, f);
+  else if (mode == GS_MSEG)
+    hipLaunchKernelGGL(gemvs_finalize_kernel<GS_MSEG>, fg, fb, 0, st, f);
+  else
+    hipLaunchKernelGGL(gemvs_finalize_kernel<GS_PLAIN>, fg, fb, 0, st, f);
+  return hipGetLastError();
+}
+
+}  // namespace ns

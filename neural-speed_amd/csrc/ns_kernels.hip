@@ -686,8 +686,10 @@ static hipError_t launch_smallm_s(const SmallMParams& p, bool asym, bool dual, i
 bool smallm_dual_ok(int m) { return m <= 16; }
 
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st) {
-  if (a.m <= 16) {  // decode / small batches: the second-generation streaming kernel (ns_gemv.hip)
-    const hipError_t e = launch_gemv(a, st);
+  if (a.m <= 16) {  // decode / small batches: the shared-activation kernel (ns_gemvs.hip) from two rows on ...
+    hipError_t e = launch_gemvs(a, st);
+    if (e != hipErrorNotSupported) return e;
+    e = launch_gemv(a, st);  // ... the one-tile-per-workgroup streaming kernel (ns_gemv.hip) for single rows
     if (e != hipErrorNotSupported) return e;
   }
   if (a.link || a.rope) return hipErrorNotSupported;  // carried norm / fused RoPE exist only in gemv_kernel: never silently dropped

@@ -8,7 +8,7 @@ for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   # FILES = which kernel sources get the flags (the others are linked from the regular build)
   objs=""
-  for f in ns_kernels ns_gemv ns_gemm ns_attn; do
+  for f in ns_kernels ns_gemv ns_gemvs ns_gemm ns_attn; do
     if [[ " ${FILES:-ns_kernels ns_gemv ns_gemm} " == *" $f "* ]]; then
       /opt/rocm/bin/hipcc -O3 -std=c++20 $flags -fPIC --offload-arch=gfx950 -c $f.hip -o /tmp/${f}_$name.o &
       objs="$objs /tmp/${f}_$name.o"
