@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-only", action="store_true", help="diagnostics: skip the roofline / prefill / CPU legs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE config 4 / config 5 legs")
+    ap.add_argument("--secondary-only", action="store_true", help="diagnostics: print the config 4 / config 5 legs alone and exit")
     ap.add_argument("--full-token-only", action="store_true", help="diagnostics: print the whole-token leg alone and exit")
     return ap.parse_args()
 
@@ -395,6 +397,9 @@ def main():
         full = fg == "force" or (fg == "1" and (backend == "nccl" or p2p_on))
         return ([True] if full else []) + ["segments", False]
 
+    if args.secondary_only and world == 1:
+        print(json.dumps(secondary_configs(pkg)))
+        return
     if args.full_token_only and world == 1:
         ft, _ = full_token(chain, pkg, 2048, fused=True)
         print(json.dumps({"full_token": ft}))
@@ -509,6 +514,12 @@ def main():
             out["config"]["prefill_m2048_tflops_int8w"] = prefill_tflops_int8w(chain, pkg)
             out["config"]["prefill_m2048_tflops_ref_int8_semantics"] = prefill_tflops_ref_int8(chain, pkg)
             out["config"]["decode_tokens_per_s_ref_int8_semantics"] = decode_ref_int8(step, pkg)
+            if not args.no_secondary:
+                sec = secondary_configs(pkg)
+                out["config"]["config4_tokens_per_s"] = sec["config4"]["tokens_per_s"]
+                out["config"]["config5_rank_ms"] = sec["config5"]["ms_per_step"]
+                out["config"]["config4"] = sec["config4"]
+                out["config"]["config5"] = sec["config5"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.layers)
         print(json.dumps(out))
@@ -936,6 +947,132 @@ def parity_vs_oracle(chain, pkg):
     lg = gpu(chain.head, x)
     out["lm_head"] = nso.rel_l2(lg.cpu().numpy(), nso.gemv_f32(x.cpu().numpy(), blob(chain.host_blobs["head"]), ncores))
     return {k: float("%.3g" % v) for k, v in out.items()}
+
+
+def secondary_configs(pkg):
+    """BASELINE.json configs 4 and 5 on this GPU, each with a parity value against the oracle:
+      config 4  Mistral-7B NF4 g128 (bf16 scales), batch 8 decode: tokens/s of the GEMM chain (fused QKV with GQA widths, WO, fused
+                gate/up, down) — enough DIFFERENT layers in one HIP graph to exceed the 256 MB Infinity Cache several times, x 32
+                layers + lm_head; the small-batch kernel (ns_gemvs.hip) serves every launch
+      config 5  Llama-2-70B Q4_0 g32, batch 1, ONE rank's shards of TP = 8 (model_files.h:145-190 split rules): ms per token of
+                that rank's GEMMs (160 all-reduces of 32 KB per token come on top)
+    Same protocol as scripts/config_bench.py (kept as the per-shape breakdown).  Parity: one layer's launches against the
+    oracle's fp64 GEMM on the same blobs (relative L2, bar 1e-3)."""
+    nso = ge.load_oracle()
+    L = pkg.lib()
+
+    def make(n, k, qt, st_dt, bs, comp, seed):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        w = torch.randn((n, k), generator=g, device="cuda") * 0.02
+        size = L.ns_BTLAGemmPackBSize(n, k, bs, qt, st_dt, False, comp, None)
+        blob = torch.zeros(size, dtype=torch.uint8, device="cuda")
+        pkg.check(L.ns_hip_quant_pack_device(blob.data_ptr(), w.data_ptr(), n, k, k, bs, qt, st_dt, False, comp, True, st))
+        wt = pkg.Weight.from_device_blob(blob.data_ptr(), size, st)
+        torch.cuda.synchronize()
+        return wt, blob
+
+    def graph_us(fn, reps=20):
+        for _ in range(3):
+            fn(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    def host(blob):
+        b = nso.aligned_bytes(blob.numel())
+        b[:] = blob.cpu().numpy()
+        return b
+
+    def run(d_in, qn, kvn, o_k, ff_n, vocab, fmt, m, n_layers, min_bytes=700e6):
+        qt, st_dt, bs, comp = fmt
+        layers = []
+        while True:
+            i = len(layers)
+            lw = {nm: make(n, k, qt, st_dt, bs, comp, 100 + 8 * i + j) for j, (nm, n, k) in enumerate(
+                [("q", qn, d_in), ("k", kvn, d_in), ("v", kvn, d_in), ("o", d_in, o_k), ("w1", ff_n, d_in), ("w3", ff_n, d_in), ("w2", d_in, ff_n)])}
+            layers.append(lw)
+            per_layer = sum(w[0].stream_bytes for w in lw.values())
+            if per_layer * len(layers) >= min_bytes or len(layers) >= n_layers:
+                break
+        ldq = max(qn, kvn)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.randn((m, d_in), generator=g, device="cuda")
+        xh = x.half()
+        qkv = torch.empty((3, m, ldq), device="cuda"); qkvh = torch.empty((3, m, ldq), device="cuda", dtype=torch.float16)
+        att = torch.empty((m, d_in), device="cuda"); atth = torch.empty((m, d_in), device="cuda", dtype=torch.float16)
+        t2 = torch.empty((m, ff_n), device="cuda"); t2h = torch.empty((m, ff_n), device="cuda", dtype=torch.float16)
+        y = torch.empty((m, d_in), device="cuda"); yh = torch.empty((m, d_in), device="cuda", dtype=torch.float16)
+
+        def layer(lw, xi, xih, s):
+            pkg.check(L.ns_hip_fusion_qkv_forward_h(xi.data_ptr(), xih.data_ptr(), lw["q"][0].h, lw["k"][0].h, lw["v"][0].h, qkv.data_ptr(),
+                                                    qkvh.data_ptr(), m, d_in, ldq, s))
+            # attention is its own operator: the first o_k columns of the q slice stand in for its output
+            pkg.check(L.ns_hip_f32f32_forward_h(qkv.data_ptr(), qkvh.data_ptr(), lw["o"][0].h, att.data_ptr(), atth.data_ptr(), m, ldq, d_in,
+                                                pkg.EPI_NONE, None, 0, s))
+            pkg.check(L.ns_hip_fusion_ffn3_forward_h(att.data_ptr(), atth.data_ptr(), lw["w1"][0].h, lw["w2"][0].h, lw["w3"][0].h, None,
+                                                     t2.data_ptr(), t2h.data_ptr(), y.data_ptr(), yh.data_ptr(), m, pkg.EPI_SILU, s))
+
+        def chain(s):
+            xi, xih = x, xh
+            for lw in layers:
+                layer(lw, xi, xih, s)
+                xi, xih = y, yh
+        us_layer = graph_us(chain) / len(layers)
+        head, head_blob = make(vocab, d_in, qt, st_dt, bs, comp, 99)
+        lg = torch.empty((m, vocab), device="cuda")
+        us_head = graph_us(lambda s: pkg.check(L.ns_hip_f32f32_forward_h(y.data_ptr(), yh.data_ptr(), head.h, lg.data_ptr(), None, m, d_in, vocab,
+                                                                         pkg.EPI_NONE, None, 0, s)), reps=10)
+        # ---- parity of layer 0's launches (they ran last inside graph_us with xi = x only for layer 0: run it again alone) ----
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        layer(layers[0], x, xh, st)
+        torch.cuda.synchronize()
+        lw = layers[0]
+        par = {}
+        xn = x.cpu().numpy()
+        qn_ = qkv.cpu().numpy()
+        for i, nm in enumerate("qkv"):
+            n = qn if nm == "q" else kvn
+            par["w" + nm] = nso.rel_l2(qn_[i][:, :n], nso.gemm_f64(xn, host(lw[nm][1])))
+        par["wo"] = nso.rel_l2(att.cpu().numpy(), nso.gemm_f64(np.ascontiguousarray(qkv[0][:, :o_k].cpu().numpy()), host(lw["o"][1])))
+        an = att.cpu().numpy()
+        h1 = nso.gemm_f64(an, host(lw["w1"][1])).astype(np.float64)
+        h3 = nso.gemm_f64(an, host(lw["w3"][1])).astype(np.float64)
+        par["ffn_gate_up"] = nso.rel_l2(t2.cpu().numpy(), (h1 / (1.0 + np.exp(-h1))) * h3)
+        par["ffn_down"] = nso.rel_l2(y.cpu().numpy(), nso.gemm_f64(t2.cpu().numpy(), host(lw["w2"][1])))
+        byt_layer = sum(w[0].stream_bytes for w in lw.values())
+        tot_us = us_layer * n_layers + us_head
+        tot_b = byt_layer * n_layers + head.stream_bytes
+        for l_ in layers:
+            for w in l_.values():
+                w[0].free()
+        head.free()
+        return {"layers_in_graph": len(layers), "us_per_layer": round(us_layer, 2), "us_lm_head": round(us_head, 2),
+                "ms_per_step": round(tot_us / 1e3, 4), "weight_bytes_per_step": int(tot_b),
+                "hbm_GBps": round(tot_b / tot_us / 1e3, 1), "frac_of_8TBps": round(tot_b / tot_us / 8e6, 3),
+                "parity_rel_l2_vs_oracle": {k: float("%.3g" % v) for k, v in par.items()}}, tot_us
+
+    out = {}
+    c4, us4 = run(4096, 4096, 1024, 4096, 14336, 32000, (pkg.F4_NF4, pkg.BF16, 128, pkg.COMP_BF16), 8, 32)
+    c4["tokens_per_s"] = round(8 * 1e6 / us4, 1)
+    c4["workload"] = "Mistral-7B NF4 g128 bf16-scale, batch 8 decode GEMM chain, 32 layers x {QKV (GQA 4096/1024/1024), WO, gate/up, down} + lm_head"
+    out["config4"] = c4
+    d, ff, kvd = 8192, 28672, 1024
+    c5, us5 = run(d, d // 8, kvd // 8, d // 8, ff // 8, 32000, (pkg.S4, pkg.BF16, 32, pkg.COMP_INT8), 1, 80)
+    c5["workload"] = "Llama-2-70B Q4_0 g32, batch 1, one rank's shards of TP = 8 (N or K / 8), 80 layers + lm_head; all-reduces not included"
+    out["config5"] = c5
+    return out
 
 
 def _cpu_model():

@@ -34,6 +34,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -45,14 +46,15 @@
 namespace ns {
 
 #ifndef NS_GVS_PF
-#define NS_GVS_PF 4
+#define NS_GVS_PF 2
 #endif
 // diagnostic builds (scripts/build_variants.sh): 1 = no code -> fp16 conversion (raw bits as operands), 2 = no activation
 // fragment reads, 3 = records are waited for and refilled but not read or multiplied (the structure's streaming rate)
 #ifndef NS_GVS_ABL
 #define NS_GVS_ABL 0
 #endif
-constexpr int kGsPF = NS_GVS_PF;        // records each streaming wave keeps in flight
+constexpr int kGsPF = NS_GVS_PF;        // records each streaming wave keeps in flight (with up to 15 waves per CU; deeper
+                                        // rings measured no faster from 12 waves on and cost LDS, profiles/r04b_ablation.txt)
 constexpr int kGsR = 2;                 // reduction slots (tiles whose partial sums may be pending in LDS)
 constexpr int kGsMaxRows = 16;
 constexpr int kGsMaxNS = 15;            // streaming waves (+ the service wave = 16 waves = 1024 threads)
@@ -103,7 +105,22 @@ struct GvsParams {
   float* slab;              // split-K: [slice][tile unit][q][64 lanes][4] fp32 partial sums
   F4Lut lut;
   F8Consts f8;
+#ifdef NS_TRACE
+  unsigned long long* trace;
+#endif
 };
+#ifdef NS_TRACE
+unsigned long long* trace_buffer();
+#define NS_SSTAMP(i)                                                                                     \
+  do {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                                     \
+      p.trace[(size_t(blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64();                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+#else
+#define NS_SSTAMP(i)
+#endif
 using GvsKArgs = const __attribute__((address_space(4))) GvsParams*;
 __device__ __forceinline__ GvsKArgs gvs_late_args() {
   uint64_t v = reinterpret_cast<uint64_t>(__builtin_amdgcn_kernarg_segment_ptr());
@@ -157,7 +174,10 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
   constexpr int PF = kGsPF;
   static_assert(PF % NQ == 0, "ring slots alternate between the two matrices");
   constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
-  constexpr bool TBL = KIND == WK_F4 && NS_GVS_ABL != 1;  // f4 codes are decoded through the LDS pair table
+  // f4 codes are decoded through the LDS pair table when the launch has enough records per wave to pay for building it
+  // (host: p.a_off != 0 — the table sits in front of the activations), by v_perm lookups otherwise
+  constexpr bool TBLK = KIND == WK_F4 && NS_GVS_ABL != 1;
+  const bool TBL = TBLK && p.a_off != 0;
   using Corr = CorrRaw<SPS, SK, ASYM>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) unsigned char* LdsPtr;
@@ -172,6 +192,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
   if constexpr (MSEG) asm volatile("" ::"s"(p.wb2), "s"(p.so2), "s"(p.tb1), "s"(p.tb2));
   if constexpr (ASYM) asm volatile("" ::"s"(p.zo0), "s"(p.zo1), "s"(p.zo2), "s"(p.zstride));
 
+  NS_SSTAMP(0);
   const int tid = threadIdx.x;
   const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
@@ -187,66 +208,87 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
   const uint32_t lds0 = uint32_t(reinterpret_cast<uintptr_t>((LdsPtr)(smem)));
   const uint32_t voff_q = uint32_t(l) * 16u;
 
-  // ---- 1. the slice of the activations: fp16 rows, HBM/L2 -> LDS by DMA in 1 KiB pieces, dealt to ALL waves ----
-  uint32_t a_reqs = 0;
-  {
+  // ---- the slice of the activations: fp16 rows, HBM/L2 -> LDS by DMA in 1 KiB pieces, dealt to ALL waves.  Requested
+  //      AFTER the streaming waves' first weight records (those come from HBM and take longest; profiles/r04e_trace.txt: with
+  //      the activations and the table in front, the first weight request left 3.4 us after entry) ----
+  const uint32_t a_row_bytes = nks * uint32_t(KSTEP) * 2u;
+  const uint32_t a_pieces = (a_row_bytes + 1023u) >> 10;
+  const uint32_t a_total = uint32_t(rows) * a_pieces;
+  const LdsPtr al = (LdsPtr)(smem) + p.a_off;
+  auto stage_a = [&]() {
     const Rsrc ra = make_rsrc(p.a, uint32_t(rows - 1) * uint32_t(p.lda) * 2u + uint32_t(p.k) * 2u);
-    const uint32_t row_bytes = nks * uint32_t(KSTEP) * 2u;
-    const uint32_t pieces = (row_bytes + 1023u) >> 10;
-    const uint32_t total = uint32_t(rows) * pieces;
-    const LdsPtr al = (LdsPtr)(smem) + p.a_off;
     uint32_t r = 0, c = w;  // piece u = w + i * (NS + 1) is (row r, piece c): stepped, not divided
-    for (uint32_t u = w; u < total; u += NS + 1u) {
-      while (c >= pieces) c -= pieces, r++;
-      const uint32_t left = row_bytes - (c << 10);
+    for (uint32_t u = w; u < a_total; u += NS + 1u) {
+      while (c >= a_pieces) c -= a_pieces, r++;
+      const uint32_t left = a_row_bytes - (c << 10);
 #if defined(__HIP_DEVICE_COMPILE__)
       if (uint32_t(l) * 16u < left)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, reinterpret_cast<__attribute__((address_space(3))) void*>(al + r * p.row_stride * 2u + (c << 10)),
                                                  16, voff_q, r * uint32_t(p.lda) * 2u + kb * uint32_t(KSTEP) * 2u + (c << 10), 0, 0);
 #endif
-      a_reqs++;
       c += NS + 1u;
     }
-  }
-  (void)a_reqs;
-  __builtin_amdgcn_sched_barrier(0);
-  // f4: every wave writes its share of the pair table while the requests above are in flight.  Lane l < 16 holds table
-  // value l (picked out of the eight argument words); entry e = {value[e & 15], value[e >> 4]} is fetched from those lanes
-  // by ds_bpermute.  Stores by hand: for a visible LDS store hipcc would first wait for every LDS-DMA request in flight.
-  if constexpr (TBL) {
-    uint32_t lv = 0;
+  };
+  auto build_table = [&]() {
+    // f4: every wave writes its share of the pair table while its requests are in flight.  Lane l < 16 holds table
+    // value l (picked out of the eight argument words); entry e = {value[e & 15], value[e >> 4]} is fetched from those lanes
+    // by ds_bpermute.  Stores by hand: for a visible LDS store hipcc would first wait for every LDS-DMA request in flight.
+    if (TBL) {
+      uint32_t lv = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) lv = ((l >> 1) == i) ? p.lut16[i] : lv;
-    lv = (l & 1) ? (lv >> 16) : (lv & 0xffffu);
-    const uint32_t nthreads = (NS + 1u) * 64u;
-    for (uint32_t idx = uint32_t(tid); idx < kGsTblBytes / 4u; idx += nthreads) {
-      const uint32_t e = idx >> 5;  // 32 consecutive words = the 32 bank copies of entry e
-      const uint32_t v0 = uint32_t(__builtin_amdgcn_ds_bpermute(int((e & 15u) << 2), int(lv)));
-      const uint32_t v1 = uint32_t(__builtin_amdgcn_ds_bpermute(int((e >> 4) << 2), int(lv)));
-      asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + idx * 4u), "v"(v0 | (v1 << 16)) : "memory");
-    }
-  }
-  // f4: once the activations have landed (first barrier), shuffle every 16-byte fragment a0..a7 -> a0 a2 a4 a6 a1 a3 a5 a7, the
-  // order in which a lane's code bytes pair its eight weights; second barrier behind it
-  auto shuffle_a = [&]() {
-    if constexpr (TBL) {
+      for (int i = 0; i < 8; i++) lv = ((l >> 1) == i) ? p.lut16[i] : lv;
+      lv = (l & 1) ? (lv >> 16) : (lv & 0xffffu);
       const uint32_t nthreads = (NS + 1u) * 64u;
-      const uint32_t abase = lds0 + p.a_off;
-      for (uint32_t off = uint32_t(tid) * 16u; off < p.a_bytes; off += nthreads * 16u) {
-        uint4v d;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(abase + off) : "memory");
-        const uint4v o = {__builtin_amdgcn_perm(d.y, d.x, 0x05040100u), __builtin_amdgcn_perm(d.w, d.z, 0x05040100u),
-                          __builtin_amdgcn_perm(d.y, d.x, 0x07060302u), __builtin_amdgcn_perm(d.w, d.z, 0x07060302u)};
-        asm volatile("ds_write_b128 %0, %1" ::"v"(abase + off), "v"(o) : "memory");
+      for (uint32_t idx = uint32_t(tid); idx < kGsTblBytes / 4u; idx += nthreads) {
+        const uint32_t e = idx >> 5;  // 32 consecutive words = the 32 bank copies of entry e
+        const uint32_t v0 = uint32_t(__builtin_amdgcn_ds_bpermute(int((e & 15u) << 2), int(lv)));
+        const uint32_t v1 = uint32_t(__builtin_amdgcn_ds_bpermute(int((e >> 4) << 2), int(lv)));
+        asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + idx * 4u), "v"(v0 | (v1 << 16)) : "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+  // f4: a lane's code bytes pair its eight weights as (i0,i2) (i4,i6) (i1,i3) (i5,i7); every 16-byte activation fragment
+  // a0..a7 is therefore re-ordered to a0 a2 a4 a6 a1 a3 a5 a7 — by the wave that requested the piece (one fragment per lane
+  // and piece), once its own requests have landed and before the workgroup barrier
+  auto shuffle_own_a = [&]() {
+    if (TBL) {
+      constexpr int B = 4;  // fragments read before the first is written back
+      uint32_t r = 0, c = w;
+      for (uint32_t u = w; u < a_total; u += (NS + 1u) * B) {
+        uint32_t addr[B];
+        uint4v d[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          addr[b] = 0xffffffffu;
+          if (u + uint32_t(b) * (NS + 1u) < a_total) {
+            while (c >= a_pieces) c -= a_pieces, r++;
+            const uint32_t left = a_row_bytes - (c << 10);
+            if (uint32_t(l) * 16u < left) addr[b] = lds0 + p.a_off + r * p.row_stride * 2u + (c << 10) + uint32_t(l) * 16u;
+            c += NS + 1u;
+          }
+          d[b] = uint4v{0u, 0u, 0u, 0u};
+          if (addr[b] != 0xffffffffu) asm volatile("ds_read_b128 %0, %1" : "=v"(d[b]) : "v"(addr[b]) : "memory");
+        }
+#pragma unroll
+        for (int b = 0; b < B; b++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[b])::"memory");
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          const uint4v o = {__builtin_amdgcn_perm(d[b].y, d[b].x, 0x05040100u), __builtin_amdgcn_perm(d[b].w, d[b].z, 0x05040100u),
+                            __builtin_amdgcn_perm(d[b].y, d[b].x, 0x07060302u), __builtin_amdgcn_perm(d[b].w, d[b].z, 0x07060302u)};
+          if (addr[b] != 0xffffffffu) asm volatile("ds_write_b128 %0, %1" ::"v"(addr[b]), "v"(o) : "memory");
+        }
+      }
     }
   };
 
   if (w < NS) {
     // =========================================== streaming wave ===========================================
-    const uint32_t nst = w < nks ? (nks - w + NS - 1u) / NS : 0u;  // k-steps of a tile's slice that are this wave's
-    const uint32_t total = ntw * nst * uint32_t(NQ);               // items (records) this wave consumes
+    // the workgroup's work is the flat sequence of units u = tile ordinal * nks + k-step; unit u belongs to wave u % NS: every
+    // wave gets the same number of units (+-1) whatever NS and nks are, and runs from one tile into the next
+    const uint32_t nunits = ntw * nks;
+    const uint32_t nun = w < nunits ? (nunits - w + NS - 1u) / NS : 0u;  // this wave's units
+    const uint32_t total = nun * uint32_t(NQ);                           // items (records) this wave consumes
+    const uint32_t j0 = w / nks, s0 = w - j0 * nks;                      // its first unit
 
     const uint8_t* wbs[3] = {p.wb0, p.wb1, p.wb2};
     const uint32_t sos[3] = {p.so0, p.so1, p.so2};
@@ -276,7 +318,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
         izo[q] = zos[q];
       }
     }
-    tile_ctx(tg);
+    if (nun) tile_ctx(tg + j0 * p.tg_count);
 
     constexpr uint32_t SLOT = 1024u + 16u * SBYTES + (ASYM ? 16u * SPS : 0u);
     constexpr int OPS = ASYM ? 3 : 2;
@@ -286,12 +328,12 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
     const uint32_t ring_corr = uint32_t(reinterpret_cast<uintptr_t>(ring)) + 1024u + uint32_t(nn) * SBYTES;
     const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
-    uint32_t ji = 0, ki = 0;  // issue side: tile ordinal, k ordinal
+    uint32_t ji = j0, ki = s0;  // issue side: tile ordinal, k-step inside the slice
     auto issue = [&](auto slot_c) {
       constexpr int slot = decltype(slot_c)::value;
       constexpr int q = slot % NQ;
 #if defined(__HIP_DEVICE_COMPILE__)
-      const uint32_t s = kb + w + ki * NS;
+      const uint32_t s = kb + ki;
       const uint32_t crow = itile_c + ((s * p.srow_mul) >> p.srow_shift);
       const LdsPtr dst = ring + slot * SLOT;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(irw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, voff_q,
@@ -305,11 +347,13 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
                                                    16, voff_q, izo[q] + crow * p.zstride, 0, 2);
       }
 #endif
-      if constexpr (q == NQ - 1) {
-        ki++;
-        if (ki == nst) {
-          ki = 0;
-          ji++;
+      if constexpr (q == NQ - 1) {  // next unit of this wave: NS units on
+        ki += NS;
+        if (ki >= nks) {
+          do {
+            ki -= nks;
+            ji++;
+          } while (ki >= nks);
           if (ji < ntw) tile_ctx(tg + ji * p.tg_count);
         }
       }
@@ -330,13 +374,21 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
     }(std::make_integer_sequence<int, PF>{});                     \
   }
 
-    // ---- 2. fill the ring ----
+    // ---- 1. this wave's share of the activations (a handful of requests, L2), its first weight records (HBM), then its
+    //      share of the f4 table while both are in flight (the table in FRONT of the weight requests delayed them to 3.4 us
+    //      after entry, profiles/r04e_trace.txt) ----
+    stage_a();
     NS_FOR_SLOTS({ if (uint32_t(i) < total) issue(ic); })
     __builtin_amdgcn_sched_barrier(0);
-    // ---- 3. this wave's activation pieces are the oldest requests in its queue ----
+    NS_SSTAMP(1);
+    build_table();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. the activation pieces are the oldest requests in this wave's queue: landed once only ring requests are left ----
     wait_records(min(total, uint32_t(PF)));
+    NS_SSTAMP(2);
+    shuffle_own_a();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    shuffle_a();
+    NS_SSTAMP(3);
 
     const uint32_t aoff = uint32_t(min(nn, rows - 1)) * p.row_stride + 8 * g;
     const _Float16* a_lds = reinterpret_cast<const _Float16*>(smem + p.a_off);
@@ -388,7 +440,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
           bq[j] = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo8, zo8});
         } else if constexpr (KIND == WK_F8) {
           bq[j] = cvt_f8x8(xw[2 * j], xw[2 * j + 1], p.f8);
-        } else if constexpr (TBL) {
+        } else if (TBLK && TBL) {
           // byte b of the word = codes (i0,i2) (i4,i6) (i1,i3) (i5,i7): entry b of this lane's table copy = their two values
           typedef __attribute__((address_space(3))) const uint32_t* L32;
           uint4v r;
@@ -432,7 +484,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
     // first wait for every LDS-DMA request in flight (the whole ring)
     const uint32_t ctl = lds0 + p.ctl_off;
     const uint32_t red_lane = lds0 + p.red_off + w * p.red_wave + uint32_t(l) * 16u;
-    uint32_t jc = 0, kc = 0;  // compute side: tile ordinal, k ordinal
+    uint32_t jc = j0, kc = s0;  // compute side: tile ordinal, k-step inside the slice
     auto flush = [&]() {
       const uint32_t slot_r = jc & uint32_t(kGsR - 1);
       if (jc >= uint32_t(kGsR)) {  // the slot's previous tile (jc - kGsR) must have been taken by the service wave
@@ -462,13 +514,18 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
         const uint32_t t = t0 + i;
         if (t < total) {
           wait_records(min(total - t - 1u, uint32_t(PF - 1)));
-          compute(ic, w + kc * NS);
+          compute(ic, kc);
           if constexpr (i % NQ == NQ - 1) {
-            kc++;
-            if (kc == nst) {
+            kc += NS;
+            if (kc >= nks || t + 1u == total) {  // the wave's next unit lies in another tile (or there is none): hand over this tile's sums
               flush();
-              kc = 0;
-              jc++;
+#ifdef NS_TRACE
+              if (jc == j0) NS_SSTAMP(4);
+#endif
+              while (kc >= nks) {
+                kc -= nks;
+                jc++;
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -478,15 +535,23 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
       })
     }
 #undef NS_FOR_SLOTS
+    NS_SSTAMP(5);
   } else {
     // =========================================== service wave ===========================================
     // the LDS control words start at zero: written here, in front of the barrier every streaming wave passes before its
     // first flush
     if (l < int(kGsCtlBytes / 4)) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + p.ctl_off + uint32_t(l) * 4u), "v"(0u) : "memory");
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    shuffle_a();
-    const uint32_t active = min(NS, nks);  // streaming waves that own k-steps (the others never flush)
+    stage_a();
+    build_table();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NS_SSTAMP(2);
+    shuffle_own_a();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    NS_SSTAMP(3);
+    // tile ordinal j's units are j * nks .. j * nks + nks - 1: its contributors are the waves (j * nks + i) % NS, i < active
+    const uint32_t active = min(NS, nks);
+    const uint32_t cstep = nks % NS;
+    uint32_t c0 = 0;  // (j * nks) % NS
     const GvsKArgs cold = gvs_late_args();
     const int ldc = cold->ldc, ldd = cold->ldd, epi = cold->epilogue;
     const float* dptr = cold->d;
@@ -494,7 +559,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
     float* slab = cold->slab;
     const uint32_t ctl = lds0 + p.ctl_off;
     const uint32_t red0 = lds0 + p.red_off + uint32_t(l) * 16u;
-    typedef const volatile __attribute__((address_space(3))) floatx4* LdsF4;
+    typedef const __attribute__((address_space(3))) floatx4* LdsF4;  // (re-read every tile: the poll below is a compiler barrier)
     for (uint32_t jt = 0; jt < ntw; jt++) {
       const uint32_t T = tg + jt * p.tg_count;
       uint32_t tl = T;
@@ -531,14 +596,28 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
 #pragma unroll
       for (int q = 0; q < NQ; q++) sum[q] = floatx4{0.f, 0.f, 0.f, 0.f};
       if (g < rows_q) {
-        for (uint32_t ww = 0; ww < active; ww++) {
+        // the contributors' partial sums in unit order, four contributors' loads in flight at a time
+        constexpr int RB = 4;
+        uint32_t ww = c0;
+        for (uint32_t ci = 0; ci < active; ci += RB) {
+          floatx4 v[RB][NQ];
 #pragma unroll
-          for (int q = 0; q < NQ; q++) {
-            const floatx4 v = *reinterpret_cast<LdsF4>(red0 + slot_r * p.red_slot + ww * p.red_wave + uint32_t(q) * uint32_t(rows_q) * 256u);
-            sum[q] += v;
+          for (int b = 0; b < RB; b++) {
+            const bool on = ci + uint32_t(b) < active;
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+              v[b][q] = on ? *reinterpret_cast<LdsF4>(red0 + slot_r * p.red_slot + ww * p.red_wave + uint32_t(q) * uint32_t(rows_q) * 256u)
+                           : floatx4{0.f, 0.f, 0.f, 0.f};
+            ww = (ww + 1u == NS ? 0u : ww + 1u);
           }
+#pragma unroll
+          for (int b = 0; b < RB; b++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) sum[q] += v[b][q];
         }
       }
+      c0 += cstep;
+      if (c0 >= NS) c0 -= NS;
       // hand the slot back: counter to zero first, then the "done" ordinal the streaming waves wait for
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (l == 0) {
@@ -556,8 +635,17 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
       } else {
         gvs_epilogue<DUAL>(sum, p.m, col, col_ok, g, cbase, c16, ldc, dvp, c2, epi);
       }
+#ifdef NS_TRACE
+      if (jt == 0) NS_SSTAMP(4);
+#endif
     }
+    NS_SSTAMP(5);
   }
+#ifdef NS_TRACE
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)
+    p.trace[(size_t(blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8 + 7] =
+        (uint64_t(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32) | uint32_t(__builtin_amdgcn_s_getreg((31 << 11) | 4));
+#endif
 }
 
 // split-K, second pass: one wave per tile unit adds the slices' partial sums in slice order and applies the epilogue
@@ -651,17 +739,17 @@ static hipError_t launch_gvs_s(const GvsParams& p, uint32_t scale_dt, bool asym,
 // tuning / diagnostics (ns_hip_set_tuning): "gvs" 0 = off, 1 = from 2 rows (default), 2 = from 1 row;
 // "gvs_slices" / "gvs_waves" / "gvs_grid" force the decomposition (0 = by shape)
 static std::atomic<int> g_gvs_mode{-1};
-static std::atomic<int> g_gvs_slices{-1}, g_gvs_waves{-1}, g_gvs_grid{-1};
+static std::atomic<int> g_gvs_slices{-1}, g_gvs_waves{-1}, g_gvs_grid{-1}, g_gvs_tbl{-2};
 static int env_or(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
 void set_gemvs_tuning(int what, int value) {
-  (what == 0 ? g_gvs_mode : what == 1 ? g_gvs_slices : what == 2 ? g_gvs_waves : g_gvs_grid).store(value);
+  (what == 0 ? g_gvs_mode : what == 1 ? g_gvs_slices : what == 2 ? g_gvs_waves : what == 3 ? g_gvs_grid : g_gvs_tbl).store(value);
 }
 static int gvs_knob(std::atomic<int>& k, const char* env, int dflt) {
   int v = k.load();
-  if (v < 0) {
+  if (v < (dflt < 0 ? -1 : 0)) {
     v = env_or(env, dflt);
     k.store(v);
   }
@@ -680,6 +768,7 @@ static int gvs_cus() {
 struct GvsPlan {
   int slices_log2 = 0, ns = 8, tg = 0;
   size_t a_bytes = 0, lds = 0;
+  bool tbl = false;
   uint32_t ksl = 0, row_stride = 0, red_wave = 0, red_slot = 0, ring_stride = 0;
   double cost = 0;
 };
@@ -738,6 +827,7 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
   const int force_s = gvs_knob(g_gvs_slices, "NS_GVS_SLICES", 0);
   const int force_ns = gvs_knob(g_gvs_waves, "NS_GVS_WAVES", 0);
   const int force_grid = gvs_knob(g_gvs_grid, "NS_GVS_GRID", 0);
+  const int force_tbl = gvs_knob(g_gvs_tbl, "NS_GVS_TABLE", -1);  // f4 pair table: -1 by size, 0 never, 1 always
   const int max_wg = force_grid > 0 ? force_grid : cus;
 
   // ---- the decomposition: slices S (power of two), tile groups, streaming waves ----
@@ -752,32 +842,39 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
     if (uint64_t(pl.ksl) * (S - 1) >= ks) return false;  // an empty last slice
     pl.row_stride = pl.ksl * uint32_t(kstep) + 8;
     pl.a_bytes = (size_t(rows) * pl.row_stride * 2 + 15) & ~size_t(15);
-    const size_t tbl = w0->kind == WK_F4 ? size_t(kGsTblBytes) : 0;
     pl.tg = int(std::min<uint32_t>(tiles, uint32_t(max_wg) / S));
     if (pl.tg < 1) return false;
+    // f4: the pair table (32 KB of LDS, ~1.5 us to build and to shuffle the activations for) pays from about a dozen
+    // records per streaming wave on (profiles/r04h_ablation.txt: 4096 x 4096 at 8 rows 8.6 us with it, 6.5 without)
+    const uint32_t tiles_max0 = (tiles + uint32_t(pl.tg) - 1) / uint32_t(pl.tg);
+    const bool use_tbl = w0->kind == WK_F4 && force_tbl != 0 && (force_tbl > 0 || uint64_t(tiles_max0) * pl.ksl * nq >= 12u * 12u);
+    pl.tbl = use_tbl;
+    const size_t tbl = use_tbl ? size_t(kGsTblBytes) : 0;
     pl.red_wave = uint32_t(nq) * uint32_t(rows_q) * 256u;
-    // streaming waves: a count LDS holds that splits the slice's k-steps evenly, preferring ten or more waves in flight
-    // (latency hiding); t = k-steps of the busiest wave x waves x that preference
+    // streaming waves: as many as LDS holds and the workgroup has units for (units are dealt round-robin: any count
+    // balances); the time of a workgroup ~ its units / waves, padded when there are fewer units than waves
     const uint32_t tiles_max = (tiles + uint32_t(pl.tg) - 1) / uint32_t(pl.tg);
     auto ring_of = [&](int ns) {
-      const size_t items = size_t((pl.ksl + ns - 1) / ns) * nq * tiles_max;
+      const size_t items = (size_t(pl.ksl) * tiles_max + ns - 1) / ns * nq;
       return (std::min<size_t>(items, size_t(kGsPF)) * slot + 15) & ~size_t(15);
     };
     int best_ns = 0;
-    double best_t = 1e30;
-    for (int ns = 1; ns <= kGsMaxNS; ns++) {
+    for (int ns = kGsMaxNS; ns >= 1; ns--) {
       if (force_ns > 0 && ns != std::min(force_ns, kGsMaxNS)) continue;
+      if (force_ns <= 0 && uint32_t(ns) > std::max<uint32_t>(1u, pl.ksl * tiles_max)) continue;
       const size_t need = tbl + pl.a_bytes + kGsCtlBytes + size_t(kGsR) * ns * pl.red_wave + size_t(ns) * ring_of(ns);
       if (need > kGsMaxLds) continue;
-      const double t = double((pl.ksl + ns - 1) / ns) * ns * (1.0 + 0.35 * std::max(0, 10 - ns) / 10.0);
-      if (t < best_t - 1e-9 || (t < best_t + 1e-9 && ns > best_ns)) best_t = t, best_ns = ns;
+      best_ns = ns;
+      break;
     }
+    const double best_t = best_ns ? double(pl.ksl) * (1.0 + 0.5 * std::max(0, 12 - best_ns) / 12.0) : 0.0;
     if (best_ns == 0) return false;
     pl.ns = best_ns;
     pl.ring_stride = uint32_t(ring_of(pl.ns));
     pl.red_slot = uint32_t(pl.ns) * pl.red_wave;
     pl.lds = tbl + pl.a_bytes + kGsCtlBytes + size_t(kGsR) * pl.red_slot + size_t(pl.ns) * pl.ring_stride;
-    pl.cost = double(tiles_max) * best_t * nq * slot + 0.5 * double(pl.a_bytes) + (S > 1 ? 75e3 : 0.0);
+    // + a fixed cost per tile of a workgroup (flush, reduction, epilogue or slab store: about 8 KB of streaming each: the service wave needs ~0.8 us per tile)
+    pl.cost = double(tiles_max) * (best_t * nq * slot + 8e3) + 0.5 * double(pl.a_bytes) + (S > 1 ? 75e3 : 0.0);
     *out = pl;
     return true;
   };
@@ -829,7 +926,7 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
   p.ns = uint32_t(best.ns);
   p.m = a.m, p.k = w0->k, p.lda = lda16;
   p.row_stride = best.row_stride;
-  p.a_off = w0->kind == WK_F4 ? kGsTblBytes : 0u;
+  p.a_off = best.tbl ? kGsTblBytes : 0u;
   p.a_bytes = uint32_t(best.a_bytes);
   p.ctl_off = p.a_off + uint32_t(best.a_bytes);
   p.red_off = p.ctl_off + kGsCtlBytes;
@@ -844,10 +941,18 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
       p.lut16[i] = uint32_t(__builtin_bit_cast(unsigned short, w0->lut[2 * i])) | (uint32_t(__builtin_bit_cast(unsigned short, w0->lut[2 * i + 1])) << 16);
   }
   p.f8 = f8_consts(w0->qtype);
+#ifdef NS_TRACE
+  p.trace = trace_buffer();
+#endif
   const size_t lds = best.lds;
   if (lds > kGsMaxLds) return hipErrorNotSupported;
   const int grid = best.tg * int(S);
   const int nwaves = best.ns + 1;
+  static const bool dbg = getenv("NS_GVS_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "gemvs: m %d tiles %u ks %u mode %d -> slices %u (ksl %u) groups %d waves %d lds %zu (A %zu) cost %.0f\n", a.m, tiles, ks,
+            mode, S, best.ksl, best.tg, best.ns, lds, best.a_bytes, best.cost);
+  if (dbg && w0->kind == WK_F4) fprintf(stderr, "gemvs: f4 pair table %s\n", best.tbl ? "on" : "off");
 
   hipError_t e = hipSuccess;
 #define NS_DISPATCH(KIND)                                                                          \

@@ -42,7 +42,7 @@ class _Tuning:
 
     def __exit__(self, *exc):
         for k in self.kv:
-            self.L.ns_hip_set_tuning(k.encode(), 1 if k == "gvs" else 0)
+            self.L.ns_hip_set_tuning(k.encode(), {"gvs": 1, "gvs_table": -1}.get(k, 0))
 
 
 def _fwd(L, pkg, wt, dA, m, k, n, epi=0, dD=None, shadow=True, want16=False):
@@ -129,6 +129,23 @@ def test_epilogues_with_and_without_split_k(L, pkg, nso, epi, name, slices):
     assert nso.rel_l2(out, want) < TOL, (name, slices, nso.rel_l2(out, want))
     assert np.array_equal(out16, out.astype(np.float16))
     wt.free()
+
+
+@pytest.mark.parametrize("table", [0, 1])
+@pytest.mark.parametrize("n,k,m,slices", [(528, 1024, 8, 1), (2064, 4096, 5, 1), (272, 2048, 16, 4)])
+def test_f4_pair_table_and_valu_decode_agree_with_the_oracle(L, pkg, nso, n, k, m, slices, table):
+    """NF4 / FP4 decode: through the LDS pair table (activations re-ordered to the code bytes' pairing) or by v_perm lookups —
+    whichever the launch size would pick, both are forced here on small and large launches, for all three f4 tables"""
+    import torch
+    for qt in (pkg.F4_NF4, pkg.F4_E2M1, pkg.F4_BNB):
+        blob, wt, _keep = _blob(L, pkg, nso, n, k, qt, pkg.BF16, 128, pkg.COMP_BF16, False, seed=n + m)
+        g = torch.Generator(device="cuda").manual_seed(m + table)
+        dA = torch.randn((m, k), generator=g, device="cuda")
+        with _Tuning(L, gvs_table=table, gvs_slices=slices):
+            out = _fwd(L, pkg, wt, dA, m, k, n)
+        ref, ref16 = nso.gemm_f64_pair(dA.cpu().numpy(), blob)
+        assert nso.rel_l2(out, ref) < TOL and nso.rel_l2(out, ref16) < 6e-4, (qt, table, nso.rel_l2(out, ref16))
+        wt.free()
 
 
 @pytest.mark.parametrize("slices,grid", [(1, 0), (1, 24), (2, 0), (8, 0)])
