@@ -538,6 +538,9 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
     NS_SSTAMP(5);
   } else {
     // =========================================== service wave ===========================================
+    // one serial instruction stream beside three or four streaming waves on its SIMD: at equal priority it gets a quarter of
+    // the issue slots and needed 2.5 us per fused gate/up tile of a 3.5 us tile period (profiles/r04l_trace_warm.txt)
+    __builtin_amdgcn_s_setprio(3);
     // the LDS control words start at zero: written here, in front of the barrier every streaming wave passes before its
     // first flush
     if (l < int(kGsCtlBytes / 4)) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + p.ctl_off + uint32_t(l) * 4u), "v"(0u) : "memory");
@@ -775,8 +778,8 @@ struct GvsPlan {
 
 // hipErrorNotSupported: outside the kernel's envelope or not the better decomposition — the caller goes on to gemv_kernel
 hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
-  const int mode_knob = gvs_knob(g_gvs_mode, "NS_GVS", 1);
-  if (mode_knob == 0 || a.m < (mode_knob >= 2 ? 1 : 2) || a.m > kGsMaxRows) return hipErrorNotSupported;
+  const int mode_knob = gvs_knob(g_gvs_mode, "NS_GVS", 1);  // 0 off, 1 by shape (below), 2 always from one row, 3 always from two rows
+  if (mode_knob == 0 || a.m < (mode_knob == 2 ? 1 : 2) || a.m > kGsMaxRows) return hipErrorNotSupported;
   if (a.link || a.rope || a.i8) return hipErrorNotSupported;  // carried norm / fused RoPE / int8-reference numerics: gemv_kernel
   const ns_weight* w0 = a.seg[0].w;
   const int nmat = a.nseg;
@@ -821,6 +824,19 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
   const int rows = a.m;
   const int rows_q = (rows + 3) / 4;
   const int nq = a.dual ? 2 : 1;
+  if (mode_knob == 1) {
+    // which kernel by shape (profiles/r04n_rows.txt, us, one-tile-per-workgroup gemv_kernel -> this kernel).  This kernel's time
+    // hardly depends on the row count, gemv_kernel's grows with the activations every tile stages; gemv_kernel's prologue is
+    // about 0.7 us leaner, so short launches of a few rows stay there:
+    //   4096 x 4096 int4      2 rows 5.6 -> 6.2    6 rows 6.1 -> 6.8    12 rows 8.5 -> 7.4   16 rows 9.0 -> 7.4
+    //   gate/up 11008 int4    2 rows 13.5 -> 15.2  4 rows 15.3 -> 16.2  6 rows 19.0 -> 16.7  12 rows 20.2 -> 17.6
+    //   gate/up 14336 nf4     2 rows 22.7 -> 20.8  6 rows 27.4 -> 21.4  16 rows 39.2 -> 28.7
+    //   4096 x 11008 int4     2 rows 8.7 -> 9.0    3 rows 11.5 -> 9.3 (66 KB of activations: beyond gemv_kernel)   16 rows 24.8 -> 14.3
+    const bool beyond_gemv = size_t(rows) * (size_t(ks) * kstep + 8) * 2 > 64 * 1024;  // gemv_kernel's activation envelope
+    const bool wide = a.dual || tiles >= 512;
+    const bool f4_wide = w0->kind == WK_F4 && wide;
+    if (!(beyond_gemv || f4_wide || (rows >= 5 && wide) || rows >= 9)) return hipErrorNotSupported;
+  }
   const uint32_t sbytes = uint32_t(w0->sps) * (w0->scale_dt == DT_F32 ? 4u : 2u);
   const uint32_t slot = 1024u + 16u * sbytes + (w0->asym ? 16u * uint32_t(w0->sps) : 0u);
   const int cus = gvs_cus();

@@ -31,6 +31,14 @@ def _blob(L, pkg, nso, n, k, qt, st_dt, bs, comp, asym, seed, wscale=0.02):
     return blob, wt, dBlob
 
 
+@pytest.fixture(autouse=True)
+def _always_this_kernel(L):
+    """the library picks gemv_kernel or gemvs_kernel by shape (ns_gemvs.hip: launch_gemvs); these tests pin gemvs_kernel"""
+    assert L.ns_hip_set_tuning(b"gvs", 3) == 0
+    yield
+    L.ns_hip_set_tuning(b"gvs", 1)
+
+
 class _Tuning:
     def __init__(self, L, **kv):
         self.L, self.kv = L, kv
@@ -42,7 +50,7 @@ class _Tuning:
 
     def __exit__(self, *exc):
         for k in self.kv:
-            self.L.ns_hip_set_tuning(k.encode(), {"gvs": 1, "gvs_table": -1}.get(k, 0))
+            self.L.ns_hip_set_tuning(k.encode(), {"gvs": 3, "gvs_table": -1}.get(k, 0))
 
 
 def _fwd(L, pkg, wt, dA, m, k, n, epi=0, dD=None, shadow=True, want16=False):
