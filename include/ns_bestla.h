@@ -148,6 +148,19 @@ const char* ns_hip_last_error(void);
 int ns_hip_blob_validate(const void* host_blob, size_t avail_bytes);
 /* host blob (reference format) -> device weight.  The blob is only read. */
 ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream);
+/* Load path of the reference's device loader (model_files.h:1515-1527): like ns_hip_weight_from_blob, but (1) the streaming
+ * layout is written INTO `dst` (dst_bytes: the slice the graph reserved for the tensor, ne_layers.c:918-945) whenever it fits
+ * there — no second copy of the model in HBM; (2) nothing is synchronised: the two words the load needs back land in
+ * `pinned_info[2]` (host memory the copy can target asynchronously) once the stream has been synchronised, and
+ * ns_hip_weight_finish_load(w, pinned_info) completes the weight then.  The host blob may be freed on return. */
+ns_weight* ns_hip_weight_load_async(const void* host_blob, void* dst, uint64_t dst_bytes, void* stream, uint32_t* pinned_info);
+int ns_hip_weight_finish_load(ns_weight* w, const uint32_t* pinned_info);
+int ns_hip_weight_is_external(const ns_weight* w);  /* 1: the weight lives in the caller's slice (not freed by ns_hip_weight_free) */
+void ns_hip_load_staging_release(void);              /* frees the loader's device staging buffer */
+/* what bestla_device_load_storage has done so far: out[0] tensors, [1] blob bytes, [2] bytes of streaming layout placed in the
+ * graph's slices, [3] bytes in allocations of their own (layout larger than the blob), [4] microseconds inside the calls
+ * (+ the one synchronisation), [5] tensors still waiting for that synchronisation */
+void ns_hip_device_load_stats(uint64_t out[6]);
 /* same, blob bytes already in device memory (dev_blob_base_mod64 = (host address the blob was packed at) & 63;
  * blobs packed by this library at 64-byte aligned bases use 0) */
 ns_weight* ns_hip_weight_from_device_blob(const void* dev_blob, size_t blob_bytes, void* stream);
@@ -159,6 +172,14 @@ void ns_hip_weight_free(ns_weight* w);
  * lcm(128 (64 for 8-bit), group size); the reference's re-quantizing behaviour is available on the host path via
  * bestla_unpackweight_fp32 + bestla_packweight_copyattr. */
 ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k1, void* stream);
+/* The same cut on the HOST, blob to blob, before anything is uploaded — what the reference's loader does per rank with
+ * bestla_split_weight (model_files.h:1538-1563, :1593-1640), without the fp32 round trip: codes, scales, zero points and block
+ * sums of columns [n0, n1) x rows [k0, k1) are copied into a new reference-format blob of that shape (same core, dtype, group
+ * size), byte-identical to quantising the cut matrix afresh.  k0 (and k1 unless it is K) must be multiples of the group size;
+ * returns -2 for cuts that need the re-quantising route, -1 for errors.  ns_bestla_split_weight_size: bytes to provide. */
+int ns_blob_shape(const void* blob, int* n, int* k);  /* N and K of a host blob (header only); -1 if it is not one */
+unsigned long long ns_bestla_split_weight_size(const void* src_blob, int dst_n, int dst_k);
+int ns_bestla_split_weight(const void* src_blob, void* dst_blob, unsigned long long dst_capacity, int n0, int n1, int k0, int k1);
 int ns_hip_weight_info(const ns_weight* w, int* n, int* k, int* bits, int* blocksize, uint64_t* device_bytes);
 /* algorithmic bytes one forward over this weight streams: packed codes + scales (+ zero points), i.e.
  * N*K*bits/8 + N*(K/g)*sizeof(scale) [+ N*(K/g)] — the reference benchmark's formula (ut/bestla_benchmark.cpp:583-586) */

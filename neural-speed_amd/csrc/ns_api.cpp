@@ -247,7 +247,7 @@ bool plan_weight(const BlobView& v, ns_weight* w) {
   return true;
 }
 
-bool alloc_weight(ns_weight* w) {
+bool alloc_weight(ns_weight* w, void* ext = nullptr, size_t ext_bytes = 0) {
   // ONE allocation per weight: [codes | scales | zero points], each 256-byte aligned, so that a kernel addresses all
   // streams from one base with 32-bit offsets (s_off / z_off)
   auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
@@ -263,7 +263,12 @@ bool alloc_weight(ns_weight* w) {
     total = s_off + pad(w->scales_bytes) + pad(w->zps_bytes);
   }
   uint8_t* base = nullptr;
-  if (!hip_ok(hipMalloc((void**)&base, total), "hipMalloc(weight)")) return false;
+  if (ext && total <= ext_bytes && (reinterpret_cast<uintptr_t>(ext) & 255) == 0) {
+    base = static_cast<uint8_t*>(ext);  // the caller's slice holds the streaming layout: no allocation of its own
+    w->external = true;
+  } else if (!hip_ok(hipMalloc((void**)&base, total), "hipMalloc(weight)")) {
+    return false;
+  }
   w->codes = reinterpret_cast<uint4*>(base);  // owned by `w` from here on: ns_hip_weight_free releases it on any later failure
   w->scales = base + s_off;
   w->zps = w->asym ? reinterpret_cast<int8_t*>(base + z_off) : nullptr;
@@ -675,6 +680,97 @@ ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream) {
   return w;
 }
 
+// ---- load path of the reference's device loader (model_files.h:1515-1527 -> bestla_device_load_storage) ----
+// One grow-only staging buffer on the device takes each blob's sections; the repack writes the streaming layout straight
+// into `dst` (the slice the graph reserved for the tensor) when it fits there, into an allocation of its own otherwise;
+// nothing is synchronised: the two words the load wants back (largest |scale|, out-of-range flag) go to `pinned_info` by an
+// asynchronous copy and are consumed by ns_hip_weight_finish_load once the caller has synchronised the stream — once per
+// model, not once per tensor.  The host blob may be freed on return (pageable-memory copies return when the source is consumed).
+namespace {
+struct Staging {
+  uint8_t* p = nullptr;
+  size_t bytes = 0;
+  uint32_t* info = nullptr;  // device: per-load pair of words, a ring of 4096 pairs
+  uint32_t next = 0;
+};
+Staging g_staging;
+constexpr uint32_t kInfoRing = 4096;
+}  // namespace
+
+ns_weight* ns_hip_weight_load_async(const void* host_blob, void* dst, uint64_t dst_bytes, void* stream, uint32_t* pinned_info) {
+  if (!have_device()) return nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  BlobView v;
+  std::string err;
+  if (!blob_parse(host_blob, &v, &err)) {
+    set_error(err);
+    return nullptr;
+  }
+  auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t need = pad(v.q_bytes) + pad(v.s_bytes) + pad(v.z_bytes);
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (need > g_staging.bytes) {  // grow (a handful of times per model: the largest tensors come early or late, not often)
+    if (g_staging.p) {
+      hipStreamSynchronize(st);
+      hipFree(g_staging.p);
+    }
+    g_staging.p = nullptr, g_staging.bytes = 0;
+    const size_t want = std::max(need + need / 8, size_t(64) << 20);
+    if (!hip_ok(hipMalloc((void**)&g_staging.p, want), "hipMalloc(load staging)")) return nullptr;
+    g_staging.bytes = want;
+  }
+  if (!g_staging.info && !hip_ok(hipMalloc((void**)&g_staging.info, size_t(kInfoRing) * 8), "hipMalloc(load info)")) return nullptr;
+  const uint8_t* base = static_cast<const uint8_t*>(host_blob);
+  uint8_t* dq = g_staging.p;
+  uint8_t* ds = dq + pad(v.q_bytes);
+  int8_t* dz = v.asym() ? reinterpret_cast<int8_t*>(ds + pad(v.s_bytes)) : nullptr;
+  if (!hip_ok(hipMemcpyAsync(dq, base + v.q_off, v.q_bytes, hipMemcpyHostToDevice, st), "H2D codes") ||
+      !hip_ok(hipMemcpyAsync(ds, base + v.s_off, v.s_bytes, hipMemcpyHostToDevice, st), "H2D scales") ||
+      (dz && !hip_ok(hipMemcpyAsync(dz, base + v.z_off, v.z_bytes, hipMemcpyHostToDevice, st), "H2D zps")))
+    return nullptr;
+  ns_weight* w = new ns_weight();
+  if (!plan_weight(v, w) || !alloc_weight(w, dst, size_t(dst_bytes))) {
+    ns_hip_weight_free(w);
+    return nullptr;
+  }
+  RepackArgs ra{dq, ds, dz, v.ntile(), v.packrow(), v.kpad, v.npad, v.cstep, int((v.kpad + v.blocksize - 1) / v.blocksize)};
+  ra.src_scale_dt = v.scale_dt;
+  uint32_t* dinfo = g_staging.info + 2 * (g_staging.next++ % kInfoRing);
+  ra.flags = dinfo + 1;
+  bool ok = hip_ok(hipMemsetAsync(dinfo, 0, 8, st), "memset") && hip_ok(launch_repack(ra, w, st), "repack") &&
+            hip_ok(launch_scale_absmax(ds, v.s_bytes / (dt_bits(v.scale_dt) / 8), v.scale_dt, dinfo, st), "scale range") &&
+            hip_ok(hipMemcpyAsync(pinned_info, dinfo, 8, hipMemcpyDeviceToHost, st), "load info D2H");
+  if (ok && v.shuf_bytes)
+    ok = hip_ok(hipMalloc((void**)&w->shuf, v.shuf_bytes), "hipMalloc(shuffle)") &&
+         hip_ok(hipMemcpy(w->shuf, base + v.shuf_off, v.shuf_bytes, hipMemcpyHostToDevice), "H2D shuffle") && check_shuffle(w);
+  if (!ok) {
+    ns_hip_weight_free(w);
+    return nullptr;
+  }
+  w->load_pending = true;
+  return w;
+}
+
+int ns_hip_weight_finish_load(ns_weight* w, const uint32_t* info) {
+  if (!w || !info) return -1;
+  w->load_pending = false;
+  if (info[1]) {
+    set_error("F8_E5M2 blob holds codes with exponent field 31 (beyond the reference quantizer's max_norm and fp16)");
+    return -1;
+  }
+  set_gemm_scale_range(w, info[0]);
+  return 0;
+}
+
+void ns_hip_load_staging_release(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_staging.p) hipFree(g_staging.p);
+  if (g_staging.info) hipFree(g_staging.info);
+  g_staging = Staging{};
+}
+
+int ns_hip_weight_is_external(const ns_weight* w) { return w && w->external ? 1 : 0; }
+
 ns_weight* ns_hip_weight_from_device_blob(const void* dev_blob, size_t blob_bytes, void* stream) {
   if (!have_device()) return nullptr;
   hipStream_t st = (hipStream_t)stream;
@@ -792,7 +888,7 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
 
 void ns_hip_weight_free(ns_weight* w) {
   if (!w) return;
-  if (w->codes) hipFree(w->codes);  // scales / zps / workspace live in the same allocation
+  if (w->codes && !w->external) hipFree(w->codes);  // scales / zps / workspace live in the same allocation
   if (w->shuf) hipFree(w->shuf);
   delete w;
 }

@@ -101,6 +101,8 @@ struct ns_weight {
   // codes, scales and zps are ONE allocation: scales = codes + s_off, zps = codes + z_off
   uint32_t s_off = 0, z_off = 0;
   size_t alloc_bytes = 0;
+  bool external = false;  // the arrays live in memory the caller owns (the slice a graph reserved, bestla_device_load_storage): never freed here
+  bool load_pending = false;  // loaded by ns_hip_weight_load_async: ns_hip_weight_finish_load has not run yet
   bool single_span = false;  // the allocation is < 4 GiB, i.e. the offsets above are usable as 32-bit soffsets
   uint64_t stream_bytes = 0;  // algorithmic bytes (reference formula)
   int device = 0;

@@ -16,6 +16,10 @@
 //                       (ns_attn.hip) read an fp16 cache, which the reference's device path does not create.
 // "queue" is a hipStream_t throughout.
 #include <hip/hip_runtime.h>
+#include <vector>
+#include <mutex>
+#include <chrono>
+#include <atomic>
 
 #include <cmath>
 #include <cstdio>
@@ -202,27 +206,96 @@ void bestla_device_memcpy_sync(void* dstptr, const void* srcptr, size_t size, vo
 /* ---- ne_bestla.h:97-98, ne_bestla_sycl.cpp:92-141 ---- */
 size_t bestla_device_storage_size(void) { return sizeof(ns::DeviceStorage); }
 
-/* hoststor: the BTLA blob as read from the model file (host memory); devstor: the tensor's storage area; deviceptr: the
- * slice of the device pool the graph reserved for this tensor (blob-sized).  The weight is re-laid-out into this
- * library's streaming layout in ITS OWN allocation (alloc_weight): the layout's size differs from the blob's (other tile
- * padding, no reduce section), so the reserved slice stays unused — 1x the model's size of HBM, out of 288 GB. */
+/* hoststor: the BTLA blob as read from the model file (host memory, freed by the caller right after: model_files.h:1526);
+ * devstor: the tensor's storage area; deviceptr: the slice of the device pool the graph reserved for this tensor (blob-sized,
+ * 256-byte aligned: ne_layers.c:918-945).  The weight is re-laid-out into this library's streaming layout INSIDE that slice
+ * whenever the layout is no larger than the blob (every 4- / 8-bit integer, f4 and fp8-with-fp32-scale format: other tile
+ * padding, no reduce section); formats the layout widens (1-3 / 5-7 bit planes, E8M0 scales expanded to fp32) get an
+ * allocation of their own and leave the slice unused.  Nothing is synchronised per tensor: the load is completed by the
+ * first forward that meets a pending weight (one stream synchronisation per model). */
+namespace {
+struct PendingLoad {
+  ns::DeviceStorage* s;
+  uint32_t* info;
+};
+std::mutex g_load_mu;
+std::vector<PendingLoad> g_pending;
+std::vector<uint32_t*> g_info_chunks;  // pinned host memory, 1024 pairs per chunk
+size_t g_info_used = 0;
+uint64_t g_stats[6] = {0, 0, 0, 0, 0, 0};
+hipStream_t g_load_stream = nullptr;
+
+uint32_t* next_info_pair() {
+  constexpr size_t kPairs = 1024;
+  if (g_info_chunks.empty() || g_info_used == kPairs) {
+    uint32_t* p = nullptr;
+    if (hipHostMalloc((void**)&p, kPairs * 8, hipHostMallocDefault) != hipSuccess) return nullptr;
+    g_info_chunks.push_back(p);
+    g_info_used = 0;
+  }
+  return g_info_chunks.back() + 2 * g_info_used++;
+}
+long long now_us() {
+  return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// completes every pending load: ONE synchronisation of the load stream, then the per-weight words
+void finish_pending_loads() {
+  std::lock_guard<std::mutex> lk(g_load_mu);
+  if (g_pending.empty()) return;
+  const long long t0 = now_us();
+  (void)hipStreamSynchronize(g_load_stream);
+  for (const PendingLoad& pl : g_pending) {
+    if (pl.s->magic != ns::kDevMagic || !pl.s->w) continue;
+    if (ns_hip_weight_finish_load(pl.s->w, pl.info) != 0) {
+      fprintf(stderr, "bestla_device_load_storage: %s\n", ns_hip_last_error());
+      ns_hip_weight_free(pl.s->w);
+      pl.s->w = nullptr;
+      pl.s->magic = 0;  // the forward refuses the tensor loudly
+    }
+  }
+  g_pending.clear();
+  g_stats[4] += uint64_t(now_us() - t0);
+  g_stats[5] = 0;
+  if (getenv("NS_LOAD_STATS"))
+    fprintf(stderr, "bestla device load: %llu tensors, %.1f MB of blobs -> %.1f MB in the graph's slices + %.1f MB in own allocations, %.3f s\n",
+            (unsigned long long)g_stats[0], g_stats[1] / 1e6, g_stats[2] / 1e6, g_stats[3] / 1e6, g_stats[4] / 1e6);
+}
+std::atomic<int> g_have_pending{0};
+}  // namespace
+
 void bestla_device_load_storage(void* hoststor, void* devstor, void* deviceptr, void* queue) {
-  (void)deviceptr;
   if (!hoststor || !devstor) return;
+  const long long t0 = now_us();
   ns::DeviceStorage* s = static_cast<ns::DeviceStorage*>(devstor);
   memset(s, 0, sizeof(*s));
   s->not_a_blob = ~0ull;
-  ns_weight* w = ns_hip_weight_from_blob(hoststor, queue);
+  uint64_t blob_bytes = 0;
+  memcpy(&blob_bytes, hoststor, 8);  // a blob starts with its serialized size (bestla_storage.h:250-317) = the slice's size
+  std::lock_guard<std::mutex> lk(g_load_mu);
+  uint32_t* info = next_info_pair();
+  static const bool own_alloc = getenv("NS_LOAD_OWN_ALLOC") != nullptr;  // diagnostics: the round-3 behaviour (slice left unused)
+  ns_weight* w = info ? ns_hip_weight_load_async(hoststor, own_alloc ? nullptr : deviceptr, blob_bytes, queue, info) : nullptr;
   if (!w) {
-    fprintf(stderr, "bestla_device_load_storage: %s\n", ns_hip_last_error());
+    fprintf(stderr, "bestla_device_load_storage: %s\n", info ? ns_hip_last_error() : "no pinned memory for the load record");
     return;  // magic stays 0: the forward refuses the tensor loudly
   }
-  (void)hipStreamSynchronize(static_cast<hipStream_t>(queue));  // the caller frees hoststor right after (model_files.h:1526)
   s->magic = ns::kDevMagic;
   s->w = w;
   int bits = 0, bs = 0;
   uint64_t db = 0;
   ns_hip_weight_info(w, &s->n, &s->k, &bits, &bs, &db);
+  g_pending.push_back(PendingLoad{s, info});
+  g_load_stream = static_cast<hipStream_t>(queue);
+  g_stats[0]++, g_stats[1] += blob_bytes;
+  g_stats[ns_hip_weight_is_external(w) ? 2 : 3] += db;
+  g_stats[4] += uint64_t(now_us() - t0);
+  g_stats[5] = g_pending.size();
+  g_have_pending.store(1);
+}
+
+void ns_hip_device_load_stats(uint64_t out[6]) {
+  std::lock_guard<std::mutex> lk(g_load_mu);
+  for (int i = 0; i < 6; i++) out[i] = g_stats[i];
 }
 
 /* ---- ne_bestla.h:99-100, ne_bestla_sycl.cpp:149-171; called by ne_compute_forward_mul_mat_q_f32_bestla
@@ -230,6 +303,10 @@ void bestla_device_load_storage(void* hoststor, void* devstor, void* deviceptr, 
 void bestla_device_f32f32_forward(float* activation, void* weiptr, float* output, int _m, int _n, int _k, int lda, int ldo,
                                   void* workspace, void* queue) {
   (void)workspace;
+  if (g_have_pending.load()) {  // first forward after a model load: one synchronisation completes every weight
+    g_have_pending.store(0);
+    finish_pending_loads();
+  }
   const ns::DeviceStorage* s = static_cast<const ns::DeviceStorage*>(weiptr);
   if (!s || s->magic != ns::kDevMagic || !s->w || s->n != _n || s->k != _k) {
     ns::set_error("bestla_device_f32f32_forward: not a weight loaded by bestla_device_load_storage (or a shape mismatch)");
@@ -244,6 +321,10 @@ void bestla_device_f32f32_forward(float* activation, void* weiptr, float* output
  * callers that reload models in one process) */
 void ns_hip_device_storage_release(void* devstor) {
   ns::DeviceStorage* s = static_cast<ns::DeviceStorage*>(devstor);
+  if (g_have_pending.load()) {
+    g_have_pending.store(0);
+    finish_pending_loads();
+  }
   if (s && s->magic == ns::kDevMagic && s->w) {
     ns_hip_weight_free(s->w);
     s->w = nullptr;

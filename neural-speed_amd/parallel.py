@@ -246,6 +246,42 @@ class ParallelContext:
         return weight.slice(0, weight.n, k0, k1, stream)
 
 
+    def shard_blob(self, blob, split_type):
+        """TP shard of a reference-format blob ON THE HOST (numpy uint8 array in, new 64-byte aligned array out), before anything
+        is uploaded — the reference's per-rank bestla_split_weight at load (model_files.h:1593-1640) without its fp32 round trip:
+        ns_bestla_split_weight copies the rank's codes / scales / zero points / block sums, byte-identical to packing the cut
+        matrix.  ROW -> this rank's columns, COLUMN -> this rank's slice of K (cuts must fall on group boundaries)."""
+        import ctypes as C
+        import numpy as np
+        if self.world == 1 or split_type == TENSOR_NO_CHANGE:
+            return blob
+        if split_type in (TENSOR_1D_QKV_ROW, TENSOR_1D_QKV_COLUMN, TENSOR_1D_ONLY_MASTER):
+            raise NotImplementedError("split type %d is not a plain N / K slice of a packed weight" % split_type)
+        from . import lib
+        L = lib()
+        L.ns_bestla_split_weight_size.restype = C.c_ulonglong
+        L.ns_bestla_split_weight_size.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ns_bestla_split_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_int]
+        n, k = C.c_int(0), C.c_int(0)
+        L.ns_blob_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if L.ns_blob_shape(blob.ctypes.data, C.byref(n), C.byref(k)) != 0:
+            raise ValueError("not a BTLA blob")
+        if split_type == TENSOR_1D_ROW:
+            (n0, n1), (k0, k1) = self.shard_range(n.value, 1), (0, k.value)
+        else:
+            (n0, n1), (k0, k1) = (0, n.value), self.shard_range(k.value, 1)
+        need = L.ns_bestla_split_weight_size(blob.ctypes.data, n1 - n0, k1 - k0)
+        if not need:
+            raise ValueError("ns_bestla_split_weight_size failed")
+        raw = np.zeros(int(need) + 64, np.uint8)
+        off = (-raw.ctypes.data) % 64
+        out = raw[off:off + int(need)]
+        rc = L.ns_bestla_split_weight(blob.ctypes.data, out.ctypes.data, need, n0, n1, k0, k1)
+        if rc != 0:
+            raise ValueError("ns_bestla_split_weight: rc %d (a cut inside a quantisation group needs the re-quantising route)" % rc)
+        return out
+
+
 _ctx = None
 
 

@@ -83,6 +83,12 @@ def main(mode="device", n_new="24", n_ctx="512"):
         ref.nellama_generate_dev.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         n = ref.nellama_generate_dev(path.encode(), pr, len(prompt), n_new, n_ctx, LAYERS, toks, None, C.byref(us))
         assert n == n_new, n
+        hip = C.CDLL(os.path.join(ROOT, "neural-speed_amd", "libns_hip.so"))
+        stats = (C.c_uint64 * 6)()
+        hip.ns_hip_device_load_stats(stats)
+        print('{"load": {"btla_tensors": %d, "blob_MB": %.1f, "streaming_layout_in_graph_slices_MB": %.1f, "own_allocations_MB": %.1f, '
+              '"seconds_in_load_storage_calls_and_the_one_sync": %.3f, "hbm_ratio_vs_blobs": %.3f}}' % (
+                  stats[0], stats[1] / 1e6, stats[2] / 1e6, stats[3] / 1e6, stats[4] / 1e6, (stats[1] + stats[3]) / max(1, stats[1])), flush=True)
         print('{"route": "device-resident (reference built with -DNS_SYCL on bestla_device_*)", "model": "llama-2-7b-shaped synthetic, Q4_0 g32 bf16", '
               '"us_per_token": %.1f, "tokens_per_s": %.1f, "n_ctx": %d, "tokens": %s, "wall_s": %.1f}' % (us.value, 1e6 / us.value, n_ctx, list(toks)[:8], time.time() - t0))
     else:
