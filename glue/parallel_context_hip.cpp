@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <thread>
 
@@ -58,11 +59,16 @@ uint64_t launch_nonce() {
   };
   const char* run = getenv("NS_TP_RUN_ID");
   if (!run) run = getenv("TORCHELASTIC_RUN_ID");
+  // only values every rank of one launch shares, whatever spawned it (torchrun, mpirun -n 2 sh -c ..., srun, several nodes
+  // over one NS_TP_ID_FILE): a parent pid is not one of them — ranks behind per-rank wrapper shells would never agree
   mix(run);
+  mix(getenv("MASTER_ADDR"));
   mix(getenv("MASTER_PORT"));
-  if (!run || !strcmp(run, "none")) h = (h ^ uint64_t(getppid())) * 1099511628211ull;  // torchrun's default run id is "none"
+  mix(getenv("NS_TP_WORLD_SIZE") ? getenv("NS_TP_WORLD_SIZE") : getenv("WORLD_SIZE"));
   return h ? h : 1;
 }
+
+const time_t g_start_time = time(nullptr);
 
 struct IdFile {  // what rank 0 publishes
   char magic[8];
@@ -107,8 +113,11 @@ ns_tp* make_tp() {
       if (fd >= 0) {
         struct stat sb;
         IdFile in;
-        // a regular file of this user, not writable by anyone else, complete, carrying THIS launch's nonce
+        // a regular file of this user, not writable by anyone else, complete, carrying THIS launch's nonce — and not a
+        // leftover of an earlier launch with the same address / port / size that died before rank 0 could remove it:
+        // written no earlier than five minutes before this process started (rank 0 also unlinks the name first thing)
         got = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_uid == getuid() && !(sb.st_mode & (S_IWGRP | S_IWOTH)) &&
+              sb.st_mtime + 300 >= g_start_time &&
               read(fd, &in, sizeof(in)) == ssize_t(sizeof(in)) && !memcmp(in.magic, "NSTPID1", 8) && in.nonce == nonce;
         if (got) rec = in;
         close(fd);

@@ -417,31 +417,6 @@ int ns_hip_binary_nd_f32(int is_mul, const float* dA, const float* dB, float* dD
 int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* dV, float* dO, int batch, int seq, int seq_all, int heads,
                                  int heads_kv, int head_size, int n_ctx, float scale, int masked, void* stream);
 
-/* ---- Part 3b — decode engine: a chain of batch-1 GEMV operators as ONE persistent launch (csrc/ns_engine.hip) ----
- * What it replaces: the per-operator calls ne_graph_compute makes for a decode token (ne_layers.c:11918-11998 ->
- * bestla_f32f32_forward / bestla_fusion_FFN_SiLu_f32f32_forward per node), when the caller can hand over the whole
- * chain at once.  One workgroup per CU stays resident for the token: a loader wave streams the weights ahead across
- * operator boundaries, consumer waves run gemv_kernel's arithmetic, outputs travel between workgroups as 8-byte tagged
- * granules.  v0 envelope: one row, int4 symmetric group-32 bf16-scale weights, K a multiple of 128 and <= 11008.
- * Results equal ns_hip_f32f32_forward_h's with 8 waves per tile (ns_hip_set_tuning("gv_nw", 8)) bit for bit. */
-typedef struct ns_engine ns_engine;
-typedef struct ns_engine_op {
-  const ns_weight* w0;
-  const ns_weight* w1; /* second matrix of a fused gate/up operator: out = (x*w1) * act(x*w0); NULL otherwise */
-  int input;           /* index of the operator whose fp16 output row feeds this one (its first K values);
-                          -1 = the external input row; -2 = the same input as the previous operator */
-  float* c;            /* fp32 output [n] in device memory, may be NULL when only later operators read it */
-  int epilogue;        /* enum ns_epilogue: NONE / SILU / GELU (fused operator: SILU or GELU) */
-} ns_engine_op;
-/* x16: fp16 [K of operator 0] in device memory, read at every launch.  NULL + ns_hip_last_error() on failure. */
-ns_engine* ns_hip_engine_create(const ns_engine_op* ops, int nops, const void* x16);
-/* one token; asynchronous on `stream`, capturable into a HIP graph */
-int ns_hip_engine_launch(ns_engine* e, void* stream);
-/* 0 = every launch so far ran to the end; else the first give-up code of a bounded wait (synchronises the device) */
-unsigned ns_hip_engine_status(ns_engine* e);
-void ns_hip_engine_destroy(ns_engine* e);
-/* diagnostics (library built with -DNS_ENG_TRACE): per workgroup and operator, eight 100 MHz time stamps */
-int ns_hip_engine_trace(ns_engine* e, unsigned long long* out, int nwg);
 
 /* ----------------------------------------------------------------------------------------------
  * Part 4 — fused attention: the C surface `ne_compute_forward_flash_attn_f32_f16_f16`

@@ -36,11 +36,6 @@ CORE_AUTO = -1
 ATTN_CAUSAL, ATTN_ALIBI8, ATTN_PREFER_FP32, ATTN_TANH30 = 1, 2, 4, 8
 
 
-class EngineOp(C.Structure):
-    """ns_engine_op (include/ns_bestla.h part 3b): one operator of a decode-engine chain"""
-    _fields_ = [("w0", C.c_void_p), ("w1", C.c_void_p), ("input", C.c_int), ("c", C.c_void_p), ("epilogue", C.c_int)]
-
-
 class NormLink(C.Structure):
     """ns_norm_link (include/ns_bestla.h): an RMS norm carried from the operator that produces a tensor to the GEMM that
     consumes it"""
@@ -201,13 +196,6 @@ def lib():
         L.ns_tp_alltoall_host.argtypes = [vp, vp, vp, sz]
         L.ns_tp_barrier_host.argtypes = [vp]
         L.ns_hip_set_tuning.argtypes = [C.c_char_p, i]
-        L.ns_hip_engine_create.restype = vp
-        L.ns_hip_engine_create.argtypes = [vp, i, vp]
-        L.ns_hip_engine_launch.argtypes = [vp, vp]
-        L.ns_hip_engine_status.restype = C.c_uint
-        L.ns_hip_engine_status.argtypes = [vp]
-        L.ns_hip_engine_destroy.restype = None
-        L.ns_hip_engine_destroy.argtypes = [vp]
         L.ns_hip_weight_info.argtypes = [vp] + [vp] * 5
         L.ns_hip_f32f32_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
         L.ns_hip_fusion_qkv_forward.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]

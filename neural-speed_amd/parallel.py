@@ -118,7 +118,7 @@ class ParallelContext:
         return buf
 
     # native communicator: RCCL through the C ABI (csrc/ns_tp.cpp) ---------------------------------------------------
-    def enable_native(self):
+    def enable_native(self, device=None):
         """Collective.  Rank 0 draws the RCCL unique id, the process group carries its 128 bytes to the others, every
         rank builds its communicator with ns_tp_init.  True when ALL ranks succeeded; otherwise every rank stays on
         torch.distributed."""
@@ -135,9 +135,14 @@ class ParallelContext:
         ok, raw = box[0]
         tp = None
         if ok:
-            # the device this process already computes on (the launcher's LOCAL_RANK unless the caller chose another: several
-            # ranks of a test may share one GPU)
-            dev = torch.cuda.current_device() if torch.cuda.is_available() else self.local_rank
+            # the launcher's LOCAL_RANK, unless the caller names a device (argument, or NS_TP_LOCAL_RANK: several ranks of a
+            # test share one GPU).  NOT torch.cuda.current_device(): with a process group the caller initialised itself (or
+            # gloo) nobody has called set_device, every rank would report device 0 and RCCL would refuse the duplicate GPU
+            if device is None:
+                device = int(os.environ["NS_TP_LOCAL_RANK"]) if os.environ.get("NS_TP_LOCAL_RANK") else self.local_rank
+            dev = int(device)
+            if torch.cuda.is_available() and dev < torch.cuda.device_count():
+                torch.cuda.set_device(dev)
             tp = L.ns_tp_init(self.rank, self.world, raw, dev)
         oks = [None] * self.world
         dist.all_gather_object(oks, bool(tp))
