@@ -3,7 +3,17 @@
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies the 128-byte requests
 of wide coalesced streaming reads at 64 B -> double it.  rocprofv3 reports FETCH_SIZE in KiB."""
-import csv, json, sys, collections
+import csv, hashlib, json, os, sys, collections
+
+
+def kernel_source_sha16():
+    """hash of the decode kernel's sources: bench.py reads a committed counter summary back only while they are unchanged"""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neural-speed_amd", "csrc")
+    h = hashlib.sha256()
+    for f in ("ns_gemv.hip", "ns_dev.h"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
@@ -31,6 +41,7 @@ if gu and len(sys.argv) > 2:
     _, g, w = k.split("|")
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 3 --warmup 1 (scripts/pmc_traffic.sh)",
                "correction": "FETCH_SIZE(KiB)*1024*2 (MI355X_MICROARCH.md HBM section: 128-B requests tallied at 64 B on gfx950)",
+               "kernel_source_sha16": kernel_source_sha16(),
                "gate_up": dict(v, kernel="gemv_kernel", kernel_full=k.split("|")[0], grid=int(g) // int(w), workgroup=int(w)),
                "all": out}, open(sys.argv[2], "w"), indent=1)
     print("wrote", sys.argv[2])
