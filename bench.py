@@ -531,7 +531,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def full_token(chain, pkg, ctx=2048, fused=True, iters=30):
+def full_token(chain, pkg, ctx=2048, fused=True, iters=30, keep=None):
     """A WHOLE decode token of the same model on the same weights, device resident in one HIP graph (SURVEY 8f rows on
     top of the GEMM chain): rms norm . gamma, fused QKV, RoPE(q, k), kv-cache append, fused attention over `ctx` cached
     positions (fp16 cache), WO + residual, rms norm . gamma, fused gate/up, down + residual; final norm + lm_head.
@@ -643,6 +643,8 @@ def full_token(chain, pkg, ctx=2048, fused=True, iters=30):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     logits = b["logits"].clone()
+    if keep is not None:  # scripts/full_token_oracle.py: the kv caches (incl. the rows this token appended) for the fp64 model
+        keep.update(kc=kc, vc=vc, n_past=n_past, x0=x0)
     return {"ctx": ctx, "ms_per_token": round(ms, 4), "tokens_per_s": round(1000.0 / ms, 1),
             "launches_per_token": launches[0], "launches_per_layer": round((launches[0] - (3 if fused else 2)) / nl, 2),
             "finite": bool(torch.isfinite(logits).all().item())}, logits
