@@ -919,8 +919,10 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_gemv_mode(value);
     return 0;
   }
-  if (key && (!strcmp(key, "gvs") || !strcmp(key, "gvs_slices") || !strcmp(key, "gvs_waves") || !strcmp(key, "gvs_grid") || !strcmp(key, "gvs_table"))) {
-    set_gemvs_tuning(!strcmp(key, "gvs") ? 0 : !strcmp(key, "gvs_slices") ? 1 : !strcmp(key, "gvs_waves") ? 2 : !strcmp(key, "gvs_grid") ? 3 : 4, value);
+  if (key && (!strcmp(key, "gvs") || !strcmp(key, "gvs_slices") || !strcmp(key, "gvs_waves") || !strcmp(key, "gvs_grid") || !strcmp(key, "gvs_table") ||
+              !strcmp(key, "gvs_finalize"))) {
+    set_gemvs_tuning(!strcmp(key, "gvs") ? 0 : !strcmp(key, "gvs_slices") ? 1 : !strcmp(key, "gvs_waves") ? 2 : !strcmp(key, "gvs_grid") ? 3 :
+                     !strcmp(key, "gvs_table") ? 4 : 5, value);
     return 0;
   }
   if (key && !strcmp(key, "g3_min_m")) {

@@ -166,6 +166,7 @@ void gemm_scratch_release();  // frees the per-stream scratch buffers
 // 2 = split-K partials, 3 = shuffled activations.  Safe under stream capture (buffers handed out while capturing are
 // never freed or moved until gemm_scratch_release()); nullptr only when the allocation itself fails.
 void* stream_scratch(hipStream_t st, size_t bytes, int slot);
+void* stream_scratch_zeroed(hipStream_t st, size_t bytes, int slot);  // zero-filled when (re)allocated: self-resetting counters
 // fp32 [m][lda] -> fp16 [m][ld16] (ld16 a multiple of 8, columns k..ld16-1 zero)
 hipError_t launch_cvt_a16(const float* a, void* out16, int m, int k, int lda, int ld16, hipStream_t st);
 // ns_gemv.hip: second-generation decode kernel (m <= 16): lean prologue, one 16-column tile per workgroup;

@@ -302,6 +302,19 @@ __global__ __launch_bounds__(256, NS_G2_OCC) void gemm2_kernel(const Gemm2Params
 // landed) -> s_barrier (everybody's has, and everybody is done reading the other stage) -> issue the DMA of the next
 // chunk into the other stage -> multiply this chunk.
 constexpr int kG3BM = 256, kG3KC = 64, kG3Tiles = 8;
+// MFMA shape of the main loop (round 4): v_mfma_f32_32x32x16_f16 — twice the multiply-adds per instruction and per operand
+// register of v_mfma_f32_16x16x32_f16 (8 vs 5 cycles per CU for 32 K vs 16 K MACs, MI355X_MICROARCH.md: 2382 vs 2075 TFLOPS
+// micro-benchmark ceilings).  A lane is then (row or column l & 31, k half l >> 5) of a 32 x 16 operand: the A image and its
+// swizzle serve that read as they are (the sixteen lanes of a ds_read_b128 group still cover sixteen distinct 16-byte slots),
+// a B operand is word t of record lane (2 e + k half, column & 15) of the column's tile, e = which 16 of the 32-deep slice.
+// Measured (profiles/r04t_gemm3_mfma_shape_ab.txt, M = 2048, same box, alternating): 4096^2 888 vs 882 TFLOPS, 11008 x 4096 945 vs 983,
+// 4096 x 11008 988 vs 974, 32000 x 4096 984 vs 1015 (32x32x16 vs 16x16x32) — no gain: the loop is not bound by the matrix pipe's issue rate.
+// The 16x16x32 loop stays the default; NS_G3_M32=1 builds this one (parity-tested on both: tests/test_gpu_gemm3.py, test_gpu_fuzz.py).
+#ifndef NS_G3_M32
+#define NS_G3_M32 0
+#endif
+constexpr bool kG3M32 = NS_G3_M32 != 0;
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 // rows from which the third-generation kernel is used (tuning: g3_min_m).  Round 3 (scripts/m_sweep.py, profiles/r03_m_sweep.txt):
 // with its 128-row tile it beats gemm2_kernel everywhere below the old threshold of 192 — 4096 x 4096: 17.5 vs 24.2 us at 65
 // rows, 21.7 vs 34.2 at 128, 25.0 vs 36.4 at 191; 11008 x 4096: 26.0 vs 44.6, 29.0 vs 49.6, 40.5 vs 71.0 — and the streaming
@@ -328,6 +341,8 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   constexpr int NJ = B8 ? 2 : 4;                // 32-deep slices per record
   constexpr int RPS = B8 ? 2 : 1;               // records per superstep (128 deep = chunks 2u, 2u + 1)
   constexpr int SBYTES = SPS * (SK == SK_F32 ? 4 : 2);
+  constexpr bool M32 = kG3M32;
+  constexpr int MB = MI / 2, NP = NIW / 2;       // 32-row / 32-column fragments of the wave tile (M32)
   using Corr = CorrRaw<SPS, SK, ASYM>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) unsigned char* LdsPtr;
@@ -354,11 +369,21 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const Rsrc ra = make_rsrc(p.a16, uint32_t(p.m) * uint32_t(p.lda16) * 2u);  // rows >= m read as zeros
   const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
-  floatx4 acc[MI][NIW];
+  floatx4 acc[M32 ? 1 : MI][M32 ? 1 : NIW];
+  floatx16 acc32[M32 ? MB : 1][M32 ? NP : 1];
+  if constexpr (M32) {
 #pragma unroll
-  for (int mi = 0; mi < MI; mi++)
+    for (int mb = 0; mb < MB; mb++)
 #pragma unroll
-    for (int ni = 0; ni < NIW; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int pp = 0; pp < NP; pp++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc32[mb][pp][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+      for (int ni = 0; ni < NIW; ni++) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // ---- A: DMA of chunk c into a stage.  Wave w, request i covers rows (8 w + i) * 8 .. + 7; lane l writes LDS piece
   //      l & 7 of row l >> 3 of them and therefore FETCHES piece (l & 7) ^ ((row >> 1) & 7) ----
@@ -385,6 +410,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
 #pragma unroll
   for (int jj = 0; jj < 2; jj++)
     a_roff[jj] = uint32_t(wm * 128 + nn) * 128u + ((uint32_t(4 * jj + g) ^ uint32_t((nn >> 1) & 7)) << 4);
+  // M32: lane (row l & 31, k half l >> 5) of the 32 x 16 operand kk (0..3 inside the 64-deep chunk) reads piece 2 kk + half of
+  // its row, swizzled like every piece by (row >> 1) & 7
+  uint32_t a_roff32[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++)
+    a_roff32[kk] = uint32_t(wm * 128 + (l & 31)) * 128u + ((uint32_t(2 * kk + (l >> 5)) ^ uint32_t(((l & 31) >> 1) & 7)) << 4);
 
   // ---- B: raw records + their scale / zero-point rows of the workgroup's 8 column tiles for one 128-deep superstep,
   //      HBM -> LDS by DMA as well (an ordinary load in this loop would make hipcc drain every DMA in flight at its
@@ -431,6 +462,47 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   struct BRec {
     uint32_t q[NIW][4 * RPS];
     Corr c[NIW][RPS];
+  };
+  // M32: per PAIR of column tiles pp a lane holds, of the tile its column l & 31 lies in, the two record lanes it is an operand
+  // lane of — (k slot 2 e + (l >> 5), column l & 15), e = 0, 1 — and that column's scales / zero points
+  struct BRec32 {
+    uint32_t q[NP > 0 ? NP : 1][2][4 * RPS];
+    Corr c[NP > 0 ? NP : 1][RPS];
+  };
+  auto read_b32 = [&](BRec32& b) {
+#pragma unroll
+    for (int pp = 0; pp < NP; pp++) {
+      const int t = wn * NIW + 2 * pp + ((l >> 4) & 1);
+#pragma unroll
+      for (int r = 0; r < RPS; r++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const uint4v v = *reinterpret_cast<const uint4v*>(b_lds + (t * RPS + r) * 1024 + ((2 * e + (l >> 5)) * 16 + nn) * 16);
+          b.q[pp][e][4 * r + 0] = v.x, b.q[pp][e][4 * r + 1] = v.y, b.q[pp][e][4 * r + 2] = v.z, b.q[pp][e][4 * r + 3] = v.w;
+        }
+        const unsigned char* sp = b_lds + kBCodes + ((r * kG3Tiles + t) * 16 + nn) * SBYTES;
+        if constexpr (SBYTES == 16) {
+          const uint4v sv = *reinterpret_cast<const uint4v*>(sp);
+          b.c[pp][r].s[0] = sv.x, b.c[pp][r].s[1] = sv.y, b.c[pp][r].s[2] = sv.z, b.c[pp][r].s[3] = sv.w;
+        } else if constexpr (SBYTES == 8) {
+          b.c[pp][r].s[0] = reinterpret_cast<const uint32_t*>(sp)[0];
+          b.c[pp][r].s[1] = reinterpret_cast<const uint32_t*>(sp)[1];
+        } else if constexpr (SBYTES == 4) {
+          b.c[pp][r].s[0] = *reinterpret_cast<const uint32_t*>(sp);
+        } else {
+          b.c[pp][r].s[0] = *reinterpret_cast<const uint16_t*>(sp);
+        }
+        if constexpr (ASYM) {
+          const unsigned char* zp = b_lds + kBCodes + kBScal + ((r * kG3Tiles + t) * 16 + nn) * SPS;
+          if constexpr (SPS == 4)
+            b.c[pp][r].z[0] = *reinterpret_cast<const uint32_t*>(zp);
+          else if constexpr (SPS == 2)
+            b.c[pp][r].z[0] = *reinterpret_cast<const uint16_t*>(zp);
+          else
+            b.c[pp][r].z[0] = *zp;
+        }
+      }
+    }
   };
   // LDS -> registers: this wave's four column tiles (wn * 4 + ni)
   auto read_b = [&](BRec& b) {
@@ -524,6 +596,66 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
       if (valu_per_mfma) __builtin_amdgcn_sched_group_barrier(0x002, valu_per_mfma, 0);             // VALU
     }
   };
+  // ---- M32 forms of the same four steps ----
+  auto dequant32 = [&](const BRec32& b, auto tc, half8_t (&bf)[NP > 0 ? NP : 1][2]) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int h = t >> 1, jj = t & 1;
+#pragma unroll
+    for (int pp = 0; pp < NP; pp++) {
+      float sc[4], zp[4];
+      corr_decode<SPS, SK, ASYM, NJ>(b.c[pp][B8 ? h : 0], sc, zp);
+      constexpr int js = B8 ? jj : t;
+      const _Float16 sh = (_Float16)(sc[js] * p.spre);
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        half8_t v;
+        if constexpr (KIND == WK_INT4) {
+          const _Float16 zl = (_Float16)(-1032.f - zp[js]), zh = (_Float16)(-72.f - zp[js]);
+          v = cvt_i4x8(b.q[pp][e][js], i4c, half2_t{zl, zl}, half2_t{zh, zh});
+        } else if constexpr (KIND == WK_INT8) {
+          const _Float16 zo = (_Float16)(-1152.f - zp[js]);
+          v = cvt_i8x8(b.q[pp][e][4 * h + 2 * jj], b.q[pp][e][4 * h + 2 * jj + 1], half2_t{zo, zo});
+        } else {
+          v = cvt_f4x8(b.q[pp][e][js], p.lut);
+        }
+        bf[pp][e] = v * half8_t{sh, sh, sh, sh, sh, sh, sh, sh};
+      }
+    }
+  };
+  auto load_af32 = [&](int stage, int jj, half8_t (&af)[MB > 0 ? MB : 1][2]) {
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const unsigned char* a_lds = smem + stage * kStage + a_roff32[2 * jj + e];
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) af[mb][e] = *reinterpret_cast<const half8_t*>(a_lds + mb * (32 * 128));
+    }
+  };
+  // one 32-deep slice = two 16-deep operand sets e: (MB x NP) v_mfma_f32_32x32x16_f16 each; operand (mb, e) is reloaded in place
+  // for the next slice behind its NP instructions, `after` is called MI times like in the 16x16x32 loop
+  auto mma32 = [&](half8_t (&af)[MB > 0 ? MB : 1][2], const half8_t (&bf)[NP > 0 ? NP : 1][2], auto reload, int stage, int jj, auto&& after) {
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const unsigned char* nxt = smem + stage * kStage + a_roff32[2 * jj + e];
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) {
+#pragma unroll
+        for (int pp = 0; pp < NP; pp++)
+          acc32[mb][pp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mb][e], bf[pp][e], acc32[mb][pp], 0, 0, 0);
+        if constexpr (decltype(reload)::value) af[mb][e] = *reinterpret_cast<const half8_t*>(nxt + mb * (32 * 128));
+        after(e * MB + mb);
+      }
+    }
+  };
+  auto interleave32 = [&](auto vpm, auto ds, auto dma) {
+    constexpr int valu_per_mfma = decltype(vpm)::value;
+#pragma unroll
+    for (int i = 0; i < 2 * MB * NP; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   // 1 MFMA (twice the work of a 16x16x32)
+      if (decltype(ds)::value && (i % NP) == NP - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 LDS read
+      if (decltype(dma)::value && (i % NP) == 0 && i / NP < APW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 DMA request
+      if (valu_per_mfma) __builtin_amdgcn_sched_group_barrier(0x002, 2 * valu_per_mfma, 0);                // VALU
+    }
+  };
   using T_ = std::true_type;
   using F_ = std::false_type;
 
@@ -532,49 +664,97 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const int cend = p.ksplit > 1 ? min(p.nchunks, cbeg + p.cps) : p.nchunks;
   const int ubeg = cbeg >> 1, uend = (cend + 1) >> 1;
 
-  BRec breg;
-  half8_t af[MI], bf0[NIW], bf1[NIW];
-  issue_a(cbeg, 0);
-  issue_b(ubeg);
-  for (int u = ubeg; u < (p.diag == 2 ? ubeg + 1 : uend); u++) {
-    const int c0 = 2 * u;
-    // ---- chunk 2u (A stage 0): this superstep's records move to registers ----
-    // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier here (hipcc drains the DMAs in flight before a
-    // barrier): the wave's own DMAs — A(2u), B(u) — have landed, then everybody's have, and everybody is done with A
-    // stage 1.
-    __syncthreads();
-    read_b(breg);
-    load_af(0, 0, af);
-    dequant(breg, std::integral_constant<int, 0>{}, bf0);
-    __builtin_amdgcn_sched_barrier(0);
-    // slice 0 multiplies while slice 1 is prepared and the next chunk's A image is requested piece by piece
-    // (requested unconditionally: past the last chunk the pieces land in a stage nobody reads — the source offsets stay
-    // inside the buffer descriptor or read as zeros — and the loop body stays one straight-line block to schedule)
-    const bool more1 = c0 + 1 < cend;
-    dequant(breg, std::integral_constant<int, 1>{}, bf1);
-    mma(af, bf0, T_{}, 0, 1, [&](int mi) {
-      if (mi < APW) issue_a_piece(c0 + 1, 1, mi);
-    });
-    interleave(std::integral_constant<int, 2>{}, T_{}, T_{});
-    __builtin_amdgcn_sched_barrier(0);
-    // slice 1 multiplies while slice 2's B fragments are prepared (its A image is behind the next barrier)
-    dequant(breg, std::integral_constant<int, 2>{}, bf0);
-    mma(af, bf1, F_{}, 0, 0, nothing);
-    interleave(std::integral_constant<int, 2>{}, F_{}, F_{});
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- chunk 2u + 1 (A stage 1) ----
-    if (more1) {
-      __syncthreads();  // A(2u + 1) has landed; everybody has copied B(u) and left A stage 0
-      if (u + 1 < uend) issue_b(u + 1);
-      load_af(1, 0, af);
+  if constexpr (M32) {
+    BRec32 breg;
+    half8_t af[MB > 0 ? MB : 1][2], bf0[NP > 0 ? NP : 1][2], bf1[NP > 0 ? NP : 1][2];
+    issue_a(cbeg, 0);
+    issue_b(ubeg);
+    for (int u = ubeg; u < (p.diag == 2 ? ubeg + 1 : uend); u++) {
+      const int c0 = 2 * u;
+      // ---- chunk 2u (A stage 0): this superstep's records move to registers ----
+      // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier here (hipcc drains the DMAs in flight before a
+      // barrier): the wave's own DMAs — A(2u), B(u) — have landed, then everybody's have, and everybody is done with A
+      // stage 1.
+      __syncthreads();
+      read_b32(breg);
+      load_af32(0, 0, af);
+      dequant32(breg, std::integral_constant<int, 0>{}, bf0);
       __builtin_amdgcn_sched_barrier(0);
-      dequant(breg, std::integral_constant<int, 3>{}, bf1);
-      mma(af, bf0, T_{}, 1, 1, [&](int mi) {
-        if (mi < APW) issue_a_piece(c0 + 2, 0, mi);
+      // slice 0 multiplies while slice 1 is prepared and the next chunk's A image is requested piece by piece
+      // (requested unconditionally: past the last chunk the pieces land in a stage nobody reads — the source offsets stay
+      // inside the buffer descriptor or read as zeros — and the loop body stays one straight-line block to schedule)
+      const bool more1 = c0 + 1 < cend;
+      dequant32(breg, std::integral_constant<int, 1>{}, bf1);
+      mma32(af, bf0, T_{}, 0, 1, [&](int mi) {
+        if (mi < APW) issue_a_piece(c0 + 1, 1, mi);
+      });
+      interleave32(std::integral_constant<int, 2>{}, T_{}, T_{});
+      __builtin_amdgcn_sched_barrier(0);
+      // slice 1 multiplies while slice 2's B fragments are prepared (its A image is behind the next barrier)
+      dequant32(breg, std::integral_constant<int, 2>{}, bf0);
+      mma32(af, bf1, F_{}, 0, 0, nothing);
+      interleave32(std::integral_constant<int, 2>{}, F_{}, F_{});
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- chunk 2u + 1 (A stage 1) ----
+      if (more1) {
+        __syncthreads();  // A(2u + 1) has landed; everybody has copied B(u) and left A stage 0
+        if (u + 1 < uend) issue_b(u + 1);
+        load_af32(1, 0, af);
+        __builtin_amdgcn_sched_barrier(0);
+        dequant32(breg, std::integral_constant<int, 3>{}, bf1);
+        mma32(af, bf0, T_{}, 1, 1, [&](int mi) {
+          if (mi < APW) issue_a_piece(c0 + 2, 0, mi);
+        });
+        interleave32(std::integral_constant<int, 2>{}, T_{}, T_{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma32(af, bf1, F_{}, 0, 0, nothing);
+      }
+    }
+  } else {
+    BRec breg;
+    half8_t af[MI], bf0[NIW], bf1[NIW];
+    issue_a(cbeg, 0);
+    issue_b(ubeg);
+    for (int u = ubeg; u < (p.diag == 2 ? ubeg + 1 : uend); u++) {
+      const int c0 = 2 * u;
+      // ---- chunk 2u (A stage 0): this superstep's records move to registers ----
+      // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier here (hipcc drains the DMAs in flight before a
+      // barrier): the wave's own DMAs — A(2u), B(u) — have landed, then everybody's have, and everybody is done with A
+      // stage 1.
+      __syncthreads();
+      read_b(breg);
+      load_af(0, 0, af);
+      dequant(breg, std::integral_constant<int, 0>{}, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      // slice 0 multiplies while slice 1 is prepared and the next chunk's A image is requested piece by piece
+      // (requested unconditionally: past the last chunk the pieces land in a stage nobody reads — the source offsets stay
+      // inside the buffer descriptor or read as zeros — and the loop body stays one straight-line block to schedule)
+      const bool more1 = c0 + 1 < cend;
+      dequant(breg, std::integral_constant<int, 1>{}, bf1);
+      mma(af, bf0, T_{}, 0, 1, [&](int mi) {
+        if (mi < APW) issue_a_piece(c0 + 1, 1, mi);
       });
       interleave(std::integral_constant<int, 2>{}, T_{}, T_{});
       __builtin_amdgcn_sched_barrier(0);
+      // slice 1 multiplies while slice 2's B fragments are prepared (its A image is behind the next barrier)
+      dequant(breg, std::integral_constant<int, 2>{}, bf0);
       mma(af, bf1, F_{}, 0, 0, nothing);
+      interleave(std::integral_constant<int, 2>{}, F_{}, F_{});
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- chunk 2u + 1 (A stage 1) ----
+      if (more1) {
+        __syncthreads();  // A(2u + 1) has landed; everybody has copied B(u) and left A stage 0
+        if (u + 1 < uend) issue_b(u + 1);
+        load_af(1, 0, af);
+        __builtin_amdgcn_sched_barrier(0);
+        dequant(breg, std::integral_constant<int, 3>{}, bf1);
+        mma(af, bf0, T_{}, 1, 1, [&](int mi) {
+          if (mi < APW) issue_a_piece(c0 + 2, 0, mi);
+        });
+        interleave(std::integral_constant<int, 2>{}, T_{}, T_{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af, bf1, F_{}, 0, 0, nothing);
+      }
     }
   }
 
@@ -608,12 +788,22 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   __syncthreads();  // every wave is done with the A stages
 #pragma unroll
   for (int hh = 0; hh < MI / 4; hh++) {
+    if constexpr (M32) {  // C of v_mfma_f32_32x32x16: lane (column l & 31, half l >> 5), register r -> row (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
-    for (int mi = 0; mi < 4; mi++)
+      for (int mbl = 0; mbl < 2; mbl++)
 #pragma unroll
-      for (int ni = 0; ni < NIW; ni++)
+        for (int pp = 0; pp < NP; pp++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) park[(mi * 16 + 4 * g + r) * kRowF + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * p.spost;
+          for (int r = 0; r < 16; r++)
+            park[(mbl * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * kRowF + pp * 32 + (l & 31)] = acc32[2 * hh + mbl][pp][r] * p.spost;
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NIW; ni++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) park[(mi * 16 + 4 * g + r) * kRowF + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * p.spost;
+    }
     // (LDS operations of one wave complete in order: no barrier between its own writes and reads)
     const int rbase = row0 + wm * 128 + hh * 64;
     if (p.diag == 1) continue;
@@ -1066,9 +1256,10 @@ struct ScratchBuf {
 };
 static std::map<std::pair<hipStream_t, int>, ScratchBuf> g_scratch;
 static std::vector<void*> g_scratch_retired;
-void* stream_scratch(hipStream_t st, size_t bytes, int slot) {
+static void* stream_scratch_impl(hipStream_t st, size_t bytes, int slot, bool* fresh) {
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   ScratchBuf& e = g_scratch[{st, slot}];
+  if (fresh) *fresh = false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess) return nullptr;
   const bool capturing = cs != hipStreamCaptureStatusNone;
@@ -1102,6 +1293,26 @@ void* stream_scratch(hipStream_t st, size_t bytes, int slot) {
   e.p = p;
   e.bytes = bytes;
   e.in_graph = capturing;
+  if (fresh) *fresh = true;
+  return p;
+}
+void* stream_scratch(hipStream_t st, size_t bytes, int slot) { return stream_scratch_impl(st, bytes, slot, nullptr); }
+// the same, zero-filled when (re)allocated — counters that every user leaves at zero again (ns_gemvs.hip: split-K tickets).
+void* stream_scratch_zeroed(hipStream_t st, size_t bytes, int slot) {
+  bool fresh = false;
+  void* p = stream_scratch_impl(st, bytes, slot, &fresh);
+  if (p && fresh) {
+    // outside a capture: filled now.  Allocated in the middle of a capture (a caller that never ran eagerly first): the fill
+    // becomes a node of that graph in front of the first user — a small memset per replay of that one graph, harmless (every
+    // user leaves the counters at zero)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    const hipError_t err = hipMemsetAsync(p, 0, bytes, st);
+    if (err != hipSuccess || (cs == hipStreamCaptureStatusNone && hipStreamSynchronize(st) != hipSuccess)) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
   return p;
 }
 void gemm_scratch_release() {

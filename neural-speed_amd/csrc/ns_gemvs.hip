@@ -15,8 +15,13 @@
 //     of per 64 KB); the prologue, the A wait and the barrier are paid once per launch, not once per tile.
 //   * split-K across workgroups where the rows x K slice does not fit LDS (FFN down: 8 x 14336 fp16 = 229 KB) or the
 //     output is too narrow to give every CU a tile: workgroup (slice s, tile group t) stages only A[:, slice s] and
-//     streams slice s of its tiles; the per-slice partial sums go to a slab in HBM and a finalize launch adds them in
-//     slice order (deterministic: no atomics on values) and applies the epilogue.
+//     streams slice s of its tiles; the per-slice partial sums go to a slab in HBM and are added in slice order
+//     (deterministic: no atomics on values) with the epilogue — by gemvs_finalize_kernel in a second launch (default), or
+//     inside the launch by the tile's OWNER, the workgroup of slice (tile ordinal mod S): every workgroup streams the
+//     tiles it owns LAST, so when an owner reaches its tile the other slices of it were published (write-through stores,
+//     then a ticket) at least a tile's streaming time earlier and the hand-off is not waited for.  Both give the same bits;
+//     they measured equal (profiles/r04u_split_k_finish.txt), and splitting beyond what LDS forces does not pay: fused
+//     gate/up at 8 rows 23.0 us unsplit, 28.2 with 2 slices, 34.2 with 4 (per-tile flush + reduction + publish).
 //   * NS streaming waves + ONE service wave per workgroup.  The streaming waves split a tile's k-steps as in
 //     gemv_kernel (private LDS-DMA rings, hand-counted vmcnt) and run straight on into the next tile: at the end of a
 //     tile each writes its partial sums to an LDS slot and bumps an LDS counter — no workgroup barrier.  The service
@@ -103,6 +108,9 @@ struct GvsParams {
   const float* d;
   int ldc, ldd, epilogue;
   float* slab;              // split-K: [slice][tile unit][q][64 lanes][4] fp32 partial sums
+  uint32_t* tickets;        // split-K finished inside the launch: one counter per tile unit (zero between launches); nullptr:
+                            // the partial sums are added by gemvs_finalize_kernel
+  uint32_t slab_bytes;
   F4Lut lut;
   F8Consts f8;
 #ifdef NS_TRACE
@@ -203,6 +211,18 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
   const uint32_t kb = sl * p.ksl;                             // first k-step of the slice
   const uint32_t nks = min(p.ks - kb, p.ksl);                 // k-steps of the slice (host: kb < ks)
   const uint32_t ntw = p.tiles_base + (tg < p.tiles_rem ? 1u : 0u);  // tiles of this workgroup
+  // order in which this workgroup streams its tiles (ordinals j = 0 .. ntw - 1 -> tile tg + j * tg_count): in-launch split-K
+  // puts the tiles this slice OWNS (j % S == slice) last, the others in ascending order in front
+  const uint32_t S1 = (1u << p.s_log2) - 1u;
+  const bool own_last = p.tickets != nullptr && S1 != 0;
+  const uint32_t n_owned = own_last && sl < ntw ? (ntw - sl + S1) >> p.s_log2 : 0u;
+  const uint32_t n_other = ntw - n_owned;
+  auto tile_ord = [&](uint32_t i) -> uint32_t {
+    if (!own_last) return i;
+    if (i >= n_other) return sl + ((i - n_other) << p.s_log2);
+    const uint32_t b = i / S1, r = i - b * S1;  // S - 1 foreign ordinals per block of S
+    return (b << p.s_log2) + (r < sl ? r : r + 1u);
+  };
   const int rows = min(p.m, kGsMaxRows);
   const int rows_q = (rows + 3) >> 2;                         // lane groups g that hold live output rows
   const uint32_t lds0 = uint32_t(reinterpret_cast<uintptr_t>((LdsPtr)(smem)));
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
         izo[q] = zos[q];
       }
     }
-    if (nun) tile_ctx(tg + j0 * p.tg_count);
+    if (nun) tile_ctx(tg + tile_ord(j0) * p.tg_count);
 
     constexpr uint32_t SLOT = 1024u + 16u * SBYTES + (ASYM ? 16u * SPS : 0u);
     constexpr int OPS = ASYM ? 3 : 2;
@@ -354,7 +374,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
             ki -= nks;
             ji++;
           } while (ki >= nks);
-          if (ji < ntw) tile_ctx(tg + ji * p.tg_count);
+          if (ji < ntw) tile_ctx(tg + tile_ord(ji) * p.tg_count);
         }
       }
     };
@@ -560,11 +580,16 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
     const float* dptr = cold->d;
     float* c2 = cold->c2;
     float* slab = cold->slab;
+    uint32_t* tickets = cold->tickets;
+    const Rsrc rslab = make_rsrc(slab, cold->slab_bytes);
+    const uint32_t nslices = 1u << p.s_log2;
     const uint32_t ctl = lds0 + p.ctl_off;
     const uint32_t red0 = lds0 + p.red_off + uint32_t(l) * 16u;
     typedef const __attribute__((address_space(3))) floatx4* LdsF4;  // (re-read every tile: the poll below is a compiler barrier)
     for (uint32_t jt = 0; jt < ntw; jt++) {
-      const uint32_t T = tg + jt * p.tg_count;
+      const uint32_t jord = tile_ord(jt);
+      const uint32_t T = tg + jord * p.tg_count;
+      const bool owner = own_last && (jord & S1) == sl;
       uint32_t tl = T;
       int sg = 0;
       if constexpr (MSEG) {
@@ -580,7 +605,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
       // what the epilogue has to fetch is requested before the wait for the tile's partial sums
       float dvp[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (!DUAL) {
-        if (dptr && col_ok && !slab) {
+        if (dptr && col_ok && (!slab || owner)) {
 #pragma unroll
           for (int rr = 0; rr < 4; rr++)
             if (4 * g + rr < p.m) dvp[rr] = dptr[size_t(4 * g + rr) * ldd + col];
@@ -628,13 +653,51 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
                      "v"(jt + 1u)
                      : "memory");
       }
-      if (slab) {
-        // split-K: the raw partial sums of (slice, tile) — summed over the slices, in slice order, by gemvs_finalize_kernel
+      if (slab && !owner) {
+        // split-K: the raw partial sums of (slice, tile).  With tickets: write-through stores (visible to the owner's CU
+        // whatever XCD it is on), drained, then the ticket — the owner adds the slices in slice order; without: plain stores,
+        // gemvs_finalize_kernel adds them after the launch
         if (g < rows_q) {
 #pragma unroll
-          for (int q = 0; q < NQ; q++)
-            *reinterpret_cast<floatx4*>(slab + ((size_t(sl) * p.ntiles + T) * NQ + q) * 256 + size_t(l) * 4) = sum[q];
+          for (int q = 0; q < NQ; q++) {
+            const uint32_t off = uint32_t(((size_t(sl) * p.ntiles + T) * NQ + q) * 1024u + uint32_t(l) * 16u);
+            if (tickets)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, sum[q]), rslab, off, 0, 16 /* sc1 */);
+            else
+              *reinterpret_cast<floatx4*>(reinterpret_cast<unsigned char*>(slab) + off) = sum[q];
+          }
         }
+        if (tickets) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (l == 0) __hip_atomic_fetch_add(tickets + T, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else if (slab) {
+        // the owner: every other slice's ticket (drawn long ago: owned tiles are streamed last), then their sums past the
+        // caches, added in slice order with this workgroup's own in its place
+        uint32_t seen = 0, spins = 0;
+        do {
+          seen = __hip_atomic_load(tickets + T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          seen = __builtin_amdgcn_readfirstlane(seen);
+          if (seen < nslices - 1u) __builtin_amdgcn_s_sleep(2);
+        } while (seen < nslices - 1u && ++spins < kGsSpinLimit);
+        floatx4 tot[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) tot[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (g < rows_q) {
+          for (uint32_t sx = 0; sx < nslices; sx++) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+              floatx4 v = sum[q];
+              if (sx != sl) {
+                const uint32_t off = uint32_t(((size_t(sx) * p.ntiles + T) * NQ + q) * 1024u + uint32_t(l) * 16u);
+                v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rslab, off, 0, 16 /* sc1 */));
+              }
+              tot[q] += v;
+            }
+          }
+        }
+        if (l == 0) __hip_atomic_store(tickets + T, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+        gvs_epilogue<DUAL>(tot, p.m, col, col_ok, g, cbase, c16, ldc, dvp, c2, epi);
       } else {
         gvs_epilogue<DUAL>(sum, p.m, col, col_ok, g, cbase, c16, ldc, dvp, c2, epi);
       }
@@ -742,13 +805,13 @@ static hipError_t launch_gvs_s(const GvsParams& p, uint32_t scale_dt, bool asym,
 // tuning / diagnostics (ns_hip_set_tuning): "gvs" 0 = off, 1 = from 2 rows (default), 2 = from 1 row;
 // "gvs_slices" / "gvs_waves" / "gvs_grid" force the decomposition (0 = by shape)
 static std::atomic<int> g_gvs_mode{-1};
-static std::atomic<int> g_gvs_slices{-1}, g_gvs_waves{-1}, g_gvs_grid{-1}, g_gvs_tbl{-2};
+static std::atomic<int> g_gvs_slices{-1}, g_gvs_waves{-1}, g_gvs_grid{-1}, g_gvs_tbl{-2}, g_gvs_fin{-1};
 static int env_or(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
 void set_gemvs_tuning(int what, int value) {
-  (what == 0 ? g_gvs_mode : what == 1 ? g_gvs_slices : what == 2 ? g_gvs_waves : what == 3 ? g_gvs_grid : g_gvs_tbl).store(value);
+  (what == 0 ? g_gvs_mode : what == 1 ? g_gvs_slices : what == 2 ? g_gvs_waves : what == 3 ? g_gvs_grid : what == 4 ? g_gvs_tbl : g_gvs_fin).store(value);
 }
 static int gvs_knob(std::atomic<int>& k, const char* env, int dflt) {
   int v = k.load();
@@ -906,9 +969,20 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
   const uint32_t S = 1u << best.slices_log2;
 
   float* slab = nullptr;
+  uint32_t* tickets = nullptr;
+  const size_t slab_bytes = size_t(S) * tiles * nq * 256 * sizeof(float);
   if (S > 1) {
-    slab = static_cast<float*>(stream_scratch(st, size_t(S) * tiles * nq * 256 * sizeof(float), 2));
+    if (slab_bytes >= (size_t(1) << 31)) return hipErrorNotSupported;
+    slab = static_cast<float*>(stream_scratch(st, slab_bytes, 2));
     if (!slab) return hipErrorNotSupported;
+    // Who adds the slices: a second launch (gemvs_finalize_kernel, the default) or — "gvs_finalize" 0 — the tile's owner inside
+    // the launch, behind one self-resetting ticket per tile unit.  Measured equal (profiles/r04u_split_k_finish.txt: 4096 x 14336
+    // at 8 rows 17.1 vs 17.3 us with 2 slices, 17.8 vs 17.8 with 4): what the in-launch finish saves in launch boundary the owner
+    // spends reading the other slices past the caches; it also needs every workgroup of the launch resident at once (an owner
+    // spins on tickets other workgroups draw), which a second launch does not — hence the default.
+    static const int kTicketCap = 1 << 16;
+    const int force_fin = gvs_knob(g_gvs_fin, "NS_GVS_FINALIZE", 1);
+    if (!force_fin && tiles <= uint32_t(kTicketCap)) tickets = static_cast<uint32_t*>(stream_scratch_zeroed(st, size_t(kTicketCap) * 4, 7));
   }
 
   const void* a16 = a.a16;
@@ -951,6 +1025,8 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
   p.red_wave = best.red_wave, p.red_slot = best.red_slot;
   p.c2 = a.c2, p.d = a.d, p.ldc = a.ldc, p.ldd = a.ldd, p.epilogue = a.epilogue;
   p.slab = slab;
+  p.tickets = tickets;
+  p.slab_bytes = uint32_t(slab_bytes);
   if (w0->kind == WK_F4) {
     f4_lut_planes(w0->lut, &p.lut);
     for (int i = 0; i < 8; i++)
@@ -989,7 +1065,7 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
     NS_DISPATCH(WK_F4)
   }
 #undef NS_DISPATCH
-  if (e != hipSuccess || S == 1) return e;
+  if (e != hipSuccess || S == 1 || tickets) return e;
 
   GvsFinParams f;
   memset(&f, 0, sizeof(f));

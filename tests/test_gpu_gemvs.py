@@ -117,6 +117,44 @@ def test_every_decomposition_gives_the_oracles_result(L, pkg, nso, slices, waves
     wt.free()
 
 
+@pytest.mark.parametrize("slices,grid,m", [(2, 0, 8), (4, 16, 3), (8, 0, 16), (4, 4, 8)])
+def test_split_k_finished_in_the_launch_equals_the_finalize_launch_bit_for_bit(L, pkg, nso, slices, grid, m):
+    """split-K two ways: the tile's owner (slice = tile ordinal mod S, its own tiles streamed last) adds the slices inside the
+    launch behind self-resetting tickets, or gemvs_finalize_kernel adds them in a second launch — the same slice order, so the
+    same bits; run three times in a row (the tickets must be back at zero), fused gate/up included"""
+    import torch
+    n, k = 1552, 4096
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    blob, wt, _k0 = _blob(L, pkg, nso, n, k, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, False, seed=slices + m)
+    blob3, wt3, _k3 = _blob(L, pkg, nso, n, k, pkg.S4, pkg.BF16, 32, pkg.COMP_INT8, False, seed=slices + m + 50)
+    g = torch.Generator(device="cuda").manual_seed(m)
+    dA = torch.randn((m, k), generator=g, device="cuda")
+    dA16 = dA.half()
+
+    def both():
+        o = _fwd(L, pkg, wt, dA, m, k, n)
+        t2 = torch.full((m, n), 7.0, device="cuda")
+        pkg.check(L.ns_hip_fusion_ffn3_gateup_h(dA.data_ptr(), dA16.data_ptr(), wt.h, wt3.h, None, t2.data_ptr(), None, m, pkg.EPI_SILU, st))
+        torch.cuda.synchronize()
+        return o, t2.cpu().numpy()
+    with _Tuning(L, gvs_slices=slices, gvs_grid=grid):
+        want, want2 = both()
+    L.ns_hip_set_tuning(b"gvs_finalize", 0)
+    try:
+        for _ in range(3):
+            with _Tuning(L, gvs_slices=slices, gvs_grid=grid):
+                got, got2 = both()
+            assert np.array_equal(got.view(np.int32), want.view(np.int32)) and np.array_equal(got2.view(np.int32), want2.view(np.int32))
+    finally:
+        L.ns_hip_set_tuning(b"gvs_finalize", 1)
+    with _Tuning(L, gvs_slices=slices, gvs_grid=grid):
+        for _ in range(1):
+            got, got2 = both()
+            assert np.array_equal(got.view(np.int32), want.view(np.int32)) and np.array_equal(got2.view(np.int32), want2.view(np.int32))
+    assert nso.rel_l2(got, nso.gemm_f64(dA.cpu().numpy(), blob)) < TOL
+    wt.free(), wt3.free()
+
+
 @pytest.mark.parametrize("epi,name", [(1, "add"), (2, "mul"), (3, "add_gelu"), (4, "gelu"), (5, "silu")])
 @pytest.mark.parametrize("slices", [1, 4])
 def test_epilogues_with_and_without_split_k(L, pkg, nso, epi, name, slices):
