@@ -142,6 +142,12 @@ struct I8Act {
   const uint8_t* corr;  // [m][nblk] fp32 scales immediately followed by [m][nblk] u8 zero points, 16-byte aligned
   int nblk, blocksize;
 };
+// expert-indexed decode launch (gemv_kernel XV = 4): the weight base comes from table[*id] on the device
+struct MoeRoute {
+  const void* table;   // device: rows {codes, scales, zps} of the group's experts (ns_moe.hip)
+  const int32_t* id;   // device: &ids[token][id]
+  int n_as;
+};
 struct SmallMArgs {
   const float* a;
   const void* a16;  // optional fp16 copy of A (same shape / lda): skips the fp32->fp16 staging conversion
@@ -157,12 +163,13 @@ struct SmallMArgs {
   const ns_norm_link* link = nullptr;  // carried RMS norm (include/ns_bestla.h); gemv_kernel only
   const ns_qkv_rope* rope = nullptr;   // RoPE(q, k) + kv-cache append as the QKV epilogue; gemv_kernel only
   const I8Act* i8 = nullptr;           // int8-reference numerics (m <= 4); gemv_kernel only: launch_gemv() directly
+  const MoeRoute* moe = nullptr;       // expert picked on the device (m = 1, fp32 activations); gemv_kernel only: launch_gemv() directly
 };
 hipError_t launch_smallm(const SmallMArgs& a, hipStream_t st);
 // ns_gemm.hip: second-generation prefill GEMM; hipErrorNotSupported = use the first-generation gemm_kernel
 hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st);
 void gemm_scratch_release();  // frees the per-stream scratch buffers
-// grow-only device scratch per (stream, slot): slot 0 = fp16 copy of A (prefill GEMM), 1 = attention partials,
+// grow-only device scratch per (stream, slot): slot 0 = fp16 copy of A (prefill GEMM), 1 = attention partials, (4, 6, 7: ns_i8ref.hip; 10-13: ns_attn.hip host entries; 21: ns_gemvs.hip split-K tickets;)
 // 2 = split-K partials, 3 = shuffled activations.  Safe under stream capture (buffers handed out while capturing are
 // never freed or moved until gemm_scratch_release()); nullptr only when the allocation itself fails.
 void* stream_scratch(hipStream_t st, size_t bytes, int slot);

@@ -76,6 +76,13 @@ struct GemvRope {
   int on;
 };
 
+// one row of an expert group's device table (ns_moe.hip: MoeExpert — same layout)
+struct MoeExpertRow {
+  const uint8_t* codes;
+  const uint8_t* scales;
+  const int8_t* zps;
+};
+
 struct GemvParams {
   // ---- hot head: everything the prologue needs, fetched by one batch of scalar loads ----
   const uint8_t* wbase0;    // matrix 0 (and, for the fused gate/up launch, matrix 1)
@@ -97,6 +104,11 @@ struct GemvParams {
   // [m][nblk] u8 zero points (one span, staged at ssq_off); k-block of column kk = kk >> i8_bshift
   const uint8_t* i8_corr;
   uint32_t i8_span, i8_nblk, i8_bshift;
+  // expert-indexed launch (XV = 4, ns_hip_mul_mat_id at decode size): the weight base is table[*moe_id].codes — every expert of a
+  // group has the same shape and layout, so the offsets above hold for all of them; an id outside [0, moe_n) zeroes the row
+  const MoeExpertRow* moe_table;
+  const int32_t* moe_id;
+  int moe_n;
   // ---- cold: read late, through the kernel-argument pointer (keeps them out of the streaming loop's SGPRs) ----
   GemvMat mat[3];
   float* c2;
@@ -156,6 +168,10 @@ enum GemvMode { GV_PLAIN = 0, GV_DUAL = 1, GV_MSEG = 2 };
 // front of the ring requests, converted (round to nearest even, as the shadow's producers do) and written to LDS once
 // only ring requests are left in flight — the weights are requested exactly as early as with a shadow.
 constexpr int kGvA32Regs = 8;  // 16-byte loads of fp32 activations a wave holds in registers
+// XV = 4 (MOE): A32 + the weight picked on the DEVICE: ne_compute_forward_mul_mat_id_q_f32_bestla (ne_layers.c:7783-7916) reads
+// ids[token][id] on the host and calls bestla_f32f32_forward per (token, expert); here the id stays where the router's top-k left
+// it — one scalar load of the id, one of the expert's base pointer, in front of the first weight request (two dependent round
+// trips, ~1 us, instead of a host synchronisation) — and the token's row streams the expert at this kernel's rate.
 // XV = 3 (I8S): the REFERENCE'S int8-compute numerics (its default for Q4_0: gemv_4bit_u8s8_fp32, kernel_ref.h:2371-2429) on the
 // same streaming skeleton: A arrives as the u8 codes / scales / zero points of quantize_fp_u8_colblock (aquant_u8_kernel,
 // bit-exact), a lane (column nn, k-slot g) takes exact integer dots of its eight codes per 32-deep slice with v_dot4 on the
@@ -163,7 +179,7 @@ constexpr int kGvA32Regs = 8;  // 16-byte loads of fp32 activations a wave holds
 // float(sum) * (scale_a * scale_b) per slice; up to four rows.  Reduction, epilogues, fused QKV / gate-up modes are shared.
 template <int KIND, int SPS, int SK, bool ASYM, int MODE, int XV>
 __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
-  constexpr bool EXT = XV == 1, A32 = XV == 2, I8S = XV == 3;
+  constexpr bool EXT = XV == 1, MOE = XV == 4, A32 = XV == 2 || MOE, I8S = XV == 3;
   static_assert(!I8S || KIND == WK_INT4 || KIND == WK_INT8, "integer weights only");
   constexpr uint32_t AEL = I8S ? 1u : 2u;  // bytes per staged activation element
   constexpr bool DUAL = MODE == GV_DUAL, MSEG = MODE == GV_MSEG;
@@ -219,6 +235,20 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
     if constexpr (ASYM) zo[0] = sg == 0 ? p.mat[0].z_off : (sg == 1 ? p.mat[1].z_off : p.mat[2].z_off);
     else zo[0] = 0;
     tl = T - (sg == 0 ? 0u : (sg == 1 ? p.tb1 : p.tb2));
+  } else if constexpr (MOE) {
+    const int e = *p.moe_id;  // wave-uniform: scalar loads
+    if (e < 0 || e >= p.moe_n) {  // an out-of-range id zeroes its row (the reference would assert)
+      const KArgs cz = late_args();
+      const int colz = int(T) * 16 + nn;
+      if (w == 0 && g == 0 && colz < cz->mat[0].n) {
+        cz->mat[0].c[colz] = 0.f;
+        if (cz->mat[0].c16) cz->mat[0].c16[colz] = (_Float16)0.f;
+      }
+      return;
+    }
+    rw[0] = make_rsrc(p.moe_table[e].codes, 0x80000000u);
+    so[0] = p.s_off0;
+    zo[0] = p.z_off0;
   } else {
     rw[0] = make_rsrc(p.wbase0, 0x80000000u);
     so[0] = p.s_off0;
@@ -750,19 +780,29 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 // ============================================================================================================
 constexpr int kGvModeA32 = 0x100;  // or-ed into the launch mode: fp32 activations (XV = 2)
 constexpr int kGvModeI8 = 0x200;   // int8-reference numerics (XV = 3)
+constexpr int kGvModeMoe = 0x400;  // expert picked on the device (XV = 4; fp32 activations)
 template <int KIND, int SPS, int SK, bool ASYM>
 static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw, size_t lds, hipStream_t st) {
   const dim3 g(grid), b(nw * 64);
   const bool ext = p.in_ssq || p.out_gamma || p.out_ssq || p.rope.on;
   const bool a32 = (mode & kGvModeA32) != 0;  // never together with ext (launch_gemv)
   const bool i8s = (mode & kGvModeI8) != 0;
-  mode &= ~(kGvModeA32 | kGvModeI8);
+  const bool moe = (mode & kGvModeMoe) != 0;
+  mode &= ~(kGvModeA32 | kGvModeI8 | kGvModeMoe);
+  if (moe) {
+    if constexpr (KIND == WK_F8) return hipErrorNotSupported;
+    if (mode != GV_PLAIN) return hipErrorNotSupported;
+  }
   if constexpr (KIND != WK_INT4 && KIND != WK_INT8)
     if (i8s) return hipErrorNotSupported;
 #define NS_GV_LAUNCH(MODEV)                                                                                     \
   {                                                                                                             \
-    if (ext) NS_GV_LAUNCH_E(MODEV, 1) else if (a32) NS_GV_LAUNCH_E(MODEV, 2) else if (i8s) NS_GV_LAUNCH_I8(MODEV)    \
+    if (moe) NS_GV_LAUNCH_MOE(MODEV) else if (ext) NS_GV_LAUNCH_E(MODEV, 1) else if (a32) NS_GV_LAUNCH_E(MODEV, 2) else if (i8s) NS_GV_LAUNCH_I8(MODEV)    \
     else NS_GV_LAUNCH_E(MODEV, 0)                                                                               \
+  }
+#define NS_GV_LAUNCH_MOE(MODEV)                                                                                  \
+  {                                                                                                             \
+    if constexpr (KIND != WK_F8 && MODEV == GV_PLAIN) NS_GV_LAUNCH_E(GV_PLAIN, 4)                               \
   }
 #define NS_GV_LAUNCH_I8(MODEV)                                                                                   \
   {                                                                                                             \
@@ -785,6 +825,7 @@ static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw,
 #undef NS_GV_LAUNCH
 #undef NS_GV_LAUNCH_E
 #undef NS_GV_LAUNCH_I8
+#undef NS_GV_LAUNCH_MOE
   return hipGetLastError();
 }
 template <int KIND, int SPS, int SK>
@@ -908,8 +949,11 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   const bool a16 = i8s || (a.a16 != nullptr && (a.lda & 7) == 0 && (w0->k & 7) == 0 && (reinterpret_cast<uintptr_t>(a.a16) & 15) == 0);
   // fp32-only callers: converted while staging (XV = 2); not together with a carried norm / fused RoPE, whose producers
   // always leave a shadow
+  const bool moe = a.moe != nullptr;
+  if (moe && (a.m != 1 || nmat != 1 || a.dual || a.link || a.rope || i8s || a.a16 || !a.moe->table || !a.moe->id)) return hipErrorNotSupported;
   const bool a32 = !a16 && a.a != nullptr && !a.link && !a.rope && (a.lda & 3) == 0 && (w0->k & 3) == 0 &&
                    (reinterpret_cast<uintptr_t>(a.a) & 15) == 0;
+  if (moe && !a32) return hipErrorNotSupported;
   if ((!a16 && !a32) || (rows > 1 && w0->k % kstep != 0)) return hipErrorNotSupported;
   p.a = i8s ? static_cast<const void*>(a.i8->aq) : (a16 ? a.a16 : static_cast<const void*>(a.a));
   // carried RMS norm (ns_norm_link): consumer side stages in_parts floats per row behind A
@@ -996,7 +1040,12 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   p.ring_stride = uint32_t(ring_bytes(nw));
   const size_t lds = size_t(p.ring_off) + size_t(nw) * p.ring_stride;
   if (lds > kGvMaxLds) return hipErrorNotSupported;
-  const int mode_x = mode | (a32 ? kGvModeA32 : 0) | (i8s ? kGvModeI8 : 0);
+  if (moe) {
+    p.moe_table = static_cast<const MoeExpertRow*>(a.moe->table);
+    p.moe_id = a.moe->id;
+    p.moe_n = a.moe->n_as;
+  }
+  const int mode_x = mode | (a32 && !moe ? kGvModeA32 : 0) | (i8s ? kGvModeI8 : 0) | (moe ? kGvModeMoe : 0);
 
 #define NS_DISPATCH(KIND)                                                                       \
   switch (w0->sps) {                                                                            \

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
           for (int q = 0; q < NQ; q++) {
             const uint32_t off = uint32_t(((size_t(sl) * p.ntiles + T) * NQ + q) * 1024u + uint32_t(l) * 16u);
             if (tickets)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, sum[q]), rslab, off, 0, 16 /* sc1 */);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, sum[q]), rslab, off, 0, 17 /* sc0 sc1: system scope, write-through */);
             else
               *reinterpret_cast<floatx4*>(reinterpret_cast<unsigned char*>(slab) + off) = sum[q];
           }
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
               floatx4 v = sum[q];
               if (sx != sl) {
                 const uint32_t off = uint32_t(((size_t(sx) * p.ntiles + T) * NQ + q) * 1024u + uint32_t(l) * 16u);
-                v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rslab, off, 0, 16 /* sc1 */));
+                v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rslab, off, 0, 17 /* sc0 sc1: past every cache */));
               }
               tot[q] += v;
             }
@@ -843,7 +843,7 @@ struct GvsPlan {
 hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
   const int mode_knob = gvs_knob(g_gvs_mode, "NS_GVS", 1);  // 0 off, 1 by shape (below), 2 always from one row, 3 always from two rows
   if (mode_knob == 0 || a.m < (mode_knob == 2 ? 1 : 2) || a.m > kGsMaxRows) return hipErrorNotSupported;
-  if (a.link || a.rope || a.i8) return hipErrorNotSupported;  // carried norm / fused RoPE / int8-reference numerics: gemv_kernel
+  if (a.link || a.rope || a.i8 || a.moe) return hipErrorNotSupported;  // carried norm / fused RoPE / int8-reference numerics: gemv_kernel
   const ns_weight* w0 = a.seg[0].w;
   const int nmat = a.nseg;
   if (nmat < 1 || nmat > 3 || (a.dual && nmat != 2)) return hipErrorNotSupported;
@@ -982,7 +982,7 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
     // spins on tickets other workgroups draw), which a second launch does not — hence the default.
     static const int kTicketCap = 1 << 16;
     const int force_fin = gvs_knob(g_gvs_fin, "NS_GVS_FINALIZE", 1);
-    if (!force_fin && tiles <= uint32_t(kTicketCap)) tickets = static_cast<uint32_t*>(stream_scratch_zeroed(st, size_t(kTicketCap) * 4, 7));
+    if (!force_fin && tiles <= uint32_t(kTicketCap)) tickets = static_cast<uint32_t*>(stream_scratch_zeroed(st, size_t(kTicketCap) * 4, 21));
   }
 
   const void* a16 = a.a16;

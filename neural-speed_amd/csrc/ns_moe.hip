@@ -268,8 +268,31 @@ int ns_hip_mul_mat_id(const float* dA, const int32_t* dIds, int ids_stride, int 
     set_error("mul_mat_id: K beyond 30720 is not supported by this first version");
     return -1;
   }
-  const dim3 grid(w->ntiles, m), block(kMoeThreads);
   hipStream_t st = (hipStream_t)stream;
+  // decode-sized calls: one launch of the decode kernel (ns_gemv.hip, XV = 4) per token row — LDS-DMA rings, MFMA on the raw
+  // codes, the expert's base pointer picked from the table on the device — instead of this file's VALU loop (Mixtral shapes,
+  // one token, 8 x {14336 x 4096, 4096 x 14336} int4: 169 us per MoE FFN layer with the loop, profiles/r04s_moe_mixtral_m1.json)
+  static const int moe_gemv_rows = getenv("NS_MOE_GEMV_ROWS") ? atoi(getenv("NS_MOE_GEMV_ROWS")) : 8;
+  if (m <= moe_gemv_rows && w->single_span) {
+    bool all = true;
+    for (int t = 0; t < m && all; t++) {
+      MoeRoute route{g->table, dIds + size_t(t) * ids_stride + id, int(g->experts.size())};
+      SmallMArgs a{};
+      a.a = dA + size_t(t) * lda, a.lda = lda, a.m = 1, a.ldc = ldc, a.nseg = 1;
+      a.seg[0] = {w, dC + size_t(t) * ldc, nullptr};
+      a.epilogue = epilogue, a.d = dD ? dD + size_t(t) * ldd : nullptr, a.ldd = ldd;
+      a.moe = &route;
+      const hipError_t e = launch_gemv(a, st);
+      if (e == hipErrorNotSupported && t == 0) {
+        all = false;  // outside that kernel's envelope: the loop below serves the whole call
+      } else if (e != hipSuccess) {
+        set_error(std::string("mul_mat_id launch: ") + hipGetErrorString(e));
+        return -1;
+      }
+    }
+    if (all) return 0;
+  }
+  const dim3 grid(w->ntiles, m), block(kMoeThreads);
   if (w->kind == WK_INT8)
     hipLaunchKernelGGL(moe_gemv_kernel<WK_INT8>, grid, block, lds, st, p);
   else if (w->kind == WK_F4)

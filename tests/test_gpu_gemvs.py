@@ -50,7 +50,7 @@ class _Tuning:
 
     def __exit__(self, *exc):
         for k in self.kv:
-            self.L.ns_hip_set_tuning(k.encode(), {"gvs": 3, "gvs_table": -1}.get(k, 0))
+            self.L.ns_hip_set_tuning(k.encode(), {"gvs": 3, "gvs_table": -1, "gvs_finalize": 1}.get(k, 0))
 
 
 def _fwd(L, pkg, wt, dA, m, k, n, epi=0, dD=None, shadow=True, want16=False):

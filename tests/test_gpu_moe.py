@@ -47,7 +47,9 @@ def test_mul_mat_id_matches_per_token_forwards(L, pkg, nso, qt, st, asym, bs, co
         ref = np.concatenate([nso.gemm_f64(a[t:t + 1], blobs[ids[t, sel]]) for t in range(m)], axis=0)
         assert nso.rel_l2(out, ref) < 1e-3
         ref16 = np.concatenate([nso.gemm_f64(a[t:t + 1], blobs[ids[t, sel]], a16=True) for t in range(m)], axis=0)
-        assert nso.rel_l2(out, ref16) < 5e-5   # same fp16-rounded activations: only fp32 summation order differs
+        # same fp16-rounded activations: only fp32 summation order differs — and, for the 4-bit float types at decode size, the
+        # value table rounded to fp16 (the decode kernel's MFMA operand, like every other f4 launch of the library)
+        assert nso.rel_l2(out, ref16) < (6e-4 if qt.startswith("F4") else 5e-5)
     L.ns_hip_expert_group_free(g)
 
 
