@@ -923,10 +923,11 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
     pl.a_bytes = (size_t(rows) * pl.row_stride * 2 + 15) & ~size_t(15);
     pl.tg = int(std::min<uint32_t>(tiles, uint32_t(max_wg) / S));
     if (pl.tg < 1) return false;
-    // f4: the pair table (32 KB of LDS, ~1.5 us to build and to shuffle the activations for) pays from about a dozen
-    // records per streaming wave on (profiles/r04h_ablation.txt: 4096 x 4096 at 8 rows 8.6 us with it, 6.5 without)
+    // f4: the pair table (32 KB of LDS, ~1.5 us to build and to shuffle the activations for) pays from about a hundred
+    // records per workgroup on (4096 x 4096 at 8 rows, 32 records: 8.6 us with it, 8.1 without; 4096 x 14336 in 4 slices, 112
+    // records: 16.4 vs 17.8; fused gate/up 14336, 256 records: 22.9 vs 27.9 — profiles/r04h_ablation.txt, r04y_table_threshold.txt)
     const uint32_t tiles_max0 = (tiles + uint32_t(pl.tg) - 1) / uint32_t(pl.tg);
-    const bool use_tbl = w0->kind == WK_F4 && force_tbl != 0 && (force_tbl > 0 || uint64_t(tiles_max0) * pl.ksl * nq >= 12u * 12u);
+    const bool use_tbl = w0->kind == WK_F4 && force_tbl != 0 && (force_tbl > 0 || uint64_t(tiles_max0) * pl.ksl * nq >= 96u);
     pl.tbl = use_tbl;
     const size_t tbl = use_tbl ? size_t(kGsTblBytes) : 0;
     pl.red_wave = uint32_t(nq) * uint32_t(rows_q) * 256u;
