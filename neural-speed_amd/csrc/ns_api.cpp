@@ -957,6 +957,14 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_attn_tuning(0, value);
     return 0;
   }
+  if (key && !strcmp(key, "attn_mfma2_rows")) {
+    set_attn_mfma2_rows(value);
+    return 0;
+  }
+  if (key && !strcmp(key, "attn_inlaunch")) {
+    set_attn_inlaunch(value);
+    return 0;
+  }
   set_error("ns_hip_set_tuning: unknown key");
   return -1;
 }

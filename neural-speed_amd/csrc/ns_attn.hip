@@ -174,7 +174,17 @@ struct AttnSplitParams {
   float* ws;       // [batch][sl_q][head][nsplit][2 + head_size] partial (m, l, acc) when nsplit > 1
   int nsplit;
   int keys_per_split;
+  uint32_t* tickets;  // one self-resetting counter per (batch, query row, kv head): the LAST split to finish merges inside the launch
+                      // (nullptr: attn_merge_kernel does it in a second launch)
 };
+
+// stores / loads past every cache (sc0 sc1): partial results cross XCDs inside one launch
+__device__ __forceinline__ void st_through(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float ld_through(const float* p) {
+  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
 
 template <int G, int DPL>  // G query heads per kv head; DPL head dims per lane (8: head_size <= 128, 16: <= 256)
 __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSplitParams sp) {
@@ -339,12 +349,71 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
       if (p.dst16) p.dst16[dst - p.dst + dd] = (_Float16)y;
     } else {
       float* wp = sp.ws + ((((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit + split) * (2 + hs);
-      if (dd == 0) {
-        wp[0] = mb;
-        wp[1] = lb;
+      if (sp.tickets) {
+        if (dd == 0) {
+          st_through(wp, mb);
+          st_through(wp + 1, lb);
+        }
+        st_through(wp + 2 + dd, ab);
+      } else {
+        if (dd == 0) {
+          wp[0] = mb;
+          wp[1] = lb;
+        }
+        wp[2 + dd] = ab;
       }
-      wp[2 + dd] = ab;
     }
+  }
+  if (sp.nsplit == 1 || !sp.tickets) return;
+  // ---- merge inside the launch: the write-through stores above are drained, the workgroup draws a ticket, and the one that
+  // draws the last of (batch, query row, kv head) combines all splits — the sums attn_merge_kernel forms, in the same order ----
+  __shared__ uint32_t drawn_s;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  uint32_t* tk = sp.tickets + ((size_t)ibs * p.sl_q + i) * p.heads_kv + ihkv;
+  if (t == 0) drawn_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (drawn_s != uint32_t(sp.nsplit - 1)) return;
+  if (t == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+  const int ns = sp.nsplit;
+  for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
+    const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
+    if (dd >= hs) continue;
+    const int ihn = ihkv * G + g;
+    const float* wq = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
+    float mb = -INFINITY, lb = 0.f, ab = 0.f;
+    if (ns <= 16) {  // every load of the merge requested at once
+      float mv[16], lv[16], ov[16];
+#pragma unroll
+      for (int s2 = 0; s2 < 16; s2++) {
+        const bool on = s2 < ns;
+        mv[s2] = on ? ld_through(wq + s2 * (2 + hs)) : -INFINITY;
+        lv[s2] = on ? ld_through(wq + s2 * (2 + hs) + 1) : 0.f;
+        ov[s2] = on ? ld_through(wq + s2 * (2 + hs) + 2 + dd) : 0.f;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 16; s2++) mb = fmaxf(mb, mv[s2]);
+#pragma unroll
+      for (int s2 = 0; s2 < 16; s2++) {
+        if (s2 < ns) {
+          const float c = mv[s2] != -INFINITY ? expf(mv[s2] - mb) : 0.f;
+          lb += lv[s2] * c;
+          ab += ov[s2] * c;
+        }
+      }
+    } else {
+      for (int s2 = 0; s2 < ns; s2++) mb = fmaxf(mb, ld_through(wq + s2 * (2 + hs)));
+      for (int s2 = 0; s2 < ns; s2++) {
+        const float ms = ld_through(wq + s2 * (2 + hs));
+        const float c = ms != -INFINITY ? expf(ms - mb) : 0.f;
+        lb += ld_through(wq + s2 * (2 + hs) + 1) * c;
+        ab += ld_through(wq + s2 * (2 + hs) + 2 + dd) * c;
+      }
+    }
+    float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
+    const float y = ab / lb * p.out_scale;
+    dst[dd] = y;
+    if (p.dst16) p.dst16[dst - p.dst + dd] = (_Float16)y;
   }
 }
 
@@ -358,6 +427,39 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
   const int ihn = blockIdx.x, i = blockIdx.y, ibs = blockIdx.z;
   const int hs = p.head_size, t = threadIdx.x, ns = sp.nsplit;  // ns <= 64
   const float* wp = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
+  if (ns <= 16 && hs <= int(blockDim.x)) {
+    // the common decode shape (<= 16 splits, one output element per thread): every thread fetches all (max, sum) pairs — wave-
+    // uniform addresses, scalar loads — and its own column of the partial outputs in ONE batch of loads, then merges in registers:
+    // one memory round trip behind the kernel boundary instead of two with a workgroup barrier between them (round 4: the launch
+    // is 4.9 us for a few KB of work; the same sums in the same order as the general form below)
+    float mv[16], lv[16], ov[16];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; s2++) {
+      const bool on = s2 < ns;
+      mv[s2] = on ? wp[s2 * (2 + hs)] : -INFINITY;
+      lv[s2] = on ? wp[s2 * (2 + hs) + 1] : 0.f;
+      ov[s2] = (on && t < hs) ? wp[s2 * (2 + hs) + 2 + t] : 0.f;
+    }
+    float mb2 = -INFINITY;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; s2++) mb2 = fmaxf(mb2, mv[s2]);
+    float lb2 = 0.f, ab2 = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; s2++) {
+      if (s2 < ns) {
+        const float c = mv[s2] != -INFINITY ? expf(mv[s2] - mb2) : 0.f;
+        lb2 += lv[s2] * c;
+        ab2 += ov[s2] * c;
+      }
+    }
+    if (t < hs) {
+      float* dst2 = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
+      const float y = ab2 / lb2 * p.out_scale;
+      dst2[t] = y;
+      if (p.dst16) p.dst16[dst2 - p.dst + t] = (_Float16)y;
+    }
+    return;
+  }
   float ms = -INFINITY, ls = 0.f;
   if (t < ns) {
     ms = wp[t * (2 + hs)];
@@ -396,7 +498,12 @@ static hipError_t launch_split_g(const AttnSplitParams& sp, dim3 grid, hipStream
 }
 
 // context splits of the fast path for a shape (1 = unsplit) — shared by the launcher and the workspace-size query
+static std::atomic<int> g_attn_mfma2_rows{getenv("NS_ATTN_MFMA2_ROWS") ? atoi(getenv("NS_ATTN_MFMA2_ROWS")) : 128};  // query rows from which attn_mfma2_kernel serves a prefill
+void set_attn_mfma2_rows(int rows) { g_attn_mfma2_rows.store(rows > 0 ? rows : 128); }
+static std::atomic<int> g_attn_inlaunch{getenv("NS_ATTN_INLAUNCH") ? atoi(getenv("NS_ATTN_INLAUNCH")) != 0 : 1};  // ns_hip_set_tuning("attn_inlaunch"): 1 = the last split merges inside the launch, 0 = attn_merge_kernel
+static constexpr size_t kAttnTicketCap = 65536;
 static std::atomic<int> g_attn_wg_target{1024}, g_attn_min_keys{128};  // ns_hip_set_tuning("attn_wg_target" / "attn_min_keys")
+void set_attn_inlaunch(int on) { g_attn_inlaunch.store(on != 0); }
 void set_attn_tuning(int wg_target, int min_keys) {
   if (wg_target > 0) g_attn_wg_target.store(wg_target);
   if (min_keys > 0) g_attn_min_keys.store(min_keys);
@@ -649,6 +756,207 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
   }
 }
 
+// ============================================================================================================
+// attn_mfma2_kernel (round 4) — prefill on the matrix cores, second generation: 128 query rows per workgroup, 32 per wave,
+// v_mfma_f32_32x32x16_f16, K and V tiles of 64 keys staged ONCE per workgroup in LDS (two stages: the next tile travels
+// global -> registers while the current one is multiplied, registers -> LDS behind the P.V products, one barrier per tile).
+//   S^T = K . Q^T   A = K rows from LDS (lane (key l & 31, half h = l >> 5): 16 bytes K[key][16 j + 8 h ..]; the 16-byte slots of a
+//                   row are XOR-swizzled by the row so that the 16 lanes of a ds_read_b128 group hit 16 distinct slots),
+//                   B = Q rows in registers (fp16, converted once).  Lane (query n = l & 31, h) receives the scores of ITS query at
+//                   keys (i & 3) + 8 (i >> 2) + 4 h of the 32-key tile, i = 0..15: softmax needs one exchange (lane ^ 32) per tile
+//                   for the maximum; row sums stay per lane until the end.
+//   O^T += V^T . P^T  A = V^T, B = P^T: the 8 probabilities i = 8 s .. 8 s + 7 a lane holds ARE its B operand of 16-deep step s if
+//                   k-slot 8 h + i' is read as key 16 s + (i' & 3) + 8 (i' >> 2) + 4 h — no data moves between lanes — and the
+//                   accumulators of a lane all belong to its own query: the rescale is lane-local.  A in that enumeration = two runs
+//                   of 4 consecutive keys at one head dim: ds_read_b64_tr_b16 (the CDNA4 transposing LDS read) from a ROW-major
+//                   image, [16-dim subtile][key][16 dims] with the subtiles 128 B off a 256 B multiple (the two 16-lane halves of
+//                   a read then cover disjoint banks).
+// Causal balance: all workgroups of a prompt are resident at once (2 per CU at 2048 x 32 heads), so the launch order cannot
+// balance; the first half of the grid takes its query blocks heaviest-first, the second half lightest-first: the two
+// workgroups that meet on a CU sum to the same work.  fp16 operands, fp32 scores / statistics / accumulators.
+// ============================================================================================================
+typedef float afloatx16 __attribute__((ext_vector_type(16)));
+typedef short ashort4_t __attribute__((ext_vector_type(4)));
+constexpr int kA2KB = 64;                  // keys per tile
+constexpr int kA2VSub = kA2KB * 32 + 128;  // bytes per V subtile: [64 keys][16 dims] fp16 + the bank offset
+template <int HS>
+constexpr int a2_stage_bytes() { return kA2KB * HS * 2 + (HS / 16) * kA2VSub; }
+
+template <int HS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma2_kernel(const AttnParams p, const int nqb, const int aligned_dst) {
+  constexpr int NJ = HS / 16, NDT = HS / 32, NCH = HS / 8, KROW = HS * 2, NSUB = HS / 16;
+  constexpr int KTILE = kA2KB * KROW, STAGE = a2_stage_bytes<HS>();
+  constexpr int KU = NCH / 4;               // 16-byte K chunks per thread and tile
+  constexpr int VRW = 4 * (8 / NSUB);       // V rows per wave-wide load
+  constexpr int VU = kA2KB / (4 * VRW);     // V chunks per thread and tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
+  const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
+  const unsigned L = blockIdx.x, total = gridDim.x;
+  const int hb = int(L / unsigned(nqb)), ordn = int(L % unsigned(nqb));
+  const int qblk = causal ? (L < (total + 1) / 2 ? nqb - 1 - ordn : ordn) : ordn;
+  const int ihn = hb % p.head_num, ibs = hb / p.head_num;
+  const int ihkv = ihn / (p.head_num / p.heads_kv);
+  const int off = p.sl_kv - p.sl_q;
+  const int q0 = qblk * 128 + w * 32;
+  const float* qb = p.q + ibs * p.step_q_bs + ihn * p.step_q_head_num;
+  const _Float16* kb = p.k + ibs * p.step_k_bs + ihkv * p.step_k_head_num;
+  const _Float16* vb = p.v + ibs * p.step_v_bs + ihkv * p.step_v_head_num;
+  float* db = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num;
+
+  ahalf8_t qf[NJ];
+  {
+    const float* qr = qb + (long long)min(q0 + n, p.sl_q - 1) * p.step_q_sl + 8 * h;
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) qf[j][i] = (_Float16)qr[16 * j + i];
+  }
+  afloatx16 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) o[dt][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // l_run: this lane's half of the row sum
+  const float sc = p.qk_scale * 1.4426950408889634f;  // scores in the exp2 domain
+  const int q_last_wg = min(qblk * 128 + 127, p.sl_q - 1);
+  const int kv_end = causal ? min(p.sl_kv, q_last_wg + off + 1) : p.sl_kv;                     // workgroup-uniform
+  const int visible = min(p.sl_kv, causal ? min(q0 + n, p.sl_q - 1) + off + 1 : p.sl_kv);      // mha_dense_wrapper.h:1440-1441
+  const int vis_first = min(p.sl_kv, causal ? q0 + off + 1 : p.sl_kv);                          // the wave's first row
+  const int vis_last = min(p.sl_kv, causal ? min(q0 + 31, p.sl_q - 1) + off + 1 : p.sl_kv);    // the wave's last row
+  const bool wave_live = q0 < p.sl_q;
+
+  // ---- tile staging: global -> registers -> LDS ----
+  ahalf8_t kst[KU], vst[VU];
+  int krow[KU], kslot[KU], vrow[VU];
+#pragma unroll
+  for (int u = 0; u < KU; u++) {
+    const int id = tid + 256 * u;
+    krow[u] = id / NCH;
+    const int c = id % NCH;
+    const int swz = HS == 128 ? (krow[u] & 15) : ((krow[u] >> 1) & 7);
+    kslot[u] = krow[u] * KROW + ((c ^ swz) << 4);
+  }
+  const int vsub = (l >> 3) % NSUB, vrq = (l >> 3) / NSUB, vr = (l >> 1) & 3, vhf = l & 1;
+#pragma unroll
+  for (int u = 0; u < VU; u++) vrow[u] = u * (4 * VRW) + w * VRW + vrq * 4 + vr;
+  const int kcol = (tid % NCH) * 8, vcol = 16 * vsub + 8 * vhf;
+  auto fetch = [&](int pos0) {
+#pragma unroll
+    for (int u = 0; u < KU; u++)
+      kst[u] = *reinterpret_cast<const ahalf8_t*>(kb + (long long)min(pos0 + krow[u], p.sl_kv - 1) * p.step_k_sl + kcol);
+#pragma unroll
+    for (int u = 0; u < VU; u++)
+      vst[u] = *reinterpret_cast<const ahalf8_t*>(vb + (long long)min(pos0 + vrow[u], p.sl_kv - 1) * p.step_v_sl + vcol);
+  };
+  auto park = [&](int stage) {
+    unsigned char* sb = smem2 + stage * STAGE;
+#pragma unroll
+    for (int u = 0; u < KU; u++) *reinterpret_cast<ahalf8_t*>(sb + kslot[u]) = kst[u];
+#pragma unroll
+    for (int u = 0; u < VU; u++) *reinterpret_cast<ahalf8_t*>(sb + KTILE + vsub * kA2VSub + vrow[u] * 32 + vhf * 16) = vst[u];
+  };
+  // operand addresses inside a stage
+  const int swz_n = HS == 128 ? (n & 15) : ((n >> 1) & 7);
+  const int k_rd = n * KROW;                                                        // + 32 T rows, slot (2 j + h) ^ swizzle
+  const int v_rd = KTILE + ((l >> 4) & 1) * kA2VSub + (4 * h + ((l & 15) >> 2)) * 32 + (l & 3) * 8;  // + 2 dt subtiles, + (32 T + 16 s) rows, + 8 rows
+
+  const int nb = (kv_end + kA2KB - 1) / kA2KB;
+  if (nb > 0) {
+    fetch(0);
+    park(0);
+  }
+  __syncthreads();
+  for (int b = 0; b < nb; b++) {
+    const int pos0 = b * kA2KB;
+    const unsigned char* sb = smem2 + (b & 1) * STAGE;
+    if (b + 1 < nb) fetch(pos0 + kA2KB);
+    if (wave_live && pos0 < vis_last) {
+      afloatx16 sv[2];
+#pragma unroll
+      for (int T = 0; T < 2; T++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) sv[T][i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const ahalf8_t kf = *reinterpret_cast<const ahalf8_t*>(sb + k_rd + 32 * T * KROW + (((2 * j + h) ^ swz_n) << 4));
+          sv[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j], sv[T], 0, 0, 0);
+        }
+      }
+      // softmax in the exp2 domain on the raw scores (sc > 0: the launcher sends other scales to the 64-row kernel): p = exp2(s sc - m sc)
+      // is one fused multiply-add and one v_exp_f32 per score; the running maximum is kept unscaled
+      if (pos0 + kA2KB > vis_first) {  // wave-uniform: only tiles on the diagonal / past the last key are masked
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+          const int i = e & 15;
+          const int pos = pos0 + 32 * (e >> 4) + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (pos >= visible) sv[e >> 4][i] = -INFINITY;
+        }
+      }
+      float mx = sv[0][0];
+#pragma unroll
+      for (int e = 1; e < 32; e++) mx = fmaxf(mx, sv[e >> 4][e & 15]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float neg_m = m_new == -INFINITY ? 0.f : -m_new * sc;  // nothing visible yet: every exp2 below is exp2(-inf) = 0
+      const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, sc, neg_m));
+      float ps = 0.f;
+      ahalf8_t pf[4];  // (T, s) -> 2 T + s
+#pragma unroll
+      for (int e = 0; e < 32; e++) {
+        const float pe = __builtin_amdgcn_exp2f(fmaf(sv[e >> 4][e & 15], sc, neg_m));
+        ps += pe;
+        pf[e >> 3][e & 7] = (_Float16)pe;
+      }
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+      if (__any(alpha != 1.f)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+        for (int ts = 0; ts < 4; ts++) {
+          const unsigned char* va = sb + v_rd + 2 * dt * kA2VSub + 16 * ts * 32;
+          const ashort4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ashort4_t __attribute__((address_space(3)))*)(va));
+          const ashort4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ashort4_t __attribute__((address_space(3)))*)(va + 8 * 32));
+          const ahalf8_t vf = __builtin_bit_cast(ahalf8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ts], o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (b + 1 < nb) park((b + 1) & 1);
+    __syncthreads();
+  }
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = l_run > 0.f ? p.out_scale / l_run : 0.f;
+  const int row = q0 + n;
+  if (row < p.sl_q) {
+    float* dr = db + (long long)row * p.step_dst_sl;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+      for (int bq = 0; bq < 4; bq++) {
+        const int d = 32 * dt + 8 * bq + 4 * h;
+        const afloatx4 y = afloatx4{o[dt][4 * bq] * inv, o[dt][4 * bq + 1] * inv, o[dt][4 * bq + 2] * inv, o[dt][4 * bq + 3] * inv};
+        if (aligned_dst) {
+          *reinterpret_cast<afloatx4*>(dr + d) = y;
+          if (p.dst16) *reinterpret_cast<ahalf4_t*>(p.dst16 + (dr - p.dst) + d) = ahalf4_t{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            dr[d + r] = y[r];
+            if (p.dst16) p.dst16[(dr - p.dst) + d + r] = (_Float16)y[r];
+          }
+        }
+      }
+    }
+  }
+}
+
 static std::atomic<int> g_alibi_heads{0}, g_alibi_off{0};  // ns_hip_attn_set_head_partition
 
 static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipStream_t st, std::string* why,
@@ -702,6 +1010,19 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
                        (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
   if (!no_mfma && a.sl_q >= 16 && (a.head_size == 64 || a.head_size == 128) && rows_ok &&
       (a.attn_flags & (NS_ATTN_FLAG_IS_ALIBI8 | NS_ATTN_FLAG_IS_TANH30)) == 0) {
+    const size_t nqb = (size_t(a.sl_q) + 127) / 128, wgs2 = nqb * a.head_num * a.batch_size;
+    if (a.sl_q >= g_attn_mfma2_rows.load(std::memory_order_relaxed) && wgs2 < (size_t(1) << 31) && p.qk_scale > 0.f) {
+      // 128-row workgroups, 32x32x16 MFMA, K / V tiles shared through LDS (attn_mfma2_kernel)
+      const int aligned = (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && a.step_dst_sl % 4 == 0 && a.step_dst_head_num % 4 == 0 &&
+                          a.step_dst_bs % 4 == 0 && (!dst16 || (reinterpret_cast<uintptr_t>(dst16) & 7) == 0);
+      auto go = [&](auto kern, int stage) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * stage);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(kern, dim3(unsigned(wgs2)), dim3(256), size_t(2) * stage, st, p, int(nqb), aligned);
+        return hipGetLastError();
+      };
+      return a.head_size == 64 ? go(attn_mfma2_kernel<64>, a2_stage_bytes<64>()) : go(attn_mfma2_kernel<128>, a2_stage_bytes<128>());
+    }
     const dim3 grid(unsigned((a.sl_q + 63) / 64), unsigned(a.head_num), unsigned(a.batch_size));
     if (a.head_size == 64)
       hipLaunchKernelGGL(attn_mfma_kernel<64>, grid, dim3(256), 0, st, p);
@@ -732,6 +1053,10 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
       if (!ws) nsplit = 1;  // scratch allocation failed: unsplit, still correct
     }
     sp.ws = ws;
+    sp.tickets = nullptr;
+    const size_t nticket = size_t(a.batch_size) * a.sl_q * a.heads_kv;
+    if (nsplit > 1 && g_attn_inlaunch.load(std::memory_order_relaxed) != 0 && nticket <= kAttnTicketCap)
+      sp.tickets = static_cast<uint32_t*>(stream_scratch_zeroed(st, kAttnTicketCap * 4, 22));  // nullptr (e.g. first use on a capturing stream): the merge launch
     sp.nsplit = nsplit;
     sp.keys_per_split = (a.sl_kv + nsplit - 1) / nsplit;
     const dim3 grid(unsigned(nsplit), unsigned(a.heads_kv * a.sl_q), unsigned(a.batch_size));
@@ -740,7 +1065,7 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
                  : G == 4 ? launch_split_g<4>(sp, grid, st)
                           : launch_split_g<8>(sp, grid, st);
     if (e != hipSuccess) return e;
-    if (nsplit > 1) {
+    if (nsplit > 1 && !sp.tickets) {
       hipLaunchKernelGGL(attn_merge_kernel, dim3(unsigned(a.head_num), unsigned(a.sl_q), unsigned(a.batch_size)), dim3(128), 0,
                          st, sp);
       e = hipGetLastError();

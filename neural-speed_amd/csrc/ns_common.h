@@ -185,6 +185,8 @@ void set_gemv_mode(int mode);  // 0 off (first-generation kernel), 1 on, -1 re-r
 hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st);
 void set_gemvs_tuning(int what, int value);  // what: 0 mode (0 off, 1 from 2 rows, 2 from 1 row), 1 slices, 2 waves, 3 workgroups
 void set_attn_tuning(int wg_target, int min_keys);
+void set_attn_mfma2_rows(int rows);  // query rows from which the 128-row prefill attention kernel is used (default 128; huge = never)
+void set_attn_inlaunch(int on);  // 1 (default): the last context split merges inside attn_split_kernel's launch; 0: attn_merge_kernel
 // NS_HOST_PROFILE=1: wall time and call count of every host-tensor entry, printed at exit (diagnostics of the default,
 // host-pointer route: where a token's milliseconds go between the graph executor and the GPU)
 struct HostScope {

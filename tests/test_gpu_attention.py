@@ -29,6 +29,13 @@ CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags, k_trans
     (1, 6, 3, 128, 16, 16, 1, False),      # smallest row count that takes this kernel
     (1, 16, 16, 128, 300, 300, 1, False),  # several row blocks with different causal extents
     (1, 4, 4, 64, 33, 1000, 1, False),     # long context, few rows
+    # ---- 128 query rows and more -> the 128-row kernel (attn_mfma2_kernel: 32x32x16 MFMA, K / V tiles through LDS) ----
+    (1, 8, 2, 64, 200, 333, 1, False),     # head size 64, GQA, ragged rows and context, chunked prefill (sl_q < sl_kv)
+    (2, 4, 4, 128, 129, 129, 1, False),    # batch 2, one row past a block
+    (1, 4, 4, 128, 256, 700, 0, False),    # unmasked, context not a multiple of the key tile
+    (1, 4, 4, 64, 512, 512, 1, False),     # head size 64, several blocks
+    (1, 2, 2, 128, 1000, 1000, 1, False),  # ragged last block, many key tiles
+    (1, 3, 1, 128, 128, 128, 1, False),    # group of 3, exactly one block
 ]
 
 
@@ -156,3 +163,78 @@ def test_attention_against_golden_rows_of_the_reference_function(L, pkg, nso, id
         assert nso.rel_l2(out[:, rows], g["c%d_kt%d_fp321" % (idx, int(kt))]) < 4e-3, (idx, kt)
         assert nso.rel_l2(out[:, rows], g["c%d_kt%d_fp320" % (idx, int(kt))]) < 1.2e-2, (idx, kt)
         assert nso.rel_l2(out, nso.attn_ref(q, kk, v, scale, flags, k_trans=kt)) < TOL, (idx, kt)
+
+
+@pytest.mark.parametrize("bs,hn,hkv,hs,sl_q,sl_kv,flags", [
+    (1, 32, 32, 128, 1, 2048, 1),   # Llama-2-7B decode: 16 splits
+    (1, 32, 8, 128, 1, 4096, 1),    # Mistral-7B head grouping: 32 splits (the general form of the merge)
+    (1, 16, 2, 256, 2, 8192, 1),    # 64 splits, group of 8, two query rows
+    (3, 8, 8, 64, 1, 700, 0),       # batch 3, head size 64, ragged last split
+    (1, 8, 8, 128, 3, 1500, 3),     # alibi, causal extents differ per row (a split of the first rows may be empty)
+])
+def test_merge_inside_the_launch_gives_the_bits_of_the_merge_kernel(L, pkg, nso, bs, hn, hkv, hs, sl_q, sl_kv, flags):
+    """round 4: the context split that finishes last combines all splits inside attn_split_kernel's launch (self-resetting
+    counters) — same sums in the same order as attn_merge_kernel, on repeated launches and inside a replayed graph"""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(sl_kv + hs)
+    q = torch.randn((bs, sl_q, hn, hs), generator=g, device="cuda")
+    k = torch.randn((bs, sl_kv, hkv, hs), generator=g, device="cuda").half()
+    v = torch.randn((bs, sl_kv, hkv, hs), generator=g, device="cuda").half()
+    scale = float(1.0 / np.sqrt(hs))
+    outs = {}
+    try:
+        for mode in (0, 1):
+            L.ns_hip_set_tuning(b"attn_inlaunch", mode)
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            res = []
+            for rep in range(3):
+                d = torch.full_like(q, 7.0)
+                a = pkg.attn_args(q.data_ptr(), k.data_ptr(), v.data_ptr(), d.data_ptr(), bs, hn, hkv, hs, sl_q, sl_kv, scale, flags)
+                pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), st))
+                torch.cuda.synchronize()
+                res.append(d)
+            assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+            outs[mode] = res[0]
+        assert torch.equal(outs[0], outs[1])
+        ref = nso.attn_ref(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), scale, flags)
+        assert nso.rel_l2(outs[1].cpu().numpy(), ref) < TOL
+        # inside a graph, replayed
+        L.ns_hip_set_tuning(b"attn_inlaunch", 1)
+        d = torch.zeros_like(q)
+        a = pkg.attn_args(q.data_ptr(), k.data_ptr(), v.data_ptr(), d.data_ptr(), bs, hn, hkv, hs, sl_q, sl_kv, scale, flags)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        for rep in range(3):
+            d.zero_()
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(d, outs[1]), rep
+    finally:
+        L.ns_hip_set_tuning(b"attn_inlaunch", 1)
+
+
+@pytest.mark.parametrize("hs,misalign", [(128, 0), (128, 1), (64, 1)])
+def test_prefill_kernel_fp16_shadow_and_unaligned_output(L, pkg, nso, hs, misalign):
+    """attn_mfma2_kernel writes whole 16-byte pieces of an output row when the destination allows it and single elements when it
+    does not (a destination one float off a 16-byte boundary); the fp16 shadow of ns_hip_attn_..._forward_h carries the same values"""
+    import torch
+    bs, hn, hkv, sl_q, sl_kv = 1, 4, 2, 300, 300
+    rng = np.random.default_rng(hs + misalign)
+    q = rng.standard_normal((bs, sl_q, hn, hs)).astype(np.float32)
+    k = rng.standard_normal((bs, sl_kv, hkv, hs)).astype(np.float16)
+    v = rng.standard_normal((bs, sl_kv, hkv, hs)).astype(np.float16)
+    scale = float(1.0 / np.sqrt(hs))
+    ref = nso.attn_ref(q, k, v, scale, 1)
+    dq, dk, dv = torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+    buf = torch.zeros(q.size + 8, device="cuda")
+    buf16 = torch.zeros(q.size + 8, device="cuda", dtype=torch.float16)
+    a = pkg.attn_args(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), buf.data_ptr() + 4 * misalign, bs, hn, hkv, hs, sl_q, sl_kv, scale, 1)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(C.byref(a), C.c_void_p(buf16.data_ptr() + 2 * misalign), st))
+    torch.cuda.synchronize()
+    out = buf[misalign:misalign + q.size].cpu().numpy().reshape(q.shape)
+    out16 = buf16[misalign:misalign + q.size].float().cpu().numpy().reshape(q.shape)
+    assert nso.rel_l2(out, ref) < TOL
+    assert np.array_equal(out16, out.astype(np.float16).astype(np.float32))
+    assert float(buf[:misalign].abs().sum()) == 0.0 and float(buf[misalign + q.size:].abs().sum()) == 0.0
