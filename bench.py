@@ -402,7 +402,7 @@ def main():
         return
     if args.full_token_only and world == 1:
         ft, _ = full_token(chain, pkg, 2048, fused=True)
-        print(json.dumps({"full_token": ft}))
+        print(json.dumps({"full_token": ft, "full_prefill": full_prefill(chain, pkg, 2048)}))
         return
     attempts = ([(m, True) for m in launch_modes(True)] if use_p2p else []) + [(m, False) for m in launch_modes(False)]
     wall_ms = ev_ms = None
@@ -510,6 +510,7 @@ def main():
             out["config"]["full_token_tokens_per_s"] = ft["tokens_per_s"]
             out["config"]["full_token"] = {"fused": ft, "one_launch_per_operator": fu,
                                            "logits_rel_l2_fused_vs_unfused": round(rel, 6)}
+            out["config"]["full_prefill"] = full_prefill(chain, pkg, 2048)
             out["config"]["prefill_m2048_tflops"] = prefill_tflops(chain, pkg)
             out["config"]["prefill_m2048_tflops_int8w"] = prefill_tflops_int8w(chain, pkg)
             out["config"]["prefill_m2048_tflops_ref_int8_semantics"] = prefill_tflops_ref_int8(chain, pkg)
@@ -648,6 +649,62 @@ def full_token(chain, pkg, ctx=2048, fused=True, iters=30, keep=None):
     return {"ctx": ctx, "ms_per_token": round(ms, 4), "tokens_per_s": round(1000.0 / ms, 1),
             "launches_per_token": launches[0], "launches_per_layer": round((launches[0] - (3 if fused else 2)) / nl, 2),
             "finite": bool(torch.isfinite(logits).all().item())}, logits
+
+
+def full_prefill(chain, pkg, m=2048, iters=5):
+    """A WHOLE prompt of m tokens through the same model on the same weights, one launch per operator: rms norm . gamma, fused
+    QKV (tiled MFMA GEMM), RoPE(q, k) + kv-cache append, causal attention over the prompt (the 128-row matrix-core kernel, fp16 K / V
+    just appended), WO + residual, norm, gate/up . SiLU, down + residual — every layer — then the final norm and the lm_head row of
+    the LAST position (what a first token needs).  tflops = 2 x weights x m + 4 x heads x head_size x m^2 / 2 per layer (causal half)."""
+    L = pkg.lib()
+    d, ff, V = chain.d, chain.ff, chain.V
+    heads, hs = CFG["n_head"], CFG["n_embd"] // CFG["n_head"]
+    nl = len(chain.layers)
+    dev, h16 = "cuda", torch.float16
+    g = torch.Generator(device=dev).manual_seed(13)
+    kc = [torch.zeros((1, m, heads, hs), device=dev, dtype=h16) for _ in range(nl)]
+    vc = [torch.zeros((1, m, heads, hs), device=dev, dtype=h16) for _ in range(nl)]
+    gam = torch.ones(d, device=dev)
+    f32 = lambda *sh: torch.empty(*sh, device=dev)
+    f16 = lambda *sh: torch.empty(*sh, device=dev, dtype=h16)
+    x0 = torch.randn((m, d), generator=g, device=dev)
+    b = dict(h=f32(m, d), qkv=f32(3, m, d), att=f32(m, d), r1=f32(m, d), h2=f32(m, d), t1=f32(m, ff), t2=f32(m, ff), x=f32(m, d),
+             logits=f32(1, V))
+    sh = dict(h=f16(m, d), att=f16(m, d), t2=f16(m, ff))
+
+    def step():
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ck = pkg.check
+        xin = x0
+        for il, lw in enumerate(chain.layers):
+            ck(L.ns_hip_norm_mul_h(m, d, True, 1e-5, xin.data_ptr(), gam.data_ptr(), b["h"].data_ptr(), sh["h"].data_ptr(), st))
+            ck(L.ns_hip_fusion_qkv_forward_h(b["h"].data_ptr(), sh["h"].data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
+                                             b["qkv"].data_ptr(), None, m, d, d, st))
+            ck(L.ns_hip_rope_qkv_append(b["qkv"][0].data_ptr(), b["qkv"][1].data_ptr(), b["qkv"][2].data_ptr(), kc[il].data_ptr(),
+                                        vc[il].data_ptr(), m, heads, heads, hs, 0, hs, 0, 10000.0, 1.0, 0.0, 1.0, heads * hs, hs, st))
+            a = pkg.attn_args(b["qkv"][0].data_ptr(), kc[il].data_ptr(), vc[il].data_ptr(), b["att"].data_ptr(), 1, heads, heads, hs,
+                              m, m, hs ** -0.5, pkg.ATTN_CAUSAL)
+            ck(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(C.byref(a), sh["att"].data_ptr(), st))
+            ck(L.ns_hip_f32f32_forward_h(b["att"].data_ptr(), sh["att"].data_ptr(), lw["o"].h, b["r1"].data_ptr(), None, m, d, d,
+                                         pkg.EPI_ADD, xin.data_ptr(), d, st))
+            ck(L.ns_hip_norm_mul_h(m, d, True, 1e-5, b["r1"].data_ptr(), gam.data_ptr(), b["h2"].data_ptr(), sh["h"].data_ptr(), st))
+            ck(L.ns_hip_fusion_ffn3_gateup_h(b["h2"].data_ptr(), sh["h"].data_ptr(), lw["w1"].h, lw["w3"].h, b["t1"].data_ptr(),
+                                             b["t2"].data_ptr(), sh["t2"].data_ptr(), m, pkg.EPI_SILU, st))
+            ck(L.ns_hip_f32f32_forward_h(b["t2"].data_ptr(), sh["t2"].data_ptr(), lw["w2"].h, b["x"].data_ptr(), None, m, ff, d,
+                                         pkg.EPI_ADD, b["r1"].data_ptr(), d, st))
+            xin = b["x"]
+        last = xin[m - 1:m]
+        ck(L.ns_hip_norm_mul_h(1, d, True, 1e-5, last.data_ptr(), gam.data_ptr(), b["h"].data_ptr(), sh["h"].data_ptr(), st))
+        ck(L.ns_hip_f32f32_forward_h(b["h"].data_ptr(), sh["h"].data_ptr(), chain.head.h, b["logits"].data_ptr(), None, 1, d, V,
+                                     pkg.EPI_NONE, None, 0, st))
+
+    ms = _timed(step, 2, iters)
+    wflops = sum(2.0 * m * lw[k].n * lw[k].k for lw in chain.layers for k in ("q", "k", "v", "o", "w1", "w3", "w2"))
+    aflops = nl * 4.0 * heads * hs * m * m / 2
+    return {"prompt_tokens": m, "ms": round(ms, 3), "prompt_tokens_per_s": round(m / ms * 1e3, 0),
+            "tflops_gemm_plus_causal_attention": round((wflops + aflops) / ms / 1e9, 1),
+            "attention_share_of_flops": round(aflops / (wflops + aflops), 3), "launches": 8 * nl + 2,
+            "finite": bool(torch.isfinite(b["logits"]).all().item())}
 
 
 ROOFLINE_KERNEL = "gemv_kernel<INT4,SPS4,BF16,sym,DUAL>"  # demangled: ns::gemv_kernel<0, 4, 0, false, 1, false>

@@ -216,8 +216,8 @@ int ns_hip_get_compute_mode(void);
  *   "attn_wg_target", "attn_min_keys"   context-split rule of the decode attention kernel (defaults 1024, 128)
  *   "attn_mfma2_rows" query rows from which a prefill takes the 128-row matrix-core attention kernel (0 = default 128; a value
  *                     above every sl_q keeps the 64-row kernel of rounds 1-3)
- *   "attn_inlaunch"   1 (default) = the context split that finishes last merges all splits inside the launch (one self-resetting
- *                     counter per kv head), 0 = a second launch (attn_merge_kernel) does; same sums in the same order
+ *   "attn_inlaunch"   0 (default) = attn_merge_kernel combines the context splits in a second launch, 1 = the split that finishes
+ *                     last does inside the launch (one self-resetting counter per kv head); same sums in the same order, same time
  *   "gv_nw"           waves per 16-column tile of the decode kernels (2 / 4 / 8 / 16), 0 = by shape (default); the
  *                     partial sums of a tile are added in wave order, so this selects the summation order
  *   "g3_min_m"        rows from which the tiled prefill GEMM is used inside its envelope (0 = default)

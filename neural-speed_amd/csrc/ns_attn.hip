@@ -500,7 +500,10 @@ static hipError_t launch_split_g(const AttnSplitParams& sp, dim3 grid, hipStream
 // context splits of the fast path for a shape (1 = unsplit) — shared by the launcher and the workspace-size query
 static std::atomic<int> g_attn_mfma2_rows{getenv("NS_ATTN_MFMA2_ROWS") ? atoi(getenv("NS_ATTN_MFMA2_ROWS")) : 128};  // query rows from which attn_mfma2_kernel serves a prefill
 void set_attn_mfma2_rows(int rows) { g_attn_mfma2_rows.store(rows > 0 ? rows : 128); }
-static std::atomic<int> g_attn_inlaunch{getenv("NS_ATTN_INLAUNCH") ? atoi(getenv("NS_ATTN_INLAUNCH")) != 0 : 1};  // ns_hip_set_tuning("attn_inlaunch"): 1 = the last split merges inside the launch, 0 = attn_merge_kernel
+// ns_hip_set_tuning("attn_inlaunch"): 1 = the last split merges inside the launch, 0 (default) = attn_merge_kernel.  Measured equal
+// (profiles/r04ab_attn_merge_in_launch.txt: split 11.8 us + merge 4.7 us against 16.5 us in one launch, whole token 600 vs 590 tok/s):
+// the cost is the write-through / ticket / read-back chain across XCDs, not the kernel boundary.
+static std::atomic<int> g_attn_inlaunch{getenv("NS_ATTN_INLAUNCH") ? atoi(getenv("NS_ATTN_INLAUNCH")) != 0 : 0};
 static constexpr size_t kAttnTicketCap = 65536;
 static std::atomic<int> g_attn_wg_target{1024}, g_attn_min_keys{128};  // ns_hip_set_tuning("attn_wg_target" / "attn_min_keys")
 void set_attn_inlaunch(int on) { g_attn_inlaunch.store(on != 0); }
@@ -783,7 +786,7 @@ template <int HS>
 constexpr int a2_stage_bytes() { return kA2KB * HS * 2 + (HS / 16) * kA2VSub; }
 
 template <int HS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma2_kernel(const AttnParams p, const int nqb, const int aligned_dst) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma2_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
   constexpr int NJ = HS / 16, NDT = HS / 32, NCH = HS / 8, KROW = HS * 2, NSUB = HS / 16;
   constexpr int KTILE = kA2KB * KROW, STAGE = a2_stage_bytes<HS>();
   constexpr int KU = NCH / 4;               // 16-byte K chunks per thread and tile
@@ -792,9 +795,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
   const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
-  const unsigned L = blockIdx.x, total = gridDim.x;
-  const int hb = int(L / unsigned(nqb)), ordn = int(L % unsigned(nqb));
-  const int qblk = causal ? (L < (total + 1) / 2 ? nqb - 1 - ordn : ordn) : ordn;
+  // workgroup -> (query block, head, batch).  Workgroups go to the XCDs round-robin (id % 8) and each XCD has its own L2: with the
+  // plain order every XCD walks every head's K / V (32 MB at 2048 x 32 heads against 4 MB of L2 — the kernel then streams K / V from
+  // memory at ~4 TB/s and is bound by that).  xcd_map: all query blocks of a kv head (and of the query heads sharing it) on ONE XCD,
+  // head after head, so a head's K / V is fetched from memory once and re-read from that L2.
+  // Causal balance: every (head, batch) unit walks its query blocks in ONE direction; the first half of the units (of the XCD's list)
+  // heaviest-first, the second half lightest-first.
+  const unsigned G = unsigned(p.head_num / p.heads_kv), units = gridDim.x / unsigned(nqb);
+  unsigned unit = blockIdx.x / unsigned(nqb), ordn = blockIdx.x % unsigned(nqb);
+  bool heavy_first = unit < (units + 1) / 2;
+  if (xcd_map) {
+    const unsigned x = blockIdx.x & 7u, sl = blockIdx.x >> 3;  // XCD, index inside the XCD's list
+    const unsigned ul = sl / unsigned(nqb);                     // the XCD's ul-th (kv head, query head of its group)
+    ordn = sl % unsigned(nqb);
+    unit = ((ul / G) * 8u + x) * G + ul % G;
+    heavy_first = ul < (units / 8u + 1) / 2;
+  }
+  const int hb = int(unit);
+  const int qblk = causal && heavy_first ? nqb - 1 - int(ordn) : int(ordn);
   const int ihn = hb % p.head_num, ibs = hb / p.head_num;
   const int ihkv = ihn / (p.head_num / p.heads_kv);
   const int off = p.sl_kv - p.sl_q;
@@ -841,13 +859,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int u = 0; u < VU; u++) vrow[u] = u * (4 * VRW) + w * VRW + vrq * 4 + vr;
   const int kcol = (tid % NCH) * 8, vcol = 16 * vsub + 8 * vhf;
+  // row pointers advance by a uniform stride per tile; only the tile that reaches past the last key clamps its rows
+  const _Float16* kp0 = kb + (long long)krow[0] * p.step_k_sl + kcol;
+  const _Float16* vp0 = vb + (long long)vrow[0] * p.step_v_sl + vcol;
+  const long long ku_step = (long long)(256 / NCH) * p.step_k_sl, vu_step = (long long)(4 * VRW) * p.step_v_sl;
+  const long long ktile_step = (long long)kA2KB * p.step_k_sl, vtile_step = (long long)kA2KB * p.step_v_sl;
   auto fetch = [&](int pos0) {
+    if (pos0 + kA2KB <= p.sl_kv) {  // workgroup-uniform
 #pragma unroll
-    for (int u = 0; u < KU; u++)
-      kst[u] = *reinterpret_cast<const ahalf8_t*>(kb + (long long)min(pos0 + krow[u], p.sl_kv - 1) * p.step_k_sl + kcol);
+      for (int u = 0; u < KU; u++) kst[u] = *reinterpret_cast<const ahalf8_t*>(kp0 + u * ku_step);
 #pragma unroll
-    for (int u = 0; u < VU; u++)
-      vst[u] = *reinterpret_cast<const ahalf8_t*>(vb + (long long)min(pos0 + vrow[u], p.sl_kv - 1) * p.step_v_sl + vcol);
+      for (int u = 0; u < VU; u++) vst[u] = *reinterpret_cast<const ahalf8_t*>(vp0 + u * vu_step);
+    } else {
+#pragma unroll
+      for (int u = 0; u < KU; u++)
+        kst[u] = *reinterpret_cast<const ahalf8_t*>(kb + (long long)min(pos0 + krow[u], p.sl_kv - 1) * p.step_k_sl + kcol);
+#pragma unroll
+      for (int u = 0; u < VU; u++)
+        vst[u] = *reinterpret_cast<const ahalf8_t*>(vb + (long long)min(pos0 + vrow[u], p.sl_kv - 1) * p.step_v_sl + vcol);
+    }
+    kp0 += ktile_step;
+    vp0 += vtile_step;
   };
   auto park = [&](int stage) {
     unsigned char* sb = smem2 + stage * STAGE;
@@ -1015,10 +1047,12 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
       // 128-row workgroups, 32x32x16 MFMA, K / V tiles shared through LDS (attn_mfma2_kernel)
       const int aligned = (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && a.step_dst_sl % 4 == 0 && a.step_dst_head_num % 4 == 0 &&
                           a.step_dst_bs % 4 == 0 && (!dst16 || (reinterpret_cast<uintptr_t>(dst16) & 7) == 0);
+      static const bool no_xcd = getenv("NS_ATTN_NO_XCD_MAP") != nullptr;  // diagnostics (A/B)
+      const int xcd_map = !no_xcd && (size_t(a.heads_kv) * a.batch_size) % 8 == 0;
       auto go = [&](auto kern, int stage) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * stage);
         if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(kern, dim3(unsigned(wgs2)), dim3(256), size_t(2) * stage, st, p, int(nqb), aligned);
+        hipLaunchKernelGGL(kern, dim3(unsigned(wgs2)), dim3(256), size_t(2) * stage, st, p, int(nqb), aligned, xcd_map);
         return hipGetLastError();
       };
       return a.head_size == 64 ? go(attn_mfma2_kernel<64>, a2_stage_bytes<64>()) : go(attn_mfma2_kernel<128>, a2_stage_bytes<128>());

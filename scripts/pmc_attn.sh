@@ -1,8 +1,11 @@
 #!/bin/bash
-# SQ counters of the prefill attention kernel (own --pmc pass)
+# SQ counters of the prefill attention kernel (own --pmc passes, one per counter group)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
+           "SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" \
+           "FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
 rm -rf gpurun_out/pmca
-timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d gpurun_out/pmca -o a -- python scripts/attn_prefill_bench.py 2048 > /dev/null 2>&1
+timeout 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmca -o a -- python scripts/attn_prefill_bench.py 2048 > /dev/null 2>&1
 python - <<'PY'
 import csv, collections
 rows = list(csv.DictReader(open("gpurun_out/pmca/a_counter_collection.csv")))
@@ -19,3 +22,4 @@ for key, c in agg.items():
     for k, v in sorted(m.items()):
         print("   %-28s %14.0f  %6.3f of WAVE_CYCLES" % (k, v, v / wc))
 PY
+done
