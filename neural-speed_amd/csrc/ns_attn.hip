@@ -780,6 +780,9 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnParams p) {
 // ============================================================================================================
 typedef float afloatx16 __attribute__((ext_vector_type(16)));
 typedef short ashort4_t __attribute__((ext_vector_type(4)));
+#ifndef NS_A2_ABL
+#define NS_A2_ABL 0  // timing ablations (diagnostic builds, wrong results): 1 no softmax, 2 no P.V, 3 no K.Q^T, 4 no tile traffic, 5 = 4 + no barrier
+#endif
 constexpr int kA2KB = 64;                  // keys per tile
 constexpr int kA2VSub = kA2KB * 32 + 128;  // bytes per V subtile: [64 keys][16 dims] fp16 + the bank offset
 template <int HS>
@@ -902,21 +905,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int b = 0; b < nb; b++) {
     const int pos0 = b * kA2KB;
     const unsigned char* sb = smem2 + (b & 1) * STAGE;
-    if (b + 1 < nb) fetch(pos0 + kA2KB);
+    if (b + 1 < nb && NS_A2_ABL < 4) fetch(pos0 + kA2KB);
     if (wave_live && pos0 < vis_last) {
+      // operands travel LDS -> registers one group of four MFMAs ahead of their use (two register sets, fenced: left alone hipcc
+      // re-uses ONE operand register and serialises read -> wait -> MFMA, ~100 exposed cycles per MFMA)
       afloatx16 sv[2];
 #pragma unroll
-      for (int T = 0; T < 2; T++) {
+      for (int T = 0; T < 2; T++)
 #pragma unroll
         for (int i = 0; i < 16; i++) sv[T][i] = 0.f;
+      {
+        constexpr int CPT = NJ / 4, NCK = 2 * CPT;  // groups per 32-key tile, groups per block
+        ahalf8_t kf[2][4];
+        auto ldk = [&](int c, ahalf8_t(&dst)[4]) {
+          const int T = c / CPT, j0 = (c % CPT) * 4;
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          const ahalf8_t kf = *reinterpret_cast<const ahalf8_t*>(sb + k_rd + 32 * T * KROW + (((2 * j + h) ^ swz_n) << 4));
-          sv[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j], sv[T], 0, 0, 0);
+          for (int u = 0; u < 4; u++)
+            dst[u] = *reinterpret_cast<const ahalf8_t*>(sb + k_rd + 32 * T * KROW + (((2 * (j0 + u) + h) ^ swz_n) << 4));
+        };
+        if (NS_A2_ABL != 3) ldk(0, kf[0]);
+#pragma unroll
+        for (int c = 0; c < (NS_A2_ABL == 3 ? 0 : NCK); c++) {
+          if (c + 1 < NCK) ldk(c + 1, kf[(c + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            sv[c / CPT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c & 1][u], qf[(c % CPT) * 4 + u], sv[c / CPT], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       // softmax in the exp2 domain on the raw scores (sc > 0: the launcher sends other scales to the 64-row kernel): p = exp2(s sc - m sc)
       // is one fused multiply-add and one v_exp_f32 per score; the running maximum is kept unscaled
+      ahalf8_t pf[4];  // (T, s) -> 2 T + s
+#if NS_A2_ABL == 1
+#pragma unroll
+      for (int e = 0; e < 32; e++) pf[e >> 3][e & 7] = (_Float16)sv[e >> 4][e & 15];
+      l_run += 1.f;
+#else
       if (pos0 + kA2KB > vis_first) {  // wave-uniform: only tiles on the diagonal / past the last key are masked
 #pragma unroll
         for (int e = 0; e < 32; e++) {
@@ -933,7 +958,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float neg_m = m_new == -INFINITY ? 0.f : -m_new * sc;  // nothing visible yet: every exp2 below is exp2(-inf) = 0
       const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, sc, neg_m));
       float ps = 0.f;
-      ahalf8_t pf[4];  // (T, s) -> 2 T + s
 #pragma unroll
       for (int e = 0; e < 32; e++) {
         const float pe = __builtin_amdgcn_exp2f(fmaf(sv[e >> 4][e & 15], sc, neg_m));
@@ -948,20 +972,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
       }
+#endif
+      {
+        ahalf8_t vf[2][4];
+        auto ldv = [&](int dt, ahalf8_t(&dst)[4]) {
 #pragma unroll
-      for (int dt = 0; dt < NDT; dt++) {
+          for (int ts = 0; ts < 4; ts++) {
+            const unsigned char* va = sb + v_rd + 2 * dt * kA2VSub + 16 * ts * 32;
+            const ashort4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ashort4_t __attribute__((address_space(3)))*)(va));
+            const ashort4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ashort4_t __attribute__((address_space(3)))*)(va + 8 * 32));
+            dst[ts] = __builtin_bit_cast(ahalf8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+        };
+        if (NS_A2_ABL != 2) ldv(0, vf[0]);
 #pragma unroll
-        for (int ts = 0; ts < 4; ts++) {
-          const unsigned char* va = sb + v_rd + 2 * dt * kA2VSub + 16 * ts * 32;
-          const ashort4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ashort4_t __attribute__((address_space(3)))*)(va));
-          const ashort4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ashort4_t __attribute__((address_space(3)))*)(va + 8 * 32));
-          const ahalf8_t vf = __builtin_bit_cast(ahalf8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ts], o[dt], 0, 0, 0);
+        for (int dt = 0; dt < (NS_A2_ABL == 2 ? 0 : NDT); dt++) {
+          if (dt + 1 < NDT) ldv(dt + 1, vf[(dt + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ts = 0; ts < 4; ts++) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt & 1][ts], pf[ts], o[dt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-    if (b + 1 < nb) park((b + 1) & 1);
-    __syncthreads();
+    if (b + 1 < nb && NS_A2_ABL < 4) park((b + 1) & 1);
+    if (NS_A2_ABL < 5) __syncthreads();
   }
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = l_run > 0.f ? p.out_scale / l_run : 0.f;
