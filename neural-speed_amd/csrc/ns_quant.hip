@@ -860,6 +860,95 @@ hipError_t launch_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, f
   return hipGetLastError();
 }
 
+// ---- prompt-sized form (round 4): the angles of a position are the same for every head and layer, and the kernel above spends its
+// time re-deriving them per pair (up to npairs sequential multiplies + cosf + sinf per thread: 86 us for 2048 tokens x 64 heads).
+// Here a table kernel writes (cos, sin) * attn_factor per (position, pair) with the SAME arithmetic, and the rotation kernel is a
+// pure stream: 4 pairs per thread (two 16-byte loads, two 16-byte stores or one 16-byte fp16 store), 8 V elements per thread. ----
+__global__ void rope_table_kernel(int m, int n_past, int npairs, int neox, float theta_scale, float freq_scale, float attn_factor,
+                                  float2* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= m * npairs) return;
+  const int i2 = gid / npairs, pr = gid % npairs;
+  float theta_base = float(n_past + i2);
+  if (neox) theta_base = __fmul_rn(theta_base, freq_scale);
+  for (int t = 0; t < pr; t++) theta_base = __fmul_rn(theta_base, theta_scale);
+  const float theta = __fmul_rn(freq_scale, theta_base);
+  out[gid] = float2{__fmul_rn(cosf(theta), attn_factor), __fmul_rn(sinf(theta), attn_factor)};
+}
+typedef float qfloat4 __attribute__((ext_vector_type(4)));
+typedef _Float16 qhalf4 __attribute__((ext_vector_type(4)));
+typedef _Float16 qhalf8 __attribute__((ext_vector_type(8)));
+__global__ void rope_qkv_append_tab_kernel(float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                           _Float16* __restrict__ kc, _Float16* __restrict__ vc, const float2* __restrict__ tab,
+                                           int seq, int heads, int heads_kv, int head_size, int n_past, int n_dims, int neox,
+                                           long long c_sl, long long c_head) {
+  const int npairs = neox ? (head_size / n_dims) * (n_dims / 2) : head_size / 2;
+  const int qpr = npairs / 4;  // groups of 4 pairs per row
+  const size_t nq = size_t(seq) * heads * qpr, nk = size_t(seq) * heads_kv * qpr;
+  const size_t nv = size_t(seq) * heads_kv * (head_size / 8);
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid < nq + nk) {
+    const bool is_k = gid >= nq;
+    const size_t g = is_k ? gid - nq : gid;
+    const int hn = is_k ? heads_kv : heads;
+    const size_t row = g / qpr;  // (i2, head)
+    const int pr = int(g % qpr) * 4, i2 = int(row / hn), ih = int(row % hn);
+    const float2* cs = tab + size_t(i2) * npairs + pr;
+    const qfloat4 cs01 = *reinterpret_cast<const qfloat4*>(cs), cs23 = *reinterpret_cast<const qfloat4*>(cs + 2);
+    const float c[4] = {cs01[0], cs01[2], cs23[0], cs23[2]}, sn[4] = {cs01[1], cs01[3], cs23[1], cs23[3]};
+    const float* x = (is_k ? k : q) + row * head_size;
+    float a[4], b[4];
+    int ia, ib;
+    if (neox) {  // pairs (ia + e, ia + e + n_dims / 2)
+      const int blk = pr / (n_dims / 2), ic = pr % (n_dims / 2);
+      ia = blk * n_dims + ic;
+      ib = ia + n_dims / 2;
+      const qfloat4 xa = *reinterpret_cast<const qfloat4*>(x + ia), xb = *reinterpret_cast<const qfloat4*>(x + ib);
+#pragma unroll
+      for (int e = 0; e < 4; e++) a[e] = xa[e], b[e] = xb[e];
+    } else {  // adjacent pairs: 8 consecutive elements
+      ia = 2 * pr;
+      ib = ia + 4;
+      const qfloat4 x0 = *reinterpret_cast<const qfloat4*>(x + ia), x1 = *reinterpret_cast<const qfloat4*>(x + ib);
+      a[0] = x0[0], b[0] = x0[1], a[1] = x0[2], b[1] = x0[3], a[2] = x1[0], b[2] = x1[1], a[3] = x1[2], b[3] = x1[3];
+    }
+    float y0[4], y1[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      y0[e] = __fsub_rn(__fmul_rn(a[e], c[e]), __fmul_rn(b[e], sn[e]));
+      y1[e] = __fadd_rn(__fmul_rn(a[e], sn[e]), __fmul_rn(b[e], c[e]));
+    }
+    if (is_k) {
+      _Float16* d = kc + (long long)(n_past + i2) * c_sl + (long long)ih * c_head;
+      if (neox) {
+        *reinterpret_cast<qhalf4*>(d + ia) = qhalf4{(_Float16)y0[0], (_Float16)y0[1], (_Float16)y0[2], (_Float16)y0[3]};
+        *reinterpret_cast<qhalf4*>(d + ib) = qhalf4{(_Float16)y1[0], (_Float16)y1[1], (_Float16)y1[2], (_Float16)y1[3]};
+      } else {
+        *reinterpret_cast<qhalf8*>(d + ia) = qhalf8{(_Float16)y0[0], (_Float16)y1[0], (_Float16)y0[1], (_Float16)y1[1],
+                                                     (_Float16)y0[2], (_Float16)y1[2], (_Float16)y0[3], (_Float16)y1[3]};
+      }
+    } else {
+      float* d = q + row * head_size;
+      if (neox) {
+        *reinterpret_cast<qfloat4*>(d + ia) = qfloat4{y0[0], y0[1], y0[2], y0[3]};
+        *reinterpret_cast<qfloat4*>(d + ib) = qfloat4{y1[0], y1[1], y1[2], y1[3]};
+      } else {
+        *reinterpret_cast<qfloat4*>(d + ia) = qfloat4{y0[0], y1[0], y0[1], y1[1]};
+        *reinterpret_cast<qfloat4*>(d + ib) = qfloat4{y0[2], y1[2], y0[3], y1[3]};
+      }
+    }
+  } else if (gid < nq + nk + nv) {
+    const size_t g = gid - nq - nk;
+    const int e = int(g % (head_size / 8)) * 8;
+    const size_t row = g / (head_size / 8);
+    const int i2 = int(row / heads_kv), ih = int(row % heads_kv);
+    const float* x = v + row * head_size + e;
+    const qfloat4 x0 = *reinterpret_cast<const qfloat4*>(x), x1 = *reinterpret_cast<const qfloat4*>(x + 4);
+    *reinterpret_cast<qhalf8*>(vc + (long long)(n_past + i2) * c_sl + (long long)ih * c_head + e) =
+        qhalf8{(_Float16)x0[0], (_Float16)x0[1], (_Float16)x0[2], (_Float16)x0[3], (_Float16)x1[0], (_Float16)x1[1], (_Float16)x1[2], (_Float16)x1[3]};
+  }
+}
+
 hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void* kc, void* vc, int seq, int heads,
                                   int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base,
                                   float freq_scale, float attn_factor, long long c_sl, long long c_head, hipStream_t st) {
@@ -868,6 +957,22 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
   const size_t total = size_t(seq) * (heads + heads_kv) * npairs + size_t(seq) * heads_kv * head_size;
   if (total == 0) return hipSuccess;
   const float theta_scale = powf(freq_base, -2.0f / n_dims);
+  // prompt-sized calls: table + streaming kernel (16-byte accesses: every row, cache row and pair group aligned)
+  static const bool no_tab = getenv("NS_ROPE_NO_TABLE") != nullptr;  // diagnostics (A/B)
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!no_tab && seq >= 16 && head_size % 8 == 0 && npairs % 4 == 0 && (!neox || (n_dims / 2) % 4 == 0) && c_sl % 8 == 0 && c_head % 8 == 0 &&
+      al16(q) && al16(k) && al16(v) && al16(kc) && al16(vc)) {
+    float2* tab = static_cast<float2*>(stream_scratch(st, size_t(seq) * npairs * sizeof(float2), 23));
+    if (tab) {
+      const size_t nt = size_t(seq) * npairs;
+      hipLaunchKernelGGL(rope_table_kernel, grid1d(nt, 256), dim3(256), 0, st, seq, n_past, int(npairs), neox ? 1 : 0, theta_scale,
+                         freq_scale, attn_factor, tab);
+      const size_t items = size_t(seq) * (heads + heads_kv) * (npairs / 4) + size_t(seq) * heads_kv * (head_size / 8);
+      hipLaunchKernelGGL(rope_qkv_append_tab_kernel, grid1d(items, 256), dim3(256), 0, st, q, k, v, static_cast<_Float16*>(kc),
+                         static_cast<_Float16*>(vc), tab, seq, heads, heads_kv, head_size, n_past, n_dims, neox ? 1 : 0, c_sl, c_head);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(rope_qkv_append_kernel, grid1d(total, 256), dim3(256), 0, st, q, k, v, static_cast<_Float16*>(kc),
                      static_cast<_Float16*>(vc), seq, heads, heads_kv, head_size, n_past, n_dims, neox ? 1 : 0, theta_scale,
                      freq_scale, attn_factor, c_sl, c_head);

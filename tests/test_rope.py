@@ -92,6 +92,37 @@ def test_rope_qkv_append_equals_separate_ops(L, pkg, nso, mode):
     assert torch.all(kc[:n_past] == 9.0) and torch.all(vc[n_past + seq:] == 9.0)  # nothing else touched
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,hs,n_dims,fscale,attn", [(0, 128, 128, 1.0, 1.0), (2, 64, 64, 0.5, 1.25), (2, 128, 64, 1.0, 1.0), (0, 80, 80, 1.0, 1.0)])
+def test_rope_qkv_append_prompt_sized_form_equals_the_row_by_row_form(L, pkg, nso, mode, hs, n_dims, fscale, attn):
+    """from 16 rows on the call takes the table + streaming kernels (round 4); one row at a time it takes the per-pair kernel:
+    the same bits in q, the K cache and the V cache, GQA and a strided cache included; head size 80 (pairs not a multiple of 4
+    per 16 bytes of cache row) stays on the per-pair kernel and must agree with itself"""
+    import torch
+    seq, heads, hkv, n_past, ctx = 37, 8, 2, 11, 64
+    g = torch.Generator(device="cuda").manual_seed(hs + mode)
+    q = torch.randn((1, seq, heads, hs), generator=g, device="cuda")
+    k = torch.randn((1, seq, hkv, hs), generator=g, device="cuda")
+    v = torch.randn((1, seq, hkv, hs), generator=g, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pad = 8  # the cache rows carry 8 unused halves per head: strides differ from the dense ones
+    def run(rows_per_call):
+        qq = q.clone()
+        kc = torch.full((ctx, hkv, hs + pad), 9.0, dtype=torch.float16, device="cuda")
+        vc = torch.full((ctx, hkv, hs + pad), 9.0, dtype=torch.float16, device="cuda")
+        for r0 in range(0, seq, rows_per_call):
+            n = min(rows_per_call, seq - r0)
+            pkg.check(L.ns_hip_rope_qkv_append(qq[0, r0].data_ptr(), k[0, r0].data_ptr(), v[0, r0].data_ptr(), kc.data_ptr(), vc.data_ptr(), n,
+                                               heads, hkv, hs, n_past + r0, n_dims, mode, 10000.0, fscale, 0.0, attn, hkv * (hs + pad), hs + pad, st))
+        torch.cuda.synchronize()
+        return qq, kc, vc
+    a, b = run(seq), run(1)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.all(a[1][:, :, hs:] == 9.0) and torch.all(a[1][:n_past] == 9.0) and torch.all(a[2][n_past + seq:] == 9.0)
+    assert torch.equal(a[2][n_past:n_past + seq, :, :hs], v[0].half())
+
+
 # ---------------------------------------------------------------------------------------------- YaRN extrapolation mix
 def _yarn_closed_form(x, n_past, n_dims, mode, base, fscale, n_orig, ext, attn, bfast, bslow):
     """rope_yarn (ne_layers.c:9196-9217) in fp64, written independently of the oracle's loop structure"""
