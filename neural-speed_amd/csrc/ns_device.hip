@@ -124,6 +124,138 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(const float* q, const floa
   }
 }
 
+// The same attention with the context split over workgroups (round 4): one workgroup per (128-key range, head, query row) instead
+// of one per (head, query row) — at 2048 cached positions the single-workgroup form has 32 workgroups stream 2 MB of fp32 K / V
+// each.  Scores: a quarter-wave per key, the lane's DPL = head_size / 16 dims as 16-byte loads, all 8 keys of the quarter-wave
+// requested before the first is used; softmax over the range in LDS; P.V: a quarter-wave per head dim walks its 128 keys of the
+// TRANSPOSED V (8 consecutive per lane).  Partials (max, sum, unnormalised output) go to a per-stream workspace,
+// mha_f32_merge_kernel combines them (one launch more; a single range writes the output itself).
+constexpr int kMhaKS = 128;  // keys per workgroup
+typedef float dfloat4 __attribute__((ext_vector_type(4)));
+template <int DPL>
+__global__ __launch_bounds__(256) void mha_f32_split_kernel(const float* q, const float* k, const float* v, float* o, float* ws, int nsplit,
+                                                            int seq, int seq_all, int heads, int heads_kv, int n_ctx, float scale,
+                                                            int masked) {
+  constexpr int HS = 16 * DPL;
+  __shared__ float sc[kMhaKS];
+  __shared__ float red[4];
+  const int split = blockIdx.x, ih = blockIdx.y, bq = blockIdx.z, ib = bq / seq, iq = bq % seq;
+  const int hkv = ih / (heads / heads_kv);
+  const int t = threadIdx.x, sub = t & 15, grp = t >> 4, w = t >> 6;
+  const float* qp = q + (size_t(bq) * heads + ih) * HS + sub * DPL;
+  const float* kp = k + (size_t(ib) * heads_kv + hkv) * size_t(n_ctx) * HS;
+  const float* vp = v + (size_t(ib) * heads_kv + hkv) * size_t(HS) * n_ctx;
+  const int visible = masked ? min(seq_all, iq + (seq_all - seq) + 1) : seq_all;
+  const int j0 = split * kMhaKS, j1 = min(visible, j0 + kMhaKS);
+  float* wp = ws + ((size_t(bq) * heads + ih) * nsplit + split) * (2 + HS);
+  if (j0 >= j1) {  // a range past this row's causal extent
+    if (t == 0) wp[0] = -INFINITY, wp[1] = 0.f;
+    return;
+  }
+  dfloat4 qv[DPL / 4];
+#pragma unroll
+  for (int c = 0; c < DPL / 4; c++) qv[c] = *reinterpret_cast<const dfloat4*>(qp + 4 * c);
+  // ---- scores ----
+  dfloat4 kv[kMhaKS / 16][DPL / 4];
+#pragma unroll
+  for (int i = 0; i < kMhaKS / 16; i++) {
+    const int j = min(j0 + grp + 16 * i, j1 - 1);
+#pragma unroll
+    for (int c = 0; c < DPL / 4; c++) kv[i][c] = *reinterpret_cast<const dfloat4*>(kp + size_t(j) * HS + sub * DPL + 4 * c);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kMhaKS / 16; i++) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DPL / 4; c++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) s += qv[c][e] * kv[i][c][e];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s = j0 + grp + 16 * i < j1 ? s * scale : -INFINITY;
+    if (sub == 0) sc[grp + 16 * i] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((t & 63) == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));  // finite: j0 < j1
+  float pe = 0.f;
+  if (t < kMhaKS) {
+    pe = expf(sc[t] - mx);  // exp(-inf) = 0 past the range
+    sc[t] = pe;
+  }
+  float sum = pe;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) sum += __shfl_xor(sum, off, 64);
+  __syncthreads();  // red[] read by everybody, sc[] complete
+  if ((t & 63) == 0) red[w] = sum;
+  // ---- P . V over the transposed V: lane sub takes keys j0 + 8 sub .. + 7 of head dim grp + 16 i ----
+  const bool v16 = (n_ctx & 3) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+  float pv[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) pv[e] = sc[8 * sub + e];
+  const int jl = j0 + 8 * sub;
+  float part[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; i++) {
+    const float* vr = vp + size_t(grp + 16 * i) * n_ctx + jl;
+    float acc = 0.f;
+    if (v16 && jl + 8 <= j1) {
+      const dfloat4 a = *reinterpret_cast<const dfloat4*>(vr), b2 = *reinterpret_cast<const dfloat4*>(vr + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc += pv[e] * a[e] + pv[4 + e] * b2[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+        if (jl + e < j1) acc += pv[e] * vr[e];  // (cache cells past the range are not read: they may hold anything)
+    }
+    part[i] = acc;
+  }
+#pragma unroll
+  for (int i = 0; i < DPL; i++) {
+    float acc = part[i];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    part[i] = acc;
+  }
+  __syncthreads();
+  const float l = red[0] + red[1] + red[2] + red[3];
+  if (sub == 0) {
+    if (nsplit == 1) {
+      float* op = o + (size_t(bq) * heads + ih) * HS;
+#pragma unroll
+      for (int i = 0; i < DPL; i++) op[grp + 16 * i] = part[i] / l;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DPL; i++) wp[2 + grp + 16 * i] = part[i];
+      if (t == 0) wp[0] = mx, wp[1] = l;
+    }
+  }
+}
+// one workgroup of head_size threads per (query row, head): combine the ranges' (max, sum, output) in range order
+__global__ void mha_f32_merge_kernel(const float* ws, float* o, int nsplit, int hs) {
+  const size_t row = blockIdx.x;  // (batch * seq + iq) * heads + head
+  const int t = threadIdx.x;
+  const float* wp = ws + row * nsplit * (2 + hs);
+  float mb = -INFINITY;
+  for (int s2 = 0; s2 < nsplit; s2++) mb = fmaxf(mb, wp[size_t(s2) * (2 + hs)]);
+  float lb = 0.f, ab = 0.f;
+  for (int s2 = 0; s2 < nsplit; s2++) {
+    const float ms = wp[size_t(s2) * (2 + hs)];
+    const float c = ms != -INFINITY ? expf(ms - mb) : 0.f;
+    lb += wp[size_t(s2) * (2 + hs) + 1] * c;
+    if (ms != -INFINITY) ab += wp[size_t(s2) * (2 + hs) + 2 + t] * c;  // (an empty range wrote no output columns)
+  }
+  o[row * hs + t] = ab / lb;
+}
+
 // what bestla_device_load_storage leaves in the tensor object behind a device-resident BTLA weight
 // (ne_layers.c:946-949 reserves bestla_device_storage_size() bytes there).  It starts with a word no BTLA blob can start
 // with (a blob's first field is its size, bestla_storage.h:250-317): the host-pointer entry points (_support, forward)
@@ -362,6 +494,30 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
       n_ctx < seq_all) {
     ns::set_error("mha_f32: invalid argument");
     return -1;
+  }
+  // ---- the context split over workgroups: head sizes 64 / 128 / 256, from two 128-key ranges on ----
+  static const bool no_split = getenv("NS_MHA_NO_SPLIT") != nullptr;  // diagnostics (A/B)
+  const int nsplit = (seq_all + ns::kMhaKS - 1) / ns::kMhaKS;
+  const size_t rows = size_t(batch) * seq * heads;
+  if (!no_split && nsplit >= 2 && (head_size == 64 || head_size == 128 || head_size == 256) && size_t(batch) * seq <= 65535 && heads <= 65535 &&
+      (reinterpret_cast<uintptr_t>(dQ) & 15) == 0 && (reinterpret_cast<uintptr_t>(dK) & 15) == 0) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* ws = static_cast<float*>(ns::stream_scratch(st, rows * nsplit * (2 + head_size) * sizeof(float), 24));
+    if (ws) {
+      const dim3 grid(unsigned(nsplit), unsigned(heads), unsigned(batch * seq));
+      if (head_size == 64)
+        hipLaunchKernelGGL(ns::mha_f32_split_kernel<4>, grid, dim3(256), 0, st, dQ, dK, dV, dO, ws, nsplit, seq, seq_all, heads, heads_kv, n_ctx, scale, masked);
+      else if (head_size == 128)
+        hipLaunchKernelGGL(ns::mha_f32_split_kernel<8>, grid, dim3(256), 0, st, dQ, dK, dV, dO, ws, nsplit, seq, seq_all, heads, heads_kv, n_ctx, scale, masked);
+      else
+        hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, dQ, dK, dV, dO, ws, nsplit, seq, seq_all, heads, heads_kv, n_ctx, scale, masked);
+      hipLaunchKernelGGL(ns::mha_f32_merge_kernel, dim3(unsigned(rows)), dim3(unsigned(head_size)), 0, st, ws, dO, nsplit, head_size);
+      if (hipGetLastError() != hipSuccess) {
+        ns::set_error("mha_f32: launch failed");
+        return -1;
+      }
+      return 0;
+    }
   }
   const size_t lds = (size_t((seq_all + 3) & ~3) + 256) * sizeof(float);
   if (lds > 160 * 1024) {
