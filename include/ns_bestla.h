@@ -214,6 +214,11 @@ int ns_hip_get_compute_mode(void);
  *   "i8_tile"         workgroup tile of that kernel: 0 = by problem size (default), 1 = 64 x 64 (four waves), 4 = 64 x 256
  *                     (sixteen waves; what large problems take); other values = default
  *   "attn_wg_target", "attn_min_keys"   context-split rule of the decode attention kernel (defaults 1024, 128)
+ *   "planes_load"     1 = weights of the 1-3 / 5 / 6 bit formats loaded FROM NOW ON also get a second device copy whose code records
+ *                     have the format's own width (bit planes back to back, 256 .. 768 bytes per k-step instead of the 1 KiB nibble /
+ *                     byte record every other kernel reads); 0 (default; NS_PLANES=1 in the environment flips it) = no such copy
+ *   "planes"          1 (default) = the decode kernel streams that copy where a weight has one, 0 = always the widened records;
+ *                     bit-identical results (measured: 0.89-1.07 x, DESIGN.md section 4.2c - hence off at load by default)
  *   "attn_mfma2_rows" query rows from which a prefill takes the 128-row matrix-core attention kernel (0 = default 128; a value
  *                     above every sl_q keeps the 64-row kernel of rounds 1-3)
  *   "attn_inlaunch"   0 (default) = attn_merge_kernel combines the context splits in a second launch, 1 = the split that finishes

@@ -164,16 +164,17 @@ void set_strides(ns_weight* w, int force_interleave = -1) {
   const uint32_t cb = 16u * w->sps * sbytes, zb = w->asym ? 16u * w->sps : 0u;
   static const bool no_il = getenv("NS_NO_INTERLEAVE") != nullptr;  // diagnostics
   w->interleaved = force_interleave >= 0 ? force_interleave != 0 : (w->srows == w->ksteps) && !no_il;
+  const uint32_t rec = w->code_rec;  // 1024, or the bit planes' own bytes in a native clone
   if (w->interleaved) {
-    w->qstride = w->sstride = w->zstride = 1024u + cb + zb;
+    w->qstride = w->sstride = w->zstride = rec + cb + zb;
     w->codes_bytes = size_t(w->ntiles) * w->ksteps * w->qstride;
-    w->scales_bytes = w->codes_bytes - 1024;
-    w->zps_bytes = w->asym ? w->codes_bytes - 1024 - cb : 0;
+    w->scales_bytes = w->codes_bytes - rec;
+    w->zps_bytes = w->asym ? w->codes_bytes - rec - cb : 0;
   } else {
-    w->qstride = 1024;
+    w->qstride = rec;
     w->sstride = cb;
     w->zstride = 16u * w->sps;
-    w->codes_bytes = size_t(w->ntiles) * w->ksteps * 1024;
+    w->codes_bytes = size_t(w->ntiles) * w->ksteps * rec;
     w->scales_bytes = size_t(w->ntiles) * w->srows * cb;
     w->zps_bytes = w->asym ? size_t(w->ntiles) * w->srows * 16 * w->sps : 0;
   }
@@ -254,8 +255,8 @@ bool alloc_weight(ns_weight* w, void* ext = nullptr, size_t ext_bytes = 0) {
   size_t s_off, z_off, total;
   if (w->interleaved) {  // scales / zps live inside the record stream
     const size_t cb = size_t(16) * w->sps * (dt_bits(w->scale_dt) / 8);
-    s_off = 1024;
-    z_off = w->asym ? 1024 + cb : 0;
+    s_off = w->code_rec;
+    z_off = w->asym ? w->code_rec + cb : 0;
     total = pad(w->codes_bytes);
   } else {
     s_off = pad(w->codes_bytes);
@@ -278,6 +279,52 @@ bool alloc_weight(ns_weight* w, void* ext = nullptr, size_t ext_bytes = 0) {
   w->alloc_bytes = total;
   hipGetDevice(&w->device);
   return true;
+}
+
+// bytes of one k-step's bit planes for the 16 columns of a tile (the decode kernel's native records): nibble-order formats span
+// 128 k (2-bit plane 512 B, 1-bit plane 256 B), byte-order formats 64 k (4-bit plane 512 B + one more plane of 256 B)
+uint32_t plane_record_bytes(int bits) {
+  switch (bits) {
+    case 1: return 256;
+    case 2: return 512;
+    case 3: return 768;
+    case 5: return 768;
+    case 6: return 768;
+    default: return 0;  // 4, 8: the container is the format; 7: no shorter form (ns_kernels.hip repack_planes_kernel)
+  }
+}
+// S1..S3 / S5..S7: build the native clone (ns_common.h ns_weight::native) from the same reference sections, on the same stream.
+// Failure to allocate is not an error: the weight then streams its widened records at decode too.
+// Off by default (ns_hip_set_tuning("planes_load", 1) / NS_PLANES=1 before the weights are loaded): measured on this chip the
+// decode kernel is bound by its per-record and per-launch costs, not by bytes — native records run 0.89-0.98 x (1-3 bit) and
+// 1.00-1.07 x (5, 6 bit) the widened ones on the 7B FFN shapes (profiles/r04aq_planes_native_vs_widened.txt) — and the clone
+// is a second copy of the weight in HBM.
+static std::atomic<int> g_planes_load{-1};
+void set_planes_load(int on) { g_planes_load.store(on != 0); }
+void add_native_planes(const RepackArgs& ra, ns_weight* w, hipStream_t st) {
+  int on = g_planes_load.load();
+  if (on < 0) {
+    const char* e = getenv("NS_PLANES");
+    on = e ? atoi(e) != 0 : 0;
+    g_planes_load.store(on);
+  }
+  const int bits = dt_bits(w->qtype);
+  if (!on || (w->kind != WK_INT4 && w->kind != WK_INT8) || !plane_record_bytes(bits) || w->native) return;
+  ns_weight* c = new ns_weight(*w);
+  c->native = nullptr, c->shuf = nullptr, c->external = false, c->load_pending = false;
+  c->codes = nullptr, c->scales = nullptr, c->zps = nullptr;
+  c->pl_bits = uint8_t(bits);
+  c->code_rec = plane_record_bytes(bits);
+  set_strides(c, w->interleaved ? 1 : 0);
+  RepackArgs rc = ra;
+  rc.flags = nullptr;
+  if (!alloc_weight(c) || launch_repack(rc, c, st) != hipSuccess) {
+    (void)hipGetLastError();
+    ns_hip_reset_error();
+    ns_hip_weight_free(c);
+    return;
+  }
+  w->native = c;
 }
 
 template <typename T>
@@ -334,7 +381,7 @@ ns_weight* weight_from_device_sections(const BlobView& v, const uint8_t* dq, con
   bool ok = dinfo.alloc(2) && hip_ok(hipMemsetAsync(dinfo.p, 0, 8, st), "memset");
   if (ok) {
     ra.flags = dinfo.p + 1;
-    ok = hip_ok(launch_repack(ra, w, st), "repack") &&
+    ok = hip_ok(launch_repack(ra, w, st), "repack") && (add_native_planes(ra, w, st), true) &&
          hip_ok(launch_scale_absmax(ds, v.s_bytes / (dt_bits(v.scale_dt) / 8), v.scale_dt, dinfo.p, st), "scale range") &&
          hip_ok(hipMemcpyAsync(info, dinfo.p, 8, hipMemcpyDeviceToHost, st), "load info D2H") &&
          hip_ok(hipStreamSynchronize(st), "sync after repack");
@@ -738,7 +785,7 @@ ns_weight* ns_hip_weight_load_async(const void* host_blob, void* dst, uint64_t d
   uint32_t* dinfo = g_staging.info + 2 * (g_staging.next++ % kInfoRing);
   ra.flags = dinfo + 1;
   bool ok = hip_ok(hipMemsetAsync(dinfo, 0, 8, st), "memset") && hip_ok(launch_repack(ra, w, st), "repack") &&
-            hip_ok(launch_scale_absmax(ds, v.s_bytes / (dt_bits(v.scale_dt) / 8), v.scale_dt, dinfo, st), "scale range") &&
+            (add_native_planes(ra, w, st), true) && hip_ok(launch_scale_absmax(ds, v.s_bytes / (dt_bits(v.scale_dt) / 8), v.scale_dt, dinfo, st), "scale range") &&
             hip_ok(hipMemcpyAsync(pinned_info, dinfo, 8, hipMemcpyDeviceToHost, st), "load info D2H");
   if (ok && v.shuf_bytes)
     ok = hip_ok(hipMalloc((void**)&w->shuf, v.shuf_bytes), "hipMalloc(shuffle)") &&
@@ -828,6 +875,7 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
   o->scales = nullptr;
   o->zps = nullptr;
   o->shuf = nullptr;
+  o->native = nullptr;  // a slice of a bit-plane weight streams its widened records (no native clone)
   o->n = n1 - n0;
   o->k = k1 - k0;
   o->ntiles = (o->n + 15) / 16;
@@ -890,6 +938,7 @@ void ns_hip_weight_free(ns_weight* w) {
   if (!w) return;
   if (w->codes && !w->external) hipFree(w->codes);  // scales / zps / workspace live in the same allocation
   if (w->shuf) hipFree(w->shuf);
+  if (w->native) ns_hip_weight_free(w->native);
   delete w;
 }
 
@@ -955,6 +1004,14 @@ int ns_hip_set_tuning(const char* key, int value) {
   }
   if (key && !strcmp(key, "attn_min_keys")) {
     set_attn_tuning(0, value);
+    return 0;
+  }
+  if (key && !strcmp(key, "planes")) {
+    set_gemv_planes(value);
+    return 0;
+  }
+  if (key && !strcmp(key, "planes_load")) {
+    set_planes_load(value);
     return 0;
   }
   if (key && !strcmp(key, "attn_mfma2_rows")) {

@@ -98,6 +98,14 @@ struct ns_weight {
   // DRAM page as its codes.
   uint32_t qstride = 1024, sstride = 0, zstride = 0;
   bool interleaved = false;
+  // Bit-plane formats (S1..S3, S5..S7).  The arrays above hold them WIDENED to nibbles / bytes — what the multi-row, prefill,
+  // unpack and slicing code reads.  `native` (round 4) is the same weight a second time with code records of the format's own
+  // width (code_rec = 256 .. 896 bytes per (tile, k-step) instead of 1024: the planes of the k-step back to back, laid out for
+  // the decode kernel's in-register assembly, ns_kernels.hip repack_planes_kernel), scales / zero points repeated behind them:
+  // what gemv_kernel streams, so a decode step reads the format's bits and not the container's.  Owned by this weight.
+  uint32_t code_rec = 1024;  // bytes of codes per record of THIS layout
+  uint8_t pl_bits = 0;       // != 0: this layout is a native clone of that bit width
+  ns_weight* native = nullptr;
   // codes, scales and zps are ONE allocation: scales = codes + s_off, zps = codes + z_off
   uint32_t s_off = 0, z_off = 0;
   size_t alloc_bytes = 0;
@@ -185,6 +193,7 @@ void set_gemv_mode(int mode);  // 0 off (first-generation kernel), 1 on, -1 re-r
 hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st);
 void set_gemvs_tuning(int what, int value);  // what: 0 mode (0 off, 1 from 2 rows, 2 from 1 row), 1 slices, 2 waves, 3 workgroups
 void set_attn_tuning(int wg_target, int min_keys);
+void set_gemv_planes(int on);  // 1 (default): bit-plane formats stream their native records at decode (ns_weight::native); 0: the widened ones
 void set_attn_mfma2_rows(int rows);  // query rows from which the 128-row prefill attention kernel is used (default 128; huge = never)
 void set_attn_inlaunch(int on);  // 1 (default): the last context split merges inside attn_split_kernel's launch; 0: attn_merge_kernel
 // NS_HOST_PROFILE=1: wall time and call count of every host-tensor entry, printed at exit (diagnostics of the default,

@@ -67,6 +67,15 @@ __device__ __forceinline__ half8_t cvt_i8x8(uint32_t x0, uint32_t x1, half2_t of
   uint4v r = {as_u32(h0), as_u32(h1), as_u32(h2), as_u32(h3)};
   return __builtin_bit_cast(half8_t, r);
 }
+// the same for UNSIGNED bytes (native bit-plane records hold the stored codes): splice under 0x64, subtract 1024 + bias + zp
+__device__ __forceinline__ half8_t cvt_u8x8(uint32_t a, uint32_t b, half2_t off) {
+  half2_t h0 = as_half2(__builtin_amdgcn_perm(0x64646464u, a, 0x04010400u)) + off;
+  half2_t h1 = as_half2(__builtin_amdgcn_perm(0x64646464u, a, 0x04030402u)) + off;
+  half2_t h2 = as_half2(__builtin_amdgcn_perm(0x64646464u, b, 0x04010400u)) + off;
+  half2_t h3 = as_half2(__builtin_amdgcn_perm(0x64646464u, b, 0x04030402u)) + off;
+  uint4v r = {as_u32(h0), as_u32(h1), as_u32(h2), as_u32(h3)};
+  return __builtin_bit_cast(half8_t, r);
+}
 // 8 fp8 codes (two dwords) -> 8 fp16, exact.  The reference's fp8 has no zero, subnormals, inf or nan (f8_to_fp32,
 // kernel_ref.h:984-1002): value = +-2^(e - bias) * (1 + m / 2^mbits) for every code.  With the byte in the high half
 // of a 16-bit lane (u = code << 8, sign already in place):

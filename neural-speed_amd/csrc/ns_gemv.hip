@@ -109,6 +109,9 @@ struct GemvParams {
   const MoeExpertRow* moe_table;
   const int32_t* moe_id;
   int moe_n;
+  // native bit-plane records (PL = true: ns_weight::native): the format's bit width and the lanes of a record request
+  // (record bytes / 16; the record's planes are contiguous, so a k-step is still ONE request)
+  uint32_t pl_bits, pl_lanes;
   // ---- cold: read late, through the kernel-argument pointer (keeps them out of the streaming loop's SGPRs) ----
   GemvMat mat[3];
   float* c2;
@@ -177,9 +180,14 @@ constexpr int kGvA32Regs = 8;  // 16-byte loads of fp32 activations a wave holds
 // bit-exact), a lane (column nn, k-slot g) takes exact integer dots of its eight codes per 32-deep slice with v_dot4 on the
 // stored codes,  sum (a - za)(q - zb) = sum a u - (zb + bias) sum a - za sum u + 8 za (zb + bias)  (u = q + bias), and adds
 // float(sum) * (scale_a * scale_b) per slice; up to four rows.  Reduction, epilogues, fused QKV / gate-up modes are shared.
-template <int KIND, int SPS, int SK, bool ASYM, int MODE, int XV>
+// PL (round 4): the codes arrive as the NATIVE bit planes of a 1-3 / 5-7 bit format (ns_weight::native, repack_planes_kernel) —
+// 256 .. 896 bytes per k-step instead of the 1 KiB nibble / byte container — and each lane rebuilds its container words from its
+// plane words with shifts and masks (stored codes, bias 2^(bits-1) folded into the conversion constants: the same fp16 values,
+// hence the same bits out, as from the widened records).  KIND says which container: WK_INT4 for 1-3 bits, WK_INT8 for 5-7.
+template <int KIND, int SPS, int SK, bool ASYM, int MODE, int XV, bool PL = false>
 __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   constexpr bool EXT = XV == 1, MOE = XV == 4, A32 = XV == 2 || MOE, I8S = XV == 3;
+  static_assert(!PL || ((KIND == WK_INT4 || KIND == WK_INT8) && !I8S && !MOE), "native planes: integer formats, fp16 numerics");
   static_assert(!I8S || KIND == WK_INT4 || KIND == WK_INT8, "integer weights only");
   constexpr uint32_t AEL = I8S ? 1u : 2u;  // bytes per staged activation element
   constexpr bool DUAL = MODE == GV_DUAL, MSEG = MODE == GV_MSEG;
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
       asm volatile("" ::"s"(p.tb1), "s"(p.tb2), "s"(p.mat[0].wbase), "s"(p.mat[1].wbase), "s"(p.mat[2].wbase), "s"(p.mat[0].s_off),
                    "s"(p.mat[1].s_off), "s"(p.mat[2].s_off));
     if constexpr (ASYM) asm volatile("" ::"s"(p.z_off0), "s"(p.z_off1), "s"(p.zstride));
+    if constexpr (PL) asm volatile("" ::"s"(p.pl_bits), "s"(p.pl_lanes));
   }
   const int tid = threadIdx.x;
   const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,8 +285,9 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc cannot type-check this builtin and would drop the kernel stub)
     const uint32_t crow = tile_c + ((s * p.srow_mul) >> p.srow_shift);
     const LdsPtr dst = ring + slot * SLOT;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, voff_q,
-                                             tile_q + s * p.qstride, 0, 2);
+    if (!PL || uint32_t(l) < p.pl_lanes)  // (a native record is shorter than 64 x 16 bytes)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, voff_q,
+                                               tile_q + s * p.qstride, 0, 2);
     if (l < SBYTES)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw[q], reinterpret_cast<__attribute__((address_space(3))) void*>(dst + 1024), 16,
                                                voff_q, so[q] + crow * p.sstride, 0, 2);
@@ -453,6 +463,10 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   auto compute = [&](auto slot_c, uint32_t s) {
     constexpr int slot = decltype(slot_c)::value;
     constexpr int q = slot % NQ;
+#if defined(NS_GV_ABL) && NS_GV_ABL == 1  // timing ablation (diagnostic builds): the stream alone, no record is decoded or multiplied
+    (void)s;
+    return;
+#endif
     if constexpr (I8S) {
       Corr cr;
       {
@@ -565,17 +579,61 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
     }
     float sc[4], zp[4];
     corr_decode<SPS, SK, ASYM, NJ>(cr, sc, zp);
-    const uint4v qvv = *reinterpret_cast<const __attribute__((address_space(3))) uint4v*>(ring_lane + uint32_t(slot) * SLOT);
-    const uint32_t xw[4] = {qvv.x, qvv.y, qvv.z, qvv.w};
+    uint32_t xw[4];
+    if constexpr (!PL) {
+      const uint4v qvv = *reinterpret_cast<const __attribute__((address_space(3))) uint4v*>(ring_lane + uint32_t(slot) * SLOT);
+      xw[0] = qvv.x, xw[1] = qvv.y, xw[2] = qvv.z, xw[3] = qvv.w;
+    } else {
+      // the lane's plane words out of the slot (layouts: repack_planes_kernel), assembled into the container words
+      typedef const __attribute__((address_space(3))) uint32_t* L32;
+      typedef const __attribute__((address_space(3))) uint16_t* L16;
+      typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+      const uint32_t rec = uint32_t(reinterpret_cast<uintptr_t>(ring)) + uint32_t(slot) * SLOT;
+      const uint32_t bits = p.pl_bits;  // wave-uniform
+      if constexpr (KIND == WK_INT4) {
+        uint32_t a0 = 0, a1 = 0, cw = 0;
+        if (bits >= 2) {
+          const uint2v av = *reinterpret_cast<const __attribute__((address_space(3))) uint2v*>(rec + 8u * uint32_t(l));
+          a0 = av.x, a1 = av.y;
+        }
+        if (bits != 2) cw = *reinterpret_cast<L32>(rec + (bits == 3 ? 512u : 0u) + 4u * uint32_t(l));
+        // the 1-bit plane's bit goes to nibble bit 0 (S1) or 2 (S3): one shift + one and-or per word
+        const uint32_t cm = bits == 3 ? 0x44444444u : 0x11111111u;
+        const uint32_t c0 = bits == 3 ? cw << 2 : cw, c1 = bits == 3 ? cw << 1 : cw >> 1, c2 = bits == 3 ? cw : cw >> 2,
+                       c3 = bits == 3 ? cw >> 1 : cw >> 3;
+        xw[0] = and_or(c0, cm, a0 & 0x33333333u);
+        xw[1] = and_or(c1, cm, (a0 >> 2) & 0x33333333u);
+        xw[2] = and_or(c2, cm, a1 & 0x33333333u);
+        xw[3] = and_or(c3, cm, (a1 >> 2) & 0x33333333u);
+      } else {
+        const uint2v nv = *reinterpret_cast<const __attribute__((address_space(3))) uint2v*>(rec + 8u * uint32_t(l));
+        const uint32_t pw = *reinterpret_cast<L32>(rec + 512u + 4u * uint32_t(l));
+        // S5: bit 4 of byte b of word d sits at bit 8 b + d of the plane word; S6: bits 4..5 at 8 b + 2 d
+        const uint32_t pm = bits == 5 ? 0x10101010u : 0x30303030u;
+        const uint32_t st = bits == 5 ? 1u : 2u;
+        xw[0] = and_or(pw << 4, pm, nv.x & 0x0f0f0f0fu);
+        xw[1] = and_or(pw << (4u - st), pm, (nv.x >> 4) & 0x0f0f0f0fu);
+        xw[2] = and_or(pw << (4u - 2u * st), pm, nv.y & 0x0f0f0f0fu);
+        xw[3] = and_or(bits == 5 ? pw << 1 : pw >> 2, pm, (nv.y >> 4) & 0x0f0f0f0fu);
+      }
+    }
     half8_t bq[NJ];
+    float full = 0.f;  // PL: the codes are the stored ones (q + 2^(bits-1)); widened records were re-biased at load
+    if constexpr (PL) full = float(1u << (p.pl_bits - 1u));
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
       if constexpr (KIND == WK_INT4) {
-        const _Float16 zl = (_Float16)(-1032.f - zp[j]), zh = (_Float16)(-72.f - zp[j]);
+        const _Float16 zl = PL ? (_Float16)(-1024.f - full - zp[j]) : (_Float16)(-1032.f - zp[j]);
+        const _Float16 zh = PL ? (_Float16)(-64.f - full - zp[j]) : (_Float16)(-72.f - zp[j]);
         bq[j] = cvt_i4x8(xw[j], i4c, half2_t{zl, zl}, half2_t{zh, zh});
       } else if constexpr (KIND == WK_INT8) {
-        const _Float16 zo8 = (_Float16)(-1152.f - zp[j]);
-        bq[j] = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo8, zo8});
+        if constexpr (PL) {
+          const _Float16 zo8 = (_Float16)(-1024.f - full - zp[j]);
+          bq[j] = cvt_u8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo8, zo8});
+        } else {
+          const _Float16 zo8 = (_Float16)(-1152.f - zp[j]);
+          bq[j] = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo8, zo8});
+        }
       } else if constexpr (KIND == WK_F8) {
         bq[j] = cvt_f8x8(xw[2 * j], xw[2 * j + 1], p.f8);
       } else {
@@ -781,8 +839,42 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
 constexpr int kGvModeA32 = 0x100;  // or-ed into the launch mode: fp32 activations (XV = 2)
 constexpr int kGvModeI8 = 0x200;   // int8-reference numerics (XV = 3)
 constexpr int kGvModeMoe = 0x400;  // expert picked on the device (XV = 4; fp32 activations)
+constexpr int kGvModePlanes = 0x800;  // native bit-plane records (PL = true)
+template <int KIND, int SPS, int SK, bool ASYM>
+static hipError_t launch_gemv_planes(const GemvParams& p, int mode, int grid, int nw, size_t lds, hipStream_t st) {
+  if constexpr ((KIND == WK_INT4 || KIND == WK_INT8) && SK != SK_F16) {
+    const dim3 g(grid), b(nw * 64);
+    const bool ext = p.in_ssq || p.out_gamma || p.out_ssq || p.rope.on;
+    const bool a32 = (mode & kGvModeA32) != 0;
+    mode &= 3;
+#define NS_GVP(MODEV, EXTV)                                                                                                  \
+  {                                                                                                                         \
+    auto k = gemv_kernel<KIND, SPS, SK, ASYM, MODEV, EXTV, true>;                                                            \
+    static const hipError_t attr =                                                                                          \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kGvMaxLds));   \
+    if (attr != hipSuccess && lds > 64 * 1024) return attr;                                                                 \
+    hipLaunchKernelGGL(k, g, b, lds, st, p);                                                                                \
+  }
+#define NS_GVP_M(MODEV)                                                              \
+  {                                                                                 \
+    if (ext) NS_GVP(MODEV, 1) else if (a32) NS_GVP(MODEV, 2) else NS_GVP(MODEV, 0)   \
+  }
+    if (mode == GV_DUAL)
+      NS_GVP_M(GV_DUAL)
+    else if (mode == GV_MSEG)
+      NS_GVP_M(GV_MSEG)
+    else
+      NS_GVP_M(GV_PLAIN)
+#undef NS_GVP_M
+#undef NS_GVP
+    return hipGetLastError();
+  } else {
+    return hipErrorNotSupported;
+  }
+}
 template <int KIND, int SPS, int SK, bool ASYM>
 static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw, size_t lds, hipStream_t st) {
+  if (mode & kGvModePlanes) return launch_gemv_planes<KIND, SPS, SK, ASYM>(p, mode & ~kGvModePlanes, grid, nw, lds, st);
   const dim3 g(grid), b(nw * 64);
   const bool ext = p.in_ssq || p.out_gamma || p.out_ssq || p.rope.on;
   const bool a32 = (mode & kGvModeA32) != 0;  // never together with ext (launch_gemv)
@@ -890,10 +982,27 @@ int decode_waves(int grid, int ks, bool dual) {
 }
 
 // hipErrorNotSupported: outside the kernel's envelope — the caller falls back to smallm_kernel
+static std::atomic<int> g_gemv_planes{-1};  // ns_hip_set_tuning("planes"): 1 (default) = bit-plane formats stream their native records
+void set_gemv_planes(int on) { g_gemv_planes.store(on != 0); }
+static bool gemv_planes() {
+  int v = g_gemv_planes.load();
+  if (v < 0) {
+    const char* e = getenv("NS_GEMV_PLANES");
+    v = e ? atoi(e) != 0 : 1;
+    g_gemv_planes.store(v);
+  }
+  return v != 0;
+}
+
 hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
-  const ns_weight* w0 = a.seg[0].w;
   if (gemv_mode() == 0 || a.m < 1 || a.m > kGvMaxRows) return hipErrorNotSupported;
   const int nmat = a.nseg;  // matrices the launch touches (dual: 2)
+  // bit-plane formats: every matrix of the launch has its native clone (same shapes and scales, shorter code records) -> stream those
+  bool planes = gemv_planes() && !a.i8 && !a.moe;
+  for (int i = 0; i < nmat; i++)
+    planes = planes && a.seg[i].w->native && a.seg[i].w->native->scale_dt != DT_F16 && a.seg[i].w->native->pl_bits == a.seg[0].w->native->pl_bits;
+  auto pick = [&](const ns_weight* w) { return planes ? static_cast<const ns_weight*>(w->native) : w; };
+  const ns_weight* w0 = pick(a.seg[0].w);
   GemvParams p;
   memset(&p, 0, sizeof(p));
   uint32_t tiles = 0;
@@ -901,7 +1010,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   const uint8_t* wb[3] = {nullptr, nullptr, nullptr};
   uint32_t soff[3] = {0, 0, 0}, zoff[3] = {0, 0, 0};
   for (int i = 0; i < nmat; i++) {
-    const ns_weight* w = a.seg[i].w;
+    const ns_weight* w = pick(a.seg[i].w);
     if (!w->single_span || w->alloc_bytes >= (size_t(1) << 31)) return hipErrorNotSupported;
     wb[i] = reinterpret_cast<const uint8_t*>(w->codes);
     soff[i] = uint32_t(reinterpret_cast<const uint8_t*>(w->scales) - wb[i]);
@@ -1045,7 +1154,9 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
     p.moe_id = a.moe->id;
     p.moe_n = a.moe->n_as;
   }
-  const int mode_x = mode | (a32 && !moe ? kGvModeA32 : 0) | (i8s ? kGvModeI8 : 0) | (moe ? kGvModeMoe : 0);
+  p.pl_bits = planes ? uint32_t(w0->pl_bits) : 0u;
+  p.pl_lanes = planes ? w0->code_rec / 16u : 64u;
+  const int mode_x = mode | (a32 && !moe ? kGvModeA32 : 0) | (i8s ? kGvModeI8 : 0) | (moe ? kGvModeMoe : 0) | (planes ? kGvModePlanes : 0);
 
 #define NS_DISPATCH(KIND)                                                                       \
   switch (w0->sps) {                                                                            \

@@ -102,6 +102,63 @@ __global__ void repack_codes_kernel(const uint8_t* __restrict__ img, uint8_t* __
   *reinterpret_cast<uint32_t*>(out + ts * qstride + size_t(lane) * 16 + d * 4) = word;
 }
 
+// Native bit-plane records (ns_common.h ns_weight::native; decode kernel: gemv_kernel<..., PL = true>).  One record = the planes of
+// one k-step of a 16-column tile, back to back, every plane indexed by lane l = (column nn = l & 15, k-slot c = l >> 4) and laid
+// out so that the kernel rebuilds its nibble / byte container words with shifts and masks only.  Codes are the reference's STORED
+// codes (q + 2^(bits-1)); columns and k past the matrix hold the code of zero.
+//   nibble order (S1..S3; 128 k per k-step; the lane's 32 codes = words j = 0..3 x nibbles i = 0..7, k = 128 s + 32 j + 8 c + i):
+//     2-bit plane, 8 B per lane at 8 l: word j >> 1 holds bits 0..1 of code (j, i) at bit nib_shift(i) + 2 (j & 1)
+//     1-bit plane, 4 B per lane (at 512 + 4 l behind a 2-bit plane, else at 4 l): top bit of code (j, i) at bit nib_shift(i) + j
+//   byte order (S5..S7; 64 k per k-step; the lane's 16 codes = words d = 0..3 x bytes b = 0..3, k = 64 s + 32 (d >> 1) + 8 c + 4 (d & 1) + b):
+//     4-bit plane, 8 B per lane at 8 l: word d >> 1 holds bits 0..3 of code (d, b) at bit 8 b + 4 (d & 1)
+//     2-bit plane (S6), 4 B per lane at 512 + 4 l: bits 4..5 of code (d, b) at bit 8 b + 2 d
+//     1-bit plane (S5), 4 B per lane at 512 + 4 l: bit 4 of code (d, b) at bit 8 b + d
+//   (S7 has no native form: 4 + 2 + 1 bit planes in whole words per lane are as long as the byte record)
+__global__ void repack_planes_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ out, uint32_t qstride, int n, int k,
+                                     int ntiles, int ksteps, int bits, int ref_ntile, int ref_packrow, int ref_kpad, int ref_npad) {
+  // one thread per (record, lane)
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t total = size_t(ntiles) * ksteps * 64;
+  if (gid >= total) return;
+  const int lane = int(gid & 63);
+  const size_t ts = gid >> 6;
+  const int s = int(ts % ksteps), t = int(ts / ksteps);
+  const int nn = lane & 15, c = lane >> 4;
+  const int col = t * 16 + nn;
+  const size_t elts = size_t(ref_npad) * ref_kpad;
+  const int full = 1 << (bits - 1);
+  uint8_t* rec = out + ts * qstride;
+  auto code = [&](int kk) {
+    return (kk < k && col < n) ? ref_stored_code(img, ref_tiled_index(kk, col, ref_ntile, ref_packrow, ref_kpad), elts, bits) : full;
+  };
+  if (bits <= 3) {
+    uint32_t a[2] = {0, 0}, cw = 0;
+    for (int j = 0; j < 4; j++)
+      for (int i = 0; i < 8; i++) {
+        const uint32_t u = uint32_t(code(s * 128 + 32 * j + 8 * c + i));
+        if (bits >= 2) a[j >> 1] |= (u & 3u) << (nib_shift(i) + 2 * (j & 1));
+        if (bits != 2) cw |= ((u >> (bits - 1)) & 1u) << (nib_shift(i) + j);
+      }
+    if (bits >= 2) {
+      reinterpret_cast<uint32_t*>(rec + 8 * lane)[0] = a[0];
+      reinterpret_cast<uint32_t*>(rec + 8 * lane)[1] = a[1];
+    }
+    if (bits != 2) *reinterpret_cast<uint32_t*>(rec + (bits == 3 ? 512 : 0) + 4 * lane) = cw;
+  } else {
+    uint32_t nw[2] = {0, 0}, pw = 0, hw = 0;
+    for (int d = 0; d < 4; d++)
+      for (int b = 0; b < 4; b++) {
+        const uint32_t u = uint32_t(code(s * 64 + 32 * (d >> 1) + 8 * c + 4 * (d & 1) + b));
+        nw[d >> 1] |= (u & 15u) << (8 * b + 4 * (d & 1));
+        if (bits == 6) pw |= ((u >> 4) & 3u) << (8 * b + 2 * d);
+        if (bits == 5) hw |= ((u >> 4) & 1u) << (8 * b + d);
+      }
+    reinterpret_cast<uint32_t*>(rec + 8 * lane)[0] = nw[0];
+    reinterpret_cast<uint32_t*>(rec + 8 * lane)[1] = nw[1];
+    *reinterpret_cast<uint32_t*>(rec + 512 + 4 * lane) = bits == 6 ? pw : hw;
+  }
+}
+
 // scales / zero points: reference [nblk][cstep] -> [ntiles][G][16][SPS]
 template <typename T>
 __global__ void repack_corr_kernel(const T* __restrict__ src, uint8_t* __restrict__ dst, uint32_t rstride, int n,
@@ -141,9 +198,13 @@ __global__ void repack_e8m0_kernel(const int8_t* __restrict__ src, uint8_t* __re
 hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st) {
   const size_t dwords = size_t(w->ntiles) * w->ksteps * 64 * 4;
   const int ref_bits = dt_bits(w->qtype);
-  hipLaunchKernelGGL(repack_codes_kernel, dim3((dwords + 255) / 256), dim3(256), 0, st, a.q, (uint8_t*)w->codes,
-                     w->qstride, w->n, w->k, w->ntiles, w->ksteps, w->kind, ref_bits, a.ref_ntile, a.ref_packrow,
-                     a.ref_kpad, a.ref_npad, w->qtype == DT_F8_E5M2 ? a.flags : nullptr);
+  if (w->pl_bits)  // a native clone: the format's own planes instead of the widened record
+    hipLaunchKernelGGL(repack_planes_kernel, dim3((dwords / 4 + 255) / 256), dim3(256), 0, st, a.q, (uint8_t*)w->codes, w->qstride, w->n,
+                       w->k, w->ntiles, w->ksteps, int(w->pl_bits), a.ref_ntile, a.ref_packrow, a.ref_kpad, a.ref_npad);
+  else
+    hipLaunchKernelGGL(repack_codes_kernel, dim3((dwords + 255) / 256), dim3(256), 0, st, a.q, (uint8_t*)w->codes,
+                       w->qstride, w->n, w->k, w->ntiles, w->ksteps, w->kind, ref_bits, a.ref_ntile, a.ref_packrow,
+                       a.ref_kpad, a.ref_npad, w->qtype == DT_F8_E5M2 ? a.flags : nullptr);
   const size_t nsc = size_t(w->ntiles) * w->srows * 16 * w->sps;
   if (a.src_scale_dt == DT_F8_E8M0)
     hipLaunchKernelGGL(repack_e8m0_kernel, dim3((nsc + 255) / 256), dim3(256), 0, st, (const int8_t*)a.scales,

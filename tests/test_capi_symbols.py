@@ -143,7 +143,7 @@ def test_tuning_keys_documented_in_the_header_are_accepted_without_a_device(L):
     block = src[src.index("Diagnostics / A-B switches of the kernels"):src.index("int ns_hip_set_tuning")]
     keys = re.findall(r'^\s*\*\s+"([a-z0-9_]+)"', block, flags=re.M) + re.findall(r'",\s*"([a-z0-9_]+)"', block)
     assert {"gemv2", "g3_bm", "g3_min_m", "i8_mfma", "i8_tile", "gv_nw", "attn_wg_target", "attn_min_keys"} <= set(keys), keys
-    defaults = {"gemv2": 1, "i8_mfma": 2}
+    defaults = {"gemv2": 1, "i8_mfma": 2, "planes": 1, "planes_load": 0}
     for k in sorted(set(keys)):
         assert L.ns_hip_set_tuning(k.encode(), defaults.get(k, 0)) == 0, k
     assert L.ns_hip_set_tuning(b"no_such_key", 1) == -1
