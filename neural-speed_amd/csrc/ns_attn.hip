@@ -788,7 +788,9 @@ constexpr int kA2VSub = kA2KB * 32 + 128;  // bytes per V subtile: [64 keys][16 
 template <int HS>
 constexpr int a2_stage_bytes() { return kA2KB * HS * 2 + (HS / 16) * kA2VSub; }
 
-template <int HS>
+// SB: the scores are biased before the softmax — ALiBi (+ key position x the head's slope, mha_dense_wrapper.h:1418-1447) and / or the
+// 30 tanh(s / 30) soft cap — as attn_split_kernel applies them; a separate instantiation, the plain kernel's loop is unchanged.
+template <int HS, bool SB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma2_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
   constexpr int NJ = HS / 16, NDT = HS / 32, NCH = HS / 8, KROW = HS * 2, NSUB = HS / 16;
   constexpr int KTILE = kA2KB * KROW, STAGE = a2_stage_bytes<HS>();
@@ -839,7 +841,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < 16; i++) o[dt][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;  // l_run: this lane's half of the row sum
-  const float sc = p.qk_scale * 1.4426950408889634f;  // scores in the exp2 domain
+  const float sc = SB ? 1.f : p.qk_scale * 1.4426950408889634f;  // scores in the exp2 domain (SB: the biased scores are scaled up front)
+  float slope = 0.f;
+  const bool tanh30 = SB && (p.flags & NS_ATTN_FLAG_IS_TANH30) != 0;
+  if (SB && (p.flags & NS_ATTN_FLAG_IS_ALIBI8) != 0) {
+    const int gh = ihn + p.alibi_head_off;
+    slope = gh < p.alibi_log2_floor ? powf(p.alibi_m0, float(gh + 1)) : powf(p.alibi_m1, float(2 * (gh - p.alibi_log2_floor) + 1));
+  }
   const int q_last_wg = min(qblk * 128 + 127, p.sl_q - 1);
   const int kv_end = causal ? min(p.sl_kv, q_last_wg + off + 1) : p.sl_kv;                     // workgroup-uniform
   const int visible = min(p.sl_kv, causal ? min(q0 + n, p.sl_q - 1) + off + 1 : p.sl_kv);      // mha_dense_wrapper.h:1440-1441
@@ -942,6 +950,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int e = 0; e < 32; e++) pf[e >> 3][e & 7] = (_Float16)sv[e >> 4][e & 15];
       l_run += 1.f;
 #else
+      if constexpr (SB) {
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+          const int i = e & 15;
+          const int pos = pos0 + 32 * (e >> 4) + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float v = sv[e >> 4][i] * p.qk_scale;
+          if (tanh30) v = 30.f * tanhf(v * (1.f / 30.f));
+          v += float(pos) * slope;
+          sv[e >> 4][i] = v * 1.4426950408889634f;
+        }
+      }
       if (pos0 + kA2KB > vis_first) {  // wave-uniform: only tiles on the diagonal / past the last key are masked
 #pragma unroll
         for (int e = 0; e < 32; e++) {
@@ -1075,10 +1094,11 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
                        a.step_k_head_num % 8 == 0 && a.step_v_head_num % 8 == 0 && a.step_k_bs % 8 == 0 &&
                        a.step_v_bs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
-  if (!no_mfma && a.sl_q >= 16 && (a.head_size == 64 || a.head_size == 128) && rows_ok &&
-      (a.attn_flags & (NS_ATTN_FLAG_IS_ALIBI8 | NS_ATTN_FLAG_IS_TANH30)) == 0) {
-    const size_t nqb = (size_t(a.sl_q) + 127) / 128, wgs2 = nqb * a.head_num * a.batch_size;
-    if (a.sl_q >= g_attn_mfma2_rows.load(std::memory_order_relaxed) && wgs2 < (size_t(1) << 31) && p.qk_scale > 0.f) {
+  const bool biased = (a.attn_flags & (NS_ATTN_FLAG_IS_ALIBI8 | NS_ATTN_FLAG_IS_TANH30)) != 0;
+  const size_t nqb = (size_t(a.sl_q) + 127) / 128, wgs2 = nqb * a.head_num * a.batch_size;
+  const bool rows128 = a.sl_q >= g_attn_mfma2_rows.load(std::memory_order_relaxed) && wgs2 < (size_t(1) << 31) && (biased || p.qk_scale > 0.f);
+  if (!no_mfma && a.sl_q >= 16 && (a.head_size == 64 || a.head_size == 128) && rows_ok && (!biased || rows128)) {  // (the 64-row kernel has no biased form)
+    if (rows128) {
       // 128-row workgroups, 32x32x16 MFMA, K / V tiles shared through LDS (attn_mfma2_kernel)
       const int aligned = (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && a.step_dst_sl % 4 == 0 && a.step_dst_head_num % 4 == 0 &&
                           a.step_dst_bs % 4 == 0 && (!dst16 || (reinterpret_cast<uintptr_t>(dst16) & 7) == 0);
@@ -1090,6 +1110,8 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
         hipLaunchKernelGGL(kern, dim3(unsigned(wgs2)), dim3(256), size_t(2) * stage, st, p, int(nqb), aligned, xcd_map);
         return hipGetLastError();
       };
+      if (biased)
+        return a.head_size == 64 ? go(attn_mfma2_kernel<64, true>, a2_stage_bytes<64>()) : go(attn_mfma2_kernel<128, true>, a2_stage_bytes<128>());
       return a.head_size == 64 ? go(attn_mfma2_kernel<64>, a2_stage_bytes<64>()) : go(attn_mfma2_kernel<128>, a2_stage_bytes<128>());
     }
     const dim3 grid(unsigned((a.sl_q + 63) / 64), unsigned(a.head_num), unsigned(a.batch_size));

@@ -36,6 +36,9 @@ CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags, k_trans
     (1, 4, 4, 64, 512, 512, 1, False),     # head size 64, several blocks
     (1, 2, 2, 128, 1000, 1000, 1, False),  # ragged last block, many key tiles
     (1, 3, 1, 128, 128, 128, 1, False),    # group of 3, exactly one block
+    (1, 8, 8, 128, 200, 333, 3, False),    # ALiBi prompt rows (MPT / Bloom / Baichuan graphs): the biased form of the 128-row kernel
+    (1, 4, 2, 64, 256, 256, 3, False),     # ALiBi, head size 64, GQA
+    (2, 16, 16, 128, 129, 129, 2, False),  # ALiBi without the causal mask, batch 2
 ]
 
 
@@ -238,3 +241,34 @@ def test_prefill_kernel_fp16_shadow_and_unaligned_output(L, pkg, nso, hs, misali
     assert nso.rel_l2(out, ref) < TOL
     assert np.array_equal(out16, out.astype(np.float16).astype(np.float32))
     assert float(buf[:misalign].abs().sum()) == 0.0 and float(buf[misalign + q.size:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("sl_q,sl_kv,hs,alibi", [(1, 700, 128, False), (150, 150, 128, False), (200, 300, 64, True)])
+def test_tanh30_soft_cap_against_fp64(L, pkg, nso, sl_q, sl_kv, hs, alibi):
+    """NE_ATTN_FLAG_IS_TANH30 (mha_dense.h:57-63): scores pass through 30 tanh(s / 30) before the bias and the softmax — decode rows
+    (split kernel) and prompt rows (the biased form of the 128-row kernel), alone and together with ALiBi; fp64 model written here"""
+    import torch
+    bs, hn, hkv = 1, 8, 4
+    rng = np.random.default_rng(sl_kv)
+    q = (rng.standard_normal((bs, sl_q, hn, hs)) * 3).astype(np.float32)  # scores large enough for the cap to matter
+    k = rng.standard_normal((bs, sl_kv, hkv, hs)).astype(np.float16)
+    v = rng.standard_normal((bs, sl_kv, hkv, hs)).astype(np.float16)
+    scale = float(1.0 / np.sqrt(hs))
+    flags = 1 | 8 | (2 if alibi else 0)
+    ref = np.zeros(q.shape, np.float64)
+    lf = 1 << int(np.floor(np.log2(hn)))
+    m0, m1 = 2.0 ** (-8.0 / lf), 2.0 ** (-4.0 / lf)
+    for h in range(hn):
+        slope = (m0 ** (h + 1) if h < lf else m1 ** (2 * (h - lf) + 1)) if alibi else 0.0
+        kk, vv = k[0, :, h // (hn // hkv)].astype(np.float64), v[0, :, h // (hn // hkv)].astype(np.float64)
+        for i in range(sl_q):
+            vis = i + (sl_kv - sl_q) + 1
+            sc = 30.0 * np.tanh(kk[:vis] @ q[0, i, h].astype(np.float64) * scale / 30.0) + np.arange(vis) * slope
+            pr = np.exp(sc - sc.max())
+            ref[0, i, h] = (pr @ vv[:vis]) / pr.sum()
+    dq, dk, dv = torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+    dd = torch.zeros_like(dq)
+    a = pkg.attn_args(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dd.data_ptr(), bs, hn, hkv, hs, sl_q, sl_kv, scale, flags)
+    pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert nso.rel_l2(dd.cpu().numpy(), ref) < TOL
