@@ -790,13 +790,16 @@ constexpr int a2_stage_bytes() { return kA2KB * HS * 2 + (HS / 16) * kA2VSub; }
 
 // SB: the scores are biased before the softmax — ALiBi (+ key position x the head's slope, mha_dense_wrapper.h:1418-1447) and / or the
 // 30 tanh(s / 30) soft cap — as attn_split_kernel applies them; a separate instantiation, the plain kernel's loop is unchanged.
-template <int HS, bool SB = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma2_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
+template <int HS, bool SB>
+__device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int nqb, const int aligned_dst, const int xcd_map) {
   constexpr int NJ = HS / 16, NDT = HS / 32, NCH = HS / 8, KROW = HS * 2, NSUB = HS / 16;
   constexpr int KTILE = kA2KB * KROW, STAGE = a2_stage_bytes<HS>();
   constexpr int KU = NCH / 4;               // 16-byte K chunks per thread and tile
-  constexpr int VRW = 4 * (8 / NSUB);       // V rows per wave-wide load
-  constexpr int VU = kA2KB / (4 * VRW);     // V chunks per thread and tile
+  // a wave-wide V load: lane = (half of a 32-byte subtile row, row of a group of VRG, subtile, group); 8 consecutive lanes write
+  // 128 contiguous LDS bytes of one subtile (head size 256: two runs of 64 in neighbouring subtiles)
+  constexpr int VRG = NSUB <= 8 ? 4 : 2, VRGL = NSUB <= 8 ? 2 : 1;
+  constexpr int VRW = VRG * (32 / VRG / NSUB);  // V rows per wave-wide load
+  constexpr int VU = kA2KB / (4 * VRW);         // V chunks per thread and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5;
   const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
@@ -863,12 +866,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int id = tid + 256 * u;
     krow[u] = id / NCH;
     const int c = id % NCH;
-    const int swz = HS == 128 ? (krow[u] & 15) : ((krow[u] >> 1) & 7);
+    const int swz = HS >= 128 ? (krow[u] & 15) : ((krow[u] >> 1) & 7);
     kslot[u] = krow[u] * KROW + ((c ^ swz) << 4);
   }
-  const int vsub = (l >> 3) % NSUB, vrq = (l >> 3) / NSUB, vr = (l >> 1) & 3, vhf = l & 1;
+  const int vsub = (l >> (1 + VRGL)) % NSUB, vrq = (l >> (1 + VRGL)) / NSUB, vr = (l >> 1) & (VRG - 1), vhf = l & 1;
 #pragma unroll
-  for (int u = 0; u < VU; u++) vrow[u] = u * (4 * VRW) + w * VRW + vrq * 4 + vr;
+  for (int u = 0; u < VU; u++) vrow[u] = u * (4 * VRW) + w * VRW + vrq * VRG + vr;
   const int kcol = (tid % NCH) * 8, vcol = 16 * vsub + 8 * vhf;
   // row pointers advance by a uniform stride per tile; only the tile that reaches past the last key clamps its rows
   const _Float16* kp0 = kb + (long long)krow[0] * p.step_k_sl + kcol;
@@ -900,7 +903,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int u = 0; u < VU; u++) *reinterpret_cast<ahalf8_t*>(sb + KTILE + vsub * kA2VSub + vrow[u] * 32 + vhf * 16) = vst[u];
   };
   // operand addresses inside a stage
-  const int swz_n = HS == 128 ? (n & 15) : ((n >> 1) & 7);
+  const int swz_n = HS >= 128 ? (n & 15) : ((n >> 1) & 7);
   const int k_rd = n * KROW;                                                        // + 32 T rows, slot (2 j + h) ^ swizzle
   const int v_rd = KTILE + ((l >> 4) & 1) * kA2VSub + (4 * h + ((l & 15) >> 2)) * 32 + (l & 3) * 8;  // + 2 dt subtiles, + (32 T + 16 s) rows, + 8 rows
 
@@ -1043,6 +1046,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+template <int HS, bool SB = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma2_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
+  attn_mfma2_body<HS, SB>(p, nqb, aligned_dst, xcd_map);
+}
+// head size 256 (GPT-J, Gemma): 128 accumulator + 64 query registers per lane -> one wave per SIMD with the whole register file,
+// one workgroup per CU (two stages of 66 KB)
+template <bool SB = false>
+__global__ __launch_bounds__(256) void attn_mfma2_hs256_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
+  attn_mfma2_body<256, SB>(p, nqb, aligned_dst, xcd_map);
+}
+
 static std::atomic<int> g_alibi_heads{0}, g_alibi_off{0};  // ns_hip_attn_set_head_partition
 
 static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipStream_t st, std::string* why,
@@ -1097,7 +1111,8 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   const bool biased = (a.attn_flags & (NS_ATTN_FLAG_IS_ALIBI8 | NS_ATTN_FLAG_IS_TANH30)) != 0;
   const size_t nqb = (size_t(a.sl_q) + 127) / 128, wgs2 = nqb * a.head_num * a.batch_size;
   const bool rows128 = a.sl_q >= g_attn_mfma2_rows.load(std::memory_order_relaxed) && wgs2 < (size_t(1) << 31) && (biased || p.qk_scale > 0.f);
-  if (!no_mfma && a.sl_q >= 16 && (a.head_size == 64 || a.head_size == 128) && rows_ok && (!biased || rows128)) {  // (the 64-row kernel has no biased form)
+  const bool hs256 = a.head_size == 256;  // (128-row kernel only)
+  if (!no_mfma && a.sl_q >= 16 && (a.head_size == 64 || a.head_size == 128 || hs256) && rows_ok && ((!biased && !hs256) || rows128)) {  // (the 64-row kernel has no biased form)
     if (rows128) {
       // 128-row workgroups, 32x32x16 MFMA, K / V tiles shared through LDS (attn_mfma2_kernel)
       const int aligned = (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && a.step_dst_sl % 4 == 0 && a.step_dst_head_num % 4 == 0 &&
@@ -1110,6 +1125,7 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
         hipLaunchKernelGGL(kern, dim3(unsigned(wgs2)), dim3(256), size_t(2) * stage, st, p, int(nqb), aligned, xcd_map);
         return hipGetLastError();
       };
+      if (hs256) return biased ? go(attn_mfma2_hs256_kernel<true>, a2_stage_bytes<256>()) : go(attn_mfma2_hs256_kernel<false>, a2_stage_bytes<256>());
       if (biased)
         return a.head_size == 64 ? go(attn_mfma2_kernel<64, true>, a2_stage_bytes<64>()) : go(attn_mfma2_kernel<128, true>, a2_stage_bytes<128>());
       return a.head_size == 64 ? go(attn_mfma2_kernel<64>, a2_stage_bytes<64>()) : go(attn_mfma2_kernel<128>, a2_stage_bytes<128>());

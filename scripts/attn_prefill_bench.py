@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package(); L = pkg.lib()
-heads, hs = 32, 128
+heads, hs = int(os.environ.get("NS_ATTN_BENCH_HEADS", "32")), int(os.environ.get("NS_ATTN_BENCH_HS", "128"))  # GPT-J: 16 x 256
 res = {}
 for sl in [int(a) for a in sys.argv[1:]] or [512, 2048, 4096]:
     q = torch.randn((1, sl, heads, hs), device="cuda")

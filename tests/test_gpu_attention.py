@@ -39,6 +39,10 @@ CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags, k_trans
     (1, 8, 8, 128, 200, 333, 3, False),    # ALiBi prompt rows (MPT / Bloom / Baichuan graphs): the biased form of the 128-row kernel
     (1, 4, 2, 64, 256, 256, 3, False),     # ALiBi, head size 64, GQA
     (2, 16, 16, 128, 129, 129, 2, False),  # ALiBi without the causal mask, batch 2
+    (1, 4, 4, 256, 200, 333, 1, False),    # head size 256 (GPT-J, Gemma) on the 128-row kernel, ragged rows and context
+    (1, 16, 2, 256, 128, 700, 1, False),   # head size 256, group of 8, chunked prefill
+    (2, 2, 2, 256, 129, 129, 0, False),    # head size 256, unmasked, batch 2
+    (1, 4, 4, 256, 150, 150, 3, False),    # head size 256 with ALiBi
 ]
 
 
