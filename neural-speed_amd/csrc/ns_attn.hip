@@ -174,8 +174,10 @@ struct AttnSplitParams {
   float* ws;       // [batch][sl_q][head][nsplit][2 + head_size] partial (m, l, acc) when nsplit > 1
   int nsplit;
   int keys_per_split;
-  uint32_t* tickets;  // one self-resetting counter per (batch, query row, kv head): the LAST split to finish merges inside the launch
-                      // (nullptr: attn_merge_kernel does it in a second launch)
+  uint32_t* tickets;  // one self-resetting counter per (batch, query row, kv head, chunk): the LAST split to finish merges inside the
+                      // launch (nullptr: attn_merge_kernel does it in a second launch)
+  int g_full, chunks;  // query heads per kv head, and in how many workgroups of G heads each they are served (round 4: any head
+                       // group — Falcon's 71 and StarCoder's 48 query heads on one kv head ran on the one-workgroup-per-head kernel)
 };
 
 // stores / loads past every cache (sc0 sc1): partial results cross XCDs inside one launch
@@ -192,7 +194,11 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   __shared__ float ml_s[4][G][2];
   extern __shared__ float acc_s[];  // [4 waves][G][16 * DPL]
   const int split = blockIdx.x;
-  const int ihkv = blockIdx.y % p.heads_kv, i = blockIdx.y / p.heads_kv, ibs = blockIdx.z;
+  const int chunk = blockIdx.y % sp.chunks, ykv = blockIdx.y / sp.chunks;
+  const int ihkv = ykv % p.heads_kv, i = ykv / p.heads_kv, ibs = blockIdx.z;
+  // query head of slot g: heads past the group's end repeat its last head (computed, never stored)
+  auto head_of = [&](int g) { return ihkv * sp.g_full + min(chunk * G + g, sp.g_full - 1); };
+  auto head_live = [&](int g) { return chunk * G + g < sp.g_full; };
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
   const int kg = t >> 4;  // key group 0..15
   const int dl = l & 15;  // dim lane
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   float q[G][DPL], acc[G][DPL], m[G], lsum[G], slope[G];
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    const int ihn = ihkv * G + g;
+    const int ihn = head_of(g);
     const float* qp = p.q + ibs * p.step_q_bs + ihn * p.step_q_head_num + i * p.step_q_sl + d0;
 #pragma unroll
     for (int e = 0; e < DPL; e++) {
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   // thread (g, d) finishes output dim d of head g
   for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
     const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
-    if (dd >= hs) continue;
+    if (dd >= hs || !head_live(g)) continue;
     float mb = -INFINITY;
 #pragma unroll
     for (int ww = 0; ww < 4; ww++) mb = fmaxf(mb, ml_s[ww][g][0]);
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
       lb += ml_s[ww][g][1] * c;
       ab += acc_s[(ww * G + g) * 16 * DPL + dd] * c;
     }
-    const int ihn = ihkv * G + g;
+    const int ihn = head_of(g);
     if (sp.nsplit == 1) {
       float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
       const float y = ab / lb * p.out_scale;
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   __shared__ uint32_t drawn_s;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  uint32_t* tk = sp.tickets + ((size_t)ibs * p.sl_q + i) * p.heads_kv + ihkv;
+  uint32_t* tk = sp.tickets + (((size_t)ibs * p.sl_q + i) * p.heads_kv + ihkv) * sp.chunks + chunk;
   if (t == 0) drawn_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (drawn_s != uint32_t(sp.nsplit - 1)) return;
@@ -378,8 +384,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   const int ns = sp.nsplit;
   for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
     const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
-    if (dd >= hs) continue;
-    const int ihn = ihkv * G + g;
+    if (dd >= hs || !head_live(g)) continue;
+    const int ihn = head_of(g);
     const float* wq = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
     float mb = -INFINITY, lb = 0.f, ab = 0.f;
     if (ns <= 16) {  // every load of the merge requested at once
@@ -511,7 +517,12 @@ void set_attn_tuning(int wg_target, int min_keys) {
   if (wg_target > 0) g_attn_wg_target.store(wg_target);
   if (min_keys > 0) g_attn_min_keys.store(min_keys);
 }
-static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv) {
+// query heads per workgroup of the split kernel (its template argument) and workgroups per kv head for a head group of g_full
+static void attn_groups(int g_full, int* G, int* chunks) {
+  *G = g_full <= 1 ? 1 : (g_full == 2 ? 2 : (g_full <= 4 ? 4 : 8));
+  *chunks = (g_full + *G - 1) / *G;
+}
+static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv) {  // heads_kv: kv heads x workgroups per kv head
   const size_t base_blocks = size_t(heads_kv) * sl_q * batch;
   const int target = g_attn_wg_target.load(), mk = g_attn_min_keys.load();
   int nsplit = int((target + base_blocks - 1) / base_blocks);     // aim at ~4 workgroups per CU
@@ -519,7 +530,9 @@ static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv) {
   return std::min(nsplit, 64);
 }
 static size_t attn_ws_bytes(int batch, int head_num, int heads_kv, int head_size, int sl_q, int sl_kv) {
-  const int ns = attn_nsplit(batch, heads_kv, sl_q, sl_kv);
+  int G, chunks;
+  attn_groups(head_num / std::max(1, heads_kv), &G, &chunks);
+  const int ns = attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv);
   return ns > 1 ? size_t(batch) * sl_q * head_num * ns * (2 + head_size) * 4 : 0;
 }
 
@@ -1139,17 +1152,19 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   }
   // ---- fast path: contiguous head dimension, 16-byte aligned rows, head group 1/2/4/8 ----
   static const bool no_split = getenv("NS_ATTN_V1") != nullptr;  // diagnostics
-  const int G = a.head_num / a.heads_kv;
+  int G, chunks;
+  attn_groups(a.head_num / a.heads_kv, &G, &chunks);
   const int dpl = a.head_size <= 128 ? 8 : 16;
-  const bool fast = !no_split && (G == 1 || G == 2 || G == 4 || G == 8) && a.step_k_head_size == 1 &&
+  const bool fast = !no_split && a.step_k_head_size == 1 &&
                     a.step_v_head_size == 1 && a.head_size % dpl == 0 && a.step_k_sl % 8 == 0 && a.step_v_sl % 8 == 0 &&
                     a.step_k_head_num % 8 == 0 && a.step_v_head_num % 8 == 0 && a.step_k_bs % 8 == 0 &&
                     a.step_v_bs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.K) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
-  if (fast && size_t(a.heads_kv) * a.sl_q <= 65535) {
+  if (fast && size_t(a.heads_kv) * a.sl_q * chunks <= 65535) {
     AttnSplitParams sp;
     sp.a = p;
-    int nsplit = attn_nsplit(a.batch_size, a.heads_kv, a.sl_q, a.sl_kv);
+    sp.g_full = a.head_num / a.heads_kv, sp.chunks = chunks;
+    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv);
     float* ws = nullptr;
     if (nsplit > 1) {
       // partials go to the caller's workspace (`tmp`, sized by bestla_fusion_attn_workspace_size: the reference's own
@@ -1161,12 +1176,12 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     }
     sp.ws = ws;
     sp.tickets = nullptr;
-    const size_t nticket = size_t(a.batch_size) * a.sl_q * a.heads_kv;
+    const size_t nticket = size_t(a.batch_size) * a.sl_q * a.heads_kv * chunks;
     if (nsplit > 1 && g_attn_inlaunch.load(std::memory_order_relaxed) != 0 && nticket <= kAttnTicketCap)
       sp.tickets = static_cast<uint32_t*>(stream_scratch_zeroed(st, kAttnTicketCap * 4, 22));  // nullptr (e.g. first use on a capturing stream): the merge launch
     sp.nsplit = nsplit;
     sp.keys_per_split = (a.sl_kv + nsplit - 1) / nsplit;
-    const dim3 grid(unsigned(nsplit), unsigned(a.heads_kv * a.sl_q), unsigned(a.batch_size));
+    const dim3 grid(unsigned(nsplit), unsigned(a.heads_kv * a.sl_q * chunks), unsigned(a.batch_size));
     hipError_t e = G == 1 ? launch_split_g<1>(sp, grid, st)
                  : G == 2 ? launch_split_g<2>(sp, grid, st)
                  : G == 4 ? launch_split_g<4>(sp, grid, st)

@@ -20,7 +20,11 @@ CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags, k_trans
     (1, 6, 3, 32, 1, 1, 1, False),         # single key
     (1, 64, 8, 128, 1, 3000, 1, False),    # Llama-2-70B head grouping (8 query heads per kv head)
     (1, 16, 2, 256, 2, 700, 1, False),     # group of 8 at the largest head size
-    (1, 12, 4, 64, 1, 999, 0, False),      # group of 3: not a fast-path group size -> generic kernel
+    (1, 12, 4, 64, 1, 999, 0, False),      # group of 3: served as a group of 4 with one idle slot (round 4; the generic kernel before)
+    (1, 71, 1, 64, 1, 2048, 1, False),     # Falcon-7B: 71 query heads on ONE kv head -> nine workgroups of 8 heads, the last with 7
+    (1, 48, 1, 128, 1, 1500, 1, False),    # StarCoder: 48 query heads on one kv head
+    (1, 12, 2, 128, 2, 700, 1, False),     # group of 6, two query rows
+    (1, 6, 2, 128, 1, 900, 3, False),      # group of 3 with ALiBi: the slopes follow the real head index
     # ---- several query rows -> matrix-core kernel (head size 64 / 128) ----
     (1, 8, 8, 128, 64, 64, 1, False),      # one full 64-row block, causal prefill
     (1, 8, 2, 128, 100, 333, 1, False),    # GQA, ragged rows and context, sl_q < sl_kv (chunked prefill)
