@@ -803,7 +803,7 @@ constexpr int a2_stage_bytes() { return kA2KB * HS * 2 + (HS / 16) * kA2VSub; }
 
 // SB: the scores are biased before the softmax — ALiBi (+ key position x the head's slope, mha_dense_wrapper.h:1418-1447) and / or the
 // 30 tanh(s / 30) soft cap — as attn_split_kernel applies them; a separate instantiation, the plain kernel's loop is unchanged.
-template <int HS, bool SB>
+template <int HS, bool SB, bool PAD>
 __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int nqb, const int aligned_dst, const int xcd_map) {
   constexpr int NJ = HS / 16, NDT = HS / 32, NCH = HS / 8, KROW = HS * 2, NSUB = HS / 16;
   constexpr int KTILE = kA2KB * KROW, STAGE = a2_stage_bytes<HS>();
@@ -843,13 +843,17 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
   const _Float16* vb = p.v + ibs * p.step_v_bs + ihkv * p.step_v_head_num;
   float* db = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num;
 
+  // PAD: HS is the PADDED head size of this instantiation (64 / 128 / 256) and the call's own head size hs < HS a multiple of 8:
+  // query dims, K / V chunks and output dims from hs on are zeros / never stored (head sizes 80, 96, 112, 160, 192 ... ride on the
+  // next size up; a separate instantiation: the predicates cost the exact sizes a third of their speed)
+  const int hs = PAD ? p.head_size : HS;
   ahalf8_t qf[NJ];
   {
     const float* qr = qb + (long long)min(q0 + n, p.sl_q - 1) * p.step_q_sl + 8 * h;
 #pragma unroll
     for (int j = 0; j < NJ; j++)
 #pragma unroll
-      for (int i = 0; i < 8; i++) qf[j][i] = (_Float16)qr[16 * j + i];
+      for (int i = 0; i < 8; i++) qf[j][i] = 16 * j + 8 * h < hs ? (_Float16)qr[16 * j + i] : (_Float16)0.f;
   }
   afloatx16 o[NDT];
 #pragma unroll
@@ -891,19 +895,36 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
   const _Float16* vp0 = vb + (long long)vrow[0] * p.step_v_sl + vcol;
   const long long ku_step = (long long)(256 / NCH) * p.step_k_sl, vu_step = (long long)(4 * VRW) * p.step_v_sl;
   const long long ktile_step = (long long)kA2KB * p.step_k_sl, vtile_step = (long long)kA2KB * p.step_v_sl;
+  const bool k_in = !PAD || kcol < hs, v_in = !PAD || vcol < hs;  // this thread's 16-byte column of the rows exists (else: zeros, once)
+  if (!k_in) {
+#pragma unroll
+    for (int u = 0; u < KU; u++) kst[u] = ahalf8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  if (!v_in) {
+#pragma unroll
+    for (int u = 0; u < VU; u++) vst[u] = ahalf8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
   auto fetch = [&](int pos0) {
     if (pos0 + kA2KB <= p.sl_kv) {  // workgroup-uniform
+      if (k_in) {
 #pragma unroll
-      for (int u = 0; u < KU; u++) kst[u] = *reinterpret_cast<const ahalf8_t*>(kp0 + u * ku_step);
+        for (int u = 0; u < KU; u++) kst[u] = *reinterpret_cast<const ahalf8_t*>(kp0 + u * ku_step);
+      }
+      if (v_in) {
 #pragma unroll
-      for (int u = 0; u < VU; u++) vst[u] = *reinterpret_cast<const ahalf8_t*>(vp0 + u * vu_step);
+        for (int u = 0; u < VU; u++) vst[u] = *reinterpret_cast<const ahalf8_t*>(vp0 + u * vu_step);
+      }
     } else {
+      if (k_in) {
 #pragma unroll
-      for (int u = 0; u < KU; u++)
-        kst[u] = *reinterpret_cast<const ahalf8_t*>(kb + (long long)min(pos0 + krow[u], p.sl_kv - 1) * p.step_k_sl + kcol);
+        for (int u = 0; u < KU; u++)
+          kst[u] = *reinterpret_cast<const ahalf8_t*>(kb + (long long)min(pos0 + krow[u], p.sl_kv - 1) * p.step_k_sl + kcol);
+      }
+      if (v_in) {
 #pragma unroll
-      for (int u = 0; u < VU; u++)
-        vst[u] = *reinterpret_cast<const ahalf8_t*>(vb + (long long)min(pos0 + vrow[u], p.sl_kv - 1) * p.step_v_sl + vcol);
+        for (int u = 0; u < VU; u++)
+          vst[u] = *reinterpret_cast<const ahalf8_t*>(vb + (long long)min(pos0 + vrow[u], p.sl_kv - 1) * p.step_v_sl + vcol);
+      }
     }
     kp0 += ktile_step;
     vp0 += vtile_step;
@@ -1043,6 +1064,7 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
 #pragma unroll
       for (int bq = 0; bq < 4; bq++) {
         const int d = 32 * dt + 8 * bq + 4 * h;
+        if (PAD && d >= hs) continue;
         const afloatx4 y = afloatx4{o[dt][4 * bq] * inv, o[dt][4 * bq + 1] * inv, o[dt][4 * bq + 2] * inv, o[dt][4 * bq + 3] * inv};
         if (aligned_dst) {
           *reinterpret_cast<afloatx4*>(dr + d) = y;
@@ -1059,15 +1081,15 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
   }
 }
 
-template <int HS, bool SB = false>
+template <int HS, bool SB = false, bool PAD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma2_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
-  attn_mfma2_body<HS, SB>(p, nqb, aligned_dst, xcd_map);
+  attn_mfma2_body<HS, SB, PAD>(p, nqb, aligned_dst, xcd_map);
 }
 // head size 256 (GPT-J, Gemma): 128 accumulator + 64 query registers per lane -> one wave per SIMD with the whole register file,
 // one workgroup per CU (two stages of 66 KB)
-template <bool SB = false>
+template <bool SB = false, bool PAD = false>
 __global__ __launch_bounds__(256) void attn_mfma2_hs256_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
-  attn_mfma2_body<256, SB>(p, nqb, aligned_dst, xcd_map);
+  attn_mfma2_body<256, SB, PAD>(p, nqb, aligned_dst, xcd_map);
 }
 
 static std::atomic<int> g_alibi_heads{0}, g_alibi_off{0};  // ns_hip_attn_set_head_partition
@@ -1124,8 +1146,9 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   const bool biased = (a.attn_flags & (NS_ATTN_FLAG_IS_ALIBI8 | NS_ATTN_FLAG_IS_TANH30)) != 0;
   const size_t nqb = (size_t(a.sl_q) + 127) / 128, wgs2 = nqb * a.head_num * a.batch_size;
   const bool rows128 = a.sl_q >= g_attn_mfma2_rows.load(std::memory_order_relaxed) && wgs2 < (size_t(1) << 31) && (biased || p.qk_scale > 0.f);
-  const bool hs256 = a.head_size == 256;  // (128-row kernel only)
-  if (!no_mfma && a.sl_q >= 16 && (a.head_size == 64 || a.head_size == 128 || hs256) && rows_ok && ((!biased && !hs256) || rows128)) {  // (the 64-row kernel has no biased form)
+  // the 128-row kernel pads any head size that is a multiple of 8 to 64 / 128 / 256; the 64-row kernel takes 64 and 128 as they are
+  const bool exact = a.head_size == 64 || a.head_size == 128, hs256 = a.head_size > 128;
+  if (!no_mfma && a.sl_q >= 16 && a.head_size % 8 == 0 && a.head_size <= 256 && rows_ok && ((!biased && exact) || rows128)) {  // (the 64-row kernel has no biased form)
     if (rows128) {
       // 128-row workgroups, 32x32x16 MFMA, K / V tiles shared through LDS (attn_mfma2_kernel)
       const int aligned = (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && a.step_dst_sl % 4 == 0 && a.step_dst_head_num % 4 == 0 &&
@@ -1138,10 +1161,16 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
         hipLaunchKernelGGL(kern, dim3(unsigned(wgs2)), dim3(256), size_t(2) * stage, st, p, int(nqb), aligned, xcd_map);
         return hipGetLastError();
       };
-      if (hs256) return biased ? go(attn_mfma2_hs256_kernel<true>, a2_stage_bytes<256>()) : go(attn_mfma2_hs256_kernel<false>, a2_stage_bytes<256>());
-      if (biased)
-        return a.head_size == 64 ? go(attn_mfma2_kernel<64, true>, a2_stage_bytes<64>()) : go(attn_mfma2_kernel<128, true>, a2_stage_bytes<128>());
-      return a.head_size == 64 ? go(attn_mfma2_kernel<64>, a2_stage_bytes<64>()) : go(attn_mfma2_kernel<128>, a2_stage_bytes<128>());
+      const bool pad = a.head_size != 64 && a.head_size != 128 && a.head_size != 256;
+      if (hs256)
+        return biased ? (pad ? go(attn_mfma2_hs256_kernel<true, true>, a2_stage_bytes<256>()) : go(attn_mfma2_hs256_kernel<true, false>, a2_stage_bytes<256>()))
+                      : (pad ? go(attn_mfma2_hs256_kernel<false, true>, a2_stage_bytes<256>()) : go(attn_mfma2_hs256_kernel<false, false>, a2_stage_bytes<256>()));
+      auto pick = [&](auto hs_c) {
+        constexpr int H = decltype(hs_c)::value;
+        if (biased) return pad ? go(attn_mfma2_kernel<H, true, true>, a2_stage_bytes<H>()) : go(attn_mfma2_kernel<H, true, false>, a2_stage_bytes<H>());
+        return pad ? go(attn_mfma2_kernel<H, false, true>, a2_stage_bytes<H>()) : go(attn_mfma2_kernel<H, false, false>, a2_stage_bytes<H>());
+      };
+      return a.head_size <= 64 ? pick(std::integral_constant<int, 64>{}) : pick(std::integral_constant<int, 128>{});
     }
     const dim3 grid(unsigned((a.sl_q + 63) / 64), unsigned(a.head_num), unsigned(a.batch_size));
     if (a.head_size == 64)

@@ -47,6 +47,10 @@ CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags, k_trans
     (1, 16, 2, 256, 128, 700, 1, False),   # head size 256, group of 8, chunked prefill
     (2, 2, 2, 256, 129, 129, 0, False),    # head size 256, unmasked, batch 2
     (1, 4, 4, 256, 150, 150, 3, False),    # head size 256 with ALiBi
+    (1, 8, 8, 80, 200, 333, 1, False),     # head size 80 (phi-2, StableLM): padded to the 128-wide instantiation
+    (1, 4, 2, 96, 130, 130, 1, False),     # head size 96 (GPT-NeoX-20B), GQA
+    (1, 4, 4, 160, 150, 200, 1, False),    # head size 160: padded to 256
+    (2, 2, 2, 40, 128, 128, 0, False),     # head size 40: padded to 64, unmasked, batch 2
 ]
 
 
