@@ -1145,7 +1145,11 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
                        (reinterpret_cast<uintptr_t>(a.V) & 15) == 0;
   const bool biased = (a.attn_flags & (NS_ATTN_FLAG_IS_ALIBI8 | NS_ATTN_FLAG_IS_TANH30)) != 0;
   const size_t nqb = (size_t(a.sl_q) + 127) / 128, wgs2 = nqb * a.head_num * a.batch_size;
-  const bool rows128 = a.sl_q >= g_attn_mfma2_rows.load(std::memory_order_relaxed) && wgs2 < (size_t(1) << 31) && (biased || p.qk_scale > 0.f);
+  // shapes the 64-row kernel cannot take (biased scores, head sizes other than 64 / 128) use the 128-row kernel from 16 rows on: a
+  // workgroup with idle waves is still far from the one-row-per-workgroup kernel they would fall to
+  const bool only128 = biased || (a.head_size != 64 && a.head_size != 128);
+  const bool rows128 = a.sl_q >= (only128 ? 16 : g_attn_mfma2_rows.load(std::memory_order_relaxed)) && wgs2 < (size_t(1) << 31) &&
+                       (biased || p.qk_scale > 0.f);
   // the 128-row kernel pads any head size that is a multiple of 8 to 64 / 128 / 256; the 64-row kernel takes 64 and 128 as they are
   const bool exact = a.head_size == 64 || a.head_size == 128, hs256 = a.head_size > 128;
   if (!no_mfma && a.sl_q >= 16 && a.head_size % 8 == 0 && a.head_size <= 256 && rows_ok && ((!biased && exact) || rows128)) {  // (the 64-row kernel has no biased form)

@@ -51,6 +51,8 @@ CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags, k_trans
     (1, 4, 2, 96, 130, 130, 1, False),     # head size 96 (GPT-NeoX-20B), GQA
     (1, 4, 4, 160, 150, 200, 1, False),    # head size 160: padded to 256
     (2, 2, 2, 40, 128, 128, 0, False),     # head size 40: padded to 64, unmasked, batch 2
+    (1, 8, 8, 128, 20, 500, 3, False),     # a short ALiBi chunk (16..127 rows): still the 128-row kernel, waves past the rows idle
+    (1, 4, 4, 256, 33, 33, 1, False),      # head size 256, 33 rows
 ]
 
 
