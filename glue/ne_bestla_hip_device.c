@@ -34,6 +34,11 @@ int ns_hip_dup_f32(const float* dSrc, void* dDst, const long long ne[4], const l
                    bool dst_is_f16, void* stream);
 int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* dV, float* dO, int batch, int seq, int seq_all, int heads,
                                  int heads_kv, int head_size, int n_ctx, float scale, int masked, void* stream);
+int ns_hip_lazy_flush(void);
+int ns_hip_lazy_rms_norm(int rows, int cols, float eps, const float* dIn, float* dOut, void* stream);
+int ns_hip_lazy_silu(const float* dSrc, float* dDst, size_t n, void* stream);
+int ns_hip_lazy_mul(const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4], const long long ne1[4],
+                    const long long nb1[4], const long long nbd[4], void* stream);
 const char* ns_hip_last_error(void);
 
 static void device_fail(const char* who) { /* the reference's device functions have no error channel either */
@@ -49,9 +54,11 @@ static void binary(const struct ne_compute_params* params, const struct ne_tenso
     ne0[i] = a->ne[i], nb0[i] = (long long)a->nb[i], ne1[i] = b->ne[i], nbd[i] = (long long)dst->nb[i];
     nb1[i] = (i > 0 && b->ne[i] == 1) ? 0 : (long long)b->nb[i]; /* ne_bestla_sycl.cpp:199-202 */
   }
-  if (ns_hip_binary_nd_f32(is_mul, (const float*)a->data, (const float*)b->data, (float*)dst->data, ne0, nb0, ne1, nb1, nbd,
-                           params->dev_queue) != 0)
-    device_fail(is_mul ? "bestla_device_mul_f32" : "bestla_device_add_f32");
+  /* a multiply may consume the norm / silu node recorded just before it (one launch for both: ns_hip_lazy_mul) */
+  const int rc = is_mul ? ns_hip_lazy_mul((const float*)a->data, (const float*)b->data, (float*)dst->data, ne0, nb0, ne1, nb1, nbd, params->dev_queue)
+                        : ns_hip_binary_nd_f32(0, (const float*)a->data, (const float*)b->data, (float*)dst->data, ne0, nb0, ne1, nb1, nbd,
+                                               params->dev_queue);
+  if (rc != 0) device_fail(is_mul ? "bestla_device_mul_f32" : "bestla_device_add_f32");
 }
 void bestla_device_mul_f32(const struct ne_compute_params* params, const struct ne_tensor* src0, const struct ne_tensor* src1,
                            struct ne_tensor* dst) {
@@ -71,7 +78,7 @@ void bestla_device_elewise_f32(const struct ne_compute_params* params, const str
     return;
   }
   const size_t n = (size_t)(src0->ne[0] * src0->ne[1] * src0->ne[2] * src0->ne[3]);
-  if (ns_hip_silu_f32((const float*)src0->data, (float*)dst->data, n, params->dev_queue) != 0) device_fail("bestla_device_elewise_f32");
+  if (ns_hip_lazy_silu((const float*)src0->data, (float*)dst->data, n, params->dev_queue) != 0) device_fail("bestla_device_elewise_f32");
 }
 
 /* rows of ne00 values; eps in dst->op_params (ne_bestla_sycl.cpp:328-407).  Rows must be dense and packed — what every
@@ -89,7 +96,7 @@ void bestla_device_rms_norm_f32(const struct ne_compute_params* params, const st
     assert(0);
     return;
   }
-  if (ns_hip_layernormalization((int)rows, (int)src0->ne[0], true, eps, (const float*)src0->data, (float*)dst->data, params->dev_queue) != 0)
+  if (ns_hip_lazy_rms_norm((int)rows, (int)src0->ne[0], eps, (const float*)src0->data, (float*)dst->data, params->dev_queue) != 0)
     device_fail("bestla_device_rms_norm_f32");
 }
 
@@ -113,6 +120,7 @@ void bestla_device_rope_f32(const struct ne_compute_params* params, const struct
     assert(0);
     return;
   }
+  if (ns_hip_lazy_flush() != 0) device_fail("bestla_device_rope_f32");
   const int rc = ext_factor != 0.0f
                      ? ns_hip_rope_f32_yarn((const float*)src0->data, (float*)dst->data, batch, seq, heads, hs, n_past, n_dims, mode, freq_base,
                                             freq_scale, n_orig_ctx, ext_factor, attn_factor, beta_fast, beta_slow, params->dev_queue)
@@ -132,6 +140,7 @@ void bestla_device_dup_f32(const struct ne_compute_params* params, const struct 
     return;
   }
   /* the reference indexes the source with the DESTINATION's coordinates (same shape after the graph's permutes) */
+  if (ns_hip_lazy_flush() != 0) device_fail("bestla_device_dup_f32");
   if (ns_hip_dup_f32((const float*)src0->data, dst->data, ne, snb, dnb, dst->type == NE_TYPE_F16, params->dev_queue) != 0)
     device_fail("bestla_device_dup_f32");
 }

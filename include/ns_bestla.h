@@ -423,6 +423,16 @@ int ns_hip_binary_nd_f32(int is_mul, const float* dA, const float* dB, float* dD
                          const long long ne1[4], const long long nb1[4], const long long nbd[4], void* stream);
 /* attention over the device prototype's fp32 kv cache (ne_bestla_sycl.cpp:592-880): q / o [batch][seq][heads][head_size],
  * k [batch][heads_kv][n_ctx][head_size], v [batch][heads_kv][head_size][n_ctx]; masked: causal with n_past = seq_all - seq */
+/* Lazy peephole of the device route (round 4): ns_hip_lazy_rms_norm / ns_hip_lazy_silu RECORD their node instead of launching it;
+ * ns_hip_lazy_mul fuses a multiply that consumes the recorded result with it — one launch writing BOTH tensors, bit for bit what
+ * the two kernels write — and everything else launches the recorded node first (ns_hip_lazy_flush; the bestla_device_* pointer
+ * entries and ns_hip_binary_nd_f32 / ns_hip_mha_f32_device_layout call it themselves, the glue calls it in front of the ns_hip_*
+ * entries it forwards to).  One recorded node at most, one issuing thread.  NS_DEV_LAZY=0: nothing is deferred. */
+int ns_hip_lazy_flush(void);
+int ns_hip_lazy_rms_norm(int rows, int cols, float eps, const float* dIn, float* dOut, void* stream);
+int ns_hip_lazy_silu(const float* dSrc, float* dDst, size_t n, void* stream);
+int ns_hip_lazy_mul(const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4], const long long ne1[4],
+                    const long long nb1[4], const long long nbd[4], void* stream);
 int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* dV, float* dO, int batch, int seq, int seq_all, int heads,
                                  int heads_kv, int head_size, int n_ctx, float scale, int masked, void* stream);
 

@@ -277,6 +277,7 @@ struct Device {
 }  // namespace ns
 
 extern "C" {
+int ns_hip_lazy_flush(void);  // (defined with the lazy peephole below: a recorded norm / silu node is launched before anything else runs)
 
 /* ---- ne_bestla.h:86-96, ne_bestla_sycl.cpp:26-92 ---- */
 void* bestla_create_device(bool profile) {
@@ -325,11 +326,15 @@ void bestla_device_free(void* ptr, void* queue) {
   if (ptr) (void)hipFree(ptr);
 }
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {
+  (void)ns_hip_lazy_flush();
   if (!dstptr || !srcptr || !size) return;
   if (hipMemcpyAsync(dstptr, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
     ns::set_error("bestla_device_memcpy failed");
 }
-void bestla_device_sync(void* queue) { (void)hipStreamSynchronize(static_cast<hipStream_t>(queue)); }
+void bestla_device_sync(void* queue) {
+  (void)ns_hip_lazy_flush();
+  (void)hipStreamSynchronize(static_cast<hipStream_t>(queue));
+}
 void bestla_device_memcpy_sync(void* dstptr, const void* srcptr, size_t size, void* queue) {
   bestla_device_memcpy(dstptr, srcptr, size, queue);
   bestla_device_sync(queue);
@@ -435,6 +440,7 @@ void ns_hip_device_load_stats(uint64_t out[6]) {
 void bestla_device_f32f32_forward(float* activation, void* weiptr, float* output, int _m, int _n, int _k, int lda, int ldo,
                                   void* workspace, void* queue) {
   (void)workspace;
+  (void)ns_hip_lazy_flush();
   if (g_have_pending.load()) {  // first forward after a model load: one synchronisation completes every weight
     g_have_pending.store(0);
     finish_pending_loads();
@@ -464,9 +470,116 @@ void ns_hip_device_storage_release(void* devstor) {
   }
 }
 
+/* ---- lazy peephole of the device route (round 4).  The reference's graph runs node by node: rms_norm, then the multiply by the norm
+ * weight; silu(gate), then the multiply by up — four launches per layer that are two.  The glue hands rms_norm and silu to
+ * ns_hip_lazy_*; they are RECORDED, not launched.  The next call decides: a multiply that consumes the recorded result (the
+ * llama graph always does) runs ONE kernel that writes BOTH tensors — the recorded node's own output and the product, bit for bit
+ * what the two kernels write, so every tensor of the graph keeps its contents whatever else reads it; anything else (another
+ * operator from the glue, a GEMM, a copy, a synchronisation) first launches the recorded node as it stands (ns_hip_lazy_flush).
+ * One recorded node at most; the reference's executor issues device nodes from one thread. ---- */
+extern "C++" {
+namespace ns {
+hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* out, hipStream_t st, const float* gamma,
+                          void* out16);
+hipError_t launch_rmsnorm_mul2(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* plain, const float* gamma, float* out,
+                               hipStream_t st);
+hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t st);
+hipError_t launch_silu_mul2(const float* x, const float* y, float* s, float* out, size_t n, int silu_first, hipStream_t st);
+namespace {
+struct LazyNode {
+  int kind = 0;  // 0 none, 1 rms norm, 2 silu
+  const float* src = nullptr;
+  float* dst = nullptr;
+  int rows = 0, cols = 0;
+  float eps = 0.f;
+  size_t n = 0;
+  hipStream_t st = nullptr;
+};
+LazyNode g_lazy;
+std::atomic<int> g_lazy_on{-1};  // NS_DEV_LAZY=0: every node launches as it comes (A/B)
+bool lazy_on() {
+  int v = g_lazy_on.load();
+  if (v < 0) {
+    const char* e = getenv("NS_DEV_LAZY");
+    v = e ? atoi(e) != 0 : 1;
+    g_lazy_on.store(v);
+  }
+  return v != 0;
+}
+int lazy_flush_impl() {
+  const LazyNode n = g_lazy;
+  g_lazy.kind = 0;
+  hipError_t e = hipSuccess;
+  if (n.kind == 1) e = launch_rmsnorm(n.rows, n.cols, true, n.eps, n.src, n.dst, n.st, nullptr, nullptr);
+  if (n.kind == 2) e = launch_silu(n.src, n.dst, n.n, n.st);
+  if (e != hipSuccess) {
+    set_error("device route: launching a deferred node failed");
+    return -1;
+  }
+  return 0;
+}
+}  // namespace
+}  // namespace ns
+}  // extern "C++"
+int ns_hip_lazy_flush(void) { return ns::g_lazy.kind ? ns::lazy_flush_impl() : 0; }
+int ns_hip_lazy_rms_norm(int rows, int cols, float eps, const float* dIn, float* dOut, void* stream) {
+  if (ns_hip_lazy_flush() != 0) return -1;
+  if (!dIn || !dOut || rows < 1 || cols < 1) {
+    ns::set_error("lazy rms_norm: invalid argument");
+    return -1;
+  }
+  ns::g_lazy = ns::LazyNode{1, dIn, dOut, rows, cols, eps, size_t(rows) * cols, static_cast<hipStream_t>(stream)};
+  return ns::lazy_on() ? 0 : ns_hip_lazy_flush();
+}
+int ns_hip_lazy_silu(const float* dSrc, float* dDst, size_t n, void* stream) {
+  if (ns_hip_lazy_flush() != 0) return -1;
+  if (n && (!dSrc || !dDst)) {
+    ns::set_error("lazy silu: null argument");
+    return -1;
+  }
+  if (!n) return 0;
+  ns::g_lazy = ns::LazyNode{2, dSrc, dDst, 0, 0, 0.f, n, static_cast<hipStream_t>(stream)};
+  return ns::lazy_on() ? 0 : ns_hip_lazy_flush();
+}
+int ns_hip_binary_nd_f32(int is_mul, const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4],
+                         const long long ne1[4], const long long nb1[4], const long long nbd[4], void* stream);
+/* the multiply node: fused with the recorded node when it consumes it, else the recorded node first and the plain kernel */
+int ns_hip_lazy_mul(const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4], const long long ne1[4],
+                    const long long nb1[4], const long long nbd[4], void* stream) {
+  const ns::LazyNode n = ns::g_lazy;
+  auto packed = [](const long long ne[4], const long long nb[4]) {
+    return nb[0] == 4 && nb[1] == 4 * ne[0] && nb[2] == nb[1] * ne[1] && nb[3] == nb[2] * ne[2];
+  };
+  if (n.kind && dA && dB && dDst && n.st == static_cast<hipStream_t>(stream) && packed(ne0, nb0) && packed(ne0, nbd)) {
+    const long long total = ne0[0] * ne0[1] * ne0[2] * ne0[3];
+    if (n.kind == 1 && dA == n.dst && total == (long long)n.n && ne0[0] == n.cols && ne1[0] == n.cols && ne1[1] <= 1 && ne1[2] <= 1 && ne1[3] <= 1 &&
+        nb1[0] == 4 && dDst != n.src) {
+      ns::g_lazy.kind = 0;
+      if (ns::launch_rmsnorm_mul2(n.rows, n.cols, true, n.eps, n.src, n.dst, dB, dDst, n.st) != hipSuccess) {
+        ns::set_error("device route: norm . weight launch failed");
+        return -1;
+      }
+      return 0;
+    }
+    const bool same_shape = ne1[0] == ne0[0] && ne1[1] == ne0[1] && ne1[2] == ne0[2] && ne1[3] == ne0[3] && packed(ne1, nb1);
+    if (n.kind == 2 && same_shape && total == (long long)n.n && (dA == n.dst) != (dB == n.dst) && dDst != n.src) {
+      ns::g_lazy.kind = 0;
+      const bool first = dA == n.dst;
+      if (ns::launch_silu_mul2(n.src, first ? dB : dA, n.dst, dDst, n.n, first ? 1 : 0, n.st) != hipSuccess) {
+        ns::set_error("device route: silu . up launch failed");
+        return -1;
+      }
+      return 0;
+    }
+  }
+  if (ns_hip_lazy_flush() != 0) return -1;
+  return ns_hip_binary_nd_f32(1, dA, dB, dDst, ne0, nb0, ne1, nb1, nbd, stream);
+}
+
 /* ---- kernels behind the tensor-level functions of glue/ne_bestla_hip_device.c ---- */
 int ns_hip_binary_nd_f32(int is_mul, const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4],
                          const long long ne1[4], const long long nb1[4], const long long nbd[4], void* stream) {
+  if (ns_hip_lazy_flush() != 0) return -1;
   if (!dA || !dB || !dDst) {
     ns::set_error("binary_nd: null argument");
     return -1;
@@ -495,6 +608,7 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
     ns::set_error("mha_f32: invalid argument");
     return -1;
   }
+  if (ns_hip_lazy_flush() != 0) return -1;
   // ---- the context split over workgroups: head sizes 64 / 128 / 256, from two 128-key ranges on ----
   static const bool no_split = getenv("NS_MHA_NO_SPLIT") != nullptr;  // diagnostics (A/B)
   const int nsplit = (seq_all + ns::kMhaKS - 1) / ns::kMhaKS;

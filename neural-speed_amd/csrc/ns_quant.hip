@@ -427,7 +427,9 @@ hipError_t launch_pack_q(const PackQArgs& a, hipStream_t st) {
 template <bool CACHED>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ in, float* __restrict__ out, int size,
                                                    bool rms, float eps, const float* __restrict__ gamma,
-                                                   _Float16* __restrict__ out16) {
+                                                   _Float16* __restrict__ out16, float* __restrict__ out_plain = nullptr) {
+  // out_plain (with gamma): the normalised values BEFORE the gamma product as well — the two tensors of the reference's norm and
+  // mul nodes from one launch (ns_device.hip: lazy peephole of the device route)
   __shared__ float red[2][4];
   const float* src = in + size_t(blockIdx.x) * size;
   float* dst = out + size_t(blockIdx.x) * size;
@@ -477,6 +479,11 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ in,
       if (i >= size) continue;
       const float4 y = {fin(v[c].x, i), fin(v[c].y, i + 1), fin(v[c].z, i + 2), fin(v[c].w, i + 3)};
       *reinterpret_cast<float4*>(dst + i) = y;
+      if (out_plain) {
+        const float4 yp = rms ? float4{v[c].x * inv, v[c].y * inv, v[c].z * inv, v[c].w * inv}
+                              : float4{(v[c].x - mean) * inv, (v[c].y - mean) * inv, (v[c].z - mean) * inv, (v[c].w - mean) * inv};
+        *reinterpret_cast<float4*>(out_plain + size_t(blockIdx.x) * size + i) = yp;
+      }
       if (out16) {
         typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
         *reinterpret_cast<half4_t*>(out16 + size_t(blockIdx.x) * size + i) =
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ in,
       const float y = fin(src[i], i);
       dst[i] = y;
       if (out16) out16[size_t(blockIdx.x) * size + i] = (_Float16)y;
+      if (out_plain) out_plain[size_t(blockIdx.x) * size + i] = rms ? src[i] * inv : (src[i] - mean) * inv;
     }
   }
 }
@@ -502,6 +510,34 @@ hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, 
   else
     hipLaunchKernelGGL(norm_kernel<false>, dim3(norm_count), dim3(256), 0, st, in, out, norm_size, isrms, eps, gamma,
                        static_cast<_Float16*>(out16));
+  return hipGetLastError();
+}
+
+// norm and the product with the norm weight in one launch, BOTH tensors written (plain = norm(in), out = plain * gamma): same values
+// as launch_rmsnorm(in -> plain) followed by the row-broadcast multiply
+hipError_t launch_rmsnorm_mul2(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* plain, const float* gamma,
+                               float* out, hipStream_t st) {
+  const bool cached = norm_size <= 4096 && (norm_size & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
+                                                                   reinterpret_cast<uintptr_t>(plain)) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(gamma) & 3) == 0;
+  if (cached)
+    hipLaunchKernelGGL(norm_kernel<true>, dim3(norm_count), dim3(256), 0, st, in, out, norm_size, isrms, eps, gamma, nullptr, plain);
+  else
+    hipLaunchKernelGGL(norm_kernel<false>, dim3(norm_count), dim3(256), 0, st, in, out, norm_size, isrms, eps, gamma, nullptr, plain);
+  return hipGetLastError();
+}
+// silu and the product that follows it in a gated FFN, both tensors written: s = silu(x) (silu_kernel's arithmetic), out = s * y
+__global__ void silu_mul2_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ s, float* __restrict__ out,
+                                 size_t n, int silu_first) {
+  const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = __fdiv_rn(x[i], __fadd_rn(1.0f, expf(-x[i])));
+  s[i] = v;
+  out[i] = silu_first ? v * y[i] : y[i] * v;
+}
+hipError_t launch_silu_mul2(const float* x, const float* y, float* s, float* out, size_t n, int silu_first, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(silu_mul2_kernel, grid1d(n, 256), dim3(256), 0, st, x, y, s, out, n, silu_first);
   return hipGetLastError();
 }
 

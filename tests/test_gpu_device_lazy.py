@@ -1,0 +1,112 @@
+"""Lazy peephole of the device route (csrc/ns_device.hip, round 4): rms_norm and silu nodes are recorded, a multiply that consumes the
+recorded result runs ONE kernel writing both tensors; everything else launches the recorded node first.  Every tensor must hold
+the bits the node-by-node kernels write."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dims(t):
+    ne = list(reversed(t.shape)) + [1] * (4 - t.dim())
+    nb, s = [], 4
+    for e in ne:
+        nb.append(s)
+        s *= e
+    return (C.c_longlong * 4)(*ne), (C.c_longlong * 4)(*nb)
+
+
+def _mul(L, fn, a, b, d, st, is_mul=None):
+    ne0, nb0 = _dims(a)
+    ne1, nb1 = _dims(b)
+    nb1 = (C.c_longlong * 4)(*[0 if (i > 0 and ne1[i] == 1) else nb1[i] for i in range(4)])
+    _, nbd = _dims(d)
+    args = [a.data_ptr(), b.data_ptr(), d.data_ptr(), ne0, nb0, ne1, nb1, nbd, st]
+    return fn(*([is_mul] + args if is_mul is not None else args))
+
+
+@pytest.fixture()
+def fns(L):
+    vp, ll4 = C.c_void_p, C.POINTER(C.c_longlong)
+    L.ns_hip_lazy_flush.restype = C.c_int
+    L.ns_hip_lazy_rms_norm.argtypes = [C.c_int, C.c_int, C.c_float, vp, vp, vp]
+    L.ns_hip_lazy_silu.argtypes = [vp, vp, C.c_size_t, vp]
+    L.ns_hip_lazy_mul.argtypes = [vp, vp, vp, ll4, ll4, ll4, ll4, ll4, vp]
+    L.ns_hip_binary_nd_f32.argtypes = [C.c_int, vp, vp, vp, ll4, ll4, ll4, ll4, ll4, vp]
+    L.ns_hip_layernormalization.argtypes = [C.c_int, C.c_int, C.c_bool, C.c_float, vp, vp, vp]
+    L.ns_hip_silu_f32.argtypes = [vp, vp, C.c_size_t, vp]
+    return L
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 4096), (5, 4096), (3, 5120), (2, 100)])
+def test_norm_then_weight_is_one_launch_with_both_tensors(fns, pkg, rows, cols):
+    import torch
+    L = fns
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(rows + cols)
+    x = torch.randn((rows, cols), generator=g, device="cuda") * 3
+    gam = torch.randn((cols,), generator=g, device="cuda")
+    a_ref, b_ref = torch.empty_like(x), torch.empty_like(x)
+    pkg.check(L.ns_hip_layernormalization(rows, cols, True, 1e-5, x.data_ptr(), a_ref.data_ptr(), st))
+    pkg.check(_mul(L, L.ns_hip_binary_nd_f32, a_ref, gam, b_ref, st, 1))
+    a, b = torch.full_like(x, 7.0), torch.full_like(x, 7.0)
+    pkg.check(L.ns_hip_lazy_rms_norm(rows, cols, 1e-5, x.data_ptr(), a.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert float((a - 7.0).abs().sum()) == 0.0  # recorded, not launched
+    pkg.check(_mul(L, L.ns_hip_lazy_mul, a, gam, b, st))
+    torch.cuda.synchronize()
+    assert torch.equal(a, a_ref) and torch.equal(b, b_ref)
+
+
+def test_silu_then_up_in_either_operand_order(fns, pkg):
+    import torch
+    L = fns
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    gate = torch.randn((3, 11008), generator=g, device="cuda") * 4
+    up = torch.randn((3, 11008), generator=g, device="cuda")
+    s_ref, p_ref = torch.empty_like(gate), torch.empty_like(gate)
+    pkg.check(L.ns_hip_silu_f32(gate.data_ptr(), s_ref.data_ptr(), gate.numel(), st))
+    pkg.check(_mul(L, L.ns_hip_binary_nd_f32, s_ref, up, p_ref, st, 1))
+    for silu_first in (True, False):
+        s, p = torch.full_like(gate, 7.0), torch.full_like(gate, 7.0)
+        pkg.check(L.ns_hip_lazy_silu(gate.data_ptr(), s.data_ptr(), gate.numel(), st))
+        pkg.check(_mul(L, L.ns_hip_lazy_mul, s, up, p, st) if silu_first else _mul(L, L.ns_hip_lazy_mul, up, s, p, st))
+        torch.cuda.synchronize()
+        assert torch.equal(s, s_ref) and torch.equal(p, p_ref), silu_first
+
+
+def test_anything_else_launches_the_recorded_node_first(fns, pkg):
+    import torch
+    L = fns
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((2, 4096), generator=g, device="cuda")
+    other = torch.randn((2, 4096), generator=g, device="cuda")
+    a_ref = torch.empty_like(x)
+    pkg.check(L.ns_hip_layernormalization(2, 4096, True, 1e-6, x.data_ptr(), a_ref.data_ptr(), st))
+    # an add that reads the normalised tensor; a multiply by an unrelated tensor; a flush on its own; a recorded node replaced by another
+    a, d = torch.full_like(x, 7.0), torch.empty_like(x)
+    pkg.check(L.ns_hip_lazy_rms_norm(2, 4096, 1e-6, x.data_ptr(), a.data_ptr(), st))
+    pkg.check(_mul(L, L.ns_hip_binary_nd_f32, a, other, d, st, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(a, a_ref) and torch.equal(d, a_ref + other)
+    a.fill_(7.0)
+    pkg.check(L.ns_hip_lazy_rms_norm(2, 4096, 1e-6, x.data_ptr(), a.data_ptr(), st))
+    pkg.check(_mul(L, L.ns_hip_lazy_mul, other, other, d, st))  # does not consume the recorded node
+    torch.cuda.synchronize()
+    assert torch.equal(a, a_ref) and torch.equal(d, other * other)
+    a.fill_(7.0)
+    pkg.check(L.ns_hip_lazy_rms_norm(2, 4096, 1e-6, x.data_ptr(), a.data_ptr(), st))
+    assert L.ns_hip_lazy_flush() == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, a_ref)
+    a.fill_(7.0)
+    s = torch.empty_like(x)
+    pkg.check(L.ns_hip_lazy_rms_norm(2, 4096, 1e-6, x.data_ptr(), a.data_ptr(), st))
+    pkg.check(L.ns_hip_lazy_silu(x.data_ptr(), s.data_ptr(), x.numel(), st))  # records silu, launches the norm
+    L.bestla_device_sync.argtypes = [C.c_void_p]
+    L.bestla_device_sync(st)  # launches the silu
+    assert torch.equal(a, a_ref) and torch.equal(s, x / (1 + torch.exp(-x)) ) or torch.allclose(s, torch.nn.functional.silu(x), rtol=1e-6, atol=1e-7)
