@@ -240,9 +240,17 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
 #ifndef NS_ATTN_U
 #define NS_ATTN_U 4
 #endif
-  constexpr int U = G * DPL <= 16 ? NS_ATTN_U : (G * DPL <= 64 ? 2 : 1);  // register budget: acc and q are G x DPL each (8: no gain)
-  for (int jb = j0 + kg; jb < j1; jb += 16 * U) {
-    half8_t kv[U][DPL / 8], vv[U][DPL / 8];
+  // NS_ATTN_DB=1 (round 4, measured and NOT adopted): two register sets, the rows of step s + 1 requested BEFORE step s is computed, half as
+  // many keys per step.  The stream alone is 8.4 us of this kernel's ~10.8 (-DNS_ATTN_ABL=1), the steps' arithmetic sits between
+  // their request batches — yet requesting ahead is SLOWER: split + merge 15.5 us against 14.4 on one box (profiles/r04bb_*), with 4
+  // keys per step as well.  Like the decode GEMV, this kernel loses when more requests are in flight earlier.
+#ifndef NS_ATTN_DB
+#define NS_ATTN_DB 0
+#endif
+  constexpr int U0 = G * DPL <= 16 ? NS_ATTN_U : (G * DPL <= 64 ? 2 : 1);  // register budget: acc and q are G x DPL each (8: no gain)
+  constexpr int U = NS_ATTN_DB ? (U0 > 1 ? U0 / 2 : 1) : U0;
+  typedef half8_t KvRows[U][DPL / 8];
+  auto request = [&](int jb, KvRows& kv, KvRows& vv) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int j = jb + 16 * u;
@@ -262,6 +270,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
         }
       }
     }
+  };
+  auto consume = [&](int jb, const KvRows& kv, const KvRows& vv) {
+#if defined(NS_ATTN_ABL) && NS_ATTN_ABL == 1  // timing ablation (diagnostic builds): the K / V stream alone
+#pragma unroll
+    for (int u = 0; u < U; u++) acc[0][0] += float(kv[u][0][0]) + float(vv[u][0][0]);
+    m[0] = 0.f, lsum[0] = 1.f;
+    return;
+#endif
 #pragma unroll
     for (int g = 0; g < G; g++) {
       float s[U];
@@ -303,6 +319,27 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
         acc[g][e] = a2;
       }
       m[g] = m_new;
+    }
+  };
+  {
+    KvRows kvA, vvA, kvB, vvB;
+    int jb = j0 + kg;
+    if (jb < j1) request(jb, kvA, vvA);
+    while (jb < j1) {
+      int jn = jb + 16 * U;
+      if (NS_ATTN_DB && jn < j1) request(jn, kvB, vvB);
+      consume(jb, kvA, vvA);
+      jb = jn;
+      if (jb >= j1) break;
+      jn = jb + 16 * U;
+      if (NS_ATTN_DB) {
+        if (jn < j1) request(jn, kvA, vvA);
+        consume(jb, kvB, vvB);
+      } else {
+        request(jb, kvA, vvA);
+        continue;
+      }
+      jb = jn;
     }
   }
 
