@@ -840,7 +840,11 @@ constexpr int a2_stage_bytes() { return kA2KB * HS * 2 + (HS / 16) * kA2VSub; }
 
 // SB: the scores are biased before the softmax — ALiBi (+ key position x the head's slope, mha_dense_wrapper.h:1418-1447) and / or the
 // 30 tanh(s / 30) soft cap — as attn_split_kernel applies them; a separate instantiation, the plain kernel's loop is unchanged.
-template <int HS, bool SB, bool PAD>
+// RG: 32-row groups per wave.  1 is what ships.  2 (256 query rows per workgroup: every K / V operand read from LDS feeds two MFMAs, the
+// tile traffic is spread over twice the rows; all 512 registers, one wave per SIMD) was built, is correct (the whole attention suite and the
+// shape fuzz pass on it) and is SLOWER: 4096 tokens 0.484 vs 0.268 ms, 8192 1.44 vs 0.85, 16384 4.89 vs 2.95 (profiles/r04bg_*) — two
+// co-resident waves per SIMD hide more than halving the LDS traffic saves, and the 128-wide form spills 24 registers.
+template <int HS, bool SB, bool PAD, int RG = 1>
 __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int nqb, const int aligned_dst, const int xcd_map) {
   constexpr int NJ = HS / 16, NDT = HS / 32, NCH = HS / 8, KROW = HS * 2, NSUB = HS / 16;
   constexpr int KTILE = kA2KB * KROW, STAGE = a2_stage_bytes<HS>();
@@ -874,7 +878,8 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
   const int ihn = hb % p.head_num, ibs = hb / p.head_num;
   const int ihkv = ihn / (p.head_num / p.heads_kv);
   const int off = p.sl_kv - p.sl_q;
-  const int q0 = qblk * 128 + w * 32;
+  constexpr int WGR = 128 * RG;  // query rows per workgroup
+  const int q0 = qblk * WGR + w * (32 * RG);
   const float* qb = p.q + ibs * p.step_q_bs + ihn * p.step_q_head_num;
   const _Float16* kb = p.k + ibs * p.step_k_bs + ihkv * p.step_k_head_num;
   const _Float16* vb = p.v + ibs * p.step_v_bs + ihkv * p.step_v_head_num;
@@ -884,20 +889,22 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
   // query dims, K / V chunks and output dims from hs on are zeros / never stored (head sizes 80, 96, 112, 160, 192 ... ride on the
   // next size up; a separate instantiation: the predicates cost the exact sizes a third of their speed)
   const int hs = PAD ? p.head_size : HS;
-  ahalf8_t qf[NJ];
-  {
-    const float* qr = qb + (long long)min(q0 + n, p.sl_q - 1) * p.step_q_sl + 8 * h;
+  ahalf8_t qf[RG][NJ];
+  afloatx16 o[RG][NDT];
+  float m_run[RG], l_run[RG];  // l_run: this lane's half of the row sum
+#pragma unroll
+  for (int rg = 0; rg < RG; rg++) {
+    const float* qr = qb + (long long)min(q0 + 32 * rg + n, p.sl_q - 1) * p.step_q_sl + 8 * h;
 #pragma unroll
     for (int j = 0; j < NJ; j++)
 #pragma unroll
-      for (int i = 0; i < 8; i++) qf[j][i] = 16 * j + 8 * h < hs ? (_Float16)qr[16 * j + i] : (_Float16)0.f;
+      for (int i = 0; i < 8; i++) qf[rg][j][i] = 16 * j + 8 * h < hs ? (_Float16)qr[16 * j + i] : (_Float16)0.f;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) o[rg][dt][i] = 0.f;
+    m_run[rg] = -INFINITY, l_run[rg] = 0.f;
   }
-  afloatx16 o[NDT];
-#pragma unroll
-  for (int dt = 0; dt < NDT; dt++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) o[dt][i] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;  // l_run: this lane's half of the row sum
   const float sc = SB ? 1.f : p.qk_scale * 1.4426950408889634f;  // scores in the exp2 domain (SB: the biased scores are scaled up front)
   float slope = 0.f;
   const bool tanh30 = SB && (p.flags & NS_ATTN_FLAG_IS_TANH30) != 0;
@@ -905,11 +912,13 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
     const int gh = ihn + p.alibi_head_off;
     slope = gh < p.alibi_log2_floor ? powf(p.alibi_m0, float(gh + 1)) : powf(p.alibi_m1, float(2 * (gh - p.alibi_log2_floor) + 1));
   }
-  const int q_last_wg = min(qblk * 128 + 127, p.sl_q - 1);
+  const int q_last_wg = min(qblk * WGR + WGR - 1, p.sl_q - 1);
   const int kv_end = causal ? min(p.sl_kv, q_last_wg + off + 1) : p.sl_kv;                     // workgroup-uniform
-  const int visible = min(p.sl_kv, causal ? min(q0 + n, p.sl_q - 1) + off + 1 : p.sl_kv);      // mha_dense_wrapper.h:1440-1441
+  int visible[RG];                                                                             // mha_dense_wrapper.h:1440-1441
+#pragma unroll
+  for (int rg = 0; rg < RG; rg++) visible[rg] = min(p.sl_kv, causal ? min(q0 + 32 * rg + n, p.sl_q - 1) + off + 1 : p.sl_kv);
   const int vis_first = min(p.sl_kv, causal ? q0 + off + 1 : p.sl_kv);                          // the wave's first row
-  const int vis_last = min(p.sl_kv, causal ? min(q0 + 31, p.sl_q - 1) + off + 1 : p.sl_kv);    // the wave's last row
+  const int vis_last = min(p.sl_kv, causal ? min(q0 + 32 * RG - 1, p.sl_q - 1) + off + 1 : p.sl_kv);  // the wave's last row
   const bool wave_live = q0 < p.sl_q;
 
   // ---- tile staging: global -> registers -> LDS ----
@@ -991,11 +1000,13 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
     if (wave_live && pos0 < vis_last) {
       // operands travel LDS -> registers one group of four MFMAs ahead of their use (two register sets, fenced: left alone hipcc
       // re-uses ONE operand register and serialises read -> wait -> MFMA, ~100 exposed cycles per MFMA)
-      afloatx16 sv[2];
+      afloatx16 sv[RG][2];
 #pragma unroll
-      for (int T = 0; T < 2; T++)
+      for (int rg = 0; rg < RG; rg++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) sv[T][i] = 0.f;
+        for (int T = 0; T < 2; T++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) sv[rg][T][i] = 0.f;
       {
         constexpr int CPT = NJ / 4, NCK = 2 * CPT;  // groups per 32-key tile, groups per block
         ahalf8_t kf[2][4];
@@ -1012,27 +1023,31 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < 4; u++)
-            sv[c / CPT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c & 1][u], qf[(c % CPT) * 4 + u], sv[c / CPT], 0, 0, 0);
+#pragma unroll
+            for (int rg = 0; rg < RG; rg++)
+              sv[rg][c / CPT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c & 1][u], qf[rg][(c % CPT) * 4 + u], sv[rg][c / CPT], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       // softmax in the exp2 domain on the raw scores (sc > 0: the launcher sends other scales to the 64-row kernel): p = exp2(s sc - m sc)
       // is one fused multiply-add and one v_exp_f32 per score; the running maximum is kept unscaled
-      ahalf8_t pf[4];  // (T, s) -> 2 T + s
+      ahalf8_t pf[RG][4];  // (T, s) -> 2 T + s
+#pragma unroll
+      for (int rg = 0; rg < RG; rg++) {
 #if NS_A2_ABL == 1
 #pragma unroll
-      for (int e = 0; e < 32; e++) pf[e >> 3][e & 7] = (_Float16)sv[e >> 4][e & 15];
-      l_run += 1.f;
+      for (int e = 0; e < 32; e++) pf[rg][e >> 3][e & 7] = (_Float16)sv[rg][e >> 4][e & 15];
+      l_run[rg] += 1.f;
 #else
       if constexpr (SB) {
 #pragma unroll
         for (int e = 0; e < 32; e++) {
           const int i = e & 15;
           const int pos = pos0 + 32 * (e >> 4) + (i & 3) + 8 * (i >> 2) + 4 * h;
-          float v = sv[e >> 4][i] * p.qk_scale;
+          float v = sv[rg][e >> 4][i] * p.qk_scale;
           if (tanh30) v = 30.f * tanhf(v * (1.f / 30.f));
           v += float(pos) * slope;
-          sv[e >> 4][i] = v * 1.4426950408889634f;
+          sv[rg][e >> 4][i] = v * 1.4426950408889634f;
         }
       }
       if (pos0 + kA2KB > vis_first) {  // wave-uniform: only tiles on the diagonal / past the last key are masked
@@ -1040,32 +1055,33 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
         for (int e = 0; e < 32; e++) {
           const int i = e & 15;
           const int pos = pos0 + 32 * (e >> 4) + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (pos >= visible) sv[e >> 4][i] = -INFINITY;
+          if (pos >= visible[rg]) sv[rg][e >> 4][i] = -INFINITY;
         }
       }
-      float mx = sv[0][0];
+      float mx = sv[rg][0][0];
 #pragma unroll
-      for (int e = 1; e < 32; e++) mx = fmaxf(mx, sv[e >> 4][e & 15]);
+      for (int e = 1; e < 32; e++) mx = fmaxf(mx, sv[rg][e >> 4][e & 15]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
+      const float m_new = fmaxf(m_run[rg], mx);
       const float neg_m = m_new == -INFINITY ? 0.f : -m_new * sc;  // nothing visible yet: every exp2 below is exp2(-inf) = 0
-      const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, sc, neg_m));
+      const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[rg], sc, neg_m));
       float ps = 0.f;
 #pragma unroll
       for (int e = 0; e < 32; e++) {
-        const float pe = __builtin_amdgcn_exp2f(fmaf(sv[e >> 4][e & 15], sc, neg_m));
+        const float pe = __builtin_amdgcn_exp2f(fmaf(sv[rg][e >> 4][e & 15], sc, neg_m));
         ps += pe;
-        pf[e >> 3][e & 7] = (_Float16)pe;
+        pf[rg][e >> 3][e & 7] = (_Float16)pe;
       }
-      l_run = l_run * alpha + ps;
-      m_run = m_new;
+      l_run[rg] = l_run[rg] * alpha + ps;
+      m_run[rg] = m_new;
       if (__any(alpha != 1.f)) {
 #pragma unroll
         for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
-          for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
+          for (int i = 0; i < 16; i++) o[rg][dt][i] *= alpha;
       }
 #endif
+      }
       {
         ahalf8_t vf[2][4];
         auto ldv = [&](int dt, ahalf8_t(&dst)[4]) {
@@ -1083,7 +1099,9 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
           if (dt + 1 < NDT) ldv(dt + 1, vf[(dt + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ts = 0; ts < 4; ts++) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt & 1][ts], pf[ts], o[dt], 0, 0, 0);
+          for (int ts = 0; ts < 4; ts++)
+#pragma unroll
+            for (int rg = 0; rg < RG; rg++) o[rg][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt & 1][ts], pf[rg][ts], o[rg][dt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1091,9 +1109,11 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
     if (b + 1 < nb && NS_A2_ABL < 4) park((b + 1) & 1);
     if (NS_A2_ABL < 5) __syncthreads();
   }
-  l_run += __shfl_xor(l_run, 32, 64);
-  const float inv = l_run > 0.f ? p.out_scale / l_run : 0.f;
-  const int row = q0 + n;
+#pragma unroll
+  for (int rg = 0; rg < RG; rg++) {
+  l_run[rg] += __shfl_xor(l_run[rg], 32, 64);
+  const float inv = l_run[rg] > 0.f ? p.out_scale / l_run[rg] : 0.f;
+  const int row = q0 + 32 * rg + n;
   if (row < p.sl_q) {
     float* dr = db + (long long)row * p.step_dst_sl;
 #pragma unroll
@@ -1102,7 +1122,7 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
       for (int bq = 0; bq < 4; bq++) {
         const int d = 32 * dt + 8 * bq + 4 * h;
         if (PAD && d >= hs) continue;
-        const afloatx4 y = afloatx4{o[dt][4 * bq] * inv, o[dt][4 * bq + 1] * inv, o[dt][4 * bq + 2] * inv, o[dt][4 * bq + 3] * inv};
+        const afloatx4 y = afloatx4{o[rg][dt][4 * bq] * inv, o[rg][dt][4 * bq + 1] * inv, o[rg][dt][4 * bq + 2] * inv, o[rg][dt][4 * bq + 3] * inv};
         if (aligned_dst) {
           *reinterpret_cast<afloatx4*>(dr + d) = y;
           if (p.dst16) *reinterpret_cast<ahalf4_t*>(p.dst16 + (dr - p.dst) + d) = ahalf4_t{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
@@ -1116,6 +1136,7 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
       }
     }
   }
+  }
 }
 
 template <int HS, bool SB = false, bool PAD = false>
@@ -1128,7 +1149,6 @@ template <bool SB = false, bool PAD = false>
 __global__ __launch_bounds__(256) void attn_mfma2_hs256_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
   attn_mfma2_body<256, SB, PAD>(p, nqb, aligned_dst, xcd_map);
 }
-
 static std::atomic<int> g_alibi_heads{0}, g_alibi_off{0};  // ns_hip_attn_set_head_partition
 
 static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipStream_t st, std::string* why,
