@@ -171,10 +171,35 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const
   // one k-step (four slices) of the staged chunk against the records in wc; t = its position in the chunk
   auto kstep = [&](const KRec& wc, int s, int t, const unsigned char* a_lds) {
     const float* sa_lds = reinterpret_cast<const float*>(a_lds + kSaOff);
+    // Slices that share a scale pair (group sizes of 64 and more: NJ / SPS slices per scale of the k-step record) are CHAINED through
+    // the MFMA accumulator — the integer sum of the whole k-block, still exact (<= 4 x 122400 / 4 x 2.1 M < 2^24), scaled ONCE: the
+    // reference's own order (one int32 sum per k-block, bestla_wrapper.h:768-831) and a quarter of the fp32 work at g128.
+    constexpr int JG = SPS >= NJ ? 1 : NJ / SPS;  // slices per scale group inside a k-step record
+    floatx4 dch[RH][CT][4];
+    floatx4 sa_g[RH][4];
+    float sb_g[CT];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
       const int k0 = s * KS + 32 * j;
-      if (k0 >= p.k) continue;
+      const bool first = j % JG == 0, last = j % JG == JG - 1;
+      if (k0 >= p.k) {
+        if constexpr (JG > 1) {  // (wave-uniform) a group cut short by K: what it holds so far is scaled now
+          if (!first && (s * KS + 32 * (j - 1)) < p.k) {
+#pragma unroll
+            for (int h = 0; h < RH; h++)
+#pragma unroll
+              for (int ct = 0; ct < CT; ct++) {
+                const float2v sb2 = {sb_g[ct], sb_g[ct]};
+#pragma unroll
+                for (int rt = 0; rt < 4; rt++) {
+                  acc[h][ct][rt][0] = __builtin_elementwise_fma(float2v{dch[h][ct][rt].x, dch[h][ct][rt].y}, float2v{sa_g[h][rt].x, sa_g[h][rt].y} * sb2, acc[h][ct][rt][0]);
+                  acc[h][ct][rt][1] = __builtin_elementwise_fma(float2v{dch[h][ct][rt].z, dch[h][ct][rt].w}, float2v{sa_g[h][rt].z, sa_g[h][rt].w} * sb2, acc[h][ct][rt][1]);
+                }
+              }
+          }
+        }
+        continue;
+      }
       const int q = t * NJ + j;
       const int e = (j * SPS) / NJ;  // a constant once the loops are unrolled
       half8_t b[CT];
@@ -235,7 +260,14 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 4) void i8mfma2_kernel(const
           const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
           floatx4 d[4];
 #pragma unroll
-          for (int rt = 0; rt < 4; rt++) d[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b[ct], zero, 0, 0, 0);
+          for (int rt = 0; rt < 4; rt++)
+            d[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], b[ct], (JG > 1 && !first) ? dch[h][ct][rt] : zero, 0, 0, 0);
+          if (JG > 1 && !last) {  // compile-time once unrolled: the group goes on with the next slice
+#pragma unroll
+            for (int rt = 0; rt < 4; rt++) dch[h][ct][rt] = d[rt], sa_g[h][rt] = sa[rt];
+            sb_g[ct] = sb[ct];
+            continue;
+          }
           const float2v sb2 = {sb[ct], sb[ct]};
 #pragma unroll
           for (int rt = 0; rt < 4; rt++) {

@@ -92,9 +92,19 @@ def test_int8_mode_both_matrix_core_kernels_return_the_same_bits(L, pkg, nso, in
     finally:
         L.ns_hip_set_tuning(b"i8_mfma", 2)
         L.ns_hip_set_tuning(b"i8_tile", 0)
+    # one scale per 32-deep slice (group 32): the same expression in the same order, bit for bit.  Wider groups: the second kernel
+    # chains the group's slices through the MFMA accumulator and scales the k-block's exact integer sum ONCE (round 4: the
+    # reference's own order, bestla_wrapper.h:768-831) while the first kernel scales slice by slice — equal to fp32 rounding;
+    # the second kernel's tiles still agree bit for bit with each other.
+    one_scale_per_slice = bs == 32
     for tile in (1, 4):
-        assert np.array_equal(outs[(1, 0)].view(np.uint32), outs[(2, tile)].view(np.uint32)), (tile, np.abs(outs[(1, 0)] - outs[(2, tile)]).max())
-    assert nso.rel_l2(outs[(2, 4)], nso.gemm_u8s8(a, blob)) < 2e-6
+        if one_scale_per_slice:
+            assert np.array_equal(outs[(1, 0)].view(np.uint32), outs[(2, tile)].view(np.uint32)), (tile, np.abs(outs[(1, 0)] - outs[(2, tile)]).max())
+        else:
+            assert nso.rel_l2(outs[(2, tile)], outs[(1, 0)]) < 1e-6
+    assert np.array_equal(outs[(2, 1)].view(np.uint32), outs[(2, 4)].view(np.uint32))
+    ref = nso.gemm_u8s8(a, blob)
+    assert nso.rel_l2(outs[(2, 4)], ref) < 2e-6 and nso.rel_l2(outs[(1, 0)], ref) < 2e-6
 
 
 def test_int8_mode_fused_qkv_at_gemm_size_prepares_the_activations_once(L, pkg, nso, int8_mode):
