@@ -616,16 +616,30 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
   if (!no_split && nsplit >= 2 && (head_size == 64 || head_size == 128 || head_size == 256) && size_t(batch) * seq <= 65535 && heads <= 65535 &&
       (reinterpret_cast<uintptr_t>(dQ) & 15) == 0 && (reinterpret_cast<uintptr_t>(dK) & 15) == 0) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float* ws = static_cast<float*>(ns::stream_scratch(st, rows * nsplit * (2 + head_size) * sizeof(float), 24));
+    // a prompt's rows (batch 1, causal) go through in chunks so that the partials stay within 64 MB of scratch whatever the prompt
+    // length (2048 rows x 32 heads x 16 ranges would be 545 MB, kept for the life of the stream): rows r0 .. r0 + nr of a causal call
+    // are the same call on `nr` rows over the first seq_all - seq + r0 + nr keys
+    const size_t per_row = size_t(heads) * nsplit * (2 + head_size) * sizeof(float);
+    int chunk = seq;
+    if (batch == 1 && masked && size_t(seq) * per_row > (size_t(64) << 20)) chunk = int(std::max<size_t>(1, (size_t(64) << 20) / per_row));
+    float* ws = static_cast<float*>(ns::stream_scratch(st, size_t(batch) * chunk * per_row, 24));
     if (ws) {
-      const dim3 grid(unsigned(nsplit), unsigned(heads), unsigned(batch * seq));
-      if (head_size == 64)
-        hipLaunchKernelGGL(ns::mha_f32_split_kernel<4>, grid, dim3(256), 0, st, dQ, dK, dV, dO, ws, nsplit, seq, seq_all, heads, heads_kv, n_ctx, scale, masked);
-      else if (head_size == 128)
-        hipLaunchKernelGGL(ns::mha_f32_split_kernel<8>, grid, dim3(256), 0, st, dQ, dK, dV, dO, ws, nsplit, seq, seq_all, heads, heads_kv, n_ctx, scale, masked);
-      else
-        hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, dQ, dK, dV, dO, ws, nsplit, seq, seq_all, heads, heads_kv, n_ctx, scale, masked);
-      hipLaunchKernelGGL(ns::mha_f32_merge_kernel, dim3(unsigned(rows)), dim3(unsigned(head_size)), 0, st, ws, dO, nsplit, head_size);
+      for (int r0 = 0; r0 < seq; r0 += chunk) {
+        const int nr = std::min(chunk, seq - r0);
+        const int sa = chunk == seq ? seq_all : seq_all - seq + r0 + nr;  // keys this chunk's last row sees
+        const int ns_c = (sa + ns::kMhaKS - 1) / ns::kMhaKS;
+        const float* q_c = dQ + size_t(r0) * heads * head_size;
+        float* o_c = dO + size_t(r0) * heads * head_size;
+        const dim3 grid(unsigned(ns_c), unsigned(heads), unsigned(batch * nr));
+        if (head_size == 64)
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<4>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked);
+        else if (head_size == 128)
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<8>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked);
+        else
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked);
+        if (ns_c > 1)
+          hipLaunchKernelGGL(ns::mha_f32_merge_kernel, dim3(unsigned(size_t(batch) * nr * heads)), dim3(unsigned(head_size)), 0, st, ws, o_c, ns_c, head_size);
+      }
       if (hipGetLastError() != hipSuccess) {
         ns::set_error("mha_f32: launch failed");
         return -1;

@@ -16,6 +16,7 @@ CASES = [  # batch, seq, seq_all, heads, heads_kv, head_size, n_ctx, masked
     (1, 3, 1001, 4, 2, 128, 1001, 1),     # n_ctx not a multiple of 4: element-wise V reads
     (1, 2, 100, 4, 4, 128, 256, 1),       # one range: the single-workgroup kernel
     (1, 1, 400, 6, 3, 80, 512, 1),        # head size outside the split kernel's set
+    (1, 700, 900, 32, 32, 128, 1024, 1),  # a prompt whose partials would exceed the 64 MB scratch bound: rows go through in two chunks
 ]
 
 
