@@ -366,9 +366,70 @@ bool check_shuffle(const ns_weight* w) {
   return true;
 }
 
+// ---- DQ8_BNB scales (round 4) ---------------------------------------------------------------------------------------------
+// The reference can store a weight's scales double-quantised (StorageWeightKBlockN*::mDqBlockSize != 0, bestla_storage.h:750-759): one
+// u8 code per scale into the bitsandbytes dynamic map + an fp32 maximum per block of `dq_blocksize` scales + one fp32 offset.  At load
+// they are expanded to the fp32 scales its kernels dequantise with (dq8_get_fp_scale, kernel_ref.h:1980-1992); everything behind the
+// load sees an fp32-scale weight.  Readable for the two weight types the reference itself reads them for: S4 and NF4.
+// The map: create_dynamic_map(signed, 7 exponent bits, 8 bits) of bitsandbytes, written with five decimals (bestla_utils.h:791-...).
+const float* dq8_lut_device() {
+  static float* d = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<double> data;
+    for (int i = 0; i < 7; i++) {
+      const int items = 1 << i;
+      const double mag = std::pow(10.0, -6 + i);
+      for (int j = 0; j < items; j++) {
+        const double b0 = 0.1 + 0.9 * double(j) / double(items), b1 = 0.1 + 0.9 * double(j + 1) / double(items);
+        data.push_back(mag * (b0 + b1) / 2.0);
+        data.push_back(-mag * (b0 + b1) / 2.0);
+      }
+    }
+    data.push_back(0.0);
+    data.push_back(1.0);
+    std::sort(data.begin(), data.end());
+    float lut[256];
+    for (int i = 0; i < 256; i++) {
+      char buf[32];
+      snprintf(buf, sizeof(buf), "%.5f", data[size_t(i)]);
+      lut[i] = strtof(buf, nullptr);
+    }
+    if (hipMalloc((void**)&d, sizeof(lut)) != hipSuccess || hipMemcpy(d, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) d = nullptr;
+  });
+  return d;
+}
+// `out` (device, csize floats) <- the expanded scales; v2 = the view the rest of the load works with
+bool dq8_expand(const BlobView& v, const uint8_t* d_codes, const float* d_dq, float* out, BlobView* v2, hipStream_t st) {
+  const bool s4 = v.prologue == 1 && dt_is_int(v.dtype) && dt_bits(v.dtype) == 4, nf4 = v.prologue == 2 && v.dtype == DT_F4_NF4;
+  if (!s4 && !nf4) {
+    set_error("blob: DQ8_BNB scales are read for S4 and NF4 weights only (as in the reference: bestla_prologue_b.h:742-751, :1298-1306)");
+    return false;
+  }
+  const float* lut = dq8_lut_device();
+  if (!lut || !d_dq) {
+    set_error("DQ8_BNB scales: no code map / no double-quantisation section on the device");
+    return false;
+  }
+  const int rows = int(v.csize / uint64_t(v.cstep));
+  if (!hip_ok(launch_dq8_expand(d_codes, d_dq, lut, out, rows, v.cstep, v.n, v.dq_blocksize, uint32_t(v.dq_bytes / 4 - 1), st), "dq8 expand"))
+    return false;
+  *v2 = v;
+  v2->scale_dt = DT_F32;
+  v2->s_bytes = v.csize * 4;
+  v2->dq_bytes = 0, v2->dq_off = 0;
+  return true;
+}
+
 // sections already in device memory -> device weight
-ns_weight* weight_from_device_sections(const BlobView& v, const uint8_t* dq, const uint8_t* ds, const int8_t* dz,
-                                       hipStream_t st) {
+ns_weight* weight_from_device_sections(const BlobView& v_in, const uint8_t* dq, const uint8_t* ds, const int8_t* dz,
+                                       hipStream_t st, const float* d_dqsec = nullptr) {
+  BlobView v = v_in;
+  DevBuf<float> dq8_scales;  // lives until the synchronisation at the end of this function
+  if (v_in.scale_dt == DT_DQ8_BNB) {
+    if (!dq8_scales.alloc(size_t(v_in.csize)) || !dq8_expand(v_in, ds, d_dqsec, dq8_scales.p, &v, st)) return nullptr;
+    ds = reinterpret_cast<const uint8_t*>(dq8_scales.p);
+  }
   ns_weight* w = new ns_weight();
   if (!plan_weight(v, w) || !alloc_weight(w)) {
     ns_hip_weight_free(w);
@@ -716,7 +777,11 @@ ns_weight* ns_hip_weight_from_blob(const void* host_blob, void* stream) {
     if (!dz.alloc(v.z_bytes)) return nullptr;
     if (!hip_ok(hipMemcpyAsync(dz.p, base + v.z_off, v.z_bytes, hipMemcpyHostToDevice, st), "H2D zps")) return nullptr;
   }
-  ns_weight* w = weight_from_device_sections(v, dq.p, ds.p, dz.p, st);
+  DevBuf<float> ddq;
+  if (v.dq_bytes && (!ddq.alloc(size_t(v.dq_bytes / 4)) ||
+                     !hip_ok(hipMemcpyAsync(ddq.p, base + v.dq_off, v.dq_bytes, hipMemcpyHostToDevice, st), "H2D double-quantisation section")))
+    return nullptr;
+  ns_weight* w = weight_from_device_sections(v, dq.p, ds.p, dz.p, st, ddq.p);
   if (w && v.shuf_bytes &&
       (!hip_ok(hipMalloc((void**)&w->shuf, v.shuf_bytes), "hipMalloc(shuffle)") ||
        !hip_ok(hipMemcpy(w->shuf, base + v.shuf_off, v.shuf_bytes, hipMemcpyHostToDevice), "H2D shuffle") ||
@@ -752,6 +817,11 @@ ns_weight* ns_hip_weight_load_async(const void* host_blob, void* dst, uint64_t d
   if (!blob_parse(host_blob, &v, &err)) {
     set_error(err);
     return nullptr;
+  }
+  if (v.scale_dt == DT_DQ8_BNB) {  // double-quantised scales: the synchronous load (own allocation; nothing is left pending)
+    ns_weight* ws = ns_hip_weight_from_blob(host_blob, stream);
+    if (ws && pinned_info) pinned_info[0] = 0, pinned_info[1] = 0;
+    return ws;
   }
   auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t need = pad(v.q_bytes) + pad(v.s_bytes) + pad(v.z_bytes);
@@ -800,6 +870,7 @@ ns_weight* ns_hip_weight_load_async(const void* host_blob, void* dst, uint64_t d
 
 int ns_hip_weight_finish_load(ns_weight* w, const uint32_t* info) {
   if (!w || !info) return -1;
+  if (!w->load_pending) return 0;  // loaded synchronously (double-quantised scales): nothing to finish
   w->load_pending = false;
   if (info[1]) {
     set_error("F8_E5M2 blob holds codes with exponent field 31 (beyond the reference quantizer's max_norm and fp16)");
@@ -841,7 +912,8 @@ ns_weight* ns_hip_weight_from_device_blob(const void* dev_blob, size_t blob_byte
     return nullptr;
   }
   ns_weight* w = weight_from_device_sections(v, base + v.q_off, base + v.s_off,
-                                             v.asym() ? (const int8_t*)(base + v.z_off) : nullptr, st);
+                                             v.asym() ? (const int8_t*)(base + v.z_off) : nullptr, st,
+                                             v.dq_bytes ? reinterpret_cast<const float*>(base + v.dq_off) : nullptr);
   if (w && v.shuf_bytes &&
       (!hip_ok(hipMalloc((void**)&w->shuf, v.shuf_bytes), "hipMalloc(shuffle)") ||
        !hip_ok(hipMemcpy(w->shuf, base + v.shuf_off, v.shuf_bytes, hipMemcpyDeviceToDevice), "D2D shuffle") ||

@@ -117,10 +117,9 @@ bool traverse(HeaderIO& io, BlobView& v, std::string* err) {
   io.section(v.s_bytes, v.s_off);
   io.optional_section(v.z_bytes, v.z_off);
   io.optional_section(v.r_bytes, v.r_off);
-  uint64_t dq_bytes = 0, dq_off = 0;
-  io.optional_section(dq_bytes, dq_off);
-  if (dq_bytes) {
-    if (err) *err = "blob: DQ8_BNB double-quantized scales are not supported";
+  io.optional_section(v.dq_bytes, v.dq_off);
+  if ((v.dq_bytes != 0) != (v.scale_dt == DT_DQ8_BNB) || (v.dq_bytes && (v.dq_blocksize <= 0 || v.dq_bytes % 4 != 0 || v.dq_bytes < 8))) {
+    if (err) *err = "blob: DQ8_BNB scales and the double-quantisation section do not go together";
     return false;
   }
   io.optional_section(v.shuf_bytes, v.shuf_off);

@@ -19,6 +19,7 @@ constexpr uint32_t DT_F4_E2M1 = 4, DT_F4_BNB = 4 | (1u << 16), DT_F4_NF4 = 4 | (
 __host__ __device__ inline int dt_bits(uint32_t t) { return int(t & 0xff); }
 __host__ __device__ inline bool dt_is_int(uint32_t t) { return ((t >> 8) & 0xff) == 1; }
 constexpr uint32_t DT_F8_E4M3 = 8, DT_F8_E5M2 = 8 | (1u << 16), DT_F8_E8M0 = 8 | (3u << 16);
+constexpr uint32_t DT_DQ8_BNB = 8 | (4u << 16);  // scale dtype: u8 codes into the bitsandbytes dynamic map, double-quantised (bestla.h:72)
 inline bool dt_is_f4(uint32_t t) { return t == DT_F4_E2M1 || t == DT_F4_BNB || t == DT_F4_NF4; }
 __host__ __device__ inline bool dt_is_f8(uint32_t t) { return t == DT_F8_E4M3 || t == DT_F8_E5M2; }
 
@@ -46,6 +47,7 @@ struct BlobView {
   // section offsets (bytes from blob base) and sizes; 0 size = absent
   uint64_t q_off = 0, q_bytes = 0, s_off = 0, s_bytes = 0, z_off = 0, z_bytes = 0, r_off = 0, r_bytes = 0,
            shuf_off = 0, shuf_bytes = 0;
+  uint64_t dq_off = 0, dq_bytes = 0;  // DQ8_BNB scales: fp32 maxima per dq block of the scale codes + the offset as the last float
   int ntile() const { return int(core_id & 0xff); }
   int packrow() const { return int((core_id >> 8) & 0xff); }
   int comp() const { return int((core_id >> 16) & 0xffff); }
@@ -135,6 +137,10 @@ struct RepackArgs {
   uint32_t* flags = nullptr;  // device word, OR-ed with 1 when an E5M2 code lies outside fp16's range
 };
 hipError_t launch_repack(const RepackArgs& a, ns_weight* w, hipStream_t st);
+// DQ8_BNB scale codes [rows][cstep] -> fp32 scales of the same shape: lut[code] * dq[(row * n + col) / dq_blocksize] + dq[dq_last]
+// (dq8_get_fp_scale, kernel_ref.h:1980-1992 as bestla_prologue_b.h:699-707 calls it); `lut` = 256 floats on the device
+hipError_t launch_dq8_expand(const uint8_t* codes, const float* dq, const float* lut, float* out, int rows, int cstep, int n, int dq_blocksize,
+                             uint32_t dq_last, hipStream_t st);
 // max |scale| over a reference scale section (finite values only), as fp32 bits, atomically max-ed into *out_bits
 hipError_t launch_scale_absmax(const void* scales, size_t count, uint32_t scale_dt, uint32_t* out_bits, hipStream_t st);
 

@@ -513,6 +513,26 @@ hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, 
   return hipGetLastError();
 }
 
+// DQ8_BNB scale codes -> fp32 scales (ns_api.cpp dq8_expand)
+__global__ void dq8_expand_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ dq, const float* __restrict__ lut,
+                                  float* __restrict__ out, int rows, int cstep, int n, int dq_blocksize, uint32_t dq_last) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= size_t(rows) * cstep) return;
+  const int r = int(gid / cstep), c = int(gid % cstep);
+  const size_t b = (size_t(r) * n + c) / size_t(dq_blocksize);
+  // separately rounded product and sum, like the reference's scalar expression (this file is compiled with -ffp-contract=off: a fused
+  // multiply-add differs in the last bit for one scale in five); padded columns (c >= n) take any block: never used
+  out[gid] = __fadd_rn(__fmul_rn(lut[codes[gid]], dq[b < dq_last ? b : dq_last]), dq[dq_last]);
+}
+hipError_t launch_dq8_expand(const uint8_t* codes, const float* dq, const float* lut, float* out, int rows, int cstep, int n, int dq_blocksize,
+                             uint32_t dq_last, hipStream_t st) {
+  const size_t total = size_t(rows) * cstep;
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(dq8_expand_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, codes, dq, lut, out, rows, cstep, n, dq_blocksize,
+                     dq_last);
+  return hipGetLastError();
+}
+
 // norm and the product with the norm weight in one launch, BOTH tensors written (plain = norm(in), out = plain * gamma): same values
 // as launch_rmsnorm(in -> plain) followed by the row-broadcast multiply
 hipError_t launch_rmsnorm_mul2(int norm_count, int norm_size, bool isrms, float eps, const float* in, float* plain, const float* gamma,

@@ -148,6 +148,10 @@ int ns_bestla_split_weight(const void* src_blob, void* dst_blob, unsigned long l
     set_error("split: range outside the weight");
     return -1;
   }
+  if (v.scale_dt == DT_DQ8_BNB) {  // dq blocks run across rows and columns of the scale array: no exact cut
+    set_error("split: a blob with DQ8_BNB scales needs the re-quantising route");
+    return -2;
+  }
   const int n = n1 - n0, k = k1 - k0;
   const bool per_channel = v.blocksize >= v.kpad;
   if (!per_channel && (k0 % v.blocksize != 0 || (k1 != v.k && k1 % v.blocksize != 0))) {

@@ -12,6 +12,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #ifdef _OPENMP
@@ -220,6 +222,81 @@ inline float round_through_ieee_f16(float f) {
   return r;
 }
 
+// ---- DQ8_BNB: double-quantised scales --------------------------------------------------------------------------------------
+// The code map (bestla_utils.h:794-...) is the bitsandbytes dynamic map create_dynamic_map(signed, 7 exponent bits, 8 bits) written
+// with FIVE decimals; restated as that construction + that rounding and pinned entry by entry to the reference's table
+// (tests/test_oracle_vs_ref.py).
+const float* dq8_lut() {
+  static float lut[256];
+  static bool init = false;
+  if (!init) {
+    std::vector<double> data;
+    const int max_exponent_bits = 7, non_sign_bits = 7;
+    auto add_level = [&](int items, double mag) {  // means of `items` + 1 boundaries linspace(0.1, 1)
+      for (int i = 0; i < items; i++) {
+        const double b0 = 0.1 + (1.0 - 0.1) * double(i) / double(items), b1 = 0.1 + (1.0 - 0.1) * double(i + 1) / double(items);
+        const double mean = (b0 + b1) / 2.0;
+        data.push_back(mag * mean);
+        data.push_back(-mag * mean);
+      }
+    };
+    for (int i = 0; i < max_exponent_bits; i++) add_level((1 << (i + non_sign_bits - max_exponent_bits)), std::pow(10.0, -(max_exponent_bits - 1) + i));
+    data.push_back(0.0);
+    data.push_back(1.0);
+    std::sort(data.begin(), data.end());
+    for (int i = 0; i < 256; i++) {
+      char buf[32];
+      snprintf(buf, sizeof(buf), "%.5f", data[size_t(i)]);
+      lut[i] = strtof(buf, nullptr);
+    }
+    init = true;
+  }
+  return lut;
+}
+// get_dq8_bnb — kernel_ref.h:1930-1950: nearest entry by binary search (ties to the lower index via `<`)
+inline uint8_t dq8_code(float v) {
+  const float* lut = dq8_lut();
+  int left = 0, right = 255;
+  while (left <= right) {
+    const int mid = left + (right - left) / 2;
+    if (lut[mid] == v) return uint8_t(mid);
+    if (lut[mid] < v)
+      left = mid + 1;
+    else
+      right = mid - 1;
+  }
+  if (right < 0) return 0;
+  if (left >= 256) return 255;
+  return uint8_t((v - lut[right] < lut[left] - v) ? right : left);
+}
+// dq8_bnb_double_quant<false> — kernel_ref.h:1951-1978, AS WRITTEN: the scales become their codes (as floats) in place; dq_buf holds a
+// maximum per dq block and the offset (mean of all scales) at index updiv(size, dq_blocksize) — and a trailing partial block writes ITS
+// maximum to that same index + 0 ... i.e. i / dq_blocksize + 1, on top of the offset (the reference's own indexing; sizes that are
+// multiples of the block never get there)
+void dq8_double_quant(float* scale, size_t scale_size, int dq_blocksize, std::vector<float>& dq_buf) {
+  dq_buf.assign(updiv(scale_size, size_t(dq_blocksize)) + 1, 0.f);
+  float offset = 0.f;
+  for (size_t i = 0; i < scale_size; i++) offset += scale[i];
+  offset /= scale_size;
+  dq_buf[updiv(scale_size, size_t(dq_blocksize))] = offset;
+  const size_t align_blk_size = scale_size / dq_blocksize * dq_blocksize;
+  size_t i = 0;
+  auto calc_scale = [&](size_t blksize) {
+    float absmax = std::numeric_limits<float>::min();
+    for (size_t j = 0; j < blksize; j++) {
+      scale[i + j] -= offset;
+      absmax = std::max(absmax, std::abs(scale[i + j]));
+    }
+    for (size_t j = 0; j < blksize; j++) {
+      scale[i + j] /= absmax;
+      scale[i + j] = dq8_code(scale[i + j]);
+    }
+    return absmax;
+  };
+  for (; i < align_blk_size; i += dq_blocksize) dq_buf[i / dq_blocksize] = calc_scale(size_t(dq_blocksize));
+  if (i < scale_size) dq_buf[i / dq_blocksize + 1] = calc_scale(scale_size - i);
+}
+
 inline float scale_to_f32(const uint8_t* sbase, uint32_t stype, size_t idx) {
   if (stype == NSO_F8_E8M0)  // decompress_kblock_f8_fp, kernel_ref.h:1013-1016: scale = pow(2, int8 shared exponent)
     return float(std::pow(2, int(int8_t(sbase[idx]))));
@@ -231,6 +308,17 @@ inline float scale_to_f32(const uint8_t* sbase, uint32_t stype, size_t idx) {
   uint16_t h;
   memcpy(&h, sbase + idx * 2, 2);
   return stype == NSO_BF16 ? nso_bf16_to_f32(h) : nso_f16_to_f32(h);
+}
+// scale of (k-block kb, column c) of a parsed blob.  DQ8_BNB — dq8_get_fp_scale, kernel_ref.h:1980-1992, called from
+// bestla_prologue_b.h:699-707: LUT[code] * dq[(kb * N + c) / dq_blocksize] + dq[last float of the buffer]
+inline float scale_at(const nso_blob_info& bi, const uint8_t* base, int kb, int c) {
+  if (bi.scale_dtype != NSO_DQ8_BNB) return scale_to_f32(base + bi.scale_off, bi.scale_dtype, size_t(kb) * bi.cstep + c);
+  const float* dq = reinterpret_cast<const float*>(base + bi.dq_off);
+  const size_t last = size_t(bi.dq_bytes / 4 - 1);
+  float block, offset;
+  memcpy(&block, dq + std::min((size_t(kb) * bi.n + c) / size_t(bi.dq_blocksize), last), 4);  // (padded columns: any block, never used)
+  memcpy(&offset, dq + last, 4);
+  return dq8_lut()[base[bi.scale_off + size_t(kb) * bi.cstep + c]] * block + offset;
 }
 
 // ---------------------------------------------------------------- blob container — bestla_storage.h
@@ -310,6 +398,9 @@ bool describe(nso_blob_info& bi, int n, int k, int blocksize, uint32_t qtype, ui
   if (!is_int && qtype != NSO_F4_NF4 && qtype != NSO_F4_BNB && qtype != NSO_F4_E2M1 && !dt_is_f8(qtype)) return false;
   if (dt_is_f8(qtype)) {  // quantize_f32_f8_rowblock_mxscale asserts E8M0 or F32 scales (kernel_ref.h:1775-1789)
     if (stype != NSO_F8_E8M0 && stype != NSO_F32) return false;
+  } else if (stype == NSO_DQ8_BNB) {  // initDoubleQuantBlkSize asserts symmetric weights and a block that is a multiple of 8 (bestla_storage.h:755-759)
+    if (asym || blocksize <= 0 || blocksize % 8 != 0) return false;
+    if (qtype != NSO_S4_CLIP && qtype != NSO_F4_NF4) return false;  // what the reference can read back (bestla_prologue_b.h:742-751, :1298-1306)
   } else if (stype != NSO_F32 && stype != NSO_BF16 && stype != NSO_F16) {
     return false;
   }
@@ -332,6 +423,10 @@ bool describe(nso_blob_info& bi, int n, int k, int blocksize, uint32_t qtype, ui
   bi.cstep = bi.npad;
   bi.csize = uint64_t(nk_scale) * bi.npad;
   bi.scale_bytes = bi.csize * dt_bytes(stype);
+  if (stype == NSO_DQ8_BNB) {  // the dq block is the weight block (bestla_storage.h:750, :851); maxima of nk_scale * N codes + the offset
+    bi.dq_blocksize = bi.blocksize;
+    bi.dq_bytes = (updiv(size_t(nk_scale) * n, size_t(bi.dq_blocksize)) + 1) * sizeof(float);
+  }
   if (is_int) {
     bi.zp_dtype = NSO_S8;      // bestla_storage.h:727
     bi.red_dtype = NSO_BF16;   // bestla_gemm.cpp:229,308 (reduce dtype fixed to BF16 by every caller)
@@ -352,7 +447,7 @@ bool describe(nso_blob_info& bi, int n, int k, int blocksize, uint32_t qtype, ui
   auto abuf = [](uint64_t bytes) { return size_t(8 + 8 + bytes + 64); };
   auto obuf = [&](uint64_t bytes) { return size_t(1 + (bytes ? abuf(bytes) : 0)); };
   size_t info = 8 + 4 + 8 + 4 * 4 + 4 + 4 + 4;
-  size_t corr = 4 * 3 + 4 + 8 + abuf(bi.scale_bytes) + obuf(bi.zp_bytes) + obuf(bi.red_bytes) + obuf(0);
+  size_t corr = 4 * 3 + 4 + 8 + abuf(bi.scale_bytes) + obuf(bi.zp_bytes) + obuf(bi.red_bytes) + obuf(bi.dq_bytes);
   size_t total = info + abuf(bi.q_bytes) + corr;
   if (is_int) total += obuf(bi.shuf_bytes);  // NFloat's final mSize leaves the (empty) shuffle flag out, :853-856
   bi.size = padto(total, 64);
@@ -381,9 +476,8 @@ bool walk(Cursor& cur, nso_blob_info& bi) {
   cur.aligned_buf(bi.scale_bytes, bi.scale_off);
   cur.optional_buf(bi.zp_bytes, bi.zp_off);
   cur.optional_buf(bi.red_bytes, bi.red_off);
-  uint64_t dq_bytes = 0, dq_off = 0;
-  cur.optional_buf(dq_bytes, dq_off);
-  if (dq_bytes) return false;  // DQ8_BNB double-quant scales: not restated
+  cur.optional_buf(bi.dq_bytes, bi.dq_off);
+  if (!cur.write && (bi.dq_bytes != 0) != (bi.scale_dtype == NSO_DQ8_BNB)) return false;
   cur.optional_buf(bi.shuf_bytes, bi.shuf_off);
   if (!cur.write) {
     bi.ntile = int(bi.core_id & 0xff);
@@ -683,6 +777,8 @@ size_t nso_pack_size(int n, int k, int blocksize, uint32_t qtype, uint32_t stype
   return bi.size;
 }
 
+const float* nso_dq8_lut(void) { return dq8_lut(); }
+
 int nso_blob_parse(const void* blob, nso_blob_info* info) {
   Cursor cur{(uint8_t*)blob, (uint8_t*)blob, false};
   memset(info, 0, sizeof(*info));
@@ -704,11 +800,22 @@ static int pack_q_impl(void* blob, const int8_t* q, int ldq, const float* scales
   uint8_t* sp = base + bi.scale_off;
   const int sb = dt_bytes(stype);
   memset(sp, 0, bi.scale_bytes);
+  std::vector<float> dq_codes;
+  if (stype == NSO_DQ8_BNB) {  // packQWeight :378-387 / :1109-1116: the raw scale array [rawnk][N] is double-quantised first
+    dq_codes.assign(scales, scales + size_t(rawnk) * n);
+    std::vector<float> dq_buf;
+    dq8_double_quant(dq_codes.data(), dq_codes.size(), bi.dq_blocksize, dq_buf);
+    memset(base + bi.dq_off, 0, bi.dq_bytes);
+    memcpy(base + bi.dq_off, dq_buf.data(), std::min<size_t>(dq_buf.size() * sizeof(float), bi.dq_bytes));
+    scales = dq_codes.data();
+  }
   for (int r = 0; r < std::min(rawnk, nk); r++)
     for (int c = 0; c < n; c++) {
       float s = scales[size_t(r) * n + c];
       size_t idx = size_t(r) * bi.npad + c;
-      if (stype == NSO_F8_E8M0) {  // static_cast<int8_t>(shared exponent), bestla_prologue_b.h:1187
+      if (stype == NSO_DQ8_BNB) {  // static_cast<uint8_t>(code), bestla_prologue_b.h:313-325
+        sp[idx] = uint8_t(s);
+      } else if (stype == NSO_F8_E8M0) {  // static_cast<int8_t>(shared exponent), bestla_prologue_b.h:1187
         sp[idx] = uint8_t(int8_t(s));
       } else if (stype == NSO_F32) {
         memcpy(sp + idx * 4, &s, 4);
@@ -739,7 +846,7 @@ static int pack_q_impl(void* blob, const int8_t* q, int ldq, const float* scales
     for (int c = 0; c < n; c++)
       for (int kb = 0; kb < rawnk; kb++) {
         float tmp = 0.f;
-        float s = scale_to_f32(sp, stype, size_t(kb) * bi.npad + c);
+        float s = scale_at(bi, base, kb, c);
         int z = bi.is_asym ? zps[size_t(kb) * n + c] : 0;
         for (int kk = kb * bi.blocksize; kk < std::min(k, (kb + 1) * bi.blocksize); kk++)
           tmp += float(int(stored[tiled_index(bi, kk, c)]) - z) * s;
@@ -816,7 +923,7 @@ int nso_unpack_canonical(const void* blob, int8_t* q, float* scales, int8_t* zps
   const int nblk = int(updiv(bi.k, bi.blocksize));
   for (int r = 0; r < nblk; r++)
     for (int c = 0; c < bi.n; c++) {
-      scales[size_t(r) * bi.n + c] = scale_to_f32(base + bi.scale_off, bi.scale_dtype, size_t(r) * bi.cstep + c);
+      scales[size_t(r) * bi.n + c] = scale_at(bi, base, r, c);
       if (zps) zps[size_t(r) * bi.n + c] = bi.is_asym ? ((const int8_t*)(base + bi.zp_off))[size_t(r) * bi.cstep + c] : 0;
     }
   return 0;
@@ -932,7 +1039,7 @@ int nso_gemv_f32(const float* a, int lda, const void* blob, float* c, int ldc, i
     const size_t tile_base = size_t(t) * NT * bi.kpad;
     for (int kb = 0; kb * bi.blocksize < bi.k; kb++) {
       for (int j = 0; j < NT; j++) {
-        sc[j] = scale_to_f32(sp, bi.scale_dtype, size_t(kb) * bi.cstep + t * NT + j);
+        sc[j] = scale_at(bi, base, kb, t * NT + j);
         if (zp) zz[j] = zp[size_t(kb) * bi.cstep + t * NT + j];
       }
       const int kend = std::min(bi.k, (kb + 1) * bi.blocksize);
@@ -1061,7 +1168,7 @@ int nso_gemv_u8s8_f32(const float* a, int lda, const void* blob, float* c, int l
     const size_t tile_base = size_t(t) * NT * bi.kpad;
     for (int kb = 0; kb < nblk; kb++) {
       for (int j = 0; j < NT; j++) {
-        sc[j] = scale_to_f32(sp, bi.scale_dtype, size_t(kb) * bi.cstep + t * NT + j);
+        sc[j] = scale_at(bi, base, kb, t * NT + j);
         if (zp) zz[j] = zp[size_t(kb) * bi.cstep + t * NT + j];
       }
       const int kend = std::min(bi.k, (kb + 1) * bi.blocksize);

@@ -42,6 +42,7 @@ enum {
   NSO_F8_E4M3 = 8,              /* weight types of WeightKBlockNFloat besides the f4 family */
   NSO_F8_E5M2 = 8 | (1 << 16),
   NSO_F8_E8M0 = 8 | (3 << 16),  /* scale type: int8 shared exponent, scale = 2^e */
+  NSO_DQ8_BNB = 8 | (4 << 16),  /* scale type: double-quantised scales, u8 codes into the bitsandbytes dynamic map (bestla.h:72) */
 };
 
 /* GEMM cores a blob can be laid out for — neural_speed/core/layers/bestla_defs.h:36-54 */
@@ -72,7 +73,11 @@ typedef struct nso_blob_info {
   int32_t is_asym, has_reduce, has_shuffle;
   /* byte offsets from the blob base (0 = absent) */
   uint64_t q_off, q_bytes, scale_off, scale_bytes, zp_off, zp_bytes, red_off, red_bytes, shuf_off, shuf_bytes;
+  uint64_t dq_off, dq_bytes; /* DQ8_BNB: fp32 block maxima of the scale codes + the offset as the last float (bestla_storage.h:222-229) */
 } nso_blob_info;
+
+/* the 256 values of the DQ8_BNB code map (bestla_utils.h:794-...: the bitsandbytes dynamic map printed with five decimals) */
+const float* nso_dq8_lut(void);
 
 uint64_t nso_core_id(int core);
 int nso_core_attr(int core, int* ntile, int* packrow, int* ktile, int* comp, int* isa);

@@ -22,6 +22,7 @@ F4_NF4 = 4 | (2 << 16)
 F8_E4M3 = 8
 F8_E5M2 = 8 | (1 << 16)
 F8_E8M0 = 8 | (3 << 16)
+DQ8_BNB = 8 | (4 << 16)   # scale dtype: double-quantised scales (bestla.h:72)
 INT_TYPES = {1: S1, 2: S2, 3: S3, 4: S4, 5: S5, 6: S6, 7: S7, 8: S8}
 
 CORE_AVX2, CORE_AVX512F, CORE_AMX_BF16, CORE_AMX_FP16, CORE_AVX512_VNNI_KB, CORE_AVX512BW_KB, CORE_AVX_VNNI_KB, \
@@ -41,7 +42,7 @@ class BlobInfo(C.Structure):
                 ("q_off", C.c_uint64), ("q_bytes", C.c_uint64), ("scale_off", C.c_uint64),
                 ("scale_bytes", C.c_uint64), ("zp_off", C.c_uint64), ("zp_bytes", C.c_uint64),
                 ("red_off", C.c_uint64), ("red_bytes", C.c_uint64), ("shuf_off", C.c_uint64),
-                ("shuf_bytes", C.c_uint64)]
+                ("shuf_bytes", C.c_uint64), ("dq_off", C.c_uint64), ("dq_bytes", C.c_uint64)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -25,6 +25,12 @@ INT_CASES = [(q, s, a, bs) for q in ("S1", "S2", "S3", "S4", "S5", "S6", "S7", "
              (("BF16", False, 32), ("F32", True, 128), ("F16", False, -1))]
 FLT_CASES = [(q, s, False, bs) for q in ("F4_NF4", "F4_BNB", "F4_E2M1") for s, bs in (("BF16", 32), ("F32", 128))] + \
             [(q, s, False, 32) for q in ("F8_E4M3", "F8_E5M2") for s in ("F8_E8M0", "F32")]
+# DQ8_BNB double-quantised scales (round 4): 32: the scale count is a multiple of the dq block; 128: it is not — the trailing
+# block's maximum lands on the offset slot, as the reference's indexing has it (kernel_ref.h:1976)
+# S4 and NF4 weights only: those are the two the reference can read back (bestla_prologue_b.h:742-751, :1298-1306; its packer writes
+# DQ8 scales for other types too, byte-equal to the oracle's, but its own unpack of them is not one)
+DQ_CASES = [("S4", "DQ8_BNB", False, 32), ("S4", "DQ8_BNB", False, 128), ("S4", "DQ8_BNB", False, 64),
+            ("F4_NF4", "DQ8_BNB", False, 32), ("F4_NF4", "DQ8_BNB", False, 128)]
 
 
 def worker(isa):
@@ -43,7 +49,7 @@ def worker(isa):
     for core in range(9):
         assert P.packref_core_id(core) == nso.lib().nso_core_id(core)
         ktile = [1, 1, 32, 32, 4, 4, 4, 4, 64][core]
-        for qn, sn, asym, bs in INT_CASES + FLT_CASES:
+        for qn, sn, asym, bs in INT_CASES + FLT_CASES + DQ_CASES:
             qt, st = getattr(nso, qn), getattr(nso, sn)
             is_flt = qn.startswith("F")
             if isa != "nosimd" and qn.startswith("F4"):
