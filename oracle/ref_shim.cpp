@@ -251,4 +251,7 @@ float ref_postop(float x, int op) {
   return kr::postop(x, op == 0 ? BTLA_ELTWISEOP::GELU : BTLA_ELTWISEOP::SWISH, nullptr);
 }
 
+/* the reference's own DQ8_BNB code map (bestla_utils.h:794-...), for the entry-by-entry pin of the oracle's construction */
+const float* ref_dq8_lut(void) { return bestla::dq8_bnb_LUT; }
+
 }  // extern "C"

@@ -420,3 +420,16 @@ def test_streamed_u8s8_gemv_equals_canonical_form(nso):
         blob = nso.quant_pack(w, bs, q, nso.BF16, asym, core)
         a = rng.standard_normal((3, k)).astype(np.float32)
         assert np.array_equal(nso.gemm_u8s8(a, blob), nso.gemv_u8s8(a, blob, 4))
+
+
+def test_dq8_code_map_equals_the_reference_table(nso, refk):
+    """DQ8_BNB: the oracle BUILDS the 256-entry code map (bitsandbytes' dynamic map printed with five decimals) instead of holding a
+    copy of the reference's table — every entry must be that table's (bestla_utils.h:794-...)"""
+    import ctypes as C
+    refk.ref_dq8_lut.restype = C.POINTER(C.c_float)
+    nso.lib().nso_dq8_lut.restype = C.POINTER(C.c_float)
+    r, o = refk.ref_dq8_lut(), nso.lib().nso_dq8_lut()
+    ref = np.array([r[i] for i in range(256)], np.float32)
+    mine = np.array([o[i] for i in range(256)], np.float32)
+    assert np.array_equal(ref.view(np.uint32), mine.view(np.uint32)), np.argwhere(ref != mine)[:5]
+    assert np.all(np.diff(mine) >= 0) and mine[0] < -0.99 and mine[-1] == 1.0  # (the smallest magnitudes print as 0.00000 / 0.00001: ties)
