@@ -76,3 +76,22 @@ def test_ragged_cuts_and_refusals(S, nso, L):
     assert S.ns_bestla_split_weight(nso.ptr(full), nso.ptr(nso.aligned_bytes(64)), 64, 0, n, 0, k) == -1   # destination too small
     assert S.ns_bestla_split_weight_size(nso.ptr(full), n + 1, k) == 0
     L.ns_hip_reset_error()
+
+
+def test_dq8_scaled_blob_is_parsed_on_the_host_and_not_cut(S, nso, L):
+    """DQ8_BNB scales (round 4): the host-side header parser accepts such a blob (shape query) — it was refused outright before — and
+    the exact cut declines it: dq blocks run across rows and columns of the scale array, so the rank's part is not a byte range"""
+    rng = np.random.default_rng(8)
+    w = (rng.standard_normal((96, 512)) * 0.02).astype(np.float32)
+    blob = nso.quant_pack(w, 32, nso.S4, nso.DQ8_BNB, False, nso.CORE_AVX512F)
+    n, k = C.c_int(0), C.c_int(0)
+    L.ns_blob_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    assert L.ns_blob_shape(nso.ptr(blob), C.byref(n), C.byref(k)) == 0 and (n.value, k.value) == (96, 512)
+    out = nso.aligned_bytes(len(blob))
+    assert S.ns_bestla_split_weight(nso.ptr(blob), nso.ptr(out), len(blob), 0, 48, 0, 512) == -2
+    assert b"DQ8_BNB" in L.ns_hip_last_error()
+    # a blob whose scale dtype says DQ8 but that carries no double-quantisation section is not a blob
+    bi = nso.parse(blob)
+    plain = nso.quant_pack(w, 32, nso.S4, nso.F32, False, nso.CORE_AVX512F)
+    pbi = nso.parse(plain)
+    assert pbi.dq_bytes == 0 and bi.dq_bytes == (96 * 16 // 32 + 1) * 4
