@@ -10,7 +10,9 @@
 //   NS_TP_ID_FILE  path on a filesystem every rank sees (default /tmp/ns_tp_id.<uid>.<launch nonce>): rank 0 removes
 //                  whatever is there, writes {magic, launch nonce, 128-byte RCCL unique id} (O_EXCL, 0600, write +
 //                  rename) and the others wait up to 60 s for a file carrying THEIR launch's nonce
-//   NS_TP_RUN_ID / TORCHELASTIC_RUN_ID  the launcher's run id, part of the nonce (else MASTER_PORT + the parent pid)
+//   NS_TP_RUN_ID / TORCHELASTIC_RUN_ID  the launcher's run id, part of the nonce; without one the nonce mixes in the session id
+//                  and the parent pid (NS_TP_NONCE_NO_PPID=1 drops it for launches behind per-rank wrapper shells)
+//   NS_TP_ID_MAX_AGE_S  how much older than this process an id file may be (default 30 s)
 // With one rank nothing is initialised and every call is the identity.
 //
 // NOTE on `count`: parallel_context.cpp hands it to ccl::allreduce as an ELEMENT count, and so does this file; the
@@ -47,25 +49,50 @@ int env_int(const char* a, const char* b, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-// Per-launch nonce shared by the ranks of ONE launch and by nobody else: the launcher's run id when it exports one
-// (torchrun: TORCHELASTIC_RUN_ID; anything: NS_TP_RUN_ID), mixed with the parent pid on a single node (the ranks of a
-// torchrun / mpirun launch are siblings).  It names the id file and is written into it, so a file left behind by a
-// crashed earlier launch is neither opened by name nor accepted by content (a stale 128-byte id made
-// ncclCommInitRank hang with no time-out).
+// Per-launch nonce shared by the ranks of ONE launch and by nobody else.  It names the id file and is written into it, so a
+// file left behind by a crashed earlier launch is neither opened by name nor accepted by content (a stale
+// 128-byte id made ncclCommInitRank hang with no time-out).  Ingredients:
+//   * the launcher's run id when it exports one (NS_TP_RUN_ID, else a TORCHELASTIC_RUN_ID other than torchrun's default
+//     "none"): unique per launch by contract, nothing else is needed beside it;
+//   * otherwise (MASTER_* + WORLD_SIZE alone are shared by every launch of that shape) the session id and the
+//     PARENT pid — the ranks of a torchrun / mpirun / srun launch on one node are siblings.  Ranks behind per-rank wrapper
+//     shells (`mpirun -n 2 sh -c ...`) have different parents: such launches set NS_TP_RUN_ID, or NS_TP_NONCE_NO_PPID=1 to
+//     drop the parent pid (the failure message says so);
+//   * MASTER_ADDR / MASTER_PORT / world size, whatever the case.
+bool nonce_uses_ppid() {
+  const char* run = getenv("NS_TP_RUN_ID");
+  if (run && *run) return false;
+  const char* te = getenv("TORCHELASTIC_RUN_ID");
+  if (te && *te && strcmp(te, "none") != 0) return false;
+  const char* off = getenv("NS_TP_NONCE_NO_PPID");
+  return !(off && atoi(off) != 0);
+}
 uint64_t launch_nonce() {
   uint64_t h = 1469598103934665603ull;
   auto mix = [&](const char* t) {
     for (; t && *t; t++) h = (h ^ uint64_t(uint8_t(*t))) * 1099511628211ull;
+    h = (h ^ 0xffu) * 1099511628211ull;  // field separator
   };
   const char* run = getenv("NS_TP_RUN_ID");
-  if (!run) run = getenv("TORCHELASTIC_RUN_ID");
-  // only values every rank of one launch shares, whatever spawned it (torchrun, mpirun -n 2 sh -c ..., srun, several nodes
-  // over one NS_TP_ID_FILE): a parent pid is not one of them — ranks behind per-rank wrapper shells would never agree
+  if (!run || !*run) run = getenv("TORCHELASTIC_RUN_ID");
   mix(run);
   mix(getenv("MASTER_ADDR"));
   mix(getenv("MASTER_PORT"));
   mix(getenv("NS_TP_WORLD_SIZE") ? getenv("NS_TP_WORLD_SIZE") : getenv("WORLD_SIZE"));
+  if (nonce_uses_ppid()) {
+    char buf[64];
+    snprintf(buf, sizeof(buf), "sid%ld.ppid%ld", long(getsid(0)), long(getppid()));
+    mix(buf);
+  }
   return h ? h : 1;
+}
+
+// how old (relative to this process's start) an id file may be: the ranks of one launch start within seconds of each other
+// and rank 0 writes the file after ITS start, so anything older than this is a leftover (NS_TP_ID_MAX_AGE_S overrides)
+time_t id_max_age_s() {
+  const char* v = getenv("NS_TP_ID_MAX_AGE_S");
+  const long s = v ? atol(v) : 30;
+  return time_t(s > 0 ? s : 30);
 }
 
 const time_t g_start_time = time(nullptr);
@@ -107,25 +134,37 @@ ns_tp* make_tp() {
       return nullptr;
     }
   } else {
+    // a regular file of this user, not writable by anyone else, complete, carrying THIS launch's nonce, and not a leftover
+    // of an earlier launch with the same nonce ingredients that died before its rank 0 could remove it: written no
+    // earlier than id_max_age_s() before this process started
+    auto read_valid = [&](IdFile* out) {
+      const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+      if (fd < 0) return false;
+      struct stat sb;
+      IdFile in;
+      const bool ok = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_uid == getuid() && !(sb.st_mode & (S_IWGRP | S_IWOTH)) &&
+                      sb.st_mtime + id_max_age_s() >= g_start_time &&
+                      read(fd, &in, sizeof(in)) == ssize_t(sizeof(in)) && !memcmp(in.magic, "NSTPID1", 8) && in.nonce == nonce;
+      close(fd);
+      if (ok) *out = in;
+      return ok;
+    };
     bool got = false;
     for (int i = 0; i < 600 && !got; i++) {
-      const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
-      if (fd >= 0) {
-        struct stat sb;
-        IdFile in;
-        // a regular file of this user, not writable by anyone else, complete, carrying THIS launch's nonce — and not a
-        // leftover of an earlier launch with the same address / port / size that died before rank 0 could remove it:
-        // written no earlier than five minutes before this process started (rank 0 also unlinks the name first thing)
-        got = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_uid == getuid() && !(sb.st_mode & (S_IWGRP | S_IWOTH)) &&
-              sb.st_mtime + 300 >= g_start_time &&
-              read(fd, &in, sizeof(in)) == ssize_t(sizeof(in)) && !memcmp(in.magic, "NSTPID1", 8) && in.nonce == nonce;
-        if (got) rec = in;
-        close(fd);
+      IdFile first, again;
+      if (read_valid(&first)) {
+        // rank 0 unlinks the name first thing: a reader that opened a leftover just before that sees, a moment later, no
+        // file or different bytes under the name — accept only an id that is still there unchanged
+        std::this_thread::sleep_for(std::chrono::milliseconds(150));
+        got = read_valid(&again) && !memcmp(&first, &again, sizeof(first));
+        if (got) rec = first;
       }
       if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
     if (!got) {
-      fprintf(stderr, "parallel_context: rank %d never saw a valid %s\n", rank, path.c_str());
+      fprintf(stderr, "parallel_context: rank %d never saw a valid %s%s\n", rank, path.c_str(),
+              nonce_uses_ppid() ? " (no launcher run id: the nonce includes the parent pid — ranks started behind per-rank wrapper "
+                                  "shells must export NS_TP_RUN_ID, or NS_TP_NONCE_NO_PPID=1)" : "");
       return nullptr;
     }
   }
@@ -146,6 +185,9 @@ ns_tp* instance() {
 }  // namespace
 
 extern "C" {
+
+// test hook (tests/test_glue.py): the nonce this process would name its id file with
+unsigned long long ns_pc_launch_nonce(void) { return launch_nonce(); }
 
 parallel_context* init_parallel_context() {
   parallel_context* p = new parallel_context();  // (the reference leaks one of these per call too)

@@ -585,6 +585,10 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
     set_error("forward: null argument");
     return -1;
   }
+  if (w->load_failed) {
+    set_error("forward: this weight's load was rejected (ns_hip_weight_finish_load)");
+    return -1;
+  }
   if (link && !link_ok(link, w, m, dA16)) return -1;
   if (!smallm_supported(w, m)) {
     set_error("forward: weight format not supported");
@@ -873,6 +877,7 @@ int ns_hip_weight_finish_load(ns_weight* w, const uint32_t* info) {
   if (!w->load_pending) return 0;  // loaded synchronously (double-quantised scales): nothing to finish
   w->load_pending = false;
   if (info[1]) {
+    w->load_failed = true;
     set_error("F8_E5M2 blob holds codes with exponent field 31 (beyond the reference quantizer's max_norm and fp16)");
     return -1;
   }
@@ -947,6 +952,8 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
   o->scales = nullptr;
   o->zps = nullptr;
   o->shuf = nullptr;
+  o->external = false;      // the slice owns the memory alloc_weight gives it, wherever the parent's lives
+  o->load_pending = false;
   o->native = nullptr;  // a slice of a bit-plane weight streams its widened records (no native clone)
   o->n = n1 - n0;
   o->k = k1 - k0;

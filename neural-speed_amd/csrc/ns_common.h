@@ -113,6 +113,7 @@ struct ns_weight {
   size_t alloc_bytes = 0;
   bool external = false;  // the arrays live in memory the caller owns (the slice a graph reserved, bestla_device_load_storage): never freed here
   bool load_pending = false;  // loaded by ns_hip_weight_load_async: ns_hip_weight_finish_load has not run yet
+  bool load_failed = false;   // ns_hip_weight_finish_load rejected the blob: every forward refuses the weight
   bool single_span = false;  // the allocation is < 4 GiB, i.e. the offsets above are usable as 32-bit soffsets
   uint64_t stream_bytes = 0;  // algorithmic bytes (reference formula)
   int device = 0;
@@ -201,7 +202,7 @@ void set_gemvs_tuning(int what, int value);  // what: 0 mode (0 off, 1 from 2 ro
 void set_attn_tuning(int wg_target, int min_keys);
 void set_gemv_planes(int on);  // 1 (default): bit-plane formats stream their native records at decode (ns_weight::native); 0: the widened ones
 void set_attn_mfma2_rows(int rows);  // query rows from which the 128-row prefill attention kernel is used (default 128; huge = never)
-void set_attn_inlaunch(int on);  // 1 (default): the last context split merges inside attn_split_kernel's launch; 0: attn_merge_kernel
+void set_attn_inlaunch(int on);  // 0 (default): attn_merge_kernel combines the context splits in a second launch; 1: the last split to finish merges inside attn_split_kernel's launch
 // NS_HOST_PROFILE=1: wall time and call count of every host-tensor entry, printed at exit (diagnostics of the default,
 // host-pointer route: where a token's milliseconds go between the graph executor and the GPU)
 struct HostScope {

@@ -300,8 +300,11 @@ void* bestla_create_device(bool profile) {
   return d;
 }
 void* bestla_get_device_queue(void* device) { return device ? static_cast<ns::Device*>(device)->stream : nullptr; }
+static void finish_pending_loads_if_any();
 void bestla_release_device(void* device) {
   if (!device) return;
+  (void)ns_hip_lazy_flush();
+  finish_pending_loads_if_any();
   ns::Device* d = static_cast<ns::Device*>(device);
   (void)hipStreamSynchronize(d->stream);
   (void)hipStreamDestroy(d->stream);
@@ -323,6 +326,9 @@ void* bestla_device_malloc(size_t size, void* queue) {
 }
 void bestla_device_free(void* ptr, void* queue) {
   (void)queue;
+  // nothing recorded or in flight may still refer to the memory: the lazy node's operands, the loads into the graph's slices
+  (void)ns_hip_lazy_flush();
+  finish_pending_loads_if_any();
   if (ptr) (void)hipFree(ptr);
 }
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {
@@ -352,8 +358,8 @@ size_t bestla_device_storage_size(void) { return sizeof(ns::DeviceStorage); }
  * first forward that meets a pending weight (one stream synchronisation per model). */
 namespace {
 struct PendingLoad {
-  ns::DeviceStorage* s;
-  uint32_t* info;
+  ns_weight* w;    // the weight itself, NOT the tensor's storage area: a model whose tensors are freed before any forward ran
+  uint32_t* info;  // must not leave pointers into freed tensor memory behind
 };
 std::mutex g_load_mu;
 std::vector<PendingLoad> g_pending;
@@ -382,13 +388,8 @@ void finish_pending_loads() {
   const long long t0 = now_us();
   (void)hipStreamSynchronize(g_load_stream);
   for (const PendingLoad& pl : g_pending) {
-    if (pl.s->magic != ns::kDevMagic || !pl.s->w) continue;
-    if (ns_hip_weight_finish_load(pl.s->w, pl.info) != 0) {
-      fprintf(stderr, "bestla_device_load_storage: %s\n", ns_hip_last_error());
-      ns_hip_weight_free(pl.s->w);
-      pl.s->w = nullptr;
-      pl.s->magic = 0;  // the forward refuses the tensor loudly
-    }
+    // a rejected blob marks the weight (load_failed): the forward refuses it loudly; the storage area is not touched here
+    if (ns_hip_weight_finish_load(pl.w, pl.info) != 0) fprintf(stderr, "bestla_device_load_storage: %s\n", ns_hip_last_error());
   }
   g_pending.clear();
   g_stats[4] += uint64_t(now_us() - t0);
@@ -399,6 +400,12 @@ void finish_pending_loads() {
 }
 std::atomic<int> g_have_pending{0};
 }  // namespace
+static void finish_pending_loads_if_any() {
+  if (g_have_pending.load()) {
+    g_have_pending.store(0);
+    finish_pending_loads();
+  }
+}
 
 void bestla_device_load_storage(void* hoststor, void* devstor, void* deviceptr, void* queue) {
   if (!hoststor || !devstor) return;
@@ -421,7 +428,7 @@ void bestla_device_load_storage(void* hoststor, void* devstor, void* deviceptr, 
   int bits = 0, bs = 0;
   uint64_t db = 0;
   ns_hip_weight_info(w, &s->n, &s->k, &bits, &bs, &db);
-  g_pending.push_back(PendingLoad{s, info});
+  g_pending.push_back(PendingLoad{w, info});
   g_load_stream = static_cast<hipStream_t>(queue);
   g_stats[0]++, g_stats[1] += blob_bytes;
   g_stats[ns_hip_weight_is_external(w) ? 2 : 3] += db;
@@ -553,7 +560,8 @@ int ns_hip_lazy_mul(const float* dA, const float* dB, float* dDst, const long lo
   if (n.kind && dA && dB && dDst && n.st == static_cast<hipStream_t>(stream) && packed(ne0, nb0) && packed(ne0, nbd)) {
     const long long total = ne0[0] * ne0[1] * ne0[2] * ne0[3];
     if (n.kind == 1 && dA == n.dst && total == (long long)n.n && ne0[0] == n.cols && ne1[0] == n.cols && ne1[1] <= 1 && ne1[2] <= 1 && ne1[3] <= 1 &&
-        nb1[0] == 4 && dDst != n.src) {
+        nb1[0] == 4 && dDst != n.src && dDst != n.dst) {  // (in place — ne_mul_inplace: dst == the norm's output — the two stores
+                                                             // of the fused kernel would alias: flush and run the plain kernel)
       ns::g_lazy.kind = 0;
       if (ns::launch_rmsnorm_mul2(n.rows, n.cols, true, n.eps, n.src, n.dst, dB, dDst, n.st) != hipSuccess) {
         ns::set_error("device route: norm . weight launch failed");
@@ -562,7 +570,7 @@ int ns_hip_lazy_mul(const float* dA, const float* dB, float* dDst, const long lo
       return 0;
     }
     const bool same_shape = ne1[0] == ne0[0] && ne1[1] == ne0[1] && ne1[2] == ne0[2] && ne1[3] == ne0[3] && packed(ne1, nb1);
-    if (n.kind == 2 && same_shape && total == (long long)n.n && (dA == n.dst) != (dB == n.dst) && dDst != n.src) {
+    if (n.kind == 2 && same_shape && total == (long long)n.n && (dA == n.dst) != (dB == n.dst) && dDst != n.src && dDst != n.dst) {
       ns::g_lazy.kind = 0;
       const bool first = dA == n.dst;
       if (ns::launch_silu_mul2(n.src, first ? dB : dA, n.dst, dDst, n.n, first ? 1 : 0, n.st) != hipSuccess) {

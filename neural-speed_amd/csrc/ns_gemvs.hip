@@ -680,10 +680,18 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
           seen = __builtin_amdgcn_readfirstlane(seen);
           if (seen < nslices - 1u) __builtin_amdgcn_s_sleep(2);
         } while (seen < nslices - 1u && ++spins < kGsSpinLimit);
+        // a slice never arrived (a grid larger than what is resident at once), now or in an earlier launch on this ticket: no
+        // sum of whatever the slab holds — the tile's outputs become NaN and the ticket stays poisoned (high bit; late
+        // arrivals only add to it), so that every later launch on this scratch fails as loudly
+        const bool expired = seen < nslices - 1u || (seen & 0x80000000u) != 0u;
         floatx4 tot[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) tot[q] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (g < rows_q) {
+        if (expired) {
+          const float qnan = __builtin_nanf("");
+#pragma unroll
+          for (int q = 0; q < NQ; q++) tot[q] = floatx4{qnan, qnan, qnan, qnan};
+        } else if (g < rows_q) {
           for (uint32_t sx = 0; sx < nslices; sx++) {
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
             }
           }
         }
-        if (l == 0) __hip_atomic_store(tickets + T, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+        if (l == 0) __hip_atomic_store(tickets + T, expired ? 0x80000000u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
         gvs_epilogue<DUAL>(tot, p.m, col, col_ok, g, cbase, c16, ldc, dvp, c2, epi);
       } else {
         gvs_epilogue<DUAL>(sum, p.m, col, col_ok, g, cbase, c16, ldc, dvp, c2, epi);

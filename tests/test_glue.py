@@ -78,6 +78,38 @@ print("PC_GLUE_OK")
     assert "PC_GLUE_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_launch_nonce_separates_launches_without_a_run_id(pkg, tmp_path):
+    """with no launcher run id the id-file nonce must still differ between two launches of the same shape (same
+    MASTER_*, same WORLD_SIZE) — it mixes in the session id and the parent pid, which sibling ranks share — while a run id
+    (or NS_TP_NONCE_NO_PPID=1, for ranks behind per-rank wrapper shells) makes it a function of the exported values only"""
+    so = str(tmp_path / "libpc_glue.so")
+    lib = pkg.LIB_PATH
+    subprocess.run(["g++", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Werror", *INC, os.path.join(ROOT, "glue", "parallel_context_hip.cpp"),
+                    "-o", so, lib, "-Wl,-rpath," + os.path.dirname(lib)], check=True)
+    base = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29500")
+    for k in ("NS_TP_RUN_ID", "TORCHELASTIC_RUN_ID", "NS_TP_NONCE_NO_PPID", "NS_TP_WORLD_SIZE"):
+        base.pop(k, None)
+    rank = "import ctypes as C, sys; g = C.CDLL(sys.argv[1]); g.ns_pc_launch_nonce.restype = C.c_ulonglong; print(g.ns_pc_launch_nonce())"
+    # one "launch" = a parent python process that starts two sibling ranks and prints their nonces
+    launch = ("import subprocess, sys; print(' '.join(subprocess.run([sys.executable, '-c', sys.argv[2], sys.argv[1]], "
+              "capture_output=True, text=True).stdout.strip() for _ in range(2)))")
+
+    def nonces(env):
+        r = subprocess.run([os.sys.executable, "-c", launch, so, rank], capture_output=True, text=True, env=env, timeout=120)
+        v = r.stdout.split()
+        assert len(v) == 2, r.stdout + r.stderr
+        return v
+    a, b = nonces(base), nonces(base)
+    assert a[0] == a[1] and b[0] == b[1], "sibling ranks of one launch must agree"
+    assert a[0] != b[0], "two launches of the same shape share an id file name"
+    for extra in ({"NS_TP_RUN_ID": "job7"}, {"TORCHELASTIC_RUN_ID": "abc"}, {"NS_TP_NONCE_NO_PPID": "1"}):
+        a, b = nonces(dict(base, **extra)), nonces(dict(base, **extra))
+        assert a[0] == a[1] == b[0] == b[1], extra
+    # torchrun's default run id "none" is not a discriminator: the parent pid still is
+    a, b = nonces(dict(base, TORCHELASTIC_RUN_ID="none")), nonces(dict(base, TORCHELASTIC_RUN_ID="none"))
+    assert a[0] == a[1] and a[0] != b[0]
+
+
 def test_reference_tp_build_is_what_the_glue_replaces():
     """Recorded fact, so that nobody looks for a test that drives ne_all_reduce through the UNCHANGED ne_layers.c: the
     reference's own NS_TP_MODEL code does not compile at this revision (ne_tp_concat / ne_split still call

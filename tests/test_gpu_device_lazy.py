@@ -110,3 +110,34 @@ def test_anything_else_launches_the_recorded_node_first(fns, pkg):
     L.bestla_device_sync.argtypes = [C.c_void_p]
     L.bestla_device_sync(st)  # launches the silu
     assert torch.equal(a, a_ref) and torch.equal(s, x / (1 + torch.exp(-x)) ) or torch.allclose(s, torch.nn.functional.silu(x), rtol=1e-6, atol=1e-7)
+
+
+def test_in_place_multiplies_are_not_fused(fns, pkg):
+    """ne_mul_inplace (dst == the recorded node's output): the fused kernels store the node's result and the product
+    to two addresses — aliased, the tensor would end up holding the norm / silu without the multiply.  The recorded node is
+    launched first and the plain multiply runs over it."""
+    import torch
+    L = fns
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    rows, cols = 3, 4096
+    x = torch.randn((rows, cols), generator=g, device="cuda") * 2
+    gam = torch.randn((cols,), generator=g, device="cuda")
+    a_ref, b_ref = torch.empty_like(x), torch.empty_like(x)
+    pkg.check(L.ns_hip_layernormalization(rows, cols, True, 1e-5, x.data_ptr(), a_ref.data_ptr(), st))
+    pkg.check(_mul(L, L.ns_hip_binary_nd_f32, a_ref, gam, b_ref, st, 1))
+    a = torch.full_like(x, 7.0)
+    pkg.check(L.ns_hip_lazy_rms_norm(rows, cols, 1e-5, x.data_ptr(), a.data_ptr(), st))
+    pkg.check(_mul(L, L.ns_hip_lazy_mul, a, gam, a, st))  # in place
+    torch.cuda.synchronize()
+    assert torch.equal(a, b_ref)
+    # silu(gate) * up, written over silu(gate)
+    gate, up = torch.randn((rows, cols), generator=g, device="cuda"), torch.randn((rows, cols), generator=g, device="cuda")
+    s_ref, p_ref = torch.empty_like(gate), torch.empty_like(gate)
+    pkg.check(L.ns_hip_silu_f32(gate.data_ptr(), s_ref.data_ptr(), gate.numel(), st))
+    pkg.check(_mul(L, L.ns_hip_binary_nd_f32, s_ref, up, p_ref, st, 1))
+    s = torch.full_like(gate, 7.0)
+    pkg.check(L.ns_hip_lazy_silu(gate.data_ptr(), s.data_ptr(), gate.numel(), st))
+    pkg.check(_mul(L, L.ns_hip_lazy_mul, s, up, s, st))
+    torch.cuda.synchronize()
+    assert torch.equal(s, p_ref)
