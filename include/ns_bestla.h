@@ -208,6 +208,8 @@ int ns_hip_get_compute_mode(void);
 /* Diagnostics / A-B switches of the kernels (process-wide, take effect at the next launch or capture):
  *   "gemv2"           0 = first-generation decode kernel only, 1 = gemv_kernel (default); also NS_GEMV2 in the environment
  *   "g3_bm"           row-tile height of the prefill GEMM (128 / 256), 0 = automatic
+ *   "g3_wide"         1 = the prefill GEMM's cross-wave output epilogue wherever the wave tiles are 1 x 4 (always used by launches
+ *                     without an fp32 output and by the fused gate / up GEMM), 0 (default) = the per-wave one, -1 = NS_G3_WIDE / default
  *   "i8_mfma"         NS_COMPUTE_REF_INT8 at 16 rows and up: 2 = one exact fp16 MFMA per 32-deep slice on
  *                     operands with both zero points folded in (default), 1 = the first kernel (integer MFMA + corrections
  *                     per accumulator); bit-identical results; also NS_I8_MFMA in the environment

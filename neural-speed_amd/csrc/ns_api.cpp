@@ -578,16 +578,39 @@ bool link_ok(const ns_norm_link* link, const ns_weight* w, int m, const void* dA
   return true;
 }
 
+// rows from which the TILED kernel serves a weight of this shape although most of its tile is padding (measurements: forward_impl)
+int tiled_from_rows(const ns_weight* w) {
+  return w->ntiles >= 512 ? 17 : w->ntiles >= 256 ? (w->k >= 8192 ? 17 : 33) : 1 << 30;
+}
+
 int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
                  const float* dD, int ldd, hipStream_t st, const void* dA16 = nullptr, void* dC16 = nullptr,
                  bool reuse_aq = false, const ns_norm_link* link = nullptr) {
-  if (!w || !dA || !dC || m <= 0) {
+  if (!w || (!dA && !dA16) || (!dC && !dC16) || m <= 0) {
     set_error("forward: null argument");
     return -1;
   }
   if (w->load_failed) {
     set_error("forward: this weight's load was rejected (ns_hip_weight_finish_load)");
     return -1;
+  }
+  if (!dA || !dC) {
+    // fp16-only activations (the producer wrote its shadow only) and / or an fp16-only output (the consumer is this library's next
+    // GEMM): the tiled kernel multiplies fp16 activations as they are and can leave the fp32 store out (round 5)
+    if (w->shuf || ref_int8_for(w) || link || w->kind == WK_F8) {
+      set_error("forward: fp16-only activations / outputs need a weight the tiled kernel takes as is (no act-order shuffle, no int8-reference mode, no fp8)");
+      return -1;
+    }
+    SmallMArgs a{};
+    a.a = dA, a.a16 = dA16, a.lda = lda, a.m = m, a.ldc = ldc, a.nseg = 1;
+    a.seg[0] = {w, dC, dC16};
+    a.epilogue = epilogue, a.d = dD, a.ldd = ldd;
+    const hipError_t e = launch_gemm2(a, st);
+    if (e == hipErrorNotSupported) {
+      set_error("forward: fp16-only activations / outputs are outside the tiled kernel's envelope (K a multiple of 64, lda a multiple of 8, 16-byte aligned)");
+      return -1;
+    }
+    return hip_ok(e, "gemm launch (fp16-only operand)") ? 0 : -1;
   }
   if (link && !link_ok(link, w, m, dA16)) return -1;
   if (!smallm_supported(w, m)) {
@@ -657,10 +680,7 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
   // Up to 16 rows every call stays on the streaming kernels all the same: their accumulation is exact in fp32 (3e-5 from the
   // fp64 product of the fp16-rounded activations, tests/test_gpu_fullsize.py), the tiled kernel rounds scaled weights to fp16
   // (2e-4), and a decode step's numerics should not depend on the shape of the matrix.
-  const int tiled_from = tiled_env > 0 ? tiled_env
-                         : w->ntiles >= 512 ? 17
-                         : w->ntiles >= 256 ? (w->k >= 8192 ? 17 : 33)
-                                            : 1 << 30;
+  const int tiled_from = tiled_env > 0 ? tiled_env : tiled_from_rows(w);
   const bool wide_tiled = m >= tiled_from && w->kind != WK_F8 && !getenv("NS_SMALLM_MAX");
   const bool small = !wide_tiled && (m <= 16 || (m <= small_max && (staging <= 140e6 || getenv("NS_SMALLM_MAX") != nullptr)));
   // fp32 activations, several rows, many column tiles: one conversion pass to fp16 (about 2 us) halves what every
@@ -1065,6 +1085,10 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_i8_mfma_gen(value);
     return 0;
   }
+  if (key && !strcmp(key, "g3_wide")) {
+    set_gemm3_wide(value);
+    return 0;
+  }
   if (key && !strcmp(key, "g3_bm")) {
     set_gemm3_bm(value);
     return 0;
@@ -1292,7 +1316,7 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
                                 float* dTmp1, float* dTmp2, void* dTmp2_16, int seq, int act, const ns_norm_link* link,
                                 void* stream) {
   if (!have_device()) return -1;
-  if (!w1 || !w3 || !dTmp2 || !dA) {
+  if (!w1 || !w3 || (!dTmp2 && !dTmp2_16) || !dA) {
     set_error("ffn3 gate/up: null argument");
     return -1;
   }
@@ -1302,6 +1326,29 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
                     w3->scale_dt == w1->scale_dt && w3->asym == w1->asym && w3->qtype == w1->qtype && !w1->shuf &&
                     !w3->shuf;
   const bool ref8 = ref_int8_for(w1);  // int8-reference mode: the two GEMVs and the activation stay separate operators
+  // GEMM size (round 5): ONE launch of the tiled kernel on gate / up tile pairs — act(A W1) * (A W3) is formed in registers, so
+  // neither tmp1 nor an fp32 tmp2 has to exist (each is written only if the caller hands a pointer: the reference's graph treats
+  // both as scratch, ne_layers.c:2573-2576); before, W1 wrote tmp1 (fp32), W3 read it back and wrote tmp2 (fp32 + fp16)
+  if (same && !ref8 && !link && seq > 16 && (seq > 64 || seq >= tiled_from_rows(w1)) && w1->kind != WK_F8 && (dTmp2 || dTmp2_16) &&
+      smallm_supported(w1, seq)) {
+    SmallMArgs a{};
+    a.a = dA, a.a16 = dA16, a.lda = fin, a.m = seq, a.ldc = fmid, a.nseg = 2;
+    a.seg[0] = {w1, dTmp2, dTmp2_16};
+    a.seg[1] = {w3, dTmp2, nullptr};
+    a.epilogue = act;
+    a.dual = true;
+    a.c2 = dTmp1;
+    const hipError_t e = launch_gemm2(a, st);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotSupported) return hip_ok(e, "ffn gate/up GEMM launch") ? 0 : -1;
+  }
+  if (!dTmp2) {  // the paths below produce the fp32 product
+    dTmp2 = static_cast<float*>(stream_scratch(st, size_t(seq) * fmid * 4, 9));
+    if (!dTmp2) {
+      set_error("ffn3 gate/up: no scratch for tmp2 (out of device memory)");
+      return -1;
+    }
+  }
   if (same && smallm_dual_ok(seq) && smallm_supported(w1, seq) && !ref8) {
     SmallMArgs a{};
     a.a = dA;
@@ -1342,9 +1389,9 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
       if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference gate/up launch") ? 0 : -1;
     }
   }
-  if (!dTmp1 && ref8) dTmp1 = static_cast<float*>(stream_scratch(st, size_t(seq) * fmid * 4, 5));
+  if (!dTmp1) dTmp1 = static_cast<float*>(stream_scratch(st, size_t(seq) * fmid * 4, 5));
   if (!dTmp1) {
-    set_error("ffn3: tmp1 required on the unfused path");
+    set_error("ffn3: no scratch for tmp1 on the unfused path (out of device memory)");
     return -1;
   }
   if (forward_impl(dA, w1, dTmp1, seq, fin, fmid, act, nullptr, 0, st, dA16, nullptr)) return -1;
@@ -1355,28 +1402,41 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
 int ns_hip_fusion_ffn3_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const ns_weight* w3,
                                float* dTmp1, float* dTmp2, float* dOut, int seq, int act, void* stream) {
   if (!have_device()) return -1;
-  if (!w1 || !w2 || !w3 || !dTmp2) {
-    set_error("ffn3: null argument");
-    return -1;
-  }
-  if (w2->k != w1->n) {
-    set_error("ffn3: shape mismatch");
-    return -1;
-  }
-  if (ns_hip_fusion_ffn3_gateup(dA, w1, w3, dTmp1, dTmp2, seq, act, stream)) return -1;
-  return forward_impl(dTmp2, w2, dOut, seq, w1->n, w2->n, NS_EPI_NONE, nullptr, 0, (hipStream_t)stream);
+  return ns_hip_fusion_ffn3_forward_h(dA, nullptr, w1, w2, w3, dTmp1, dTmp2, nullptr, dOut, nullptr, seq, act, stream);
 }
 
 int ns_hip_fusion_ffn3_forward_h(const float* dA, const void* dA16, const ns_weight* w1, const ns_weight* w2,
                                  const ns_weight* w3, float* dTmp1, float* dTmp2, void* dTmp2_16, float* dOut,
                                  void* dOut16, int seq, int act, void* stream) {
   if (!have_device()) return -1;
-  if (!w1 || !w2 || !w3 || !dTmp2 || w2->k != w1->n) {
+  if (!w1 || !w2 || !w3 || w2->k != w1->n) {
     set_error("ffn3: bad argument");
     return -1;
   }
+  hipStream_t st = (hipStream_t)stream;
+  const int fmid = w1->n;
+  // GEMM size, no fp32 tmp2 asked for: the intermediate exists as fp16 only (the down projection multiplies fp16 activations anyway);
+  // it lives in the caller's dTmp2_16 or in per-stream scratch
+  if (!dTmp2 && seq > 16 && !w2->shuf && !ref_int8_for(w2) && w2->kind != WK_F8 && fmid % 64 == 0) {
+    void* t16 = dTmp2_16 ? dTmp2_16 : stream_scratch(st, size_t(seq) * fmid * 2, 8);
+    if (t16 && ns_hip_fusion_ffn3_gateup_h(dA, dA16, w1, w3, dTmp1, nullptr, t16, seq, act, stream) == 0) {
+      SmallMArgs a{};
+      a.a = nullptr, a.a16 = t16, a.lda = fmid, a.m = seq, a.ldc = w2->n, a.nseg = 1;
+      a.seg[0] = {w2, dOut, dOut16};
+      a.epilogue = NS_EPI_NONE;
+      const hipError_t e = launch_gemm2(a, st);
+      if (e == hipSuccess) return 0;
+      if (e != hipErrorNotSupported) return hip_ok(e, "ffn down GEMM launch") ? 0 : -1;
+    }
+    // (outside the tiled kernel's envelope: the general path below, on an fp32 intermediate)
+  }
+  if (!dTmp2) dTmp2 = static_cast<float*>(stream_scratch(st, size_t(seq) * fmid * 4, 9));
+  if (!dTmp2) {
+    set_error("ffn3: no scratch for tmp2 (out of device memory)");
+    return -1;
+  }
   if (ns_hip_fusion_ffn3_gateup_h(dA, dA16, w1, w3, dTmp1, dTmp2, dTmp2_16, seq, act, stream)) return -1;
-  return forward_impl(dTmp2, w2, dOut, seq, w1->n, w2->n, NS_EPI_NONE, nullptr, 0, (hipStream_t)stream, dTmp2_16, dOut16);
+  return forward_impl(dTmp2, w2, dOut, seq, w1->n, w2->n, NS_EPI_NONE, nullptr, 0, st, dTmp2_16, dOut16);
 }
 
 int ns_hip_fusion_ffn2_forward(const float* dA, const ns_weight* w1, const ns_weight* w2, const float* dB1,

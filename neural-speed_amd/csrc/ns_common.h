@@ -215,6 +215,7 @@ void kv_mirrors_clear();  // ns_attn.hip: drops the device mirrors of library-ma
 void set_i8_tile(int tile);     // ns_i8ref.hip: workgroup tile of i8mfma2_kernel (0 = by size)
 void set_i8_mfma_gen(int gen);  // ns_i8ref.hip: 2 = i8mfma2_kernel for nibble containers (default), 1 = i8mfma_kernel everywhere
 void set_gemm3_min_m(int m);  // ns_gemm.hip: rows from which gemm3_kernel is used (0 = default)
+void set_gemm3_wide(int on);  // ns_gemm.hip: 1 the cross-wave output epilogue of gemm3_kernel's 1 x 4 wave tiles, 0 (default) the per-wave one, -1 = environment / default
 void set_gemm3_bm(int bm);  // ns_gemm.hip: force gemm3_kernel's row-tile height (tests / A-B runs); 0 = automatic  // ns_attn.hip: context-split rule of the decode attention kernel
 void set_decode_waves(int nw);  // 0 = by shape
 int decode_waves(int grid, int ks, bool dual);  // waves per workgroup of a decode launch (both kernel generations)

@@ -83,6 +83,15 @@ struct Gemm2Params {
   int bm3;   // gemm3_kernel: rows of the workgroup tile (256 / 128)
   int tall3; // gemm3_kernel, bm3 = 256: waves 1 x 4 of 256 x 32 instead of 2 x 2 of 128 x 64
   int diag;  // NS_G3_DIAG (diagnostics): 1 = skip the output stores, 2 = skip the main loop, 3 = DMA and barriers only, 4 = no DMA
+  // gemm3_kernel, fused gate/up (round 5; ip_fusion_ffn.cpp:364-406 at GEMM size): codes / scales / zps = W1 (gate), *2 = W3 (up), same
+  // shape and format; a column block is 4 tile PAIRS = 64 output columns, wave w multiplies gate tile and up tile 4 bn + w, the MFMA
+  // layout puts gate and up of one (row, column) into the same lane: out = act(gate) * up in registers.  c / c16 / c2 are each optional.
+  int dual;
+  const void* codes2;
+  const void* scales2;
+  const int8_t* zps2;
+  float* c2;  // optional act(gate) (the reference's tmp1)
+  int wide;   // 1: the cross-wave epilogue (waves 1 x 4 only): whole tile rows leave as 256 / 512-byte runs, the fp16 shadow as 16-byte stores
 };
 
 template <int KIND, int SPS, int SK, bool ASYM>
@@ -329,9 +338,10 @@ constexpr int kG3BStageMax = 8 * 2 * 1024 + 8 * 2 * 16 * 16 + 8 * 2 * 16 * 4;  /
 // few tiles (4096 wide at 2048 rows: 256 of the tall tiles, one per CU) instead of a K split and its reduction pass.
 // TALL (BM = 256 only): waves 1 x 4 like BM = 128, but 256 rows each — wave tile 256 x 32: the dequantisation of a B fragment
 // (the VALU work of the loop) is shared by 16 row fragments instead of 8, the same 128 accumulator registers per lane
-template <int KIND, int SPS, int SK, bool ASYM, int BM, bool TALL = false>
-__global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
+template <int KIND, int SPS, int SK, bool ASYM, int BM, bool TALL = false, bool DUAL = false>
+__global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void gemm3_kernel(const Gemm2Params p) {  // (128- / 64-row tiles: three workgroups per CU = three waves per SIMD, at most 168 registers)
   static_assert(!TALL || BM == 256, "the tall wave tile is a 256-row workgroup tile");
+  static_assert(!DUAL || (BM <= 128 && !kG3M32), "gate/up pairs: waves 1 x 4 with two column tiles each");
   constexpr bool SQ = BM == 256 && !TALL;       // waves 2 x 2
   constexpr int MI = (SQ ? 128 : BM) / 16;      // row fragments (16 rows) per wave
   constexpr int NIW = SQ ? 4 : 2;               // column tiles (16 wide) per wave
@@ -361,11 +371,15 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   const int n_cols = p.nseg > 1 ? p.seg_n[sg] : p.n;
   float* const c_out = p.nseg > 1 ? p.seg_c[sg] : p.c;
   _Float16* const c16_out = p.nseg > 1 ? p.seg_c16[sg] : p.c16;
-  const int tile0 = bnl * kG3Tiles + wn * NIW, row0 = bm * BM;
+  const int tile0 = DUAL ? bnl * 4 + w : bnl * kG3Tiles + wn * NIW, row0 = bm * BM;  // DUAL: the tile of BOTH matrices (output columns 16 tile0 ..)
 
   const Rsrc rq = p.nseg > 1 ? make_rsrc(p.seg_codes[sg], p.seg_codes_bytes[sg]) : make_rsrc(p.codes, p.codes_bytes);
   const Rsrc rs = p.nseg > 1 ? make_rsrc(p.seg_scales[sg], p.seg_scales_bytes[sg]) : make_rsrc(p.scales, p.scales_bytes);
   const Rsrc rz = p.nseg > 1 ? make_rsrc(p.seg_zps[sg], p.seg_zps_bytes[sg]) : make_rsrc(p.zps, p.zps_bytes);
+  // DUAL: the up matrix (LDS tile slot 2 w + 1 of the wave; slot 2 w is the gate tile)
+  const Rsrc rq2 = DUAL ? make_rsrc(p.codes2, p.codes_bytes) : rq;
+  const Rsrc rs2 = DUAL ? make_rsrc(p.scales2, p.scales_bytes) : rs;
+  const Rsrc rz2 = DUAL ? make_rsrc(p.zps2, p.zps_bytes) : rz;
   const Rsrc ra = make_rsrc(p.a16, uint32_t(p.m) * uint32_t(p.lda16) * 2u);  // rows >= m read as zeros
   const I4Consts i4c = {0x000f000fu, 0x00f000f0u, 0x64006400u};
 
@@ -426,11 +440,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   constexpr uint32_t kBScal = kG3Tiles * RPS * 16u * SBYTES;   // [record][tile][16 columns x SBYTES]
   constexpr uint32_t kBZp = ASYM ? kG3Tiles * RPS * 16u * SPS : 0u;
   unsigned char* const b_lds = smem + kG3Stages * kStage;
-  const uint32_t btile0 = uint32_t(bnl * kG3Tiles + 2 * w);
+  const uint32_t btile0 = DUAL ? uint32_t(bnl * 4 + w) : uint32_t(bnl * kG3Tiles + 2 * w);
   // scale rows: 16 * SBYTES bytes per (tile, row) = SBYTES lanes of 16 B; lanes [0, 2 * SBYTES) cover the wave's two tiles
-  const uint32_t s_lane_tile = uint32_t(l) / uint32_t(SBYTES), s_lane_piece = uint32_t(l) % uint32_t(SBYTES);
+  // (DUAL: the two slots are the same tile of two matrices — one request per matrix, lanes [0, SBYTES) each)
+  const uint32_t s_lane_tile = DUAL ? 0u : uint32_t(l) / uint32_t(SBYTES), s_lane_piece = uint32_t(l) % uint32_t(SBYTES);
   const uint32_t s_voff = (btile0 + s_lane_tile) * uint32_t(p.srows) * p.sstride + s_lane_piece * 16u;
-  const uint32_t z_lane_tile = uint32_t(l) / uint32_t(SPS), z_lane_piece = uint32_t(l) % uint32_t(SPS);
+  const uint32_t z_lane_tile = DUAL ? 0u : uint32_t(l) / uint32_t(SPS), z_lane_piece = uint32_t(l) % uint32_t(SPS);
   const uint32_t z_voff = (btile0 + z_lane_tile) * uint32_t(p.srows) * p.zstride + z_lane_piece * 16u;
   auto issue_b = [&](int u) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -440,20 +455,41 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
 #pragma unroll
       for (int t = 0; t < 2; t++) {
         const LdsPtr dst = (LdsPtr)(b_lds) + ((2 * w + t) * RPS + r) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, uint32_t(l) * 16u,
-                                                 ((btile0 + t) * uint32_t(p.ksteps) + s) * p.qstride, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(DUAL && t ? rq2 : rq, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, uint32_t(l) * 16u,
+                                                 ((btile0 + (DUAL ? 0u : uint32_t(t))) * uint32_t(p.ksteps) + s) * p.qstride, 0, 0);
       }
       const uint32_t srow = (s * uint32_t(p.srow_mul)) >> p.srow_shift;
-      if (l < 2 * SBYTES) {
-        const LdsPtr dst = (LdsPtr)(b_lds) + kBCodes + (r * kG3Tiles + 2 * w) * (16 * SBYTES);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, s_voff,
-                                                 srow * p.sstride, 0, 0);
-      }
-      if constexpr (ASYM) {
-        if (l < 2 * SPS) {
-          const LdsPtr dst = (LdsPtr)(b_lds) + kBCodes + kBScal + (r * kG3Tiles + 2 * w) * (16 * SPS);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, z_voff,
-                                                   srow * p.zstride, 0, 0);
+      if constexpr (DUAL) {
+        if (l < SBYTES) {
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const LdsPtr dst = (LdsPtr)(b_lds) + kBCodes + (r * kG3Tiles + 2 * w + t) * (16 * SBYTES);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(t ? rs2 : rs, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, s_voff,
+                                                     srow * p.sstride, 0, 0);
+          }
+        }
+        if constexpr (ASYM) {
+          if (l < SPS) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+              const LdsPtr dst = (LdsPtr)(b_lds) + kBCodes + kBScal + (r * kG3Tiles + 2 * w + t) * (16 * SPS);
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(t ? rz2 : rz, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, z_voff,
+                                                       srow * p.zstride, 0, 0);
+            }
+          }
+        }
+      } else {
+        if (l < 2 * SBYTES) {
+          const LdsPtr dst = (LdsPtr)(b_lds) + kBCodes + (r * kG3Tiles + 2 * w) * (16 * SBYTES);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, s_voff,
+                                                   srow * p.sstride, 0, 0);
+        }
+        if constexpr (ASYM) {
+          if (l < 2 * SPS) {
+            const LdsPtr dst = (LdsPtr)(b_lds) + kBCodes + kBScal + (r * kG3Tiles + 2 * w) * (16 * SPS);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, z_voff,
+                                                     srow * p.zstride, 0, 0);
+          }
         }
       }
     }
@@ -765,15 +801,6 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
   //      back as float4 along the rows and stores 256-byte runs; the operator is applied on the way out, in a plain loop
   //      (nothing below indexes the accumulators dynamically — with the switch inside the unrolled accumulator loops hipcc
   //      kept all 128 accumulator registers in scratch memory, a store behind every MFMA of the main loop). ----
-  constexpr int kCols = NIW * 16;     // columns of the wave tile
-  constexpr int kRowF = kCols + 4;    // floats per parked row
-  constexpr int kLpr = kCols / 4;     // lanes per row in the float4 read-back
-  float* park = reinterpret_cast<float*>(smem) + w * (64 * kRowF);
-  const int colw = tile0 * 16;  // first column of this wave's 64
-  const bool vec4 = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(c_out) & 15) == 0 && colw + kCols <= n_cols &&
-                    (p.ksplit > 1 ? (p.n & 3) == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 : true) &&
-                    (!p.d || ((p.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(p.d) & 15) == 0)) &&
-                    (!c16_out || (reinterpret_cast<uintptr_t>(c16_out) & 7) == 0);
   const int epi = p.epilogue;
   auto finish = [&](float v, float dv) {
     switch (epi) {
@@ -785,6 +812,113 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
       default: return v;
     }
   };
+  // ---- the cross-wave form of that epilogue (round 5; waves 1 x 4).  Measured on the 7B shapes at 2048 rows (profiles/r05a_prefill_probe.txt):
+  //      with the stores skipped a 11008-wide GEMM takes 184 us, with the fp32 stores 187, with fp32 + the fp16 shadow 205 — the shadow left
+  //      each wave as 8-byte stores in 64-byte runs (half a memory line).  Here the four waves park their 64-row halves side by side
+  //      (row = the workgroup tile's whole width), each wave then owns 16 of the 64 rows: fp32 leaves as float4 per lane in 512-byte
+  //      runs (256 for gate/up pairs), the fp16 shadow in a second read-back as 16-byte stores (8 columns per lane) in 256-byte runs
+  //      (128).  DUAL: gate and up of one (row, column) sit in the same lane, the product is formed before parking. ----
+  if constexpr (!SQ && !M32) {
+    if (p.wide && p.ksplit <= 1) {
+      constexpr int PC = NIW * 16;               // parked columns per wave (DUAL: 16 gate + 16 up)
+      constexpr int WROW = 4 * PC + 4;           // floats per parked row (ds_write_b32 of the MFMA layout stays conflict-free)
+      constexpr int OC = DUAL ? 16 : PC;         // output columns per wave
+      constexpr int W = 4 * OC;                  // output columns of the workgroup tile
+      constexpr int LA = W / 4, RA = 64 / LA, IA = 16 / RA;  // fp32 pass: lanes per row, rows per wave instruction, iterations
+      constexpr int LB = W / 8, RB = 64 / LB, IB = 16 / RB;  // fp16 pass
+      float* parkw = reinterpret_cast<float*>(smem);
+      const int colb = bnl * W;  // first output column of the tile inside its matrix
+      const bool full = colb + W <= n_cols;
+      const bool al = (p.ldc & 7) == 0 && (!c_out || (reinterpret_cast<uintptr_t>(c_out) & 15) == 0) &&
+                      (!c16_out || (reinterpret_cast<uintptr_t>(c16_out) & 15) == 0) &&
+                      (!p.d || ((p.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(p.d) & 15) == 0)) &&
+                      (!DUAL || !p.c2 || (reinterpret_cast<uintptr_t>(p.c2) & 15) == 0);
+      const bool use_d = !DUAL && p.d && epi >= 1 && epi <= 3;
+      typedef _Float16 half8o_t __attribute__((ext_vector_type(8)));
+      // parked column of output column oc: the wave that multiplied it, then its place among that wave's columns
+      auto pcol = [&](int oc) { return DUAL ? (oc >> 4) * PC + (oc & 15) : oc; };
+      // one float4 of finished outputs at (parked row pr, output columns oc .. oc + 3); DUAL: act(gate) * up, gate4 = act(gate)
+      auto out4 = [&](int pr, int oc, int row, float4* gate4) {
+        const float* q = parkw + pr * WROW + pcol(oc);
+        float4 v = *reinterpret_cast<const float4*>(q);
+        if constexpr (DUAL) {
+          const float4 u = *reinterpret_cast<const float4*>(q + 16);
+          v = float4{finish(v.x, 0.f), finish(v.y, 0.f), finish(v.z, 0.f), finish(v.w, 0.f)};
+          if (gate4) *gate4 = v;
+          v = float4{v.x * u.x, v.y * u.y, v.z * u.z, v.w * u.w};
+        } else {
+          float4 dv = {0.f, 0.f, 0.f, 0.f};
+          if (use_d) dv = *reinterpret_cast<const float4*>(p.d + size_t(row) * p.ldd + colb + oc);
+          v = float4{finish(v.x, dv.x), finish(v.y, dv.y), finish(v.z, dv.z), finish(v.w, dv.w)};
+        }
+        return v;
+      };
+#pragma unroll
+      for (int hh = 0; hh < MI / 4; hh++) {
+        __syncthreads();  // every wave is done with the A stages / with the previous read-back
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NIW; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              parkw[(mi * 16 + 4 * g + r) * WROW + w * PC + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * p.spost;
+        __syncthreads();
+        if (p.diag == 1) continue;
+        const int rb = row0 + hh * 64 + w * 16;  // this wave's 16 rows of the half
+        if (full && al) {
+          if (c_out || (DUAL && p.c2)) {
+            for (int it = 0; it < IA; it++) {
+              const int rl = it * RA + l / LA, row = rb + rl, oc = (l % LA) * 4;
+              if (row >= p.m) continue;
+              float4 gate4;
+              const float4 v = out4(w * 16 + rl, oc, row, &gate4);
+              if (c_out) *reinterpret_cast<float4*>(c_out + size_t(row) * p.ldc + colb + oc) = v;
+              if constexpr (DUAL) {
+                if (p.c2) *reinterpret_cast<float4*>(p.c2 + size_t(row) * p.ldc + colb + oc) = gate4;
+              }
+            }
+          }
+          if (c16_out) {
+            for (int it = 0; it < IB; it++) {
+              const int rl = it * RB + l / LB, row = rb + rl, oc = (l % LB) * 8;
+              if (row >= p.m) continue;
+              const float4 v0 = out4(w * 16 + rl, oc, row, nullptr), v1 = out4(w * 16 + rl, oc + 4, row, nullptr);
+              *reinterpret_cast<half8o_t*>(c16_out + size_t(row) * p.ldc + colb + oc) =
+                  half8o_t{(_Float16)v0.x, (_Float16)v0.y, (_Float16)v0.z, (_Float16)v0.w, (_Float16)v1.x, (_Float16)v1.y, (_Float16)v1.z, (_Float16)v1.w};
+            }
+          }
+        } else {  // ragged right edge or unaligned outputs: element by element, row-major over the wave's 16 x W part
+          for (int e = l; e < 16 * W; e += 64) {
+            const int rl = e / W, oc = e % W, row = rb + rl, col = colb + oc;
+            if (row >= p.m || col >= n_cols) continue;
+            const float* q = parkw + (w * 16 + rl) * WROW + pcol(oc);
+            float v = q[0];
+            if constexpr (DUAL) {
+              v = finish(v, 0.f);
+              if (p.c2) p.c2[size_t(row) * p.ldc + col] = v;
+              v *= q[16];
+            } else {
+              v = finish(v, use_d ? p.d[size_t(row) * p.ldd + col] : 0.f);
+            }
+            if (c_out) c_out[size_t(row) * p.ldc + col] = v;
+            if (c16_out) c16_out[size_t(row) * p.ldc + col] = (_Float16)v;
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (DUAL) return;  // (gate/up launches always take the cross-wave epilogue)
+  constexpr int kCols = NIW * 16;     // columns of the wave tile
+  constexpr int kRowF = kCols + 4;    // floats per parked row
+  constexpr int kLpr = kCols / 4;     // lanes per row in the float4 read-back
+  float* park = reinterpret_cast<float*>(smem) + w * (64 * kRowF);
+  const int colw = tile0 * 16;  // first column of this wave's 64
+  const bool vec4 = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(c_out) & 15) == 0 && colw + kCols <= n_cols &&
+                    (p.ksplit > 1 ? (p.n & 3) == 0 && (reinterpret_cast<uintptr_t>(p.part) & 15) == 0 : true) &&
+                    (!p.d || ((p.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(p.d) & 15) == 0)) &&
+                    (!c16_out || (reinterpret_cast<uintptr_t>(c16_out) & 7) == 0);
   __syncthreads();  // every wave is done with the A stages
 #pragma unroll
   for (int hh = 0; hh < MI / 4; hh++) {
@@ -819,7 +953,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
         float4 dv = {0.f, 0.f, 0.f, 0.f};
         if (p.d && epi >= 1 && epi <= 3) dv = *reinterpret_cast<const float4*>(p.d + size_t(row) * p.ldd + col);
         v = float4{finish(v.x, dv.x), finish(v.y, dv.y), finish(v.z, dv.z), finish(v.w, dv.w)};
-        *reinterpret_cast<float4*>(c_out + size_t(row) * p.ldc + col) = v;
+        if (c_out) *reinterpret_cast<float4*>(c_out + size_t(row) * p.ldc + col) = v;
         if (c16_out) {
           typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
           *reinterpret_cast<half4_t*>(c16_out + size_t(row) * p.ldc + col) =
@@ -838,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Params p) {
         }
         const float dv = (p.d && epi >= 1 && epi <= 3) ? p.d[size_t(row) * p.ldd + col] : 0.f;
         v = finish(v, dv);
-        c_out[size_t(row) * p.ldc + col] = v;
+        if (c_out) c_out[size_t(row) * p.ldc + col] = v;
         if (c16_out) c16_out[size_t(row) * p.ldc + col] = (_Float16)v;
       }
     }
@@ -1347,14 +1481,17 @@ static hipError_t launch_gemm2_k(const Gemm2Params& p, bool asym, dim3 grid, siz
     return go(gemm2_kernel<KIND, SPS, SK, false>);
   }
 }
-template <int KIND, int SPS, int SK, int BM, bool TALL = false>
+template <int KIND, int SPS, int SK, int BM, bool TALL = false, bool DUAL = false>
 static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hipStream_t st) {
   // A stages + the B stage of this format: records, scale rows, zero-point rows of 8 column tiles for one superstep
   constexpr int rps = KIND == WK_INT8 ? 2 : 1;
   constexpr int sbytes = SPS * (SK == SK_F32 ? 4 : 2);
   // (the epilogue parks 64 rows x (wave columns + 4) floats per wave over the stage memory: the 64-row tile's stages alone are
   // smaller than that)
-  constexpr size_t park_bytes = size_t(4) * 64 * (((BM == 256 && !TALL) ? 64 : 32) + 4) * 4;
+  constexpr size_t park_old = size_t(4) * 64 * (((BM == 256 && !TALL) ? 64 : 32) + 4) * 4;
+  // the cross-wave epilogue (waves 1 x 4) parks 64 rows of the whole tile width: 128 columns (64 for gate/up pairs) + 4
+  constexpr size_t park_wide = (BM == 256 && !TALL) ? 0 : size_t(64) * (128 + 4) * 4;
+  const size_t park_bytes = std::max(park_old, p.wide ? park_wide : size_t(0));
   const size_t lds3 = std::max(size_t(kG3Stages) * BM * kG3KC * 2 + size_t(kG3Tiles) * rps * (1024 + 16 * sbytes + (asym ? 16 * SPS : 0)), park_bytes);
   auto go = [&](auto kern) {
     static const hipError_t attr =
@@ -1371,10 +1508,10 @@ static hipError_t launch_gemm3_k(const Gemm2Params& p, bool asym, dim3 grid, hip
   };
   if constexpr (KIND == WK_F4) {
     (void)asym;
-    return go(gemm3_kernel<KIND, SPS, SK, false, BM, TALL>);
+    return go(gemm3_kernel<KIND, SPS, SK, false, BM, TALL, DUAL>);
   } else {
-    if (asym) return go(gemm3_kernel<KIND, SPS, SK, true, BM, TALL>);
-    return go(gemm3_kernel<KIND, SPS, SK, false, BM, TALL>);
+    if (asym) return go(gemm3_kernel<KIND, SPS, SK, true, BM, TALL, DUAL>);
+    return go(gemm3_kernel<KIND, SPS, SK, false, BM, TALL, DUAL>);
   }
 }
 #ifdef NS_WITH_GEMM3D
@@ -1417,6 +1554,16 @@ static hipError_t launch_gemm3_s(const Gemm2Params& p, uint32_t scale_dt, bool a
 #else
   (void)deep;
 #endif
+  if (p.dual) {  // gate/up pairs: the 1 x 4 wave tiles only
+    if (p.bm3 == 64) {
+      if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 64, false, true>(p, asym, grid, st);
+      if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 64, false, true>(p, asym, grid, st);
+      return launch_gemm3_k<KIND, SPS, SK_BF16, 64, false, true>(p, asym, grid, st);
+    }
+    if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 128, false, true>(p, asym, grid, st);
+    if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 128, false, true>(p, asym, grid, st);
+    return launch_gemm3_k<KIND, SPS, SK_BF16, 128, false, true>(p, asym, grid, st);
+  }
   if (p.bm3 == 64) {  // calls of at most 64 rows: a quarter / half of the 128-row tile's MFMA work is padding otherwise
     if (scale_dt == DT_F32) return launch_gemm3_k<KIND, SPS, SK_F32, 64>(p, asym, grid, st);
     if (scale_dt == DT_F16) return launch_gemm3_k<KIND, SPS, SK_F16, 64>(p, asym, grid, st);
@@ -1448,6 +1595,8 @@ static hipError_t launch_gemm2_s(const Gemm2Params& p, uint32_t scale_dt, bool a
 }
 
 static std::atomic<int> g_g3_bm{0};
+static std::atomic<int> g_g3_wide{-1};  // ns_hip_set_tuning("g3_wide", 0 / 1): -1 = NS_G3_WIDE or the default (0)
+void set_gemm3_wide(int on) { g_g3_wide.store(on < 0 ? -1 : (on != 0)); }
 static std::atomic<int> g_g3_min_m{0};  // ns_hip_set_tuning("g3_min_m", rows): 0 = the default below
 void set_gemm3_min_m(int m) { g_g3_min_m.store(m > 0 ? m : 0); }
 static int gemm3_min_m() {
@@ -1477,6 +1626,8 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   if (a16) {
     p.a16 = a16;
     p.lda16 = a.lda;
+  } else if (!a.a) {
+    return hipErrorNotSupported;  // fp16-only activations that cannot be multiplied as they are: the caller's general path
   } else {
     const size_t bytes = size_t(a.m) * kpad * 2;
     if (bytes >= (size_t(1) << 32)) return hipErrorNotSupported;
@@ -1513,6 +1664,45 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
   static const int g3_diag = getenv("NS_G3_DIAG") ? atoi(getenv("NS_G3_DIAG")) : 0;
   p.diag = g3_diag;
   p.nbn = (w0->ntiles + kG2Tiles - 1) / kG2Tiles;
+  if (a.dual) {  // fused gate/up at GEMM size (round 5): gemm3_kernel only, a column block = 4 tile pairs = 64 output columns
+    static const bool g3_off_env = getenv("NS_GEMM3") && atoi(getenv("NS_GEMM3")) != 1;
+    const ns_weight* w = a.seg[1].w;
+    if (a.nseg != 2 || !w || a.m < gemm3_min_m() || (p.lda16 & 7) != 0 || g3_off_env || a.d || kG3M32) return hipErrorNotSupported;
+    if (w->k != w0->k || w->n != w0->n || w->kind != w0->kind || w->sps != w0->sps || w->scale_dt != w0->scale_dt || w->asym != w0->asym ||
+        w->ksteps != w0->ksteps || w->qstride != w0->qstride || w->sstride != w0->sstride || w->zstride != w0->zstride ||
+        w->srows != w0->srows || w->g2_pre != w0->g2_pre || w->g2_post != w0->g2_post || w->qtype != w0->qtype ||
+        w->codes_bytes != w0->codes_bytes || w->scales_bytes != w0->scales_bytes || w->zps_bytes != w0->zps_bytes)
+      return hipErrorNotSupported;
+    if (!p.c && !p.c16) return hipErrorInvalidValue;
+    p.dual = 1;
+    p.codes2 = w->codes, p.scales2 = w->scales, p.zps2 = w->zps;
+    p.c2 = a.c2;
+    p.nbn = (w0->ntiles + 3) / 4;
+    p.cpx = (p.nbn + 7) / 8;
+    p.wide = 1;
+    p.bm3 = a.m <= 64 ? 64 : 128;
+    p.ksplit = 1;
+    p.cps = p.nchunks;
+    const int nbm3 = (a.m + p.bm3 - 1) / p.bm3;
+    const dim3 grid3(unsigned(8 * p.cpx * nbm3), 1u);
+    switch (w0->kind) {
+      case WK_INT4:
+        switch (w0->sps) {
+          case 4: return launch_gemm3_s<WK_INT4, 4>(p, w0->scale_dt, w0->asym, grid3, st, false);
+          case 2: return launch_gemm3_s<WK_INT4, 2>(p, w0->scale_dt, w0->asym, grid3, st, false);
+          default: return launch_gemm3_s<WK_INT4, 1>(p, w0->scale_dt, w0->asym, grid3, st, false);
+        }
+      case WK_INT8:
+        if (w0->sps == 2) return launch_gemm3_s<WK_INT8, 2>(p, w0->scale_dt, w0->asym, grid3, st, false);
+        return launch_gemm3_s<WK_INT8, 1>(p, w0->scale_dt, w0->asym, grid3, st, false);
+      default:
+        switch (w0->sps) {
+          case 4: return launch_gemm3_s<WK_F4, 4>(p, w0->scale_dt, w0->asym, grid3, st, false);
+          case 2: return launch_gemm3_s<WK_F4, 2>(p, w0->scale_dt, w0->asym, grid3, st, false);
+          default: return launch_gemm3_s<WK_F4, 1>(p, w0->scale_dt, w0->asym, grid3, st, false);
+        }
+    }
+  }
   if (a.nseg > 1) {  // fused QKV at GEMM size: gemm3_kernel only, whole column blocks per matrix
     static const bool g3_off_env = getenv("NS_GEMM3") && atoi(getenv("NS_GEMM3")) != 1;
     if (a.nseg > 3 || a.dual || a.m < gemm3_min_m() || (p.lda16 & 7) != 0 || g3_off_env) return hipErrorNotSupported;
@@ -1555,6 +1745,18 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
     p.tall3 = bm_env == 257 && w0->kind == WK_INT4;
     p.bm3 = p.tall3 ? 256 : bm_env == 64 || bm_env == 128 || bm_env == 256 ? bm_env : a.m <= 64 ? 64 : (tall_tiles >= 1024 && w0->kind != WK_INT8 ? 256 : 128);  // 8-bit codes: the tall tile's LDS
                                                                                             // footprint (81 KiB) leaves one workgroup per CU
+    // outputs: the per-wave epilogue by default; the cross-wave one (ns_hip_set_tuning("g3_wide", 1) / NS_G3_WIDE=1) measured 2-8 % SLOWER
+    // with both outputs on the 7B shapes at 2048 rows (profiles/r05b_gemm3_epilogue_ab.txt: 4096^2 100.4 vs 92.9 us, 11008 x 4096 208.2 vs
+    // 204.8, 4096 x 11008 197.5 vs 191.7) and level with the fp32 output alone — its two extra workgroup barriers per 64-row half cost more
+    // than the longer store runs return.  A launch without an fp32 output (fp16 only: the consumer is this library's next GEMM) and the
+    // gate / up pairs need it (their per-wave runs would be 16 columns)
+    static const int wide_env = getenv("NS_G3_WIDE") ? atoi(getenv("NS_G3_WIDE")) : 0;
+    const int wide_on = g_g3_wide.load() >= 0 ? g_g3_wide.load() : wide_env;
+    if (!p.c && p.nseg <= 1) {
+      if (!p.c16) return hipErrorInvalidValue;
+      if (p.bm3 == 256 && !p.tall3) p.bm3 = 128;
+    }
+    p.wide = (p.bm3 != 256 || p.tall3) && !kG3M32 && (wide_on != 0 || (!p.c && p.nseg <= 1));
     const int nbm3 = (a.m + p.bm3 - 1) / p.bm3;
     p.ksplit = 1;
     p.cps = p.nchunks;
@@ -1564,7 +1766,7 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
       int ks = 1;
       // gemm3_kernel wants two workgroups per CU, the deep kernel one
       while (ks < 8 && tiles * ks * 2 <= (deep ? 256 : 512) && p.nchunks / (ks * 2) >= 8) ks *= 2;
-      if (ks > 1 && !no_splitk && p.nseg <= 1) {
+      if (ks > 1 && !no_splitk && p.nseg <= 1 && p.c) {  // (a launch with the fp16 output only never splits K: the reduction pass writes fp32)
         const size_t bytes = size_t(ks) * a.m * w0->n * 4;
         float* part = static_cast<float*>(stream_scratch(st, bytes, 2));
         if (part) {

@@ -16,7 +16,12 @@ import __graft_entry__ as ge  # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-torch.cuda.set_device(0)
+# NS_TP_WORKER_DEVICE=local (scripts/tp_first_contact.sh on a multi-GPU node): one GPU per rank, the real collective library;
+# default: every rank on cuda:0 over the stand-in.  NS_TP_WORKER_EXACT=0: the collective library's sums are compared with the
+# fp64 sums to 1e-6 (a ring does not add in rank order); the peer-memory kernel adds in rank order and stays bit-exact.
+DEV = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("NS_TP_WORKER_DEVICE") == "local" else 0
+EXACT = os.environ.get("NS_TP_WORKER_EXACT", "1") != "0"
+torch.cuda.set_device(DEV)
 pkg = ge.load_package()
 L = pkg.lib()
 L.ns_tp_init.restype = C.c_void_p
@@ -46,13 +51,22 @@ def rank_order_sum(n, seed):
     return acc
 
 
+def is_sum(got, n, seed, exact=None):
+    """got (cpu tensor / numpy) == the ranks' sum: bit-equal to the rank-order fp32 sum, or (EXACT off) within 1e-6 of the fp64 sum"""
+    got = torch.as_tensor(got)
+    if EXACT if exact is None else exact:
+        return torch.equal(got, rank_order_sum(n, seed))
+    ref = sum(data(r, n, seed).double() for r in range(world))
+    return float((got.double() - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+
+
 # ---- 1. the unique id travels, every rank builds its communicator ------------------------------------------------
 idbuf = C.create_string_buffer(128)
 if rank == 0:
     assert L.ns_tp_unique_id(idbuf) == 0, pkg.last_error()
 box = [bytes(idbuf.raw)]
 dist.broadcast_object_list(box, src=0)
-tp = L.ns_tp_init(rank, world, box[0], 0)
+tp = L.ns_tp_init(rank, world, box[0], DEV)
 assert tp, pkg.last_error()
 assert L.ns_tp_size(tp) == world and L.ns_tp_rank(tp) == rank and L.ns_tp_is_master(tp) == int(rank == 0)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -60,12 +74,11 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 # ---- 2. device-pointer collectives ----------------------------------------------------------------------------------
 for n, seed in ((1, 1), (4096, 2), (11008, 3), (2048 * 4096, 4)):  # a decode vector ... a prefill activation (32 MB)
     x = data(rank, n, seed).cuda()
-    want = rank_order_sum(n, seed)
     y = torch.empty_like(x)
     assert L.ns_tp_reduce_add(tp, x.data_ptr(), y.data_ptr(), n, st) == 0, pkg.last_error()  # out of place
     assert L.ns_tp_reduce_add(tp, x.data_ptr(), x.data_ptr(), n, st) == 0, pkg.last_error()  # in place
     torch.cuda.synchronize()
-    assert torch.equal(y.cpu(), want) and torch.equal(x.cpu(), want), (n, float((x.cpu() - want).abs().max()))
+    assert is_sum(y.cpu(), n, seed) and is_sum(x.cpu(), n, seed), (n, float((x.cpu() - rank_order_sum(n, seed)).abs().max()))
 b = (data(0, 5000, 9) if rank == 0 else torch.zeros(5000)).cuda()
 assert L.ns_tp_broadcast(tp, b.data_ptr(), b.numel(), st) == 0, pkg.last_error()
 torch.cuda.synchronize()
@@ -99,7 +112,7 @@ assert torch.equal(z.cpu(), torch.arange(4096, dtype=torch.float32) * float(2 * 
 h = data(rank, 3000, 30).numpy().copy()
 o = np.zeros_like(h)
 assert L.ns_tp_reduce_add_host(tp, h.ctypes.data, o.ctypes.data, h.size) == 0, pkg.last_error()
-assert np.array_equal(o, rank_order_sum(3000, 30).numpy())
+assert is_sum(o, 3000, 30)
 hb = data(0, 100, 31).numpy().copy() if rank == 0 else np.zeros(100, np.float32)
 assert L.ns_tp_broadcast_host(tp, hb.ctypes.data, hb.size) == 0 and np.array_equal(hb, data(0, 100, 31).numpy())
 hs = np.concatenate([data(rank, 50, 40 + p).numpy() for p in range(world)])
@@ -129,8 +142,9 @@ if all(ok for ok, _ in infos) and L.ns_hip_p2p_connect(p2p, b"".join(hh for _, h
         assert L.ns_tp_reduce_add(tp, x.data_ptr(), x.data_ptr(), n, st) == 0, pkg.last_error()
         torch.cuda.synchronize()
         got, want = x.cpu(), rank_order_sum(n, seed)
-        # the kernel adds in rank order too (ns_p2p.hip): bit-equal; tolerate a reassociation only in the message
-        assert torch.equal(got, want), (n, float((got - want).abs().max()))
+        # the kernel adds in rank order too (ns_p2p.hip): bit-equal whatever the collective library does; above the slot the
+        # library serves the call
+        assert is_sum(got, n, seed, exact=True if n * 4 <= (1 << 20) else None), (n, float((got - want).abs().max()))
     assert L.ns_hip_p2p_error(p2p) == 0
     routed = "peer-memory kernel + stand-in"
     L.ns_tp_attach_p2p(tp, None, 0)
@@ -160,7 +174,7 @@ ctx = G.init_parallel_context()
 assert G.get_tp_size(ctx) == world and G.get_tp_rank(ctx) == rank and G.is_master(ctx) == (rank == 0)
 t = data(rank, 4096, 60).numpy().copy()  # ne_compute_forward_all_reduce: reduce_add(dst->data, dst->data, ...) in place
 G.reduce_add(ctx, t.ctypes.data, t.ctypes.data, t.size)
-assert np.array_equal(t, rank_order_sum(4096, 60).numpy())
+assert is_sum(t, 4096, 60)
 bb = data(0, 64, 61).numpy().copy() if rank == 0 else np.zeros(64, np.float32)
 G.broadcast(ctx, bb.ctypes.data, bb.size)
 assert np.array_equal(bb, data(0, 64, 61).numpy())
