@@ -231,6 +231,18 @@ int ns_hip_get_compute_mode(void);
  * Returns 0, or -1 for an unknown key. */
 int ns_hip_set_tuning(const char* key, int value);
 
+/* Replay of the reference's per-token device graph (csrc/ns_route.cpp; the reference rebuilds its graph every token,
+ * models/llama/llama.cpp:148, and issues it node by node, core/ne_layers.c:11915-12028).  The launches of the bestla_device_* route on the
+ * queue bestla_create_device made are recorded; two consecutive tokens whose launch sequences differ only in one moving value per launch
+ * (RoPE position, kv-cache cell, context length) make a plan of HIP-graph segments; later tokens are compared launch by launch and each
+ * segment is replayed once its last launch has matched - a token that deviates falls back to plain launches without side effects.
+ * ns_hip_route_set_enabled(0 / 1) (environment NS_DEVICE_REPLAY) returns the previous setting; ns_hip_route_stats: [0] tokens replayed,
+ * [1] tokens launched eagerly, [2] plans built, [3] fall-backs, [4] the reference's launches per token in the last plan, [5] the launches its graphs hold for them (runs of
+ * single operators become the library's fused launches at capture time),
+ * [6] plans that could not be captured, [7] 1 while a plan is held. */
+int ns_hip_route_set_enabled(int on);
+void ns_hip_route_stats(uint64_t out[8]);
+
 /* epilogue selector for the device forwards */
 enum ns_epilogue {
   NS_EPI_NONE = 0,      /* AccumulatorWriteBackFp32 (bestla_epilogue.h:114-136) */

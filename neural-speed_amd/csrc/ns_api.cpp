@@ -2019,6 +2019,14 @@ int ns_hip_norm_mul_h(int norm_count, int norm_size, bool isrms, float epsilon, 
 int ns_hip_rope_f32(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                     int mode, float freq_base, float freq_scale, float ext_factor, float attn_factor, void* stream) {
   if (!have_device()) return -1;
+  if (route_hook(stream)) {  // the reference's device route: described, verified against the plan, replayed (ns_route.cpp)
+    RouteOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = RK_ROPE, op.p[0] = dSrc, op.p[1] = dDst;
+    op.i[0] = batch, op.i[1] = seq, op.i[2] = heads, op.i[3] = head_size, op.i[4] = n_past, op.i[5] = n_dims, op.i[6] = mode;
+    op.f[0] = freq_base, op.f[1] = freq_scale, op.f[2] = ext_factor, op.f[3] = attn_factor;
+    return route_submit(op);
+  }
   if (!dSrc || !dDst || batch < 0 || seq < 0 || heads < 0 || head_size <= 0 || (head_size & 1) || n_dims <= 0 ||
       (n_dims & 1) || n_dims > head_size || n_past < 0) {
     set_error("rope: invalid argument");
@@ -2084,6 +2092,14 @@ static int rope_ext(const float* dSrc, float* dDst, int batch, int seq, int head
 int ns_hip_rope_f32_yarn(const float* dSrc, float* dDst, int batch, int seq, int heads, int head_size, int n_past,
                          int n_dims, int mode, float freq_base, float freq_scale, int n_orig_ctx, float ext_factor,
                          float attn_factor, float beta_fast, float beta_slow, void* stream) {
+  if (route_hook(stream)) {
+    RouteOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = RK_ROPE_YARN, op.p[0] = dSrc, op.p[1] = dDst;
+    op.i[0] = batch, op.i[1] = seq, op.i[2] = heads, op.i[3] = head_size, op.i[4] = n_past, op.i[5] = n_dims, op.i[6] = mode, op.i[7] = n_orig_ctx;
+    op.f[0] = freq_base, op.f[1] = freq_scale, op.f[2] = ext_factor, op.f[3] = attn_factor, op.f[4] = beta_fast, op.f[5] = beta_slow;
+    return route_submit(op);
+  }
   if (mode & 0x10) {
     set_error("rope: long-rope needs ns_hip_rope_f32_longrope (factor array)");
     return -1;
@@ -2140,6 +2156,14 @@ int ns_hip_dup_f32(const float* dSrc, void* dDst, const long long ne[4], const l
       set_error("dup: negative extent");
       return -1;
     }
+  if (route_hook(stream)) {
+    RouteOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = RK_DUP, op.p[0] = dSrc, op.p[1] = dDst;
+    for (int i = 0; i < 4; i++) op.i[i] = ne[i], op.i[4 + i] = src_nb[i], op.i[8 + i] = dst_nb[i];
+    op.i[12] = dst_is_f16 ? 1 : 0;
+    return route_submit(op);
+  }
   return hip_ok(launch_dup(dSrc, dDst, ne, src_nb, dst_nb, dst_is_f16, (hipStream_t)stream), "dup launch") ? 0 : -1;
 }
 

@@ -263,6 +263,32 @@ hipError_t launch_rmsnorm(int norm_count, int norm_size, bool isrms, float eps, 
                           hipStream_t st, const float* gamma = nullptr, void* out16 = nullptr);
 hipError_t launch_norm_prep(int m, int n, const float* x, int ldx, const float* gamma, void* x16, float* ssq,
                             int ssq_stride, hipStream_t st);
+// Replay of the reference's device route (round 5, ns_device.hip "route"): a captured launch may take ONE moving value — a position, a
+// context length, a cache address — as base + delta * (*k), k a device word the replayed graph increments once per token.  The
+// launchers below that have such a value (launch_rope: n_past, launch_dup: dst, the device-layout attention: seq_all) read this
+// thread-local; k == nullptr (always, outside a route capture) = the plain value.
+struct Affine {
+  const int* k = nullptr;
+  long long delta = 0;
+  long long delta2 = 0;  // launch_dup2: the second copy's destination
+};
+extern thread_local Affine g_affine;
+// ns_route.cpp: one launch of the reference's device route as plain data (compared bytewise: zero-initialise before filling)
+enum RouteKind : uint32_t { RK_GEMM = 1, RK_ADD, RK_MUL, RK_SILU, RK_RMSNORM, RK_ROPE, RK_ROPE_YARN, RK_DUP, RK_MHA };
+struct RouteOp {
+  uint32_t kind, flags;
+  const void* p[4];
+  long long i[24];
+  float f[8];
+};
+bool route_hook(void* stream);             // true: the caller describes its launch in a RouteOp and hands it to route_submit
+int route_submit(const RouteOp& op);
+int route_sync_point(void* stream);        // bestla_device_sync / _memcpy: pending work goes out, a token may end here
+void route_attach(void* stream);           // bestla_create_device
+void route_detach(void* stream);
+void route_invalidate();                   // bestla_device_free
+void* route_translate_dst(void* dst, const void* src, size_t size, void* stream);  // bestla_device_memcpy while a plan is held (ns_route.cpp)
+const void* route_translate_src(const void* src, void* stream);
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st,
                        float ext_factor = 0.f, float corr0 = 0.f, float corr1 = 0.f, const float* lr_factor = nullptr,
@@ -290,6 +316,14 @@ hipError_t i8_quantize_for_decode(const float* a, int lda, const ns_weight* w, i
 hipError_t launch_i8ref(const float* a, int lda, const ns_weight* w, float* c, void* c16, int m, int ldc, int epilogue,
                         const float* d, int ldd, hipStream_t st, bool reuse_aq = false);
 hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t st);
+// rope(q), rope(k) in place on adjacent rows + the K and V cache writes of one decode position in one launch (ns_route.cpp)
+hipError_t launch_rope_append(float* qk, int rows_front, int rows_k_first, int rows_k, int head_size, int n_past, int n_dims, int mode, float freq_base,
+                              float freq_scale, float attn_factor, float ext_factor, float corr0, float corr1, const void* ksrc, void* kdst,
+                              const long long* kne, const long long* ksnb, const long long* kdnb, const void* vsrc, void* vdst, const long long* vne,
+                              const long long* vsnb, const long long* vdnb, long long kd_k, long long kd_v, hipStream_t st);
+// two strided copies in one launch (the K and V cache writes of a decode step: ns_route.cpp fuses the reference's two cpy nodes)
+hipError_t launch_dup2(const void* src0, void* dst0, const long long* ne0, const long long* snb0, const long long* dnb0, bool f16_0,
+                       const void* src1, void* dst1, const long long* ne1, const long long* snb1, const long long* dnb1, bool f16_1, hipStream_t st);
 hipError_t launch_dup(const void* src, void* dst, const long long* ne, const long long* snb, const long long* dnb, bool dst_f16,
                       hipStream_t st);
 hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float* v, int vstep, float* out, bool mul,

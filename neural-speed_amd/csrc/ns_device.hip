@@ -135,8 +135,15 @@ typedef float dfloat4 __attribute__((ext_vector_type(4)));
 template <int DPL>
 __global__ __launch_bounds__(256) void mha_f32_split_kernel(const float* q, const float* k, const float* v, float* o, float* ws, int nsplit,
                                                             int seq, int seq_all, int heads, int heads_kv, int n_ctx, float scale,
-                                                            int masked) {
+                                                            int masked, const int* __restrict__ kmove, int kdelta) {
   constexpr int HS = 16 * DPL;
+  // replayed device route (ns_common.h Affine): the context length moves with the graph's token counter; the grid and the partials'
+  // layout are those of the longest context (nsplit = ranges of n_ctx), ranges past the live length leave at once and the merge
+  // (always launched then) reads the live ones only
+  if (kmove) {
+    seq_all += kdelta * *kmove;
+    if (int(blockIdx.x) * kMhaKS >= seq_all) return;
+  }
   __shared__ float sc[kMhaKS];
   __shared__ float red[4];
   const int split = blockIdx.x, ih = blockIdx.y, bq = blockIdx.z, ib = bq / seq, iq = bq % seq;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256) void mha_f32_split_kernel(const float* q, cons
   __syncthreads();
   const float l = red[0] + red[1] + red[2] + red[3];
   if (sub == 0) {
-    if (nsplit == 1) {
+    if (nsplit == 1 && !kmove) {
       float* op = o + (size_t(bq) * heads + ih) * HS;
 #pragma unroll
       for (int i = 0; i < DPL; i++) op[grp + 16 * i] = part[i] / l;
@@ -240,10 +247,11 @@ __global__ __launch_bounds__(256) void mha_f32_split_kernel(const float* q, cons
   }
 }
 // one workgroup of head_size threads per (query row, head): combine the ranges' (max, sum, output) in range order
-__global__ void mha_f32_merge_kernel(const float* ws, float* o, int nsplit, int hs) {
+__global__ void mha_f32_merge_kernel(const float* ws, float* o, int nsplit, int hs, int seq_all, const int* __restrict__ kmove, int kdelta) {
   const size_t row = blockIdx.x;  // (batch * seq + iq) * heads + head
   const int t = threadIdx.x;
   const float* wp = ws + row * nsplit * (2 + hs);
+  if (kmove) nsplit = (seq_all + kdelta * *kmove + kMhaKS - 1) / kMhaKS;  // the live ranges of a layout made for the longest context
   float mb = -INFINITY;
   for (int s2 = 0; s2 < nsplit; s2++) mb = fmaxf(mb, wp[size_t(s2) * (2 + hs)]);
   float lb = 0.f, ab = 0.f;
@@ -274,6 +282,16 @@ struct Device {
   int id;
 };
 
+// a strided binary node of the device route as plain data (ns_route.cpp)
+inline RouteOp binary_op(uint32_t kind, const float* a, const float* b, float* d, const long long ne0[4], const long long nb0[4], const long long ne1[4],
+                         const long long nb1[4], const long long nbd[4]) {
+  RouteOp op;
+  memset(&op, 0, sizeof(op));
+  op.kind = kind, op.p[0] = a, op.p[1] = b, op.p[2] = d;
+  for (int i = 0; i < 4; i++) op.i[i] = ne0[i], op.i[4 + i] = nb0[i], op.i[8 + i] = ne1[i], op.i[12 + i] = nb1[i], op.i[16 + i] = nbd[i];
+  return op;
+}
+
 }  // namespace ns
 
 extern "C" {
@@ -297,6 +315,7 @@ void* bestla_create_device(bool profile) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, d->id) == hipSuccess)
     fprintf(stderr, "bestla device: %s, %d CUs, %.1f GB\n", prop.name, prop.multiProcessorCount, double(prop.totalGlobalMem) / 1e9);
+  ns::route_attach(d->stream);  // ns_route.cpp: the per-token graph this queue carries is verified and replayed
   return d;
 }
 void* bestla_get_device_queue(void* device) { return device ? static_cast<ns::Device*>(device)->stream : nullptr; }
@@ -306,6 +325,7 @@ void bestla_release_device(void* device) {
   (void)ns_hip_lazy_flush();
   finish_pending_loads_if_any();
   ns::Device* d = static_cast<ns::Device*>(device);
+  ns::route_detach(d->stream);
   (void)hipStreamSynchronize(d->stream);
   (void)hipStreamDestroy(d->stream);
   delete d;
@@ -328,17 +348,23 @@ void bestla_device_free(void* ptr, void* queue) {
   (void)queue;
   // nothing recorded or in flight may still refer to the memory: the lazy node's operands, the loads into the graph's slices
   (void)ns_hip_lazy_flush();
+  ns::route_invalidate();
   finish_pending_loads_if_any();
   if (ptr) (void)hipFree(ptr);
 }
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {
   (void)ns_hip_lazy_flush();
+  (void)ns::route_sync_point(queue);
   if (!dstptr || !srcptr || !size) return;
+  // (replayed tokens run on the plan's activations: the embeddings go there, the logits come from there — ns_route.cpp)
+  dstptr = ns::route_translate_dst(dstptr, srcptr, size, queue);
+  srcptr = ns::route_translate_src(srcptr, queue);
   if (hipMemcpyAsync(dstptr, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
     ns::set_error("bestla_device_memcpy failed");
 }
 void bestla_device_sync(void* queue) {
   (void)ns_hip_lazy_flush();
+  (void)ns::route_sync_point(queue);
   (void)hipStreamSynchronize(static_cast<hipStream_t>(queue));
 }
 void bestla_device_memcpy_sync(void* dstptr, const void* srcptr, size_t size, void* queue) {
@@ -458,8 +484,18 @@ void bestla_device_f32f32_forward(float* activation, void* weiptr, float* output
     printf("Err: invalid parameters (bestla_device_f32f32_forward: %s)\n", ns_hip_last_error());
     return;
   }
-  if (ns_hip_f32f32_forward(activation, s->w, output, _m, lda, ldo, NS_EPI_NONE, nullptr, 0, queue) != 0)
-    printf("Err: invalid parameters (bestla_device_f32f32_forward: %s)\n", ns_hip_last_error());
+  int rc;
+  if (ns::route_hook(queue)) {
+    ns::RouteOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = ns::RK_GEMM;
+    op.p[0] = activation, op.p[1] = s->w, op.p[2] = output;
+    op.i[0] = _m, op.i[1] = _n, op.i[2] = _k, op.i[3] = lda, op.i[4] = ldo;
+    rc = ns::route_submit(op);
+  } else {
+    rc = ns_hip_f32f32_forward(activation, s->w, output, _m, lda, ldo, NS_EPI_NONE, nullptr, 0, queue);
+  }
+  if (rc != 0) printf("Err: invalid parameters (bestla_device_f32f32_forward: %s)\n", ns_hip_last_error());
 }
 
 /* releases the device copy behind a storage area (the reference never frees its device weights either; offered for
@@ -530,6 +566,12 @@ int lazy_flush_impl() {
 }  // extern "C++"
 int ns_hip_lazy_flush(void) { return ns::g_lazy.kind ? ns::lazy_flush_impl() : 0; }
 int ns_hip_lazy_rms_norm(int rows, int cols, float eps, const float* dIn, float* dOut, void* stream) {
+  if (ns::route_hook(stream)) {
+    ns::RouteOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = ns::RK_RMSNORM, op.p[0] = dIn, op.p[1] = dOut, op.i[0] = rows, op.i[1] = cols, op.f[0] = eps;
+    return ns::route_submit(op);
+  }
   if (ns_hip_lazy_flush() != 0) return -1;
   if (!dIn || !dOut || rows < 1 || cols < 1) {
     ns::set_error("lazy rms_norm: invalid argument");
@@ -539,6 +581,12 @@ int ns_hip_lazy_rms_norm(int rows, int cols, float eps, const float* dIn, float*
   return ns::lazy_on() ? 0 : ns_hip_lazy_flush();
 }
 int ns_hip_lazy_silu(const float* dSrc, float* dDst, size_t n, void* stream) {
+  if (ns::route_hook(stream)) {
+    ns::RouteOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = ns::RK_SILU, op.p[0] = dSrc, op.p[1] = dDst, op.i[0] = (long long)n;
+    return ns::route_submit(op);
+  }
   if (ns_hip_lazy_flush() != 0) return -1;
   if (n && (!dSrc || !dDst)) {
     ns::set_error("lazy silu: null argument");
@@ -553,6 +601,7 @@ int ns_hip_binary_nd_f32(int is_mul, const float* dA, const float* dB, float* dD
 /* the multiply node: fused with the recorded node when it consumes it, else the recorded node first and the plain kernel */
 int ns_hip_lazy_mul(const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4], const long long ne1[4],
                     const long long nb1[4], const long long nbd[4], void* stream) {
+  if (ns::route_hook(stream)) return ns::route_submit(ns::binary_op(ns::RK_MUL, dA, dB, dDst, ne0, nb0, ne1, nb1, nbd));
   const ns::LazyNode n = ns::g_lazy;
   auto packed = [](const long long ne[4], const long long nb[4]) {
     return nb[0] == 4 && nb[1] == 4 * ne[0] && nb[2] == nb[1] * ne[1] && nb[3] == nb[2] * ne[2];
@@ -587,6 +636,7 @@ int ns_hip_lazy_mul(const float* dA, const float* dB, float* dDst, const long lo
 /* ---- kernels behind the tensor-level functions of glue/ne_bestla_hip_device.c ---- */
 int ns_hip_binary_nd_f32(int is_mul, const float* dA, const float* dB, float* dDst, const long long ne0[4], const long long nb0[4],
                          const long long ne1[4], const long long nb1[4], const long long nbd[4], void* stream) {
+  if (ns::route_hook(stream)) return ns::route_submit(ns::binary_op(is_mul ? ns::RK_MUL : ns::RK_ADD, dA, dB, dDst, ne0, nb0, ne1, nb1, nbd));
   if (ns_hip_lazy_flush() != 0) return -1;
   if (!dA || !dB || !dDst) {
     ns::set_error("binary_nd: null argument");
@@ -616,12 +666,25 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
     ns::set_error("mha_f32: invalid argument");
     return -1;
   }
+  if (ns::route_hook(stream)) {
+    ns::RouteOp op;
+    memset(&op, 0, sizeof(op));
+    op.kind = ns::RK_MHA, op.p[0] = dQ, op.p[1] = dK, op.p[2] = dV, op.p[3] = dO;
+    op.i[0] = batch, op.i[1] = seq, op.i[2] = seq_all, op.i[3] = heads, op.i[4] = heads_kv, op.i[5] = head_size, op.i[6] = n_ctx, op.i[7] = masked;
+    op.f[0] = scale;
+    return ns::route_submit(op);
+  }
   if (ns_hip_lazy_flush() != 0) return -1;
   // ---- the context split over workgroups: head sizes 64 / 128 / 256, from two 128-key ranges on ----
   static const bool no_split = getenv("NS_MHA_NO_SPLIT") != nullptr;  // diagnostics (A/B)
-  const int nsplit = (seq_all + ns::kMhaKS - 1) / ns::kMhaKS;
+  const ns::Affine aff = ns::g_affine;
+  if (aff.k && !(seq == 1 && (head_size == 64 || head_size == 128 || head_size == 256) && n_ctx >= seq_all)) {
+    ns::set_error("mha_f32: a moving context length needs the context-split kernel (decode step, head size 64 / 128 / 256)");
+    return -1;
+  }
+  const int nsplit = aff.k ? (n_ctx + ns::kMhaKS - 1) / ns::kMhaKS : (seq_all + ns::kMhaKS - 1) / ns::kMhaKS;
   const size_t rows = size_t(batch) * seq * heads;
-  if (!no_split && nsplit >= 2 && (head_size == 64 || head_size == 128 || head_size == 256) && size_t(batch) * seq <= 65535 && heads <= 65535 &&
+  if ((!no_split || aff.k) && (nsplit >= 2 || aff.k) && (head_size == 64 || head_size == 128 || head_size == 256) && size_t(batch) * seq <= 65535 && heads <= 65535 &&
       (reinterpret_cast<uintptr_t>(dQ) & 15) == 0 && (reinterpret_cast<uintptr_t>(dK) & 15) == 0) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     // a prompt's rows (batch 1, causal) go through in chunks so that the partials stay within 64 MB of scratch whatever the prompt
@@ -635,18 +698,19 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
       for (int r0 = 0; r0 < seq; r0 += chunk) {
         const int nr = std::min(chunk, seq - r0);
         const int sa = chunk == seq ? seq_all : seq_all - seq + r0 + nr;  // keys this chunk's last row sees
-        const int ns_c = (sa + ns::kMhaKS - 1) / ns::kMhaKS;
+        const int ns_c = aff.k ? nsplit : (sa + ns::kMhaKS - 1) / ns::kMhaKS;
         const float* q_c = dQ + size_t(r0) * heads * head_size;
         float* o_c = dO + size_t(r0) * heads * head_size;
         const dim3 grid(unsigned(ns_c), unsigned(heads), unsigned(batch * nr));
         if (head_size == 64)
-          hipLaunchKernelGGL(ns::mha_f32_split_kernel<4>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked);
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<4>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta));
         else if (head_size == 128)
-          hipLaunchKernelGGL(ns::mha_f32_split_kernel<8>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked);
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<8>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta));
         else
-          hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked);
-        if (ns_c > 1)
-          hipLaunchKernelGGL(ns::mha_f32_merge_kernel, dim3(unsigned(size_t(batch) * nr * heads)), dim3(unsigned(head_size)), 0, st, ws, o_c, ns_c, head_size);
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta));
+        if (ns_c > 1 || aff.k)
+          hipLaunchKernelGGL(ns::mha_f32_merge_kernel, dim3(unsigned(size_t(batch) * nr * heads)), dim3(unsigned(head_size)), 0, st, ws, o_c, ns_c, head_size,
+                             sa, aff.k, int(aff.delta));
       }
       if (hipGetLastError() != hipSuccess) {
         ns::set_error("mha_f32: launch failed");
@@ -654,6 +718,10 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
       }
       return 0;
     }
+  }
+  if (aff.k) {
+    ns::set_error("mha_f32: the moving-length form needs 16-byte aligned q / k and scratch for the partials");
+    return -1;
   }
   const size_t lds = (size_t((seq_all + 3) & ~3) + 256) * sizeof(float);
   if (lds > 160 * 1024) {

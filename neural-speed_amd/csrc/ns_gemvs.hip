@@ -43,6 +43,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <utility>
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "../../include/ns_bestla.h"
 #include "ns_common.h"
@@ -102,6 +106,8 @@ struct GvsParams {
   uint32_t a_off;           // LDS offset of the staged activations (behind the f4 pair table when there is one)
   uint32_t a_bytes;         // bytes of the staged activations (rows x row_stride halves)
   uint32_t lut16[8];        // f4: the 16 table values as fp16, two per word
+  const void* tbl_img;      // f4: the 32 KB pair table as a device image (round 5: fetched by LDS-DMA beside the activations instead of
+                            // ~1.4 us of VALU per launch); nullptr: the waves build it (the image did not exist yet at capture time)
   // ---- cold ----
   GvsMat mat[3];
   float* c2;
@@ -142,6 +148,37 @@ __device__ __forceinline__ void gvs_wait_vmcnt() {
 }
 
 enum GvsMode { GS_PLAIN = 0, GS_DUAL = 1, GS_MSEG = 2 };
+
+// ---- f4 pair-table images (host side): entry e = {value[e & 15], value[e >> 4]} as two fp16, 32 bank copies each — what build_table
+//      writes.  One image per value table (NF4 / FP4-BNB / FP4-E2M1), created on the first launch that wants it OUTSIDE a stream
+//      capture (an allocation + a synchronous copy); a launch that finds none gets nullptr and builds the table with its waves ----
+static std::mutex g_tbl_mu;
+static std::map<std::array<uint16_t, 16>, void*> g_tbl_img;
+static const void* gvs_f4_table_image(const _Float16* lut, hipStream_t st) {
+  static const bool off = getenv("NS_GVS_TABLE_DMA") && atoi(getenv("NS_GVS_TABLE_DMA")) == 0;  // A-B runs
+  if (off) return nullptr;
+  std::array<uint16_t, 16> key;
+  for (int i = 0; i < 16; i++) key[i] = __builtin_bit_cast(uint16_t, lut[i]);
+  std::lock_guard<std::mutex> lk(g_tbl_mu);
+  auto it = g_tbl_img.find(key);
+  if (it != g_tbl_img.end()) return it->second;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  std::vector<uint32_t> img(kGsTblBytes / 4);
+  for (uint32_t e = 0; e < 256; e++)
+    for (uint32_t c = 0; c < 32; c++) img[e * 32 + c] = uint32_t(key[e & 15]) | (uint32_t(key[e >> 4]) << 16);
+  void* d = nullptr;
+  if (hipMalloc(&d, kGsTblBytes) != hipSuccess || hipMemcpy(d, img.data(), kGsTblBytes, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    if (d) (void)hipFree(d);
+    return nullptr;  // (not cached: tried again next time)
+  }
+  g_tbl_img.emplace(key, d);
+  return d;
+}
 
 // epilogue of one tile: lane (nn, g) holds rows 4g .. 4g+3 of column `col` (custom::epilogue::*, bestla_f32f32_forward;
 // dual: tmp1 = act(A*W1), out = (A*W3) * tmp1, neural_speed/core/layers/ip_fusion_ffn.cpp:364-406)
@@ -248,6 +285,18 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
 #endif
       c += NS + 1u;
     }
+  };
+  // f4, round 5: the pair table is the same 32 KB for every launch on a value table — one device image per table (host:
+  // gvs_f4_table_image), its 32 one-KiB pieces dealt to all waves and requested right behind the activation pieces (L2-resident:
+  // every workgroup of every launch reads the same 32 KB); same queue position as the activations, so the same wait covers them
+  auto stage_table = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (TBL) {
+      const Rsrc rt = make_rsrc(p.tbl_img, kGsTblBytes);
+      for (uint32_t u = w; u < kGsTblBytes / 1024u; u += NS + 1u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, reinterpret_cast<__attribute__((address_space(3))) void*>((LdsPtr)(smem) + (u << 10)), 16, voff_q, u << 10, 0, 0);
+    }
+#endif
   };
   auto build_table = [&]() {
     // f4: every wave writes its share of the pair table while its requests are in flight.  Lane l < 16 holds table
@@ -397,11 +446,13 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
     // ---- 1. this wave's share of the activations (a handful of requests, L2), its first weight records (HBM), then its
     //      share of the f4 table while both are in flight (the table in FRONT of the weight requests delayed them to 3.4 us
     //      after entry, profiles/r04e_trace.txt) ----
+    const bool tbl_dma = p.tbl_img != nullptr;  // (uniform)
     stage_a();
+    if (tbl_dma) stage_table();
     NS_FOR_SLOTS({ if (uint32_t(i) < total) issue(ic); })
     __builtin_amdgcn_sched_barrier(0);
     NS_SSTAMP(1);
-    build_table();
+    if (!tbl_dma) build_table();
     __builtin_amdgcn_sched_barrier(0);
     // ---- 2. the activation pieces are the oldest requests in this wave's queue: landed once only ring requests are left ----
     wait_records(min(total, uint32_t(PF)));
@@ -565,7 +616,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
     // first flush
     if (l < int(kGsCtlBytes / 4)) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + p.ctl_off + uint32_t(l) * 4u), "v"(0u) : "memory");
     stage_a();
-    build_table();
+    if (p.tbl_img) stage_table(); else build_table();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NS_SSTAMP(2);
     shuffle_own_a();
@@ -1040,6 +1091,7 @@ hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st) {
     f4_lut_planes(w0->lut, &p.lut);
     for (int i = 0; i < 8; i++)
       p.lut16[i] = uint32_t(__builtin_bit_cast(unsigned short, w0->lut[2 * i])) | (uint32_t(__builtin_bit_cast(unsigned short, w0->lut[2 * i + 1])) << 16);
+    p.tbl_img = best.tbl ? gvs_f4_table_image(w0->lut, st) : nullptr;
   }
   p.f8 = f8_consts(w0->qtype);
 #ifdef NS_TRACE

@@ -807,7 +807,8 @@ __device__ __forceinline__ float rope_theta(float theta_extrap, float freq_scale
 }
 __global__ void rope_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int heads, int seq,
                             int head_size, int n_past, int n_dims, int neox, float theta_scale, float freq_scale,
-                            float attn_factor, RopeYarn yarn) {
+                            float attn_factor, RopeYarn yarn, const int* __restrict__ kmove, int kdelta) {
+  if (kmove) n_past += kdelta * *kmove;  // replayed device route: the position moves with the graph's token counter (ns_common.h Affine)
   const int half = head_size / 2;  // pairs per row in both modes ((head_size / n_dims) * (n_dims / 2) for NeoX)
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(half);
@@ -1035,6 +1036,8 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
   return hipGetLastError();
 }
 
+thread_local Affine g_affine;
+
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st, float ext_factor,
                        float corr0, float corr1, const float* lr_factor, float lr_scale) {
@@ -1049,7 +1052,8 @@ hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int hea
   const float theta_scale = powf(freq_base, -2.0f / n_dims);
   const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(head_size / 2);
   hipLaunchKernelGGL(rope_kernel, grid1d(rows * npairs, 256), dim3(256), 0, st, src, dst, rows, heads, seq, head_size, n_past,
-                     n_dims, neox ? 1 : 0, theta_scale, freq_scale, attn_factor, RopeYarn{ext_factor, corr0, corr1, lr_factor, lr_scale});
+                     n_dims, neox ? 1 : 0, theta_scale, freq_scale, attn_factor, RopeYarn{ext_factor, corr0, corr1, lr_factor, lr_scale},
+                     g_affine.k, int(g_affine.delta));
   return hipGetLastError();
 }
 
@@ -1121,7 +1125,9 @@ hipError_t launch_silu(const float* x, float* y, size_t n, hipStream_t st) {
 struct DupDims {
   long long ne[4], snb[4], dnb[4];  // extents of dst, byte strides of src and dst
 };
-__global__ void dup_kernel(const char* __restrict__ src, char* __restrict__ dst, DupDims d, int dst_f16) {
+__global__ void dup_kernel(const char* __restrict__ src, char* __restrict__ dst, DupDims d, int dst_f16, const int* __restrict__ kmove,
+                           long long kdelta) {
+  if (kmove) dst += kdelta * (long long)*kmove;  // replayed device route: the kv-cache cell moves with the graph's token counter
   const long long total = d.ne[0] * d.ne[1] * d.ne[2] * d.ne[3];
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -1138,6 +1144,130 @@ __global__ void dup_kernel(const char* __restrict__ src, char* __restrict__ dst,
   else
     *reinterpret_cast<float*>(o) = v;
 }
+// RoPE of q and k (adjacent rows, in place, one position) + the two kv-cache writes of a decode step in ONE launch (ns_route.cpp fuses the
+// reference's rope(q), rope(k), cpy(k), cpy(v) nodes of a replayed token: llama.cpp:232-262).  Thread t < pairs rotates pair t of the q / k rows
+// with rope_kernel's arithmetic (same angle products) and, for a k element, also stores it at its cache cell; the next nv threads copy v.
+__global__ void rope_append_kernel(float* __restrict__ qk, int rows_front, int rows_k_first, int rows_k, int head_size, int n_past, int n_dims,
+                                   int neox, float theta_scale, float freq_scale, float attn_factor, RopeYarn yarn, const float* __restrict__ ksrc,
+                                   char* __restrict__ kdst, DupDims dk, const char* __restrict__ vsrc, char* __restrict__ vdst, DupDims dv,
+                                   const int* __restrict__ kmove, int kd_pos, long long kd_k, long long kd_v) {
+  if (kmove) {
+    const int kk = *kmove;
+    n_past += kd_pos * kk;
+    kdst += kd_k * (long long)kk;
+    vdst += kd_v * (long long)kk;
+  }
+  const int half = head_size / 2;
+  const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(half);
+  const size_t rows = size_t(rows_front);
+  const long long nk = dk.ne[0] * dk.ne[1] * dk.ne[2] * dk.ne[3], nv = dv.ne[0] * dv.ne[1] * dv.ne[2] * dv.ne[3];
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid < rows * npairs) {
+    const size_t row = gid / npairs;
+    const int pr = int(gid % npairs);
+    float theta_base = float(n_past);
+    if (neox) theta_base = __fmul_rn(theta_base, freq_scale);
+    for (int t = 0; t < pr; t++) theta_base = __fmul_rn(theta_base, theta_scale);
+    int ia, ib, i0;
+    if (neox) {
+      const int blk = pr / (n_dims / 2), ic = pr % (n_dims / 2);
+      ia = blk * n_dims + ic;
+      ib = ia + n_dims / 2;
+      i0 = int(__fsub_rn(__fmul_rn(__fdiv_rn(-1.f, float(n_dims)), float(2 * ic)), float(blk)));
+    } else {
+      ia = 2 * pr;
+      ib = ia + 1;
+      i0 = ia;
+    }
+    const float theta = rope_theta(theta_base, freq_scale, i0, yarn);
+    const float c = __fmul_rn(cosf(theta), attn_factor), sn = __fmul_rn(sinf(theta), attn_factor);
+    float* x = qk + row * head_size;
+    const float x0 = x[ia], x1 = x[ib];
+    const float y0 = __fsub_rn(__fmul_rn(x0, c), __fmul_rn(x1, sn)), y1 = __fadd_rn(__fmul_rn(x0, sn), __fmul_rn(x1, c));
+    x[ia] = y0;
+    x[ib] = y1;
+    // a k row: its two elements also go to the cache (k is [head_size][1][heads_kv] here: element index = head * head_size + dim)
+    const long long krow = (long long)row - rows_k_first;
+    if (krow >= 0 && krow < rows_k) {
+      for (int e = 0; e < 2; e++) {
+        long long i = krow * head_size + (e ? ib : ia);
+        const float val = e ? y1 : y0;
+        const long long i0d = i % dk.ne[0];
+        i /= dk.ne[0];
+        const long long i1d = i % dk.ne[1];
+        i /= dk.ne[1];
+        const long long i2d = i % dk.ne[2];
+        const long long i3d = i / dk.ne[2];
+        // (the cpy node indexes the source with the destination's coordinates: the element order of the packed source IS that walk)
+        *reinterpret_cast<float*>(kdst + i0d * dk.dnb[0] + i1d * dk.dnb[1] + i2d * dk.dnb[2] + i3d * dk.dnb[3]) = val;
+      }
+    }
+    return;
+  }
+  long long i = (long long)(gid - rows * npairs);
+  if (i >= nv) return;
+  const long long i0 = i % dv.ne[0];
+  i /= dv.ne[0];
+  const long long i1 = i % dv.ne[1];
+  i /= dv.ne[1];
+  const long long i2 = i % dv.ne[2];
+  const long long i3 = i / dv.ne[2];
+  *reinterpret_cast<float*>(vdst + i0 * dv.dnb[0] + i1 * dv.dnb[1] + i2 * dv.dnb[2] + i3 * dv.dnb[3]) =
+      *reinterpret_cast<const float*>(vsrc + i0 * dv.snb[0] + i1 * dv.snb[1] + i2 * dv.snb[2] + i3 * dv.snb[3]);
+  (void)ksrc;
+  (void)nk;
+}
+hipError_t launch_rope_append(float* qk, int rows_front, int rows_k_first, int rows_k, int head_size, int n_past, int n_dims, int mode, float freq_base,
+                              float freq_scale, float attn_factor, float ext_factor, float corr0, float corr1, const void* ksrc, void* kdst,
+                              const long long* kne, const long long* ksnb, const long long* kdnb, const void* vsrc, void* vdst, const long long* vne,
+                              const long long* vsnb, const long long* vdnb, long long kd_k, long long kd_v, hipStream_t st) {
+  DupDims dk, dv;
+  for (int i = 0; i < 4; i++) dk.ne[i] = kne[i], dk.snb[i] = ksnb[i], dk.dnb[i] = kdnb[i], dv.ne[i] = vne[i], dv.snb[i] = vsnb[i], dv.dnb[i] = vdnb[i];
+  const bool neox = (mode & 2) != 0;
+  const float theta_scale = powf(freq_base, -2.0f / n_dims);
+  const size_t npairs = neox ? size_t(head_size / n_dims) * (n_dims / 2) : size_t(head_size / 2);
+  const size_t total = size_t(rows_front) * npairs + size_t(vne[0] * vne[1] * vne[2] * vne[3]);
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(rope_append_kernel, grid1d(total, 256), dim3(256), 0, st, qk, rows_front, rows_k_first, rows_k, head_size, n_past, n_dims,
+                     neox ? 1 : 0, theta_scale, freq_scale, attn_factor, RopeYarn{ext_factor, corr0, corr1, nullptr, 1.f}, static_cast<const float*>(ksrc),
+                     static_cast<char*>(kdst), dk, static_cast<const char*>(vsrc), static_cast<char*>(vdst), dv, g_affine.k, int(g_affine.delta), kd_k, kd_v);
+  return hipGetLastError();
+}
+__global__ void dup2_kernel(const char* __restrict__ src0, char* __restrict__ dst0, DupDims d0, int f16_0, const char* __restrict__ src1,
+                            char* __restrict__ dst1, DupDims d1, int f16_1, const int* __restrict__ kmove, long long kdelta0, long long kdelta1) {
+  const long long total0 = d0.ne[0] * d0.ne[1] * d0.ne[2] * d0.ne[3];
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = i >= total0;
+  if (second) i -= total0;
+  const DupDims& d = second ? d1 : d0;
+  if (i >= d.ne[0] * d.ne[1] * d.ne[2] * d.ne[3]) return;
+  const char* src = second ? src1 : src0;
+  char* dst = second ? dst1 : dst0;
+  if (kmove) dst += (second ? kdelta1 : kdelta0) * (long long)*kmove;
+  const long long i0 = i % d.ne[0];
+  i /= d.ne[0];
+  const long long i1 = i % d.ne[1];
+  i /= d.ne[1];
+  const long long i2 = i % d.ne[2];
+  const long long i3 = i / d.ne[2];
+  const float v = *reinterpret_cast<const float*>(src + i0 * d.snb[0] + i1 * d.snb[1] + i2 * d.snb[2] + i3 * d.snb[3]);
+  char* o = dst + i0 * d.dnb[0] + i1 * d.dnb[1] + i2 * d.dnb[2] + i3 * d.dnb[3];
+  if (second ? f16_1 : f16_0)
+    *reinterpret_cast<_Float16*>(o) = (_Float16)v;
+  else
+    *reinterpret_cast<float*>(o) = v;
+}
+hipError_t launch_dup2(const void* src0, void* dst0, const long long* ne0, const long long* snb0, const long long* dnb0, bool f16_0,
+                       const void* src1, void* dst1, const long long* ne1, const long long* snb1, const long long* dnb1, bool f16_1, hipStream_t st) {
+  DupDims d0, d1;
+  for (int i = 0; i < 4; i++) d0.ne[i] = ne0[i], d0.snb[i] = snb0[i], d0.dnb[i] = dnb0[i], d1.ne[i] = ne1[i], d1.snb[i] = snb1[i], d1.dnb[i] = dnb1[i];
+  const long long total = ne0[0] * ne0[1] * ne0[2] * ne0[3] + ne1[0] * ne1[1] * ne1[2] * ne1[3];
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dup2_kernel, grid1d(size_t(total), 256), dim3(256), 0, st, static_cast<const char*>(src0), static_cast<char*>(dst0), d0,
+                     f16_0 ? 1 : 0, static_cast<const char*>(src1), static_cast<char*>(dst1), d1, f16_1 ? 1 : 0, g_affine.k, g_affine.delta,
+                     g_affine.delta2);
+  return hipGetLastError();
+}
 hipError_t launch_dup(const void* src, void* dst, const long long* ne, const long long* snb, const long long* dnb, bool dst_f16,
                       hipStream_t st) {
   DupDims d;
@@ -1145,7 +1275,7 @@ hipError_t launch_dup(const void* src, void* dst, const long long* ne, const lon
   const long long total = ne[0] * ne[1] * ne[2] * ne[3];
   if (total <= 0) return hipSuccess;
   hipLaunchKernelGGL(dup_kernel, grid1d(size_t(total), 256), dim3(256), 0, st, static_cast<const char*>(src),
-                     static_cast<char*>(dst), d, dst_f16 ? 1 : 0);
+                     static_cast<char*>(dst), d, dst_f16 ? 1 : 0, g_affine.k, g_affine.delta);
   return hipGetLastError();
 }
 

@@ -124,8 +124,17 @@ int nellama_generate(const char* model_path, const int* prompt, int n_prompt, in
  * (model_utils.cpp:140-160) and the device branch of the graph builder (llama.cpp:190-330: ne_device_sync, device RoPE,
  * ne_cpy into the cache, ne_flash_attn -> bestla_device_mha_f32).  libns_hip.so + glue/ne_bestla_hip_device.c answer the
  * bestla_device_* calls.  out_us_per_token: wall time of the single-token evals (may be NULL). */
+/* wall time of every single-token eval of the last nellama_generate_dev call, in order (the mean handed back by the call includes the
+ * eval at whose end the device route captures its replay plan: scripts read the median / the steady tail from here) */
+static std::vector<double> g_eval_us;
+int nellama_eval_times(double* out, int cap) {
+  const int n = static_cast<int>(g_eval_us.size()) < cap ? static_cast<int>(g_eval_us.size()) : cap;
+  for (int i = 0; i < n; i++) out[i] = g_eval_us[i];
+  return static_cast<int>(g_eval_us.size());
+}
 int nellama_generate_dev(const char* model_path, const int* prompt, int n_prompt, int n_new, int n_ctx, int n_gpu_layers,
                          int* out_tokens, float* out_logits, double* out_us_per_token) {
+  g_eval_us.clear();
   model_init_backend();
   ne_sycl_context* dev = model_init_sycl(false);
   if (!dev) return -3;
@@ -165,6 +174,7 @@ int nellama_generate_dev(const char* model_path, const int* prompt, int n_prompt
       return -2;
     }
     if (cur.size() == 1 && step > 1) us += double(ne_time_us() - t0), timed++;
+    if (cur.size() == 1) g_eval_us.push_back(double(ne_time_us() - t0));
     n_past += static_cast<int>(cur.size());
     const float* logits = model_get_logits(ctx);
     int best = 0;

@@ -89,6 +89,18 @@ def main(mode="device", n_new="24", n_ctx="512"):
         print('{"load": {"btla_tensors": %d, "blob_MB": %.1f, "streaming_layout_in_graph_slices_MB": %.1f, "own_allocations_MB": %.1f, '
               '"seconds_in_load_storage_calls_and_the_one_sync": %.3f, "hbm_ratio_vs_blobs": %.3f}}' % (
                   stats[0], stats[1] / 1e6, stats[2] / 1e6, stats[3] / 1e6, stats[4] / 1e6, (stats[1] + stats[3]) / max(1, stats[1])), flush=True)
+        times = (C.c_double * 4096)()
+        ref.nellama_eval_times.argtypes = [C.c_void_p, C.c_int]
+        nt = min(4096, ref.nellama_eval_times(times, 4096))
+        ev = sorted(times[i] for i in range(nt))
+        tail = [times[i] for i in range(nt // 2, nt)]
+        rs = (C.c_uint64 * 8)()
+        hip.ns_hip_route_stats(rs)
+        print('{"replay": {"tokens_replayed": %d, "tokens_eager": %d, "plans": %d, "fallbacks": %d, "launches_per_token": %d, "captured_launches": %d, '
+              '"capture_failures": %d}, "single_token_evals": %d, "us_median": %.1f, "tokens_per_s_median": %.1f, "us_mean_second_half": %.1f, '
+              '"tokens_per_s_second_half": %.1f, "us_max": %.1f}' % (rs[0], rs[1], rs[2], rs[3], rs[4], rs[5], rs[6], nt, ev[nt // 2] if nt else 0.0,
+                                                                   1e6 / ev[nt // 2] if nt else 0.0, sum(tail) / max(1, len(tail)),
+                                                                   1e6 * len(tail) / max(1e-9, sum(tail)), ev[-1] if nt else 0.0), flush=True)
         print('{"route": "device-resident (reference built with -DNS_SYCL on bestla_device_*)", "model": "llama-2-7b-shaped synthetic, Q4_0 g32 bf16", '
               '"us_per_token": %.1f, "tokens_per_s": %.1f, "n_ctx": %d, "tokens": %s, "wall_s": %.1f}' % (us.value, 1e6 / us.value, n_ctx, list(toks)[:8], time.time() - t0))
     else:

@@ -69,3 +69,29 @@ def test_reference_llama_runs_device_resident_through_its_own_device_switch(tmp_
     d = np.load(tmp_path / "device_f32_4.npz")
     assert list(p["tokens"]) == list(d["tokens"])
     assert nso.rel_l2(d["logits"], p["logits"]) < 5e-3
+
+
+def test_device_route_is_replayed_from_verified_graph_segments(tmp_path, nso):
+    """csrc/ns_route.cpp (round 5): the reference rebuilds and re-issues its graph every token (llama.cpp:148, ne_layers.c:11915-12028);
+    the launches behind bestla_device_* are recorded, two agreeing single-token evals make a plan of HIP-graph segments whose moving values
+    (RoPE position, kv-cache cell, context length) follow a device-side token counter, and later evals are verified launch by launch and
+    replayed.  12 new tokens: the prompt and two evals are launched one by one, the other nine are replayed — every token's logits are
+    checked against the fp64 model by the worker; tokens equal to those of the same run with the layer off."""
+    import re
+    run_worker("product", tmp_path, "auto", 4)
+    q = tmp_path / "llama_q_product_4.bin"
+    on = run_worker("device", tmp_path, "f32", 4, given=q, env={"NS_WORKER_N_NEW": "12"})
+    m = re.search(r"device route replay: tokens_replayed=(\d+) tokens_eager=(\d+) plans=(\d+) fallbacks=(\d+) launches_per_token=(\d+) captured_launches=(\d+) capture_failures=(\d+)", on)
+    assert m, on[-2000:]
+    replayed, eager, plans, fallbacks, per_token, captured, failures = (int(x) for x in m.groups())
+    assert replayed == 9 and eager == 3 and plans == 1 and fallbacks == 0 and failures == 0 and per_token > 20, m.group(0)
+    assert captured <= per_token * 0.6, m.group(0)  # runs of single operators were captured as the library's fused launches
+    a = np.load(tmp_path / "device_f32_4.npz")
+    tok_on, log_on = list(a["tokens"]), a["logits"].copy()
+    off = run_worker("device", tmp_path, "f32", 4, given=q, env={"NS_WORKER_N_NEW": "12", "NS_DEVICE_REPLAY": "0"})
+    assert "tokens_replayed=0 " in off
+    b = np.load(tmp_path / "device_f32_4.npz")
+    assert tok_on == list(b["tokens"])
+    # (the replayed attention adds its context ranges in another order; 22 layers of GEMVs that round their activations to fp16 turn
+    # last-bit differences into 2^-11 ones here and there: measured 4.5e-4; both runs are within 1e-2 of the fp64 model, checked by the worker)
+    assert nso.rel_l2(log_on, b["logits"]) < 2e-3

@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", gguf=False, experts=0, timeout=900):
+def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", gguf=False, experts=0, timeout=900, env=None):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libne_llama_ref.so")) and not os.path.exists(
             "/root/reference/neural_speed/models/llama/llama.cpp"):
         pytest.skip("oracle/_ref/libne_llama_ref.so not built (reference tree absent)")
@@ -22,7 +22,7 @@ def run_worker(mode, workdir, kv, heads_kv, given=None, family="llama", gguf=Fal
         pytest.skip("no gcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "llama_model_worker.py"), mode, str(workdir), kv,
                         str(heads_kv), str(given) if given else "-", family], capture_output=True, text=True, timeout=timeout, cwd=ROOT,
-                       env=dict(os.environ, NS_WORKER_GGUF="1" if gguf else "0", NS_WORKER_EXPERTS=str(experts)))
+                       env=dict(os.environ, NS_WORKER_GGUF="1" if gguf else "0", NS_WORKER_EXPERTS=str(experts), **(env or {})))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "LLAMA_MODEL_%s_OK" % mode.upper() in r.stdout
     return r.stdout

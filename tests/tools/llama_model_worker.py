@@ -37,7 +37,7 @@ import nso  # noqa: E402
 
 V, D, HEADS, FF, LAYERS, N_CTX, EPS, BASE = 384, 256, 4, 704, 22, 64, 1e-5, 10000.0
 PROMPT = [1, 17, 200, 3, 99, 42, 311]   # bos first (llama.cpp:80-85 warns otherwise)
-N_NEW = 6
+N_NEW = int(os.environ.get("NS_WORKER_N_NEW", "6"))
 KV = {"auto": 0, "f16": 1, "f32": 2}
 
 
@@ -329,6 +329,12 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
         ref.nellama_generate_dev.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         n = ref.nellama_generate_dev(qpath.encode(), prompt, len(PROMPT), N_NEW, N_CTX, LAYERS, toks, logits.ctypes.data, C.byref(us))
         print("device-resident graph: %.1f us per single-token eval (%d layers, d %d)" % (us.value, LAYERS, D))
+        # ns_route.cpp: how the single-token evals were issued (replayed from the plan / launched one by one)
+        hipl = C.CDLL(os.path.join(ROOT, "neural-speed_amd", "libns_hip.so"))
+        rs = (C.c_uint64 * 8)()
+        hipl.ns_hip_route_stats(rs)
+        print("device route replay: tokens_replayed=%d tokens_eager=%d plans=%d fallbacks=%d launches_per_token=%d captured_launches=%d capture_failures=%d"
+              % (rs[0], rs[1], rs[2], rs[3], rs[4], rs[5], rs[6]))
     else:
         n = ref.nellama_generate(qpath.encode(), prompt, len(PROMPT), N_NEW, N_CTX, KV[kv], toks, logits.ctypes.data)
     assert n == N_NEW, n
