@@ -10,8 +10,7 @@
 //   NS_TP_ID_FILE  path on a filesystem every rank sees (default /tmp/ns_tp_id.<uid>.<launch nonce>): rank 0 removes
 //                  whatever is there, writes {magic, launch nonce, 128-byte RCCL unique id} (O_EXCL, 0600, write +
 //                  rename) and the others wait up to 60 s for a file carrying THEIR launch's nonce
-//   NS_TP_RUN_ID / TORCHELASTIC_RUN_ID  the launcher's run id, part of the nonce; without one the nonce mixes in the session id
-//                  and the parent pid (NS_TP_NONCE_NO_PPID=1 drops it for launches behind per-rank wrapper shells)
+//   NS_TP_RUN_ID / TORCHELASTIC_RUN_ID  the launcher's run id, part of the nonce; without one the nonce mixes in the parent pid (NS_TP_NONCE_NO_PPID=1 drops it for launches behind per-rank wrapper shells)
 //   NS_TP_ID_MAX_AGE_S  how much older than this process an id file may be (default 30 s)
 // With one rank nothing is initialised and every call is the identity.
 //
@@ -54,8 +53,7 @@ int env_int(const char* a, const char* b, int dflt) {
 // 128-byte id made ncclCommInitRank hang with no time-out).  Ingredients:
 //   * the launcher's run id when it exports one (NS_TP_RUN_ID, else a TORCHELASTIC_RUN_ID other than torchrun's default
 //     "none"): unique per launch by contract, nothing else is needed beside it;
-//   * otherwise (MASTER_* + WORLD_SIZE alone are shared by every launch of that shape) the session id and the
-//     PARENT pid — the ranks of a torchrun / mpirun / srun launch on one node are siblings.  Ranks behind per-rank wrapper
+//   * otherwise (MASTER_* + WORLD_SIZE alone are shared by every launch of that shape) the PARENT pid — the ranks of a torchrun / mpirun / srun launch on one node are siblings.  Ranks behind per-rank wrapper
 //     shells (`mpirun -n 2 sh -c ...`) have different parents: such launches set NS_TP_RUN_ID, or NS_TP_NONCE_NO_PPID=1 to
 //     drop the parent pid (the failure message says so);
 //   * MASTER_ADDR / MASTER_PORT / world size, whatever the case.
@@ -81,7 +79,7 @@ uint64_t launch_nonce() {
   mix(getenv("NS_TP_WORLD_SIZE") ? getenv("NS_TP_WORLD_SIZE") : getenv("WORLD_SIZE"));
   if (nonce_uses_ppid()) {
     char buf[64];
-    snprintf(buf, sizeof(buf), "sid%ld.ppid%ld", long(getsid(0)), long(getppid()));
+    snprintf(buf, sizeof(buf), "ppid%ld", long(getppid()));  // (not the session id: torchrun starts every worker in a session of its own)
     mix(buf);
   }
   return h ? h : 1;

@@ -583,6 +583,17 @@ int tiled_from_rows(const ns_weight* w) {
   return w->ntiles >= 512 ? 17 : w->ntiles >= 256 ? (w->k >= 8192 ? 17 : 33) : 1 << 30;
 }
 
+// int8-reference decode launch: the kernel quantizes the activations itself where it can; where it cannot it says so, the quantizer
+// launch runs, and the launch is repeated on the codes
+hipError_t launch_gemv_i8(const SmallMArgs& a, I8Act* q, hipStream_t st) {
+  hipError_t e = launch_gemv(a, st);
+  if (e == hipErrorNotReady) {
+    e = i8_quantize_finish(q, st);
+    if (e == hipSuccess) e = launch_gemv(a, st);
+  }
+  return e;
+}
+
 int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda, int ldc, int epilogue,
                  const float* dD, int ldd, hipStream_t st, const void* dA16 = nullptr, void* dC16 = nullptr,
                  bool reuse_aq = false, const ns_norm_link* link = nullptr) {
@@ -636,7 +647,7 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
       a.seg[0] = {w, dC, dC16};
       a.epilogue = epilogue, a.d = dD, a.ldd = ldd;
       a.i8 = &q;
-      const hipError_t e = launch_gemv(a, st);
+      const hipError_t e = launch_gemv_i8(a, &q, st);
       if (e == hipSuccess) return 0;
       if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference decode launch") ? 0 : -1;
       reuse_aq = false;  // outside that kernel's envelope: the general int8-reference kernel, with its own scratch
@@ -1256,7 +1267,7 @@ int ns_hip_fusion_qkv_forward_x(const float* dA, const void* dA16, const ns_weig
         a.seg[i] = {ws[i], dC + size_t(i) * m * ldc, dC16 ? static_cast<uint16_t*>(dC16) + size_t(i) * m * ldc : nullptr};
       a.epilogue = NS_EPI_NONE;
       a.i8 = &q;
-      const hipError_t e = launch_gemv(a, st);
+      const hipError_t e = launch_gemv_i8(a, &q, st);
       if (e == hipSuccess) return 0;
       if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference qkv launch") ? 0 : -1;
     }
@@ -1384,7 +1395,7 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
       a.dual = true;
       a.c2 = dTmp1;
       a.i8 = &q;
-      const hipError_t e = launch_gemv(a, st);
+      const hipError_t e = launch_gemv_i8(a, &q, st);
       if (e == hipSuccess) return 0;
       if (e != hipErrorNotSupported) return hip_ok(e, "int8-reference gate/up launch") ? 0 : -1;
     }

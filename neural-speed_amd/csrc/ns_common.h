@@ -156,7 +156,14 @@ struct I8Act {
   int ldq;
   const uint8_t* corr;  // [m][nblk] fp32 scales immediately followed by [m][nblk] u8 zero points, 16-byte aligned
   int nblk, blocksize;
+  // round 5: the quantizer launch is DEFERRED — a32 / lda32 are the fp32 rows, `quantized` says whether aq / corr hold their codes yet.
+  // launch_gemv quantizes inside its own launch where it can (gemv_kernel XV = 5) and answers hipErrorNotReady where it cannot: the
+  // caller then runs i8_quantize_finish() and launches again (XV = 3 on the codes)
+  const float* a32 = nullptr;
+  int lda32 = 0, rows = 0, cols = 0;
+  bool quantized = true;
 };
+hipError_t i8_quantize_finish(I8Act* q, hipStream_t st);  // ns_i8ref.hip
 // expert-indexed decode launch (gemv_kernel XV = 4): the weight base comes from table[*id] on the device
 struct MoeRoute {
   const void* table;   // device: rows {codes, scales, zps} of the group's experts (ns_moe.hip)

@@ -12,6 +12,26 @@ typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
 
 namespace ns {
 
+// x86 float -> integer conversions as the reference binary performs them (the activation quantizer of the int8-compute path,
+// kernel_ref.h:1824-1883; ns_quant.hip holds the same functions for the offline quantizer).  Every operation is a correctly rounded
+// intrinsic: no FMA contraction whatever the translation unit's flags are.
+__device__ __forceinline__ float x86_round_half_away(float x) {  // roundf, exact: x - trunc(x) is always representable
+  const float t = truncf(x);
+  return (fabsf(__fsub_rn(x, t)) >= 0.5f) ? __fadd_rn(t, copysignf(1.f, x)) : t;
+}
+__device__ __forceinline__ int x86_cvt_round_int(float v) {  // cast<float,int>: cvttss2si yields INT_MIN for NaN / out of range
+  const float r = x86_round_half_away(v);
+  if (!(r >= -2147483648.f && r < 2147483648.f)) return (-2147483647 - 1);
+  return int(r);
+}
+__device__ __forceinline__ int x86_cast_f32_u8(float v) {  // bestla_utils.h:515-521: +0.5, clamp, truncate; NaN -> 0
+  if (v != v) return 0;
+  v = __fadd_rn(v, 0.5f);
+  v = v > 255.f ? 255.f : v;
+  v = v < 0.f ? 0.f : v;
+  return int(v);
+}
+
 // ============================================================================================================
 // small device helpers
 // ============================================================================================================

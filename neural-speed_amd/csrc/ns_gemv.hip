@@ -33,6 +33,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <utility>
 
 #include "../../include/ns_bestla.h"
@@ -180,13 +181,18 @@ constexpr int kGvA32Regs = 8;  // 16-byte loads of fp32 activations a wave holds
 // bit-exact), a lane (column nn, k-slot g) takes exact integer dots of its eight codes per 32-deep slice with v_dot4 on the
 // stored codes,  sum (a - za)(q - zb) = sum a u - (zb + bias) sum a - za sum u + 8 za (zb + bias)  (u = q + bias), and adds
 // float(sum) * (scale_a * scale_b) per slice; up to four rows.  Reduction, epilogues, fused QKV / gate-up modes are shared.
+// XV = 5 (I8Q, round 5): I8S with the activation quantizer INSIDE the launch — the rows arrive as fp32 (staged through registers like
+// XV = 2), every workgroup quantizes them itself (quantize_fp_u8_colblock's arithmetic operation by operation: the lanes of a k-block
+// combine max / min by xor-shuffles, order-independent like in aquant_u8_coop_kernel, so codes / scales / zero points are the same bits)
+// and leaves codes, scales and zero points in LDS where XV = 3 finds the ones it fetched.  Saves the aquant launch in front of every
+// GEMV of an int8-reference decode step (129 per Llama-2-7B token, ~3 us each); k-blocks of 32 .. 256 that divide K.
 // PL (round 4): the codes arrive as the NATIVE bit planes of a 1-3 / 5-7 bit format (ns_weight::native, repack_planes_kernel) —
 // 256 .. 896 bytes per k-step instead of the 1 KiB nibble / byte container — and each lane rebuilds its container words from its
 // plane words with shifts and masks (stored codes, bias 2^(bits-1) folded into the conversion constants: the same fp16 values,
 // hence the same bits out, as from the widened records).  KIND says which container: WK_INT4 for 1-3 bits, WK_INT8 for 5-7.
 template <int KIND, int SPS, int SK, bool ASYM, int MODE, int XV, bool PL = false>
 __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
-  constexpr bool EXT = XV == 1, MOE = XV == 4, A32 = XV == 2 || MOE, I8S = XV == 3;
+  constexpr bool EXT = XV == 1, MOE = XV == 4, I8Q = XV == 5, A32 = XV == 2 || MOE || I8Q, I8S = XV == 3 || I8Q;
   static_assert(!PL || ((KIND == WK_INT4 || KIND == WK_INT8) && !I8S && !MOE), "native planes: integer formats, fp16 numerics");
   static_assert(!I8S || KIND == WK_INT4 || KIND == WK_INT8, "integer weights only");
   constexpr uint32_t AEL = I8S ? 1u : 2u;  // bytes per staged activation element
@@ -427,6 +433,64 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
     const uint32_t pieces = (row_bytes + 1023u) >> 10;
     const uint32_t total = uint32_t(rows) * pieces;
     uint32_t r = 0, c = w;
+    if constexpr (I8Q) {
+      const uint32_t lds0q = uint32_t(reinterpret_cast<uintptr_t>((LdsPtr)(smem)));
+      const uint32_t lpb = 1u << (p.i8_bshift - 2u);  // lanes per k-block (4 columns per lane): 8 .. 64
+      const uint32_t k_bytes = uint32_t(p.k) * 4u;
+#pragma unroll
+      for (int i = 0; i < kGvA32Regs; i++) {
+        const uint32_t u = w + (uint32_t(i) << p.nw_log2);
+        if (u < total) {  // (wave-uniform)
+          while (c >= pieces) c -= pieces, r++;
+          const floatx4 v = areg[i];
+          float maxval = 1.17549435e-38f /* FLT_MIN: a full block, kernel_ref.h:1832 */, minval = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            maxval = v[e] > maxval ? v[e] : maxval;  // std::max(f, maxval): a NaN in f keeps maxval
+            minval = v[e] < minval ? v[e] : minval;
+          }
+          // the k-block's lanes combine max / min (order-independent).  Up to 16 lanes by DPP — quad swaps, then the mirror of the
+          // 8-lane half, then of the 16-lane row: no LDS operation, for which hipcc would first drain every LDS-DMA request of the ring —
+          // wider blocks by ds_bpermute on top
+          auto dpp = [](float x, auto ctrl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+          };
+          auto combine = [&](float om, float on) {
+            maxval = om > maxval ? om : maxval;
+            minval = on < minval ? on : minval;
+          };
+          combine(dpp(maxval, std::integral_constant<int, 0xB1>{}), dpp(minval, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
+          combine(dpp(maxval, std::integral_constant<int, 0x4E>{}), dpp(minval, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
+          combine(dpp(maxval, std::integral_constant<int, 0x141>{}), dpp(minval, std::integral_constant<int, 0x141>{}));  // row_half_mirror: 8 lanes
+          if (lpb > 8u) combine(dpp(maxval, std::integral_constant<int, 0x140>{}), dpp(minval, std::integral_constant<int, 0x140>{}));  // row_mirror: 16
+#pragma unroll
+          for (uint32_t d = 16; d < 64u; d <<= 1) {
+            if (d < lpb) {  // (wave-uniform)
+              const float om = __shfl_xor(maxval, int(d), 64), on = __shfl_xor(minval, int(d), 64);
+              combine(om, on);
+            }
+          }
+          const float scale = __fdiv_rn(__fsub_rn(maxval, minval), 255.f);
+          const int zp = x86_cast_f32_u8(__fdiv_rn(__fsub_rn(0.f, minval), scale));
+          const float rscale = __fdiv_rn(1.f, scale), zpf = float(zp);
+          uint32_t codes = 0;
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            codes |= uint32_t(x86_cast_f32_u8(__fadd_rn(zpf, float(x86_cvt_round_int(__fmul_rn(v[e], rscale)))))) << (8 * e);
+          const uint32_t col_b = (c << 10) + uint32_t(l) * 16u;  // byte offset of this lane's four columns in the fp32 row
+          if (col_b < k_bytes) {  // (K is a multiple of the k-block: a block's lanes are live or dead together)
+            // by hand: for a visible LDS store hipcc would first wait for every LDS-DMA request in flight (the whole ring)
+            asm volatile("ds_write_b32 %0, %1" ::"v"(lds0q + r * p.row_stride * 2u + (col_b >> 2)), "v"(codes) : "memory");
+            if ((uint32_t(l) & (lpb - 1u)) == 0u) {
+              const uint32_t kb = (col_b >> 2) >> p.i8_bshift;
+              asm volatile("ds_write_b32 %0, %1" ::"v"(lds0q + p.ssq_off + (r * p.i8_nblk + kb) * 4u), "v"(scale) : "memory");
+              asm volatile("ds_write_b8 %0, %1" ::"v"(lds0q + p.ssq_off + uint32_t(rows) * p.i8_nblk * 4u + r * p.i8_nblk + kb), "v"(uint32_t(zp)) : "memory");
+            }
+          }
+          c += NW;
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < kGvA32Regs; i++) {
       const uint32_t u = w + (uint32_t(i) << p.nw_log2);
@@ -440,6 +504,7 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
           asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"((uint64_t(as_u32(hi)) << 32) | as_u32(lo)) : "memory");
         c += NW;
       }
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -889,12 +954,16 @@ static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw,
     if (i8s) return hipErrorNotSupported;
 #define NS_GV_LAUNCH(MODEV)                                                                                     \
   {                                                                                                             \
-    if (moe) NS_GV_LAUNCH_MOE(MODEV) else if (ext) NS_GV_LAUNCH_E(MODEV, 1) else if (a32) NS_GV_LAUNCH_E(MODEV, 2) else if (i8s) NS_GV_LAUNCH_I8(MODEV)    \
+    if (moe) NS_GV_LAUNCH_MOE(MODEV) else if (ext) NS_GV_LAUNCH_E(MODEV, 1) else if (i8s && a32) NS_GV_LAUNCH_I8Q(MODEV) else if (a32) NS_GV_LAUNCH_E(MODEV, 2) else if (i8s) NS_GV_LAUNCH_I8(MODEV)    \
     else NS_GV_LAUNCH_E(MODEV, 0)                                                                               \
   }
 #define NS_GV_LAUNCH_MOE(MODEV)                                                                                  \
   {                                                                                                             \
     if constexpr (KIND != WK_F8 && MODEV == GV_PLAIN) NS_GV_LAUNCH_E(GV_PLAIN, 4)                               \
+  }
+#define NS_GV_LAUNCH_I8Q(MODEV)                                                                                  \
+  {                                                                                                             \
+    if constexpr (KIND == WK_INT4 || KIND == WK_INT8) NS_GV_LAUNCH_E(MODEV, 5)                                  \
   }
 #define NS_GV_LAUNCH_I8(MODEV)                                                                                   \
   {                                                                                                             \
@@ -917,6 +986,7 @@ static hipError_t launch_gemv_k(const GemvParams& p, int mode, int grid, int nw,
 #undef NS_GV_LAUNCH
 #undef NS_GV_LAUNCH_E
 #undef NS_GV_LAUNCH_I8
+#undef NS_GV_LAUNCH_I8Q
 #undef NS_GV_LAUNCH_MOE
   return hipGetLastError();
 }
@@ -1033,6 +1103,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   // staged activations: [rows][ks * KSTEP + 8] halves (int8-reference numerics: [rows][ks * KSTEP + 16] bytes)
   const int rows = a.m;
   const bool i8s = a.i8 != nullptr;
+  bool i8q = false;
   const uint32_t row_stride = i8s ? (ks * uint32_t(kstep) + 16) / 2 : ks * uint32_t(kstep) + 8;
   const size_t a_bytes = size_t(rows) * row_stride * 2;
   if (a_bytes > kGvMaxALds) return hipErrorNotSupported;
@@ -1048,6 +1119,11 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
         (!one_block && ((1u << i8_shift) != uint32_t(q.blocksize) || q.blocksize < 32)))
       return hipErrorNotSupported;
     if (one_block) i8_shift = 31;
+    // XV = 5: quantize inside the launch when the rows are at hand as fp32 and the k-block is 32 .. 256 columns dividing K
+    static const bool i8q_off = getenv("NS_I8_INKERNEL") && atoi(getenv("NS_I8_INKERNEL")) == 0;  // A-B runs
+    i8q = !i8q_off && q.a32 && !one_block && i8_shift >= 5 && i8_shift <= 8 && w0->k % q.blocksize == 0 && (q.lda32 & 3) == 0 &&
+          (w0->k & 3) == 0 && (reinterpret_cast<uintptr_t>(q.a32) & 15) == 0;
+    if (!i8q && !q.quantized) return hipErrorNotReady;  // the caller runs the quantizer launch (i8_quantize_finish) and comes back
     p.i8_corr = q.corr;
     p.i8_nblk = uint32_t(q.nblk);
     p.i8_span = (uint32_t(rows) * uint32_t(q.nblk) * 5u + 3u) & ~3u;  // whole words: a buffer load drops a word that straddles the bound (the scratch has the slack)
@@ -1055,16 +1131,16 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   }
   // fp16 activations with 16-byte aligned rows; several rows need K to fill whole k-steps (a row's padding columns
   // would otherwise read the next row through the descriptor)
-  const bool a16 = i8s || (a.a16 != nullptr && (a.lda & 7) == 0 && (w0->k & 7) == 0 && (reinterpret_cast<uintptr_t>(a.a16) & 15) == 0);
+  const bool a16 = (i8s && !i8q) || (!i8s && a.a16 != nullptr && (a.lda & 7) == 0 && (w0->k & 7) == 0 && (reinterpret_cast<uintptr_t>(a.a16) & 15) == 0);
   // fp32-only callers: converted while staging (XV = 2); not together with a carried norm / fused RoPE, whose producers
   // always leave a shadow
   const bool moe = a.moe != nullptr;
   if (moe && (a.m != 1 || nmat != 1 || a.dual || a.link || a.rope || i8s || a.a16 || !a.moe->table || !a.moe->id)) return hipErrorNotSupported;
-  const bool a32 = !a16 && a.a != nullptr && !a.link && !a.rope && (a.lda & 3) == 0 && (w0->k & 3) == 0 &&
-                   (reinterpret_cast<uintptr_t>(a.a) & 15) == 0;
+  const bool a32 = i8q || (!i8s && !a16 && a.a != nullptr && !a.link && !a.rope && (a.lda & 3) == 0 && (w0->k & 3) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.a) & 15) == 0);
   if (moe && !a32) return hipErrorNotSupported;
   if ((!a16 && !a32) || (rows > 1 && w0->k % kstep != 0)) return hipErrorNotSupported;
-  p.a = i8s ? static_cast<const void*>(a.i8->aq) : (a16 ? a.a16 : static_cast<const void*>(a.a));
+  p.a = i8q ? static_cast<const void*>(a.i8->a32) : i8s ? static_cast<const void*>(a.i8->aq) : (a16 ? a.a16 : static_cast<const void*>(a.a));
   // carried RMS norm (ns_norm_link): consumer side stages in_parts floats per row behind A
   size_t ssq_bytes = 0;
   if (i8s) ssq_bytes = (size_t(p.i8_span) + 1023) >> 10 << 10;  // the scales / zero points span sits where a carried norm's sums would
@@ -1116,8 +1192,10 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   }
   uint32_t nw_log2 = 0;
   while ((1 << nw_log2) < nw) nw_log2++;
-  if (a32 && uint64_t(rows) * ((uint64_t(ks) * uint32_t(kstep) * 4u + 1023u) >> 10) > uint64_t(nw) * kGvA32Regs)
+  if (a32 && uint64_t(rows) * ((uint64_t(ks) * uint32_t(kstep) * 4u + 1023u) >> 10) > uint64_t(nw) * kGvA32Regs) {
+    if (i8q) return a.i8->quantized ? hipErrorNotSupported : hipErrorNotReady;  // (quantized beforehand it fits: the caller's retry takes XV = 3)
     return hipErrorNotSupported;  // more fp32 pieces than the waves hold in registers: smallm_kernel stages those
+  }
 
   p.ks = ks;
   p.qstride = w0->qstride;
@@ -1132,7 +1210,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
   }
   p.m = a.m;
   p.k = w0->k;
-  p.lda = i8s ? a.i8->ldq : a.lda;
+  p.lda = i8q ? a.i8->lda32 : i8s ? a.i8->ldq : a.lda;
   p.row_stride = row_stride;
   p.ssq_off = uint32_t((a_bytes + 15) & ~size_t(15));
   p.ring_off = p.ssq_off + uint32_t(ssq_bytes);

@@ -524,6 +524,13 @@ int prep_state(hipStream_t st, bool set, int value = 0) {
 // quantize_fp_u8_colblock(A) into the stream's scratch (slot 6) in the layout gemv_kernel's int8-reference variant stages:
 // codes [m][ldq] (ldq = K rounded up to 16) | [m][nblk] fp32 scales | [m][nblk] u8 zero points.  reuse: the scratch already
 // holds it for this (A, m, K, blocksize) — the previous call of a fused QKV / gate-up group
+struct LastAq {
+  const float* a;
+  int m, k, bs;
+  hipStream_t st;
+  bool valid;
+};
+static LastAq g_last_aq = {nullptr, 0, 0, 0, nullptr, false};  // what the decode scratch (slot 6) holds codes of
 hipError_t i8_quantize_for_decode(const float* a, int lda, const ns_weight* w, int m, hipStream_t st, bool reuse, I8Act* out) {
   const int bs = w->blocksize >= w->k ? w->k : w->blocksize;
   const int nblk = (w->k + bs - 1) / bs;
@@ -533,14 +540,28 @@ hipError_t i8_quantize_for_decode(const float* a, int lda, const ns_weight* w, i
   if (!base) return hipErrorOutOfMemory;
   float* as = reinterpret_cast<float*>(base + aq_bytes);
   uint8_t* az = base + aq_bytes + size_t(m) * nblk * 4;
-  if (!reuse) {
-    const hipError_t e = launch_aquant_u8(m, w->k, a, lda, base, ldq, as, nblk, az, bs, nullptr, st);
-    if (e != hipSuccess) return e;
-  }
   out->aq = base, out->ldq = ldq;
   out->corr = base + aq_bytes;
   out->nblk = nblk, out->blocksize = bs;
+  // the quantizer launch itself is deferred: the decode kernel quantizes inside its own launch where it can (gemv_kernel XV = 5)
+  out->a32 = a, out->lda32 = lda, out->rows = m, out->cols = w->k;
+  // `reuse`: the caller's previous call quantized the same rows — true only if that call really ran the quantizer launch (it may
+  // have quantized inside its kernel instead, leaving the scratch untouched)
+  out->quantized = reuse && g_last_aq.valid && g_last_aq.a == a && g_last_aq.m == m && g_last_aq.k == w->k && g_last_aq.bs == bs && g_last_aq.st == st;
+  if (!out->quantized) g_last_aq.valid = false;
   return hipSuccess;
+}
+hipError_t i8_quantize_finish(I8Act* q, hipStream_t st) {
+  if (q->quantized) return hipSuccess;
+  uint8_t* base = const_cast<uint8_t*>(q->aq);
+  float* as = reinterpret_cast<float*>(const_cast<uint8_t*>(q->corr));
+  uint8_t* az = const_cast<uint8_t*>(q->corr) + size_t(q->rows) * q->nblk * 4;
+  const hipError_t e = launch_aquant_u8(q->rows, q->cols, q->a32, q->lda32, base, q->ldq, as, q->nblk, az, q->blocksize, nullptr, st);
+  if (e == hipSuccess) {
+    q->quantized = true;
+    g_last_aq = LastAq{q->a32, q->rows, q->cols, q->blocksize, st, true};
+  }
+  return e;
 }
 
 void set_i8_mfma_gen(int gen) { g_i8_mfma_gen.store(gen == 1 ? 1 : 2); }

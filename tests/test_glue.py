@@ -80,7 +80,7 @@ print("PC_GLUE_OK")
 
 def test_launch_nonce_separates_launches_without_a_run_id(pkg, tmp_path):
     """with no launcher run id the id-file nonce must still differ between two launches of the same shape (same
-    MASTER_*, same WORLD_SIZE) — it mixes in the session id and the parent pid, which sibling ranks share — while a run id
+    MASTER_*, same WORLD_SIZE) — it mixes in the parent pid, which sibling ranks share (not the session id: torchrun gives every worker its own) — while a run id
     (or NS_TP_NONCE_NO_PPID=1, for ranks behind per-rank wrapper shells) makes it a function of the exported values only"""
     so = str(tmp_path / "libpc_glue.so")
     lib = pkg.LIB_PATH
