@@ -225,6 +225,8 @@ int ns_hip_get_compute_mode(void);
  *                     above every sl_q keeps the 64-row kernel of rounds 1-3)
  *   "attn_inlaunch"   0 (default) = attn_merge_kernel combines the context splits in a second launch, 1 = the split that finishes
  *                     last does inside the launch (one self-resetting counter per kv head); same sums in the same order, same time
+ *   "attn_heads_first" dispatch order of the decode attention's workgroups: 1 = the kv heads of one context range side by side, 0 = the
+ *                     ranges of one head, -1 (default) = by the cache layout (position-major caches take 1: 5-10 % faster at 2048 / 4096 keys)
  *   "gv_nw"           waves per 16-column tile of the decode kernels (2 / 4 / 8 / 16), 0 = by shape (default); the
  *                     partial sums of a tile are added in wave order, so this selects the summation order
  *   "g3_min_m"        rows from which the tiled prefill GEMM is used inside its envelope (0 = default)

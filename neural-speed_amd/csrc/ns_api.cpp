@@ -1096,6 +1096,10 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_i8_mfma_gen(value);
     return 0;
   }
+  if (key && !strcmp(key, "attn_heads_first")) {
+    set_attn_heads_first(value);
+    return 0;
+  }
   if (key && !strcmp(key, "g3_wide")) {
     set_gemm3_wide(value);
     return 0;

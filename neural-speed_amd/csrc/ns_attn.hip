@@ -176,6 +176,8 @@ struct AttnSplitParams {
   int keys_per_split;
   uint32_t* tickets;  // one self-resetting counter per (batch, query row, kv head, chunk): the LAST split to finish merges inside the
                       // launch (nullptr: attn_merge_kernel does it in a second launch)
+  int heads_first;     // 1: blockIdx.x walks the (kv head, row) pairs and blockIdx.y the context ranges — neighbouring workgroups then read
+                       // neighbouring 256-byte pieces of a position-major cache ([position][head][dim]); 0: the ranges of one head first
   int g_full, chunks;  // query heads per kv head, and in how many workgroups of G heads each they are served (round 4: any head
                        // group — Falcon's 71 and StarCoder's 48 query heads on one kv head ran on the one-workgroup-per-head kernel)
 };
@@ -193,8 +195,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   const AttnParams& p = sp.a;
   __shared__ float ml_s[4][G][2];
   extern __shared__ float acc_s[];  // [4 waves][G][16 * DPL]
-  const int split = blockIdx.x;
-  const int chunk = blockIdx.y % sp.chunks, ykv = blockIdx.y / sp.chunks;
+  const int split = sp.heads_first ? blockIdx.y : blockIdx.x;
+  const int by = sp.heads_first ? blockIdx.x : blockIdx.y;
+  const int chunk = by % sp.chunks, ykv = by / sp.chunks;
   const int ihkv = ykv % p.heads_kv, i = ykv / p.heads_kv, ibs = blockIdx.z;
   // query head of slot g: heads past the group's end repeat its last head (computed, never stored)
   auto head_of = [&](int g) { return ihkv * sp.g_full + min(chunk * G + g, sp.g_full - 1); };
@@ -548,6 +551,8 @@ void set_attn_mfma2_rows(int rows) { g_attn_mfma2_rows.store(rows > 0 ? rows : 1
 // the cost is the write-through / ticket / read-back chain across XCDs, not the kernel boundary.
 static std::atomic<int> g_attn_inlaunch{getenv("NS_ATTN_INLAUNCH") ? atoi(getenv("NS_ATTN_INLAUNCH")) != 0 : 0};
 static constexpr size_t kAttnTicketCap = 65536;
+static std::atomic<int> g_attn_heads_first{getenv("NS_ATTN_HEADS_FIRST") ? atoi(getenv("NS_ATTN_HEADS_FIRST")) : -1};  // ns_hip_set_tuning("attn_heads_first"): -1 by layout
+void set_attn_heads_first(int on) { g_attn_heads_first.store(on < 0 ? -1 : (on != 0)); }
 static std::atomic<int> g_attn_wg_target{1024}, g_attn_min_keys{128};  // ns_hip_set_tuning("attn_wg_target" / "attn_min_keys")
 void set_attn_inlaunch(int on) { g_attn_inlaunch.store(on != 0); }
 void set_attn_tuning(int wg_target, int min_keys) {
@@ -1271,7 +1276,15 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
       sp.tickets = static_cast<uint32_t*>(stream_scratch_zeroed(st, kAttnTicketCap * 4, 22));  // nullptr (e.g. first use on a capturing stream): the merge launch
     sp.nsplit = nsplit;
     sp.keys_per_split = (a.sl_kv + nsplit - 1) / nsplit;
-    const dim3 grid(unsigned(nsplit), unsigned(a.heads_kv * a.sl_q * chunks), unsigned(a.batch_size));
+    // dispatch order (round 5, profiles/r05m_attn_layout_order_ab.txt): on a position-major cache ([position][head][dim]: a head's rows are
+    // pieces one position stride apart) neighbouring workgroups should be neighbouring HEADS of one context range — split + merge 14.3 -> 13.7 us
+    // at 2048 positions, 22.0 -> 19.9 at 4096 (Llama-2-7B shape); on a head-major cache (one slab per head) the ranges of one head first
+    // (20.7 vs 23.4 us at 4096).  ns_hip_set_tuning("attn_heads_first", 0 / 1) forces one, -1 = by layout.
+    const int hf = g_attn_heads_first.load();
+    const bool position_major = a.step_k_head_num < a.step_k_sl;
+    sp.heads_first = (hf < 0 ? position_major : hf != 0) && size_t(nsplit) <= 65535;
+    const dim3 grid = sp.heads_first ? dim3(unsigned(a.heads_kv * a.sl_q * chunks), unsigned(nsplit), unsigned(a.batch_size))
+                                     : dim3(unsigned(nsplit), unsigned(a.heads_kv * a.sl_q * chunks), unsigned(a.batch_size));
     hipError_t e = G == 1 ? launch_split_g<1>(sp, grid, st)
                  : G == 2 ? launch_split_g<2>(sp, grid, st)
                  : G == 4 ? launch_split_g<4>(sp, grid, st)

@@ -207,6 +207,7 @@ void set_gemv_mode(int mode);  // 0 off (first-generation kernel), 1 on, -1 re-r
 hipError_t launch_gemvs(const SmallMArgs& a, hipStream_t st);
 void set_gemvs_tuning(int what, int value);  // what: 0 mode (0 off, 1 from 2 rows, 2 from 1 row), 1 slices, 2 waves, 3 workgroups
 void set_attn_tuning(int wg_target, int min_keys);
+void set_attn_heads_first(int on);  // ns_attn.hip: dispatch order of the decode attention's workgroups (AttnSplitParams::heads_first)
 void set_gemv_planes(int on);  // 1 (default): bit-plane formats stream their native records at decode (ns_weight::native); 0: the widened ones
 void set_attn_mfma2_rows(int rows);  // query rows from which the 128-row prefill attention kernel is used (default 128; huge = never)
 void set_attn_inlaunch(int on);  // 0 (default): attn_merge_kernel combines the context splits in a second launch; 1: the last split to finish merges inside attn_split_kernel's launch
