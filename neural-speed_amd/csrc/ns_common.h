@@ -295,7 +295,7 @@ int route_sync_point(void* stream);        // bestla_device_sync / _memcpy: pend
 void route_attach(void* stream);           // bestla_create_device
 void route_detach(void* stream);
 void route_invalidate();                   // bestla_device_free
-void* route_translate_dst(void* dst, const void* src, size_t size, void* stream);  // bestla_device_memcpy while a plan is held (ns_route.cpp)
+void* route_twin_dst(void* dst, void* stream);  // bestla_device_memcpy while a plan is held (ns_route.cpp): the plan's twin of an activation, or nullptr
 const void* route_translate_src(const void* src, void* stream);
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st,

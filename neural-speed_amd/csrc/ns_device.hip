@@ -356,9 +356,11 @@ void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* q
   (void)ns_hip_lazy_flush();
   (void)ns::route_sync_point(queue);
   if (!dstptr || !srcptr || !size) return;
-  // (replayed tokens run on the plan's activations: the embeddings go there, the logits come from there — ns_route.cpp)
-  dstptr = ns::route_translate_dst(dstptr, srcptr, size, queue);
+  // (replayed tokens run on the plan's activations: the embeddings go there as well, the logits come from there — ns_route.cpp)
+  void* twin = ns::route_twin_dst(dstptr, queue);
   srcptr = ns::route_translate_src(srcptr, queue);
+  if (twin && hipMemcpyAsync(twin, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
+    ns::set_error("bestla_device_memcpy failed");
   if (hipMemcpyAsync(dstptr, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
     ns::set_error("bestla_device_memcpy failed");
 }

@@ -93,12 +93,6 @@ struct Route {
   // copies are redirected there (route_translate_*).  Weights and the kv cache do not move and are compared as they are.
   long long act_delta = 0;
   std::unordered_set<const void*> act_ptrs;  // plan addresses of the shifted pointers
-  struct {
-    void* dst_asked = nullptr;  // where the reference wanted this token's host-to-device copy
-    const void* src = nullptr;
-    size_t size = 0;
-    bool redirected = false;
-  } h2d;
   bool last_replayed = false;  // the token that just ended ran from the plan: its logits are at the plan's address
   // NS_ROUTE_TIMING=1 (diagnostics): events around a replayed token's segments -> GPU span per token, printed when the route detaches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -146,7 +140,6 @@ void drop_plan() {
   R.pos = R.seg = 0;
   R.act_delta = 0;
   R.act_ptrs.clear();
-  R.h2d.redirected = false;
   R.last_replayed = false;
 }
 
@@ -202,14 +195,11 @@ RouteOp expected(const PlanOp& po, long long k) {
 
 // The token deviates from the plan.  Segments launched so far ran on the PLAN's activations, the reference's remaining launches will read
 // the addresses it asked for: the token is issued again from its first launch at those addresses (its verified ops are in R.cur; every
-// launch of the route is a pure function of its inputs and kv-cache cells are rewritten with the same values), after the token's
-// host-to-device copy has been repeated where the reference wanted it.  Then the plan is forgotten.
+// launch of the route is a pure function of its inputs and kv-cache cells are rewritten with the same values; the token's input was
+// copied to both places, route_twin_dst).  Then the plan is forgotten.
 int bail_out() {
   R.stats[3]++;
   int rc = 0;
-  if (R.h2d.redirected && R.h2d.dst_asked &&
-      hipMemcpyAsync(R.h2d.dst_asked, R.h2d.src, R.h2d.size, hipMemcpyHostToDevice, R.st) != hipSuccess)
-    rc = -1;
   const int beg = R.act_delta != 0 ? 0 : (R.seg < int(R.segs.size()) ? R.segs[R.seg].beg : R.pos);
   for (int j = beg; j < R.pos && rc == 0; j++) rc = execute(R.cur[j], R.st);
   drop_plan();
@@ -553,7 +543,6 @@ bool make_plan() {
   R.xops.swap(xops);
   R.act_delta = act_delta;
   R.act_ptrs.swap(act_ptrs);
-  R.h2d.redirected = false;
   R.last_replayed = false;
   R.have_plan = true;
   R.khost = 0;
@@ -629,7 +618,6 @@ int route_sync_point(void* stream) {
       R.prev.swap(R.cur);
       R.cur.clear();
       R.last_replayed = true;
-      R.h2d.redirected = false;
       if (R.ev_pending) {
         float ms = 0.f;
         if (hipEventSynchronize(R.ev1) == hipSuccess && hipEventElapsedTime(&ms, R.ev0, R.ev1) == hipSuccess) R.gpu_ms_sum += ms, R.gpu_tokens++;
@@ -653,15 +641,14 @@ int route_sync_point(void* stream) {
   return rc;
 }
 
-// bestla_device_memcpy on the route's queue while a plan is held: the copy that brings a token's embeddings (its destination is an
-// activation of the NEXT token: expected at plan address + act_delta * (k + 1)) goes to the plan's address, the copy that fetches a replayed
-// token's logits reads the plan's address.  Pointers that are not the plan's activations pass through.
-void* route_translate_dst(void* dst, const void* src, size_t size, void* stream) {
-  if (t_in_exec || !R.have_plan || R.act_delta == 0 || static_cast<hipStream_t>(stream) != R.st || R.pos != 0) return dst;
+// bestla_device_memcpy on the route's queue while a plan is held.  The copy that brings a token's embeddings has an activation of the NEXT
+// token as its destination (expected at plan address + act_delta * (k + 1)): the bytes go where they were asked for AND to the plan's twin of
+// that tensor (returned here; nullptr: no twin), so a token that is replayed finds them and a token that falls back does too.  The copy that
+// fetches a replayed token's logits reads the plan's address.  Pointers that are not the plan's activations pass through.
+void* route_twin_dst(void* dst, void* stream) {
+  if (t_in_exec || !R.have_plan || R.act_delta == 0 || static_cast<hipStream_t>(stream) != R.st || R.pos != 0) return nullptr;
   void* cand = static_cast<char*>(dst) - R.act_delta * (R.khost + 1);
-  if (!R.act_ptrs.count(cand)) return dst;
-  R.h2d.dst_asked = dst, R.h2d.src = src, R.h2d.size = size, R.h2d.redirected = true;
-  return cand;
+  return R.act_ptrs.count(cand) ? cand : nullptr;
 }
 const void* route_translate_src(const void* src, void* stream) {
   if (t_in_exec || !R.have_plan || R.act_delta == 0 || static_cast<hipStream_t>(stream) != R.st || !R.last_replayed) return src;
