@@ -18,6 +18,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/ns_bestla.h"
@@ -55,6 +56,48 @@ struct MoeParams {
   int ldd;
   float lut[16];  // 4-bit float types: code -> value
 };
+
+// ---- prefill size (round 5): the token rows grouped by expert, ONE tiled GEMM per expert over its rows ----------------------------
+// The per-row kernels below let every token stream its whole expert: 2048 tokens x 2 experts of a Mixtral layer read 2048 x 29 MB per
+// matrix.  The reference groups the rows on the host too (`matrix_rows`, ne_layers.c:7855-7866) and then still calls one
+// bestla_f32f32_forward per row; here the id column comes back to the host once (m ints), the rows are gathered in expert order as the
+// fp16 operand the tiled GEMM multiplies anyway, every expert's rows are ONE gemm3_kernel launch, and a scatter kernel applies the
+// epilogue per token row.  Not capturable (the host reads the ids): a capturing stream keeps the per-row form.
+__global__ void moe_ids_column_kernel(const int32_t* __restrict__ ids, int ids_stride, int id, int m, int32_t* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < m) out[t] = ids[size_t(t) * ids_stride + id];
+}
+__global__ void moe_gather_rows_kernel(const float* __restrict__ a, int lda, const int32_t* __restrict__ perm, int rows, int k, int kpad,
+                                       _Float16* __restrict__ out) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one thread per 8 columns
+  const int per_row = kpad / 8;
+  if (gid >= size_t(rows) * per_row) return;
+  const int j = int(gid / per_row), c = int(gid % per_row) * 8;
+  const float* src = a + size_t(perm[j]) * lda + c;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 v;
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = c + e < k ? (_Float16)src[e] : (_Float16)0.f;
+  *reinterpret_cast<h8*>(out + size_t(j) * kpad + c) = v;
+}
+__global__ void moe_scatter_epilogue_kernel(const float* __restrict__ cg, const int32_t* __restrict__ perm, const int32_t* __restrict__ valid, int rows,
+                                            int n, float* __restrict__ c, int ldc, int epilogue, const float* __restrict__ d, int ldd) {
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= size_t(rows) * n) return;
+  const int j = int(gid / n), col = int(gid % n);
+  const int t = perm[j];
+  float v = valid[j] ? cg[size_t(j) * n + col] : 0.f;  // an id outside the group: a zero product (the per-row kernels do the same)
+  const float dv = d ? d[size_t(t) * ldd + col] : 0.f;
+  switch (epilogue) {
+    case 1: v = v + dv; break;
+    case 2: v = v * dv; break;
+    case 3: v = epi_gelu(v + dv); break;
+    case 4: v = epi_gelu(v); break;
+    case 5: v = epi_silu(v); break;
+    default: break;
+  }
+  c[size_t(t) * ldc + col] = v;
+}
 
 template <int KIND>  // WK_INT4, WK_INT8 or WK_F4
 __global__ __launch_bounds__(kMoeThreads) void moe_gemv_kernel(const MoeParams p) {
@@ -188,6 +231,81 @@ struct ns_expert_group {
 
 using namespace ns;
 
+namespace ns {
+// 0 = done, -1 = error (set_error), 1 = not taken (the caller's per-row path serves the call)
+static int mul_mat_id_grouped(const float* dA, const int32_t* dIds, int ids_stride, int id, const ns_expert_group* g, float* dC, int m, int lda,
+                              int ldc, int epilogue, const float* dD, int ldd, hipStream_t st) {
+  const ns_weight* w0 = g->experts[0];
+  const int n_as = int(g->experts.size()), n = w0->n, k = w0->k;
+  if (w0->kind == WK_F8 || w0->shuf || (k % 64) != 0) return 1;
+  const int kpad = k;
+  // scratch: ids column + permutation + validity (3 m ints), gathered fp16 rows [m + 1][k], raw products [m + 1][n] (one padding row: a
+  // single-row group is launched with two rows — the tiled kernel's minimum — and its second row belongs to the NEXT group, launched later)
+  int32_t* ints = static_cast<int32_t*>(stream_scratch(st, size_t(3) * m * 4, 30));
+  _Float16* ag = static_cast<_Float16*>(stream_scratch(st, size_t(m + 1) * kpad * 2, 31));
+  float* cg = static_cast<float*>(stream_scratch(st, size_t(m + 1) * n * 4, 32));
+  if (!ints || !ag || !cg) return 1;
+  int32_t *d_col = ints, *d_perm = ints + m, *d_valid = ints + 2 * size_t(m);
+  hipLaunchKernelGGL(moe_ids_column_kernel, dim3((m + 255) / 256), dim3(256), 0, st, dIds, ids_stride, id, m, d_col);
+  std::vector<int32_t> col(m), perm(m), valid(m);
+  if (hipMemcpyAsync(col.data(), d_col, size_t(m) * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    set_error("mul_mat_id: reading the expert ids failed");
+    return -1;
+  }
+  // counting sort by expert; ids outside the group go last (their rows are written as zero products)
+  std::vector<int> count(n_as + 1, 0), off(n_as + 2, 0);
+  for (int t = 0; t < m; t++) count[col[t] >= 0 && col[t] < n_as ? col[t] : n_as]++;
+  for (int e = 0; e <= n_as; e++) off[e + 1] = off[e] + count[e];
+  std::vector<int> fill(off.begin(), off.end() - 1);
+  for (int t = 0; t < m; t++) {
+    const int e = col[t] >= 0 && col[t] < n_as ? col[t] : n_as;
+    perm[fill[e]] = t, valid[fill[e]] = e < n_as ? 1 : 0;
+    fill[e]++;
+  }
+  if (hipMemcpyAsync(d_perm, perm.data(), size_t(m) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_valid, valid.data(), size_t(m) * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+    set_error("mul_mat_id: uploading the row order failed");
+    return -1;
+  }
+  {
+    const size_t units = size_t(m) * (kpad / 8);
+    hipLaunchKernelGGL(moe_gather_rows_kernel, dim3(unsigned((units + 255) / 256)), dim3(256), 0, st, dA, lda, d_perm, m, k, kpad, ag);
+    // the padding row: zeros (read by the last group when it has a single row)
+    if (hipMemsetAsync(ag + size_t(m) * kpad, 0, size_t(kpad) * 2, st) != hipSuccess) return -1;
+  }
+  for (int e = 0; e < n_as; e++) {
+    const int r = count[e];
+    if (!r) continue;
+    SmallMArgs a{};
+    a.a = nullptr, a.a16 = ag + size_t(off[e]) * kpad, a.lda = kpad, a.m = r < 2 ? 2 : r, a.ldc = n, a.nseg = 1;
+    a.seg[0] = {g->experts[e], cg + size_t(off[e]) * n, nullptr};
+    a.epilogue = NS_EPI_NONE;
+    const hipError_t er = launch_gemm2(a, st);
+    if (er == hipErrorNotSupported) {
+      // (nothing has been written to dC yet: the per-row path can still serve the whole call)
+      (void)hipStreamSynchronize(st);  // the host vectors above are being read by the two uploads
+      return 1;
+    }
+    if (er != hipSuccess) {
+      set_error(std::string("mul_mat_id (grouped): ") + hipGetErrorString(er));
+      (void)hipStreamSynchronize(st);
+      return -1;
+    }
+  }
+  {
+    const size_t total = size_t(m) * n;
+    hipLaunchKernelGGL(moe_scatter_epilogue_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, cg, d_perm, d_valid, m, n, dC, ldc, epilogue, dD, ldd);
+  }
+  // the uploads read host vectors that die with this frame
+  if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
+    set_error("mul_mat_id (grouped): launch failed");
+    return -1;
+  }
+  return 0;
+}
+}  // namespace ns
+using ns::mul_mat_id_grouped;
+
 extern "C" {
 
 ns_expert_group* ns_hip_expert_group_create(const ns_weight* const* experts, int n_as) {
@@ -269,6 +387,17 @@ int ns_hip_mul_mat_id(const float* dA, const int32_t* dIds, int ids_stride, int 
     return -1;
   }
   hipStream_t st = (hipStream_t)stream;
+  // prefill-sized calls: rows grouped by expert, one tiled GEMM per expert (see moe_gather_rows_kernel)
+  static const int grouped_from = getenv("NS_MOE_GROUPED_ROWS") ? atoi(getenv("NS_MOE_GROUPED_ROWS")) : 32;
+  if (m >= grouped_from && grouped_from > 0) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+    if (!capturing) {
+      const int rc = mul_mat_id_grouped(dA, dIds, ids_stride, id, g, dC, m, lda, ldc, epilogue, dD, ldd, st);
+      if (rc <= 0) return rc;  // 0 done, -1 failed; 1: outside the tiled kernel's envelope — the per-row kernels below
+    }
+  }
   // decode-sized calls: one launch of the decode kernel (ns_gemv.hip, XV = 4) per token row — LDS-DMA rings, MFMA on the raw
   // codes, the expert's base pointer picked from the table on the device — instead of this file's VALU loop (Mixtral shapes,
   // one token, 8 x {14336 x 4096, 4096 x 14336} int4: 169 us per MoE FFN layer with the loop, profiles/r04s_moe_mixtral_m1.json)

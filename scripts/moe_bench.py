@@ -59,18 +59,26 @@ def chain(s):
 for _ in range(3):
     chain(st)
 torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    chain(C.c_void_p(torch.cuda.current_stream().cuda_stream))
-for _ in range(3):
-    g.replay()
-torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-reps = 30
-for _ in range(reps):
-    g.replay()
-e1.record(); torch.cuda.synchronize()
+if m >= 32:
+    # prefill size (round 5): the grouped form reads the ids on the host, so it is timed as plain calls (NS_MOE_GROUPED_ROWS=0: the per-row kernels)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        chain(st)
+    e1.record(); torch.cuda.synchronize()
+else:
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        chain(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    reps = 30
+    for _ in range(reps):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / reps / nlay
 # parity of the last layer's last selection (token 0): silu(a Wg) * (a Wu) then Wd, fp64 over the oracle's blobs
 (wg, _), (wu, _), (wd, _) = layers[-1]
@@ -87,4 +95,6 @@ touched = sum(w[0][e2][0].stream_bytes for w in layers[0] for e2 in set(ids_np.r
 print(json.dumps({"what": "Mixtral-8x7B-shaped MoE FFN (8 x {14336x4096 gate, up; 4096x14336 down}, top-2, int4 g32 bf16), %d token(s)" % m,
                   "us_per_moe_ffn_layer": round(us, 2), "expert_weight_bytes_touched_per_layer": int(touched),
                   "hbm_GBps_over_touched_weights": round(touched / us / 1e3, 1), "tokens_per_s_of_32_moe_ffn_layers": round(m * 1e6 / (32 * us), 1),
-                  "parity_rel_l2_vs_fp64_oracle_token0": float("%.3g" % par), "launches_per_layer": 3 * topk}))
+                  "parity_rel_l2_vs_fp64_oracle_token0": float("%.3g" % par), "launches_per_layer": 3 * topk,
+                  "grouped_by_expert": m >= 32 and os.environ.get("NS_MOE_GROUPED_ROWS", "32") != "0",
+                  "tflops": round(m * topk * 3 * 2.0 * d * ff / us / 1e6, 1)}))

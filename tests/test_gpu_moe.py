@@ -107,3 +107,44 @@ def test_ffn_id_composition_in_a_graph_and_bad_ids(L, pkg, nso):
     L.ns_hip_reset_error()
     for g in (gg, gu, gd):
         L.ns_hip_expert_group_free(g)
+
+
+@pytest.mark.parametrize("qt,st,asym,bs,core", FORMATS[:3] + [("F4_NF4", "BF16", False, 64, "CORE_AVX512F")])
+@pytest.mark.parametrize("epi", ["none", "silu", "mul"])
+def test_mul_mat_id_at_prefill_size_groups_the_rows_by_expert(L, pkg, nso, qt, st, asym, bs, core, epi):
+    """round 5: from 32 token rows on the rows are grouped by expert on the host (the reference groups them too: `matrix_rows`,
+    ne_layers.c:7855-7866) and every expert's rows are ONE launch of the tiled GEMM instead of one weight stream per token; the epilogue
+    is applied per token row by the scatter kernel.  Ragged groups (an expert with one row, an expert with none), an id outside the
+    group (zero product, like the per-row kernels), every row against the oracle's fp64 product with ITS expert."""
+    import torch
+    rng = np.random.default_rng(len(qt) * 7 + bs + len(epi))
+    n_as, n, k, m, topk = 5, 272, 512, 150, 2
+    blobs, weights, g = _group(L, pkg, nso, rng, n_as, n, k, qt, st, asym, bs, core)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    ids = rng.integers(0, 3, size=(m, topk)).astype(np.int32)   # experts 0..2 share most rows
+    ids[17, 1] = 3                                              # expert 3: exactly one row
+    ids[40, 1] = 99                                             # outside the group; expert 4: no row at all
+    d = rng.standard_normal((m, n)).astype(np.float32)
+    dA, dI, dD = torch.from_numpy(a).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(d).cuda()
+    st_ = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    code = {"none": pkg.EPI_NONE, "silu": pkg.EPI_SILU, "mul": pkg.EPI_MUL}[epi]
+    dC = torch.full((m, n + 3), 7.0, device="cuda")
+    pkg.check(L.ns_hip_mul_mat_id(dA.data_ptr(), dI.data_ptr(), topk, 1, g, dC.data_ptr(), m, k, n + 3, code,
+                                  dD.data_ptr() if epi == "mul" else None, n, st_))
+    torch.cuda.synchronize()
+    out = dC.cpu().numpy()
+    assert np.all(out[:, n:] == 7.0)
+    ref = np.zeros((m, n))
+    for t in range(m):
+        e = ids[t, 1]
+        if 0 <= e < n_as:
+            ref[t] = nso.gemm_f64(a[t:t + 1], blobs[e])[0]
+    if epi == "silu":
+        ref = ref / (1.0 + np.exp(-ref))
+    if epi == "mul":
+        ref = ref * d
+    assert nso.rel_l2(out[:, :n], ref) < 1e-3
+    assert np.all(out[40, :n] == 0.0)
+    L.ns_hip_expert_group_free(g)
+    for w in weights:
+        w.free()
