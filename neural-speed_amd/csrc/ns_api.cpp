@@ -1136,6 +1136,18 @@ int ns_hip_set_tuning(const char* key, int value) {
     set_attn_mfma2_rows(value);
     return 0;
   }
+  if (key && !strcmp(key, "attn_stream_wg_target")) {
+    set_attn_stream_tuning(value, 0);
+    return 0;
+  }
+  if (key && !strcmp(key, "attn_stream_min_keys")) {
+    set_attn_stream_tuning(0, value);
+    return 0;
+  }
+  if (key && !strcmp(key, "attn_stream")) {
+    set_attn_stream(value);
+    return 0;
+  }
   if (key && !strcmp(key, "attn_inlaunch")) {
     set_attn_inlaunch(value);
     return 0;

@@ -190,6 +190,135 @@ __device__ __forceinline__ float ld_through(const float* p) {
   return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
 
+// What follows the key loop of a split kernel (attn_split_kernel and attn_stream_kernel share it): the four key groups of a wave are
+// combined by shuffles, the waves through LDS (acc_s: [4 waves][G][16 * DPL] floats), then either the output row (one split) or the
+// split's partial (max, sum, unnormalised output) is stored — and, with tickets, the last split of a kv head merges inside the launch.
+template <int G, int DPL>
+__device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, float (&acc)[G][DPL], float (&m)[G], float (&lsum)[G], float* acc_s,
+                                                  float (&ml_s)[4][G][2], int split, int chunk, int ihkv, int i, int ibs) {
+  const AttnParams& p = sp.a;
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int hs = p.head_size;
+  const int d0 = (l & 15) * DPL;
+  auto head_of = [&](int g) { return ihkv * sp.g_full + min(chunk * G + g, sp.g_full - 1); };
+  auto head_live = [&](int g) { return chunk * G + g < sp.g_full; };
+  // ---- merge the 4 key groups of a wave (lanes with equal dl) by shuffles ----
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float mo = __shfl_xor(m[g], off, 64), lo = __shfl_xor(lsum[g], off, 64);
+      const float mn = fmaxf(m[g], mo);
+      const float ca = mn == -INFINITY ? 0.f : expf(m[g] - mn), cb = mn == -INFINITY ? 0.f : expf(mo - mn);
+      lsum[g] = lsum[g] * ca + lo * cb;
+#pragma unroll
+      for (int e = 0; e < DPL; e++) acc[g][e] = acc[g][e] * ca + __shfl_xor(acc[g][e], off, 64) * cb;
+      m[g] = mn;
+    }
+  }
+  // ---- across the 4 waves through LDS ----
+  if (l < 16) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (l == 0) {
+        ml_s[w][g][0] = m[g];
+        ml_s[w][g][1] = lsum[g];
+      }
+#pragma unroll
+      for (int e = 0; e < DPL; e++) acc_s[(w * G + g) * 16 * DPL + d0 + e] = acc[g][e];
+    }
+  }
+  __syncthreads();
+  // thread (g, d) finishes output dim d of head g
+  for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
+    const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
+    if (dd >= hs || !head_live(g)) continue;
+    float mb = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++) mb = fmaxf(mb, ml_s[ww][g][0]);
+    float lb = 0.f, ab = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++) {
+      const float c = ml_s[ww][g][0] == -INFINITY ? 0.f : expf(ml_s[ww][g][0] - mb);
+      lb += ml_s[ww][g][1] * c;
+      ab += acc_s[(ww * G + g) * 16 * DPL + dd] * c;
+    }
+    const int ihn = head_of(g);
+    if (sp.nsplit == 1) {
+      float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
+      const float y = ab / lb * p.out_scale;
+      dst[dd] = y;
+      if (p.dst16) p.dst16[dst - p.dst + dd] = (_Float16)y;
+    } else {
+      float* wp = sp.ws + ((((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit + split) * (2 + hs);
+      if (sp.tickets) {
+        if (dd == 0) {
+          st_through(wp, mb);
+          st_through(wp + 1, lb);
+        }
+        st_through(wp + 2 + dd, ab);
+      } else {
+        if (dd == 0) {
+          wp[0] = mb;
+          wp[1] = lb;
+        }
+        wp[2 + dd] = ab;
+      }
+    }
+  }
+  if (sp.nsplit == 1 || !sp.tickets) return;
+  // ---- merge inside the launch: the write-through stores above are drained, the workgroup draws a ticket, and the one that
+  // draws the last of (batch, query row, kv head) combines all splits — the sums attn_merge_kernel forms, in the same order ----
+  __shared__ uint32_t drawn_s;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  uint32_t* tk = sp.tickets + (((size_t)ibs * p.sl_q + i) * p.heads_kv + ihkv) * sp.chunks + chunk;
+  if (t == 0) drawn_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (drawn_s != uint32_t(sp.nsplit - 1)) return;
+  if (t == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+  const int ns = sp.nsplit;
+  for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
+    const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
+    if (dd >= hs || !head_live(g)) continue;
+    const int ihn = head_of(g);
+    const float* wq = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
+    float mb = -INFINITY, lb = 0.f, ab = 0.f;
+    if (ns <= 16) {  // every load of the merge requested at once
+      float mv[16], lv[16], ov[16];
+#pragma unroll
+      for (int s2 = 0; s2 < 16; s2++) {
+        const bool on = s2 < ns;
+        mv[s2] = on ? ld_through(wq + s2 * (2 + hs)) : -INFINITY;
+        lv[s2] = on ? ld_through(wq + s2 * (2 + hs) + 1) : 0.f;
+        ov[s2] = on ? ld_through(wq + s2 * (2 + hs) + 2 + dd) : 0.f;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 16; s2++) mb = fmaxf(mb, mv[s2]);
+#pragma unroll
+      for (int s2 = 0; s2 < 16; s2++) {
+        if (s2 < ns) {
+          const float c = mv[s2] != -INFINITY ? expf(mv[s2] - mb) : 0.f;
+          lb += lv[s2] * c;
+          ab += ov[s2] * c;
+        }
+      }
+    } else {
+      for (int s2 = 0; s2 < ns; s2++) mb = fmaxf(mb, ld_through(wq + s2 * (2 + hs)));
+      for (int s2 = 0; s2 < ns; s2++) {
+        const float ms = ld_through(wq + s2 * (2 + hs));
+        const float c = ms != -INFINITY ? expf(ms - mb) : 0.f;
+        lb += ld_through(wq + s2 * (2 + hs) + 1) * c;
+        ab += ld_through(wq + s2 * (2 + hs) + 2 + dd) * c;
+      }
+    }
+    float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
+    const float y = ab / lb * p.out_scale;
+    dst[dd] = y;
+    if (p.dst16) p.dst16[dst - p.dst + dd] = (_Float16)y;
+  }
+}
+
 template <int G, int DPL>  // G query heads per kv head; DPL head dims per lane (8: head_size <= 128, 16: <= 256)
 __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSplitParams sp) {
   const AttnParams& p = sp.a;
@@ -346,121 +475,211 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
     }
   }
 
-  // ---- merge the 4 key groups of a wave (lanes with equal dl) by shuffles ----
+  attn_split_finish<G, DPL>(sp, acc, m, lsum, acc_s, ml_s, split, chunk, ihkv, i, ibs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// attn_stream_kernel (round 5) — attn_split_kernel's arithmetic on the decode GEMV's streaming skeleton (ns_gemv.hip): the K and V rows
+// of the workgroup's context range go HBM -> LDS by DMA (buffer_load ... lds, 16 B per lane, non-temporal) into a PRIVATE ring per
+// wave, every request of the range in flight before the first key is multiplied; the lanes then read back exactly the 16 bytes they
+// requested (lane-linear image: no bank conflicts, no staging registers held across the memory round trip) behind hand-counted
+// s_waitcnt vmcnt.  What this changes against attn_split_kernel: that kernel holds U = 4 keys per lane in registers, so a range of
+// 128 keys is two dependent round trips of 32 KiB per workgroup (the stream alone is 8.4 of its 10.8 us at 2048 positions,
+// profiles/r04bb_*); here a workgroup has its whole range — 64 KiB at 128 keys — requested within the first few hundred cycles.
+// Same key -> lane mapping (wave w, step u: keys j0 + 16 u + 4 w .. + 3, lane group l >> 4 one key each, lane l & 15 eight head
+// dims), same U-key softmax update, same finish: the partials, and so the outputs, are the bits attn_split_kernel writes.
+// A step = 4 keys = one 1 KiB request of K + one of V per wave; ring of kAsSteps steps per wave (refilled behind the reads for longer
+// ranges).  Rows past the range's end lie outside the buffer descriptor (the DMA writes zeros for them); their scores are masked and
+// their V is selected to zero as in attn_split_kernel, so nothing depends on what such a slot holds.
+constexpr int kAsSteps = 8;
+constexpr size_t kAsLdsBytes = size_t(4) * kAsSteps * 2048;
+template <int G>
+__global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSplitParams sp) {
+  constexpr int DPL = 8;
+  const AttnParams& p = sp.a;
+  __shared__ float ml_s[4][G][2];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_s[];  // [4 waves][kAsSteps][K image 1 KiB | V image 1 KiB]; afterwards acc_s
+  typedef __attribute__((address_space(3))) unsigned char* LdsPtr;
+  const int split = sp.heads_first ? blockIdx.y : blockIdx.x;
+  const int by = sp.heads_first ? blockIdx.x : blockIdx.y;
+  const int chunk = by % sp.chunks, ykv = by / sp.chunks;
+  const int ihkv = ykv % p.heads_kv, i = ykv / p.heads_kv, ibs = blockIdx.z;
+  auto head_of = [&](int g) { return ihkv * sp.g_full + min(chunk * G + g, sp.g_full - 1); };
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int dl = l & 15;
+  const int hs = p.head_size;
+  const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
+  const bool alibi = (p.flags & NS_ATTN_FLAG_IS_ALIBI8) != 0;
+  const bool tanh30 = (p.flags & NS_ATTN_FLAG_IS_TANH30) != 0;
+  const int unmasked = causal ? (p.sl_kv - p.sl_q) + i + 1 : p.sl_kv;
+  const int j0 = split * sp.keys_per_split, j1 = min(unmasked, j0 + sp.keys_per_split);
+  const int d0 = dl * DPL;
+  const bool dact = d0 < hs;
+  constexpr int U = G * DPL <= 16 ? 4 : 2;  // keys per lane and softmax update: attn_split_kernel's rule (the update order decides the bits)
+  static_assert(kAsSteps % U == 0, "a batch of U steps never wraps inside the ring");
+  const int nsteps = j1 > j0 ? (((j1 - j0 + 15) >> 4) + U - 1) / U * U : 0;  // whole batches: steps past the end fetch nothing (outside the descriptor)
+
+  // ---- 0. the query rows are requested first (ordinary loads, OLDER than the stream: loads return in order, a row requested behind the
+  //      ring would be usable only when the whole ring has landed) ----
+  //      Written by hand: for a load it knows hipcc waits with vmcnt(0) at the first use, i.e. for the whole ring (it does not count
+  //      the LDS-DMA requests behind it); the counted wait is in step 2.
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  f4_t qa[G], qb[G];
 #pragma unroll
   for (int g = 0; g < G; g++) {
+    // (no branch around the asm and no other definition of its outputs: hipcc takes an asm's outputs for complete and would copy
+    // them — e.g. to merge them with a zero — while the data is still on its way; lanes past the head size load dims 0..7, unused)
+    const float* qp = p.q + ibs * p.step_q_bs + head_of(g) * p.step_q_head_num + i * p.step_q_sl + (dact ? d0 : 0);
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(qa[g]), "=&v"(qb[g]) : "v"(qp) : "memory");
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 1. the whole range (up to the ring's depth) is requested before anything else is touched ----
+  const _Float16* kh = p.k + ibs * p.step_k_bs + ihkv * p.step_k_head_num;
+  const _Float16* vh = p.v + ibs * p.step_v_bs + ihkv * p.step_v_head_num;
+  const uint32_t k_bytes = j1 > j0 ? uint32_t((size_t(j1 - 1) * p.step_k_sl + hs) * 2) : 0u;
+  const uint32_t v_bytes = j1 > j0 ? uint32_t((size_t(j1 - 1) * p.step_v_sl + hs) * 2) : 0u;
+  // (the descriptors are wave-uniform; said explicitly, or hipcc wraps every request into a readfirstlane loop)
+  auto uniform_ptr = [](const _Float16* ptr) {
+    const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return reinterpret_cast<_Float16*>((uint64_t(hi) << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(kh), 0, __builtin_amdgcn_readfirstlane(k_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(vh), 0, __builtin_amdgcn_readfirstlane(v_bytes), 0x00020000);
+  const uint32_t key_l = uint32_t(j0 + 4 * w + (l >> 4));  // this lane's key of step 0
+  const uint32_t k_voff = (key_l * uint32_t(p.step_k_sl) + uint32_t(d0)) * 2u, k_step = 16u * uint32_t(p.step_k_sl) * 2u;
+  const uint32_t v_voff = (key_l * uint32_t(p.step_v_sl) + uint32_t(d0)) * 2u, v_step = 16u * uint32_t(p.step_v_sl) * 2u;
+  const LdsPtr ring = (LdsPtr)(ring_s) + w * (kAsSteps * 2048);
+  auto issue = [&](int s) {  // step s -> slot s % kAsSteps; the key offset is part of the per-lane offset (the part the descriptor checks)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const LdsPtr dst = ring + (s & (kAsSteps - 1)) * 2048;
+    if (dact) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, reinterpret_cast<__attribute__((address_space(3))) void*>(dst), 16, k_voff + uint32_t(s) * k_step, 0, 0, 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, reinterpret_cast<__attribute__((address_space(3))) void*>(dst + 1024), 16, v_voff + uint32_t(s) * v_step, 0, 0, 2);
+    }
+#endif
+  };
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const float mo = __shfl_xor(m[g], off, 64), lo = __shfl_xor(lsum[g], off, 64);
-      const float mn = fmaxf(m[g], mo);
-      const float ca = mn == -INFINITY ? 0.f : expf(m[g] - mn), cb = mn == -INFINITY ? 0.f : expf(mo - mn);
-      lsum[g] = lsum[g] * ca + lo * cb;
+  for (int s = 0; s < kAsSteps; s++)
+    if (s < nsteps) issue(s);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- 2. the query rows' first use (their wait is counted: the stream's requests are younger and stay in flight) ----
+  switch (min(nsteps, kAsSteps)) {  // requests issued behind the query loads: two per step
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+  }
+  static_assert(kAsSteps == 8, "the cases above");
+  float q[G][DPL], acc[G][DPL], m[G], lsum[G], slope[G];
 #pragma unroll
-      for (int e = 0; e < DPL; e++) acc[g][e] = acc[g][e] * ca + __shfl_xor(acc[g][e], off, 64) * cb;
-      m[g] = mn;
+  for (int g = 0; g < G; g++) {
+    const int ihn = head_of(g);
+    asm volatile("" : "+v"(qa[g]), "+v"(qb[g]));  // (uses of the rows stay behind the wait)
+#pragma unroll
+    for (int e = 0; e < DPL; e++) {
+      q[g][e] = dact ? (e < 4 ? qa[g][e & 3] : qb[g][e & 3]) * p.qk_scale : 0.f;
+      acc[g][e] = 0.f;
+    }
+    m[g] = -INFINITY;
+    lsum[g] = 0.f;
+    slope[g] = 0.f;
+    if (alibi) {
+      const int gh = ihn + p.alibi_head_off;
+      slope[g] = gh < p.alibi_log2_floor ? powf(p.alibi_m0, float(gh + 1)) : powf(p.alibi_m1, float(2 * (gh - p.alibi_log2_floor) + 1));
     }
   }
-  // ---- across the 4 waves through LDS ----
-  if (l < 16) {
+
+  typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+  typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+  const uint32_t lane_lds = uint32_t(reinterpret_cast<uintptr_t>(ring)) + uint32_t(l) * 16u;
+  // at most `younger` STEPS requested after the batch about to be read are still in flight (two requests per step)
+  auto wait_steps = [&](int younger) {
+    switch (younger) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+  };
+  for (int s0 = 0; s0 < nsteps; s0 += U) {
+    wait_steps(min(nsteps - s0 - U, kAsSteps - U));
+    u4_t kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t a = lane_lds + uint32_t((s0 + u) & (kAsSteps - 1)) * 2048u;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(kr[u]), "=&v"(vr[u]) : "v"(a) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < U; u++) asm volatile("" : "+v"(kr[u]), "+v"(vr[u]));  // (uses stay behind the wait)
+    __builtin_amdgcn_sched_barrier(0);
+    // the slots are free: the steps one ring ahead are requested before this batch is multiplied
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (s0 + kAsSteps + u < nsteps) issue(s0 + kAsSteps + u);
+    __builtin_amdgcn_sched_barrier(0);
+    const int jb = j0 + 16 * s0 + 4 * w + (l >> 4);
+    // rows past the range's end and lanes past the head size count as zeros, as attn_split_kernel's unrequested registers do
+    half8_t kv[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const bool live = dact && jb + 16 * u < j1;
+      const u4_t zero = {0u, 0u, 0u, 0u};
+      kv[u] = __builtin_bit_cast(half8_t, live ? kr[u] : zero);
+      vv[u] = __builtin_bit_cast(half8_t, live ? vr[u] : zero);
+    }
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      if (l == 0) {
-        ml_s[w][g][0] = m[g];
-        ml_s[w][g][1] = lsum[g];
+      float s[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        float t2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < DPL; e++) t2 += q[g][e] * float(kv[u][e]);
+        s[u] = t2;
       }
 #pragma unroll
-      for (int e = 0; e < DPL; e++) acc_s[(w * G + g) * 16 * DPL + d0 + e] = acc[g][e];
+      for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+        for (int u = 0; u < U; u++) s[u] += __shfl_xor(s[u], off, 64);
+      }
+      float m_new = m[g];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int j = jb + 16 * u;
+        if (tanh30) s[u] = 30.f * tanhf(s[u] * (1.f / 30.f));
+        s[u] += float(j) * slope[g];
+        if (j >= j1) s[u] = -INFINITY;
+        m_new = fmaxf(m_new, s[u]);
+      }
+      // a lane group whose keys of this batch are all past the end keeps m = -inf: then m_new = -inf and exp(-inf - -inf) would be NaN
+      const float corr = m_new == -INFINITY ? 1.f : expf(m[g] - m_new);
+      float pj[U], psum = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        pj[u] = m_new == -INFINITY ? 0.f : expf(s[u] - m_new);
+        psum += pj[u];
+      }
+      lsum[g] = lsum[g] * corr + psum;
+#pragma unroll
+      for (int e = 0; e < DPL; e++) {
+        float a2 = acc[g][e] * corr;
+#pragma unroll
+        for (int u = 0; u < U; u++) a2 += pj[u] * float(vv[u][e]);
+        acc[g][e] = a2;
+      }
+      m[g] = m_new;
     }
   }
-  __syncthreads();
-  // thread (g, d) finishes output dim d of head g
-  for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
-    const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
-    if (dd >= hs || !head_live(g)) continue;
-    float mb = -INFINITY;
-#pragma unroll
-    for (int ww = 0; ww < 4; ww++) mb = fmaxf(mb, ml_s[ww][g][0]);
-    float lb = 0.f, ab = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < 4; ww++) {
-      const float c = ml_s[ww][g][0] == -INFINITY ? 0.f : expf(ml_s[ww][g][0] - mb);
-      lb += ml_s[ww][g][1] * c;
-      ab += acc_s[(ww * G + g) * 16 * DPL + dd] * c;
-    }
-    const int ihn = head_of(g);
-    if (sp.nsplit == 1) {
-      float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
-      const float y = ab / lb * p.out_scale;
-      dst[dd] = y;
-      if (p.dst16) p.dst16[dst - p.dst + dd] = (_Float16)y;
-    } else {
-      float* wp = sp.ws + ((((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit + split) * (2 + hs);
-      if (sp.tickets) {
-        if (dd == 0) {
-          st_through(wp, mb);
-          st_through(wp + 1, lb);
-        }
-        st_through(wp + 2 + dd, ab);
-      } else {
-        if (dd == 0) {
-          wp[0] = mb;
-          wp[1] = lb;
-        }
-        wp[2 + dd] = ab;
-      }
-    }
-  }
-  if (sp.nsplit == 1 || !sp.tickets) return;
-  // ---- merge inside the launch: the write-through stores above are drained, the workgroup draws a ticket, and the one that
-  // draws the last of (batch, query row, kv head) combines all splits — the sums attn_merge_kernel forms, in the same order ----
-  __shared__ uint32_t drawn_s;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  uint32_t* tk = sp.tickets + (((size_t)ibs * p.sl_q + i) * p.heads_kv + ihkv) * sp.chunks + chunk;
-  if (t == 0) drawn_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (drawn_s != uint32_t(sp.nsplit - 1)) return;
-  if (t == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
-  const int ns = sp.nsplit;
-  for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
-    const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
-    if (dd >= hs || !head_live(g)) continue;
-    const int ihn = head_of(g);
-    const float* wq = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
-    float mb = -INFINITY, lb = 0.f, ab = 0.f;
-    if (ns <= 16) {  // every load of the merge requested at once
-      float mv[16], lv[16], ov[16];
-#pragma unroll
-      for (int s2 = 0; s2 < 16; s2++) {
-        const bool on = s2 < ns;
-        mv[s2] = on ? ld_through(wq + s2 * (2 + hs)) : -INFINITY;
-        lv[s2] = on ? ld_through(wq + s2 * (2 + hs) + 1) : 0.f;
-        ov[s2] = on ? ld_through(wq + s2 * (2 + hs) + 2 + dd) : 0.f;
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 16; s2++) mb = fmaxf(mb, mv[s2]);
-#pragma unroll
-      for (int s2 = 0; s2 < 16; s2++) {
-        if (s2 < ns) {
-          const float c = mv[s2] != -INFINITY ? expf(mv[s2] - mb) : 0.f;
-          lb += lv[s2] * c;
-          ab += ov[s2] * c;
-        }
-      }
-    } else {
-      for (int s2 = 0; s2 < ns; s2++) mb = fmaxf(mb, ld_through(wq + s2 * (2 + hs)));
-      for (int s2 = 0; s2 < ns; s2++) {
-        const float ms = ld_through(wq + s2 * (2 + hs));
-        const float c = ms != -INFINITY ? expf(ms - mb) : 0.f;
-        lb += ld_through(wq + s2 * (2 + hs) + 1) * c;
-        ab += ld_through(wq + s2 * (2 + hs) + 2 + dd) * c;
-      }
-    }
-    float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
-    const float y = ab / lb * p.out_scale;
-    dst[dd] = y;
-    if (p.dst16) p.dst16[dst - p.dst + dd] = (_Float16)y;
-  }
+  __syncthreads();  // every wave has left its ring: its first bytes become attn_split_finish's acc_s
+  attn_split_finish<G, DPL>(sp, acc, m, lsum, reinterpret_cast<float*>(ring_s), ml_s, split, chunk, ihkv, i, ibs);
 }
 
 // one workgroup per (batch, query row, head): combine the splits' (m, l, acc).  The per-split (m, l) are fetched by
@@ -473,14 +692,16 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
   const int ihn = blockIdx.x, i = blockIdx.y, ibs = blockIdx.z;
   const int hs = p.head_size, t = threadIdx.x, ns = sp.nsplit;  // ns <= 64
   const float* wp = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
-  if (ns <= 16 && hs <= int(blockDim.x)) {
-    // the common decode shape (<= 16 splits, one output element per thread): every thread fetches all (max, sum) pairs — wave-
-    // uniform addresses, scalar loads — and its own column of the partial outputs in ONE batch of loads, then merges in registers:
-    // one memory round trip behind the kernel boundary instead of two with a workgroup barrier between them (round 4: the launch
-    // is 4.9 us for a few KB of work; the same sums in the same order as the general form below)
-    float mv[16], lv[16], ov[16];
+  // the common decode shapes (<= 32 splits, one output element per thread): every thread fetches all (max, sum) pairs — wave-
+  // uniform addresses, scalar loads — and its own column of the partial outputs in ONE batch of loads, then merges in registers:
+  // one memory round trip behind the kernel boundary instead of two with a workgroup barrier between them (round 4: the launch
+  // is 4.9 us for a few KB of work; the same sums in the same order as the general form below).  Round 5: also for 17 .. 32 splits
+  // (the LDS-ring kernel splits a kv head shared by 4 query heads into 32 ranges at 2048 positions).
+  auto fast = [&](auto n_c) {
+    constexpr int N = decltype(n_c)::value;
+    float mv[N], lv[N], ov[N];
 #pragma unroll
-    for (int s2 = 0; s2 < 16; s2++) {
+    for (int s2 = 0; s2 < N; s2++) {
       const bool on = s2 < ns;
       mv[s2] = on ? wp[s2 * (2 + hs)] : -INFINITY;
       lv[s2] = on ? wp[s2 * (2 + hs) + 1] : 0.f;
@@ -488,10 +709,10 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
     }
     float mb2 = -INFINITY;
 #pragma unroll
-    for (int s2 = 0; s2 < 16; s2++) mb2 = fmaxf(mb2, mv[s2]);
+    for (int s2 = 0; s2 < N; s2++) mb2 = fmaxf(mb2, mv[s2]);
     float lb2 = 0.f, ab2 = 0.f;
 #pragma unroll
-    for (int s2 = 0; s2 < 16; s2++) {
+    for (int s2 = 0; s2 < N; s2++) {
       if (s2 < ns) {
         const float c = mv[s2] != -INFINITY ? expf(mv[s2] - mb2) : 0.f;
         lb2 += lv[s2] * c;
@@ -504,8 +725,9 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
       dst2[t] = y;
       if (p.dst16) p.dst16[dst2 - p.dst + t] = (_Float16)y;
     }
-    return;
-  }
+  };
+  if (ns <= 16 && hs <= int(blockDim.x)) return fast(std::integral_constant<int, 16>{});
+  if (ns <= 32 && hs <= int(blockDim.x)) return fast(std::integral_constant<int, 32>{});
   float ms = -INFINITY, ls = 0.f;
   if (t < ns) {
     ms = wp[t * (2 + hs)];
@@ -532,9 +754,27 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
   }
 }
 
+// ns_hip_set_tuning("attn_stream", 0 / 1): 1 (default) = decode attention of head sizes <= 128 streams K / V through LDS rings (attn_stream_kernel),
+// 0 = attn_split_kernel (registers).  Same bits either way.
+static std::atomic<int> g_attn_stream{getenv("NS_ATTN_STREAM") ? atoi(getenv("NS_ATTN_STREAM")) != 0 : 1};
+void set_attn_stream(int on) { g_attn_stream.store(on != 0); }
+// whether a fast-path call streams through the LDS rings: head sizes 72 .. 128 (up to 64 only half of a request's lanes carry data — measured
+// slower from 4096 positions on), row offsets inside a 32-bit buffer descriptor, 16-byte query loads
+static bool attn_streams(const AttnParams& a) {
+  const bool in32 = (size_t(a.sl_kv) * size_t(a.step_k_sl) + 256) * 2 < (size_t(1) << 32) && (size_t(a.sl_kv) * size_t(a.step_v_sl) + 256) * 2 < (size_t(1) << 32);
+  const bool q16 = (reinterpret_cast<uintptr_t>(a.q) & 15) == 0 && a.step_q_bs % 4 == 0 && a.step_q_head_num % 4 == 0 && a.step_q_sl % 4 == 0;
+  return a.head_size > 64 && a.head_size <= 128 && in32 && q16 && g_attn_stream.load(std::memory_order_relaxed) != 0;
+}
 template <int G>
-static hipError_t launch_split_g(const AttnSplitParams& sp, dim3 grid, hipStream_t st) {
+static hipError_t launch_split_g(const AttnSplitParams& sp, dim3 grid, hipStream_t st, bool stream) {
   const int hs = sp.a.head_size;
+  if (stream) {
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_stream_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kAsLdsBytes));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((attn_stream_kernel<G>), grid, dim3(kAttnThreads), kAsLdsBytes, st, sp);
+    return hipGetLastError();
+  }
   if (hs <= 128) {
     hipLaunchKernelGGL((attn_split_kernel<G, 8>), grid, dim3(kAttnThreads), size_t(4) * G * 128 * 4, st, sp);
   } else {
@@ -564,9 +804,19 @@ static void attn_groups(int g_full, int* G, int* chunks) {
   *G = g_full <= 1 ? 1 : (g_full == 2 ? 2 : (g_full <= 4 ? 4 : 8));
   *chunks = (g_full + *G - 1) / *G;
 }
-static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv) {  // heads_kv: kv heads x workgroups per kv head
+// The LDS-ring kernel has its own rule (ns_hip_set_tuning("attn_stream_wg_target" / "attn_stream_min_keys"; profiles/r05p_attn_stream.txt): a
+// workgroup keeps 64 KiB in flight whatever its range, so ONE workgroup per CU streams best — 32 kv heads at 2048 positions: 8 ranges of 256
+// keys 12.9 us (split + merge) against 13.7 with 16 x 128 and 15.2 with 32 x 64; 8 kv heads: 32 ranges of 64 keys 13.5 us against 16.6 with
+// 16 x 128 (128 workgroups: half the chip idle).
+static std::atomic<int> g_attn_wg_target_s{256}, g_attn_min_keys_s{32};
+void set_attn_stream_tuning(int wg_target, int min_keys) {
+  if (wg_target > 0) g_attn_wg_target_s.store(wg_target);
+  if (min_keys > 0) g_attn_min_keys_s.store(min_keys);
+}
+static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv, bool stream) {  // heads_kv: kv heads x workgroups per kv head
   const size_t base_blocks = size_t(heads_kv) * sl_q * batch;
-  const int target = g_attn_wg_target.load(), mk = g_attn_min_keys.load();
+  const int target = stream ? g_attn_wg_target_s.load() : g_attn_wg_target.load(), mk = stream ? g_attn_min_keys_s.load() : g_attn_min_keys.load();
+  if (stream && sl_kv <= 128 && base_blocks >= 32) return 1;  // (a range's worth of keys on 32+ workgroups: the merge launch costs more than it saves, 7.0 vs 7.8 us)
   int nsplit = int((target + base_blocks - 1) / base_blocks);     // aim at ~4 workgroups per CU
   nsplit = std::min(nsplit, std::max(1, (sl_kv + mk - 1) / mk));  // at least 128 keys per split
   return std::min(nsplit, 64);
@@ -574,7 +824,7 @@ static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv) {  // heads
 static size_t attn_ws_bytes(int batch, int head_num, int heads_kv, int head_size, int sl_q, int sl_kv) {
   int G, chunks;
   attn_groups(head_num / std::max(1, heads_kv), &G, &chunks);
-  const int ns = attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv);
+  const int ns = std::max(attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv, false), attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv, true));  // (either kernel)
   return ns > 1 ? size_t(batch) * sl_q * head_num * ns * (2 + head_size) * 4 : 0;
 }
 
@@ -1259,7 +1509,8 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     AttnSplitParams sp;
     sp.a = p;
     sp.g_full = a.head_num / a.heads_kv, sp.chunks = chunks;
-    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv);
+    const bool stream = attn_streams(p);
+    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv, stream);
     float* ws = nullptr;
     if (nsplit > 1) {
       // partials go to the caller's workspace (`tmp`, sized by bestla_fusion_attn_workspace_size: the reference's own
@@ -1285,10 +1536,10 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     sp.heads_first = (hf < 0 ? position_major : hf != 0) && size_t(nsplit) <= 65535;
     const dim3 grid = sp.heads_first ? dim3(unsigned(a.heads_kv * a.sl_q * chunks), unsigned(nsplit), unsigned(a.batch_size))
                                      : dim3(unsigned(nsplit), unsigned(a.heads_kv * a.sl_q * chunks), unsigned(a.batch_size));
-    hipError_t e = G == 1 ? launch_split_g<1>(sp, grid, st)
-                 : G == 2 ? launch_split_g<2>(sp, grid, st)
-                 : G == 4 ? launch_split_g<4>(sp, grid, st)
-                          : launch_split_g<8>(sp, grid, st);
+    hipError_t e = G == 1 ? launch_split_g<1>(sp, grid, st, stream)
+                 : G == 2 ? launch_split_g<2>(sp, grid, st, stream)
+                 : G == 4 ? launch_split_g<4>(sp, grid, st, stream)
+                          : launch_split_g<8>(sp, grid, st, stream);
     if (e != hipSuccess) return e;
     if (nsplit > 1 && !sp.tickets) {
       hipLaunchKernelGGL(attn_merge_kernel, dim3(unsigned(a.head_num), unsigned(a.sl_q), unsigned(a.batch_size)), dim3(128), 0,

@@ -210,6 +210,8 @@ void set_attn_tuning(int wg_target, int min_keys);
 void set_attn_heads_first(int on);  // ns_attn.hip: dispatch order of the decode attention's workgroups (AttnSplitParams::heads_first)
 void set_gemv_planes(int on);  // 1 (default): bit-plane formats stream their native records at decode (ns_weight::native); 0: the widened ones
 void set_attn_mfma2_rows(int rows);  // query rows from which the 128-row prefill attention kernel is used (default 128; huge = never)
+void set_attn_stream_tuning(int wg_target, int min_keys);  // context-range rule of the LDS-ring kernel (defaults 256 workgroups, >= 32 keys)
+void set_attn_stream(int on);    // 1 (default): decode attention streams K / V through LDS rings (attn_stream_kernel); 0: attn_split_kernel
 void set_attn_inlaunch(int on);  // 0 (default): attn_merge_kernel combines the context splits in a second launch; 1: the last split to finish merges inside attn_split_kernel's launch
 // NS_HOST_PROFILE=1: wall time and call count of every host-tensor entry, printed at exit (diagnostics of the default,
 // host-pointer route: where a token's milliseconds go between the graph executor and the GPU)

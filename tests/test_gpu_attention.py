@@ -286,3 +286,88 @@ def test_tanh30_soft_cap_against_fp64(L, pkg, nso, sl_q, sl_kv, hs, alibi):
     pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     assert nso.rel_l2(dd.cpu().numpy(), ref) < TOL
+
+
+STREAM_CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags: decode-side shapes of the fast path (contiguous head dimension)
+    (1, 32, 32, 128, 1, 2048, 1),   # Llama-2-7B: 8 ranges of 256 keys (ring refilled once per range)
+    (1, 32, 8, 128, 1, 777, 1),     # group of 4, ragged ranges
+    (1, 64, 8, 128, 1, 3000, 1),    # group of 8
+    (1, 16, 8, 128, 1, 130, 1),     # group of 2, barely more than a range
+    (1, 32, 32, 128, 1, 100, 1),    # unsplit: one workgroup per head, a partial last step
+    (1, 32, 32, 128, 1, 5, 1),      # fewer keys than one step of the workgroup
+    (2, 8, 8, 96, 3, 1000, 1),      # head size 96 (lanes 12..15 idle), three query rows, batch 2
+    (1, 8, 2, 80, 2, 300, 1),       # head size 80
+    (1, 16, 16, 128, 3, 1500, 3),   # ALiBi + causal
+    (1, 8, 8, 128, 1, 640, 0),      # unmasked
+    (1, 48, 1, 128, 1, 1500, 1),    # 48 query heads on one kv head: six workgroups of 8 heads per range
+    (1, 32, 32, 128, 1, 9000, 1),   # long context: 8 ranges x 71 steps through an 8-step ring
+]
+
+
+@pytest.mark.parametrize("bs,hn,hkv,hs,sl_q,sl_kv,flags", STREAM_CASES)
+def test_decode_kv_through_lds_rings_and_through_registers(L, pkg, nso, bs, hn, hkv, hs, sl_q, sl_kv, flags):
+    """attn_stream_kernel (K / V HBM -> LDS by DMA into per-wave rings; ns_hip_set_tuning("attn_stream", 1), the default for head sizes
+    72 .. 128) and attn_split_kernel (through registers; 0): each against the oracle, and against each other at fp32 rounding — the two
+    split a context differently, so their sums associate differently."""
+    import torch
+    rng = np.random.default_rng(hs + sl_kv)
+    q = rng.standard_normal((bs, sl_q, hn, hs)).astype(np.float32)
+    k = rng.standard_normal((bs, sl_kv, hkv, hs)).astype(np.float16)
+    v = rng.standard_normal((bs, sl_kv, hkv, hs)).astype(np.float16)
+    scale = float(1.0 / np.sqrt(hs))
+    ref = nso.attn_ref(q, k, v, scale, flags)
+    dq, dk, dv = torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            assert L.ns_hip_set_tuning(b"attn_stream", mode) == 0
+            dd = torch.full_like(dq, 7.0)
+            dd16 = torch.zeros(dq.shape, dtype=torch.float16, device="cuda")
+            a = pkg.attn_args(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dd.data_ptr(), bs, hn, hkv, hs, sl_q, sl_kv, scale, flags)
+            pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(C.byref(a), dd16.data_ptr(), st))
+            torch.cuda.synchronize()
+            outs[mode] = dd.cpu().numpy()
+            assert np.all(np.isfinite(outs[mode]))
+            assert nso.rel_l2(outs[mode], ref) < TOL, mode
+            assert np.array_equal(dd16.cpu().numpy(), outs[mode].astype(np.float16)), mode  # the fp16 shadow is the rounded output
+    finally:
+        L.ns_hip_set_tuning(b"attn_stream", 1)
+    assert nso.rel_l2(outs[1], outs[0]) < 2e-6
+
+
+def test_ring_kernel_inside_a_graph_with_the_merge_in_the_launch(L, pkg, nso):
+    """The LDS-ring kernel with the callers' workspace contract, captured, replayed at the same context — and with the last range merging inside
+    the launch (attn_inlaunch): the same bits as with the merge launch."""
+    import torch
+    bs, hn, hkv, hs, sl_kv = 1, 32, 8, 128, 1200
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((bs, 1, hn, hs)).astype(np.float32)
+    k = rng.standard_normal((bs, sl_kv, hkv, hs)).astype(np.float16)
+    v = rng.standard_normal((bs, sl_kv, hkv, hs)).astype(np.float16)
+    scale = float(1.0 / np.sqrt(hs))
+    ref = nso.attn_ref(q, k, v, scale, 1)
+    dq, dk, dv = torch.from_numpy(q).cuda(), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+    shape = pkg.AttnShape(bs, hn, hkv, hs, 1, sl_kv)
+    ws = torch.empty(L.bestla_fusion_attn_workspace_size(C.byref(shape)), dtype=torch.uint8, device="cuda")
+    res = {}
+    try:
+        for inl in (0, 1):
+            L.ns_hip_set_tuning(b"attn_inlaunch", inl)
+            dd = torch.zeros_like(dq)
+            a = pkg.attn_args(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dd.data_ptr(), bs, hn, hkv, hs, 1, sl_kv, scale, 1)
+            a.tmp = ws.data_ptr()
+            pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))  # (allocates the tickets outside the capture)
+            torch.cuda.synchronize()
+            dd.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                pkg.check(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            res[inl] = dd.cpu().numpy()
+            assert nso.rel_l2(res[inl], ref) < TOL
+    finally:
+        L.ns_hip_set_tuning(b"attn_inlaunch", 0)
+    assert np.array_equal(res[0], res[1])
