@@ -241,7 +241,10 @@ int ns_hip_set_tuning(const char* key, int value);
  * queue bestla_create_device made are recorded; two consecutive tokens whose launch sequences differ only in one moving value per launch
  * (RoPE position, kv-cache cell, context length) make a plan of HIP-graph segments; later tokens are compared launch by launch and each
  * segment is replayed once its last launch has matched - a token that deviates falls back to plain launches without side effects.
- * ns_hip_route_set_enabled(0 / 1) (environment NS_DEVICE_REPLAY) returns the previous setting; ns_hip_route_stats: [0] tokens replayed,
+ * ns_hip_route_set_enabled(0 / 1) (environment NS_DEVICE_REPLAY) returns the previous setting.  A plan CARRIES the RMS norms (ns_norm_link below:
+ * rms_norm + mul(gamma) in front of a mul_mat launch are not launched, the launch that made the normed tensor writes fp16(gamma . x) and the sums
+ * of squares; 7B-shaped model 400 -> 451 tok/s) unless NS_ROUTE_LINKS=0 or ns_hip_route_set_enabled(5) say otherwise ((3) forces it on); the range note of
+ * ns_norm_link applies.  ns_hip_route_stats: [0] tokens replayed,
  * [1] tokens launched eagerly, [2] plans built, [3] fall-backs, [4] the reference's launches per token in the last plan, [5] the launches its graphs hold for them (runs of
  * single operators become the library's fused launches at capture time),
  * [6] plans that could not be captured, [7] 1 while a plan is held. */

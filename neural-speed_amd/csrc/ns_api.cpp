@@ -708,6 +708,7 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
 
 namespace ns {
 void set_error(const std::string& s) { g_err = s; }
+bool route_link_weight_ok(const ns_weight* w) { return w && !w->shuf && !w->load_failed && !ref_int8_for(w) && w->kind != WK_F8 && smallm_supported(w, 1); }
 }  // namespace ns
 
 extern "C" {

@@ -283,6 +283,11 @@ struct Affine {
   long long delta2 = 0;  // launch_dup2: the second copy's destination
 };
 extern thread_local Affine g_affine;
+// ... and the device-layout attention may be asked for an fp16 copy of its output row beside the fp32 one (the carried norm of the route's
+// attention-output projection needs the fp16 shadow of its activations): set around the captured call, nullptr otherwise
+extern thread_local void* g_mha_out16;
+// ns_api.cpp: may this weight's decode launch carry an RMS norm (ns_norm_link)?  (what link_ok() refuses, without setting an error)
+bool route_link_weight_ok(const ns_weight* w);
 // ns_route.cpp: one launch of the reference's device route as plain data (compared bytewise: zero-initialise before filling)
 enum RouteKind : uint32_t { RK_GEMM = 1, RK_ADD, RK_MUL, RK_SILU, RK_RMSNORM, RK_ROPE, RK_ROPE_YARN, RK_DUP, RK_MHA };
 struct RouteOp {

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void mha_f32_split_kernel(const float* q, cons
   }
 }
 // one workgroup of head_size threads per (query row, head): combine the ranges' (max, sum, output) in range order
-__global__ void mha_f32_merge_kernel(const float* ws, float* o, int nsplit, int hs, int seq_all, const int* __restrict__ kmove, int kdelta) {
+__global__ void mha_f32_merge_kernel(const float* ws, float* o, int nsplit, int hs, int seq_all, const int* __restrict__ kmove, int kdelta, _Float16* o16) {
   const size_t row = blockIdx.x;  // (batch * seq + iq) * heads + head
   const int t = threadIdx.x;
   const float* wp = ws + row * nsplit * (2 + hs);
@@ -261,7 +261,9 @@ __global__ void mha_f32_merge_kernel(const float* ws, float* o, int nsplit, int 
     lb += wp[size_t(s2) * (2 + hs) + 1] * c;
     if (ms != -INFINITY) ab += wp[size_t(s2) * (2 + hs) + 2 + t] * c;  // (an empty range wrote no output columns)
   }
-  o[row * hs + t] = ab / lb;
+  const float y = ab / lb;
+  o[row * hs + t] = y;
+  if (o16) o16[row * hs + t] = (_Float16)y;  // (replayed route: the projection behind it streams fp16 activations)
 }
 
 // what bestla_device_load_storage leaves in the tensor object behind a device-resident BTLA weight
@@ -712,7 +714,7 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
           hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta));
         if (ns_c > 1 || aff.k)
           hipLaunchKernelGGL(ns::mha_f32_merge_kernel, dim3(unsigned(size_t(batch) * nr * heads)), dim3(unsigned(head_size)), 0, st, ws, o_c, ns_c, head_size,
-                             sa, aff.k, int(aff.delta));
+                             sa, aff.k, int(aff.delta), (aff.k && seq == 1) ? static_cast<_Float16*>(ns::g_mha_out16) : nullptr);
       }
       if (hipGetLastError() != hipSuccess) {
         ns::set_error("mha_f32: launch failed");

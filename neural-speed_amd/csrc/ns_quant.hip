@@ -1037,6 +1037,7 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
 }
 
 thread_local Affine g_affine;
+thread_local void* g_mha_out16 = nullptr;
 
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st, float ext_factor,

@@ -69,10 +69,26 @@ struct Segment {
 //   XK_GEMM_ADD mul_mat whose only reader is the residual add           -> the GEMV's Add epilogue         (bestla_common.hpp:121-147)
 //   XK_GATEUP   mul_mat(w1), silu, mul_mat(w3), mul                     -> ns_hip_fusion_ffn3_gateup      (ip_fusion_ffn.cpp:364-406)
 // The intermediate tensors a fused launch does not write (the raw mul_mat results) are checked to have no other reader in the token.
+//   carried RMS norms (round 5, ns_norm_link; llama.cpp:178-184, :385-391): rms_norm + mul(gamma) in front of a QKV / gate-up / mul_mat launch
+//   whose input tensor came out of a XK_GEMM_ADD launch are not launched at all — that producer also writes fp16(gamma . x) and the tiles'
+//   sums of squares, the consumer streams them and divides its dot products by rms(x).  The producer needs the fp16 shadow of ITS input:
+//   the attention's merge kernel and the gate/up launch write one when asked (ExecOp::o16).
 enum ExecKind : uint32_t { XK_OP = 0, XK_QKV, XK_ROPE2, XK_DUP2, XK_GEMM_ADD, XK_GATEUP, XK_ROPE_APPEND };
+constexpr int kXIdx = 6;
 struct ExecOp {
   uint32_t xk;
-  int idx[4];  // the plan ops it stands for (-1: unused); XK_OP: idx[0]
+  int idx[kXIdx];    // the plan ops it stands for (-1: unused); XK_OP: idx[0]; a carried norm's rms_norm / mul ride in idx[4], idx[5] of its consumer
+  int in_link = -1;  // consumes Route::links[in_link] (its activations are that link's shadow)
+  int out_link = -1; // XK_GEMM_ADD: produces Route::links[out_link]
+  int a16 = -1;      // XK_GEMM_ADD: fp16 shadow of its input = Route::shadows[a16]
+  int o16 = -1;      // attention / XK_GATEUP: also writes the fp16 shadow Route::shadows[o16] of its output
+};
+inline ExecOp xop(uint32_t xk, int a, int b = -1, int c = -1, int d = -1) { return ExecOp{xk, {a, b, c, d, -1, -1}}; }
+struct NormLink {
+  const float* gamma;
+  float eps;
+  int n, stride;           // norm size; floats per row of the sums (a multiple of 4 >= ceil(n / 16))
+  size_t h_off, s_off;     // fp16(gamma . x) and the tile sums inside Route::link_mem
 };
 struct Route {
   hipStream_t st = nullptr;
@@ -100,6 +116,10 @@ struct Route {
   double gpu_ms_sum = 0.0, host_us_sum = 0.0;
   long long gpu_tokens = 0;
   long long t_first_us = 0;
+  std::vector<NormLink> links;     // carried norms of the plan
+  std::vector<size_t> shadows;     // fp16 shadows (offsets into link_mem)
+  char* link_mem = nullptr;        // device memory behind both
+  int links_enabled = -1;  // carried norms: -1 = NS_ROUTE_LINKS not read yet
   int failures = 0;  // plans that could not be captured: after a few the layer turns itself off
   uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tokens replayed, tokens eager, plans built, bail-outs, ops per token, captured launches per token, capture failures, -
 };
@@ -135,6 +155,9 @@ void drop_plan() {
     if (s.exec) (void)hipGraphExecDestroy(s.exec);
   R.segs.clear();
   R.xops.clear();
+  R.links.clear();
+  R.shadows.clear();
+  if (R.link_mem) (void)hipFree(R.link_mem), R.link_mem = nullptr;
   R.plan.clear();
   R.have_plan = false;
   R.pos = R.seg = 0;
@@ -283,15 +306,15 @@ std::vector<ExecOp> optimize(const std::vector<PlanOp>& plan) {
         const bool append = rope2 && !no_append && rk.kind == RK_ROPE && rk.f[2] == 0.f && dk.i[0] == rk.i[3] && dk.i[1] == 1 && dk.i[2] == rk.i[2] &&
                             dk.i[3] == 1 && dk.i[4] == 4 && dk.i[6] == rk.i[3] * 4 && dk.i[12] == 0 && dvv.i[12] == 0;
         if (qkv) {
-          x.push_back(ExecOp{XK_QKV, {g[0], g[1], g[2], -1}});
+          x.push_back(xop(XK_QKV, g[0], g[1], g[2], -1));
           if (append) {
-            x.push_back(ExecOp{XK_ROPE_APPEND, {q_first ? j + 6 : j + 1, q_first ? j + 1 : j + 6, j + 2, j + 4}});
+            x.push_back(xop(XK_ROPE_APPEND, q_first ? j + 6 : j + 1, q_first ? j + 1 : j + 6, j + 2, j + 4));
             for (int t = j; t <= j + 6; t++) used[t] = 1;
             continue;
           }
-          if (rope2) x.push_back(ExecOp{XK_ROPE2, {q_first ? j + 6 : j + 1, q_first ? j + 1 : j + 6, -1, -1}});
-          else x.push_back(ExecOp{XK_OP, {j + 1, -1, -1, -1}}), x.push_back(ExecOp{XK_OP, {j + 6, -1, -1, -1}});
-          x.push_back(ExecOp{XK_DUP2, {j + 2, j + 4, -1, -1}});
+          if (rope2) x.push_back(xop(XK_ROPE2, q_first ? j + 6 : j + 1, q_first ? j + 1 : j + 6, -1, -1));
+          else x.push_back(xop(XK_OP, j + 1, -1, -1, -1)), x.push_back(xop(XK_OP, j + 6, -1, -1, -1));
+          x.push_back(xop(XK_DUP2, j + 2, j + 4, -1, -1));
           for (int t = j; t <= j + 6; t++) used[t] = 1;
           continue;
         }
@@ -305,7 +328,7 @@ std::vector<ExecOp> optimize(const std::vector<PlanOp>& plan) {
         const bool operands = (mu.p[0] == s && mu.p[1] == t3) || (mu.p[0] == t3 && mu.p[1] == s);
         if (operands && packed_vec(mu.i, mu.i + 4, o.i[1]) && packed_vec(mu.i + 8, mu.i + 12, o.i[1]) && mu.i[16] == 4 && mu.p[2] != s && mu.p[2] != t3 &&
             !read_later(plan, o.p[2], j + 2, -1) && !read_later(plan, t3, j + 4, -1)) {
-          x.push_back(ExecOp{XK_GATEUP, {j, j + 1, j + 2, j + 3}});
+          x.push_back(xop(XK_GATEUP, j, j + 1, j + 2, j + 3));
           for (int t = j; t <= j + 3; t++) used[t] = 1;
           continue;
         }
@@ -316,16 +339,122 @@ std::vector<ExecOp> optimize(const std::vector<PlanOp>& plan) {
         const bool first = ad.p[0] == o.p[2], second = ad.p[1] == o.p[2];
         if ((first != second) && packed_vec(ad.i, ad.i + 4, o.i[1]) && packed_vec(ad.i + 8, ad.i + 12, o.i[1]) && ad.i[16] == 4 && ad.p[2] != o.p[2] &&
             !read_later(plan, o.p[2], j + 2, -1)) {
-          x.push_back(ExecOp{XK_GEMM_ADD, {j, j + 1, -1, -1}});
+          x.push_back(xop(XK_GEMM_ADD, j, j + 1, -1, -1));
           used[j] = used[j + 1] = 1;
           continue;
         }
       }
     }
-    x.push_back(ExecOp{XK_OP, {j, -1, -1, -1}});
+    x.push_back(xop(XK_OP, j, -1, -1, -1));
     used[j] = 1;
   }
   return x;
+}
+
+// tensor `ptr` from plan op `from` on, until somebody rewrites it: read by exactly the ops in `allowed` (all of them) and nobody else?
+bool only_read_by(const std::vector<PlanOp>& plan, const void* ptr, size_t from, const int* allowed, int nallowed) {
+  int seen = 0;
+  for (size_t j = from; j < plan.size(); j++) {
+    if (is_input_of(plan[j].op, ptr)) {
+      bool ok = false;
+      for (int a = 0; a < nallowed; a++) ok = ok || allowed[a] == int(j);
+      if (!ok) return false;
+      seen++;
+    }
+    if (output_of(plan[j].op) == ptr) break;
+  }
+  return seen == nallowed;
+}
+bool route_debug();
+// On by default (NS_ROUTE_LINKS=0 or ns_hip_route_set_enabled(5) turn it off, (3) forces it on).  7B-shaped model, n_ctx 512, same box, alternating
+// (profiles/r05r_route_carried_norms.txt): 323 -> 195 captured launches, GPU span per token 2009 / 1989 -> 1731 / 1737 us, 399 / 400 -> 451 / 452 tok/s.
+// The carried form holds gamma . x un-normalised in fp16 (range note at ns_norm_link): an overflow shows as inf / nan, never as a wrong finite value.
+bool links_on() {
+  if (R.links_enabled < 0) R.links_enabled = getenv("NS_ROUTE_LINKS") && atoi(getenv("NS_ROUTE_LINKS")) == 0 ? 0 : 1;
+  return R.links_enabled != 0;
+}
+// carried RMS norms (see ExecKind): rms_norm, mul(gamma), consumer launch -> the consumer alone, if the normed tensor came out of a residual
+// add that a XK_GEMM_ADD launch makes and that launch can be given the fp16 shadow of its own input.  `bytes`: device memory asked for.
+void link_norms(std::vector<ExecOp>& x, const std::vector<PlanOp>& plan, std::vector<NormLink>& links, std::vector<size_t>& shadows, size_t* bytes) {
+  auto O = [&](int j) -> const RouteOp& { return plan[j].op; };
+  auto Wt = [](const void* p) { return static_cast<const ns_weight*>(p); };
+  auto take = [&](size_t nbytes) {
+    const size_t off = *bytes;
+    *bytes += (nbytes + 255) / 256 * 256;
+    return off;
+  };
+  std::vector<char> dead(x.size(), 0);
+  auto why = [&](int jn, const char* reason) {
+    if (route_debug()) fprintf(stderr, "route: the norm at launch %d stays a launch: %s\n", jn, reason);
+  };
+  for (size_t e = 0; e + 2 < x.size(); e++) {
+    if (x[e].xk != XK_OP || x[e + 1].xk != XK_OP) continue;
+    const int jn = x[e].idx[0], jm = x[e + 1].idx[0];
+    const RouteOp &no = O(jn), &mu = O(jm);
+    if (no.kind != RK_RMSNORM || mu.kind != RK_MUL || no.i[0] != 1 || jm != jn + 1) continue;
+    const long long n = no.i[1];
+    const void *X = no.p[0], *N = no.p[1], *N2 = mu.p[2];
+    const bool first = mu.p[0] == N, second = mu.p[1] == N;
+    if (first == second || N2 == X) { why(jn, "the mul does not multiply its result by a vector"); continue; }
+    const float* gamma = static_cast<const float*>(first ? mu.p[1] : mu.p[0]);
+    if (!packed_vec(mu.i, mu.i + 4, n) || !packed_vec(mu.i + 8, mu.i + 12, n) || mu.i[16] != 4) { why(jn, "gamma is not a dense vector of the norm's size"); continue; }
+    // ---- the consumer: every mul_mat of it reads the normed tensor, one row, K = the norm's size ----
+    ExecOp& c = x[e + 2];
+    int gi[3] = {-1, -1, -1}, ng = 0;
+    if (c.xk == XK_QKV) gi[0] = c.idx[0], gi[1] = c.idx[1], gi[2] = c.idx[2], ng = 3;
+    else if (c.xk == XK_GATEUP) gi[0] = c.idx[0], gi[1] = c.idx[2], ng = 2;
+    else if (c.xk == XK_GEMM_ADD) gi[0] = c.idx[0], ng = 1;
+    else if (c.xk == XK_OP && O(c.idx[0]).kind == RK_GEMM) gi[0] = c.idx[0], ng = 1;
+    else { why(jn, "what follows is not a mul_mat launch"); continue; }
+    bool ok = c.in_link < 0;
+    for (int g = 0; g < ng && ok; g++) {
+      const RouteOp& go = O(gi[g]);
+      ok = go.p[0] == N2 && go.i[0] == 1 && go.i[2] == n && route_link_weight_ok(Wt(go.p[1]));
+    }
+    if (!ok) { why(jn, "the consumer's mul_mat do not all read the normed row (one row, K = norm size, a weight the decode kernel carries norms for)"); continue; }
+    if (!only_read_by(plan, N, size_t(jn) + 1, &jm, 1) || !only_read_by(plan, N2, size_t(jm) + 1, gi, ng)) { why(jn, "the normed tensors have other readers"); continue; }
+    // ---- the producer: the launch whose residual add wrote the tensor that is normed ----
+    int P = -1;
+    for (int q = int(e) - 1; q >= 0 && P < 0; q--)
+      if (x[q].xk == XK_GEMM_ADD && O(x[q].idx[1]).p[2] == X) P = q;
+    if (P < 0 || x[P].out_link >= 0) { why(jn, "its input is not the result of a mul_mat + add launch"); continue; }
+    const RouteOp& pg = O(x[P].idx[0]);
+    if (pg.i[1] != n || pg.i[0] != 1 || !route_link_weight_ok(Wt(pg.p[1]))) { why(jn, "the producing mul_mat cannot carry a norm"); continue; }
+    // ... needs its own activations as fp16: from the attention's merge or from the gate/up launch (itself on fp16 activations)
+    int sh = x[P].a16;
+    if (sh < 0) {
+      int Q = -1;
+      for (int q = P - 1; q >= 0 && Q < 0; q--) {
+        if (x[q].xk == XK_OP && O(x[q].idx[0]).kind == RK_MHA && O(x[q].idx[0]).p[3] == pg.p[0]) Q = q;
+        else if (x[q].xk == XK_GATEUP && O(x[q].idx[3]).p[2] == pg.p[0]) Q = q;
+      }
+      if (Q < 0) { why(jn, "no launch can hand the producer its activations as fp16"); continue; }
+      if (x[Q].xk == XK_OP) {
+        const RouteOp& mh = O(x[Q].idx[0]);
+        if (mh.i[0] != 1 || mh.i[1] != 1 || mh.i[3] * mh.i[5] != pg.i[2] || !(mh.i[5] == 64 || mh.i[5] == 128 || mh.i[5] == 256)) { why(jn, "the attention in front of the producer is not a one-row decode step"); continue; }
+      } else if (x[Q].in_link < 0 || O(x[Q].idx[0]).i[1] != pg.i[2]) {
+        why(jn, "the gate/up launch in front of the producer is not on fp16 activations itself");
+        continue;
+      }
+      if (x[Q].o16 < 0) {
+        shadows.push_back(take(size_t(pg.i[2]) * 2));
+        x[Q].o16 = int(shadows.size()) - 1;
+      }
+      sh = x[Q].o16;
+    }
+    NormLink L;
+    L.gamma = gamma, L.eps = no.f[0], L.n = int(n), L.stride = (int((n + 15) / 16) + 3) & ~3;
+    L.h_off = take(size_t(n) * 2), L.s_off = take(size_t(L.stride) * 4);
+    links.push_back(L);
+    const int li = int(links.size()) - 1;
+    x[P].out_link = li, x[P].a16 = sh;
+    c.in_link = li, c.idx[4] = jn, c.idx[5] = jm;
+    dead[e] = dead[e + 1] = 1;
+  }
+  size_t o = 0;
+  for (size_t e = 0; e < x.size(); e++)
+    if (!dead[e]) x[o++] = x[e];
+  x.resize(o);
 }
 
 // one captured launch (inside a stream capture; the device counter moves what moves)
@@ -341,11 +470,22 @@ int capture_xop(const ExecOp& xo, const std::vector<PlanOp>& plan, const int* kd
   auto F = [](const void* p) { return static_cast<const float*>(p); };
   auto M = [](const void* p) { return static_cast<float*>(const_cast<void*>(p)); };
   auto W = [](const void* p) { return static_cast<const ns_weight*>(p); };
+  auto in_link = [&](int li) {  // the consumer side of a carried norm
+    const NormLink& L = R.links[li];
+    ns_norm_link lk{};
+    lk.in_ssq = reinterpret_cast<const float*>(R.link_mem + L.s_off), lk.in_parts = (L.n + 15) / 16, lk.in_stride = L.stride, lk.eps = L.eps, lk.norm_size = L.n;
+    return lk;
+  };
   if (xo.xk != XK_OP && ns_hip_lazy_flush() != 0) return -1;
   switch (xo.xk) {
     case XK_QKV: {
       const RouteOp &a = P(0).op, &b = P(1).op, &c = P(2).op;
       const long long ldc = (static_cast<const char*>(b.p[2]) - static_cast<const char*>(a.p[2])) / 4;
+      if (xo.in_link >= 0) {
+        const ns_norm_link lk = in_link(xo.in_link);
+        return ns_hip_fusion_qkv_forward_x(F(a.p[0]), R.link_mem + R.links[xo.in_link].h_off, W(a.p[1]), W(b.p[1]), W(c.p[1]), M(a.p[2]), nullptr, 1, int(a.i[3]),
+                                           int(ldc), &lk, st);
+      }
       return ns_hip_fusion_qkv_forward(F(a.p[0]), W(a.p[1]), W(b.p[1]), W(c.p[1]), M(a.p[2]), 1, int(a.i[3]), int(ldc), st);
     }
     case XK_ROPE2: {
@@ -384,17 +524,40 @@ int capture_xop(const ExecOp& xo, const std::vector<PlanOp>& plan, const int* kd
     case XK_GEMM_ADD: {
       const RouteOp &g = P(0).op, &ad = P(1).op;
       const void* other = ad.p[0] == g.p[2] ? ad.p[1] : ad.p[0];
+      if (xo.in_link >= 0 || xo.out_link >= 0) {
+        ns_norm_link lk = xo.in_link >= 0 ? in_link(xo.in_link) : ns_norm_link{};
+        void* c16 = nullptr;
+        if (xo.out_link >= 0) {
+          const NormLink& L = R.links[xo.out_link];
+          lk.out_gamma = L.gamma, lk.out_ssq = reinterpret_cast<float*>(R.link_mem + L.s_off), lk.out_stride = L.stride;
+          c16 = R.link_mem + L.h_off;
+        }
+        const void* a16 = xo.in_link >= 0 ? R.link_mem + R.links[xo.in_link].h_off : (xo.a16 >= 0 ? R.link_mem + R.shadows[xo.a16] : nullptr);
+        return ns_hip_f32f32_forward_x(F(g.p[0]), a16, W(g.p[1]), M(ad.p[2]), c16, 1, int(g.i[3]), int(g.i[1]), NS_EPI_ADD, F(other), int(g.i[1]), &lk, st);
+      }
       return ns_hip_f32f32_forward(F(g.p[0]), W(g.p[1]), M(ad.p[2]), 1, int(g.i[3]), int(g.i[1]), NS_EPI_ADD, F(other), int(g.i[1]), st);
     }
     case XK_GATEUP: {
       const RouteOp &g1 = P(0).op, &si = P(1).op, &g3 = P(2).op, &mu = P(3).op;
+      if (xo.in_link >= 0) {
+        const ns_norm_link lk = in_link(xo.in_link);
+        return ns_hip_fusion_ffn3_gateup_x(F(g1.p[0]), R.link_mem + R.links[xo.in_link].h_off, W(g1.p[1]), W(g3.p[1]), M(si.p[1]), M(mu.p[2]),
+                                           xo.o16 >= 0 ? R.link_mem + R.shadows[xo.o16] : nullptr, 1, NS_EPI_SILU, &lk, st);
+      }
       return ns_hip_fusion_ffn3_gateup(F(g1.p[0]), W(g1.p[1]), W(g3.p[1]), M(si.p[1]), M(mu.p[2]), 1, NS_EPI_SILU, st);
     }
     default: {
       const PlanOp& po = P(0);
+      if (xo.in_link >= 0 && po.op.kind == RK_GEMM) {  // (the model's last norm in front of the output projection)
+        const ns_norm_link lk = in_link(xo.in_link);
+        return ns_hip_f32f32_forward_x(F(po.op.p[0]), R.link_mem + R.links[xo.in_link].h_off, W(po.op.p[1]), M(po.op.p[2]), nullptr, int(po.op.i[0]), int(po.op.i[3]),
+                                       int(po.op.i[4]), NS_EPI_NONE, nullptr, 0, &lk, st);
+      }
       t_in_exec = false;  // (execute() guards itself)
       if (po.moving) g_affine = Affine{kdev, po.delta, 0};
+      if (xo.o16 >= 0 && po.op.kind == RK_MHA) g_mha_out16 = R.link_mem + R.shadows[xo.o16];
       const int rc = execute(po.op, st);
+      g_mha_out16 = nullptr;
       return rc;
     }
   }
@@ -482,48 +645,73 @@ bool make_plan() {
     }
   // the launches (fused where possible), then segments of about seg_ops() of them.  A segment may end only where the launches so far
   // stand for a PREFIX of the reference's launches (fusion reorders inside a layer), and never on a node the lazy peephole only records
-  std::vector<ExecOp> xops = optimize(plan);
+  std::vector<ExecOp> xops;
   std::vector<Segment> segs;
-  {
-    std::vector<char> covered(n, 0);
-    int ncov = 0, maxcov = -1, xbeg = 0, obeg = 0;
-    for (int e = 0; e < int(xops.size()); e++) {
-      for (int q = 0; q < 4; q++)
-        if (xops[e].idx[q] >= 0 && !covered[xops[e].idx[q]]) covered[xops[e].idx[q]] = 1, ncov++, maxcov = std::max(maxcov, xops[e].idx[q]);
-      const bool prefix = ncov == maxcov + 1;
-      const uint32_t lastk = xops[e].xk == XK_OP ? plan[xops[e].idx[0]].op.kind : 0u;
-      const bool enough = e + 1 - xbeg >= seg_ops() && int(xops.size()) - (e + 1) >= seg_ops() / 3;
-      if (e + 1 == int(xops.size()) || (prefix && enough && lastk != RK_RMSNORM && lastk != RK_SILU)) {
-        segs.push_back(Segment{obeg, maxcov + 1, xbeg, e + 1, nullptr});
-        xbeg = e + 1, obeg = maxcov + 1;
+  // one attempt: the launches, their segments, the captures.  With carried norms first; should their captures be refused (a weight or shape the
+  // decode kernel does not carry a norm for), once more without them
+  auto attempt = [&](bool with_links) {
+    xops = optimize(plan);
+    segs.clear();
+    R.links.clear(), R.shadows.clear();
+    if (R.link_mem) (void)hipFree(R.link_mem), R.link_mem = nullptr;
+    if (with_links) {
+      size_t bytes = 0;
+      const size_t before = xops.size();
+      link_norms(xops, plan, R.links, R.shadows, &bytes);
+      if (route_debug()) fprintf(stderr, "route: %zu carried norms, %zu fp16 shadows, %zu -> %zu launches, %zu bytes\n", R.links.size(), R.shadows.size(), before, xops.size(), bytes);
+      if (bytes && hipMalloc(reinterpret_cast<void**>(&R.link_mem), bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
       }
     }
-    if (ncov != int(n)) return false;  // (cannot happen: every op is in exactly one launch)
-  }
-  bool ok = true;
-  for (size_t s = 0; s < segs.size() && ok; s++) {
-    hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(R.st, hipStreamCaptureModeRelaxed) != hipSuccess) {
-      ok = false;
-      break;
-    }
-    if (s == 0) hipLaunchKernelGGL(route_count_kernel, dim3(1), dim3(1), 0, R.st, R.kdev);
-    for (int e = segs[s].xbeg; e < segs[s].xend && ok; e++) ok = capture_xop(xops[e], plan, R.kdev, R.st) == 0;
     {
-      t_in_exec = true;
-      ok = ns_hip_lazy_flush() == 0 && ok;
-      t_in_exec = false;
+      std::vector<char> covered(n, 0);
+      int ncov = 0, maxcov = -1, xbeg = 0, obeg = 0;
+      for (int e = 0; e < int(xops.size()); e++) {
+        for (int q = 0; q < kXIdx; q++)
+          if (xops[e].idx[q] >= 0 && !covered[xops[e].idx[q]]) covered[xops[e].idx[q]] = 1, ncov++, maxcov = std::max(maxcov, xops[e].idx[q]);
+        const bool prefix = ncov == maxcov + 1;
+        const uint32_t lastk = xops[e].xk == XK_OP ? plan[xops[e].idx[0]].op.kind : 0u;
+        const bool enough = e + 1 - xbeg >= seg_ops() && int(xops.size()) - (e + 1) >= seg_ops() / 3;
+        if (e + 1 == int(xops.size()) || (prefix && enough && lastk != RK_RMSNORM && lastk != RK_SILU)) {
+          segs.push_back(Segment{obeg, maxcov + 1, xbeg, e + 1, nullptr});
+          xbeg = e + 1, obeg = maxcov + 1;
+        }
+      }
+      if (ncov != int(n)) return false;  // (cannot happen: every op is in exactly one launch)
     }
-    const hipError_t ec = hipStreamEndCapture(R.st, &graph);
-    ok = ok && ec == hipSuccess && graph != nullptr;
-    if (ok) ok = hipGraphInstantiate(&segs[s].exec, graph, nullptr, nullptr, 0) == hipSuccess;
-    if (graph) (void)hipGraphDestroy(graph);
-  }
-  if (!ok) {
-    (void)hipGetLastError();
-    ns_hip_reset_error();
-    for (Segment& s : segs)
-      if (s.exec) (void)hipGraphExecDestroy(s.exec);
+    bool ok = true;
+    for (size_t sg = 0; sg < segs.size() && ok; sg++) {
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(R.st, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        ok = false;
+        break;
+      }
+      if (sg == 0) hipLaunchKernelGGL(route_count_kernel, dim3(1), dim3(1), 0, R.st, R.kdev);
+      for (int e = segs[sg].xbeg; e < segs[sg].xend && ok; e++) ok = capture_xop(xops[e], plan, R.kdev, R.st) == 0;
+      {
+        t_in_exec = true;
+        ok = ns_hip_lazy_flush() == 0 && ok;
+        t_in_exec = false;
+      }
+      const hipError_t ec = hipStreamEndCapture(R.st, &graph);
+      ok = ok && ec == hipSuccess && graph != nullptr;
+      if (ok) ok = hipGraphInstantiate(&segs[sg].exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+    }
+    if (!ok) {
+      if (route_debug()) fprintf(stderr, "route: capture %s failed: %s\n", with_links ? "with carried norms" : "", ns_hip_last_error());
+      (void)hipGetLastError();
+      ns_hip_reset_error();
+      for (Segment& sg : segs)
+        if (sg.exec) (void)hipGraphExecDestroy(sg.exec), sg.exec = nullptr;
+    }
+    return ok;
+  };
+  const bool try_links = fuse_on() && links_on();
+  if (!(try_links && attempt(true)) && !attempt(false)) {
+    R.links.clear(), R.shadows.clear();
+    if (R.link_mem) (void)hipFree(R.link_mem), R.link_mem = nullptr;
     R.stats[6]++;
     if (++R.failures >= 3) R.enabled = 0;  // this process's graphs cannot be captured: stay eager
     return false;
@@ -672,6 +860,7 @@ extern "C" int ns_hip_route_set_enabled(int on) {
   const int prev = ns::enabled() ? 1 : 0;
   if (!on) ns::route_invalidate();
   ns::R.enabled = on ? 1 : 0;
+  if (on) ns::R.links_enabled = (on & 2) ? 1 : (on & 4) ? 0 : -1;  // 3: with carried norms, 5: without, 1: NS_ROUTE_LINKS (default on)
   ns::R.failures = 0;
   return prev;
 }
