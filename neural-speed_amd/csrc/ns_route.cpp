@@ -139,6 +139,14 @@ int seg_ops() {
   static const int v = getenv("NS_ROUTE_SEG") ? atoi(getenv("NS_ROUTE_SEG")) : 64;
   return v > 0 ? v : 64;
 }
+// the FIRST segment is shorter: the GPU starts on a token when the reference's executor has handed over its first 16 launches, not its
+// first third (with the norms carried 64 launches are ~210 of the reference's nodes) — NS_ROUTE_SEG0, launches.  Worth little
+// (profiles/r05r_route_carried_norms.txt: 64 / 16 / 6 -> 429 / 436 / 434 tok/s at n_ctx 2048, 451 / 454 / 436 at 512): what precedes a token's
+// first launch is the reference building its graph, not this comparison loop.
+int seg0_ops() {
+  static const int v = getenv("NS_ROUTE_SEG0") ? atoi(getenv("NS_ROUTE_SEG0")) : 16;
+  return v > 0 ? v : 16;
+}
 // the one integer field of a kind that may move from token to token (index into RouteOp::i), -1: none
 int moving_int(uint32_t kind) {
   switch (kind) {
@@ -672,7 +680,7 @@ bool make_plan() {
           if (xops[e].idx[q] >= 0 && !covered[xops[e].idx[q]]) covered[xops[e].idx[q]] = 1, ncov++, maxcov = std::max(maxcov, xops[e].idx[q]);
         const bool prefix = ncov == maxcov + 1;
         const uint32_t lastk = xops[e].xk == XK_OP ? plan[xops[e].idx[0]].op.kind : 0u;
-        const bool enough = e + 1 - xbeg >= seg_ops() && int(xops.size()) - (e + 1) >= seg_ops() / 3;
+        const bool enough = e + 1 - xbeg >= (segs.empty() ? seg0_ops() : seg_ops()) && int(xops.size()) - (e + 1) >= seg_ops() / 3;
         if (e + 1 == int(xops.size()) || (prefix && enough && lastk != RK_RMSNORM && lastk != RK_SILU)) {
           segs.push_back(Segment{obeg, maxcov + 1, xbeg, e + 1, nullptr});
           xbeg = e + 1, obeg = maxcov + 1;
