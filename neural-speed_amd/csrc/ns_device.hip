@@ -131,11 +131,19 @@ __global__ __launch_bounds__(256) void mha_f32_kernel(const float* q, const floa
 // TRANSPOSED V (8 consecutive per lane).  Partials (max, sum, unnormalised output) go to a per-stream workspace,
 // mha_f32_merge_kernel combines them (one launch more; a single range writes the output itself).
 constexpr int kMhaKS = 128;  // keys per workgroup
+// stores / loads past every cache (sc0 sc1): partial results cross XCDs inside one launch (as ns_attn.hip st_through / ld_through)
+__device__ __forceinline__ void dev_st_through(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float dev_ld_through(const float* p) {
+  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
 typedef float dfloat4 __attribute__((ext_vector_type(4)));
 template <int DPL>
 __global__ __launch_bounds__(256) void mha_f32_split_kernel(const float* q, const float* k, const float* v, float* o, float* ws, int nsplit,
                                                             int seq, int seq_all, int heads, int heads_kv, int n_ctx, float scale,
-                                                            int masked, const int* __restrict__ kmove, int kdelta) {
+                                                            int masked, const int* __restrict__ kmove, int kdelta, uint32_t* tickets = nullptr,
+                                                            _Float16* o16 = nullptr) {
   constexpr int HS = 16 * DPL;
   // replayed device route (ns_common.h Affine): the context length moves with the graph's token counter; the grid and the partials'
   // layout are those of the longest context (nsplit = ranges of n_ctx), ranges past the live length leave at once and the merge
@@ -234,16 +242,60 @@ __global__ __launch_bounds__(256) void mha_f32_split_kernel(const float* q, cons
   }
   __syncthreads();
   const float l = red[0] + red[1] + red[2] + red[3];
+  // replayed route with tickets (round 5): no merge launch — the live ranges of a (row, head) draw a self-resetting ticket once their
+  // partials are out (stores and loads past the per-XCD L2s), the last one combines them in range order: the sums mha_f32_merge_kernel forms.
+  // A single live range (contexts up to 128 keys) writes the output row itself.
+  const int live = kmove ? (seq_all + kMhaKS - 1) / kMhaKS : nsplit;  // (seq_all already moved above)
+  if (tickets && live == 1) {
+    if (sub == 0) {
+      float* op = o + (size_t(bq) * heads + ih) * HS;
+#pragma unroll
+      for (int i = 0; i < DPL; i++) {
+        const float y = part[i] / l;
+        op[grp + 16 * i] = y;
+        if (o16) o16[(size_t(bq) * heads + ih) * HS + grp + 16 * i] = (_Float16)y;
+      }
+    }
+    return;
+  }
   if (sub == 0) {
     if (nsplit == 1 && !kmove) {
       float* op = o + (size_t(bq) * heads + ih) * HS;
 #pragma unroll
       for (int i = 0; i < DPL; i++) op[grp + 16 * i] = part[i] / l;
+    } else if (tickets) {
+#pragma unroll
+      for (int i = 0; i < DPL; i++) dev_st_through(wp + 2 + grp + 16 * i, part[i]);
+      if (t == 0) dev_st_through(wp, mx), dev_st_through(wp + 1, l);
     } else {
 #pragma unroll
       for (int i = 0; i < DPL; i++) wp[2 + grp + 16 * i] = part[i];
       if (t == 0) wp[0] = mx, wp[1] = l;
     }
+  }
+  if (!tickets) return;
+  __shared__ uint32_t drawn_s;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  uint32_t* tk = tickets + size_t(bq) * heads + ih;
+  if (t == 0) drawn_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (drawn_s != uint32_t(live - 1)) return;
+  if (t == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next token
+  if (t < HS) {
+    const float* wq = ws + (size_t(bq) * heads + ih) * nsplit * (2 + HS);
+    float mb = -INFINITY;
+    for (int s2 = 0; s2 < live; s2++) mb = fmaxf(mb, dev_ld_through(wq + size_t(s2) * (2 + HS)));
+    float lb = 0.f, ab = 0.f;
+    for (int s2 = 0; s2 < live; s2++) {
+      const float ms = dev_ld_through(wq + size_t(s2) * (2 + HS));
+      const float c = ms != -INFINITY ? expf(ms - mb) : 0.f;
+      lb += dev_ld_through(wq + size_t(s2) * (2 + HS) + 1) * c;
+      if (ms != -INFINITY) ab += dev_ld_through(wq + size_t(s2) * (2 + HS) + 2 + t) * c;
+    }
+    const float y = ab / lb;
+    o[(size_t(bq) * heads + ih) * HS + t] = y;
+    if (o16) o16[(size_t(bq) * heads + ih) * HS + t] = (_Float16)y;
   }
 }
 // one workgroup of head_size threads per (query row, head): combine the ranges' (max, sum, output) in range order
@@ -706,12 +758,28 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
         const float* q_c = dQ + size_t(r0) * heads * head_size;
         float* o_c = dO + size_t(r0) * heads * head_size;
         const dim3 grid(unsigned(ns_c), unsigned(heads), unsigned(batch * nr));
+        // replayed decode step: the last live range merges inside the launch (tickets zeroed when allocated, self-resetting; sized by
+        // ns_route.cpp before the capture) — NS_MHA_INLAUNCH=0: the merge launch
+        static const bool inl_off = getenv("NS_MHA_INLAUNCH") && atoi(getenv("NS_MHA_INLAUNCH")) == 0;
+        uint32_t* tickets = nullptr;
+        if (aff.k && seq == 1 && !inl_off && size_t(batch) * heads <= 65536)
+          tickets = static_cast<uint32_t*>(ns::stream_scratch_zeroed(st, 65536 * 4, 25));
+        _Float16* o16 = (aff.k && seq == 1) ? static_cast<_Float16*>(ns::g_mha_out16) : nullptr;
+        if (tickets) {
+          if (head_size == 64)
+            hipLaunchKernelGGL(ns::mha_f32_split_kernel<4>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta), tickets, o16);
+          else if (head_size == 128)
+            hipLaunchKernelGGL(ns::mha_f32_split_kernel<8>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta), tickets, o16);
+          else
+            hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta), tickets, o16);
+          continue;
+        }
         if (head_size == 64)
-          hipLaunchKernelGGL(ns::mha_f32_split_kernel<4>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta));
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<4>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta), static_cast<uint32_t*>(nullptr), static_cast<_Float16*>(nullptr));
         else if (head_size == 128)
-          hipLaunchKernelGGL(ns::mha_f32_split_kernel<8>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta));
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<8>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta), static_cast<uint32_t*>(nullptr), static_cast<_Float16*>(nullptr));
         else
-          hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta));
+          hipLaunchKernelGGL(ns::mha_f32_split_kernel<16>, grid, dim3(256), 0, st, q_c, dK, dV, o_c, ws, ns_c, nr, sa, heads, heads_kv, n_ctx, scale, masked, aff.k, int(aff.delta), static_cast<uint32_t*>(nullptr), static_cast<_Float16*>(nullptr));
         if (ns_c > 1 || aff.k)
           hipLaunchKernelGGL(ns::mha_f32_merge_kernel, dim3(unsigned(size_t(batch) * nr * heads)), dim3(unsigned(head_size)), 0, st, ws, o_c, ns_c, head_size,
                              sa, aff.k, int(aff.delta), (aff.k && seq == 1) ? static_cast<_Float16*>(ns::g_mha_out16) : nullptr);

@@ -650,6 +650,7 @@ bool make_plan() {
       const long long* i = po.op.i;
       const size_t nsplit_max = size_t((i[6] + 127) / 128);
       if (!stream_scratch(R.st, size_t(i[0]) * i[1] * i[3] * nsplit_max * (2 + i[5]) * sizeof(float), 24)) return false;
+      if (!stream_scratch_zeroed(R.st, 65536 * 4, 25)) return false;  // the tickets of the merge inside the launch (ns_device.hip)
     }
   // the launches (fused where possible), then segments of about seg_ops() of them.  A segment may end only where the launches so far
   // stand for a PREFIX of the reference's launches (fusion reorders inside a layer), and never on a node the lazy peephole only records

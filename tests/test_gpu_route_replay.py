@@ -166,9 +166,9 @@ def test_replayed_tokens_and_a_deviating_token_compute_what_plain_launches_compu
 NL = 2  # decoder layers of the second stream
 
 
-def _run_layers(L, nso, blobs, gam, xs, replay):
+def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None):
     """NL decoder layers WITH the attention node and the model's last norm + output projection: the shape in which the plan carries RMS norms
-    across launches (ns_route.cpp link_norms).  Positions 0, 1, 2, ...  Returns (outputs per token, K caches, V caches, route statistics)."""
+    across launches (ns_route.cpp link_norms).  Positions pos0, pos0 + 1, ... of caches made for nctx positions (cache0: their initial contents).  Returns (outputs per token, K caches, V caches, route statistics)."""
     _api(L)
     vp, i = C.c_void_p, C.c_int
     L.ns_hip_mha_f32_device_layout.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, C.c_float, i, vp]
@@ -185,12 +185,12 @@ def _run_layers(L, nso, blobs, gam, xs, replay):
         slices.append(dptr)
     f4 = 4
     pool = L.bestla_device_malloc(1 << 21, q)
-    zero = np.zeros(HEADS * NCTX * HS, np.float32)
+    zero = np.zeros(HEADS * nctx * HS, np.float32)
     kcs, vcs = [], []
     for _ in range(NL):
         kc, vc = L.bestla_device_malloc(zero.nbytes, q), L.bestla_device_malloc(zero.nbytes, q)
-        L.bestla_device_memcpy_sync(kc, nso.ptr(zero), zero.nbytes, q)
-        L.bestla_device_memcpy_sync(vc, nso.ptr(zero), zero.nbytes, q)
+        L.bestla_device_memcpy_sync(kc, nso.ptr(zero if cache0 is None else cache0[len(kcs)]), zero.nbytes, q)
+        L.bestla_device_memcpy_sync(vc, nso.ptr(zero if cache0 is None else cache0[NL + len(vcs)]), zero.nbytes, q)
         kcs.append(kc), vcs.append(vc)
     dg = L.bestla_device_malloc(D * f4, q)
     L.bestla_device_memcpy_sync(dg, nso.ptr(gam), gam.nbytes, q)
@@ -198,8 +198,9 @@ def _run_layers(L, nso, blobs, gam, xs, replay):
     vec = lambda n: (_ll(n, 1, 1, 1), _ll(4, 4 * n, 4 * n, 4 * n))
     ne, nb = vec(D)
     nef, nbf = vec(FF)
-    for pos, x in enumerate(xs):
-        base = pool + pos * DELTA
+    for tok, x in enumerate(xs):
+        pos = pos0 + tok
+        base = pool + tok * DELTA
         off = [0]
 
         def alloc(nfloat):
@@ -219,13 +220,13 @@ def _run_layers(L, nso, blobs, gam, xs, replay):
             L.bestla_device_f32f32_forward(ph, nso.ptr(stors["wk"]), pk, 1, D, D, D, D, None, q)
             assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_rope_f32(pk, pk, 1, 1, HEADS, HS, pos, HS, 0, 10000.0, 1.0, 0.0, 1.0, q) == 0
             assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_dup_f32(pk, kc + pos * HS * f4, _ll(HS, 1, HEADS, 1), _ll(4, HS * HEADS * 4, HS * 4, HS * HEADS * 4),
-                                                                      _ll(4, HS * 4, NCTX * HS * 4, HEADS * NCTX * HS * 4), False, q) == 0
+                                                                      _ll(4, HS * 4, nctx * HS * 4, HEADS * nctx * HS * 4), False, q) == 0
             L.bestla_device_f32f32_forward(ph, nso.ptr(stors["wv"]), pv, 1, D, D, D, D, None, q)
             assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_dup_f32(pv, vc + pos * f4, _ll(1, HS, HEADS, 1), _ll(HS * HEADS * 4, 4, HS * 4, HS * HEADS * 4),
-                                                                      _ll(4, NCTX * 4, HS * NCTX * 4, HEADS * HS * NCTX * 4), False, q) == 0
+                                                                      _ll(4, nctx * 4, HS * nctx * 4, HEADS * HS * nctx * 4), False, q) == 0
             L.bestla_device_f32f32_forward(ph, nso.ptr(stors["wq"]), pq, 1, D, D, D, D, None, q)
             assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_rope_f32(pq, pq, 1, 1, HEADS, HS, pos, HS, 0, 10000.0, 1.0, 0.0, 1.0, q) == 0
-            assert L.ns_hip_mha_f32_device_layout(pq, kc, vc, pa, 1, 1, pos + 1, HEADS, HEADS, HS, NCTX, HS ** -0.5, 1, q) == 0
+            assert L.ns_hip_mha_f32_device_layout(pq, kc, vc, pa, 1, 1, pos + 1, HEADS, HEADS, HS, nctx, HS ** -0.5, 1, q) == 0
             L.bestla_device_f32f32_forward(pa, nso.ptr(stors["wo"]), pt, 1, D, D, D, D, None, q)
             assert L.ns_hip_binary_nd_f32(0, pt, px, pr, ne, nb, ne, nb, nb, q) == 0
             assert L.ns_hip_lazy_rms_norm(1, D, 1e-5, pr, pn2, q) == 0
@@ -247,7 +248,7 @@ def _run_layers(L, nso, blobs, gam, xs, replay):
         outs.append(out)
     caches = []
     for c in kcs + vcs:
-        h = np.zeros(HEADS * NCTX * HS, np.float32)
+        h = np.zeros(HEADS * nctx * HS, np.float32)
         L.bestla_device_memcpy_sync(nso.ptr(h), c, h.nbytes, q)
         caches.append(h)
     st = (C.c_uint64 * 8)()
@@ -293,3 +294,27 @@ def test_plan_carries_the_rms_norms_across_launches(L, pkg, nso):
         assert nso.rel_l2(b, a) < 2e-3, (t, nso.rel_l2(b, a))
     for a, b in zip(ref_c, got_c):
         assert np.count_nonzero(b) > 0 and nso.rel_l2(b, a) < 2e-3
+
+
+def test_replayed_attention_over_several_context_ranges(L, pkg, nso):
+    """Positions 250 .. 261 of caches made for 512: the replayed attention covers 2 and then 3 live ranges of 128 keys (of the 4 its grid is
+    made for) and its last range to finish merges them inside the launch (ns_device.hip, tickets) — no merge launch in the plan."""
+    rng = np.random.default_rng(6)
+    mk = lambda n, k: nso.quant_pack((rng.standard_normal((n, k)) * k ** -0.5).astype(np.float32), 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    blobs = {"wq": mk(D, D), "wk": mk(D, D), "wv": mk(D, D), "wo": mk(D, D), "w1": mk(FF, D), "w3": mk(FF, D), "w2": mk(D, FF)}
+    gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    xs = [rng.standard_normal(D).astype(np.float32) for _ in range(12)]
+    nctx, pos0 = 512, 250
+    cache0 = [(0.5 * rng.standard_normal(HEADS * nctx * HS)).astype(np.float32) for _ in range(2 * NL)]
+    _api(L)
+    ref_out, ref_c, _ = _run_layers(L, nso, blobs, gam, xs, 0, nctx, pos0, cache0)
+    st1 = (C.c_uint64 * 8)()
+    L.ns_hip_route_stats(st1)
+    got_out, got_c, st2 = _run_layers(L, nso, blobs, gam, xs, 3, nctx, pos0, cache0)
+    replayed, eager, plans, fallbacks = (st2[i] - st1[i] for i in range(4))
+    assert (replayed, eager, plans, fallbacks) == (10, 2, 1, 0), (replayed, eager, plans, fallbacks)
+    for t, (a, b) in enumerate(zip(ref_out, got_out)):
+        assert np.all(np.isfinite(b))
+        assert nso.rel_l2(b, a) < 2e-3, (t, nso.rel_l2(b, a))
+    for a, b in zip(ref_c, got_c):
+        assert nso.rel_l2(b, a) < 2e-3
