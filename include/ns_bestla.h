@@ -223,9 +223,10 @@ int ns_hip_get_compute_mode(void);
  *                     bit-identical results (measured: 0.89-1.07 x, DESIGN.md section 4.2c - hence off at load by default)
  *   "attn_mfma2_rows" query rows from which a prefill takes the 128-row matrix-core attention kernel (0 = default 128; a value
  *                     above every sl_q keeps the 64-row kernel of rounds 1-3)
- *   "attn_stream"     1 (default) = decode attention (head sizes <= 128, contiguous head dimension) moves K / V HBM -> LDS by DMA into
+ *   "attn_stream"     1 (default) = decode attention (head sizes 72 .. 128, contiguous head dimension) moves K / V HBM -> LDS by DMA into
  *                     per-wave rings, the whole context range of a workgroup in flight at once (attn_stream_kernel); 0 = through
- *                     registers (attn_split_kernel).  The same bits
+ *                     registers (attn_split_kernel); the two agree to fp32 rounding.  "attn_stream_wg_target" / "attn_stream_min_keys": its
+ *                     context-range rule (defaults 256 workgroups, >= 32 keys per range)
  *   "attn_inlaunch"   0 (default) = attn_merge_kernel combines the context splits in a second launch, 1 = the split that finishes
  *                     last does inside the launch (one self-resetting counter per kv head); same sums in the same order, same time
  *   "attn_heads_first" dispatch order of the decode attention's workgroups: 1 = the kv heads of one context range side by side, 0 = the

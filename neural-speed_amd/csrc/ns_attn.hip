@@ -487,7 +487,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
 // 128 keys is two dependent round trips of 32 KiB per workgroup (the stream alone is 8.4 of its 10.8 us at 2048 positions,
 // profiles/r04bb_*); here a workgroup has its whole range — 64 KiB at 128 keys — requested within the first few hundred cycles.
 // Same key -> lane mapping (wave w, step u: keys j0 + 16 u + 4 w .. + 3, lane group l >> 4 one key each, lane l & 15 eight head
-// dims), same U-key softmax update, same finish: the partials, and so the outputs, are the bits attn_split_kernel writes.
+// dims), same U-key softmax update, same finish (attn_split_finish); the two kernels split a context differently (own range rule below) and hipcc contracts
+// their sums differently, so their outputs agree to fp32 rounding (2e-6 relative, tests/test_gpu_attention.py), not bit for bit.
 // A step = 4 keys = one 1 KiB request of K + one of V per wave; ring of kAsSteps steps per wave (refilled behind the reads for longer
 // ranges).  Rows past the range's end lie outside the buffer descriptor (the DMA writes zeros for them); their scores are masked and
 // their V is selected to zero as in attn_split_kernel, so nothing depends on what such a slot holds.
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
 }
 
 // ns_hip_set_tuning("attn_stream", 0 / 1): 1 (default) = decode attention of head sizes <= 128 streams K / V through LDS rings (attn_stream_kernel),
-// 0 = attn_split_kernel (registers).  Same bits either way.
+// 0 = attn_split_kernel (registers).  The two agree to fp32 rounding.
 static std::atomic<int> g_attn_stream{getenv("NS_ATTN_STREAM") ? atoi(getenv("NS_ATTN_STREAM")) != 0 : 1};
 void set_attn_stream(int on) { g_attn_stream.store(on != 0); }
 // whether a fast-path call streams through the LDS rings: head sizes 72 .. 128 (up to 64 only half of a request's lanes carry data — measured
