@@ -223,7 +223,7 @@ int ns_hip_get_compute_mode(void);
  *                     bit-identical results (measured: 0.89-1.07 x, DESIGN.md section 4.2c - hence off at load by default)
  *   "attn_mfma2_rows" query rows from which a prefill takes the 128-row matrix-core attention kernel (0 = default 128; a value
  *                     above every sl_q keeps the 64-row kernel of rounds 1-3)
- *   "attn_stream"     1 (default) = decode attention (head sizes 72 .. 128, contiguous head dimension) moves K / V HBM -> LDS by DMA into
+ *   "attn_stream"     1 (default) = decode attention (head sizes 40 .. 128, contiguous head dimension) moves K / V HBM -> LDS by DMA into
  *                     per-wave rings, the whole context range of a workgroup in flight at once (attn_stream_kernel); 0 = through
  *                     registers (attn_split_kernel); the two agree to fp32 rounding.  "attn_stream_wg_target" / "attn_stream_min_keys": its
  *                     context-range rule (defaults 256 workgroups, >= 32 keys per range)

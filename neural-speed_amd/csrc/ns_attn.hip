@@ -193,20 +193,20 @@ __device__ __forceinline__ float ld_through(const float* p) {
 // What follows the key loop of a split kernel (attn_split_kernel and attn_stream_kernel share it): the four key groups of a wave are
 // combined by shuffles, the waves through LDS (acc_s: [4 waves][G][16 * DPL] floats), then either the output row (one split) or the
 // split's partial (max, sum, unnormalised output) is stored — and, with tickets, the last split of a kv head merges inside the launch.
-template <int G, int DPL>
+template <int G, int DPL, int LPK = 16>  // LPK: lanes per key (64 / LPK key groups in a wave)
 __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, float (&acc)[G][DPL], float (&m)[G], float (&lsum)[G], float* acc_s,
                                                   float (&ml_s)[4][G][2], int split, int chunk, int ihkv, int i, int ibs) {
   const AttnParams& p = sp.a;
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
   const int hs = p.head_size;
-  const int d0 = (l & 15) * DPL;
+  const int d0 = (l & (LPK - 1)) * DPL;
   auto head_of = [&](int g) { return ihkv * sp.g_full + min(chunk * G + g, sp.g_full - 1); };
   auto head_live = [&](int g) { return chunk * G + g < sp.g_full; };
   // ---- merge the 4 key groups of a wave (lanes with equal dl) by shuffles ----
 #pragma unroll
   for (int g = 0; g < G; g++) {
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
+    for (int off = LPK; off <= 32; off <<= 1) {
       const float mo = __shfl_xor(m[g], off, 64), lo = __shfl_xor(lsum[g], off, 64);
       const float mn = fmaxf(m[g], mo);
       const float ca = mn == -INFINITY ? 0.f : expf(m[g] - mn), cb = mn == -INFINITY ? 0.f : expf(mo - mn);
@@ -217,7 +217,7 @@ __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, flo
     }
   }
   // ---- across the 4 waves through LDS ----
-  if (l < 16) {
+  if (l < LPK) {
 #pragma unroll
     for (int g = 0; g < G; g++) {
       if (l == 0) {
@@ -225,13 +225,13 @@ __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, flo
         ml_s[w][g][1] = lsum[g];
       }
 #pragma unroll
-      for (int e = 0; e < DPL; e++) acc_s[(w * G + g) * 16 * DPL + d0 + e] = acc[g][e];
+      for (int e = 0; e < DPL; e++) acc_s[(w * G + g) * LPK * DPL + d0 + e] = acc[g][e];
     }
   }
   __syncthreads();
   // thread (g, d) finishes output dim d of head g
-  for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
-    const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
+  for (int idx = t; idx < G * LPK * DPL; idx += kAttnThreads) {
+    const int g = idx / (LPK * DPL), dd = idx % (LPK * DPL);
     if (dd >= hs || !head_live(g)) continue;
     float mb = -INFINITY;
 #pragma unroll
@@ -241,7 +241,7 @@ __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, flo
     for (int ww = 0; ww < 4; ww++) {
       const float c = ml_s[ww][g][0] == -INFINITY ? 0.f : expf(ml_s[ww][g][0] - mb);
       lb += ml_s[ww][g][1] * c;
-      ab += acc_s[(ww * G + g) * 16 * DPL + dd] * c;
+      ab += acc_s[(ww * G + g) * LPK * DPL + dd] * c;
     }
     const int ihn = head_of(g);
     if (sp.nsplit == 1) {
@@ -278,8 +278,8 @@ __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, flo
   if (drawn_s != uint32_t(sp.nsplit - 1)) return;
   if (t == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
   const int ns = sp.nsplit;
-  for (int idx = t; idx < G * 16 * DPL; idx += kAttnThreads) {
-    const int g = idx / (16 * DPL), dd = idx % (16 * DPL);
+  for (int idx = t; idx < G * LPK * DPL; idx += kAttnThreads) {
+    const int g = idx / (LPK * DPL), dd = idx % (LPK * DPL);
     if (dd >= hs || !head_live(g)) continue;
     const int ihn = head_of(g);
     const float* wq = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
@@ -494,9 +494,11 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
 // their V is selected to zero as in attn_split_kernel, so nothing depends on what such a slot holds.
 constexpr int kAsSteps = 8;
 constexpr size_t kAsLdsBytes = size_t(4) * kAsSteps * 2048;
-template <int G>
+template <int G, int LPK = 16>  // LPK lanes per key: 16 (head sizes 72 .. 128) or 8 (40 .. 64: a 1 KiB request then holds 8 key rows, a wave step 8 keys)
 __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSplitParams sp) {
   constexpr int DPL = 8;
+  constexpr int KPW = 64 / LPK;  // keys per wave and step
+  constexpr int KPS = 4 * KPW;   // keys per workgroup and step
   const AttnParams& p = sp.a;
   __shared__ float ml_s[4][G][2];
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_s[];  // [4 waves][kAsSteps][K image 1 KiB | V image 1 KiB]; afterwards acc_s
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
   auto head_of = [&](int g) { return ihkv * sp.g_full + min(chunk * G + g, sp.g_full - 1); };
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int dl = l & 15;
+  const int dl = l & (LPK - 1);
   const int hs = p.head_size;
   const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
   const bool alibi = (p.flags & NS_ATTN_FLAG_IS_ALIBI8) != 0;
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
   const bool dact = d0 < hs;
   constexpr int U = G * DPL <= 16 ? 4 : 2;  // keys per lane and softmax update: attn_split_kernel's rule (the update order decides the bits)
   static_assert(kAsSteps % U == 0, "a batch of U steps never wraps inside the ring");
-  const int nsteps = j1 > j0 ? (((j1 - j0 + 15) >> 4) + U - 1) / U * U : 0;  // whole batches: steps past the end fetch nothing (outside the descriptor)
+  const int nsteps = j1 > j0 ? (((j1 - j0 + KPS - 1) / KPS) + U - 1) / U * U : 0;  // whole batches: steps past the end fetch nothing (outside the descriptor)
 
   // ---- 0. the query rows are requested first (ordinary loads, OLDER than the stream: loads return in order, a row requested behind the
   //      ring would be usable only when the whole ring has landed) ----
@@ -548,9 +550,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
   };
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(kh), 0, __builtin_amdgcn_readfirstlane(k_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(vh), 0, __builtin_amdgcn_readfirstlane(v_bytes), 0x00020000);
-  const uint32_t key_l = uint32_t(j0 + 4 * w + (l >> 4));  // this lane's key of step 0
-  const uint32_t k_voff = (key_l * uint32_t(p.step_k_sl) + uint32_t(d0)) * 2u, k_step = 16u * uint32_t(p.step_k_sl) * 2u;
-  const uint32_t v_voff = (key_l * uint32_t(p.step_v_sl) + uint32_t(d0)) * 2u, v_step = 16u * uint32_t(p.step_v_sl) * 2u;
+  const uint32_t key_l = uint32_t(j0 + KPW * w + l / LPK);  // this lane's key of step 0
+  const uint32_t k_voff = (key_l * uint32_t(p.step_k_sl) + uint32_t(d0)) * 2u, k_step = uint32_t(KPS) * uint32_t(p.step_k_sl) * 2u;
+  const uint32_t v_voff = (key_l * uint32_t(p.step_v_sl) + uint32_t(d0)) * 2u, v_step = uint32_t(KPS) * uint32_t(p.step_v_sl) * 2u;
   const LdsPtr ring = (LdsPtr)(ring_s) + w * (kAsSteps * 2048);
   auto issue = [&](int s) {  // step s -> slot s % kAsSteps; the key offset is part of the per-lane offset (the part the descriptor checks)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -626,12 +628,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
     for (int u = 0; u < U; u++)
       if (s0 + kAsSteps + u < nsteps) issue(s0 + kAsSteps + u);
     __builtin_amdgcn_sched_barrier(0);
-    const int jb = j0 + 16 * s0 + 4 * w + (l >> 4);
+    const int jb = j0 + KPS * s0 + KPW * w + l / LPK;
     // rows past the range's end and lanes past the head size count as zeros, as attn_split_kernel's unrequested registers do
     half8_t kv[U], vv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const bool live = dact && jb + 16 * u < j1;
+      const bool live = dact && jb + KPS * u < j1;
       const u4_t zero = {0u, 0u, 0u, 0u};
       kv[u] = __builtin_bit_cast(half8_t, live ? kr[u] : zero);
       vv[u] = __builtin_bit_cast(half8_t, live ? vr[u] : zero);
@@ -647,14 +649,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
         s[u] = t2;
       }
 #pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
+      for (int off = LPK / 2; off > 0; off >>= 1) {
 #pragma unroll
         for (int u = 0; u < U; u++) s[u] += __shfl_xor(s[u], off, 64);
       }
       float m_new = m[g];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int j = jb + 16 * u;
+        const int j = jb + KPS * u;
         if (tanh30) s[u] = 30.f * tanhf(s[u] * (1.f / 30.f));
         s[u] += float(j) * slope[g];
         if (j >= j1) s[u] = -INFINITY;
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
     }
   }
   __syncthreads();  // every wave has left its ring: its first bytes become attn_split_finish's acc_s
-  attn_split_finish<G, DPL>(sp, acc, m, lsum, reinterpret_cast<float*>(ring_s), ml_s, split, chunk, ihkv, i, ibs);
+  attn_split_finish<G, DPL, LPK>(sp, acc, m, lsum, reinterpret_cast<float*>(ring_s), ml_s, split, chunk, ihkv, i, ibs);
 }
 
 // one workgroup per (batch, query row, head): combine the splits' (m, l, acc).  The per-split (m, l) are fetched by
@@ -759,21 +761,28 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
 // 0 = attn_split_kernel (registers).  The two agree to fp32 rounding.
 static std::atomic<int> g_attn_stream{getenv("NS_ATTN_STREAM") ? atoi(getenv("NS_ATTN_STREAM")) != 0 : 1};
 void set_attn_stream(int on) { g_attn_stream.store(on != 0); }
-// whether a fast-path call streams through the LDS rings: head sizes 72 .. 128 (up to 64 only half of a request's lanes carry data — measured
-// slower from 4096 positions on), row offsets inside a 32-bit buffer descriptor, 16-byte query loads
+// whether a fast-path call streams through the LDS rings: head sizes 40 .. 128 (72 .. 128: sixteen lanes per key; 40 .. 64: eight — with sixteen, half of a
+// request's lanes would carry nothing: measured slower from 4096 positions on), row offsets inside a 32-bit buffer descriptor, 16-byte query loads
 static bool attn_streams(const AttnParams& a) {
   const bool in32 = (size_t(a.sl_kv) * size_t(a.step_k_sl) + 256) * 2 < (size_t(1) << 32) && (size_t(a.sl_kv) * size_t(a.step_v_sl) + 256) * 2 < (size_t(1) << 32);
   const bool q16 = (reinterpret_cast<uintptr_t>(a.q) & 15) == 0 && a.step_q_bs % 4 == 0 && a.step_q_head_num % 4 == 0 && a.step_q_sl % 4 == 0;
-  return a.head_size > 64 && a.head_size <= 128 && in32 && q16 && g_attn_stream.load(std::memory_order_relaxed) != 0;
+  return a.head_size > 32 && a.head_size <= 128 && in32 && q16 && g_attn_stream.load(std::memory_order_relaxed) != 0;
 }
 template <int G>
 static hipError_t launch_split_g(const AttnSplitParams& sp, dim3 grid, hipStream_t st, bool stream) {
   const int hs = sp.a.head_size;
-  if (stream) {
+  if (stream && hs > 64) {
     static const hipError_t attr =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_stream_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kAsLdsBytes));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_stream_kernel<G, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kAsLdsBytes));
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((attn_stream_kernel<G>), grid, dim3(kAttnThreads), kAsLdsBytes, st, sp);
+    hipLaunchKernelGGL((attn_stream_kernel<G, 16>), grid, dim3(kAttnThreads), kAsLdsBytes, st, sp);
+    return hipGetLastError();
+  }
+  if (stream) {  // head sizes 40 .. 64: eight lanes per key
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_stream_kernel<G, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kAsLdsBytes));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((attn_stream_kernel<G, 8>), grid, dim3(kAttnThreads), kAsLdsBytes, st, sp);
     return hipGetLastError();
   }
   if (hs <= 128) {
@@ -814,13 +823,22 @@ void set_attn_stream_tuning(int wg_target, int min_keys) {
   if (wg_target > 0) g_attn_wg_target_s.store(wg_target);
   if (min_keys > 0) g_attn_min_keys_s.store(min_keys);
 }
-static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv, bool stream) {  // heads_kv: kv heads x workgroups per kv head
+// batch_keys (ring kernel): keys one softmax update of a workgroup covers (U steps); a range that is not a multiple of it computes masked key slots,
+// which costs where the update is VALU-heavy (8 query heads per workgroup: Falcon-7B's 71 heads on one kv head at 2048 keys, 29 ranges of 71 keys
+// 32.5 us against 16 x 128 keys 28.5) — ranges are rounded up to it while that leaves at least 128 workgroups
+static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv, bool stream, int batch_keys = 0) {  // heads_kv: kv heads x workgroups per kv head
   const size_t base_blocks = size_t(heads_kv) * sl_q * batch;
   const int target = stream ? g_attn_wg_target_s.load() : g_attn_wg_target.load(), mk = stream ? g_attn_min_keys_s.load() : g_attn_min_keys.load();
   if (stream && sl_kv <= 128 && base_blocks >= 32) return 1;  // (a range's worth of keys on 32+ workgroups: the merge launch costs more than it saves, 7.0 vs 7.8 us)
   int nsplit = int((target + base_blocks - 1) / base_blocks);     // aim at ~4 workgroups per CU
   nsplit = std::min(nsplit, std::max(1, (sl_kv + mk - 1) / mk));  // at least 128 keys per split
-  return std::min(nsplit, 64);
+  nsplit = std::min(nsplit, 64);
+  if (stream && batch_keys > 0 && nsplit > 1) {
+    const int kps = ((sl_kv + nsplit - 1) / nsplit + batch_keys - 1) / batch_keys * batch_keys;
+    const int rounded = (sl_kv + kps - 1) / kps;
+    if (size_t(rounded) * base_blocks >= 128) nsplit = rounded;
+  }
+  return nsplit;
 }
 static size_t attn_ws_bytes(int batch, int head_num, int heads_kv, int head_size, int sl_q, int sl_kv) {
   int G, chunks;
@@ -1511,7 +1529,8 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     sp.a = p;
     sp.g_full = a.head_num / a.heads_kv, sp.chunks = chunks;
     const bool stream = attn_streams(p);
-    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv, stream);
+    const int batch_keys = (G * 8 <= 16 ? 4 : 2) * 4 * (a.head_size > 64 ? 4 : 8);  // attn_stream_kernel's U x keys per workgroup step
+    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv, stream, batch_keys);
     float* ws = nullptr;
     if (nsplit > 1) {
       // partials go to the caller's workspace (`tmp`, sized by bestla_fusion_attn_workspace_size: the reference's own

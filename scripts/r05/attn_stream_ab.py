@@ -13,7 +13,7 @@ ctxs = [int(x) for x in sys.argv[1:]] or [2048]
 nl = 32
 out_rows = []
 for ctx in ctxs:
-    for heads, hkv, hs, layout in ((32, 32, 128, "position-major"), (32, 32, 128, "head-major"), (32, 8, 128, "position-major"), (32, 32, 64, "position-major")):
+    for heads, hkv, hs, layout in ((32, 32, 128, "position-major"), (32, 32, 128, "head-major"), (32, 8, 128, "position-major"), (32, 32, 64, "position-major"), (32, 8, 64, "position-major"), (71, 1, 64, "position-major")):
         q = torch.randn((1, 1, heads, hs), device="cuda")
         out = torch.zeros_like(q)
         out16 = torch.zeros((1, 1, heads, hs), device="cuda", dtype=torch.float16)

@@ -301,13 +301,21 @@ STREAM_CASES = [  # bs, heads, heads_kv, head_size, sl_q, sl_kv, flags: decode-s
     (1, 8, 8, 128, 1, 640, 0),      # unmasked
     (1, 48, 1, 128, 1, 1500, 1),    # 48 query heads on one kv head: six workgroups of 8 heads per range
     (1, 32, 32, 128, 1, 9000, 1),   # long context: 8 ranges x 71 steps through an 8-step ring
+    # ---- head sizes 40 .. 64: eight lanes per key, eight keys per request ----
+    (1, 32, 8, 64, 1, 2048, 1),     # Llama-3.2-1B heads
+    (1, 32, 4, 64, 1, 777, 1),      # TinyLlama: group of 8, ragged ranges
+    (1, 71, 1, 64, 1, 2048, 1),     # Falcon-7B: 71 query heads on one kv head
+    (2, 12, 12, 64, 2, 300, 1),     # GPT-2-class heads, two rows, batch 2
+    (1, 8, 8, 48, 1, 100, 1),       # head size 48 (lanes 6, 7 of a key idle), unsplit, partial last step
+    (1, 16, 16, 40, 3, 1100, 3),    # head size 40 with ALiBi, three rows
+    (1, 8, 2, 56, 1, 33, 0),        # head size 56, one key more than a step of the workgroup, unmasked
 ]
 
 
 @pytest.mark.parametrize("bs,hn,hkv,hs,sl_q,sl_kv,flags", STREAM_CASES)
 def test_decode_kv_through_lds_rings_and_through_registers(L, pkg, nso, bs, hn, hkv, hs, sl_q, sl_kv, flags):
     """attn_stream_kernel (K / V HBM -> LDS by DMA into per-wave rings; ns_hip_set_tuning("attn_stream", 1), the default for head sizes
-    72 .. 128) and attn_split_kernel (through registers; 0): each against the oracle, and against each other at fp32 rounding — the two
+    40 .. 128) and attn_split_kernel (through registers; 0): each against the oracle, and against each other at fp32 rounding — the two
     split a context differently, so their sums associate differently."""
     import torch
     rng = np.random.default_rng(hs + sl_kv)
