@@ -1530,7 +1530,9 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     sp.g_full = a.head_num / a.heads_kv, sp.chunks = chunks;
     const bool stream = attn_streams(p);
     const int batch_keys = (G * 8 <= 16 ? 4 : 2) * 4 * (a.head_size > 64 ? 4 : 8);  // attn_stream_kernel's U x keys per workgroup step
-    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv, stream, batch_keys);
+    // head sizes above 128 (register kernel, 16 dims per lane) take the ring kernel's range rule too: 16 x 256 heads 14.6 -> 10.4 us at 512 keys,
+    // 51.8 -> 36.5 at 8192; 8 heads on one kv head 51 -> 40 at 2048 (scripts/r05/attn_regs_rule.py; head sizes <= 32 lose with it at 2048+ keys)
+    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv, stream || a.head_size > 128, stream ? batch_keys : 0);
     float* ws = nullptr;
     if (nsplit > 1) {
       // partials go to the caller's workspace (`tmp`, sized by bestla_fusion_attn_workspace_size: the reference's own
