@@ -826,9 +826,13 @@ void set_attn_stream_tuning(int wg_target, int min_keys) {
 // batch_keys (ring kernel): keys one softmax update of a workgroup covers (U steps); a range that is not a multiple of it computes masked key slots,
 // which costs where the update is VALU-heavy (8 query heads per workgroup: Falcon-7B's 71 heads on one kv head at 2048 keys, 29 ranges of 71 keys
 // 32.5 us against 16 x 128 keys 28.5) — ranges are rounded up to it while that leaves at least 128 workgroups
-static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv, bool stream, int batch_keys = 0) {  // heads_kv: kv heads x workgroups per kv head
+// heavy (workgroups that serve 4 or 8 query heads per key: twice the arithmetic per byte): two workgroups per CU overlap better than one once a batch
+// brings 64+ workgroups per range — batch 8 x 32 / 8 heads at 2048 keys 36.7 -> 32.0 us, batch 16 64.0 -> 50.5 (scripts/r05/attn_batch_rule.py)
+static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv, bool stream, int batch_keys = 0, bool heavy = false) {  // heads_kv: kv heads x workgroups per kv head
   const size_t base_blocks = size_t(heads_kv) * sl_q * batch;
-  const int target = stream ? g_attn_wg_target_s.load() : g_attn_wg_target.load(), mk = stream ? g_attn_min_keys_s.load() : g_attn_min_keys.load();
+  int target = stream ? g_attn_wg_target_s.load() : g_attn_wg_target.load();
+  const int mk = stream ? g_attn_min_keys_s.load() : g_attn_min_keys.load();
+  if (stream && heavy && base_blocks >= 64) target *= 2;
   if (stream && sl_kv <= 128 && base_blocks >= 32) return 1;  // (a range's worth of keys on 32+ workgroups: the merge launch costs more than it saves, 7.0 vs 7.8 us)
   int nsplit = int((target + base_blocks - 1) / base_blocks);     // aim at ~4 workgroups per CU
   nsplit = std::min(nsplit, std::max(1, (sl_kv + mk - 1) / mk));  // at least 128 keys per split
@@ -843,7 +847,8 @@ static int attn_nsplit(int batch, int heads_kv, int sl_q, int sl_kv, bool stream
 static size_t attn_ws_bytes(int batch, int head_num, int heads_kv, int head_size, int sl_q, int sl_kv) {
   int G, chunks;
   attn_groups(head_num / std::max(1, heads_kv), &G, &chunks);
-  const int ns = std::max(attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv, false), attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv, true));  // (either kernel)
+  const int ns = std::max(attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv, false),
+                          std::max(attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv, true), attn_nsplit(batch, heads_kv * chunks, sl_q, sl_kv, true, 0, true)));  // (any rule)
   return ns > 1 ? size_t(batch) * sl_q * head_num * ns * (2 + head_size) * 4 : 0;
 }
 
@@ -1532,7 +1537,7 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     const int batch_keys = (G * 8 <= 16 ? 4 : 2) * 4 * (a.head_size > 64 ? 4 : 8);  // attn_stream_kernel's U x keys per workgroup step
     // head sizes above 128 (register kernel, 16 dims per lane) take the ring kernel's range rule too: 16 x 256 heads 14.6 -> 10.4 us at 512 keys,
     // 51.8 -> 36.5 at 8192; 8 heads on one kv head 51 -> 40 at 2048 (scripts/r05/attn_regs_rule.py; head sizes <= 32 lose with it at 2048+ keys)
-    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv, stream || a.head_size > 128, stream ? batch_keys : 0);
+    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv, stream || a.head_size > 128, stream ? batch_keys : 0, stream && G >= 4);
     float* ws = nullptr;
     if (nsplit > 1) {
       // partials go to the caller's workspace (`tmp`, sized by bestla_fusion_attn_workspace_size: the reference's own
