@@ -664,9 +664,12 @@ def full_token(chain, pkg, ctx=2048, fused=True, iters=30, keep=None):
             "finite": bool(torch.isfinite(logits).all().item())}, logits
 
 
+PREFILL_ROPE_IN_QKV = os.environ.get("NS_BENCH_PREFILL_ROPE_IN_QKV", "1") != "0"  # 0: RoPE + cache append as a launch of its own (rounds 2-4; A/B)
+
+
 def full_prefill(chain, pkg, m=2048, iters=5):
     """A WHOLE prompt of m tokens through the same model on the same weights, one launch per operator: rms norm . gamma, fused
-    QKV (tiled MFMA GEMM), RoPE(q, k) + kv-cache append, causal attention over the prompt (the 128-row matrix-core kernel, fp16 K / V
+    QKV (tiled MFMA GEMM) with RoPE(q, k) + kv-cache append as its epilogue (round 5; before: a launch of their own), causal attention over the prompt (the 128-row matrix-core kernel, fp16 K / V
     just appended), WO + residual, norm, gate/up . SiLU, down + residual — every layer — then the final norm and the lm_head row of
     the LAST position (what a first token needs).  tflops = 2 x weights x m + 4 x heads x head_size x m^2 / 2 per layer (causal half)."""
     L = pkg.lib()
@@ -684,16 +687,26 @@ def full_prefill(chain, pkg, m=2048, iters=5):
     b = dict(h=f32(m, d), qkv=f32(3, m, d), att=f32(m, d), r1=f32(m, d), h2=f32(m, d), x=f32(m, d), logits=f32(1, V))
     sh = dict(h=f16(m, d), att=f16(m, d), t2=f16(m, ff))
 
+    rope_tab = torch.zeros((m, hs // 2, 2), device=dev)  # (cos, sin) per (position, pair): the same for every layer, filled once per prompt
+
     def step():
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ck = pkg.check
         xin = x0
+        if PREFILL_ROPE_IN_QKV:
+            ck(L.ns_hip_rope_cos_sin(m, 0, hs, 10000.0, 1.0, 1.0, rope_tab.data_ptr(), st))
         for il, lw in enumerate(chain.layers):
             ck(L.ns_hip_norm_mul_h(m, d, True, 1e-5, xin.data_ptr(), gam.data_ptr(), b["h"].data_ptr(), sh["h"].data_ptr(), st))
-            ck(L.ns_hip_fusion_qkv_forward_h(b["h"].data_ptr(), sh["h"].data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
-                                             b["qkv"].data_ptr(), None, m, d, d, st))
-            ck(L.ns_hip_rope_qkv_append(b["qkv"][0].data_ptr(), b["qkv"][1].data_ptr(), b["qkv"][2].data_ptr(), kc[il].data_ptr(),
-                                        vc[il].data_ptr(), m, heads, heads, hs, 0, hs, 0, 10000.0, 1.0, 0.0, 1.0, heads * hs, hs, st))
+            if PREFILL_ROPE_IN_QKV:
+                # one launch: the fused-QKV GEMM rotates q / k and appends k, v to the fp16 cache in its epilogue; k and v are never fp32 tensors
+                rp = pkg.QkvRope(kc[il].data_ptr(), vc[il].data_ptr(), rope_tab.data_ptr(), heads, heads, hs, 0, hs, 0, heads * hs, hs, 1)
+                ck(L.ns_hip_fusion_qkv_rope_forward_x(b["h"].data_ptr(), sh["h"].data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
+                                                      b["qkv"].data_ptr(), m, d, d, None, C.byref(rp), st))
+            else:
+                ck(L.ns_hip_fusion_qkv_forward_h(b["h"].data_ptr(), sh["h"].data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
+                                                 b["qkv"].data_ptr(), None, m, d, d, st))
+                ck(L.ns_hip_rope_qkv_append(b["qkv"][0].data_ptr(), b["qkv"][1].data_ptr(), b["qkv"][2].data_ptr(), kc[il].data_ptr(),
+                                            vc[il].data_ptr(), m, heads, heads, hs, 0, hs, 0, 10000.0, 1.0, 0.0, 1.0, heads * hs, hs, st))
             a = pkg.attn_args(b["qkv"][0].data_ptr(), kc[il].data_ptr(), vc[il].data_ptr(), b["att"].data_ptr(), 1, heads, heads, hs,
                               m, m, hs ** -0.5, pkg.ATTN_CAUSAL)
             ck(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(C.byref(a), sh["att"].data_ptr(), st))
@@ -716,7 +729,8 @@ def full_prefill(chain, pkg, m=2048, iters=5):
     aflops = nl * 4.0 * heads * hs * m * m / 2
     return {"prompt_tokens": m, "ms": round(ms, 3), "prompt_tokens_per_s": round(m / ms * 1e3, 0),
             "tflops_gemm_plus_causal_attention": round((wflops + aflops) / ms / 1e9, 1),
-            "attention_share_of_flops": round(aflops / (wflops + aflops), 3), "launches": 8 * nl + 2,
+            "attention_share_of_flops": round(aflops / (wflops + aflops), 3), "launches": (7 * nl + 3) if PREFILL_ROPE_IN_QKV else (8 * nl + 2),
+            "rope_and_cache_append": "QKV GEMM epilogue" if PREFILL_ROPE_IN_QKV else "own launch",
             "finite": bool(torch.isfinite(b["logits"]).all().item())}
 
 

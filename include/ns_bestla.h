@@ -335,14 +335,18 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
  * positions n_past, n_past + 1, ...; fp16 shadow of A required.  The angles do not depend on the layer: cos_sin is the
  * table ns_hip_rope_cos_sin fills ONCE per token ([m][head_size / 2] pairs (cos, sin) * attn_factor, theta built by the
  * reference's sequential fp32 products), shared by every layer's launch.  Same arithmetic as ns_hip_rope_qkv_append
- * (bitwise). */
+ * (bitwise).  m > 16 (round 5): the tiled GEMM carries the epilogue (see NS_QKV_ROPE_KV_CACHE_ONLY below); no norm link there. */
 typedef struct ns_qkv_rope {
   void* kcache16;
   void* vcache16;
   const float* cos_sin;
   int heads, heads_kv, head_size, n_past, n_dims, mode;
   long long cache_step_sl, cache_step_head; /* cache element strides per position / per head */
+  int flags;                                /* NS_QKV_ROPE_* (0 = as before) */
 } ns_qkv_rope;
+/* Round 5: the same epilogue at PREFILL size (m > 16: the tiled GEMM, fused QKV as column segments; head_size a multiple of 4, matrix widths
+ * multiples of 128, cos_sin rows for all m positions).  k and v then need not exist as fp32 tensors at all - the attention reads the cache: */
+#define NS_QKV_ROPE_KV_CACHE_ONLY 1 /* m > 16 only: k (rotated) and v go to the fp16 cache alone, dC[1] / dC[2] are not written */
 int ns_hip_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, float freq_scale, float attn_factor,
                         float* dCosSin, void* stream);
 int ns_hip_fusion_qkv_rope_forward_x(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk,

@@ -47,7 +47,7 @@ class QkvRope(C.Structure):
     """ns_qkv_rope (include/ns_bestla.h)"""
     _fields_ = ([("kcache16", C.c_void_p), ("vcache16", C.c_void_p), ("cos_sin", C.c_void_p)] +
                 [(n, C.c_int) for n in ("heads", "heads_kv", "head_size", "n_past", "n_dims", "mode")] +
-                [("cache_step_sl", C.c_longlong), ("cache_step_head", C.c_longlong)])
+                [("cache_step_sl", C.c_longlong), ("cache_step_head", C.c_longlong), ("flags", C.c_int)])
 
 
 class AttnShape(C.Structure):

@@ -1227,6 +1227,25 @@ int ns_hip_fusion_qkv_rope_forward_x(const float* dA, const void* dA16, const ns
     return -1;
   }
   const ns_weight* ws[3] = {wq, wk, wv};
+  if (m > 16) {  // prefill size (round 5): the tiled GEMM's fused-QKV launch carries the epilogue; k / v optionally to the cache only
+    bool one = !ref_int8_for(wq) && !link && wq->kind != WK_F8;
+    for (int i = 0; i < 3; i++)
+      one &= ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize && ws[i]->scale_dt == wq->scale_dt &&
+             ws[i]->asym == wq->asym && ws[i]->qtype == wq->qtype && !ws[i]->shuf && !ws[i]->load_failed;
+    if (one) {
+      const bool cache_only = (rope->flags & NS_QKV_ROPE_KV_CACHE_ONLY) != 0;
+      SmallMArgs a{};
+      a.a = dA, a.a16 = dA16, a.lda = lda, a.m = m, a.ldc = ldc, a.nseg = 3;
+      for (int i = 0; i < 3; i++) a.seg[i] = {ws[i], (i == 0 || !cache_only) ? dC + size_t(i) * m * ldc : nullptr, nullptr};
+      a.epilogue = NS_EPI_NONE;
+      a.rope = rope;
+      const hipError_t e = launch_gemm2(a, (hipStream_t)stream);
+      if (e != hipErrorNotSupported) return hip_ok(e, "qkv+rope GEMM launch") ? 0 : -1;
+    }
+    if (getenv("NS_ROPE_GEMM_DEBUG")) fprintf(stderr, "qkv+rope at prefill size refused: one format %d, m %d, k %d, n %d %d %d, head_size %d, ldc %d\n", int(one), m, wq->k, wq->n, wk->n, wv->n, rope->head_size, ldc);
+    set_error("qkv+rope at prefill size: needs three weights of one integer / f4 format, plain whole-head RoPE, head_size a multiple of 4, matrix widths multiples of 128, 16-byte aligned outputs and no norm link");
+    return -1;
+  }
   bool same = !ref_int8_for(wq) && m <= 16 && dA16;
   for (int i = 0; i < 3; i++)
     same &= ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize &&

@@ -24,6 +24,7 @@
 #include <mutex>
 #include <vector>
 
+#include "../../include/ns_bestla.h"
 #include "ns_common.h"
 #include "ns_dev.h"
 
@@ -62,6 +63,13 @@ struct Gemm2Params {
   const float* d;
   int ldd;
   int nbn, cpx;  // column blocks; column blocks per XCD
+  // gemm3_kernel, fused QKV with RoPE(q, k) + kv-cache append as its epilogue (round 5; ns_qkv_rope at prefill size): segment 0 = q (rotated, fp32),
+  // 1 = k (rotated -> fp16 cache [+ fp32]), 2 = v (-> fp16 cache [+ fp32]); cos / sin pairs per (row, pair) from the caller's table
+  float seg_spre[3], seg_spost[3];  // fused QKV: each matrix's own factors (round 5: real models' q / k / v scales differ in range)
+  int rope_on, rope_hs, rope_npast;
+  const float2* rope_tab;
+  _Float16 *rope_kc, *rope_vc;
+  long long rope_csl, rope_chead;
   int ksplit;    // > 1: split-K (few output tiles): workgroup z = blockIdx.y takes chunks [z*cps, (z+1)*cps) and writes a
   int cps;       //      raw fp32 partial tile to `part` [ksplit][m][n]; gemm2_reduce_kernel sums them and applies the epilogue
   float* part;
@@ -371,6 +379,8 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void gemm3_kernel(const G
   const int n_cols = p.nseg > 1 ? p.seg_n[sg] : p.n;
   float* const c_out = p.nseg > 1 ? p.seg_c[sg] : p.c;
   _Float16* const c16_out = p.nseg > 1 ? p.seg_c16[sg] : p.c16;
+  // the weight's fp16-range factors (scales are multiplied by spre before the fp16 product, results by spost): per matrix in a fused launch
+  const float spre_ = p.nseg > 1 ? p.seg_spre[sg] : p.spre, spost_ = p.nseg > 1 ? p.seg_spost[sg] : p.spost;
   const int tile0 = DUAL ? bnl * 4 + w : bnl * kG3Tiles + wn * NIW, row0 = bm * BM;  // DUAL: the tile of BOTH matrices (output columns 16 tile0 ..)
 
   const Rsrc rq = p.nseg > 1 ? make_rsrc(p.seg_codes[sg], p.seg_codes_bytes[sg]) : make_rsrc(p.codes, p.codes_bytes);
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void gemm3_kernel(const G
       } else {
         v = cvt_f4x8(b.q[ni][js], p.lut);
       }
-      const _Float16 sh = (_Float16)(sc[js] * p.spre);
+      const _Float16 sh = (_Float16)(sc[js] * spre_);
       bf[ni] = v * half8_t{sh, sh, sh, sh, sh, sh, sh, sh};
     }
   };
@@ -641,7 +651,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void gemm3_kernel(const G
       float sc[4], zp[4];
       corr_decode<SPS, SK, ASYM, NJ>(b.c[pp][B8 ? h : 0], sc, zp);
       constexpr int js = B8 ? jj : t;
-      const _Float16 sh = (_Float16)(sc[js] * p.spre);
+      const _Float16 sh = (_Float16)(sc[js] * spre_);
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         half8_t v;
@@ -862,7 +872,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void gemm3_kernel(const G
           for (int ni = 0; ni < NIW; ni++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
-              parkw[(mi * 16 + 4 * g + r) * WROW + w * PC + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * p.spost;
+              parkw[(mi * 16 + 4 * g + r) * WROW + w * PC + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * spost_;
         __syncthreads();
         if (p.diag == 1) continue;
         const int rb = row0 + hh * 64 + w * 16;  // this wave's 16 rows of the half
@@ -929,14 +939,14 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void gemm3_kernel(const G
         for (int pp = 0; pp < NP; pp++)
 #pragma unroll
           for (int r = 0; r < 16; r++)
-            park[(mbl * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * kRowF + pp * 32 + (l & 31)] = acc32[2 * hh + mbl][pp][r] * p.spost;
+            park[(mbl * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * kRowF + pp * 32 + (l & 31)] = acc32[2 * hh + mbl][pp][r] * spost_;
     } else {
 #pragma unroll
       for (int mi = 0; mi < 4; mi++)
 #pragma unroll
         for (int ni = 0; ni < NIW; ni++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) park[(mi * 16 + 4 * g + r) * kRowF + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * p.spost;
+          for (int r = 0; r < 4; r++) park[(mi * 16 + 4 * g + r) * kRowF + ni * 16 + nn] = acc[4 * hh + mi][ni][r] * spost_;
     }
     // (LDS operations of one wave complete in order: no barrier between its own writes and reads)
     const int rbase = row0 + wm * 128 + hh * 64;
@@ -948,6 +958,24 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void gemm3_kernel(const G
         float4 v = *reinterpret_cast<const float4*>(park + rl * kRowF + (l % kLpr) * 4);
         if (p.ksplit > 1) {  // raw partial; the operator is applied by gemm2_reduce_kernel
           *reinterpret_cast<float4*>(p.part + (size_t(blockIdx.y) * p.m + row) * p.n + col) = v;
+          continue;
+        }
+        if (p.rope_on) {  // fused QKV + RoPE + cache append: rope_qkv_append_tab_kernel's arithmetic on the four columns (two adjacent pairs) of this lane
+          typedef _Float16 half4r_t __attribute__((ext_vector_type(4)));
+          const int hd = col / p.rope_hs, dcol = col - hd * p.rope_hs;
+          if (sg < 2) {
+#pragma clang fp contract(off)  // (rope_kernel's products and sums are rounded one by one: ns_quant.hip is built with -ffp-contract=off, this file is not)
+            const float4 cs = *reinterpret_cast<const float4*>(p.rope_tab + (size_t(row) * size_t(p.rope_hs >> 1) + size_t(dcol >> 1)));
+            const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            // (plain operators: hipcc's __fmul_rn / __fadd_rn are inline x * y / x + y carrying their header's contraction mode, which fuses them here)
+            const float p0 = x0 * cs.x, p1 = x1 * cs.y, p2 = x0 * cs.y, p3 = x1 * cs.x, p4 = x2 * cs.z, p5 = x3 * cs.w, p6 = x2 * cs.w, p7 = x3 * cs.z;
+            v.x = p0 - p1, v.y = p2 + p3, v.z = p4 - p5, v.w = p6 + p7;
+          }
+          if (sg > 0) {
+            _Float16* cell = (sg == 1 ? p.rope_kc : p.rope_vc) + (long long)(p.rope_npast + row) * p.rope_csl + (long long)hd * p.rope_chead + dcol;
+            *reinterpret_cast<half4r_t*>(cell) = half4r_t{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+          }
+          if (c_out) *reinterpret_cast<float4*>(c_out + size_t(row) * p.ldc + col) = v;
           continue;
         }
         float4 dv = {0.f, 0.f, 0.f, 0.f};
@@ -1712,8 +1740,9 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
       const ns_weight* w = a.seg[i].w;
       if (w->k != w0->k || w->kind != w0->kind || w->sps != w0->sps || w->scale_dt != w0->scale_dt || w->asym != w0->asym ||
           w->ksteps != w0->ksteps || w->qstride != w0->qstride || w->sstride != w0->sstride || w->zstride != w0->zstride ||
-          w->srows != w0->srows || w->g2_pre != w0->g2_pre || w->g2_post != w0->g2_post || w->qtype != w0->qtype)
+          w->srows != w0->srows || w->qtype != w0->qtype)
         return hipErrorNotSupported;
+      p.seg_spre[i] = w->g2_pre, p.seg_spost[i] = w->g2_post;
       p.seg_bn0[i] = bn0;
       p.seg_n[i] = w->n;
       p.seg_codes[i] = w->codes, p.seg_scales[i] = w->scales, p.seg_zps[i] = w->zps;
@@ -1724,6 +1753,24 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
       bn0 += (w->ntiles + kG2Tiles - 1) / kG2Tiles;
     }
     p.nbn = bn0;
+    if (a.rope) {  // RoPE + kv-cache append in the epilogue: plain whole-head RoPE, whole 128-column blocks per matrix, 16-byte fp32 / 8-byte cache stores
+      const ns_qkv_rope& r = *a.rope;
+      const bool ok = a.nseg == 3 && r.mode == 0 && r.n_dims == r.head_size && r.head_size >= 4 && (r.head_size & 3) == 0 && r.kcache16 && r.vcache16 && r.cos_sin &&
+                      r.n_past >= 0 && a.seg[0].w->n == r.heads * r.head_size && a.seg[1].w->n == r.heads_kv * r.head_size &&
+                      a.seg[2].w->n == r.heads_kv * r.head_size && a.seg[0].w->n % 128 == 0 && a.seg[1].w->n % 128 == 0 && (a.ldc & 3) == 0 &&
+                      (r.cache_step_sl & 3) == 0 && (r.cache_step_head & 3) == 0 && (reinterpret_cast<uintptr_t>(r.kcache16) & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(r.vcache16) & 7) == 0 && (reinterpret_cast<uintptr_t>(r.cos_sin) & 15) == 0 && a.seg[0].c &&
+                      (reinterpret_cast<uintptr_t>(a.seg[0].c) & 15) == 0 && (!a.seg[1].c || (reinterpret_cast<uintptr_t>(a.seg[1].c) & 15) == 0) &&
+                      (!a.seg[2].c || (reinterpret_cast<uintptr_t>(a.seg[2].c) & 15) == 0) && !a.seg[0].c16 && !a.seg[1].c16 && !a.seg[2].c16 &&
+                      a.epilogue == NS_EPI_NONE && !kG3M32;
+      if (!ok) return hipErrorNotSupported;
+      p.rope_on = 1, p.rope_hs = r.head_size, p.rope_npast = r.n_past;
+      p.rope_tab = reinterpret_cast<const float2*>(r.cos_sin);
+      p.rope_kc = static_cast<_Float16*>(r.kcache16), p.rope_vc = static_cast<_Float16*>(r.vcache16);
+      p.rope_csl = r.cache_step_sl, p.rope_chead = r.cache_step_head;
+    }
+  } else if (a.rope) {
+    return hipErrorNotSupported;
   }
   p.cpx = (p.nbn + 7) / 8;
   // third-generation kernel (256-row tiles, A by LDS DMA, B dequantised in registers): from 192 rows up; below that
@@ -1756,7 +1803,7 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
       if (!p.c16) return hipErrorInvalidValue;
       if (p.bm3 == 256 && !p.tall3) p.bm3 = 128;
     }
-    p.wide = (p.bm3 != 256 || p.tall3) && !kG3M32 && (wide_on != 0 || (!p.c && p.nseg <= 1));
+    p.wide = (p.bm3 != 256 || p.tall3) && !kG3M32 && !p.rope_on && (wide_on != 0 || (!p.c && p.nseg <= 1));  // (the RoPE epilogue lives in the per-wave form)
     const int nbm3 = (a.m + p.bm3 - 1) / p.bm3;
     p.ksplit = 1;
     p.cps = p.nchunks;
@@ -1793,6 +1840,7 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
     }
 #undef NS_G3DISPATCH
   }
+  if (p.rope_on) return hipErrorNotSupported;  // (the RoPE epilogue is gemm3_kernel's)
   const int nbm = (a.m + kG2BM - 1) / kG2BM;
   // few output tiles (M up to a few hundred rows): split K so that the launch still fills the chip
   p.ksplit = 1;

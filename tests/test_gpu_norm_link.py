@@ -200,3 +200,62 @@ def test_qkv_with_rope_and_kv_append_epilogue(L, pkg, nso, m, n_past, heads, hkv
     assert L.ns_hip_fusion_qkv_rope_forward_x(x.data_ptr(), x16.data_ptr(), wq.h, wk.h, wv.h, qkv_b.data_ptr(), m, d, ldc,
                                               C.byref(lk), C.byref(rp3), st) != 0
     L.ns_hip_reset_error()
+
+
+@pytest.mark.parametrize("m,heads,hkv,hs,qt", [(300, 8, 8, 128, None), (2048, 8, 2, 128, None), (77, 16, 4, 64, "s8"), (130, 4, 4, 96, None)])
+def test_qkv_rope_cache_append_as_the_tiled_gemms_epilogue(L, pkg, nso, m, heads, hkv, hs, qt):
+    """ns_hip_fusion_qkv_rope_forward_x at PREFILL size (round 5): the fused-QKV launch of the tiled GEMM rotates q and k and writes k / v to the fp16 cache
+    in its epilogue — the same bits as three GEMMs + ns_hip_rope_qkv_append, with and without the fp32 k / v tensors (NS_QKV_ROPE_KV_CACHE_ONLY)."""
+    import torch
+    rng = np.random.default_rng(m + hs)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d, dkv, n_past = heads * hs, hkv * hs, 19
+    if dkv % 128 or d % 128:
+        pytest.skip("matrix widths must be whole 128-column blocks")
+    ctx = n_past + m + 5
+    q8 = nso.S8 if qt == "s8" else None
+    wq, _a, _0 = _w(pkg, nso, rng, d, d, st, q8)
+    wk, Wk, _1 = _w(pkg, nso, rng, dkv, d, st, q8)
+    wv, _b, _2 = _w(pkg, nso, rng, dkv, d, st, q8)
+    x = torch.from_numpy(rng.standard_normal((m, d)).astype(np.float32)).cuda()
+    x16 = x.half()
+    # separate operators: the fused-QKV GEMM launch (the same tiles, never split along K), then RoPE + append on packed copies of its outputs
+    ldc = d
+    qkv_a = torch.zeros(3, m, ldc, device="cuda")
+    pkg.check(L.ns_hip_fusion_qkv_forward_h(x.data_ptr(), x16.data_ptr(), wq.h, wk.h, wv.h, qkv_a.data_ptr(), None, m, d, ldc, st))
+    q_a, k_a, v_a = qkv_a[0].contiguous(), qkv_a[1][:, :dkv].contiguous(), qkv_a[2][:, :dkv].contiguous()
+    v_raw = v_a.clone()
+    kc_a = torch.zeros(1, ctx, hkv, hs, device="cuda", dtype=torch.float16)
+    vc_a = torch.zeros_like(kc_a)
+    pkg.check(L.ns_hip_rope_qkv_append(q_a.data_ptr(), k_a.data_ptr(), v_a.data_ptr(), kc_a.data_ptr(), vc_a.data_ptr(), m, heads, hkv, hs, n_past, hs, 0,
+                                       10000.0, 1.0, 0.0, 1.0, hkv * hs, hs, st))
+    tab = torch.zeros(m, hs // 2, 2, device="cuda")
+    pkg.check(L.ns_hip_rope_cos_sin(m, n_past, hs, 10000.0, 1.0, 1.0, tab.data_ptr(), st))
+    for flags in (0, 1):
+        qkv_b = torch.full((3, m, ldc), 7.0, device="cuda")
+        kc_b, vc_b = torch.zeros_like(kc_a), torch.zeros_like(kc_a)
+        rp = pkg.QkvRope(kc_b.data_ptr(), vc_b.data_ptr(), tab.data_ptr(), heads, hkv, hs, n_past, hs, 0, hkv * hs, hs, flags)
+        pkg.check(L.ns_hip_fusion_qkv_rope_forward_x(x.data_ptr(), x16.data_ptr(), wq.h, wk.h, wv.h, qkv_b.data_ptr(), m, d, ldc, None, C.byref(rp), st))
+        torch.cuda.synchronize()
+        assert torch.equal(qkv_b[0], q_a), flags
+        assert torch.equal(kc_b, kc_a) and torch.equal(vc_b, vc_a), flags
+        assert torch.count_nonzero(kc_b[0, n_past:n_past + m]) > 0 and torch.count_nonzero(kc_b[0, :n_past]) == 0
+        if flags == 0:  # k comes out rotated, v as it is — the fp32 tensors a graph may read
+            kr = kc_a[0, n_past:n_past + m].reshape(m, dkv).float()
+            assert torch.equal(qkv_b[1][:, :dkv].half().float(), kr) and torch.equal(qkv_b[2][:, :dkv], v_raw)
+        else:
+            assert bool((qkv_b[1] == 7.0).all()) and bool((qkv_b[2] == 7.0).all())
+    # against fp64: GEMM -> rope (closed form)
+    kr = (x16.float().cpu().numpy().astype(np.float64) @ Wk).reshape(m, hkv, hs)
+    ts = 10000.0 ** (-2.0 / hs)
+    ref = kr.copy()
+    for i in range(m):
+        th = (n_past + i) * ts ** np.arange(hs // 2)
+        c, s = np.cos(th), np.sin(th)
+        ref[i, :, 0::2] = kr[i, :, 0::2] * c - kr[i, :, 1::2] * s
+        ref[i, :, 1::2] = kr[i, :, 0::2] * s + kr[i, :, 1::2] * c
+    assert nso.rel_l2(kc_b[0, n_past:n_past + m].float().cpu().numpy(), ref) < 2e-3
+    # refused at this size: NeoX pairs (they are 64 columns apart: other lanes' columns)
+    rp2 = pkg.QkvRope(kc_b.data_ptr(), vc_b.data_ptr(), tab.data_ptr(), heads, hkv, hs, n_past, hs, 2, hkv * hs, hs, 0)
+    assert L.ns_hip_fusion_qkv_rope_forward_x(x.data_ptr(), x16.data_ptr(), wq.h, wk.h, wv.h, qkv_b.data_ptr(), m, d, ldc, None, C.byref(rp2), st) != 0
+    L.ns_hip_reset_error()
