@@ -696,11 +696,12 @@ def full_prefill(chain, pkg, m=2048, iters=5):
         if PREFILL_ROPE_IN_QKV:
             ck(L.ns_hip_rope_cos_sin(m, 0, hs, 10000.0, 1.0, 1.0, rope_tab.data_ptr(), st))
         for il, lw in enumerate(chain.layers):
-            ck(L.ns_hip_norm_mul_h(m, d, True, 1e-5, xin.data_ptr(), gam.data_ptr(), b["h"].data_ptr(), sh["h"].data_ptr(), st))
+            # (the norms write their fp16 result only where the tiled GEMM behind them multiplies fp16 activations as they are: PREFILL_ROPE_IN_QKV)
+            ck(L.ns_hip_norm_mul_h(m, d, True, 1e-5, xin.data_ptr(), gam.data_ptr(), None if PREFILL_ROPE_IN_QKV else b["h"].data_ptr(), sh["h"].data_ptr(), st))
             if PREFILL_ROPE_IN_QKV:
                 # one launch: the fused-QKV GEMM rotates q / k and appends k, v to the fp16 cache in its epilogue; k and v are never fp32 tensors
                 rp = pkg.QkvRope(kc[il].data_ptr(), vc[il].data_ptr(), rope_tab.data_ptr(), heads, heads, hs, 0, hs, 0, heads * hs, hs, 1)
-                ck(L.ns_hip_fusion_qkv_rope_forward_x(b["h"].data_ptr(), sh["h"].data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
+                ck(L.ns_hip_fusion_qkv_rope_forward_x(None, sh["h"].data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
                                                       b["qkv"].data_ptr(), m, d, d, None, C.byref(rp), st))
             else:
                 ck(L.ns_hip_fusion_qkv_forward_h(b["h"].data_ptr(), sh["h"].data_ptr(), lw["q"].h, lw["k"].h, lw["v"].h,
@@ -712,9 +713,9 @@ def full_prefill(chain, pkg, m=2048, iters=5):
             ck(L.ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(C.byref(a), sh["att"].data_ptr(), st))
             ck(L.ns_hip_f32f32_forward_h(b["att"].data_ptr(), sh["att"].data_ptr(), lw["o"].h, b["r1"].data_ptr(), None, m, d, d,
                                          pkg.EPI_ADD, xin.data_ptr(), d, st))
-            ck(L.ns_hip_norm_mul_h(m, d, True, 1e-5, b["r1"].data_ptr(), gam.data_ptr(), b["h2"].data_ptr(), sh["h"].data_ptr(), st))
+            ck(L.ns_hip_norm_mul_h(m, d, True, 1e-5, b["r1"].data_ptr(), gam.data_ptr(), None if PREFILL_ROPE_IN_QKV else b["h2"].data_ptr(), sh["h"].data_ptr(), st))
             # gate / up tile pairs, one launch, the product in fp16 only; the down projection (+ residual) multiplies it as it is
-            ck(L.ns_hip_fusion_ffn3_gateup_h(b["h2"].data_ptr(), sh["h"].data_ptr(), lw["w1"].h, lw["w3"].h, None, None, sh["t2"].data_ptr(),
+            ck(L.ns_hip_fusion_ffn3_gateup_h(None if PREFILL_ROPE_IN_QKV else b["h2"].data_ptr(), sh["h"].data_ptr(), lw["w1"].h, lw["w3"].h, None, None, sh["t2"].data_ptr(),
                                              m, pkg.EPI_SILU, st))
             ck(L.ns_hip_f32f32_forward_h(None, sh["t2"].data_ptr(), lw["w2"].h, b["x"].data_ptr(), None, m, ff, d,
                                          pkg.EPI_ADD, b["r1"].data_ptr(), d, st))

@@ -1218,7 +1218,7 @@ int ns_hip_fusion_qkv_rope_forward_x(const float* dA, const void* dA16, const ns
                                      const ns_weight* wv, float* dC, int m, int lda, int ldc, const ns_norm_link* link,
                                      const ns_qkv_rope* rope, void* stream) {
   if (!have_device()) return -1;
-  if (!wq || !wk || !wv || !dA || !dC || !rope || m < 1) {
+  if (!wq || !wk || !wv || (!dA && !(dA16 && m > 16)) || !dC || !rope || m < 1) {  // (dA may be NULL at prefill size: fp16-only activations)
     set_error("qkv+rope: null argument");
     return -1;
   }
@@ -1363,7 +1363,7 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
                                 float* dTmp1, float* dTmp2, void* dTmp2_16, int seq, int act, const ns_norm_link* link,
                                 void* stream) {
   if (!have_device()) return -1;
-  if (!w1 || !w3 || (!dTmp2 && !dTmp2_16) || !dA) {
+  if (!w1 || !w3 || (!dTmp2 && !dTmp2_16) || (!dA && !dA16)) {  // (dA may be NULL at GEMM size: fp16-only activations, as for the single forward)
     set_error("ffn3 gate/up: null argument");
     return -1;
   }
@@ -1388,6 +1388,10 @@ int ns_hip_fusion_ffn3_gateup_x(const float* dA, const void* dA16, const ns_weig
     const hipError_t e = launch_gemm2(a, st);
     if (e == hipSuccess) return 0;
     if (e != hipErrorNotSupported) return hip_ok(e, "ffn gate/up GEMM launch") ? 0 : -1;
+  }
+  if (!dA) {
+    set_error("ffn3 gate/up: fp16-only activations need the tiled kernel's fused launch (matching formats, more than 16 rows, K a multiple of 64, 16-byte aligned)");
+    return -1;
   }
   if (!dTmp2) {  // the paths below produce the fp32 product
     dTmp2 = static_cast<float*>(stream_scratch(st, size_t(seq) * fmid * 4, 9));
@@ -2056,7 +2060,7 @@ int ns_hip_layernormalization(int norm_count, int norm_size, bool isrms, float e
 int ns_hip_norm_mul_h(int norm_count, int norm_size, bool isrms, float epsilon, const float* dIn, const float* dGamma,
                       float* dOut, void* dOut16, void* stream) {
   if (!have_device()) return -1;
-  if (!dIn || !dOut || norm_count < 0 || norm_size <= 0) {
+  if (!dIn || (!dOut && !dOut16) || norm_count < 0 || norm_size <= 0) {  // (dOut may be NULL: the fp16 shadow alone)
     set_error("norm_mul: invalid argument");
     return -1;
   }

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ in,
       const int i = (c * 256 + threadIdx.x) * 4;
       if (i >= size) continue;
       const float4 y = {fin(v[c].x, i), fin(v[c].y, i + 1), fin(v[c].z, i + 2), fin(v[c].w, i + 3)};
-      *reinterpret_cast<float4*>(dst + i) = y;
+      if (out) *reinterpret_cast<float4*>(dst + i) = y;  // (round 5: the fp16 shadow alone where the consumer is this library's next GEMM)
       if (out_plain) {
         const float4 yp = rms ? float4{v[c].x * inv, v[c].y * inv, v[c].z * inv, v[c].w * inv}
                               : float4{(v[c].x - mean) * inv, (v[c].y - mean) * inv, (v[c].z - mean) * inv, (v[c].w - mean) * inv};
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ in,
   } else {
     for (int i = threadIdx.x; i < size; i += 256) {
       const float y = fin(src[i], i);
-      dst[i] = y;
+      if (out) dst[i] = y;
       if (out16) out16[size_t(blockIdx.x) * size + i] = (_Float16)y;
       if (out_plain) out_plain[size_t(blockIdx.x) * size + i] = rms ? src[i] * inv : (src[i] - mean) * inv;
     }

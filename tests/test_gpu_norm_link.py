@@ -259,3 +259,43 @@ def test_qkv_rope_cache_append_as_the_tiled_gemms_epilogue(L, pkg, nso, m, heads
     rp2 = pkg.QkvRope(kc_b.data_ptr(), vc_b.data_ptr(), tab.data_ptr(), heads, hkv, hs, n_past, hs, 2, hkv * hs, hs, 0)
     assert L.ns_hip_fusion_qkv_rope_forward_x(x.data_ptr(), x16.data_ptr(), wq.h, wk.h, wv.h, qkv_b.data_ptr(), m, d, ldc, None, C.byref(rp2), st) != 0
     L.ns_hip_reset_error()
+
+
+def test_norm_with_the_fp16_result_only_and_gemms_on_fp16_only_activations(L, pkg, nso):
+    """Prefill plumbing (round 5): ns_hip_norm_mul_h with dOut = NULL writes the fp16 shadow alone; the fused gate/up and QKV + RoPE launches of the tiled GEMM
+    take dA = NULL (fp16 activations as they are) — the same bits as with the fp32 tensors present."""
+    import torch
+    rng = np.random.default_rng(77)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    m, d, ff, heads, hs = 200, 512, 1408, 4, 128
+    gam = torch.from_numpy((1.0 + 0.2 * rng.standard_normal(d)).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.standard_normal((m, d)).astype(np.float32)).cuda()
+    h32, h16a, h16b = torch.zeros(m, d, device="cuda"), torch.zeros(m, d, device="cuda", dtype=torch.float16), torch.zeros(m, d, device="cuda", dtype=torch.float16)
+    pkg.check(L.ns_hip_norm_mul_h(m, d, True, 1e-5, x.data_ptr(), gam.data_ptr(), h32.data_ptr(), h16a.data_ptr(), st))
+    pkg.check(L.ns_hip_norm_mul_h(m, d, True, 1e-5, x.data_ptr(), gam.data_ptr(), None, h16b.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(h16a, h16b) and torch.equal(h16a, h32.half())
+    w1, _a, _0 = _w(pkg, nso, rng, ff, d, st)
+    w3, _b, _1 = _w(pkg, nso, rng, ff, d, st)
+    t_a, t_b = torch.zeros(m, ff, device="cuda", dtype=torch.float16), torch.zeros(m, ff, device="cuda", dtype=torch.float16)
+    pkg.check(L.ns_hip_fusion_ffn3_gateup_h(h32.data_ptr(), h16a.data_ptr(), w1.h, w3.h, None, None, t_a.data_ptr(), m, pkg.EPI_SILU, st))
+    pkg.check(L.ns_hip_fusion_ffn3_gateup_h(None, h16a.data_ptr(), w1.h, w3.h, None, None, t_b.data_ptr(), m, pkg.EPI_SILU, st))
+    torch.cuda.synchronize()
+    assert torch.equal(t_a, t_b) and torch.count_nonzero(t_b) > 0
+    wq, _c, _2 = _w(pkg, nso, rng, d, d, st)
+    wk, _d, _3 = _w(pkg, nso, rng, d, d, st)
+    wv, _e, _4 = _w(pkg, nso, rng, d, d, st)
+    tab = torch.zeros(m, hs // 2, 2, device="cuda")
+    pkg.check(L.ns_hip_rope_cos_sin(m, 0, hs, 10000.0, 1.0, 1.0, tab.data_ptr(), st))
+    outs = []
+    for a32 in (h32.data_ptr(), None):
+        q = torch.zeros(3, m, d, device="cuda")
+        kc, vc = torch.zeros(1, m, heads, hs, device="cuda", dtype=torch.float16), torch.zeros(1, m, heads, hs, device="cuda", dtype=torch.float16)
+        rp = pkg.QkvRope(kc.data_ptr(), vc.data_ptr(), tab.data_ptr(), heads, heads, hs, 0, hs, 0, heads * hs, hs, 1)
+        pkg.check(L.ns_hip_fusion_qkv_rope_forward_x(a32, h16a.data_ptr(), wq.h, wk.h, wv.h, q.data_ptr(), m, d, d, None, C.byref(rp), st))
+        torch.cuda.synchronize()
+        outs.append((q[0].clone(), kc, vc))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])) and torch.count_nonzero(outs[1][1]) > 0
+    # fp16-only activations at DECODE size have no kernel that takes them: refused, not guessed
+    assert L.ns_hip_fusion_ffn3_gateup_h(None, h16a.data_ptr(), w1.h, w3.h, None, None, t_b.data_ptr(), 1, pkg.EPI_SILU, st) != 0
+    L.ns_hip_reset_error()
