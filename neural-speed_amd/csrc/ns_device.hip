@@ -318,6 +318,42 @@ __global__ void mha_f32_merge_kernel(const float* ws, float* o, int nsplit, int 
   if (o16) o16[row * hs + t] = (_Float16)y;  // (replayed route: the projection behind it streams fp16 activations)
 }
 
+// ---- prompt-sized calls of the device-layout attention (round 5): the kernels above serve one query row per workgroup — right for a decode step,
+//      but a 1500-token prompt re-read its whole K / V once per row (184 ms through the reference's unchanged model_eval, 5.7 ms per layer).  From
+//      kMhaPromptRows rows on the call's K rows and (transposed) V rows are converted ONCE into fp16 [batch][head][position][head_size] scratch and the
+//      matrix-core prefill kernels of ns_attn.hip run on them (ns_hip_attn_fp32_fp16_fp16_fp32_forward: 128 query rows per workgroup, K / V tiles shared
+//      through LDS).  K / V are rounded to fp16 there, as in the reference's own CPU caches (its default kv type is fp16); decode steps stay on the fp32 kernels.
+constexpr int kMhaPromptRows = 32;
+// K [heads][n_ctx][hs] fp32 -> [heads][keys][hs] fp16 (rows 0 .. keys of every head), 4 elements per thread
+__global__ void mha_k_to_f16_kernel(const float* __restrict__ k, _Float16* __restrict__ out, int heads, int n_ctx, int keys, int hs) {
+  const size_t per_head = size_t(keys) * hs / 4;
+  const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= per_head * heads) return;
+  const size_t h = gid / per_head, e = (gid - h * per_head) * 4;
+  const dfloat4 v = *reinterpret_cast<const dfloat4*>(k + h * size_t(n_ctx) * hs + e);
+  typedef _Float16 dhalf4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<dhalf4*>(out + h * size_t(keys) * hs + e) = dhalf4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+}
+// V [heads][hs][n_ctx] fp32 (transposed) -> [heads][keys][hs] fp16: 32 x 32 tiles through LDS (reads run along the positions, writes along the head dims)
+__global__ __launch_bounds__(256) void mha_vt_to_f16_kernel(const float* __restrict__ v, _Float16* __restrict__ out, int n_ctx, int keys, int hs) {
+  __shared__ float tile[32][33];
+  const int h = blockIdx.z, j0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* src = v + size_t(h) * hs * n_ctx;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int d = d0 + ty + 8 * r, j = j0 + tx;
+    tile[ty + 8 * r][tx] = (d < hs && j < keys) ? src[size_t(d) * n_ctx + j] : 0.f;
+  }
+  __syncthreads();
+  _Float16* dst = out + size_t(h) * keys * hs;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int j = j0 + ty + 8 * r, d = d0 + tx;
+    if (j < keys && d < hs) dst[size_t(j) * hs + d] = (_Float16)tile[tx][ty + 8 * r];
+  }
+}
+
 // what bestla_device_load_storage leaves in the tensor object behind a device-resident BTLA weight
 // (ne_layers.c:946-949 reserves bestla_device_storage_size() bytes there).  It starts with a word no BTLA blob can start
 // with (a blob's first field is its size, bestla_storage.h:250-317): the host-pointer entry points (_support, forward)
@@ -731,9 +767,42 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
     return ns::route_submit(op);
   }
   if (ns_hip_lazy_flush() != 0) return -1;
+  const ns::Affine aff = ns::g_affine;
+  // ---- a prompt's rows: fp16 copies of the call's K / V rows, then the matrix-core prefill attention (see kMhaPromptRows) ----
+  static const bool no_prompt_path = getenv("NS_MHA_PROMPT_MFMA") && atoi(getenv("NS_MHA_PROMPT_MFMA")) == 0;  // diagnostics (A/B)
+  if (!no_prompt_path && !aff.k && seq >= ns::kMhaPromptRows && head_size % 8 == 0 && head_size <= 256 && (size_t(seq_all) * head_size) % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(dK) & 15) == 0 && size_t(batch) * heads_kv <= 65535 && size_t(seq) * heads * head_size < (size_t(1) << 31) &&
+      size_t(seq_all) * heads_kv * head_size < (size_t(1) << 31)) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t kv_elems = size_t(batch) * heads_kv * seq_all * head_size;
+    _Float16* k16 = static_cast<_Float16*>(ns::stream_scratch(st, kv_elems * 2, 26));
+    _Float16* v16 = static_cast<_Float16*>(ns::stream_scratch(st, kv_elems * 2, 27));
+    if (k16 && v16) {
+      const int hb = batch * heads_kv;
+      const size_t units = kv_elems / 4;
+      hipLaunchKernelGGL(ns::mha_k_to_f16_kernel, dim3(unsigned((units + 255) / 256)), dim3(256), 0, st, dK, k16, hb, n_ctx, seq_all, head_size);
+      hipLaunchKernelGGL(ns::mha_vt_to_f16_kernel, dim3(unsigned((seq_all + 31) / 32), unsigned((head_size + 31) / 32), unsigned(hb)), dim3(256), 0, st, dV, v16,
+                         n_ctx, seq_all, head_size);
+      if (hipGetLastError() != hipSuccess) {
+        ns::set_error("mha_f32: fp16 conversion launch failed");
+        return -1;
+      }
+      attn_fp32_fp16_fp16_fp32_fwd_args_t a;
+      memset(&a, 0, sizeof(a));
+      a.Q = const_cast<float*>(dQ), a.K = reinterpret_cast<uint16_t*>(k16), a.V = reinterpret_cast<uint16_t*>(v16), a.dst = dO;
+      a.Q_sc = a.K_sc = a.V_sc = a.dst_sc = 1.f;
+      a.QK_scale = scale;
+      a.attn_flags = masked ? NS_ATTN_FLAG_IS_CAUSAL : NS_ATTN_FLAG_NONE;
+      a.batch_size = batch, a.head_num = heads, a.heads_kv = heads_kv, a.head_size = head_size, a.sl_q = seq, a.sl_kv = seq_all;
+      a.step_q_bs = seq * heads * head_size, a.step_q_head_num = head_size, a.step_q_sl = heads * head_size;
+      a.step_k_bs = heads_kv * seq_all * head_size, a.step_k_head_num = seq_all * head_size, a.step_k_sl = head_size, a.step_k_head_size = 1;
+      a.step_v_bs = a.step_k_bs, a.step_v_head_num = a.step_k_head_num, a.step_v_sl = head_size, a.step_v_head_size = 1;
+      a.step_dst_bs = a.step_q_bs, a.step_dst_head_num = head_size, a.step_dst_sl = heads * head_size;
+      return ns_hip_attn_fp32_fp16_fp16_fp32_forward(&a, stream);
+    }
+  }
   // ---- the context split over workgroups: head sizes 64 / 128 / 256, from two 128-key ranges on ----
   static const bool no_split = getenv("NS_MHA_NO_SPLIT") != nullptr;  // diagnostics (A/B)
-  const ns::Affine aff = ns::g_affine;
   if (aff.k && !(seq == 1 && (head_size == 64 || head_size == 128 || head_size == 256) && n_ctx >= seq_all)) {
     ns::set_error("mha_f32: a moving context length needs the context-split kernel (decode step, head size 64 / 128 / 256)");
     return -1;

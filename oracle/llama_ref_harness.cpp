@@ -127,6 +127,8 @@ int nellama_generate(const char* model_path, const int* prompt, int n_prompt, in
 /* wall time of every single-token eval of the last nellama_generate_dev call, in order (the mean handed back by the call includes the
  * eval at whose end the device route captures its replay plan: scripts read the median / the steady tail from here) */
 static std::vector<double> g_eval_us;
+static double g_prompt_us = 0.0; /* wall time of the prompt's eval (all its tokens in one model_eval) of the last nellama_generate_dev call */
+double nellama_prompt_us(void) { return g_prompt_us; }
 int nellama_eval_times(double* out, int cap) {
   const int n = static_cast<int>(g_eval_us.size()) < cap ? static_cast<int>(g_eval_us.size()) : cap;
   for (int i = 0; i < n; i++) out[i] = g_eval_us[i];
@@ -175,6 +177,7 @@ int nellama_generate_dev(const char* model_path, const int* prompt, int n_prompt
     }
     if (cur.size() == 1 && step > 1) us += double(ne_time_us() - t0), timed++;
     if (cur.size() == 1) g_eval_us.push_back(double(ne_time_us() - t0));
+    else if (step == 0) g_prompt_us = double(ne_time_us() - t0);
     n_past += static_cast<int>(cur.size());
     const float* logits = model_get_logits(ctx);
     int best = 0;

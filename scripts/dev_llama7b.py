@@ -94,6 +94,10 @@ def main(mode="device", n_new="24", n_ctx="512"):
         nt = min(4096, ref.nellama_eval_times(times, 4096))
         ev = sorted(times[i] for i in range(nt))
         tail = [times[i] for i in range(nt // 2, nt)]
+        if hasattr(ref, "nellama_prompt_us"):
+            ref.nellama_prompt_us.restype = C.c_double
+            pus = ref.nellama_prompt_us()
+            print('{"prompt_eval": {"tokens": %d, "ms": %.2f, "tokens_per_s": %.0f}}' % (len(prompt), pus / 1e3, len(prompt) * 1e6 / max(1.0, pus)), flush=True)
         rs = (C.c_uint64 * 8)()
         hip.ns_hip_route_stats(rs)
         print('{"replay": {"tokens_replayed": %d, "tokens_eager": %d, "plans": %d, "fallbacks": %d, "launches_per_token": %d, "captured_launches": %d, '
