@@ -141,3 +141,43 @@ def test_in_place_multiplies_are_not_fused(fns, pkg):
     pkg.check(_mul(L, L.ns_hip_lazy_mul, s, up, s, st))
     torch.cuda.synchronize()
     assert torch.equal(s, p_ref)
+
+
+def test_dense_and_strided_binary_nodes_compute_the_same_values(L, pkg):
+    """ns_hip_binary_nd_f32: dense tensors of one shape and dense-tensor x row-vector take a four-elements-per-thread kernel (round 5), everything else the
+    strided one; both are exact fp32 adds / multiplies."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    ll4 = C.POINTER(C.c_longlong)
+    L.ns_hip_binary_nd_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, ll4, ll4, ll4, ll4, ll4, C.c_void_p]
+    L.ns_hip_binary_nd_f32.restype = C.c_int
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ll = lambda *v: (C.c_longlong * 4)(*v)
+    rng = np.random.default_rng(4)
+    rows, cols = 300, 512
+    a = torch.from_numpy(rng.standard_normal((rows, cols)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.standard_normal((rows, cols)).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal(cols).astype(np.float32)).cuda()
+    ne, nb = ll(cols, rows, 1, 1), ll(4, 4 * cols, 4 * cols * rows, 4 * cols * rows)
+    d = torch.zeros_like(a)
+    for op, ref in ((0, a + b), (1, a * b)):  # dense, same shape
+        d.zero_()
+        pkg.check(L.ns_hip_binary_nd_f32(op, a.data_ptr(), b.data_ptr(), d.data_ptr(), ne, nb, ne, nb, nb, st))
+        torch.cuda.synchronize()
+        assert torch.equal(d, ref)
+    d.zero_()  # dense x row vector (the mul by a norm weight)
+    pkg.check(L.ns_hip_binary_nd_f32(1, a.data_ptr(), g.data_ptr(), d.data_ptr(), ne, nb, ll(cols, 1, 1, 1), ll(4, 4 * cols, 4 * cols, 4 * cols), nb, st))
+    torch.cuda.synchronize()
+    assert torch.equal(d, a * g)
+    # a view with a row stride (every second row of a taller tensor): the strided kernel
+    tall = torch.from_numpy(rng.standard_normal((2 * rows, cols)).astype(np.float32)).cuda()
+    d.zero_()
+    pkg.check(L.ns_hip_binary_nd_f32(0, tall.data_ptr(), b.data_ptr(), d.data_ptr(), ne, ll(4, 8 * cols, 8 * cols * rows, 8 * cols * rows), ne, nb, nb, st))
+    torch.cuda.synchronize()
+    assert torch.equal(d, tall[0::2] + b)
+    # in place (dst == src0), as ne_add_inplace hands it over
+    a2 = a.clone()
+    pkg.check(L.ns_hip_binary_nd_f32(0, a2.data_ptr(), b.data_ptr(), a2.data_ptr(), ne, nb, ne, nb, nb, st))
+    torch.cuda.synchronize()
+    assert torch.equal(a2, a + b)
