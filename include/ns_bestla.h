@@ -236,6 +236,10 @@ int ns_hip_get_compute_mode(void);
  *   "g3_min_m"        rows from which the tiled prefill GEMM is used inside its envelope (0 = default)
  * Returns 0, or -1 for an unknown key. */
 int ns_hip_set_tuning(const char* key, int value);
+/* Loads the code objects of the hot kernels (tiled GEMM, decode GEMV, attention, the operators between them) for the current device now instead of at the
+ * first launch from each (36 + 21 + ... ms otherwise paid by the first prompt and the first generated token); idempotent, called by bestla_create_device.
+ * NS_WARM_UP=0 turns it off. */
+int ns_hip_warm_up(void);
 
 /* Replay of the reference's per-token device graph (csrc/ns_route.cpp; the reference rebuilds its graph every token,
  * models/llama/llama.cpp:148, and issues it node by node, core/ne_layers.c:11915-12028).  The launches of the bestla_device_* route on the

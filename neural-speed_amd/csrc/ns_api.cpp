@@ -1203,6 +1203,21 @@ int ns_hip_fusion_qkv_forward_h(const float* dA, const void* dA16, const ns_weig
   return ns_hip_fusion_qkv_forward_x(dA, dA16, wq, wk, wv, dC, dC16, m, lda, ldc, nullptr, stream);
 }
 
+int ns_hip_warm_up(void) {
+  if (!have_device()) return -1;
+  static const bool off = getenv("NS_WARM_UP") && atoi(getenv("NS_WARM_UP")) == 0;  // diagnostics
+  static std::once_flag once;
+  if (!off)
+    std::call_once(once, [] {
+      touch_gemm_module();
+      touch_gemv_module();
+      touch_attn_module();
+      touch_quant_module();
+      ns_hip_reset_error();
+    });
+  return 0;
+}
+
 int ns_hip_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, float freq_scale, float attn_factor,
                         float* dCosSin, void* stream) {
   if (!have_device()) return -1;

@@ -2018,4 +2018,9 @@ void bestla_fusion_attn_fp32_fp16_fp16_fp32_forward(const attn_fp32_fp16_fp16_fp
 
 namespace ns {
 void kv_mirrors_clear() { kv_mirrors_clear_impl(); }
+void touch_attn_module() {
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(attn_merge_kernel));
+  (void)hipGetLastError();
+}
 }  // namespace ns

@@ -282,6 +282,13 @@ struct Affine {
   long long delta = 0;
   long long delta2 = 0;  // launch_dup2: the second copy's destination
 };
+// One function per translation unit with kernels of the hot paths: asks the runtime for one kernel's attributes, which makes it load that unit's code object
+// for the device NOW (HIP loads a code object at the first launch from it: 36 ms for the tiled GEMM's, 21 ms for the decode GEMV's — otherwise paid by the first
+// prompt and the first generated token).  ns_hip_warm_up() / bestla_create_device call them once.
+void touch_gemm_module();
+void touch_gemv_module();
+void touch_attn_module();
+void touch_quant_module();
 extern thread_local Affine g_affine;
 // ... and the device-layout attention may be asked for an fp16 copy of its output row beside the fp32 one (the carried norm of the route's
 // attention-output projection needs the fp16 shadow of its activations): set around the captured call, nullptr otherwise

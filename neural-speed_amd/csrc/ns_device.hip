@@ -418,6 +418,7 @@ void* bestla_create_device(bool profile) {
   if (hipGetDeviceProperties(&prop, d->id) == hipSuccess)
     fprintf(stderr, "bestla device: %s, %d CUs, %.1f GB\n", prop.name, prop.multiProcessorCount, double(prop.totalGlobalMem) / 1e9);
   ns::route_attach(d->stream);  // ns_route.cpp: the per-token graph this queue carries is verified and replayed
+  (void)ns_hip_warm_up();       // the code objects of the GEMM / GEMV / attention / operator kernels are loaded here, not under the first prompt and token
   return d;
 }
 void* bestla_get_device_queue(void* device) { return device ? static_cast<ns::Device*>(device)->stream : nullptr; }

@@ -1886,4 +1886,9 @@ hipError_t launch_gemm2(const SmallMArgs& a, hipStream_t st) {
 #endif
 }
 
+void touch_gemm_module() {
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gemm3_kernel<WK_INT4, 4, SK_BF16, false, 128, false, false>));
+  (void)hipGetLastError();
+}
 }  // namespace ns

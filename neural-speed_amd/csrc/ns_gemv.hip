@@ -1256,4 +1256,9 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
 #undef NS_DISPATCH
 }
 
+void touch_gemv_module() {
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gemv_kernel<WK_INT4, 4, SK_BF16, false, GV_PLAIN, 0>));
+  (void)hipGetLastError();
+}
 }  // namespace ns

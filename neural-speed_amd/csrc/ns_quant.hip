@@ -1300,4 +1300,9 @@ hipError_t launch_bcast_binary(int batch, int vsize, const float* t, const float
   return hipGetLastError();
 }
 
+void touch_quant_module() {
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(silu_kernel));
+  (void)hipGetLastError();
+}
 }  // namespace ns
