@@ -241,16 +241,23 @@ int ns_hip_set_tuning(const char* key, int value);
  * NS_WARM_UP=0 turns it off. */
 int ns_hip_warm_up(void);
 
-/* Replay of the reference's per-token device graph (csrc/ns_route.cpp; the reference rebuilds its graph every token,
- * models/llama/llama.cpp:148, and issues it node by node, core/ne_layers.c:11915-12028).  The launches of the bestla_device_* route on the
- * queue bestla_create_device made are recorded; two consecutive tokens whose launch sequences differ only in one moving value per launch
- * (RoPE position, kv-cache cell, context length) make a plan of HIP-graph segments; later tokens are compared launch by launch and each
- * segment is replayed once its last launch has matched - a token that deviates falls back to plain launches without side effects.
- * ns_hip_route_set_enabled(0 / 1) (environment NS_DEVICE_REPLAY) returns the previous setting.  A plan CARRIES the RMS norms (ns_norm_link below:
- * rms_norm + mul(gamma) in front of a mul_mat launch are not launched, the launch that made the normed tensor writes fp16(gamma . x) and the sums
- * of squares; 7B-shaped model 400 -> 451 tok/s) unless NS_ROUTE_LINKS=0 or ns_hip_route_set_enabled(5) say otherwise ((3) forces it on); the range note of
- * ns_norm_link applies.  ns_hip_route_stats: [0] tokens replayed,
- * [1] tokens launched eagerly, [2] plans built, [3] fall-backs, [4] the reference's launches per token in the last plan, [5] the launches its graphs hold for them (runs of
+/* The reference's per-token device graph: deferred, fused, verified, replayed (csrc/ns_route.cpp; the reference rebuilds its graph every token,
+ * models/llama/llama.cpp:148, and issues it node by node, core/ne_layers.c:11915-12028).  The launches of the bestla_device_* route on a
+ * queue bestla_create_device made (one route per queue) are recorded, not launched: they go out at the evaluation's next synchronisation point
+ * (bestla_device_sync / _memcpy) as this library's fused launches — one-launch QKV, gate / up, mul_mat + residual add, rope + cache writes (the WINDOW,
+ * round 6: a prompt and the first tokens of a generation too).  Two consecutive tokens whose launch sequences differ only in one moving value per launch
+ * (RoPE position, kv-cache cell, context length) make a PLAN of HIP-graph segments; later tokens are compared launch by launch and each
+ * segment is replayed once its last launch has matched - a token that deviates falls back to the window without side effects (its input is put back from a
+ * device-side copy), and from the second fall-back in a row the next plan waits for 4, 8 .. 64 agreeing tokens.
+ * ns_hip_route_set_enabled(on) (environment NS_DEVICE_REPLAY=0: all off; NS_ROUTE_WINDOW=0: window off) returns the previous plan setting:
+ *   0 = the layer is off, every operator launches when it is handed over; 1 = window + plans; 8 = the window alone.
+ * A plan CARRIES the RMS norms (ns_norm_link below: rms_norm + mul(gamma) in front of a mul_mat launch are not launched, the launch that made the normed
+ * tensor writes fp16(gamma . x) and the sums of squares; 7B-shaped model 400 -> 451 tok/s) unless NS_ROUTE_LINKS=0 or ns_hip_route_set_enabled(5) say
+ * otherwise ((3) forces it on).  The route's attention reads an fp16 MIRROR of the reference's fp32 device kv cache (csrc/ns_route.h: NS_DEVICE_KV=f32 /
+ * ns_hip_set_tuning("device_kv_f16", 0) keep the fp32 kernels).  Both fp16 shortcuts are guarded: a value beyond the fp16 range raises a flag, the route
+ * turns them off for the process (one line on stderr) and evaluates the token again on the fp32 forms before its results are read.
+ * ns_hip_route_stats (sums over the process's routes): [0] tokens replayed,
+ * [1] evaluations not replayed (window / plain), [2] plans built, [3] fall-backs, [4] the reference's launches per token in the last plan, [5] the launches its graphs hold for them (runs of
  * single operators become the library's fused launches at capture time),
  * [6] plans that could not be captured, [7] 1 while a plan is held. */
 int ns_hip_route_set_enabled(int on);

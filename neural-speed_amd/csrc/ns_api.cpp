@@ -27,6 +27,7 @@
 
 #include "../../include/ns_bestla.h"
 #include "ns_common.h"
+#include "ns_route.h"
 
 using namespace ns;  // NOLINT
 
@@ -707,6 +708,34 @@ int forward_impl(const float* dA, const ns_weight* w, float* dC, int m, int lda,
 }  // namespace
 
 namespace ns {
+// the device route's replayed QKV launch (ns_route.cpp XK_QKV_ROPE): one row, carried norm on the input, RoPE + fp16 mirror + fp32 cache cells in the epilogue
+int qkv_rope_route_forward(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk, const ns_weight* wv, float* cq, float* ck,
+                           float* cv, int lda, const ns_norm_link* link, const ns_qkv_rope* rope, const QkvRopeRoute* rr, hipStream_t st) {
+  if (!have_device()) return -1;
+  if (!wq || !wk || !wv || !dA16 || !cq || !ck || !cv || !rope || !rr) {
+    set_error("route qkv+rope: null argument");
+    return -1;
+  }
+  const ns_weight* ws[3] = {wq, wk, wv};
+  bool same = !ref_int8_for(wq);
+  for (int i = 0; i < 3; i++)
+    same &= ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize && ws[i]->scale_dt == wq->scale_dt &&
+            ws[i]->asym == wq->asym && ws[i]->qtype == wq->qtype && !ws[i]->shuf && !ws[i]->load_failed;
+  if (!same || !smallm_supported(wq, 1) || (link && (link->out_gamma || link->out_ssq)) || (link && !link_ok(link, wq, 1, dA16))) {
+    if (same) set_error("route qkv+rope: the launch cannot carry this norm / these weights");
+    else set_error("route qkv+rope: needs three weights of one format in the fp16 compute mode");
+    return -1;
+  }
+  SmallMArgs a{};
+  a.a = dA, a.a16 = dA16, a.lda = lda, a.m = 1, a.ldc = wq->n, a.nseg = 3;
+  float* cs[3] = {cq, ck, cv};
+  for (int i = 0; i < 3; i++) a.seg[i] = {ws[i], cs[i], nullptr};
+  a.epilogue = NS_EPI_NONE;
+  a.link = link;
+  a.rope = rope;
+  a.rope_route = rr;
+  return hip_ok(launch_smallm(a, st), "route qkv+rope launch") ? 0 : -1;
+}
 void set_error(const std::string& s) { g_err = s; }
 bool route_link_weight_ok(const ns_weight* w) { return w && !w->shuf && !w->load_failed && !ref_int8_for(w) && w->kind != WK_F8 && smallm_supported(w, 1); }
 }  // namespace ns
@@ -1047,6 +1076,7 @@ ns_weight* ns_hip_weight_slice(const ns_weight* w, int n0, int n1, int k0, int k
 
 void ns_hip_weight_free(ns_weight* w) {
   if (!w) return;
+  route_invalidate();  // (no plan / window of the device route may keep the weight's device arrays; a later load may be given this address again)
   if (w->codes && !w->external) hipFree(w->codes);  // scales / zps / workspace live in the same allocation
   if (w->shuf) hipFree(w->shuf);
   if (w->native) ns_hip_weight_free(w->native);
@@ -1151,6 +1181,10 @@ int ns_hip_set_tuning(const char* key, int value) {
   }
   if (key && !strcmp(key, "attn_inlaunch")) {
     set_attn_inlaunch(value);
+    return 0;
+  }
+  if (key && !strcmp(key, "device_kv_f16")) {  // the device route's attention reads the fp16 mirror of the fp32 kv cache (1, default) or the fp32 cache itself (0); -1: NS_DEVICE_KV
+    kv16_set(value);
     return 0;
   }
   set_error("ns_hip_set_tuning: unknown key");

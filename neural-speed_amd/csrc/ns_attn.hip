@@ -180,7 +180,17 @@ struct AttnSplitParams {
                        // neighbouring 256-byte pieces of a position-major cache ([position][head][dim]); 0: the ranges of one head first
   int g_full, chunks;  // query heads per kv head, and in how many workgroups of G heads each they are served (round 4: any head
                        // group — Falcon's 71 and StarCoder's 48 query heads on one kv head ran on the one-workgroup-per-head kernel)
+  // replayed device route (round 6, ns_common.h Affine): the context length moves with the captured graph's token counter —
+  // sl_kv = a.sl_kv + kdelta * *kmove.  Grid, keys_per_split and the partials' layout are those of the LONGEST context (nsplit ranges);
+  // ranges past the live length leave at once, a single live range writes the output row itself, the merge reads the live ones only.
+  const int* kmove;
+  int kdelta;
 };
+// live context length / live ranges of a launch (kmove == nullptr: what the host said)
+__device__ __forceinline__ int attn_live_kv(const AttnSplitParams& sp) { return sp.kmove ? sp.a.sl_kv + sp.kdelta * *sp.kmove : sp.a.sl_kv; }
+__device__ __forceinline__ int attn_live_splits(const AttnSplitParams& sp, int sl_kv) {
+  return sp.kmove ? (sl_kv + sp.keys_per_split - 1) / sp.keys_per_split : sp.nsplit;
+}
 
 // stores / loads past every cache (sc0 sc1): partial results cross XCDs inside one launch
 __device__ __forceinline__ void st_through(float* p, float v) {
@@ -195,7 +205,7 @@ __device__ __forceinline__ float ld_through(const float* p) {
 // split's partial (max, sum, unnormalised output) is stored — and, with tickets, the last split of a kv head merges inside the launch.
 template <int G, int DPL, int LPK = 16>  // LPK: lanes per key (64 / LPK key groups in a wave)
 __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, float (&acc)[G][DPL], float (&m)[G], float (&lsum)[G], float* acc_s,
-                                                  float (&ml_s)[4][G][2], int split, int chunk, int ihkv, int i, int ibs) {
+                                                  float (&ml_s)[4][G][2], int split, int chunk, int ihkv, int i, int ibs, int live) {
   const AttnParams& p = sp.a;
   const int t = threadIdx.x, w = t >> 6, l = t & 63;
   const int hs = p.head_size;
@@ -244,7 +254,7 @@ __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, flo
       ab += acc_s[(ww * G + g) * LPK * DPL + dd] * c;
     }
     const int ihn = head_of(g);
-    if (sp.nsplit == 1) {
+    if (live == 1) {
       float* dst = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num + i * p.step_dst_sl;
       const float y = ab / lb * p.out_scale;
       dst[dd] = y;
@@ -266,7 +276,7 @@ __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, flo
       }
     }
   }
-  if (sp.nsplit == 1 || !sp.tickets) return;
+  if (live == 1 || !sp.tickets) return;
   // ---- merge inside the launch: the write-through stores above are drained, the workgroup draws a ticket, and the one that
   // draws the last of (batch, query row, kv head) combines all splits — the sums attn_merge_kernel forms, in the same order ----
   __shared__ uint32_t drawn_s;
@@ -275,14 +285,14 @@ __device__ __forceinline__ void attn_split_finish(const AttnSplitParams& sp, flo
   uint32_t* tk = sp.tickets + (((size_t)ibs * p.sl_q + i) * p.heads_kv + ihkv) * sp.chunks + chunk;
   if (t == 0) drawn_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (drawn_s != uint32_t(sp.nsplit - 1)) return;
+  if (drawn_s != uint32_t(live - 1)) return;
   if (t == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
-  const int ns = sp.nsplit;
+  const int ns = live;
   for (int idx = t; idx < G * LPK * DPL; idx += kAttnThreads) {
     const int g = idx / (LPK * DPL), dd = idx % (LPK * DPL);
     if (dd >= hs || !head_live(g)) continue;
     const int ihn = head_of(g);
-    const float* wq = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
+    const float* wq = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit * (2 + hs);
     float mb = -INFINITY, lb = 0.f, ab = 0.f;
     if (ns <= 16) {  // every load of the merge requested at once
       float mv[16], lv[16], ov[16];
@@ -338,7 +348,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
   const bool alibi = (p.flags & NS_ATTN_FLAG_IS_ALIBI8) != 0;
   const bool tanh30 = (p.flags & NS_ATTN_FLAG_IS_TANH30) != 0;
-  const int unmasked = causal ? (p.sl_kv - p.sl_q) + i + 1 : p.sl_kv;
+  const int sl_kv = attn_live_kv(sp), live = attn_live_splits(sp, sl_kv);
+  if (split >= live) return;  // (moving context length: a range past the live keys)
+  const int unmasked = causal ? (sl_kv - p.sl_q) + i + 1 : sl_kv;
   const int j0 = split * sp.keys_per_split, j1 = min(unmasked, j0 + sp.keys_per_split);
   const int d0 = dl * DPL;
   const bool dact = d0 < hs;  // head sizes that are not a multiple of DPL are rejected by the host
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
     }
   }
 
-  attn_split_finish<G, DPL>(sp, acc, m, lsum, acc_s, ml_s, split, chunk, ihkv, i, ibs);
+  attn_split_finish<G, DPL>(sp, acc, m, lsum, acc_s, ml_s, split, chunk, ihkv, i, ibs, live);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -515,7 +527,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
   const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
   const bool alibi = (p.flags & NS_ATTN_FLAG_IS_ALIBI8) != 0;
   const bool tanh30 = (p.flags & NS_ATTN_FLAG_IS_TANH30) != 0;
-  const int unmasked = causal ? (p.sl_kv - p.sl_q) + i + 1 : p.sl_kv;
+  const int sl_kv = attn_live_kv(sp), live = attn_live_splits(sp, sl_kv);
+  if (split >= live) return;  // (moving context length: a range past the live keys)
+  const int unmasked = causal ? (sl_kv - p.sl_q) + i + 1 : sl_kv;
   const int j0 = split * sp.keys_per_split, j1 = min(unmasked, j0 + sp.keys_per_split);
   const int d0 = dl * DPL;
   const bool dact = d0 < hs;
@@ -682,7 +696,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
     }
   }
   __syncthreads();  // every wave has left its ring: its first bytes become attn_split_finish's acc_s
-  attn_split_finish<G, DPL, LPK>(sp, acc, m, lsum, reinterpret_cast<float*>(ring_s), ml_s, split, chunk, ihkv, i, ibs);
+  attn_split_finish<G, DPL, LPK>(sp, acc, m, lsum, reinterpret_cast<float*>(ring_s), ml_s, split, chunk, ihkv, i, ibs, live);
 }
 
 // one workgroup per (batch, query row, head): combine the splits' (m, l, acc).  The per-split (m, l) are fetched by
@@ -693,8 +707,10 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const AttnSplitParams s
   __shared__ float c_s[64];
   __shared__ float l_s[64];
   const int ihn = blockIdx.x, i = blockIdx.y, ibs = blockIdx.z;
-  const int hs = p.head_size, t = threadIdx.x, ns = sp.nsplit;  // ns <= 64
-  const float* wp = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * ns * (2 + hs);
+  const int hs = p.head_size, t = threadIdx.x;
+  const int ns = attn_live_splits(sp, attn_live_kv(sp));  // ns <= 64
+  if (sp.kmove && ns == 1) return;  // (a single live range wrote the output row itself)
+  const float* wp = sp.ws + (((size_t)ibs * p.sl_q + i) * p.head_num + ihn) * sp.nsplit * (2 + hs);
   // the common decode shapes (<= 32 splits, one output element per thread): every thread fetches all (max, sum) pairs — wave-
   // uniform addresses, scalar loads — and its own column of the partial outputs in ONE batch of loads, then merges in registers:
   // one memory round trip behind the kernel boundary instead of two with a workgroup barrier between them (round 4: the launch
@@ -1473,6 +1489,12 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     *why = "attention: head_num / batch_size above the grid limit";
     return hipErrorInvalidValue;
   }
+  // replayed device route (ns_route.cpp): the context length of a captured decode step moves with the graph's token counter
+  const Affine aff = g_affine;
+  if (aff.k && (a.sl_q != 1 || aff.cap < a.sl_kv)) {
+    *why = "attention: a moving context length is served for decode steps (one query row) within the cache's capacity";
+    return hipErrorInvalidValue;
+  }
   // ---- several query rows: matrix cores (head size 64 / 128, contiguous 16-byte aligned rows, no alibi / tanh) ----
   static const bool no_mfma = getenv("NS_ATTN_NO_MFMA") != nullptr;  // diagnostics
   const bool rows_ok = a.step_k_head_size == 1 && a.step_v_head_size == 1 && a.step_k_sl % 8 == 0 && a.step_v_sl % 8 == 0 &&
@@ -1533,27 +1555,32 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     AttnSplitParams sp;
     sp.a = p;
     sp.g_full = a.head_num / a.heads_kv, sp.chunks = chunks;
-    const bool stream = attn_streams(p);
+    const int rule_kv = aff.k ? int(aff.cap) : a.sl_kv;  // (moving length: ranges, partials and descriptors laid out for the longest context)
+    AttnParams pc = p;
+    pc.sl_kv = rule_kv;
+    const bool stream = attn_streams(pc);
     const int batch_keys = (G * 8 <= 16 ? 4 : 2) * 4 * (a.head_size > 64 ? 4 : 8);  // attn_stream_kernel's U x keys per workgroup step
     // head sizes above 128 (register kernel, 16 dims per lane) take the ring kernel's range rule too: 16 x 256 heads 14.6 -> 10.4 us at 512 keys,
     // 51.8 -> 36.5 at 8192; 8 heads on one kv head 51 -> 40 at 2048 (scripts/r05/attn_regs_rule.py; head sizes <= 32 lose with it at 2048+ keys)
-    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, a.sl_kv, stream || a.head_size > 128, stream ? batch_keys : 0, stream && G >= 4);
+    int nsplit = attn_nsplit(a.batch_size, a.heads_kv * chunks, a.sl_q, rule_kv, stream || a.head_size > 128, stream ? batch_keys : 0, stream && G >= 4);
     float* ws = nullptr;
     if (nsplit > 1) {
       // partials go to the caller's workspace (`tmp`, sized by bestla_fusion_attn_workspace_size: the reference's own
       // contract, and the only choice that works on a stream being captured for the first time); without one, to a
       // grow-only per-stream scratch
       ws = device_tmp ? reinterpret_cast<float*>(a.tmp) : nullptr;
-      if (!ws) ws = static_cast<float*>(stream_scratch(st, attn_ws_bytes(a.batch_size, a.head_num, a.heads_kv, a.head_size, a.sl_q, a.sl_kv), 1));
+      if (!ws) ws = static_cast<float*>(stream_scratch(st, attn_ws_bytes(a.batch_size, a.head_num, a.heads_kv, a.head_size, a.sl_q, rule_kv), 1));
       if (!ws) nsplit = 1;  // scratch allocation failed: unsplit, still correct
     }
     sp.ws = ws;
     sp.tickets = nullptr;
     const size_t nticket = size_t(a.batch_size) * a.sl_q * a.heads_kv * chunks;
-    if (nsplit > 1 && g_attn_inlaunch.load(std::memory_order_relaxed) != 0 && nticket <= kAttnTicketCap)
+    // (the replayed route merges inside the launch: one launch less per layer of a token that is all launches — profiles/r05r_*)
+    if (nsplit > 1 && (g_attn_inlaunch.load(std::memory_order_relaxed) != 0 || (aff.k && aff.inlaunch)) && nticket <= kAttnTicketCap)
       sp.tickets = static_cast<uint32_t*>(stream_scratch_zeroed(st, kAttnTicketCap * 4, 22));  // nullptr (e.g. first use on a capturing stream): the merge launch
     sp.nsplit = nsplit;
-    sp.keys_per_split = (a.sl_kv + nsplit - 1) / nsplit;
+    sp.keys_per_split = (rule_kv + nsplit - 1) / nsplit;
+    sp.kmove = aff.k, sp.kdelta = int(aff.delta);
     // dispatch order (round 5, profiles/r05m_attn_layout_order_ab.txt): on a position-major cache ([position][head][dim]: a head's rows are
     // pieces one position stride apart) neighbouring workgroups should be neighbouring HEADS of one context range — split + merge 14.3 -> 13.7 us
     // at 2048 positions, 22.0 -> 19.9 at 4096 (Llama-2-7B shape); on a head-major cache (one slab per head) the ranges of one head first
@@ -1578,6 +1605,13 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
   const dim3 grid(unsigned(a.sl_q), unsigned(a.head_num), unsigned(a.batch_size));
   hipLaunchKernelGGL(attn_kernel, grid, dim3(kAttnThreads), 0, st, p);
   return hipGetLastError();
+}
+
+// scratch a moving-length decode launch needs (partials for the longest context, the merge tickets): allocated BEFORE the route's capture
+bool attn_prepare_moving(hipStream_t st, int batch, int heads, int heads_kv, int head_size, int cap) {
+  const size_t b = attn_ws_bytes(batch, heads, heads_kv, head_size, 1, cap);
+  if (b && !stream_scratch(st, b, 1)) return false;
+  return stream_scratch_zeroed(st, kAttnTicketCap * 4, 22) != nullptr;
 }
 
 // elements spanned by a strided 4-d tensor

@@ -170,6 +170,16 @@ struct MoeRoute {
   const int32_t* id;   // device: &ids[token][id]
   int n_as;
 };
+// replayed device route (ns_route.cpp XK_QKV_ROPE; gemv_kernel only, one row): the fused QKV launch's RoPE epilogue (ns_qkv_rope) also stores k (rotated)
+// and v into the reference's fp32 cache cells, and its position — RoPE angle table aside, which a captured launch of its own fills — follows the graph's counter
+struct QkvRopeRoute {
+  float* k32;      // the K cell of (head 0, dim 0) at the plan token's position; element strides per head / dim, elements per token
+  float* v32;
+  long long k32_head, k32_dim, k32_tok, v32_head, v32_dim, v32_tok;
+  const int* kmove;
+  int kd_pos;      // positions per token
+  uint32_t* overflow;
+};
 struct SmallMArgs {
   const float* a;
   const void* a16;  // optional fp16 copy of A (same shape / lda): skips the fp32->fp16 staging conversion
@@ -184,6 +194,7 @@ struct SmallMArgs {
   float* c2;       // optional tmp1 output in dual mode
   const ns_norm_link* link = nullptr;  // carried RMS norm (include/ns_bestla.h); gemv_kernel only
   const ns_qkv_rope* rope = nullptr;   // RoPE(q, k) + kv-cache append as the QKV epilogue; gemv_kernel only
+  const QkvRopeRoute* rope_route = nullptr;  // ... of a replayed token of the device route (with `rope`)
   const I8Act* i8 = nullptr;           // int8-reference numerics (m <= 4); gemv_kernel only: launch_gemv() directly
   const MoeRoute* moe = nullptr;       // expert picked on the device (m = 1, fp32 activations); gemv_kernel only: launch_gemv() directly
 };
@@ -281,7 +292,11 @@ struct Affine {
   const int* k = nullptr;
   long long delta = 0;
   long long delta2 = 0;  // launch_dup2: the second copy's destination
+  long long cap = 0;     // decode attention (ns_attn.hip): the largest value the moving context length can take (the cache's n_ctx)
+  int inlaunch = 1;      // decode attention: the context ranges merge inside the launch (tickets)
 };
+// ns_attn.hip: per-stream scratch of a moving-length decode attention, allocated before the capture that uses it
+bool attn_prepare_moving(hipStream_t st, int batch, int heads, int heads_kv, int head_size, int cap);
 // One function per translation unit with kernels of the hot paths: asks the runtime for one kernel's attributes, which makes it load that unit's code object
 // for the device NOW (HIP loads a code object at the first launch from it: 36 ms for the tiled GEMM's, 21 ms for the decode GEMV's — otherwise paid by the first
 // prompt and the first generated token).  ns_hip_warm_up() / bestla_create_device call them once.
@@ -305,7 +320,13 @@ struct RouteOp {
 };
 bool route_hook(void* stream);             // true: the caller describes its launch in a RouteOp and hands it to route_submit
 int route_submit(const RouteOp& op);
-int route_sync_point(void* stream);        // bestla_device_sync / _memcpy: pending work goes out, a token may end here
+// bestla_device_sync / _memcpy: the window goes out, an evaluation ends here; src / bytes: the device-side source of the copy that follows
+int route_sync_point(void* stream, const void* src = nullptr, size_t bytes = 0);
+bool route_after_sync(void* stream);       // the queue has been waited for: the fp16 overflow flag is looked at (ns_route.h); true: the evaluation was run again
+bool route_defer_sync(void* stream);       // a wait with only launches in flight may be left to the next copy's
+void route_note_copy(void* stream);
+void route_note_input(void* dst, size_t bytes, void* stream);  // a copy into device memory in front of an evaluation: its input (kept for a re-issue)
+void route_time_mark(void* stream, int what);                   // NS_ROUTE_TIMING
 void route_attach(void* stream);           // bestla_create_device
 void route_detach(void* stream);
 void route_invalidate();                   // bestla_device_free
@@ -318,7 +339,10 @@ hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int hea
 hipError_t launch_rope_glm(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                            bool skip, float freq_base, int prompt_size, const int* n_padding, hipStream_t st);
 hipError_t launch_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, float freq_scale, float attn_factor,
-                               float* out, hipStream_t st);
+                               float* out, hipStream_t st);  // (n_past follows g_affine inside a route capture)
+// ns_api.cpp: the fused QKV + RoPE + cache-write launch of a replayed token: weights by ROLE, each result at its own tensor
+int qkv_rope_route_forward(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk, const ns_weight* wv, float* cq, float* ck,
+                           float* cv, int lda, const ns_norm_link* link, const ns_qkv_rope* rope, const QkvRopeRoute* rr, hipStream_t st);
 hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void* kc, void* vc, int seq, int heads,
                                   int heads_kv, int head_size, int n_past, int n_dims, int mode, float freq_base,
                                   float freq_scale, float attn_factor, long long c_sl, long long c_head, hipStream_t st);

@@ -27,6 +27,7 @@
 
 #include "../../include/ns_bestla.h"
 #include "ns_common.h"
+#include "ns_route.h"
 
 namespace ns {
 
@@ -330,39 +331,43 @@ __global__ void mha_f32_merge_kernel(const float* ws, float* o, int nsplit, int 
   if (o16) o16[row * hs + t] = (_Float16)y;  // (replayed route: the projection behind it streams fp16 activations)
 }
 
-// ---- prompt-sized calls of the device-layout attention (round 5): the kernels above serve one query row per workgroup — right for a decode step,
-//      but a 1500-token prompt re-read its whole K / V once per row (184 ms through the reference's unchanged model_eval, 5.7 ms per layer).  From
-//      kMhaPromptRows rows on the call's K rows and (transposed) V rows are converted ONCE into fp16 [batch][head][position][head_size] scratch and the
-//      matrix-core prefill kernels of ns_attn.hip run on them (ns_hip_attn_fp32_fp16_fp16_fp32_forward: 128 query rows per workgroup, K / V tiles shared
-//      through LDS).  K / V are rounded to fp16 there, as in the reference's own CPU caches (its default kv type is fp16); decode steps stay on the fp32 kernels.
-constexpr int kMhaPromptRows = 32;
-// K [heads][n_ctx][hs] fp32 -> [heads][keys][hs] fp16 (rows 0 .. keys of every head), 4 elements per thread
-__global__ void mha_k_to_f16_kernel(const float* __restrict__ k, _Float16* __restrict__ out, int heads, int n_ctx, int keys, int hs) {
-  const size_t per_head = size_t(keys) * hs / 4;
+// ---- the fp16 mirror's converters (round 5 made them for prompt-sized calls — the kernels above serve one query row per workgroup, a 1500-token prompt
+//      re-read its whole K / V once per row: 184 ms through the reference's unchanged model_eval — round 6 feeds every call shape from them, ns_route.h) ----
+// K [heads][n_ctx][hs] fp32 -> fp16 [heads][out_ctx][hs], positions lo .. hi of every head, 4 elements per thread (out_ctx = n_ctx: the mirror)
+__global__ void mha_k_to_f16_kernel(const float* __restrict__ k, _Float16* __restrict__ out, int heads, int n_ctx, int out_ctx, int lo, int hi, int hs,
+                                    uint32_t* overflow) {
+  const size_t per_head = size_t(hi - lo) * hs / 4;
   const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (gid >= per_head * heads) return;
-  const size_t h = gid / per_head, e = (gid - h * per_head) * 4;
+  const size_t h = gid / per_head, e = size_t(lo) * hs + (gid - h * per_head) * 4;
   const dfloat4 v = *reinterpret_cast<const dfloat4*>(k + h * size_t(n_ctx) * hs + e);
   typedef _Float16 dhalf4 __attribute__((ext_vector_type(4)));
-  *reinterpret_cast<dhalf4*>(out + h * size_t(keys) * hs + e) = dhalf4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  if (overflow && fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > 65504.f)
+    __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  *reinterpret_cast<dhalf4*>(out + h * size_t(out_ctx) * hs + e) = dhalf4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
 }
-// V [heads][hs][n_ctx] fp32 (transposed) -> [heads][keys][hs] fp16: 32 x 32 tiles through LDS (reads run along the positions, writes along the head dims)
-__global__ __launch_bounds__(256) void mha_vt_to_f16_kernel(const float* __restrict__ v, _Float16* __restrict__ out, int n_ctx, int keys, int hs) {
+// V [heads][hs][n_ctx] fp32 (transposed) -> fp16 [heads][out_ctx][hs], positions lo .. hi: 32 x 32 tiles through LDS (reads run along the positions, writes along the head dims)
+__global__ __launch_bounds__(256) void mha_vt_to_f16_kernel(const float* __restrict__ v, _Float16* __restrict__ out, int n_ctx, int out_ctx, int lo, int hi, int hs,
+                                                            uint32_t* overflow) {
   __shared__ float tile[32][33];
-  const int h = blockIdx.z, j0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+  const int h = blockIdx.z, j0 = lo + blockIdx.x * 32, d0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const float* src = v + size_t(h) * hs * n_ctx;
+  bool big = false;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int d = d0 + ty + 8 * r, j = j0 + tx;
-    tile[ty + 8 * r][tx] = (d < hs && j < keys) ? src[size_t(d) * n_ctx + j] : 0.f;
+    const float x = (d < hs && j < hi) ? src[size_t(d) * n_ctx + j] : 0.f;
+    big = big || fabsf(x) > 65504.f;
+    tile[ty + 8 * r][tx] = x;
   }
+  if (big && overflow) __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
-  _Float16* dst = out + size_t(h) * keys * hs;
+  _Float16* dst = out + size_t(h) * out_ctx * hs;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int j = j0 + ty + 8 * r, d = d0 + tx;
-    if (j < keys && d < hs) dst[size_t(j) * hs + d] = (_Float16)tile[tx][ty + 8 * r];
+    if (j < hi && d < hs) dst[size_t(j) * hs + d] = (_Float16)tile[tx][ty + 8 * r];
   }
 }
 
@@ -392,6 +397,126 @@ inline RouteOp binary_op(uint32_t kind, const float* a, const float* b, float* d
   op.kind = kind, op.p[0] = a, op.p[1] = b, op.p[2] = d;
   for (int i = 0; i < 4; i++) op.i[i] = ne0[i], op.i[4 + i] = nb0[i], op.i[8 + i] = ne1[i], op.i[12 + i] = nb1[i], op.i[16 + i] = nbd[i];
   return op;
+}
+
+// ---- the fp16 mirror of the reference's fp32 device kv cache (round 6; ns_route.h says why and how it stays coherent) ----
+namespace {
+struct KvMirror {
+  const char* k32 = nullptr;   // the fp32 K cache the graph handed to the attention node ([slots][heads_kv][n_ctx][hs])
+  const char* v32 = nullptr;   // ... and its V cache ([slots][heads_kv][hs][n_ctx])
+  size_t bytes32 = 0;          // of each
+  int slots = 0, heads_kv = 0, hs = 0, n_ctx = 0;
+  _Float16 *k16 = nullptr, *v16 = nullptr;  // [slots][heads_kv][n_ctx][hs] both
+  std::vector<int> valid;      // per slot: positions [0, valid) of the mirror hold the cache
+};
+std::vector<KvMirror*> g_kvms;
+const char *g_kvm_lo = nullptr, *g_kvm_hi = nullptr;  // hull of every mirrored fp32 range (one compare rules a pointer out)
+uint32_t* g_kvm_overflow = nullptr;
+std::atomic<int> g_kv16{-1};
+
+void kvm_hull() {
+  g_kvm_lo = g_kvm_hi = nullptr;
+  for (const KvMirror* m : g_kvms)
+    for (const char* b : {m->k32, m->v32}) {
+      if (!g_kvm_lo || b < g_kvm_lo) g_kvm_lo = b;
+      if (!g_kvm_hi || b + m->bytes32 > g_kvm_hi) g_kvm_hi = b + m->bytes32;
+    }
+}
+void kvm_drop(size_t i) {
+  KvMirror* m = g_kvms[i];
+  (void)hipFree(m->k16);
+  (void)hipFree(m->v16);
+  delete m;
+  g_kvms.erase(g_kvms.begin() + long(i));
+}
+inline bool overlaps(const char* a, size_t na, const char* b, size_t nb) { return a < b + nb && b < a + na; }
+// the mirror that holds the `slots` cache slots starting at (dK, dV), made (and older, overlapping ones dropped) when there is none
+KvMirror* kvm_get(const float* dK, const float* dV, int slots, int heads_kv, int hs, int n_ctx, int* slot0) {
+  const char *k = reinterpret_cast<const char*>(dK), *v = reinterpret_cast<const char*>(dV);
+  const size_t per_slot = size_t(heads_kv) * n_ctx * hs * 4, bytes = per_slot * slots;
+  for (KvMirror* m : g_kvms) {
+    if (m->heads_kv != heads_kv || m->hs != hs || m->n_ctx != n_ctx || k < m->k32 || k + bytes > m->k32 + m->bytes32) continue;
+    const size_t off = size_t(k - m->k32);
+    if (off % per_slot != 0 || v != m->v32 + off) continue;
+    *slot0 = int(off / per_slot);
+    return m;
+  }
+  for (size_t i = g_kvms.size(); i-- > 0;)
+    if (overlaps(k, bytes, g_kvms[i]->k32, g_kvms[i]->bytes32) || overlaps(v, bytes, g_kvms[i]->v32, g_kvms[i]->bytes32) ||
+        overlaps(k, bytes, g_kvms[i]->v32, g_kvms[i]->bytes32) || overlaps(v, bytes, g_kvms[i]->k32, g_kvms[i]->bytes32))
+      kvm_drop(i);
+  KvMirror* m = new KvMirror();
+  m->k32 = k, m->v32 = v, m->bytes32 = bytes, m->slots = slots, m->heads_kv = heads_kv, m->hs = hs, m->n_ctx = n_ctx;
+  m->valid.assign(size_t(slots), 0);
+  if (hipMalloc(reinterpret_cast<void**>(&m->k16), bytes / 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&m->v16), bytes / 2) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(m->k16);
+    delete m;
+    kvm_hull();
+    return nullptr;
+  }
+  g_kvms.push_back(m);
+  kvm_hull();
+  *slot0 = 0;
+  return m;
+}
+}  // namespace
+
+bool kv16_enabled() {
+  int v = g_kv16.load();
+  if (v < 0) {
+    const char* e = getenv("NS_DEVICE_KV");
+    v = (e && (!strcmp(e, "f32") || !strcmp(e, "fp32") || !strcmp(e, "0"))) ? 0 : 1;
+    g_kv16.store(v);
+  }
+  return v != 0;
+}
+void kv16_set(int on) { g_kv16.store(on < 0 ? -1 : (on != 0)); }
+uint32_t* kvm_overflow_word() {
+  if (!g_kvm_overflow) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&g_kvm_overflow), 64, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      g_kvm_overflow = nullptr;
+      return nullptr;
+    }
+    *g_kvm_overflow = 0;
+  }
+  return g_kvm_overflow;
+}
+bool kvm_overflowed() { return g_kvm_overflow && *reinterpret_cast<volatile uint32_t*>(g_kvm_overflow) != 0; }
+void kvm_overflow_reset() {
+  if (g_kvm_overflow) *reinterpret_cast<volatile uint32_t*>(g_kvm_overflow) = 0;
+}
+bool kvm_args_for_cell(const void* cell, KvMirrorArgs* out) {
+  const char* c = static_cast<const char*>(cell);
+  if (!g_kvm_lo || c < g_kvm_lo || c >= g_kvm_hi) return false;
+  for (const KvMirror* m : g_kvms) {
+    const bool in_k = c >= m->k32 && c < m->k32 + m->bytes32, in_v = c >= m->v32 && c < m->v32 + m->bytes32;
+    if (!in_k && !in_v) continue;
+    out->base32 = in_k ? m->k32 : m->v32, out->m16 = in_k ? m->k16 : m->v16, out->elems = (long long)(m->bytes32 / 4);
+    out->n_ctx = m->n_ctx, out->hs = m->hs, out->transposed = in_k ? 0 : 1, out->overflow = kvm_overflow_word();
+    return true;
+  }
+  return false;
+}
+void kvm_note_foreign_write(const void* dst, size_t bytes) {
+  const char* c = static_cast<const char*>(dst);
+  if (!g_kvm_lo || !c || c >= g_kvm_hi || c + bytes <= g_kvm_lo) return;
+  for (KvMirror* m : g_kvms)
+    if (overlaps(c, bytes ? bytes : 1, m->k32, m->bytes32) || overlaps(c, bytes ? bytes : 1, m->v32, m->bytes32)) std::fill(m->valid.begin(), m->valid.end(), 0);
+}
+void kvm_set_valid(const void* k32, int valid) {
+  const char* c = static_cast<const char*>(k32);
+  if (!g_kvm_lo || c < g_kvm_lo || c >= g_kvm_hi) return;
+  for (KvMirror* m : g_kvms)
+    if (c >= m->k32 && c < m->k32 + m->bytes32) {
+      const size_t per_slot = m->bytes32 / size_t(m->slots);
+      m->valid[size_t(c - m->k32) / per_slot] = std::min(valid, m->n_ctx);
+    }
+}
+void kvm_clear() {
+  while (!g_kvms.empty()) kvm_drop(g_kvms.size() - 1);
+  kvm_hull();
 }
 
 }  // namespace ns
@@ -428,7 +553,9 @@ void bestla_release_device(void* device) {
   (void)ns_hip_lazy_flush();
   finish_pending_loads_if_any();
   ns::Device* d = static_cast<ns::Device*>(device);
+  (void)ns::route_sync_point(d->stream);
   ns::route_detach(d->stream);
+  ns::kvm_clear();
   (void)hipStreamSynchronize(d->stream);
   (void)hipStreamDestroy(d->stream);
   delete d;
@@ -438,6 +565,16 @@ size_t bestla_device_gmem_size(void* device) {
   size_t fr = 0, total = 0;
   return hipMemGetInfo(&fr, &total) == hipSuccess ? total : 0;
 }
+// the reference's device pools come from here: what lies inside one of these allocations is device memory (no runtime query per copy)
+static std::mutex g_pool_mu;
+static std::vector<std::pair<const char*, size_t>> g_pools;
+static bool in_device_pool(const void* p) {
+  const char* c = static_cast<const char*>(p);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (const auto& a : g_pools)
+    if (c >= a.first && c < a.first + a.second) return true;
+  return false;
+}
 void* bestla_device_malloc(size_t size, void* queue) {
   (void)queue;
   void* p = nullptr;
@@ -445,19 +582,33 @@ void* bestla_device_malloc(size_t size, void* queue) {
     ns::set_error("bestla_device_malloc: out of device memory");
     return nullptr;
   }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pools.emplace_back(static_cast<const char*>(p), size ? size : 1);
   return p;
 }
 void bestla_device_free(void* ptr, void* queue) {
   (void)queue;
-  // nothing recorded or in flight may still refer to the memory: the lazy node's operands, the loads into the graph's slices
+  // nothing recorded or in flight may still refer to the memory: the lazy node's operands, the route's window and plans, the kv mirrors,
+  // the loads into the graph's slices
   (void)ns_hip_lazy_flush();
   ns::route_invalidate();
+  ns::kvm_clear();
   finish_pending_loads_if_any();
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pools.size(); i++)
+      if (g_pools[i].first == static_cast<const char*>(ptr)) {
+        g_pools.erase(g_pools.begin() + long(i));
+        break;
+      }
+  }
   if (ptr) (void)hipFree(ptr);
 }
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {
   (void)ns_hip_lazy_flush();
-  (void)ns::route_sync_point(queue);
+  // what the route holds back (its window) goes out first; a copy FROM device memory reads a tensor behind the window's last op
+  const bool from_dev = srcptr && in_device_pool(srcptr);
+  (void)ns::route_sync_point(queue, from_dev ? srcptr : nullptr, from_dev ? size : 0);
   if (!dstptr || !srcptr || !size) return;
   // (replayed tokens run on the plan's activations: the embeddings go there as well, the logits come from there — ns_route.cpp)
   void* twin = ns::route_twin_dst(dstptr, queue);
@@ -466,15 +617,29 @@ void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* q
     ns::set_error("bestla_device_memcpy failed");
   if (hipMemcpyAsync(dstptr, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
     ns::set_error("bestla_device_memcpy failed");
+  ns::route_note_copy(queue);
+  if (in_device_pool(dstptr)) {
+    ns::kvm_note_foreign_write(dstptr, size);      // (a copy into a mirrored kv cache: its mirror starts over)
+    ns::route_note_input(dstptr, size, queue);     // an evaluation's input: kept so that the evaluation can be issued again
+  }
 }
-void bestla_device_sync(void* queue) {
+static bool device_sync_impl(void* queue) {
   (void)ns_hip_lazy_flush();
+  ns::route_time_mark(queue, 0);
   (void)ns::route_sync_point(queue);
+  if (ns::route_defer_sync(queue)) return false;  // (only launches in flight: the next copy's wait covers them — ns_route.cpp)
   (void)hipStreamSynchronize(static_cast<hipStream_t>(queue));
+  return ns::route_after_sync(queue);
 }
+void bestla_device_sync(void* queue) { (void)device_sync_impl(queue); }
 void bestla_device_memcpy_sync(void* dstptr, const void* srcptr, size_t size, void* queue) {
   bestla_device_memcpy(dstptr, srcptr, size, queue);
-  bestla_device_sync(queue);
+  if (device_sync_impl(queue)) {  // the evaluation this copy reads from was run again (fp16 overflow, ns_route.h): its results are fetched again
+    bestla_device_memcpy(dstptr, srcptr, size, queue);
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(queue));
+    (void)ns::route_after_sync(queue);
+  }
+  ns::route_time_mark(queue, 1);
 }
 
 /* ---- ne_bestla.h:97-98, ne_bestla_sycl.cpp:92-141 ---- */
@@ -612,6 +777,7 @@ void ns_hip_device_storage_release(void* devstor) {
     finish_pending_loads();
   }
   if (s && s->magic == ns::kDevMagic && s->w) {
+    ns::route_invalidate();  // (a plan holds the weight's device arrays and recognises it by its address — which the next load may be given again)
     ns_hip_weight_free(s->w);
     s->w = nullptr;
     s->magic = 0;
@@ -805,24 +971,40 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
   }
   if (ns_hip_lazy_flush() != 0) return -1;
   const ns::Affine aff = ns::g_affine;
-  // ---- a prompt's rows: fp16 copies of the call's K / V rows, then the matrix-core prefill attention (see kMhaPromptRows) ----
-  static const bool no_prompt_path = getenv("NS_MHA_PROMPT_MFMA") && atoi(getenv("NS_MHA_PROMPT_MFMA")) == 0;  // diagnostics (A/B)
-  if (!no_prompt_path && !aff.k && seq >= ns::kMhaPromptRows && head_size % 8 == 0 && head_size <= 256 && (size_t(seq_all) * head_size) % 4 == 0 &&
-      (reinterpret_cast<uintptr_t>(dK) & 15) == 0 && size_t(batch) * heads_kv <= 65535 && size_t(seq) * heads * head_size < (size_t(1) << 31) &&
-      size_t(seq_all) * heads_kv * head_size < (size_t(1) << 31)) {
+  // ---- fp16 mirror of the cache + this library's attention kernels (round 6, ns_route.h): every call shape — a prompt's rows on the matrix-core
+  //      prefill kernels (round 5 converted the call's K / V into scratch for those: 184 -> 81 ms for a 1500-token prompt), a decode step on the
+  //      LDS-ring kernel, a replayed decode step (aff.k) on the same kernel with its context length moving with the graph's token counter ----
+  if (ns::kv16_enabled() && head_size % 8 == 0 && head_size <= 256 && (reinterpret_cast<uintptr_t>(dK) & 15) == 0 && (reinterpret_cast<uintptr_t>(dV) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(dQ) & 15) == 0 && size_t(batch) * heads_kv <= 65535 && size_t(seq) * heads * head_size < (size_t(1) << 31) &&
+      size_t(n_ctx) * heads_kv * head_size < (size_t(1) << 31) && (!aff.k || seq == 1)) {
+    attn_shape_t shp;
+    memset(&shp, 0, sizeof(shp));
+    shp.batch_size = batch, shp.head_num = heads, shp.heads_kv = heads_kv, shp.head_size = head_size, shp.sl_q = seq, shp.sl_kv = seq_all;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t kv_elems = size_t(batch) * heads_kv * seq_all * head_size;
-    _Float16* k16 = static_cast<_Float16*>(ns::stream_scratch(st, kv_elems * 2, 26));
-    _Float16* v16 = static_cast<_Float16*>(ns::stream_scratch(st, kv_elems * 2, 27));
-    if (k16 && v16) {
-      const int hb = batch * heads_kv;
-      const size_t units = kv_elems / 4;
-      hipLaunchKernelGGL(ns::mha_k_to_f16_kernel, dim3(unsigned((units + 255) / 256)), dim3(256), 0, st, dK, k16, hb, n_ctx, seq_all, head_size);
-      hipLaunchKernelGGL(ns::mha_vt_to_f16_kernel, dim3(unsigned((seq_all + 31) / 32), unsigned((head_size + 31) / 32), unsigned(hb)), dim3(256), 0, st, dV, v16,
-                         n_ctx, seq_all, head_size);
-      if (hipGetLastError() != hipSuccess) {
-        ns::set_error("mha_f32: fp16 conversion launch failed");
-        return -1;
+    int slot0 = 0;
+    ns::KvMirror* mir = bestla_fusion_attn_fp32_fp16_fp16_fp32_support(&shp) ? ns::kvm_get(dK, dV, batch, heads_kv, head_size, n_ctx, &slot0) : nullptr;
+    if (mir) {
+      const size_t per_slot = size_t(heads_kv) * n_ctx * head_size;
+      _Float16 *k16 = mir->k16 + size_t(slot0) * per_slot, *v16 = mir->v16 + size_t(slot0) * per_slot;
+      if (!aff.k) {
+        // positions this evaluation wrote (the last `seq`) are converted again, older ones once; several slots: each from its own mark
+        // (a caller outside the route — a test, a bench — may have filled the cache by any means: everything live is converted for it)
+        int lo = ns::route_executing() ? seq_all - seq : 0;
+        for (int b = 0; b < batch; b++) lo = std::min(lo, mir->valid[size_t(slot0 + b)]);
+        lo = std::max(0, lo);
+        if (lo < seq_all) {
+          const int hb = batch * heads_kv, npos = seq_all - lo;
+          const size_t units = size_t(hb) * npos * head_size / 4;
+          uint32_t* ovf = ns::kvm_overflow_word();
+          hipLaunchKernelGGL(ns::mha_k_to_f16_kernel, dim3(unsigned((units + 255) / 256)), dim3(256), 0, st, dK, k16, hb, n_ctx, n_ctx, lo, seq_all, head_size, ovf);
+          hipLaunchKernelGGL(ns::mha_vt_to_f16_kernel, dim3(unsigned((npos + 31) / 32), unsigned((head_size + 31) / 32), unsigned(hb)), dim3(256), 0, st, dV, v16,
+                             n_ctx, n_ctx, lo, seq_all, head_size, ovf);
+          if (hipGetLastError() != hipSuccess) {
+            ns::set_error("mha_f32: fp16 mirror conversion launch failed");
+            return -1;
+          }
+        }
+        for (int b = 0; b < batch; b++) mir->valid[size_t(slot0 + b)] = seq_all;
       }
       attn_fp32_fp16_fp16_fp32_fwd_args_t a;
       memset(&a, 0, sizeof(a));
@@ -832,10 +1014,15 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
       a.attn_flags = masked ? NS_ATTN_FLAG_IS_CAUSAL : NS_ATTN_FLAG_NONE;
       a.batch_size = batch, a.head_num = heads, a.heads_kv = heads_kv, a.head_size = head_size, a.sl_q = seq, a.sl_kv = seq_all;
       a.step_q_bs = seq * heads * head_size, a.step_q_head_num = head_size, a.step_q_sl = heads * head_size;
-      a.step_k_bs = heads_kv * seq_all * head_size, a.step_k_head_num = seq_all * head_size, a.step_k_sl = head_size, a.step_k_head_size = 1;
+      a.step_k_bs = heads_kv * n_ctx * head_size, a.step_k_head_num = n_ctx * head_size, a.step_k_sl = head_size, a.step_k_head_size = 1;
       a.step_v_bs = a.step_k_bs, a.step_v_head_num = a.step_k_head_num, a.step_v_sl = head_size, a.step_v_head_size = 1;
       a.step_dst_bs = a.step_q_bs, a.step_dst_head_num = head_size, a.step_dst_sl = heads * head_size;
-      return ns_hip_attn_fp32_fp16_fp16_fp32_forward(&a, stream);
+      if (aff.k) {  // (launch_attn reads the moving length from g_affine; the cache's capacity bounds it)
+        ns::g_affine.cap = n_ctx;
+        static const bool inl_off = getenv("NS_MHA_INLAUNCH") && atoi(getenv("NS_MHA_INLAUNCH")) == 0;
+        ns::g_affine.inlaunch = inl_off ? 0 : 1;
+      }
+      return ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(&a, aff.k ? ns::g_mha_out16 : nullptr, stream);
     }
   }
   // ---- the context split over workgroups: head sizes 64 / 128 / 256, from two 128-key ranges on ----

@@ -38,6 +38,7 @@
 
 #include "../../include/ns_bestla.h"
 #include "ns_common.h"
+#include "ns_route.h"
 #include "ns_dev.h"
 
 namespace ns {
@@ -75,6 +76,14 @@ struct GemvRope {
   const float2* cos_sin;   // [row][head_size / 2] (cos, sin) * attn_factor of position n_past + row (ns_hip_rope_cos_sin)
   int head_size, n_past;
   int on;
+  // replayed device route (QkvRopeRoute, ns_common.h; one row): k (rotated) and v also go to the reference's fp32 cache cells, and the
+  // position follows the captured graph's token counter
+  int kd_pos;
+  const int* kmove;
+  float* k32;
+  float* v32;
+  long long k32_head, k32_dim, k32_tok, v32_head, v32_dim, v32_tok;
+  uint32_t* ovf;
 };
 
 // one row of an expert group's device table (ns_moe.hip: MoeExpert — same layout)
@@ -128,6 +137,7 @@ struct GemvParams {
   const float* out_gamma;     // carried norm, producer: fp16 shadow = v * gamma[col] ...
   float* out_ssq;             // ... and out_ssq[row * out_stride + tile] = sum of v^2 over the tile's columns
   uint32_t out_stride;
+  uint32_t* out_ovf;          // pinned host word, set when gamma * v does not fit the fp16 shadow (ns_route.h: the route then evaluates the token again without carried norms)
   GemvRope rope;
   F4Lut lut;
   F8Consts f8;
@@ -782,6 +792,7 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
   int rope_head = 0, rope_e = 0;
   bool rope_on = false;
   _Float16* rope_cache = nullptr;
+  float* rope_cell = nullptr;
   long long rope_sl = 0;
   // carried norm, consumer side: A was gamma * x, not yet normalised; the row's 1 / rms scales the finished dot
   // products (ne_compute_forward_rms_norm_f32, ne_layers.c: scale = 1 / sqrtf(mean + eps)).  Per row the 64 lanes add
@@ -808,8 +819,12 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
             for (int rr = 0; rr < 4; rr++) cs[rr] = cold->rope.cos_sin[min(4 * g + rr, rows - 1) * (hs >> 1) + (rope_e >> 1)];
           }
           rope_sl = cold->rope.c_sl;
-          rope_cache = (sg == 1 ? cold->rope.kc : cold->rope.vc) + (long long)cold->rope.n_past * rope_sl +
+          const long long kk = cold->rope.kmove ? (long long)*cold->rope.kmove : 0ll;  // tokens since the plan was captured
+          rope_cache = (sg == 1 ? cold->rope.kc : cold->rope.vc) + ((long long)cold->rope.n_past + kk * cold->rope.kd_pos) * rope_sl +
                        (long long)rope_head * cold->rope.c_head + rope_e;
+          if (sg > 0 && cold->rope.k32)
+            rope_cell = sg == 1 ? cold->rope.k32 + kk * cold->rope.k32_tok + rope_head * cold->rope.k32_head + rope_e * cold->rope.k32_dim
+                                : cold->rope.v32 + kk * cold->rope.v32_tok + rope_head * cold->rope.v32_head + rope_e * cold->rope.v32_dim;
         }
       }
       if (in_ssq) {  // wave 0 requested the pieces itself and has waited for all its requests (last record: vmcnt 0)
@@ -854,7 +869,13 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
           if (sg < 2)
             v = (rope_e & 1) ? __fadd_rn(__fmul_rn(vp, cs[rr].y), __fmul_rn(v, cs[rr].x))
                              : __fsub_rn(__fmul_rn(v, cs[rr].x), __fmul_rn(vp, cs[rr].y));
-          if (ok && sg > 0) rope_cache[(long long)row * rope_sl] = (_Float16)v;
+          if (ok && sg > 0) {
+            rope_cache[(long long)row * rope_sl] = (_Float16)v;
+            if (rope_cell && row == 0) {
+              *rope_cell = v;
+              if (fabsf(v) > 65504.f && cold->rope.ovf) __hip_atomic_store(cold->rope.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+          }
         }
       }
       if (ok) {
@@ -878,6 +899,9 @@ __global__ __launch_bounds__(1024) void gemv_kernel(const GemvParams p) {
         // carried norm, producer side: the shadow the NEXT operator streams is gamma * v (its norm's weight), the
         // normalisation itself follows from the partial sums below
         if (c16) c16[size_t(row) * ldc + col] = (_Float16)(v * gam);
+        if constexpr (EXT) {
+          if (ogamma && fabsf(v * gam) > 65504.f && cold->out_ovf) __hip_atomic_store(cold->out_ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
       if (EXT && ossq) {  // sum of squares of this tile's 16 columns of row `row`, fixed order
         float t = ok ? v * v : 0.f;
@@ -1159,6 +1183,7 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
     if (k.out_ssq || k.out_gamma) {
       if (a.dual || nmat != 1 || (k.out_ssq && k.out_stride < w0->ntiles)) return hipErrorInvalidValue;
       p.out_gamma = k.out_gamma, p.out_ssq = k.out_ssq, p.out_stride = uint32_t(k.out_stride);
+      p.out_ovf = k.out_gamma ? kvm_overflow_word() : nullptr;
     }
   }
   if (a.rope) {
@@ -1172,6 +1197,15 @@ hipError_t launch_gemv(const SmallMArgs& a, hipStream_t st) {
     p.rope.head_size = r.head_size, p.rope.n_past = r.n_past;
     p.rope.cos_sin = reinterpret_cast<const float2*>(r.cos_sin);
     p.rope.on = 1;
+    if (a.rope_route) {
+      const QkvRopeRoute& q = *a.rope_route;
+      if (rows != 1) return hipErrorInvalidValue;
+      p.rope.kmove = q.kmove, p.rope.kd_pos = q.kd_pos;
+      p.rope.k32 = q.k32, p.rope.v32 = q.v32;
+      p.rope.k32_head = q.k32_head, p.rope.k32_dim = q.k32_dim, p.rope.k32_tok = q.k32_tok;
+      p.rope.v32_head = q.v32_head, p.rope.v32_dim = q.v32_dim, p.rope.v32_tok = q.v32_tok;
+      p.rope.ovf = q.overflow;
+    }
   }
   if (uint64_t(rows) * uint64_t(a.lda) * 4 >= (uint64_t(1) << 30)) return hipErrorNotSupported;  // staging offsets
 

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "ns_common.h"
+#include "ns_route.h"
 
 namespace ns {
 
@@ -899,9 +900,10 @@ __global__ void rope_qkv_append_kernel(float* __restrict__ q, const float* __res
 // (cos, sin) * attn_factor of the mode-0 pairs of positions n_past .. n_past + m - 1: the angle arithmetic of
 // rope_qkv_append_kernel, once per token for all layers (ns_qkv_rope)
 __global__ void rope_cos_sin_kernel(int m, int n_past, int npairs, float theta_scale, float freq_scale, float attn_factor,
-                                    float2* __restrict__ out) {
+                                    float2* __restrict__ out, const int* __restrict__ kmove, int kdelta) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= m * npairs) return;
+  if (kmove) n_past += kdelta * *kmove;  // replayed device route: the position moves with the graph's token counter
   const int i2 = gid / npairs, pr = gid % npairs;
   float theta_base = float(n_past + i2);
   for (int t = 0; t < pr; t++) theta_base = __fmul_rn(theta_base, theta_scale);
@@ -913,7 +915,7 @@ hipError_t launch_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, f
   const int total = m * (n_dims / 2);
   if (total <= 0) return hipSuccess;
   hipLaunchKernelGGL(rope_cos_sin_kernel, grid1d(size_t(total), 64), dim3(64), 0, st, m, n_past, n_dims / 2,
-                     powf(freq_base, -2.0f / n_dims), freq_scale, attn_factor, reinterpret_cast<float2*>(out));
+                     powf(freq_base, -2.0f / n_dims), freq_scale, attn_factor, reinterpret_cast<float2*>(out), g_affine.k, int(g_affine.delta));
   return hipGetLastError();
 }
 
@@ -1038,6 +1040,21 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
 
 thread_local Affine g_affine;
 thread_local void* g_mha_out16 = nullptr;
+thread_local KvMirrorPair g_kvm;
+// a cache cell at `addr` received `v`: its fp16 mirror cell, found from the cell's address (ns_route.h)
+__device__ __forceinline__ void kvm_store(const KvMirrorArgs& m, const char* addr, float v) {
+  if (!m.m16) return;
+  const long long idx = (addr - m.base32) >> 2;
+  if (idx < 0 || idx >= m.elems) return;
+  if (fabsf(v) > 65504.f && m.overflow) __hip_atomic_store(m.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (!m.transposed) {
+    m.m16[idx] = (_Float16)v;
+  } else {  // V cache [head][dim][position] -> mirror [head][position][dim]
+    const long long per = (long long)m.hs * m.n_ctx, bh = idx / per, r = idx - bh * per;
+    const long long dim = r / m.n_ctx, pos = r - dim * m.n_ctx;
+    m.m16[(bh * m.n_ctx + pos) * m.hs + dim] = (_Float16)v;
+  }
+}
 
 hipError_t launch_rope(const float* src, float* dst, int batch, int seq, int heads, int head_size, int n_past, int n_dims,
                        int mode, float freq_base, float freq_scale, float attn_factor, hipStream_t st, float ext_factor,
@@ -1151,7 +1168,7 @@ __global__ void dup_kernel(const char* __restrict__ src, char* __restrict__ dst,
 __global__ void rope_append_kernel(float* __restrict__ qk, int rows_front, int rows_k_first, int rows_k, int head_size, int n_past, int n_dims,
                                    int neox, float theta_scale, float freq_scale, float attn_factor, RopeYarn yarn, const float* __restrict__ ksrc,
                                    char* __restrict__ kdst, DupDims dk, const char* __restrict__ vsrc, char* __restrict__ vdst, DupDims dv,
-                                   const int* __restrict__ kmove, int kd_pos, long long kd_k, long long kd_v) {
+                                   const int* __restrict__ kmove, int kd_pos, long long kd_k, long long kd_v, KvMirrorPair kvm) {
   if (kmove) {
     const int kk = *kmove;
     n_past += kd_pos * kk;
@@ -1200,7 +1217,9 @@ __global__ void rope_append_kernel(float* __restrict__ qk, int rows_front, int r
         const long long i2d = i % dk.ne[2];
         const long long i3d = i / dk.ne[2];
         // (the cpy node indexes the source with the destination's coordinates: the element order of the packed source IS that walk)
-        *reinterpret_cast<float*>(kdst + i0d * dk.dnb[0] + i1d * dk.dnb[1] + i2d * dk.dnb[2] + i3d * dk.dnb[3]) = val;
+        char* cell = kdst + i0d * dk.dnb[0] + i1d * dk.dnb[1] + i2d * dk.dnb[2] + i3d * dk.dnb[3];
+        *reinterpret_cast<float*>(cell) = val;
+        kvm_store(kvm.k, cell, val);
       }
     }
     return;
@@ -1213,8 +1232,10 @@ __global__ void rope_append_kernel(float* __restrict__ qk, int rows_front, int r
   i /= dv.ne[1];
   const long long i2 = i % dv.ne[2];
   const long long i3 = i / dv.ne[2];
-  *reinterpret_cast<float*>(vdst + i0 * dv.dnb[0] + i1 * dv.dnb[1] + i2 * dv.dnb[2] + i3 * dv.dnb[3]) =
-      *reinterpret_cast<const float*>(vsrc + i0 * dv.snb[0] + i1 * dv.snb[1] + i2 * dv.snb[2] + i3 * dv.snb[3]);
+  const float vval = *reinterpret_cast<const float*>(vsrc + i0 * dv.snb[0] + i1 * dv.snb[1] + i2 * dv.snb[2] + i3 * dv.snb[3]);
+  char* vcell = vdst + i0 * dv.dnb[0] + i1 * dv.dnb[1] + i2 * dv.dnb[2] + i3 * dv.dnb[3];
+  *reinterpret_cast<float*>(vcell) = vval;
+  kvm_store(kvm.v, vcell, vval);
   (void)ksrc;
   (void)nk;
 }
@@ -1231,11 +1252,12 @@ hipError_t launch_rope_append(float* qk, int rows_front, int rows_k_first, int r
   if (!total) return hipSuccess;
   hipLaunchKernelGGL(rope_append_kernel, grid1d(total, 256), dim3(256), 0, st, qk, rows_front, rows_k_first, rows_k, head_size, n_past, n_dims,
                      neox ? 1 : 0, theta_scale, freq_scale, attn_factor, RopeYarn{ext_factor, corr0, corr1, nullptr, 1.f}, static_cast<const float*>(ksrc),
-                     static_cast<char*>(kdst), dk, static_cast<const char*>(vsrc), static_cast<char*>(vdst), dv, g_affine.k, int(g_affine.delta), kd_k, kd_v);
+                     static_cast<char*>(kdst), dk, static_cast<const char*>(vsrc), static_cast<char*>(vdst), dv, g_affine.k, int(g_affine.delta), kd_k, kd_v, g_kvm);
   return hipGetLastError();
 }
 __global__ void dup2_kernel(const char* __restrict__ src0, char* __restrict__ dst0, DupDims d0, int f16_0, const char* __restrict__ src1,
-                            char* __restrict__ dst1, DupDims d1, int f16_1, const int* __restrict__ kmove, long long kdelta0, long long kdelta1) {
+                            char* __restrict__ dst1, DupDims d1, int f16_1, const int* __restrict__ kmove, long long kdelta0, long long kdelta1,
+                            KvMirrorPair kvm) {
   const long long total0 = d0.ne[0] * d0.ne[1] * d0.ne[2] * d0.ne[3];
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool second = i >= total0;
@@ -1253,10 +1275,12 @@ __global__ void dup2_kernel(const char* __restrict__ src0, char* __restrict__ ds
   const long long i3 = i / d.ne[2];
   const float v = *reinterpret_cast<const float*>(src + i0 * d.snb[0] + i1 * d.snb[1] + i2 * d.snb[2] + i3 * d.snb[3]);
   char* o = dst + i0 * d.dnb[0] + i1 * d.dnb[1] + i2 * d.dnb[2] + i3 * d.dnb[3];
-  if (second ? f16_1 : f16_0)
+  if (second ? f16_1 : f16_0) {
     *reinterpret_cast<_Float16*>(o) = (_Float16)v;
-  else
+  } else {
     *reinterpret_cast<float*>(o) = v;
+    kvm_store(second ? kvm.v : kvm.k, o, v);  // (first copy: the K cells, second: the V cells — ns_route.cpp XK_DUP2)
+  }
 }
 hipError_t launch_dup2(const void* src0, void* dst0, const long long* ne0, const long long* snb0, const long long* dnb0, bool f16_0,
                        const void* src1, void* dst1, const long long* ne1, const long long* snb1, const long long* dnb1, bool f16_1, hipStream_t st) {
@@ -1266,7 +1290,7 @@ hipError_t launch_dup2(const void* src0, void* dst0, const long long* ne0, const
   if (total <= 0) return hipSuccess;
   hipLaunchKernelGGL(dup2_kernel, grid1d(size_t(total), 256), dim3(256), 0, st, static_cast<const char*>(src0), static_cast<char*>(dst0), d0,
                      f16_0 ? 1 : 0, static_cast<const char*>(src1), static_cast<char*>(dst1), d1, f16_1 ? 1 : 0, g_affine.k, g_affine.delta,
-                     g_affine.delta2);
+                     g_affine.delta2, g_kvm);
   return hipGetLastError();
 }
 hipError_t launch_dup(const void* src, void* dst, const long long* ne, const long long* snb, const long long* dnb, bool dst_f16,

@@ -49,35 +49,38 @@ def _ll(*v):
     return (C.c_longlong * 4)(*v)
 
 
-def _run(L, nso, blobs, gam, xs, positions, replay):
-    """the token stream; returns (outputs per token, K cache, V cache, route statistics)"""
-    _api(L)
-    L.ns_hip_route_set_enabled(1 if replay else 0)
-    dev = L.bestla_create_device(False)
-    q = L.bestla_get_device_queue(dev)
-    # weights through the reference's loader entry
-    stors, slices = {}, []
-    for name, blob in blobs.items():
-        size = int(np.frombuffer(blob[:8].tobytes(), np.uint64)[0])
-        dptr = L.bestla_device_malloc((size + 255) // 256 * 256, q)
-        stor = np.zeros(int(L.bestla_device_storage_size()), np.uint8)
-        L.bestla_device_load_storage(nso.ptr(blob.copy()), nso.ptr(stor), dptr, q)
-        stors[name] = stor
-        slices.append(dptr)
-    f4 = 4
-    pool_bytes = 1 << 20
-    pool = L.bestla_device_malloc(pool_bytes, q)
-    kc = L.bestla_device_malloc(HEADS * NCTX * HS * f4, q)  # [head][n_ctx][hs]
-    vc = L.bestla_device_malloc(HEADS * HS * NCTX * f4, q)  # [head][hs][n_ctx]
-    zero = np.zeros(HEADS * NCTX * HS, np.float32)
-    L.bestla_device_memcpy_sync(kc, nso.ptr(zero), zero.nbytes, q)
-    L.bestla_device_memcpy_sync(vc, nso.ptr(zero), zero.nbytes, q)
-    dg = L.bestla_device_malloc(D * f4, q)
-    L.bestla_device_memcpy_sync(dg, nso.ptr(gam), gam.nbytes, q)
-    outs = []
-    vec = lambda n: (_ll(n, 1, 1, 1), _ll(4, 4 * n, 4 * n, 4 * n))
-    for t, (x, pos) in enumerate(zip(xs, positions)):
-        base = pool + t * DELTA
+class _Stream:
+    """one device context (bestla_create_device) with its weights, activation pool and kv cache; token() issues one token's launches the way the
+    reference's executor does.  `late_extra`: the token gets one more launch at its end (an add) — it deviates from a plan AFTER every segment of
+    the plan has been launched."""
+
+    def __init__(self, L, nso, blobs, gam):
+        self.L, self.nso = L, nso
+        self.dev = L.bestla_create_device(False)
+        q = self.q = L.bestla_get_device_queue(self.dev)
+        self.stors, self.slices = {}, []
+        for name, blob in blobs.items():
+            size = int(np.frombuffer(blob[:8].tobytes(), np.uint64)[0])
+            dptr = L.bestla_device_malloc((size + 255) // 256 * 256, q)
+            stor = np.zeros(int(L.bestla_device_storage_size()), np.uint8)
+            L.bestla_device_load_storage(nso.ptr(blob.copy()), nso.ptr(stor), dptr, q)
+            self.stors[name] = stor
+            self.slices.append(dptr)
+        self.pool = L.bestla_device_malloc(1 << 20, q)
+        self.kc = L.bestla_device_malloc(HEADS * NCTX * HS * 4, q)  # [head][n_ctx][hs]
+        self.vc = L.bestla_device_malloc(HEADS * HS * NCTX * 4, q)  # [head][hs][n_ctx]
+        zero = np.zeros(HEADS * NCTX * HS, np.float32)
+        L.bestla_device_memcpy_sync(self.kc, nso.ptr(zero), zero.nbytes, q)
+        L.bestla_device_memcpy_sync(self.vc, nso.ptr(zero), zero.nbytes, q)
+        self.dg = L.bestla_device_malloc(D * 4, q)
+        L.bestla_device_memcpy_sync(self.dg, nso.ptr(gam), gam.nbytes, q)
+        self.t = 0
+
+    def token(self, x, pos, late_extra=False):
+        L, nso, q, stors, kc, vc, dg, f4 = self.L, self.nso, self.q, self.stors, self.kc, self.vc, self.dg, 4
+        vec = lambda n: (_ll(n, 1, 1, 1), _ll(4, 4 * n, 4 * n, 4 * n))
+        base = self.pool + self.t * DELTA
+        self.t += 1
         off = [0]
 
         def alloc(nfloat):
@@ -87,6 +90,7 @@ def _run(L, nso, blobs, gam, xs, positions, replay):
         px, pn, ph, pk, pv, pq = alloc(D), alloc(D), alloc(D), alloc(D), alloc(D), alloc(D)
         pt, pr, pn2, ph2 = alloc(D), alloc(D), alloc(D), alloc(D)
         pt1, ps, pt3, pp, pt2, po = alloc(FF), alloc(FF), alloc(FF), alloc(FF), alloc(D), alloc(D)
+        po2 = alloc(D)
         # (allocation order as the llama graph makes it: q in front of k in front of v is NOT assumed — here k, v, q like the graph's dump)
         L.bestla_device_sync(q)
         L.bestla_device_memcpy_sync(px, nso.ptr(x), x.nbytes, q)
@@ -116,20 +120,36 @@ def _run(L, nso, blobs, gam, xs, positions, replay):
         assert L.ns_hip_lazy_mul(ps, pt3, pp, nef, nbf, nef, nbf, nbf, q) == 0
         L.bestla_device_f32f32_forward(pp, nso.ptr(stors["w2"]), pt2, 1, D, FF, FF, D, None, q)
         assert L.ns_hip_binary_nd_f32(0, pt2, pr, po, ne, nb, ne, nb, nb, q) == 0
+        if late_extra:   # out = (down + residual) + input embedding: reads the token's INPUT again after everything else ran
+            assert L.ns_hip_binary_nd_f32(0, po, px, po2, ne, nb, ne, nb, nb, q) == 0
+            po = po2
         L.bestla_device_sync(q)
         out = np.zeros(D, np.float32)
         L.bestla_device_memcpy_sync(nso.ptr(out), po, out.nbytes, q)
-        outs.append(out)
-    kcache, vcache = np.zeros(HEADS * NCTX * HS, np.float32), np.zeros(HEADS * HS * NCTX, np.float32)
-    L.bestla_device_memcpy_sync(nso.ptr(kcache), kc, kcache.nbytes, q)
-    L.bestla_device_memcpy_sync(nso.ptr(vcache), vc, vcache.nbytes, q)
+        return out
+
+    def finish(self):
+        L, nso, q = self.L, self.nso, self.q
+        kcache, vcache = np.zeros(HEADS * NCTX * HS, np.float32), np.zeros(HEADS * HS * NCTX, np.float32)
+        L.bestla_device_memcpy_sync(nso.ptr(kcache), self.kc, kcache.nbytes, q)
+        L.bestla_device_memcpy_sync(nso.ptr(vcache), self.vc, vcache.nbytes, q)
+        for s in self.stors.values():
+            L.ns_hip_device_storage_release(nso.ptr(s))
+        for p in self.slices + [self.pool, self.kc, self.vc, self.dg]:
+            L.bestla_device_free(p, q)
+        L.bestla_release_device(self.dev)
+        return kcache, vcache
+
+
+def _run(L, nso, blobs, gam, xs, positions, replay, late=()):
+    """the token stream; returns (outputs per token, K cache, V cache, route statistics)"""
+    _api(L)
+    L.ns_hip_route_set_enabled(1 if replay else 0)
+    sm = _Stream(L, nso, blobs, gam)
+    outs = [sm.token(x, pos, late_extra=(t in late)) for t, (x, pos) in enumerate(zip(xs, positions))]
     st = (C.c_uint64 * 8)()
     L.ns_hip_route_stats(st)
-    for s in stors.values():
-        L.ns_hip_device_storage_release(nso.ptr(s))
-    for p in slices + [pool, kc, vc, dg]:
-        L.bestla_device_free(p, q)
-    L.bestla_release_device(dev)
+    kcache, vcache = sm.finish()
     L.ns_hip_route_set_enabled(1)
     return outs, kcache, vcache, list(st)
 
@@ -140,7 +160,7 @@ def test_replayed_tokens_and_a_deviating_token_compute_what_plain_launches_compu
     blobs = {"wq": mk(D, D), "wk": mk(D, D), "wv": mk(D, D), "wo": mk(D, D), "w1": mk(FF, D), "w3": mk(FF, D), "w2": mk(D, FF)}
     gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
     # positions 0..7, then a JUMP (token 8 is at position 20), then on from there
-    positions = list(range(8)) + [20, 21, 22, 23, 24, 25]
+    positions = list(range(8)) + list(range(20, 32))
     xs = [rng.standard_normal(D).astype(np.float32) for _ in positions]
     base = [int(v) for v in (C.c_uint64 * 8)()]
     st0 = (C.c_uint64 * 8)()
@@ -151,16 +171,78 @@ def test_replayed_tokens_and_a_deviating_token_compute_what_plain_launches_compu
     L.ns_hip_route_stats(st1)
     got_out, got_k, got_v, st2 = _run(L, nso, blobs, gam, xs, positions, replay=True)
     replayed, eager, plans, fallbacks = (st2[i] - st1[i] for i in range(4))
-    # tokens 0, 1 launched one by one -> plan; 2..7 replayed; 8 deviates (fallback).  Tokens 7 and 8 agree in everything but their moving
-    # values (position +13), so they make a plan too — which token 9 (position +1) leaves at its first rope: a second fallback; 8 and 9
-    # make the plan that 10..13 are replayed from
-    assert (replayed, eager, plans, fallbacks) == (10, 4, 3, 2), (replayed, eager, plans, fallbacks)
+    # tokens 0, 1 go out through the window -> plan; 2..7 replayed; 8 deviates (fallback).  Tokens 7 and 8 agree in everything but their moving
+    # values (position +13), so they make a plan too — which token 9 (position +1) leaves at its first rope: a second fallback IN A ROW, after
+    # which the next plan waits for four agreeing tokens (round 6: no capture every other token for interleaved sequences): 9 .. 13 go through the
+    # window, 12 and 13 make the plan that 14 .. 19 are replayed from
+    assert (replayed, eager, plans, fallbacks) == (12, 8, 3, 2), (replayed, eager, plans, fallbacks)
     assert st2[5] < st2[4], (st2[4], st2[5])  # the plan's graphs hold fewer launches than the token has (fused QKV / gate-up / residual adds / rope + cache writes)
     for t, (a, b) in enumerate(zip(ref_out, got_out)):
         # fused launches compute the same values (the residual add in the GEMV's epilogue, silu * up in registers): bit-equal or last-bit close
         assert np.allclose(a, b, rtol=2e-5, atol=2e-5), (t, float(np.abs(a - b).max()))
     assert np.array_equal(ref_k, got_k) and np.array_equal(ref_v, got_v)
     assert np.count_nonzero(got_k) > 0 and np.count_nonzero(got_v) > 0
+
+
+def _blobs(nso, rng):
+    mk = lambda n, k: nso.quant_pack((rng.standard_normal((n, k)) * k ** -0.5).astype(np.float32), 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    return {"wq": mk(D, D), "wk": mk(D, D), "wv": mk(D, D), "wo": mk(D, D), "w1": mk(FF, D), "w3": mk(FF, D), "w2": mk(D, FF)}
+
+
+def test_a_token_that_deviates_after_every_segment_ran_is_issued_again_from_its_kept_input(L, pkg, nso):
+    """a replayed token runs on the PLAN's activations, and its own tensors sit only DELTA * k bytes above them — inside memory the
+    plan's segments write.  Token 6 is the plan's launches plus one more at its end that reads the token's INPUT again: every segment has been
+    launched when it deviates, the input it asked for has been written over, and the token must still compute what plain launches compute (the
+    route keeps a device-side copy of every evaluation's input and puts it back before it issues the token again)."""
+    rng = np.random.default_rng(33)
+    blobs = _blobs(nso, rng)
+    gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    positions = list(range(12))
+    xs = [rng.standard_normal(D).astype(np.float32) for _ in positions]
+    _api(L)
+    ref_out, ref_k, ref_v, _ = _run(L, nso, blobs, gam, xs, positions, replay=False, late=(6,))
+    st1 = (C.c_uint64 * 8)()
+    L.ns_hip_route_stats(st1)
+    got_out, got_k, got_v, st2 = _run(L, nso, blobs, gam, xs, positions, replay=True, late=(6,))
+    replayed, eager, plans, fallbacks = (st2[i] - st1[i] for i in range(4))
+    # 0, 1 -> plan; 2 .. 5 replayed; 6 falls back at its extra launch; 7 deviates from nothing (no plan held); 7, 8 make the next plan; 9 .. 11 replayed
+    assert (replayed, eager, plans, fallbacks) == (7, 5, 2, 1), (replayed, eager, plans, fallbacks)
+    for t, (a, b) in enumerate(zip(ref_out, got_out)):
+        assert np.allclose(a, b, rtol=2e-5, atol=2e-5), (t, float(np.abs(a - b).max()))
+    assert np.array_equal(ref_k, got_k) and np.array_equal(ref_v, got_v)
+
+
+def test_two_device_contexts_alternating_tokens_keep_separate_plans(L, pkg, nso):
+    """round 5 had ONE process-global route bound to the first queue — a second model (a draft + a target model, two servers in one
+    process) ran unrecorded or thrashed the first one's plan.  Round 6: one route per device queue.  Two contexts with different weights generate
+    alternately, token by token; each must replay from its own plan and compute what it computes alone with the layer off."""
+    rng = np.random.default_rng(34)
+    blobs_a, blobs_b = _blobs(nso, rng), _blobs(nso, rng)
+    gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    n = 10
+    xa = [rng.standard_normal(D).astype(np.float32) for _ in range(n)]
+    xb = [rng.standard_normal(D).astype(np.float32) for _ in range(n)]
+    _api(L)
+    ref_a = _run(L, nso, blobs_a, gam, xa, list(range(n)), replay=False)
+    ref_b = _run(L, nso, blobs_b, gam, xb, list(range(5, 5 + n)), replay=False)
+    st1 = (C.c_uint64 * 8)()
+    L.ns_hip_route_stats(st1)
+    L.ns_hip_route_set_enabled(1)
+    sa, sb = _Stream(L, nso, blobs_a, gam), _Stream(L, nso, blobs_b, gam)
+    out_a, out_b = [], []
+    for t in range(n):
+        out_a.append(sa.token(xa[t], t))
+        out_b.append(sb.token(xb[t], 5 + t))
+    st2 = (C.c_uint64 * 8)()
+    L.ns_hip_route_stats(st2)
+    ka, va = sa.finish()
+    kb, vb = sb.finish()
+    replayed, eager, plans, fallbacks = (st2[i] - st1[i] for i in range(4))
+    assert (replayed, eager, plans, fallbacks) == (2 * (n - 2), 4, 2, 0), (replayed, eager, plans, fallbacks)
+    for ref, outs, kk, vv in ((ref_a, out_a, ka, va), (ref_b, out_b, kb, vb)):
+        for t, (a, b) in enumerate(zip(ref[0], outs)):
+            assert np.allclose(a, b, rtol=2e-5, atol=2e-5), (t, float(np.abs(a - b).max()))
+        assert np.array_equal(ref[1], kk) and np.array_equal(ref[2], vv)
 
 
 NL = 2  # decoder layers of the second stream
@@ -318,3 +400,33 @@ def test_replayed_attention_over_several_context_ranges(L, pkg, nso):
         assert nso.rel_l2(b, a) < 2e-3, (t, nso.rel_l2(b, a))
     for a, b in zip(ref_c, got_c):
         assert nso.rel_l2(b, a) < 2e-3
+
+
+def test_values_beyond_fp16_turn_the_fp16_shortcuts_off_and_the_token_is_evaluated_again(L, pkg, nso, capfd):
+    """the route's fp16 shortcuts — the kv mirror its attention reads, a carried norm's shadow — cannot hold |x| > 65504, which
+    the fp32 kernels of the reference's device path can.  A key projection scaled so that K is ~1e5: the converting kernel raises the flag, the route
+    reads it behind the token's synchronisation, says so once on stderr, turns both shortcuts off for the process and evaluates the token again on
+    the fp32 forms BEFORE its result is copied out — every token then equals the run that had the mirror off from the start (NS_DEVICE_KV=f32)."""
+    rng = np.random.default_rng(8)
+    mk = lambda n, k, s=1.0: nso.quant_pack((rng.standard_normal((n, k)) * s * k ** -0.5).astype(np.float32), 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    blobs = {"wq": mk(D, D, 1e-4), "wk": mk(D, D, 1e5), "wv": mk(D, D), "wo": mk(D, D), "w1": mk(FF, D), "w3": mk(FF, D), "w2": mk(D, FF)}
+    gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    xs = [rng.standard_normal(D).astype(np.float32) for _ in range(8)]
+    _api(L)
+    L.ns_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    try:
+        assert L.ns_hip_set_tuning(b"device_kv_f16", 0) == 0
+        ref_out, ref_c, _ = _run_layers(L, nso, blobs, gam, xs, replay=5)   # fp32 kernels, plans without carried norms
+        capfd.readouterr()
+        assert L.ns_hip_set_tuning(b"device_kv_f16", 1) == 0
+        got_out, got_c, _ = _run_layers(L, nso, blobs, gam, xs, replay=3)   # mirror + carried norms: overflows at the first token
+        err = capfd.readouterr().err
+        assert err.count("beyond the fp16 range") == 1, err[-1500:]
+        for t, (a, b) in enumerate(zip(ref_out, got_out)):
+            assert np.all(np.isfinite(b)), t
+            assert nso.rel_l2(b, a) < 2e-3, (t, nso.rel_l2(b, a))
+        for a, b in zip(ref_c, got_c):
+            assert np.array_equal(a, b) or nso.rel_l2(b, a) < 2e-3
+    finally:
+        L.ns_hip_set_tuning(b"device_kv_f16", -1)
+        L.ns_hip_route_set_enabled(1)

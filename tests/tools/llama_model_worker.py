@@ -35,7 +35,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 import ne_file  # noqa: E402
 import nso  # noqa: E402
 
-V, D, HEADS, FF, LAYERS, N_CTX, EPS, BASE = 384, 256, 4, 704, 22, 64, 1e-5, 10000.0
+V, D, HEADS, FF, LAYERS, EPS, BASE = 384, 256, 4, 704, 22, 1e-5, 10000.0
+N_CTX = int(os.environ.get("NS_WORKER_N_CTX", "64"))   # (long generations: test_gpu_llama_model.py's 330-token run)
 PROMPT = [1, 17, 200, 3, 99, 42, 311]   # bos first (llama.cpp:80-85 warns otherwise)
 N_NEW = int(os.environ.get("NS_WORKER_N_NEW", "6"))
 KV = {"auto": 0, "f16": 1, "f32": 2}
@@ -193,8 +194,9 @@ def weights_from_file(path):
     return deq
 
 
-def model_fp64(deq, heads_kv, tokens, kv_fp16, n_experts=0, gaps=None):
-    """logits of the LAST position.  gaps (list): receives, per layer and position, the relative gap between the second and
+def model_fp64(deq, heads_kv, tokens, kv_fp16, n_experts=0, gaps=None, all_positions=False):
+    """logits of the LAST position (all_positions: of every position — the model is causal, row t is what it says after tokens[: t + 1]).
+    gaps (list): receives, per layer and position, the relative gap between the second and
     the third router probability (how safely the two experts were chosen)"""
     hs, T, grp = D // HEADS, len(tokens), HEADS // heads_kv
 
@@ -246,7 +248,7 @@ def model_fp64(deq, heads_kv, tokens, kv_fp16, n_experts=0, gaps=None):
         else:
             g = h2 @ deq[p + "feed_forward.w1.weight"]
             x = x + (g / (1 + np.exp(-g)) * (h2 @ deq[p + "feed_forward.w3.weight"])) @ deq[p + "feed_forward.w2.weight"]
-    return rms(x[-1:], deq["norm.weight"]) @ deq["output.weight"]
+    return rms(x if all_positions else x[-1:], deq["norm.weight"]) @ deq["output.weight"]
 
 
 def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
@@ -342,8 +344,14 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     deq = weights_from_file(qpath)
     # independent fp64 model: same greedy tokens wherever its own top-1 margin is clear of the path's tolerance
     seq, errs, margins, gaps = list(PROMPT), [], [], []
+    # the device route's attention reads an fp16 mirror of its fp32 cache (csrc/ns_route.h) unless NS_DEVICE_KV=f32 keeps the fp32 kernels
+    kv16_model = kv != "f32" or (device and os.environ.get("NS_DEVICE_KV", "f16") not in ("f32", "fp32", "0"))
+    long_run = family == "llama" and not n_experts and N_NEW > 16
+    if long_run:   # one pass over the whole generated sequence instead of one per token (the model is causal)
+        want_all = model_fp64(deq, heads_kv, list(PROMPT) + toks[:-1], kv16_model, all_positions=True)
     for i in range(N_NEW):
-        want = (model_fp64(deq, heads_kv, seq, kv != "f32", n_experts, gaps) if family == "llama" else model_fp64_gptj(deq, seq, kv != "f32"))[0]
+        want = (want_all[len(PROMPT) - 1 + i] if long_run else
+                (model_fp64(deq, heads_kv, seq, kv16_model, n_experts, gaps) if family == "llama" else model_fp64_gptj(deq, seq, kv != "f32"))[0])
         errs.append(nso.rel_l2(logits[i], want))
         top = np.sort(want)[-2:]
         margins.append(float(top[1] - top[0]))
