@@ -104,10 +104,13 @@ def run_device(path, prompt, n_new, n_ctx):
     tail = [times[i] for i in range(nt // 2, nt)]
     ref.nellama_prompt_us.restype = C.c_double
     pus = ref.nellama_prompt_us() if len(prompt) > 1 else 0.0
+    ref.nellama_prompt_warm_us.restype = C.c_double
+    pwarm = ref.nellama_prompt_warm_us()   # NS_HARNESS_PROMPT_REPEAT=1: the prompt evaluated a second time in the same context
     rs = (C.c_uint64 * 8)()
     hip.ns_hip_route_stats(rs)
     return {"n_prompt": len(prompt), "n_new": n_new, "n_ctx": n_ctx, "tokens": list(toks),
             "prompt_ms": round(pus / 1e3, 3), "prompt_tokens_per_s": round(len(prompt) * 1e6 / max(1.0, pus), 1),
+            "prompt_ms_second_evaluation": round(pwarm / 1e3, 3) if pwarm else None,
             "single_token_evals": nt, "us_median": round(ev[nt // 2], 1) if nt else None,
             "tokens_per_s_median": round(1e6 / ev[nt // 2], 1) if nt else None,
             "tokens_per_s_second_half": round(1e6 * len(tail) / max(1e-9, sum(tail)), 1) if tail else None,
@@ -170,7 +173,8 @@ def main(mode="device", n_new="24", n_ctx="512"):
         r = run_device(path, prompt, n_new, n_ctx)
         print(json.dumps({"load": r["load"]}), flush=True)
         if len(prompt) > 1:
-            print(json.dumps({"prompt_eval": {"tokens": len(prompt), "ms": r["prompt_ms"], "tokens_per_s": r["prompt_tokens_per_s"]}}), flush=True)
+            print(json.dumps({"prompt_eval": {"tokens": len(prompt), "ms": r["prompt_ms"], "tokens_per_s": r["prompt_tokens_per_s"],
+                                              "ms_second_evaluation": r["prompt_ms_second_evaluation"]}}), flush=True)
         print(json.dumps({k: r[k] for k in ("replay", "single_token_evals", "us_median", "tokens_per_s_median", "tokens_per_s_second_half", "us_max")}), flush=True)
         print('{"route": "device-resident (reference built with -DNS_SYCL on bestla_device_*)", "model": "llama-2-7b-shaped synthetic, Q4_0 g32 bf16", '
               '"us_per_token": %.1f, "tokens_per_s": %.1f, "n_ctx": %d, "tokens": %s, "wall_s": %.1f}' % (
