@@ -206,6 +206,67 @@ int nellama_generate_dev(const char* model_path, const int* prompt, int n_prompt
   model_release_sycl(dev);
   return made;
 }
+/* A conversation on the device route: turn t evaluates its prompt chunk (n_tok[t] tokens: one model_eval over all of them) at the position the
+ * previous turn ended on — or, when rewind[t] != 0, at position 0 of the SAME context (the cache is written over: a new sequence) — and then
+ * generates n_new[t] tokens greedily.  What the route's layers see: a plan held over single-token evals meets a multi-token eval (it falls back through the window),
+ * the fp16 kv mirror converts a chunk in the middle of a cache / starts over, two agreeing tokens make the next plan.  out_tokens / out_logits: every
+ * generated token of every turn in order ([sum n_new] and [sum n_new][n_vocab]).  Returns the number of generated tokens, < 0 on failure. */
+int nellama_generate_dev_turns(const char* model_path, int n_turns, const int* chunks, const int* n_tok, const int* n_new, const int* rewind, int n_ctx,
+                               int n_gpu_layers, int* out_tokens, float* out_logits) {
+  model_init_backend();
+  ne_sycl_context* dev = model_init_sycl(false);
+  if (!dev) return -3;
+  model_context_params p = model_context_default_params();
+  p.arch = NS_FAMILY_ARCH;
+  p.n_ctx = n_ctx;
+  p.seed = 1;
+  p.kv_type = KV_MEM_TYPE_F32;
+  p.use_mmap = false;
+  p.batch_size = 1;
+  p.max_request_num = 1;
+  p.beam_size = 1;
+  p.beam_search = false;
+  p.cont_batching = false;
+  p.scratch_size_ratio = 0.125f;
+  p.n_gpu_layers = n_gpu_layers;
+  p.dev_ctx = dev;
+  model_context* ctx = model_init_from_file(model_path, p);
+  if (!ctx) return -1;
+  const int n_vocab = model_n_vocab(ctx);
+  int n_past = 0, made = 0, off = 0;
+  for (int t = 0; t < n_turns; t++) {
+    if (rewind[t]) n_past = 0;
+    std::vector<model_token> cur(chunks + off, chunks + off + n_tok[t]);
+    off += n_tok[t];
+    const int n_prompt = n_tok[t];
+    for (int step = 0; step < n_new[t]; step++) {
+      model_input in;
+      in.tokens = cur.data();
+      in.n_tokens = static_cast<uint32_t>(cur.size());
+      in.n_prompt_tokens = static_cast<uint32_t>(n_prompt);
+      in.n_past = static_cast<uint32_t>(n_past);
+      in.n_total = static_cast<uint32_t>(n_past);
+      in.request_idx = 0;
+      in.beam_idx = 0;
+      if (model_eval(ctx, &in, 1, 1) != 0) {
+        model_free(ctx);
+        return -2;
+      }
+      n_past += static_cast<int>(cur.size());
+      const float* logits = model_get_logits(ctx);
+      int best = 0;
+      for (int i = 1; i < n_vocab; i++)
+        if (logits[i] > logits[best]) best = i;
+      if (out_logits) memcpy(out_logits + static_cast<size_t>(made) * n_vocab, logits, sizeof(float) * n_vocab);
+      out_tokens[made++] = best;
+      cur.assign(1, best);
+    }
+    /* (the last generated token of a turn is not evaluated: the next chunk follows the cache as it stands, as a chat front end that cuts a reply does) */
+  }
+  model_free(ctx);
+  model_release_sycl(dev);
+  return made;
+}
 #endif
 
 /* Continuous batching the way the reference's serving loop evaluates it (models/llama/llama.cpp:66-70, :330-350, :496-571:

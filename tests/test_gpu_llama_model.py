@@ -125,3 +125,20 @@ def test_device_route_330_replayed_tokens_over_a_growing_context_match_the_fp64_
     first = int(np.argmax(a["tokens"] != b["tokens"])) if same < len(a["tokens"]) else len(a["tokens"])
     assert first >= 8, (first, same)
     assert nso.rel_l2(a["logits"][:first], b["logits"][:first]) < 5e-3
+
+
+def test_device_route_conversation_follow_up_chunk_and_a_new_sequence_in_the_same_cache(tmp_path):
+    """Plan, window and kv mirror across evaluation shapes (round 6): a prompt and 12 replayed tokens; a 5-token chunk that FOLLOWS the cache (a multi-token
+    evaluation meets the held plan: fall-back through the window, the mirror converts positions in the middle of the cache) and 12 tokens; a 9-token chunk
+    evaluated at position 0 of the same cache (a new sequence written over the old one: the mirror's marks go back) and 12 tokens.  The worker checks every
+    generated token's logits against the fp64 model of what the cache holds at that point.  (Batch > 1, beam search and the ring-buffer shift are not device shapes
+    of the reference itself: its device branch is taken for one request of one group without shift only — models/llama/llama.cpp:241-242.)"""
+    import re
+    run_worker("product", tmp_path, "auto", 4)
+    out = run_worker("device", tmp_path, "f32", 4, given=tmp_path / "llama_q_product_4.bin", env={"NS_WORKER_TURNS": "1"})
+    m = re.search(r"device route replay: tokens_replayed=(\d+) tokens_eager=(\d+) plans=(\d+) fallbacks=(\d+)", out)
+    assert m, out[-2000:]
+    replayed, eager, plans, fallbacks = (int(x) for x in m.groups())
+    # per turn: the chunk and two tokens go through the window, then a plan; every later chunk drops the plan it meets
+    assert plans == 3 and fallbacks == 2 and replayed >= 3 * 8, m.group(0)
+    assert "three turns" in out

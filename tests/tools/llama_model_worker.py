@@ -251,6 +251,53 @@ def model_fp64(deq, heads_kv, tokens, kv_fp16, n_experts=0, gaps=None, all_posit
     return rms(x if all_positions else x[-1:], deq["norm.weight"]) @ deq["output.weight"]
 
 
+def device_turns(ref, qpath, heads_kv):
+    """A conversation through the reference's unchanged model_eval on the device route (oracle/llama_ref_harness.cpp nellama_generate_dev_turns):
+    prompt, 12 tokens; a second chunk of 5 tokens that FOLLOWS the cache, 12 tokens; a third chunk of 9 tokens that starts over at position 0 of the
+    same cache, 12 tokens.  Every generated token's logits against the fp64 model of the sequence the cache holds at that point."""
+    rng = np.random.default_rng(3)
+    chunks = [list(PROMPT), [int(t) for t in rng.integers(3, V, 5)], [1] + [int(t) for t in rng.integers(3, V, 8)]]
+    n_new, rewind = [12, 12, 12], [0, 0, 1]
+    flat = [t for c in chunks for t in c]
+    total = sum(n_new)
+    toks = (C.c_int * total)()
+    logits = np.zeros((total, V), np.float32)
+    ia = lambda v: (C.c_int * len(v))(*v)
+    ref.nellama_generate_dev_turns.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = ref.nellama_generate_dev_turns(qpath.encode(), 3, ia(flat), ia([len(c) for c in chunks]), ia(n_new), ia(rewind), N_CTX, LAYERS, toks, logits.ctypes.data)
+    assert n == total, n
+    toks = list(toks)
+    hipl = C.CDLL(os.path.join(ROOT, "neural-speed_amd", "libns_hip.so"))
+    rs = (C.c_uint64 * 8)()
+    hipl.ns_hip_route_stats(rs)
+    print("device route replay: tokens_replayed=%d tokens_eager=%d plans=%d fallbacks=%d launches_per_token=%d captured_launches=%d capture_failures=%d"
+          % (rs[0], rs[1], rs[2], rs[3], rs[4], rs[5], rs[6]))
+    deq = weights_from_file(qpath)
+    kv16_model = os.environ.get("NS_DEVICE_KV", "f16") not in ("f32", "fp32", "0")
+    errs, checked = [], 0
+    seq, made = [], 0
+    for t, chunk in enumerate(chunks):
+        if rewind[t]:
+            seq = []
+        # the cache holds: what it held, this chunk, and the turn's generated tokens but the last (which is never evaluated)
+        gen = toks[made:made + n_new[t]]
+        full = seq + chunk + gen[:-1]
+        want_all = model_fp64(deq, heads_kv, full, kv16_model, all_positions=True)
+        for i in range(n_new[t]):
+            want = want_all[len(seq) + len(chunk) - 1 + i]
+            errs.append(nso.rel_l2(logits[made + i], want))
+            top = np.sort(want)[-2:]
+            if top[1] - top[0] > 0.05:
+                assert gen[i] == int(np.argmax(want)), (t, i, gen[i], int(np.argmax(want)))
+                checked += 1
+        seq = full
+        made += n_new[t]
+    print("device route, three turns (follow-up chunk, then a new sequence at position 0 of the same cache): tokens %s, logits rel l2 vs the fp64 model max %.2e, "
+          "%d of %d tokens had a clear margin and are the model's" % (toks, max(errs), checked, total))
+    assert max(errs) < 1e-2, errs
+    print("LLAMA_MODEL_DEVICE_OK")
+
+
 def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
     heads_kv = int(heads_kv)
     given = None if given in (None, "-") else given
@@ -321,6 +368,8 @@ def main(mode, workdir, kv, heads_kv, given=None, family="llama"):
             else:
                 assert typ == ne_file.NE_TYPE_F32 and data == np.ascontiguousarray(t, np.float32).tobytes(), name
         print("reference quantizer driver on libns_hip.so: %d BTLA blobs equal to the oracle's in every written byte" % n_blobs)
+    if device and os.environ.get("NS_WORKER_TURNS") == "1":
+        return device_turns(ref, qpath, heads_kv)
     toks = (C.c_int * N_NEW)()
     logits = np.zeros((N_NEW, V), np.float32)
     prompt = (C.c_int * len(PROMPT))(*PROMPT)
