@@ -712,11 +712,15 @@ namespace ns {
 int qkv_rope_route_forward(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk, const ns_weight* wv, float* cq, float* ck,
                            float* cv, int lda, const ns_norm_link* link, const ns_qkv_rope* rope, const QkvRopeRoute* rr, hipStream_t st) {
   if (!have_device()) return -1;
-  if (!wq || !wk || !wv || !dA16 || !cq || !ck || !cv || !rope || !rr) {
+  const ns_weight* ws[3] = {wq, wk, wv};
+  if (!rr) {  // a window's prompt-sized launch (rows: rope->flags' place is taken by the caller's m in `lda`'s partner below): the tiled GEMM carries the epilogue
+    set_error("route qkv+rope: prompt-sized calls go through qkv_rope_route_forward_m");
+    return -1;
+  }
+  if (!wq || !wk || !wv || !dA16 || !cq || !ck || !cv || !rope) {
     set_error("route qkv+rope: null argument");
     return -1;
   }
-  const ns_weight* ws[3] = {wq, wk, wv};
   bool same = !ref_int8_for(wq);
   for (int i = 0; i < 3; i++)
     same &= ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize && ws[i]->scale_dt == wq->scale_dt &&
@@ -735,6 +739,29 @@ int qkv_rope_route_forward(const float* dA, const void* dA16, const ns_weight* w
   a.rope = rope;
   a.rope_route = rr;
   return hip_ok(launch_smallm(a, st), "route qkv+rope launch") ? 0 : -1;
+}
+// ... and of a window's prompt-sized evaluation (m > 16): the tiled GEMM's fused-QKV launch rotates q / k from a table of m positions, writes the three fp32
+// tensors where the graph has them and k / v as fp16 into the kv mirror (rope->kcache16 / vcache16).  -2: the launch does not take this shape (the caller keeps
+// its separate launches)
+int qkv_rope_route_forward_m(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk, const ns_weight* wv, float* cq, float* ck, float* cv, int m,
+                             int lda, int ldc, const ns_qkv_rope* rope, hipStream_t st) {
+  if (!have_device()) return -1;
+  const ns_weight* ws[3] = {wq, wk, wv};
+  if (!wq || !wk || !wv || !dA || !cq || !ck || !cv || !rope || m <= 16) return -2;
+  bool one = !ref_int8_for(wq) && wq->kind != WK_F8;
+  for (int i = 0; i < 3; i++)
+    one &= ws[i]->k == wq->k && ws[i]->kind == wq->kind && ws[i]->blocksize == wq->blocksize && ws[i]->scale_dt == wq->scale_dt && ws[i]->asym == wq->asym &&
+           ws[i]->qtype == wq->qtype && !ws[i]->shuf && !ws[i]->load_failed;
+  if (!one) return -2;
+  SmallMArgs a{};
+  a.a = dA, a.a16 = dA16, a.lda = lda, a.m = m, a.ldc = ldc, a.nseg = 3;
+  float* cs[3] = {cq, ck, cv};
+  for (int i = 0; i < 3; i++) a.seg[i] = {ws[i], cs[i], nullptr};
+  a.epilogue = NS_EPI_NONE;
+  a.rope = rope;
+  const hipError_t e = launch_gemm2(a, st);
+  if (e == hipErrorNotSupported) return -2;
+  return hip_ok(e, "route qkv+rope GEMM launch") ? 0 : -1;
 }
 void set_error(const std::string& s) { g_err = s; }
 bool route_link_weight_ok(const ns_weight* w) { return w && !w->shuf && !w->load_failed && !ref_int8_for(w) && w->kind != WK_F8 && smallm_supported(w, 1); }

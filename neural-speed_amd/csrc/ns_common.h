@@ -341,6 +341,9 @@ hipError_t launch_rope_glm(const float* src, float* dst, int batch, int seq, int
 hipError_t launch_rope_cos_sin(int m, int n_past, int n_dims, float freq_base, float freq_scale, float attn_factor,
                                float* out, hipStream_t st);  // (n_past follows g_affine inside a route capture)
 // ns_api.cpp: the fused QKV + RoPE + cache-write launch of a replayed token: weights by ROLE, each result at its own tensor
+int qkv_rope_route_forward_m(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk, const ns_weight* wv, float* cq, float* ck, float* cv, int m,
+                             int lda, int ldc, const ns_qkv_rope* rope, hipStream_t st);  // a window's prompt-sized form (-2: shape not taken)
+extern thread_local bool g_mha_out16_written;  // the device-layout attention wrote the fp16 copy it was asked for (g_mha_out16)
 int qkv_rope_route_forward(const float* dA, const void* dA16, const ns_weight* wq, const ns_weight* wk, const ns_weight* wv, float* cq, float* ck,
                            float* cv, int lda, const ns_norm_link* link, const ns_qkv_rope* rope, const QkvRopeRoute* rr, hipStream_t st);
 hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void* kc, void* vc, int seq, int heads,

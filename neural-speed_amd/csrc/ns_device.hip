@@ -411,6 +411,7 @@ struct KvMirror {
   int slots = 0, heads_kv = 0, hs = 0, n_ctx = 0;
   _Float16 *k16 = nullptr, *v16 = nullptr;  // [slots][heads_kv][n_ctx][hs] both
   std::vector<int> valid;      // per slot: positions [0, valid) of the mirror hold the cache
+  int fresh_lo = 0, fresh_hi = 0;  // slot 0: positions a producer stored into the mirror itself since the last attention (kvm_for_producer)
 };
 std::vector<KvMirror*> g_kvms;
 const char *g_kvm_lo = nullptr, *g_kvm_hi = nullptr;  // hull of every mirrored fp32 range (one compare rules a pointer out)
@@ -506,7 +507,10 @@ void kvm_note_foreign_write(const void* dst, size_t bytes) {
   const char* c = static_cast<const char*>(dst);
   if (!g_kvm_lo || !c || c >= g_kvm_hi || c + bytes <= g_kvm_lo) return;
   for (KvMirror* m : g_kvms)
-    if (overlaps(c, bytes ? bytes : 1, m->k32, m->bytes32) || overlaps(c, bytes ? bytes : 1, m->v32, m->bytes32)) std::fill(m->valid.begin(), m->valid.end(), 0);
+    if (overlaps(c, bytes ? bytes : 1, m->k32, m->bytes32) || overlaps(c, bytes ? bytes : 1, m->v32, m->bytes32)) {
+      std::fill(m->valid.begin(), m->valid.end(), 0);
+      m->fresh_lo = m->fresh_hi = 0;
+    }
 }
 void kvm_set_valid(const void* k32, int valid) {
   const char* c = static_cast<const char*>(k32);
@@ -516,6 +520,16 @@ void kvm_set_valid(const void* k32, int valid) {
       const size_t per_slot = m->bytes32 / size_t(m->slots);
       m->valid[size_t(c - m->k32) / per_slot] = std::min(valid, m->n_ctx);
     }
+}
+bool kvm_for_producer(const void* k32, const void* v32, int heads_kv, int hs, int n_ctx, int n_past, int m, _Float16** k16, _Float16** v16) {
+  if (!kv16_enabled() || n_past < 0 || m < 1 || n_past + m > n_ctx) return false;
+  int slot0 = 0;
+  KvMirror* mir = kvm_get(static_cast<const float*>(k32), static_cast<const float*>(v32), 1, heads_kv, hs, n_ctx, &slot0);
+  if (!mir) return false;
+  const size_t per_slot = size_t(heads_kv) * n_ctx * hs;
+  *k16 = mir->k16 + size_t(slot0) * per_slot, *v16 = mir->v16 + size_t(slot0) * per_slot;
+  if (slot0 == 0) mir->fresh_lo = n_past, mir->fresh_hi = n_past + m;
+  return true;
 }
 void kvm_clear() {
   while (!g_kvms.empty()) kvm_drop(g_kvms.size() - 1);
@@ -1105,6 +1119,7 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
     return ns::route_submit(op);
   }
   if (ns_hip_lazy_flush() != 0) return -1;
+  ns::g_mha_out16_written = false;
   const ns::Affine aff = ns::g_affine;
   // ---- fp16 mirror of the cache + this library's attention kernels (round 6, ns_route.h): every call shape — a prompt's rows on the matrix-core
   //      prefill kernels (round 5 converted the call's K / V into scratch for those: 184 -> 81 ms for a 1500-token prompt), a decode step on the
@@ -1127,6 +1142,9 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
         int lo = ns::route_executing() ? seq_all - seq : 0;
         for (int b = 0; b < batch; b++) lo = std::min(lo, mir->valid[size_t(slot0 + b)]);
         lo = std::max(0, lo);
+        // rows the fused QKV launch of this evaluation stored into the mirror itself (ns_route.cpp XK_QKV_ROPE_M) are in place
+        if (ns::route_executing() && batch == 1 && slot0 == 0 && mir->fresh_hi > mir->fresh_lo && lo >= mir->fresh_lo && seq_all <= mir->fresh_hi) lo = seq_all;
+        mir->fresh_lo = mir->fresh_hi = 0;
         if (lo < seq_all) {
           const int hb = batch * heads_kv, npos = seq_all - lo;
           const size_t units = size_t(hb) * npos * head_size / 4;
@@ -1157,7 +1175,10 @@ int ns_hip_mha_f32_device_layout(const float* dQ, const float* dK, const float* 
         static const bool inl_off = getenv("NS_MHA_INLAUNCH") && atoi(getenv("NS_MHA_INLAUNCH")) == 0;
         ns::g_affine.inlaunch = inl_off ? 0 : 1;
       }
-      return ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(&a, aff.k ? ns::g_mha_out16 : nullptr, stream);
+      // (an fp16 copy of the output rows for the projection behind the attention: asked for by a replayed plan and by a window's prompt evaluation)
+      const int rc = ns_hip_attn_fp32_fp16_fp16_fp32_forward_h(&a, ns::route_executing() ? ns::g_mha_out16 : nullptr, stream);
+      ns::g_mha_out16_written = rc == 0 && ns::route_executing() && ns::g_mha_out16 != nullptr;
+      return rc;
     }
   }
   // ---- the context split over workgroups: head sizes 64 / 128 / 256, from two 128-key ranges on ----

@@ -1040,6 +1040,7 @@ hipError_t launch_rope_qkv_append(float* q, const float* k, const float* v, void
 
 thread_local Affine g_affine;
 thread_local void* g_mha_out16 = nullptr;
+thread_local bool g_mha_out16_written = false;
 thread_local KvMirrorPair g_kvm;
 // a cache cell at `addr` received `v`: its fp16 mirror cell, found from the cell's address (ns_route.h)
 __device__ __forceinline__ void kvm_store(const KvMirrorArgs& m, const char* addr, float v) {

@@ -84,7 +84,13 @@ struct Segment {
 //   XK_QKV_ROPE (round 6)  XK_QKV with a carried norm + XK_ROPE_APPEND                                 -> ONE launch: the decode GEMV's RoPE epilogue (ns_qkv_rope, as the
 //               library's own whole-token path uses it) rotates q and k from a per-token angle table (XK_ROPE_TABLE: one captured launch per token, shared by
 //               every layer) and stores k / v into the fp16 mirror AND the reference's fp32 cache cells: 32 launches of a 7B token gone
-enum ExecKind : uint32_t { XK_OP = 0, XK_QKV, XK_ROPE2, XK_DUP2, XK_GEMM_ADD, XK_GATEUP, XK_ROPE_APPEND, XK_QKV_ROPE, XK_ROPE_TABLE };
+// A window's PROMPT-sized evaluation (round 6, prefill_pass): the tiled GEMMs multiply fp16 activations, so every producer that can hands its consumer an fp16 copy
+// beside the fp32 tensor the graph defines (ExecOp::o16p -> a16p: the attention's output rows, the gate / up product, the normed rows) instead of a conversion pass
+// per GEMM, and
+//   XK_NORM16      rms_norm + mul(gamma) whose plain result nobody else reads       -> ns_hip_norm_mul_h: gamma . norm(x) as fp32 and fp16, one launch
+//   XK_QKV_ROPE_M  XK_QKV + rope(q) + rope(k)                                         -> the fused-QKV GEMM with the RoPE epilogue (as the library's own prefill path):
+//                  q, k rotated and v where the graph has them, k / v also as fp16 straight into the kv mirror (no conversion in front of the attention)
+enum ExecKind : uint32_t { XK_OP = 0, XK_QKV, XK_ROPE2, XK_DUP2, XK_GEMM_ADD, XK_GATEUP, XK_ROPE_APPEND, XK_QKV_ROPE, XK_ROPE_TABLE, XK_NORM16, XK_QKV_ROPE_M };
 constexpr int kXIdx = 10;
 struct ExecOp {
   uint32_t xk;
@@ -95,6 +101,8 @@ struct ExecOp {
   int a16 = -1;      // XK_GEMM_ADD: fp16 shadow of its input = Route::shadows[a16]
   int o16 = -1;      // attention / XK_GATEUP: also writes the fp16 shadow Route::shadows[o16] of its output
   int aux = -1;      // XK_ROPE_TABLE: the plan's rope op whose parameters the table is made from (the launch stands for none of the reference's)
+  void* a16p = nullptr;  // window, prompt size: fp16 copy of the launch's activations (written by an earlier launch of the window) ...
+  void* o16p = nullptr;  // ... and where this launch leaves the fp16 copy of its result
 };
 inline ExecOp xop(uint32_t xk, int a, int b = -1, int c = -1, int d = -1) { return ExecOp{xk, {a, b, c, d, -1, -1, -1, -1, -1, -1}}; }
 struct NormLink {
@@ -656,6 +664,118 @@ void fuse_qkv_rope(std::vector<ExecOp>& x, const std::vector<PlanOp>& plan, size
   x.swap(y);
 }
 
+// per-stream scratch of a window's prompt-sized evaluation (ns_common.h stream_scratch slots)
+constexpr int kSlotNorm16 = 30, kSlotAttn16 = 31, kSlotFfn16 = 32, kSlotRopeTab = 33;
+// see ExecKind: fp16 hand-overs and the two fused forms of a prompt-sized window
+void prefill_pass(std::vector<ExecOp>& x, const std::vector<PlanOp>& plan, hipStream_t st) {
+  static const bool off = getenv("NS_ROUTE_PREFILL_FUSE") && atoi(getenv("NS_ROUTE_PREFILL_FUSE")) == 0;
+  if (off || !fuse_on()) return;
+  auto O = [&](int j) -> const RouteOp& { return plan[j].op; };
+  auto Wt = [](const void* p) { return static_cast<const ns_weight*>(p); };
+  std::vector<char> dead(x.size(), 0);
+  auto gemm_of = [&](const ExecOp& c, int* gi) {  // the mul_mat ops of a launch that multiplies activations
+    if (c.xk == XK_QKV || c.xk == XK_QKV_ROPE_M) return gi[0] = c.idx[0], gi[1] = c.idx[1], gi[2] = c.idx[2], 3;
+    if (c.xk == XK_GATEUP) return gi[0] = c.idx[0], gi[1] = c.idx[2], 2;
+    if (c.xk == XK_GEMM_ADD) return gi[0] = c.idx[0], 1;
+    if (c.xk == XK_OP && O(c.idx[0]).kind == RK_GEMM) return gi[0] = c.idx[0], 1;
+    return 0;
+  };
+  for (size_t e = 0; e < x.size(); e++) {
+    // ---- QKV + the two ropes -> the GEMM's RoPE epilogue (k / v into the kv mirror) ----
+    if (x[e].xk == XK_QKV && e + 3 < x.size() && x[e + 1].xk == XK_OP && x[e + 2].xk == XK_OP && x[e + 3].xk == XK_DUP2 && x[e + 3].idx[1] >= 0 && kv16_enabled()) {
+      const RouteOp &r1 = O(x[e + 1].idx[0]), &r2 = O(x[e + 2].idx[0]), &dk = O(x[e + 3].idx[0]), &dv = O(x[e + 3].idx[1]);
+      const long long M = O(x[e].idx[0]).i[0];
+      int jq = -1, jk = -1, jv = -1;
+      for (int t = 0; t < 3; t++) {
+        const int j = x[e].idx[t];
+        if (O(j).p[2] == dk.p[0]) jk = j;
+        else if (O(j).p[2] == dv.p[0]) jv = j;
+        else jq = j;
+      }
+      const bool ropes = r1.kind == RK_ROPE && r2.kind == RK_ROPE && same_rope(r1, r2) && r1.p[0] == r1.p[1] && r2.p[0] == r2.p[1];
+      if (M > 16 && ropes && jq >= 0 && jk >= 0 && jv >= 0) {
+        const RouteOp& rk = r1.p[0] == O(jk).p[2] ? r1 : r2;
+        const RouteOp& rq = &rk == &r1 ? r2 : r1;
+        const long long hs = rk.i[3], hkv = rk.i[2], hq = rq.i[2], np = rk.i[4];
+        // plain whole-head RoPE in adjacent pairs over M consecutive positions of one sequence; K cells [head][n_ctx][hs], V cells [head][hs][n_ctx] from np on
+        bool ok = rk.p[0] == O(jk).p[2] && rq.p[0] == O(jq).p[2] && rk.i[0] == 1 && rk.i[1] == M && rk.i[6] == 0 && rk.i[5] == hs && rk.f[2] == 0.f && (hs & 3) == 0 &&
+                  Wt(O(jq).p[1])->n == hq * hs && Wt(O(jk).p[1])->n == hkv * hs && Wt(O(jv).p[1])->n == hkv * hs && dk.i[12] == 0 && dv.i[12] == 0 &&
+                  dk.i[0] == hs && dk.i[1] == M && dk.i[2] == hkv && dk.i[3] == 1 && dk.i[8] == 4 && dk.i[9] == 4 * hs && dk.i[10] % (4 * hs) == 0 &&
+                  dv.i[0] == M && dv.i[1] == hs && dv.i[2] == hkv && dv.i[3] == 1 && dv.i[8] == 4 && dv.i[9] % 4 == 0 && dv.i[10] == dv.i[9] * hs;
+        const long long n_ctx = ok ? dk.i[10] / (4 * hs) : 0;
+        ok = ok && n_ctx >= np + M && dv.i[9] == 4 * n_ctx;
+        _Float16 *k16 = nullptr, *v16 = nullptr;
+        if (ok) {
+          const char *kbase = static_cast<const char*>(dk.p[1]) - np * hs * 4, *vbase = static_cast<const char*>(dv.p[1]) - np * 4;
+          ok = kvm_for_producer(kbase, vbase, int(hkv), int(hs), int(n_ctx), int(np), int(M), &k16, &v16) &&
+               stream_scratch(st, size_t(M) * size_t(hs / 2) * 8, kSlotRopeTab) != nullptr;
+        }
+        if (ok) {
+          ExecOp f = x[e];
+          f.xk = XK_QKV_ROPE_M;
+          f.idx[0] = jq, f.idx[1] = jk, f.idx[2] = jv;
+          f.idx[3] = &rq == &r1 ? x[e + 1].idx[0] : x[e + 2].idx[0], f.idx[6] = &rk == &r1 ? x[e + 1].idx[0] : x[e + 2].idx[0];
+          f.idx[7] = x[e + 3].idx[0], f.idx[8] = x[e + 3].idx[1];  // (the cache writes stay a launch of their own: x[e + 3]; here for the mirror's geometry)
+          x[e] = f;
+          dead[e + 1] = dead[e + 2] = 1;
+        }
+      }
+    }
+  }
+  {
+    size_t o = 0;
+    for (size_t e = 0; e < x.size(); e++)
+      if (!dead[e]) x[o++] = x[e];
+    x.resize(o);
+    dead.assign(x.size(), 0);
+  }
+  for (size_t e = 0; e < x.size(); e++) {
+    int gi[3];
+    // ---- rms_norm + mul(gamma) in front of a prompt-sized mul_mat launch -> one launch, fp32 + fp16 ----
+    if (e + 2 < x.size() && x[e].xk == XK_OP && x[e + 1].xk == XK_OP && O(x[e].idx[0]).kind == RK_RMSNORM && O(x[e + 1].idx[0]).kind == RK_MUL) {
+      const int jn = x[e].idx[0], jm = x[e + 1].idx[0];
+      const RouteOp &no = O(jn), &mu = O(jm);
+      const long long rows = no.i[0], n = no.i[1];
+      const void *N = no.p[1], *N2 = mu.p[2];
+      const bool first = mu.p[0] == N, second = mu.p[1] == N;
+      const int ng = gemm_of(x[e + 2], gi);
+      // (ne_mul(normed rows, gamma): the rows are the first operand, gamma the row vector — llama.cpp:178-184)
+      bool ok = rows > 16 && jm == jn + 1 && first && !second && N2 != no.p[0] && N2 != N && ng > 0 && !x[e + 2].a16p && packed_mat(mu.i, mu.i + 4, n, rows) &&
+                packed_vec(mu.i + 8, mu.i + 12, n) && mu.i[16] == 4 && mu.i[17] == 4 * n && !read_later(plan, N, size_t(rows) * n * 4, size_t(jm) + 1, -1);
+      for (int g = 0; g < ng && ok; g++) ok = O(gi[g]).p[0] == N2 && O(gi[g]).i[0] == rows && O(gi[g]).i[2] == n && O(gi[g]).i[3] == n;
+      void* sh = ok ? stream_scratch(st, size_t(rows) * n * 2, kSlotNorm16) : nullptr;
+      if (sh) {
+        ExecOp f = xop(XK_NORM16, jn, jm);
+        f.o16p = sh;
+        x[e] = f;
+        dead[e + 1] = 1;
+        x[e + 2].a16p = sh;
+        continue;
+      }
+    }
+    // ---- the attention's rows / the gate-up product as fp16 for the projection that multiplies them ----
+    const bool is_mha = x[e].xk == XK_OP && O(x[e].idx[0]).kind == RK_MHA && O(x[e].idx[0]).i[1] > 16 && O(x[e].idx[0]).i[0] == 1 && kv16_enabled();
+    const bool is_gu = x[e].xk == XK_GATEUP && O(x[e].idx[0]).i[0] > 16;
+    if (is_mha || is_gu) {
+      const void* out = is_mha ? O(x[e].idx[0]).p[3] : O(x[e].idx[3]).p[2];
+      const long long rows = is_mha ? O(x[e].idx[0]).i[1] : O(x[e].idx[0]).i[0];
+      const long long cols = is_mha ? O(x[e].idx[0]).i[3] * O(x[e].idx[0]).i[5] : O(x[e].idx[0]).i[1];
+      for (size_t c = e + 1; c < x.size() && c < e + 4; c++) {
+        const int ng = gemm_of(x[c], gi);
+        if (ng == 1 && O(gi[0]).p[0] == out && O(gi[0]).i[0] == rows && O(gi[0]).i[2] == cols && O(gi[0]).i[3] == cols && !x[c].a16p) {
+          void* sh = stream_scratch(st, size_t(rows) * cols * 2, is_mha ? kSlotAttn16 : kSlotFfn16);
+          if (sh) x[e].o16p = sh, x[c].a16p = sh;
+          break;
+        }
+      }
+    }
+  }
+  size_t o = 0;
+  for (size_t e = 0; e < x.size(); e++)
+    if (!dead[e]) x[o++] = x[e];
+  x.resize(o);
+}
+
 // one launch of a plan (inside a stream capture; the device counter moves what moves) or of a window (kdev == nullptr: plain values, launched now)
 int capture_xop(const ExecOp& xo, const std::vector<PlanOp>& plan, const int* kdev, hipStream_t st) {
   struct Guard {
@@ -682,6 +802,41 @@ int capture_xop(const ExecOp& xo, const std::vector<PlanOp>& plan, const int* kd
   };
   if (xo.xk != XK_OP && ns_hip_lazy_flush() != 0) return -1;
   switch (xo.xk) {
+    case XK_NORM16: {
+      const RouteOp &no = P(0).op, &mu = P(1).op;
+      return ns_hip_norm_mul_h(int(no.i[0]), int(no.i[1]), true, no.f[0], F(no.p[0]), F(mu.p[1]), M(mu.p[2]), xo.o16p, st);
+    }
+    case XK_QKV_ROPE_M: {
+      const RouteOp &gq = P(0).op, &gk = P(1).op, &gv = P(2).op, &rk = P(6).op, &dk = P(7).op, &dv = P(8).op;
+      const long long hs = rk.i[3], hkv = rk.i[2], np = rk.i[4], m = gq.i[0], n_ctx = dk.i[10] / (4 * hs);
+      _Float16 *k16 = nullptr, *v16 = nullptr;
+      float* tab = static_cast<float*>(stream_scratch(st, size_t(m) * size_t(hs / 2) * 8, kSlotRopeTab));
+      int rc = -2;
+      if (tab && kvm_for_producer(static_cast<const char*>(dk.p[1]) - np * hs * 4, static_cast<const char*>(dv.p[1]) - np * 4, int(hkv), int(hs), int(n_ctx), int(np), int(m),
+                                  &k16, &v16) &&
+          launch_rope_cos_sin(int(m), int(np), int(rk.i[5]), rk.f[0], rk.f[1], rk.f[3], tab, st) == hipSuccess) {
+        ns_qkv_rope r{};
+        r.kcache16 = k16, r.vcache16 = v16, r.cos_sin = tab;
+        r.heads = int(P(3).op.i[2]), r.heads_kv = int(hkv), r.head_size = int(hs), r.n_past = int(np), r.n_dims = int(rk.i[5]), r.mode = 0;
+        r.cache_step_sl = hs, r.cache_step_head = n_ctx * hs, r.flags = 0;
+        rc = qkv_rope_route_forward_m(F(gq.p[0]), xo.a16p, W(gq.p[1]), W(gk.p[1]), W(gv.p[1]), M(gq.p[2]), M(gk.p[2]), M(gv.p[2]), int(m), int(gq.i[3]), int(gq.i[4]), &r, st);
+      }
+      if (rc != -2) return rc;
+      kvm_note_foreign_write(dk.p[1], 1);  // (nothing was stored into the mirror after all: it starts over)
+      // the GEMM does not take this shape: the three mul_mat in one launch and the two ropes, as the window had them (the mirror's rows are converted by the attention)
+      ns_hip_reset_error();
+      {
+        const long long ldc = gq.i[4];
+        const RouteOp* g3[3] = {&gq, &gk, &gv};
+        for (const RouteOp* g : g3)
+          if (ns_hip_f32f32_forward_h(F(g->p[0]), xo.a16p, W(g->p[1]), M(g->p[2]), nullptr, int(m), int(g->i[3]), int(ldc), NS_EPI_NONE, nullptr, 0, st) != 0) return -1;
+      }
+      if (execute(P(6).op, st) != 0) return -1;
+      t_in_exec = true;  // (execute()'s guard cleared it)
+      const int rq = execute(P(3).op, st);
+      t_in_exec = true;
+      return rq;
+    }
     case XK_ROPE_TABLE: {
       const PlanOp& po = plan[xo.aux];
       const RouteOp& r = po.op;
@@ -726,6 +881,7 @@ int capture_xop(const ExecOp& xo, const std::vector<PlanOp>& plan, const int* kd
         return ns_hip_fusion_qkv_forward_x(F(a.p[0]), R.link_mem + R.links[xo.in_link].h_off, W(a.p[1]), W(b.p[1]), W(c.p[1]), M(a.p[2]), nullptr, 1, int(a.i[3]),
                                            int(ldc), &lk, st);
       }
+      if (xo.a16p) return ns_hip_fusion_qkv_forward_h(F(a.p[0]), xo.a16p, W(a.p[1]), W(b.p[1]), W(c.p[1]), M(a.p[2]), nullptr, m, int(a.i[3]), int(ldc), st);
       return ns_hip_fusion_qkv_forward(F(a.p[0]), W(a.p[1]), W(b.p[1]), W(c.p[1]), M(a.p[2]), m, int(a.i[3]), int(ldc), st);
     }
     case XK_ROPE2: {
@@ -789,6 +945,8 @@ int capture_xop(const ExecOp& xo, const std::vector<PlanOp>& plan, const int* kd
         const void* a16 = xo.in_link >= 0 ? R.link_mem + R.links[xo.in_link].h_off : (xo.a16 >= 0 ? R.link_mem + R.shadows[xo.a16] : nullptr);
         return ns_hip_f32f32_forward_x(F(g.p[0]), a16, W(g.p[1]), M(ad.p[2]), c16, 1, int(g.i[3]), int(g.i[1]), NS_EPI_ADD, F(other), int(g.i[1]), &lk, st);
       }
+      if (xo.a16p)
+        return ns_hip_f32f32_forward_h(F(g.p[0]), xo.a16p, W(g.p[1]), M(ad.p[2]), nullptr, int(g.i[0]), int(g.i[3]), int(g.i[1]), NS_EPI_ADD, F(other), int(g.i[1]), st);
       return ns_hip_f32f32_forward(F(g.p[0]), W(g.p[1]), M(ad.p[2]), int(g.i[0]), int(g.i[3]), int(g.i[1]), NS_EPI_ADD, F(other), int(g.i[1]), st);
     }
     case XK_GATEUP: {
@@ -798,6 +956,8 @@ int capture_xop(const ExecOp& xo, const std::vector<PlanOp>& plan, const int* kd
         return ns_hip_fusion_ffn3_gateup_x(F(g1.p[0]), R.link_mem + R.links[xo.in_link].h_off, W(g1.p[1]), W(g3.p[1]), M(si.p[1]), M(mu.p[2]),
                                            xo.o16 >= 0 ? R.link_mem + R.shadows[xo.o16] : nullptr, 1, NS_EPI_SILU, &lk, st);
       }
+      if (xo.a16p || xo.o16p)
+        return ns_hip_fusion_ffn3_gateup_x(F(g1.p[0]), xo.a16p, W(g1.p[1]), W(g3.p[1]), M(si.p[1]), M(mu.p[2]), xo.o16p, int(g1.i[0]), NS_EPI_SILU, nullptr, st);
       return ns_hip_fusion_ffn3_gateup(F(g1.p[0]), W(g1.p[1]), W(g3.p[1]), M(si.p[1]), M(mu.p[2]), int(g1.i[0]), NS_EPI_SILU, st);
     }
     default: {
@@ -807,9 +967,12 @@ int capture_xop(const ExecOp& xo, const std::vector<PlanOp>& plan, const int* kd
         return ns_hip_f32f32_forward_x(F(po.op.p[0]), R.link_mem + R.links[xo.in_link].h_off, W(po.op.p[1]), M(po.op.p[2]), nullptr, int(po.op.i[0]), int(po.op.i[3]),
                                        int(po.op.i[4]), NS_EPI_NONE, nullptr, 0, &lk, st);
       }
+      if (xo.a16p && po.op.kind == RK_GEMM)  // (a window's prompt-sized projection on the fp16 rows its producer left)
+        return ns_hip_f32f32_forward_h(F(po.op.p[0]), xo.a16p, W(po.op.p[1]), M(po.op.p[2]), nullptr, int(po.op.i[0]), int(po.op.i[3]), int(po.op.i[4]), NS_EPI_NONE, nullptr, 0, st);
       t_in_exec = false;  // (execute() guards itself)
       if (po.moving) g_affine = Affine{kdev, po.delta, 0};
       if (xo.o16 >= 0 && po.op.kind == RK_MHA) g_mha_out16 = R.link_mem + R.shadows[xo.o16];
+      if (xo.o16p && po.op.kind == RK_MHA) g_mha_out16 = xo.o16p;
       const int rc = execute(po.op, st);
       g_mha_out16 = nullptr;
       return rc;
@@ -1014,10 +1177,19 @@ int flush_window(const void* src, size_t bytes) {
   for (size_t j = 0; j < w.size(); j++) w[j] = PlanOp{R.cur[R.launched + j], 0, 0, 0u};
   t_extra = ExtraRead{static_cast<const char*>(src), bytes};
   const long long t0 = route_timing() ? now_us() : 0;
-  const std::vector<ExecOp> x = optimize(w);
+  std::vector<ExecOp> x = optimize(w);
+  bool prompt_sized = false;
+  for (const PlanOp& po : w) prompt_sized = prompt_sized || (po.op.kind == RK_GEMM && po.op.i[0] > 16);
+  if (prompt_sized) prefill_pass(x, w, R.st);
   t_extra = ExtraRead{};
   int rc = 0;
-  for (size_t e = 0; e < x.size() && rc == 0; e++) rc = capture_xop(x[e], w, nullptr, R.st);
+  for (size_t e = 0; e < x.size() && rc == 0; e++) {
+    rc = capture_xop(x[e], w, nullptr, R.st);
+    // an attention that took the fp32 kernels left no fp16 rows behind: the projection that was promised them converts its own
+    if (rc == 0 && x[e].o16p && x[e].xk == XK_OP && w[x[e].idx[0]].op.kind == RK_MHA && !g_mha_out16_written)
+      for (size_t c = e + 1; c < x.size(); c++)
+        if (x[c].a16p == x[e].o16p) x[c].a16p = nullptr;
+  }
   if (route_timing()) R.win_t0 = t0, R.win_ops = (long long)w.size(), R.win_launches = (long long)x.size(), R.win_issue_us = now_us() - t0;
   {
     t_in_exec = true;

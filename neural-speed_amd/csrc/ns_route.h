@@ -54,6 +54,9 @@ bool kvm_args_for_cell(const void* cell, KvMirrorArgs* out);
 void kvm_note_foreign_write(const void* dst, size_t bytes);
 // a replayed decode step advanced the mirrors its plan writes: positions [0, valid) of slot 0.. hold the cache
 void kvm_set_valid(const void* k32, int valid);
+// a producer is about to store positions [n_past, n_past + m) of slot 0.. of the cache at (k32, v32) into its mirror itself (the fused QKV launch's epilogue at
+// prompt size): the mirror (made when there is none) and where its rows start; the attention that follows finds those rows in place.  false: no mirror
+bool kvm_for_producer(const void* k32, const void* v32, int heads_kv, int hs, int n_ctx, int n_past, int m, _Float16** k16, _Float16** v16);
 void kvm_clear();             // device memory is being freed
 uint32_t* kvm_overflow_word();  // pinned; nullptr when it could not be allocated
 bool kvm_overflowed();        // reads (and leaves) the flag

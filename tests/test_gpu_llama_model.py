@@ -142,3 +142,17 @@ def test_device_route_conversation_follow_up_chunk_and_a_new_sequence_in_the_sam
     # per turn: the chunk and two tokens go through the window, then a plan; every later chunk drops the plan it meets
     assert plans == 3 and fallbacks == 2 and replayed >= 3 * 8, m.group(0)
     assert "three turns" in out
+
+
+@pytest.mark.parametrize("kvmode", ["f16", "f32"])
+def test_device_route_prompt_sized_prompt_through_the_windows_prefill_forms(tmp_path, kvmode):
+    """A 40-token prompt (more than 16 rows) through the reference's unchanged model_eval on the device route: the window issues it as the prompt-sized fused forms
+    (round 6: fused-QKV GEMM with the RoPE epilogue storing k / v into the kv mirror, norm . gamma as fp32 + fp16 in one launch, fp16 hand-overs between the
+    attention / gate-up launches and the projections behind them, tiled transposing cache write); the worker checks the logits behind the prompt and behind every
+    generated token against the fp64 model.  f32: the same with the fp32 attention kernels (no mirror: the QKV launch keeps its separate ropes)."""
+    run_worker("product", tmp_path, "auto", 4)
+    env = {"NS_WORKER_PROMPT_LEN": "40", "NS_WORKER_N_NEW": "8"}
+    if kvmode == "f32":
+        env["NS_DEVICE_KV"] = "f32"
+    out = run_worker("device", tmp_path, "f32", 4, given=tmp_path / "llama_q_product_4.bin", env=env)
+    assert "LLAMA_MODEL_DEVICE_OK" in out

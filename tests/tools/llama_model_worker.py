@@ -38,6 +38,8 @@ import nso  # noqa: E402
 V, D, HEADS, FF, LAYERS, EPS, BASE = 384, 256, 4, 704, 22, 1e-5, 10000.0
 N_CTX = int(os.environ.get("NS_WORKER_N_CTX", "64"))   # (long generations: test_gpu_llama_model.py's 330-token run)
 PROMPT = [1, 17, 200, 3, 99, 42, 311]   # bos first (llama.cpp:80-85 warns otherwise)
+if int(os.environ.get("NS_WORKER_PROMPT_LEN", "0")) > len(PROMPT):   # a prompt-SIZED prompt (more than 16 rows: the tiled GEMMs and, on the device route, the window's prefill forms)
+    PROMPT = PROMPT + [int(t_) for t_ in np.random.default_rng(11).integers(3, V, int(os.environ["NS_WORKER_PROMPT_LEN"]) - len(PROMPT))]
 N_NEW = int(os.environ.get("NS_WORKER_N_NEW", "6"))
 KV = {"auto": 0, "f16": 1, "f32": 2}
 
