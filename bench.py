@@ -1271,7 +1271,7 @@ def secondary_configs(pkg):
                 w[0].free()
         head.free()
         return {"layers_in_graph": len(layers), "us_per_layer": round(us_layer, 2), "us_lm_head": round(us_head, 2),
-                "ms_per_step": round(tot_us / 1e3, 4), "weight_bytes_per_step": int(tot_b),
+                "ms_per_step": round(tot_us / 1e3, 4), "weight_bytes_per_step": int(tot_b), "weight_bytes_per_layer": int(byt_layer),
                 "hbm_GBps": round(tot_b / tot_us / 1e3, 1), "frac_of_8TBps": round(tot_b / tot_us / 8e6, 3),
                 "parity_rel_l2_vs_oracle": {k: float("%.3g" % v) for k, v in par.items()}}, tot_us
 

@@ -62,6 +62,14 @@ bool nonce_uses_ppid() {
   if (run && *run) return false;
   const char* te = getenv("TORCHELASTIC_RUN_ID");
   if (te && *te && strcmp(te, "none") != 0) return false;
+  // an id file the launcher named itself (shared between the nodes of a multi-node launch) or more than one node: the parent pids differ from node to
+  // node, the nonce would too — the named file / the launcher's rendezvous is what ties the ranks together then
+  const char* idf = getenv("NS_TP_ID_FILE");
+  if (idf && *idf) return false;
+  const char* nn = getenv("NS_TP_NNODES") ? getenv("NS_TP_NNODES") : getenv("GROUP_WORLD_SIZE");
+  if (nn && atoi(nn) > 1) return false;
+  const char *lw = getenv("LOCAL_WORLD_SIZE"), *ww = getenv("NS_TP_WORLD_SIZE") ? getenv("NS_TP_WORLD_SIZE") : getenv("WORLD_SIZE");
+  if (lw && ww && atoi(lw) > 0 && atoi(ww) > atoi(lw)) return false;  // (more ranks than this node holds)
   const char* off = getenv("NS_TP_NONCE_NO_PPID");
   return !(off && atoi(off) != 0);
 }
@@ -85,15 +93,15 @@ uint64_t launch_nonce() {
   return h ? h : 1;
 }
 
-// how old (relative to this process's start) an id file may be: the ranks of one launch start within seconds of each other
-// and rank 0 writes the file after ITS start, so anything older than this is a leftover (NS_TP_ID_MAX_AGE_S overrides)
+// how old an id file may be when a rank READS it (its age against the reader's clock at that moment, not against the reader's start — a rank that
+// starts a minute behind rank 0 must still be able to join): rank 0 removes the file as soon as every rank has read it, so a file that is
+// still there after this long is the leftover of a launch that died (NS_TP_ID_MAX_AGE_S overrides; the ranks wait 60 s for it in any case)
 time_t id_max_age_s() {
   const char* v = getenv("NS_TP_ID_MAX_AGE_S");
-  const long s = v ? atol(v) : 30;
-  return time_t(s > 0 ? s : 30);
+  const long s = v ? atol(v) : 300;
+  return time_t(s > 0 ? s : 300);
 }
 
-const time_t g_start_time = time(nullptr);
 
 struct IdFile {  // what rank 0 publishes
   char magic[8];
@@ -133,15 +141,15 @@ ns_tp* make_tp() {
     }
   } else {
     // a regular file of this user, not writable by anyone else, complete, carrying THIS launch's nonce, and not a leftover
-    // of an earlier launch with the same nonce ingredients that died before its rank 0 could remove it: written no
-    // earlier than id_max_age_s() before this process started
+    // of an earlier launch with the same nonce ingredients that died before its rank 0 could remove it: no older
+    // than id_max_age_s() at the moment it is read
     auto read_valid = [&](IdFile* out) {
       const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
       if (fd < 0) return false;
       struct stat sb;
       IdFile in;
       const bool ok = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_uid == getuid() && !(sb.st_mode & (S_IWGRP | S_IWOTH)) &&
-                      sb.st_mtime + id_max_age_s() >= g_start_time &&
+                      sb.st_mtime + id_max_age_s() >= time(nullptr) &&
                       read(fd, &in, sizeof(in)) == ssize_t(sizeof(in)) && !memcmp(in.magic, "NSTPID1", 8) && in.nonce == nonce;
       close(fd);
       if (ok) *out = in;

@@ -353,7 +353,8 @@ typedef struct ns_qkv_rope {
   const float* cos_sin;
   int heads, heads_kv, head_size, n_past, n_dims, mode;
   long long cache_step_sl, cache_step_head; /* cache element strides per position / per head */
-  int flags;                                /* NS_QKV_ROPE_* (0 = as before) */
+  int flags;                                /* NS_QKV_ROPE_* (0 = as before).  Added in round 5 as the LAST field: zero the struct before filling it —
+                                             * unknown bits are refused (-1), never interpreted */
 } ns_qkv_rope;
 /* Round 5: the same epilogue at PREFILL size (m > 16: the tiled GEMM, fused QKV as column segments; head_size a multiple of 4, matrix widths
  * multiples of 128, cos_sin rows for all m positions).  k and v then need not exist as fp32 tensors at all - the attention reads the cache: */

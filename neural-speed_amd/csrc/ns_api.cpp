@@ -1302,6 +1302,10 @@ int ns_hip_fusion_qkv_rope_forward_x(const float* dA, const void* dA16, const ns
     set_error("qkv+rope: the producer side of a norm link needs a single-matrix forward");
     return -1;
   }
+  if (rope->flags & ~NS_QKV_ROPE_KV_CACHE_ONLY) {  // (`flags` is the struct's newest field — a caller built against the older header passes what lay behind it)
+    set_error("qkv+rope: unknown bits in ns_qkv_rope::flags (zero the struct before filling it: the field was added in round 5)");
+    return -1;
+  }
   const ns_weight* ws[3] = {wq, wk, wv};
   if (m > 16) {  // prefill size (round 5): the tiled GEMM's fused-QKV launch carries the epilogue; k / v optionally to the cache only
     bool one = !ref_int8_for(wq) && !link && wq->kind != WK_F8;

@@ -20,9 +20,6 @@
 #include <mutex>
 #include <chrono>
 #include <atomic>
-#include <condition_variable>
-#include <functional>
-#include <thread>
 
 #include <cmath>
 #include <cstdio>
@@ -621,129 +618,10 @@ void bestla_device_free(void* ptr, void* queue) {
   }
   if (ptr) (void)hipFree(ptr);
 }
-// ---- large copies between the device and PAGEABLE host memory (round 6).  The runtime's own path stages them through pinned chunks and moves every chunk
-//      with ONE host thread: the reference's prompt evaluation ends with its logits tensor for every prompt position crossing to the host (1500 x 32000 fp32 =
-//      192 MB, ne_layers.c:8345-8346) — six 32 MB chunks of 0.24 ms DMA + 3 ms memcpy each, 19 of the prompt's 56 ms on the trace
-//      (profiles/r06e_prompt_timeline.txt).  Here: two pinned 16 MB stages, the DMA of chunk i + 1 under the host copy of chunk i, and that copy cut over a small
-//      pool of threads.  From 8 MB on; registered / pinned host memory and everything smaller take the runtime's path.  NS_BIG_COPY=0: off. ----
-namespace {
-class CopyPool {
- public:
-  static CopyPool& get() {
-    static CopyPool p;
-    return p;
-  }
-  // dst[0, n) = src[0, n) on every worker + the caller
-  void copy(char* dst, const char* src, size_t n) {
-    const int parts = int(workers_.size()) + 1;
-    const size_t per = ((n + parts - 1) / parts + 4095) & ~size_t(4095);
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      dst_ = dst, src_ = src, n_ = n, per_ = per;
-      pending_ = int(workers_.size());
-      gen_++;
-    }
-    cv_.notify_all();
-    if (n > per * workers_.size()) memcpy(dst + per * workers_.size(), src + per * workers_.size(), n - per * workers_.size());
-    std::unique_lock<std::mutex> lk(mu_);
-    done_.wait(lk, [&] { return pending_ == 0; });
-  }
-
- private:
-  CopyPool() {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int n = int(std::min(7u, hw > 2 ? hw / 2 - 1 : 0u));
-    for (int i = 0; i < n; i++) workers_.emplace_back([this, i] { run(i); });
-  }
-  ~CopyPool() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : workers_) t.join();
-  }
-  void run(int i) {
-    uint64_t seen = 0;
-    for (;;) {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-      if (stop_) return;
-      seen = gen_;
-      char* d = dst_;
-      const char* s = src_;
-      const size_t n = n_, per = per_;
-      lk.unlock();
-      const size_t off = per * size_t(i);
-      if (off < n) memcpy(d + off, s + off, std::min(per, n - off));
-      lk.lock();
-      if (--pending_ == 0) done_.notify_all();
-    }
-  }
-  std::mutex mu_;
-  std::condition_variable cv_, done_;
-  std::vector<std::thread> workers_;
-  char* dst_ = nullptr;
-  const char* src_ = nullptr;
-  size_t n_ = 0, per_ = 0;
-  int pending_ = 0;
-  uint64_t gen_ = 0;
-  bool stop_ = false;
-};
-constexpr size_t kBigCopy = size_t(8) << 20, kStage = size_t(16) << 20;
-char* g_stage[2] = {nullptr, nullptr};
-hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
-std::mutex g_big_mu;
-bool big_copy_ready() {
-  static const bool off = getenv("NS_BIG_COPY") && atoi(getenv("NS_BIG_COPY")) == 0;
-  if (off) return false;
-  if (g_stage[0]) return true;
-  for (int i = 0; i < 2; i++)
-    if (hipHostMalloc(reinterpret_cast<void**>(&g_stage[i]), kStage, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      g_stage[0] = nullptr;
-      return false;
-    }
-  return true;
-}
-bool plain_host_memory(const void* p) {  // neither device memory nor pinned / registered host memory
-  hipPointerAttribute_t at;
-  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-    (void)hipGetLastError();
-    return true;
-  }
-  return at.type == hipMemoryTypeUnregistered;
-}
-// synchronous; false: not done (the caller takes the runtime's path)
-bool big_copy(void* dst, const void* src, size_t size, bool to_host, hipStream_t st) {
-  std::lock_guard<std::mutex> lk(g_big_mu);
-  if (!big_copy_ready()) return false;
-  char* d = static_cast<char*>(dst);
-  const char* s = static_cast<const char*>(src);
-  const size_t nchunk = (size + kStage - 1) / kStage;
-  auto len = [&](size_t c) { return std::min(kStage, size - c * kStage); };
-  if (to_host) {
-    if (hipMemcpyAsync(g_stage[0], s, len(0), hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(g_stage_ev[0], st) != hipSuccess) return false;
-    for (size_t c = 0; c < nchunk; c++) {
-      if (c + 1 < nchunk && (hipMemcpyAsync(g_stage[(c + 1) & 1], s + (c + 1) * kStage, len(c + 1), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                             hipEventRecord(g_stage_ev[(c + 1) & 1], st) != hipSuccess))
-        return false;  // (chunks so far are in place; the caller's plain copy redoes the whole range)
-      if (hipEventSynchronize(g_stage_ev[c & 1]) != hipSuccess) return false;
-      CopyPool::get().copy(d + c * kStage, g_stage[c & 1], len(c));
-    }
-    return true;
-  }
-  for (size_t c = 0; c < nchunk; c++) {
-    if (c >= 2 && hipEventSynchronize(g_stage_ev[c & 1]) != hipSuccess) return false;  // the stage's previous chunk has left
-    CopyPool::get().copy(g_stage[c & 1], s + c * kStage, len(c));
-    if (hipMemcpyAsync(d + c * kStage, g_stage[c & 1], len(c), hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(g_stage_ev[c & 1], st) != hipSuccess)
-      return false;
-  }
-  return hipStreamSynchronize(st) == hipSuccess;  // (the stages are free again; the bytes are on the device)
-}
-}  // namespace
-
+// (Round 6 measured and did NOT adopt a library-side path for large copies to / from pageable host memory — two pinned 16 MB stages, the DMA of chunk i + 1 under
+// the host copy of chunk i, that copy cut over eight threads — for the 192 MB of logits a 1500-token prompt's evaluation ends with (ne_layers.c:8345-8346): the
+// runtime's own staged copy is as fast once the destination's pages exist (3.45 vs 3.8 ms) and what a FIRST evaluation pays is the first touch of those pages
+// (10-18 ms either way, run to run); towards the device the runtime was faster outright (24.6 MB: 1.3 vs 3.5 ms).  profiles/r06_route_timings.txt.)
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {
   (void)ns_hip_lazy_flush();
   // what the route holds back (its window) goes out first; a copy FROM device memory reads a tensor behind the window's last op
@@ -755,16 +633,7 @@ void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* q
   srcptr = ns::route_translate_src(srcptr, queue);
   if (twin && hipMemcpyAsync(twin, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
     ns::set_error("bestla_device_memcpy failed");
-  const bool to_dev = in_device_pool(dstptr);
-  bool done = false;
-  if (size >= kBigCopy && from_dev != to_dev && plain_host_memory(from_dev ? dstptr : srcptr)) {
-    static const bool timing = getenv("NS_ROUTE_TIMING") != nullptr;
-    auto clk = [] { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const long long t0 = timing ? clk() : 0;
-    done = big_copy(dstptr, srcptr, size, from_dev, static_cast<hipStream_t>(queue));
-    if (timing) fprintf(stderr, "route timing: %.1f MB %s pageable host memory in %.2f ms (incl. whatever was in front of it on the queue)\n", size / 1e6, from_dev ? "to" : "from", (clk() - t0) / 1e3);
-  }
-  if (!done && hipMemcpyAsync(dstptr, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
+  if (hipMemcpyAsync(dstptr, srcptr, size, hipMemcpyDefault, static_cast<hipStream_t>(queue)) != hipSuccess)
     ns::set_error("bestla_device_memcpy failed");
   ns::route_note_copy(queue);
   if (in_device_pool(dstptr)) {
@@ -782,8 +651,14 @@ static bool device_sync_impl(void* queue) {
 }
 void bestla_device_sync(void* queue) { (void)device_sync_impl(queue); }
 void bestla_device_memcpy_sync(void* dstptr, const void* srcptr, size_t size, void* queue) {
+  static const bool timing = getenv("NS_ROUTE_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   bestla_device_memcpy(dstptr, srcptr, size, queue);
-  if (device_sync_impl(queue)) {  // the evaluation this copy reads from was run again (fp16 overflow, ns_route.h): its results are fetched again
+  const bool again = device_sync_impl(queue);
+  if (timing && size >= (size_t(8) << 20))
+    fprintf(stderr, "route timing: bestla_device_memcpy_sync of %.1f MB took %.2f ms\n", size / 1e6,
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() / 1e3);
+  if (again) {  // the evaluation this copy reads from was run again (fp16 overflow, ns_route.h): its results are fetched again
     bestla_device_memcpy(dstptr, srcptr, size, queue);
     (void)hipStreamSynchronize(static_cast<hipStream_t>(queue));
     (void)ns::route_after_sync(queue);

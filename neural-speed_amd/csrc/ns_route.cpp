@@ -1384,10 +1384,12 @@ bool route_after_sync(void* stream) {
 }
 // bestla_device_sync with nothing but launches on the queue since it was last waited for: nothing the host can see depends on them before a copy
 // is asked for — and that copy is ordered behind them on the queue.  The reference's token ends with sync, copy, sync (ne_layers.c:8345-8346): the first
-// of the two waits (a wake-up of the host thread, ~40 us on the trace) is left to the second.  NS_ROUTE_LAZY_SYNC=0: every wait waits.
+// of the two waits (a wake-up of the host thread, ~40 us on the profiler's trace) can be left to the second: NS_ROUTE_LAZY_SYNC=1.
 bool route_defer_sync(void* stream) {
-  static const bool off = getenv("NS_ROUTE_LAZY_SYNC") && atoi(getenv("NS_ROUTE_LAZY_SYNC")) == 0;
-  if (off || t_in_exec) return false;
+  // measured (profiles/r06_route_timings.txt): no difference — 2074 vs 2065 / 2088 us per token at 1500 cached positions; the wake-up the trace showed
+  // belongs to the profiler.  Off unless NS_ROUTE_LAZY_SYNC=1 asks for it.
+  static const bool on = getenv("NS_ROUTE_LAZY_SYNC") && atoi(getenv("NS_ROUTE_LAZY_SYNC")) != 0;
+  if (!on || t_in_exec) return false;
   Route* r = find_route(stream);
   return r && r->copies_pending == 0 && (window_on() || g_enabled.load() != 0);
 }

@@ -20,7 +20,7 @@ for r in rows:
     if r.get("Counter_Name") != "FETCH_SIZE":
         continue
     name = r["Kernel_Name"]
-    if "smallm" not in name and "gemv_kernel" not in name and "gemm" not in name:
+    if "smallm" not in name and "gemv_kernel" not in name and "gemm" not in name and "gemvs" not in name:
         continue
     short = name.split("(")[0].replace("void ns::", "")
     key = (short, r.get("Grid_Size", ""), r.get("Workgroup_Size", ""))
@@ -45,3 +45,18 @@ if gu and len(sys.argv) > 2:
                "gate_up": dict(v, kernel="gemv_kernel", kernel_full=k.split("|")[0], grid=int(g) // int(w), workgroup=int(w)),
                "all": out}, open(sys.argv[2], "w"), indent=1)
     print("wrote", sys.argv[2])
+
+# second mode (round 6): `pmc_summary.py <counter csv> --config4 <out json> <weight bytes per layer>` — the small-batch kernel's launches of
+# BASELINE config 4 (bench.py --secondary-only): counter traffic of a layer's launches against the layer's algorithmic weight bytes
+if len(sys.argv) > 4 and sys.argv[2] == "--config4":
+    layer_bytes = float(sys.argv[4])
+    gv = {k: v for k, v in out.items() if "gemvs" in k}
+    # a layer = one launch of every distinct (kernel, grid) shape among the gemvs launches that ran n_layers times (the lm_head's shape ran once per pass)
+    most = max((v["calls"] for v in gv.values()), default=0)
+    per_layer = {k: v for k, v in gv.items() if v["calls"] == most}
+    total = sum(v["hbm_bytes_corrected"] for v in per_layer.values())
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --secondary-only (scripts/pmc_traffic.sh)",
+               "correction": "FETCH_SIZE(KiB)*1024*2", "config4_layer_launches": per_layer, "config4_layer_hbm_bytes_corrected": total,
+               "config4_layer_algorithmic_weight_bytes": layer_bytes, "ratio": total / layer_bytes if layer_bytes else None,
+               "all_gemvs": gv}, open(sys.argv[3], "w"), indent=1)
+    print("config 4: counter traffic per layer %.2f MB / algorithmic %.2f MB = %.3f" % (total / 1e6, layer_bytes / 1e6, total / layer_bytes if layer_bytes else 0))
