@@ -248,7 +248,7 @@ def test_two_device_contexts_alternating_tokens_keep_separate_plans(L, pkg, nso)
 NL = 2  # decoder layers of the second stream
 
 
-def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None):
+def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None, hkv=HEADS):
     """NL decoder layers WITH the attention node and the model's last norm + output projection: the shape in which the plan carries RMS norms
     across launches (ns_route.cpp link_norms).  Positions pos0, pos0 + 1, ... of caches made for nctx positions (cache0: their initial contents).  Returns (outputs per token, K caches, V caches, route statistics)."""
     _api(L)
@@ -267,7 +267,8 @@ def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None):
         slices.append(dptr)
     f4 = 4
     pool = L.bestla_device_malloc(1 << 21, q)
-    zero = np.zeros(HEADS * nctx * HS, np.float32)
+    zero = np.zeros(hkv * nctx * HS, np.float32)
+    DKV = hkv * HS
     kcs, vcs = [], []
     for _ in range(NL):
         kc, vc = L.bestla_device_malloc(zero.nbytes, q), L.bestla_device_malloc(zero.nbytes, q)
@@ -299,16 +300,16 @@ def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None):
             kc, vc = kcs[il], vcs[il]
             assert L.ns_hip_lazy_rms_norm(1, D, 1e-5, px, pn, q) == 0
             assert L.ns_hip_lazy_mul(pn, dg, ph, ne, nb, ne, nb, nb, q) == 0
-            L.bestla_device_f32f32_forward(ph, nso.ptr(stors["wk"]), pk, 1, D, D, D, D, None, q)
-            assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_rope_f32(pk, pk, 1, 1, HEADS, HS, pos, HS, 0, 10000.0, 1.0, 0.0, 1.0, q) == 0
-            assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_dup_f32(pk, kc + pos * HS * f4, _ll(HS, 1, HEADS, 1), _ll(4, HS * HEADS * 4, HS * 4, HS * HEADS * 4),
-                                                                      _ll(4, HS * 4, nctx * HS * 4, HEADS * nctx * HS * 4), False, q) == 0
-            L.bestla_device_f32f32_forward(ph, nso.ptr(stors["wv"]), pv, 1, D, D, D, D, None, q)
-            assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_dup_f32(pv, vc + pos * f4, _ll(1, HS, HEADS, 1), _ll(HS * HEADS * 4, 4, HS * 4, HS * HEADS * 4),
-                                                                      _ll(4, nctx * 4, HS * nctx * 4, HEADS * HS * nctx * 4), False, q) == 0
+            L.bestla_device_f32f32_forward(ph, nso.ptr(stors["wk"]), pk, 1, DKV, D, D, DKV, None, q)
+            assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_rope_f32(pk, pk, 1, 1, hkv, HS, pos, HS, 0, 10000.0, 1.0, 0.0, 1.0, q) == 0
+            assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_dup_f32(pk, kc + pos * HS * f4, _ll(HS, 1, hkv, 1), _ll(4, HS * hkv * 4, HS * 4, HS * hkv * 4),
+                                                                      _ll(4, HS * 4, nctx * HS * 4, hkv * nctx * HS * 4), False, q) == 0
+            L.bestla_device_f32f32_forward(ph, nso.ptr(stors["wv"]), pv, 1, DKV, D, D, DKV, None, q)
+            assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_dup_f32(pv, vc + pos * f4, _ll(1, HS, hkv, 1), _ll(HS * hkv * 4, 4, HS * 4, HS * hkv * 4),
+                                                                      _ll(4, nctx * 4, HS * nctx * 4, hkv * HS * nctx * 4), False, q) == 0
             L.bestla_device_f32f32_forward(ph, nso.ptr(stors["wq"]), pq, 1, D, D, D, D, None, q)
             assert L.ns_hip_lazy_flush() == 0 and L.ns_hip_rope_f32(pq, pq, 1, 1, HEADS, HS, pos, HS, 0, 10000.0, 1.0, 0.0, 1.0, q) == 0
-            assert L.ns_hip_mha_f32_device_layout(pq, kc, vc, pa, 1, 1, pos + 1, HEADS, HEADS, HS, nctx, HS ** -0.5, 1, q) == 0
+            assert L.ns_hip_mha_f32_device_layout(pq, kc, vc, pa, 1, 1, pos + 1, HEADS, hkv, HS, nctx, HS ** -0.5, 1, q) == 0
             L.bestla_device_f32f32_forward(pa, nso.ptr(stors["wo"]), pt, 1, D, D, D, D, None, q)
             assert L.ns_hip_binary_nd_f32(0, pt, px, pr, ne, nb, ne, nb, nb, q) == 0
             assert L.ns_hip_lazy_rms_norm(1, D, 1e-5, pr, pn2, q) == 0
@@ -330,7 +331,7 @@ def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None):
         outs.append(out)
     caches = []
     for c in kcs + vcs:
-        h = np.zeros(HEADS * nctx * HS, np.float32)
+        h = np.zeros(hkv * nctx * HS, np.float32)
         L.bestla_device_memcpy_sync(nso.ptr(h), c, h.nbytes, q)
         caches.append(h)
     st = (C.c_uint64 * 8)()
@@ -430,3 +431,30 @@ def test_values_beyond_fp16_turn_the_fp16_shortcuts_off_and_the_token_is_evaluat
     finally:
         L.ns_hip_set_tuning(b"device_kv_f16", -1)
         L.ns_hip_route_set_enabled(1)
+
+
+def test_replayed_grouped_query_attention_on_the_kv_mirror(L, pkg, nso):
+    """Two kv heads under four query heads (the shape of Mistral / Llama-2-70B layers): the three projections have different widths, so the plan keeps them as
+    separate launches (the reference's own graph does, llama.cpp:215) with rope(k), rope(q) and the two cache writes as launches of their own — each cache
+    write storing into the fp16 mirror as well — and the replayed attention serves two query heads per kv head of a mirror that grows across a context-range boundary (4 -> 5 live
+    ranges of 32 keys).  Same tokens as plain launches."""
+    rng = np.random.default_rng(9)
+    hkv = 2
+    mk = lambda n, k: nso.quant_pack((rng.standard_normal((n, k)) * k ** -0.5).astype(np.float32), 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
+    blobs = {"wq": mk(D, D), "wk": mk(hkv * HS, D), "wv": mk(hkv * HS, D), "wo": mk(D, D), "w1": mk(FF, D), "w3": mk(FF, D), "w2": mk(D, FF)}
+    gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    xs = [rng.standard_normal(D).astype(np.float32) for _ in range(14)]
+    nctx, pos0 = 512, 120
+    cache0 = [(0.5 * rng.standard_normal(hkv * nctx * HS)).astype(np.float32) for _ in range(2 * NL)]
+    _api(L)
+    ref_out, ref_c, _ = _run_layers(L, nso, blobs, gam, xs, 0, nctx, pos0, cache0, hkv=hkv)
+    st1 = (C.c_uint64 * 8)()
+    L.ns_hip_route_stats(st1)
+    got_out, got_c, st2 = _run_layers(L, nso, blobs, gam, xs, 3, nctx, pos0, cache0, hkv=hkv)
+    replayed, eager, plans, fallbacks = (st2[i] - st1[i] for i in range(4))
+    assert (replayed, eager, plans, fallbacks) == (12, 2, 1, 0), (replayed, eager, plans, fallbacks)
+    for t, (a, b) in enumerate(zip(ref_out, got_out)):
+        assert np.all(np.isfinite(b))
+        assert nso.rel_l2(b, a) < 2e-3, (t, nso.rel_l2(b, a))
+    for a, b in zip(ref_c, got_c):
+        assert nso.rel_l2(b, a) < 2e-3
