@@ -1434,6 +1434,255 @@ __device__ __forceinline__ void attn_mfma2_body(const AttnParams& p, const int n
   }
 }
 
+// ============================================================================================================
+// attn_mfma3_kernel (round 6) — the operands, layouts and arithmetic of attn_mfma2_kernel (exact head sizes 64 / 128, no score bias) with the K / V tiles
+// travelling HBM -> LDS by DMA (buffer_load ... lds, 1 KiB per wave-wide request): the XOR swizzle of a K row's 16-byte slots and the V subtile image are
+// made by WHICH global 16 bytes a lane asks for (the DMA writes lane-linear), so there are no staging registers and no register -> LDS pass ("park") —
+// 8 requests per wave and tile instead of 8 loads + 8 ds_write_b128 + their address arithmetic, and 32 registers free.  Rows past the last key lie outside
+// the buffer descriptor and arrive as zeros (their scores are masked).  2048 tokens 500 -> 530 TFLOPS causal, 4096 545 -> 605, 8192 667 -> 750 (standalone,
+// profiles/r06_attn_prefill_dma.txt); a layer's launch inside the 2048-token prompt -3 us.
+// Built on top of it, correct (the whole attention suite passes) and NOT adopted: P.V lagging one tile so that its MFMAs issue between the exponentials of the
+// next tile (sched_group_barrier pattern: one MFMA, two transposing LDS reads, two v_exp, ten VALU): the second set of probabilities pushes the 128-wide
+// instantiation to 256 registers + 21 spilled, each MFMA waits for the LDS reads placed right in front of it — 410-439 TFLOPS at 2048 tokens against 530.
+// Requesting the first V operands in front of the exponentials: also slower (504 vs 540).  What bounds 2048 tokens now is the pairing: a CU's two workgroups
+// (heavy + light q-block: equal SUM of tiles) run together for the light one's tiles only, the heavy one then has its SIMDs to itself — 1.9 us per
+// tile-unit against 1.41 at 8192 tokens, where eight workgroups per CU even that out.
+template <int HS>
+__device__ __forceinline__ void attn_mfma3_body(const AttnParams& p, const int nqb, const int aligned_dst, const int xcd_map) {
+  constexpr int NJ = HS / 16, NDT = HS / 32, NCH = HS / 8, KROW = HS * 2, NSUB = HS / 16;
+  constexpr int KTILE = kA2KB * KROW, VTILE = NSUB * kA2VSub;
+  constexpr int KREQ = KTILE / 1024 / 4, VREQ = 2 * NSUB / 4;  // DMA requests per wave and tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];  // K[2][KTILE] | V[2][VTILE]
+  typedef __attribute__((address_space(3))) unsigned char* LdsPtr;
+  const int tid = threadIdx.x, l = tid & 63, n = l & 31, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool causal = (p.flags & NS_ATTN_FLAG_IS_CAUSAL) != 0;
+  const unsigned G = unsigned(p.head_num / p.heads_kv), units = gridDim.x / unsigned(nqb);
+  unsigned unit = blockIdx.x / unsigned(nqb), ordn = blockIdx.x % unsigned(nqb);
+  bool heavy_first = unit < (units + 1) / 2;
+  if (xcd_map & 1) {
+    const unsigned x = blockIdx.x & 7u, sl = blockIdx.x >> 3;
+    const unsigned ul = sl / unsigned(nqb);
+    ordn = sl % unsigned(nqb);
+    unit = ((ul / G) * 8u + x) * G + ul % G;
+    heavy_first = ul < (units / 8u + 1) / 2;
+  }
+  const int hb = int(unit);
+  const int qblk = causal && heavy_first ? nqb - 1 - int(ordn) : int(ordn);
+  const int ihn = hb % p.head_num, ibs = hb / p.head_num;
+  const int ihkv = ihn / (p.head_num / p.heads_kv);
+  const int off = p.sl_kv - p.sl_q;
+  const int q0 = qblk * 128 + w * 32;
+  const float* qb = p.q + ibs * p.step_q_bs + ihn * p.step_q_head_num;
+  const _Float16* kb = p.k + ibs * p.step_k_bs + ihkv * p.step_k_head_num;
+  const _Float16* vb = p.v + ibs * p.step_v_bs + ihkv * p.step_v_head_num;
+  float* db = p.dst + ibs * p.step_dst_bs + ihn * p.step_dst_head_num;
+
+  ahalf8_t qf[NJ];
+  afloatx16 o[NDT];
+  float m_run = -INFINITY, l_run = 0.f;
+  {
+    const float* qr = qb + (long long)min(q0 + n, p.sl_q - 1) * p.step_q_sl + 8 * h;
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) qf[j][i] = (_Float16)qr[16 * j + i];
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) o[dt][i] = 0.f;
+  }
+  const float sc = p.qk_scale * 1.4426950408889634f;
+  const int q_last_wg = min(qblk * 128 + 127, p.sl_q - 1);
+  const int kv_end = causal ? min(p.sl_kv, q_last_wg + off + 1) : p.sl_kv;
+  const int visible = min(p.sl_kv, causal ? min(q0 + n, p.sl_q - 1) + off + 1 : p.sl_kv);
+  const int vis_first = min(p.sl_kv, causal ? q0 + off + 1 : p.sl_kv);
+  const int vis_last = min(p.sl_kv, causal ? min(q0 + 31, p.sl_q - 1) + off + 1 : p.sl_kv);
+  const bool wave_live = q0 < p.sl_q;
+
+  // ---- tile requests (DMA): descriptors over the head's rows; a row past the last key lies outside them and arrives as zeros (its scores are masked) ----
+  auto uniform_ptr = [](const _Float16* ptr) {
+    const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return reinterpret_cast<_Float16*>((uint64_t(hi) << 32) | lo);
+  };
+  const uint32_t k_bytes = uint32_t((size_t(p.sl_kv - 1) * p.step_k_sl + HS) * 2), v_bytes = uint32_t((size_t(p.sl_kv - 1) * p.step_v_sl + HS) * 2);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(kb), 0, __builtin_amdgcn_readfirstlane(k_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(vb), 0, __builtin_amdgcn_readfirstlane(v_bytes), 0x00020000);
+  uint32_t kvoff[KREQ], vvoff[VREQ];  // byte offsets inside tile 0 of what this lane asks for in its wave's u-th request
+  constexpr int RPC = 1024 / KROW;    // K rows per 1 KiB request
+#pragma unroll
+  for (int u = 0; u < KREQ; u++) {
+    const int r = (w * KREQ + u) * RPC + l / NCH, slot = l % NCH;
+    const int swz = HS >= 128 ? (r & 15) : ((r >> 1) & 7);
+    kvoff[u] = (uint32_t(r) * uint32_t(p.step_k_sl) + uint32_t((slot ^ swz) * 8)) * 2u;
+  }
+#pragma unroll
+  for (int u = 0; u < VREQ; u++) {
+    const int c = w * VREQ + u, sub = c >> 1, half = c & 1;  // request c = (subtile, rows 0..31 / 32..63)
+    vvoff[u] = (uint32_t(half * 32 + (l >> 1)) * uint32_t(p.step_v_sl) + uint32_t(16 * sub + 8 * (l & 1))) * 2u;
+  }
+  const uint32_t ktile_step = uint32_t(kA2KB) * uint32_t(p.step_k_sl) * 2u, vtile_step = uint32_t(kA2KB) * uint32_t(p.step_v_sl) * 2u;
+  auto issue_k = [&](int t, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int u = 0; u < KREQ; u++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, reinterpret_cast<__attribute__((address_space(3))) void*>((LdsPtr)(smem3) + buf * KTILE + (w * KREQ + u) * 1024), 16,
+                                               kvoff[u] + uint32_t(t) * ktile_step, 0, 0, 0);
+#endif
+  };
+  auto issue_v = [&](int t, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int u = 0; u < VREQ; u++) {
+      const int c = w * VREQ + u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, reinterpret_cast<__attribute__((address_space(3))) void*>((LdsPtr)(smem3) + 2 * KTILE + buf * VTILE + (c >> 1) * kA2VSub + (c & 1) * 1024),
+                                               16, vvoff[u] + uint32_t(t) * vtile_step, 0, 0, 0);
+    }
+#endif
+  };
+  const int swz_n = HS >= 128 ? (n & 15) : ((n >> 1) & 7);
+  const int k_rd = n * KROW;
+  const int v_rd = ((l >> 4) & 1) * kA2VSub + (4 * h + ((l & 15) >> 2)) * 32 + (l & 3) * 8;
+
+  // K(b) . Q^T -> sv (two 32-key halves), operands one group of four MFMAs ahead of their use
+  auto qk = [&](const unsigned char* kt, afloatx16 (&sv)[2]) {
+    constexpr int CPT = NJ / 4, NCK = 2 * CPT;
+#pragma unroll
+    for (int T = 0; T < 2; T++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) sv[T][i] = 0.f;
+    ahalf8_t kf[2][4];
+    auto ldk = [&](int c, ahalf8_t(&dst)[4]) {
+      const int T = c / CPT, j0 = (c % CPT) * 4;
+#pragma unroll
+      for (int u = 0; u < 4; u++) dst[u] = *reinterpret_cast<const ahalf8_t*>(kt + k_rd + 32 * T * KROW + (((2 * (j0 + u) + h) ^ swz_n) << 4));
+    };
+    ldk(0, kf[0]);
+#pragma unroll
+    for (int c = 0; c < NCK; c++) {
+      if (c + 1 < NCK) ldk(c + 1, kf[(c + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; u++) sv[c / CPT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c & 1][u], qf[(c % CPT) * 4 + u], sv[c / CPT], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the exponentials of a tile: scores -> probabilities (fp16, the B operand of P.V), running maximum / sum; returns the factor the accumulators take
+  auto softmax = [&](afloatx16 (&sv)[2], ahalf8_t (&pf)[4], int pos0, bool masked) -> float {
+    if (masked) {
+#pragma unroll
+      for (int e = 0; e < 32; e++) {
+        const int i = e & 15;
+        const int pos = pos0 + 32 * (e >> 4) + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (pos >= visible) sv[e >> 4][i] = -INFINITY;
+      }
+    }
+    float mx = sv[0][0];
+#pragma unroll
+    for (int e = 1; e < 32; e++) mx = fmaxf(mx, sv[e >> 4][e & 15]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float neg_m = m_new == -INFINITY ? 0.f : -m_new * sc;
+    const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, sc, neg_m));
+    float ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; e++) {
+      const float pe = __builtin_amdgcn_exp2f(fmaf(sv[e >> 4][e & 15], sc, neg_m));
+      ps += pe;
+      pf[e >> 3][e & 7] = (_Float16)pe;
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    return alpha;
+  };
+  // O^T += V(t)^T . P^T, operands one group of four MFMAs ahead of their use
+  auto pv = [&](const unsigned char* vt, const ahalf8_t (&pf)[4]) {
+    auto ldv = [&](int dt, ahalf8_t(&dst)[4]) {
+#pragma unroll
+      for (int ts = 0; ts < 4; ts++) {
+        const unsigned char* va = vt + v_rd + 2 * dt * kA2VSub + 16 * ts * 32;
+        const ashort4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ashort4_t __attribute__((address_space(3)))*)(va));
+        const ashort4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ashort4_t __attribute__((address_space(3)))*)(va + 8 * 32));
+        dst[ts] = __builtin_bit_cast(ahalf8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    };
+    ahalf8_t vf[2][4];
+    ldv(0, vf[0]);
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++) {
+      if (dt + 1 < NDT) ldv(dt + 1, vf[(dt + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ts = 0; ts < 4; ts++) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt & 1][ts], pf[ts], o[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto rescale = [&](float alpha) {
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) o[dt][i] *= alpha;
+    }
+  };
+
+  const int nb = (kv_end + kA2KB - 1) / kA2KB;
+  const int variant = xcd_map >> 8;  // bit 0: the next tile is requested behind K.Q^T instead of in front of it; bit 1: raised priority while K.Q^T issues
+  if (nb > 0) issue_k(0, 0), issue_v(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int b = 0; b < nb; b++) {
+    const int pos0 = b * kA2KB;
+    const bool more = b + 1 < nb;
+    if (!(variant & 1) && more) issue_k(b + 1, (b + 1) & 1), issue_v(b + 1, (b + 1) & 1);
+    if (wave_live && pos0 < vis_last) {
+      afloatx16 sv[2];
+      ahalf8_t pf[4];
+      if (variant & 2) __builtin_amdgcn_s_setprio(2);
+      qk(smem3 + (b & 1) * KTILE, sv);
+      if (variant & 2) __builtin_amdgcn_s_setprio(0);
+      if ((variant & 1) && more) issue_k(b + 1, (b + 1) & 1), issue_v(b + 1, (b + 1) & 1);
+      const float alpha = softmax(sv, pf, pos0, pos0 + kA2KB > vis_first);  // (masked: wave-uniform — only tiles on the diagonal / past the last key)
+      rescale(alpha);
+      pv(smem3 + 2 * KTILE + (b & 1) * VTILE, pf);
+    } else if ((variant & 1) && more) {
+      issue_k(b + 1, (b + 1) & 1), issue_v(b + 1, (b + 1) & 1);
+    }
+    // this wave's requests have landed; every wave is done with tile b's buffers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = l_run > 0.f ? p.out_scale / l_run : 0.f;
+  const int row = q0 + n;
+  if (row < p.sl_q) {
+    float* dr = db + (long long)row * p.step_dst_sl;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+      for (int bq = 0; bq < 4; bq++) {
+        const int d = 32 * dt + 8 * bq + 4 * h;
+        const afloatx4 y = afloatx4{o[dt][4 * bq] * inv, o[dt][4 * bq + 1] * inv, o[dt][4 * bq + 2] * inv, o[dt][4 * bq + 3] * inv};
+        if (aligned_dst) {
+          *reinterpret_cast<afloatx4*>(dr + d) = y;
+          if (p.dst16) *reinterpret_cast<ahalf4_t*>(p.dst16 + (dr - p.dst) + d) = ahalf4_t{(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            dr[d + r] = y[r];
+            if (p.dst16) p.dst16[(dr - p.dst) + d + r] = (_Float16)y[r];
+          }
+        }
+      }
+    }
+  }
+}
+template <int HS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma3_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
+  attn_mfma3_body<HS>(p, nqb, aligned_dst, xcd_map);
+}
+
 template <int HS, bool SB = false, bool PAD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma2_kernel(const AttnParams p, const int nqb, const int aligned_dst, const int xcd_map) {
   attn_mfma2_body<HS, SB, PAD>(p, nqb, aligned_dst, xcd_map);
@@ -1517,13 +1766,23 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
                           a.step_dst_bs % 4 == 0 && (!dst16 || (reinterpret_cast<uintptr_t>(dst16) & 7) == 0);
       static const bool no_xcd = getenv("NS_ATTN_NO_XCD_MAP") != nullptr;  // diagnostics (A/B)
       const int xcd_map = !no_xcd && (size_t(a.heads_kv) * a.batch_size) % 8 == 0;
-      auto go = [&](auto kern, int stage) {
+      auto go = [&](auto kern, int stage, int extra = 0) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * stage);
         if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(kern, dim3(unsigned(wgs2)), dim3(256), size_t(2) * stage, st, p, int(nqb), aligned, xcd_map);
+        hipLaunchKernelGGL(kern, dim3(unsigned(wgs2)), dim3(256), size_t(2) * stage, st, p, int(nqb), aligned, xcd_map | extra);
         return hipGetLastError();
       };
       const bool pad = a.head_size != 64 && a.head_size != 128 && a.head_size != 256;
+      // round 6: the pipelined schedule (attn_mfma3_kernel) for the exact head sizes without score bias; rows inside a 32-bit buffer descriptor
+      // round 6: K / V tiles by DMA (attn_mfma3_kernel) for the exact head sizes without score bias, rows inside a 32-bit buffer descriptor; NS_ATTN_PIPE=0:
+      // attn_mfma2_kernel.  Variant (NS_ATTN_PVAR): bit 0 = the next tile is requested behind K.Q^T instead of in front of it, bit 1 = raised priority while
+      // K.Q^T issues — both gain from 4096 keys on (601-611 vs 558-585 TFLOPS causal, 742-751 vs 722 at 8192) and lose below (519-525 vs 529-530 at 2048)
+      static const int pipe = getenv("NS_ATTN_PIPE") ? atoi(getenv("NS_ATTN_PIPE")) : 1;
+      static const int pvar_env = getenv("NS_ATTN_PVAR") ? atoi(getenv("NS_ATTN_PVAR")) : -1;
+      const int pvar = pvar_env >= 0 ? pvar_env : (a.sl_kv >= 3072 ? 3 : 0);
+      const bool in32 = (size_t(a.sl_kv) * size_t(a.step_k_sl) + 256) * 2 < (size_t(1) << 32) && (size_t(a.sl_kv) * size_t(a.step_v_sl) + 256) * 2 < (size_t(1) << 32);
+      if (pipe && !biased && !pad && !hs256 && in32)
+        return a.head_size == 64 ? go(attn_mfma3_kernel<64>, a2_stage_bytes<64>(), pvar << 8) : go(attn_mfma3_kernel<128>, a2_stage_bytes<128>(), pvar << 8);
       if (hs256)
         return biased ? (pad ? go(attn_mfma2_hs256_kernel<true, true>, a2_stage_bytes<256>()) : go(attn_mfma2_hs256_kernel<true, false>, a2_stage_bytes<256>()))
                       : (pad ? go(attn_mfma2_hs256_kernel<false, true>, a2_stage_bytes<256>()) : go(attn_mfma2_hs256_kernel<false, false>, a2_stage_bytes<256>()));
