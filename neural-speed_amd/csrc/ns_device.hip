@@ -778,6 +778,11 @@ void bestla_device_f32f32_forward(float* activation, void* weiptr, float* output
     printf("Err: invalid parameters (bestla_device_f32f32_forward: %s)\n", ns_hip_last_error());
     return;
   }
+  if (s->w->load_failed) {  // (refused HERE: a window or a plan would otherwise carry the weight into a fused launch — ADVICE r05)
+    ns::set_error("bestla_device_f32f32_forward: the blob behind this weight was rejected when it was loaded");
+    printf("Err: invalid parameters (bestla_device_f32f32_forward: %s)\n", ns_hip_last_error());
+    return;
+  }
   int rc;
   if (ns::route_hook(queue)) {
     ns::RouteOp op;
