@@ -47,16 +47,28 @@ if gu and len(sys.argv) > 2:
     print("wrote", sys.argv[2])
 
 # second mode (round 6): `pmc_summary.py <counter csv> --config4 <out json> <weight bytes per layer>` — the small-batch kernel's launches of
-# BASELINE config 4 (bench.py --secondary-only): counter traffic of a layer's launches against the layer's algorithmic weight bytes
+# BASELINE config 4 (bench.py --secondary-only): counter traffic of a layer's launches against the layer's algorithmic weight bytes.  A layer = one fused QKV
+# launch (mode 2), one gate / up launch (mode 1), two plain launches (WO, down: mode 0) and the down projection's finalize; the output projection is a plain launch
+# too (one per pass): the plain launches beyond two per layer are the largest ones and are left out.
 if len(sys.argv) > 4 and sys.argv[2] == "--config4":
     layer_bytes = float(sys.argv[4])
-    gv = {k: v for k, v in out.items() if "gemvs" in k}
-    # a layer = one launch of every distinct (kernel, grid) shape among the gemvs launches that ran n_layers times (the lm_head's shape ran once per pass)
-    most = max((v["calls"] for v in gv.values()), default=0)
-    per_layer = {k: v for k, v in gv.items() if v["calls"] == most}
-    total = sum(v["hbm_bytes_corrected"] for v in per_layer.values())
+    per = collections.defaultdict(list)   # kernel (with template arguments) -> bytes of every dispatch
+    for r in rows:
+        if r.get("Counter_Name") != "FETCH_SIZE" or "gemvs" not in r["Kernel_Name"]:
+            continue
+        per[r["Kernel_Name"].split("(")[0].replace("void ns::", "")].append(float(r["Counter_Value"]) * 1024 * 2)
+    mode = lambda k: k.rstrip(">").split(",")[-1].strip() if "gemvs_kernel<" in k else "fin"
+    n_layers = sum(len(v) for k, v in per.items() if mode(k) == "1")
+    total, detail = 0.0, {}
+    for k, v in per.items():
+        v = sorted(v)
+        if mode(k) == "0" and len(v) > 2 * n_layers:
+            v = v[:2 * n_layers]   # (the output projection's launches: the largest plain ones)
+        total += sum(v)
+        detail[k] = {"dispatches_counted": len(v), "hbm_bytes_corrected_avg": sum(v) / max(1, len(v))}
+    per_layer = total / max(1, n_layers)
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --secondary-only (scripts/pmc_traffic.sh)",
-               "correction": "FETCH_SIZE(KiB)*1024*2", "config4_layer_launches": per_layer, "config4_layer_hbm_bytes_corrected": total,
-               "config4_layer_algorithmic_weight_bytes": layer_bytes, "ratio": total / layer_bytes if layer_bytes else None,
-               "all_gemvs": gv}, open(sys.argv[3], "w"), indent=1)
-    print("config 4: counter traffic per layer %.2f MB / algorithmic %.2f MB = %.3f" % (total / 1e6, layer_bytes / 1e6, total / layer_bytes if layer_bytes else 0))
+               "correction": "FETCH_SIZE(KiB)*1024*2 (MI355X_MICROARCH.md HBM section: 128-B requests tallied at 64 B on gfx950)",
+               "layers_counted": n_layers, "config4_layer_hbm_bytes_corrected": per_layer, "config4_layer_algorithmic_weight_bytes": layer_bytes,
+               "ratio": per_layer / layer_bytes if layer_bytes else None, "launches": detail}, open(sys.argv[3], "w"), indent=1)
+    print("config 4: counter traffic per layer %.2f MB / algorithmic %.2f MB = %.3f (%d layers)" % (per_layer / 1e6, layer_bytes / 1e6, per_layer / layer_bytes if layer_bytes else 0, n_layers))
