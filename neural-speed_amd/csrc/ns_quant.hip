@@ -1311,6 +1311,29 @@ __global__ __launch_bounds__(256) void dup_transpose_kernel(const char* __restri
     }
   }
 }
+// fp32 -> fp32 with both sides contiguous along axis 0 (the K cache write of a prompt: rows of head_size floats): four elements per thread, 16-byte accesses
+__global__ void dup_vec4_kernel(const char* __restrict__ src, char* __restrict__ dst, DupDims d) {
+  const long long n0 = d.ne[0] >> 2, total = n0 * d.ne[1] * d.ne[2] * d.ne[3];
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long i0 = (i % n0) << 2;
+  i /= n0;
+  const long long i1 = i % d.ne[1];
+  i /= d.ne[1];
+  const long long i2 = i % d.ne[2];
+  const long long i3 = i / d.ne[2];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<f4*>(dst + i0 * 4 + i1 * d.dnb[1] + i2 * d.dnb[2] + i3 * d.dnb[3]) =
+      *reinterpret_cast<const f4*>(src + i0 * 4 + i1 * d.snb[1] + i2 * d.snb[2] + i3 * d.snb[3]);
+}
+static bool dup_vec4_ok(const void* src, const void* dst, const long long* ne, const long long* snb, const long long* dnb, bool f16) {
+  if (f16 || g_affine.k || g_kvm.k.m16 || g_kvm.v.m16) return false;
+  if (ne[0] * ne[1] * ne[2] * ne[3] < (1 << 16) || (ne[0] & 3) || snb[0] != 4 || dnb[0] != 4) return false;
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return false;
+  for (int i = 1; i < 4; i++)
+    if (ne[i] > 1 && ((snb[i] | dnb[i]) & 15)) return false;
+  return true;
+}
 // the axis the transposing form walks on the source side, or -1: a plain launch serves the copy as well (or it is small)
 static int dup_transpose_axis(const long long* ne, const long long* snb, const long long* dnb, bool f16) {
   if (g_affine.k || g_kvm.k.m16 || g_kvm.v.m16) return -1;
@@ -1355,6 +1378,10 @@ hipError_t launch_dup(const void* src, void* dst, const long long* ne, const lon
   const long long total = ne[0] * ne[1] * ne[2] * ne[3];
   if (total <= 0) return hipSuccess;
   if (const int ax = dup_transpose_axis(ne, snb, dnb, dst_f16); ax >= 0) return launch_dup_transpose(src, dst, d, ax, dst_f16, st);
+  if (dup_vec4_ok(src, dst, ne, snb, dnb, dst_f16)) {
+    hipLaunchKernelGGL(dup_vec4_kernel, grid1d(size_t(total / 4), 256), dim3(256), 0, st, static_cast<const char*>(src), static_cast<char*>(dst), d);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(dup_kernel, grid1d(size_t(total), 256), dim3(256), 0, st, static_cast<const char*>(src),
                      static_cast<char*>(dst), d, dst_f16 ? 1 : 0, g_affine.k, g_affine.delta);
   return hipGetLastError();

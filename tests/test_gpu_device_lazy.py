@@ -181,3 +181,34 @@ def test_dense_and_strided_binary_nodes_compute_the_same_values(L, pkg):
     pkg.check(L.ns_hip_binary_nd_f32(0, a2.data_ptr(), b.data_ptr(), a2.data_ptr(), ne, nb, ne, nb, nb, st))
     torch.cuda.synchronize()
     assert torch.equal(a2, a + b)
+
+
+@pytest.mark.parametrize("seq,heads,hs,n_ctx,pos", [(300, 8, 128, 512, 100), (70, 4, 64, 256, 0), (33, 4, 128, 64, 5)])
+def test_prompt_sized_cache_writes_take_the_vector_and_the_transposing_copy(L, pkg, seq, heads, hs, n_ctx, pos):
+    """The two kv-cache writes of a prompt as the reference's device graph issues them (llama.cpp:241-285: ne_cpy of the permuted K rows into
+    [head][n_ctx][hs] cells, of the permuted V rows into the TRANSPOSED [head][hs][n_ctx] cells).  From 65 536 elements on ns_hip_dup_f32 serves the first with
+    16-byte accesses (dup_vec4_kernel) and the second through 32 x 32 LDS tiles (dup_transpose_kernel; round 6: dup_kernel read 4 bytes out of every 16 KB row
+    per thread); below that the element-wise kernel.  Every cell, and nothing but the written cells, against numpy."""
+    import torch
+    rng = np.random.default_rng(seq)
+    k = rng.standard_normal((seq, heads, hs)).astype(np.float32)
+    v = rng.standard_normal((seq, heads, hs)).astype(np.float32)
+    kc = np.full((heads, n_ctx, hs), 7.0, np.float32)
+    vc = np.full((heads, hs, n_ctx), 7.0, np.float32)
+    dk, dv, dkc, dvc = (torch.from_numpy(a).cuda() for a in (k, v, kc, vc))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ll4 = C.POINTER(C.c_longlong)
+    L.ns_hip_dup_f32.argtypes = [C.c_void_p, C.c_void_p, ll4, ll4, ll4, C.c_bool, C.c_void_p]
+    ll = lambda *a: (C.c_longlong * 4)(*a)
+    f4 = 4
+    # K: destination extents (hs, seq, heads, 1); the source is indexed with the destination's coordinates
+    pkg.check(L.ns_hip_dup_f32(dk.data_ptr(), dkc.data_ptr() + pos * hs * f4, ll(hs, seq, heads, 1), ll(f4, heads * hs * f4, hs * f4, seq * heads * hs * f4),
+                               ll(f4, hs * f4, n_ctx * hs * f4, heads * n_ctx * hs * f4), False, st))
+    # V: destination extents (seq, hs, heads, 1) of the transposed cache
+    pkg.check(L.ns_hip_dup_f32(dv.data_ptr(), dvc.data_ptr() + pos * f4, ll(seq, hs, heads, 1), ll(heads * hs * f4, f4, hs * f4, seq * heads * hs * f4),
+                               ll(f4, n_ctx * f4, hs * n_ctx * f4, heads * hs * n_ctx * f4), False, st))
+    torch.cuda.synchronize()
+    kc[:, pos:pos + seq, :] = k.transpose(1, 0, 2)
+    vc[:, :, pos:pos + seq] = v.transpose(1, 2, 0)
+    assert np.array_equal(dkc.cpu().numpy(), kc)
+    assert np.array_equal(dvc.cpu().numpy(), vc)
