@@ -500,14 +500,17 @@ bool kvm_args_for_cell(const void* cell, KvMirrorArgs* out) {
   }
   return false;
 }
-void kvm_note_foreign_write(const void* dst, size_t bytes) {
+bool kvm_note_foreign_write(const void* dst, size_t bytes) {
   const char* c = static_cast<const char*>(dst);
-  if (!g_kvm_lo || !c || c >= g_kvm_hi || c + bytes <= g_kvm_lo) return;
+  if (!g_kvm_lo || !c || c >= g_kvm_hi || c + bytes <= g_kvm_lo) return false;
+  bool hit = false;
   for (KvMirror* m : g_kvms)
     if (overlaps(c, bytes ? bytes : 1, m->k32, m->bytes32) || overlaps(c, bytes ? bytes : 1, m->v32, m->bytes32)) {
       std::fill(m->valid.begin(), m->valid.end(), 0);
       m->fresh_lo = m->fresh_hi = 0;
+      hit = true;
     }
+  return hit;
 }
 void kvm_set_valid(const void* k32, int valid) {
   const char* c = static_cast<const char*>(k32);
@@ -637,7 +640,12 @@ void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* q
     ns::set_error("bestla_device_memcpy failed");
   ns::route_note_copy(queue);
   if (in_device_pool(dstptr)) {
-    ns::kvm_note_foreign_write(dstptr, size);      // (a copy into a mirrored kv cache: its mirror starts over)
+    // a copy into a mirrored kv cache (a restored session, a beam's rows): its mirror starts over, and no plan may go on replaying on the old one.
+    // The order matters: plans are dropped first (that leaves every mirror marked up to the last replayed token), THEN the mirror is marked empty
+    if (ns::kvm_note_foreign_write(dstptr, size)) {
+      ns::route_invalidate();
+      (void)ns::kvm_note_foreign_write(dstptr, size);
+    }
     ns::route_note_input(dstptr, size, queue);     // an evaluation's input: kept so that the evaluation can be issued again
   }
 }

@@ -50,8 +50,9 @@ bool kv16_enabled();          // NS_DEVICE_KV / ns_hip_set_tuning("device_kv_f16
 void kv16_set(int on);        // -1: environment / default (on)
 // the mirror behind the fp32 cache cell at `cell` (a cpy node's destination): fills `out`, false when no mirror holds it
 bool kvm_args_for_cell(const void* cell, KvMirrorArgs* out);
-// an operator other than a recognised cache write / a copy stores to `dst`: mirrors that hold it start over
-void kvm_note_foreign_write(const void* dst, size_t bytes);
+// an operator other than a recognised cache write / a copy stores to `dst`: mirrors that hold it start over (true: there was one — a plan that
+// keeps a mirror current by its own cache writes must not go on: the caller drops it)
+bool kvm_note_foreign_write(const void* dst, size_t bytes);
 // a replayed decode step advanced the mirrors its plan writes: positions [0, valid) of slot 0.. hold the cache
 void kvm_set_valid(const void* k32, int valid);
 // a producer is about to store positions [n_past, n_past + m) of slot 0.. of the cache at (k32, v32) into its mirror itself (the fused QKV launch's epilogue at

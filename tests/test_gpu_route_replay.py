@@ -248,7 +248,7 @@ def test_two_device_contexts_alternating_tokens_keep_separate_plans(L, pkg, nso)
 NL = 2  # decoder layers of the second stream
 
 
-def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None, hkv=HEADS):
+def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None, hkv=HEADS, poke=None):
     """NL decoder layers WITH the attention node and the model's last norm + output projection: the shape in which the plan carries RMS norms
     across launches (ns_route.cpp link_norms).  Positions pos0, pos0 + 1, ... of caches made for nctx positions (cache0: their initial contents).  Returns (outputs per token, K caches, V caches, route statistics)."""
     _api(L)
@@ -292,6 +292,11 @@ def _run_layers(L, nso, blobs, gam, xs, replay, nctx=NCTX, pos0=0, cache0=None, 
             return p
         px = alloc(D)
         L.bestla_device_sync(q)
+        if poke is not None and tok == poke[0]:   # a copy INTO the kv caches between two tokens (a restored session): (token index, fp32 rows for position poke[1])
+            for il in range(NL):
+                for h_ in range(hkv):
+                    row = np.ascontiguousarray(poke[2][il][h_])
+                    L.bestla_device_memcpy_sync(kcs[il] + (h_ * nctx + poke[1]) * HS * f4, nso.ptr(row), row.nbytes, q)
         L.bestla_device_memcpy_sync(px, nso.ptr(x), x.nbytes, q)
         for il in range(NL):
             pn, ph, pk, pv, pq, pa = alloc(D), alloc(D), alloc(D), alloc(D), alloc(D), alloc(D)
@@ -456,5 +461,32 @@ def test_replayed_grouped_query_attention_on_the_kv_mirror(L, pkg, nso):
     for t, (a, b) in enumerate(zip(ref_out, got_out)):
         assert np.all(np.isfinite(b))
         assert nso.rel_l2(b, a) < 2e-3, (t, nso.rel_l2(b, a))
+    for a, b in zip(ref_c, got_c):
+        assert nso.rel_l2(b, a) < 2e-3
+
+
+def test_a_copy_into_the_kv_cache_between_two_replayed_tokens_reaches_the_attention(L, pkg, nso):
+    """The route's attention reads an fp16 MIRROR of the fp32 cache, kept current by the plan's own cache writes.  A copy into the cache from outside the graph
+    (a restored session, a beam's rows) between two replayed tokens must reach it: the copy drops the plan and empties the mirror, the next token goes through
+    the window and its attention converts the cache afresh.  K rows of position 2 are overwritten in front of token 6; every token as with plain launches."""
+    rng = np.random.default_rng(10)
+    blobs = _blobs(nso, rng)
+    gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    xs = [rng.standard_normal(D).astype(np.float32) for _ in range(12)]
+    poke = (6, 2, [[(3.0 * rng.standard_normal(HS)).astype(np.float32) for _ in range(HEADS)] for _ in range(NL)])
+    _api(L)
+    ref_out, ref_c, _ = _run_layers(L, nso, blobs, gam, xs, 0, poke=poke)
+    st1 = (C.c_uint64 * 8)()
+    L.ns_hip_route_stats(st1)
+    got_out, got_c, st2 = _run_layers(L, nso, blobs, gam, xs, 3, poke=poke)
+    replayed, eager, plans, fallbacks = (st2[i] - st1[i] for i in range(4))
+    # 0, 1 -> plan; 2 .. 5 replayed; the copy drops the plan; 6, 7 through the window -> plan; 8 .. 11 replayed
+    assert (replayed, eager, plans) == (8, 4, 2), (replayed, eager, plans, fallbacks)
+    for t, (a, b) in enumerate(zip(ref_out, got_out)):
+        assert np.all(np.isfinite(b))
+        assert nso.rel_l2(b, a) < 2e-3, (t, nso.rel_l2(b, a))
+    # the poke changes what the tokens behind it compute (the test would pass on a stale mirror otherwise)
+    plain_out, _, _ = _run_layers(L, nso, blobs, gam, xs, 3)
+    assert nso.rel_l2(plain_out[7], got_out[7]) > 1e-2
     for a, b in zip(ref_c, got_c):
         assert nso.rel_l2(b, a) < 2e-3
