@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/ns_bestla.h"
 #include "ns_common.h"
@@ -541,6 +542,26 @@ void kvm_clear() {
 extern "C" {
 int ns_hip_lazy_flush(void);  // (defined with the lazy peephole below: a recorded norm / silu node is launched before anything else runs)
 
+// The runtime builds its pinned staging for copies from / to pageable host memory under the first such copy (a prompt's embeddings: 24.6 MB in 2.1 ms the
+// first time, 0.5 ms afterwards).  One 32 MB round trip at device creation — model-load time — moves that out of the first prompt.
+static void warm_pageable_copies(hipStream_t s) {
+  static const bool off = getenv("NS_WARM_UP") && atoi(getenv("NS_WARM_UP")) == 0;
+  static std::once_flag once;
+  if (off) return;
+  std::call_once(once, [s] {
+    const size_t n = size_t(32) << 20;
+    void* d = nullptr;
+    char* h = static_cast<char*>(calloc(n, 1));
+    if (h && hipMalloc(&d, n) == hipSuccess) {
+      (void)hipMemcpyAsync(d, h, n, hipMemcpyDefault, s);
+      (void)hipMemcpyAsync(h, d, n, hipMemcpyDefault, s);
+      (void)hipStreamSynchronize(s);
+    }
+    if (d) (void)hipFree(d);
+    free(h);
+    (void)hipGetLastError();
+  });
+}
 /* ---- ne_bestla.h:86-96, ne_bestla_sycl.cpp:26-92 ---- */
 void* bestla_create_device(bool profile) {
   (void)profile;
@@ -561,6 +582,7 @@ void* bestla_create_device(bool profile) {
     fprintf(stderr, "bestla device: %s, %d CUs, %.1f GB\n", prop.name, prop.multiProcessorCount, double(prop.totalGlobalMem) / 1e9);
   ns::route_attach(d->stream);  // ns_route.cpp: the per-token graph this queue carries is verified and replayed
   (void)ns_hip_warm_up();       // the code objects of the GEMM / GEMV / attention / operator kernels are loaded here, not under the first prompt and token
+  warm_pageable_copies(d->stream);
   return d;
 }
 void* bestla_get_device_queue(void* device) { return device ? static_cast<ns::Device*>(device)->stream : nullptr; }
@@ -625,6 +647,9 @@ void bestla_device_free(void* ptr, void* queue) {
 // the host copy of chunk i, that copy cut over eight threads — for the 192 MB of logits a 1500-token prompt's evaluation ends with (ne_layers.c:8345-8346): the
 // runtime's own staged copy is as fast once the destination's pages exist (3.45 vs 3.8 ms) and what a FIRST evaluation pays is the first touch of those pages
 // (10-18 ms either way, run to run); towards the device the runtime was faster outright (24.6 MB: 1.3 vs 3.5 ms).  profiles/r06_route_timings.txt.)
+// Also measured and not adopted: faulting the destination's pages in ahead of the copy (MADV_POPULATE_WRITE by eight threads when sampled pages are not
+// resident): populate + copy 23.6-24.4 ms against 13.9-17.2 ms for the copy alone, three runs each — first-touching that range costs at least as much from
+// eight threads as inside the runtime's copy.  docs/kernels/experiments.md.)
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {
   (void)ns_hip_lazy_flush();
   // what the route holds back (its window) goes out first; a copy FROM device memory reads a tensor behind the window's last op
