@@ -25,6 +25,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include "../../include/ns_bestla.h"
 #include "ns_common.h"
@@ -650,12 +653,37 @@ void bestla_device_free(void* ptr, void* queue) {
 // Also measured and not adopted: faulting the destination's pages in ahead of the copy (MADV_POPULATE_WRITE by eight threads when sampled pages are not
 // resident): populate + copy 23.6-24.4 ms against 13.9-17.2 ms for the copy alone, three runs each — first-touching that range costs at least as much from
 // eight threads as inside the runtime's copy.  docs/kernels/experiments.md.)
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+// The destination of a large copy to pageable host memory, first-touched while the queue still works on what the copy waits for (contents untouched;
+// 8 MB at a time, stopping as soon as the queue is empty; anything the call refuses — an older kernel, a special mapping — is left to the copy)
+static void touch_destination_while_queue_runs(void* dst, size_t size, hipStream_t s) {
+  static const bool off = getenv("NS_DEVICE_PRETOUCH") && atoi(getenv("NS_DEVICE_PRETOUCH")) == 0;
+  if (off || size < (size_t(8) << 20) || hipStreamQuery(s) != hipErrorNotReady) {
+    (void)hipGetLastError();
+    return;
+  }
+  hipPointerAttribute_t at;
+  const bool known = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type != hipMemoryTypeUnregistered;
+  (void)hipGetLastError();
+  if (known) return;  // pinned / device / managed: nothing to fault in
+  const uintptr_t pg = uintptr_t(sysconf(_SC_PAGESIZE)), step = uintptr_t(8) << 20;
+  uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + pg - 1) & ~(pg - 1);
+  const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + size) & ~(pg - 1);
+  for (; lo < hi; lo += step) {
+    if (madvise(reinterpret_cast<void*>(lo), size_t(std::min(step, hi - lo)), MADV_POPULATE_WRITE) != 0) break;
+    if (hipStreamQuery(s) != hipErrorNotReady) break;
+  }
+  (void)hipGetLastError();
+}
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {
   (void)ns_hip_lazy_flush();
   // what the route holds back (its window) goes out first; a copy FROM device memory reads a tensor behind the window's last op
   const bool from_dev = srcptr && in_device_pool(srcptr);
   (void)ns::route_sync_point(queue, from_dev ? srcptr : nullptr, from_dev ? size : 0);
   if (!dstptr || !srcptr || !size) return;
+  if (from_dev && !in_device_pool(dstptr)) touch_destination_while_queue_runs(dstptr, size, static_cast<hipStream_t>(queue));
   // (replayed tokens run on the plan's activations: the embeddings go there as well, the logits come from there — ns_route.cpp)
   void* twin = ns::route_twin_dst(dstptr, queue);
   srcptr = ns::route_translate_src(srcptr, queue);

@@ -17,6 +17,6 @@ for spec in "$@"; do
     fi
   done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libns_hip_$name.so ns_api.o ns_blob.o ns_split.o ns_tp.o $objs ns_quant.o ns_p2p.o ns_i8ref.o ns_i8g2_n4.o ns_i8g2_n2.o ns_i8g2_n1.o ns_i8g2_b2.o ns_i8g2_b1.o ns_moe.o ns_device.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libns_hip_$name.so ns_api.o ns_blob.o ns_split.o ns_tp.o ns_route.o $objs ns_quant.o ns_p2p.o ns_i8ref.o ns_i8g2_n4.o ns_i8g2_n2.o ns_i8g2_n1.o ns_i8g2_b2.o ns_i8g2_b1.o ns_moe.o ns_device.o -ldl
   echo built variants/libns_hip_$name.so
 done
