@@ -448,6 +448,9 @@ void* bestla_device_malloc(size_t size, void* queue);
 void bestla_device_free(void* ptr, void* queue);
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue);
 void bestla_device_memcpy_sync(void* dstptr, const void* srcptr, size_t size, void* queue);
+/* Waits for the queue — except when nothing but kernel launches went onto it since it was last waited for (no copy in either direction): the wait is
+ * then left to the next copy / synchronisation on the queue, which is ordered behind those launches (the reference ends an evaluation with sync, copy,
+ * sync: ne_layers.c:8345-8346; a prompt's logits copy can then be prepared by the host while the launches run).  NS_ROUTE_LAZY_SYNC=0: always waits. */
 void bestla_device_sync(void* queue);
 size_t bestla_device_storage_size(void);
 /* hoststor: BTLA blob in host memory; devstor: bestla_device_storage_size() bytes inside the tensor object

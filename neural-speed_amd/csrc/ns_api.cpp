@@ -1840,8 +1840,18 @@ void bestla_f32f32_forward(float* activation, void* weiptr, float* output, int _
     invalid_parameters("bestla_f32f32_forward");
 }
 
+// The reference's model code asks these for every layer of every evaluation (llama.cpp:212, :609).  On its device route a weight tensor's data is the
+// storage record of bestla_device_load_storage, not a blob (first word all ones: no blob starts like that, csrc/ns_device.hip DeviceStorage) — refused
+// here as the parse would refuse it, without the lock, the cache lookup and the error text: the unfused nodes the reference then builds are the ones its
+// own device branch builds (ne_bestla.cpp:222-225).
+static inline bool is_device_record(const void* p) {
+  uint64_t v = 0;
+  if (p) memcpy(&v, p, 8);
+  return v == ~uint64_t(0);
+}
 bool bestla_fusion_add_f32f32_support(void* weiptr, int _m, int _n, int _k) {
   (void)_m;
+  if (is_device_record(weiptr)) return false;
   if (ns_hip_device_count() <= 0) return false;
   std::lock_guard<std::mutex> host_lock(g_host_mu);
   CachePin pin;
@@ -1865,6 +1875,7 @@ unsigned long long bestla_fusion_QKV_f32f32_get_workspace_size(int _m, int _n, i
 
 bool bestla_fusion_QKV_f32f32_support(void* wqptr, void* wkptr, void* wvptr, int _m, int _n, int _k) {
   (void)_m;
+  if (is_device_record(wqptr) || is_device_record(wkptr) || is_device_record(wvptr)) return false;
   if (ns_hip_device_count() <= 0) return false;
   std::lock_guard<std::mutex> host_lock(g_host_mu);
   CachePin pin;
@@ -1929,6 +1940,7 @@ unsigned long long bestla_fusion_FFN_f32f32_get_workspace_size(int seq, int fin,
 }
 
 static bool ffn3_support(void* w1ptr, void* w2ptr, void* w3ptr, int fin, int fmid, int fout) {
+  if (is_device_record(w1ptr) || is_device_record(w2ptr) || is_device_record(w3ptr)) return false;
   if (ns_hip_device_count() <= 0) return false;
   std::lock_guard<std::mutex> host_lock(g_host_mu);
   CachePin pin;
@@ -2017,6 +2029,7 @@ void bestla_fusion_FFN_Gelu_Mul_f32f32_forward(float* activation, void* w1ptr, v
 }
 
 static bool ffn2_support(void* w1ptr, void* w2ptr, int fin, int fmid, int fout) {
+  if (is_device_record(w1ptr) || is_device_record(w2ptr)) return false;
   if (ns_hip_device_count() <= 0) return false;
   std::lock_guard<std::mutex> host_lock(g_host_mu);
   CachePin pin;

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <thread>
 
 #include "../../include/ns_bestla.h"
 #include "ns_common.h"
@@ -650,9 +651,10 @@ void bestla_device_free(void* ptr, void* queue) {
 // the host copy of chunk i, that copy cut over eight threads — for the 192 MB of logits a 1500-token prompt's evaluation ends with (ne_layers.c:8345-8346): the
 // runtime's own staged copy is as fast once the destination's pages exist (3.45 vs 3.8 ms) and what a FIRST evaluation pays is the first touch of those pages
 // (10-18 ms either way, run to run); towards the device the runtime was faster outright (24.6 MB: 1.3 vs 3.5 ms).  profiles/r06_route_timings.txt.)
-// Also measured and not adopted: faulting the destination's pages in ahead of the copy (MADV_POPULATE_WRITE by eight threads when sampled pages are not
-// resident): populate + copy 23.6-24.4 ms against 13.9-17.2 ms for the copy alone, three runs each — first-touching that range costs at least as much from
-// eight threads as inside the runtime's copy.  docs/kernels/experiments.md.)
+// Also measured and not adopted: faulting the destination's pages in by eight threads IN FRONT of the copy (the queue already empty): populate + copy
+// 23.6-24.4 ms against 13.9-17.2 ms for the copy alone.  docs/kernels/experiments.md.)
+// What IS done: one thread, while the queue still works on what the copy waits for — bestla_device_sync in front of the copy is deferred (ns_route.cpp
+// route_defer_sync), so the copy call arrives with the prompt's launches in flight and the host otherwise idle.
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif
@@ -668,13 +670,23 @@ static void touch_destination_while_queue_runs(void* dst, size_t size, hipStream
   const bool known = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type != hipMemoryTypeUnregistered;
   (void)hipGetLastError();
   if (known) return;  // pinned / device / managed: nothing to fault in
+  // two threads: 192 MB of fresh pages measured 17-19 ms with one, 9-11 with two, 5-13 with four, 15-16 with eight or sixteen (the GPU boxes' hosts)
   const uintptr_t pg = uintptr_t(sysconf(_SC_PAGESIZE)), step = uintptr_t(8) << 20;
-  uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + pg - 1) & ~(pg - 1);
-  const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + size) & ~(pg - 1);
-  for (; lo < hi; lo += step) {
-    if (madvise(reinterpret_cast<void*>(lo), size_t(std::min(step, hi - lo)), MADV_POPULATE_WRITE) != 0) break;
-    if (hipStreamQuery(s) != hipErrorNotReady) break;
+  const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + pg - 1) & ~(pg - 1), hi = (reinterpret_cast<uintptr_t>(dst) + size) & ~(pg - 1);
+  if (hi <= lo) return;
+  const uintptr_t mid = (lo + (hi - lo) / 2) & ~(pg - 1);
+  std::atomic<bool> stop{false};
+  auto run = [&stop, step](uintptr_t a, uintptr_t e) {
+    for (; a < e && !stop.load(std::memory_order_relaxed); a += step)
+      if (madvise(reinterpret_cast<void*>(a), size_t(std::min(step, e - a)), MADV_POPULATE_WRITE) != 0) break;
+  };
+  std::thread helper(run, mid, hi);
+  for (uintptr_t a = lo; a < mid; a += step) {
+    if (madvise(reinterpret_cast<void*>(a), size_t(std::min(step, mid - a)), MADV_POPULATE_WRITE) != 0) break;
+    if (hipStreamQuery(s) != hipErrorNotReady) break;  // the queue is empty: the rest is left to the copy
   }
+  stop.store(true);
+  helper.join();
   (void)hipGetLastError();
 }
 void bestla_device_memcpy(void* dstptr, const void* srcptr, size_t size, void* queue) {

@@ -1383,12 +1383,14 @@ bool route_after_sync(void* stream) {
   return again;
 }
 // bestla_device_sync with nothing but launches on the queue since it was last waited for: nothing the host can see depends on them before a copy
-// is asked for — and that copy is ordered behind them on the queue.  The reference's token ends with sync, copy, sync (ne_layers.c:8345-8346): the first
-// of the two waits (a wake-up of the host thread, ~40 us on the profiler's trace) can be left to the second: NS_ROUTE_LAZY_SYNC=1.
+// is asked for — and that copy is ordered behind them on the queue.  The reference's evaluation ends with sync, copy, sync (ne_layers.c:8345-8346): the
+// first of the two waits is left to the second.  For a token this measured level (2074 vs 2065 / 2088 us at 1500 cached positions).  For a prompt it is
+// what lets the copy's host-side preparation run UNDER the launches instead of behind them: the copy of a 1500-token prompt's logits (192 MB into pages
+// the reference has not touched yet) arrives while the queue still has 28 ms of work, the runtime maps the destination and ns_device.hip first-touches
+// it meanwhile — first evaluation of a process 59.0 -> 52.1 (deferral alone) -> 46.2 / 48.4 ms on one box (profiles/r06_route_timings.txt), later
+// evaluations unchanged.  NS_ROUTE_LAZY_SYNC=0 waits where the caller asked.
 bool route_defer_sync(void* stream) {
-  // measured (profiles/r06_route_timings.txt): no difference — 2074 vs 2065 / 2088 us per token at 1500 cached positions; the wake-up the trace showed
-  // belongs to the profiler.  Off unless NS_ROUTE_LAZY_SYNC=1 asks for it.
-  static const bool on = getenv("NS_ROUTE_LAZY_SYNC") && atoi(getenv("NS_ROUTE_LAZY_SYNC")) != 0;
+  static const bool on = !getenv("NS_ROUTE_LAZY_SYNC") || atoi(getenv("NS_ROUTE_LAZY_SYNC")) != 0;
   if (!on || t_in_exec) return false;
   Route* r = find_route(stream);
   return r && r->copies_pending == 0 && (window_on() || g_enabled.load() != 0);

@@ -16,7 +16,7 @@ echo "---- default, prompt 8, run $i";  NS_ROUTE_TIMING=1 timeout 300 $D device 
 echo "---- default, prompt 1500 (NS_HARNESS_PROMPT_REPEAT=1: the prompt is evaluated a second time in its context), run $i"
 NS_ROUTE_TIMING=1 NS_HARNESS_PROMPT_REPEAT=1 NS_DEV7B_PROMPT=1500 timeout 300 $D device 64 2048 2>&1 | flt
 done
-for cfg in "NS_ROUTE_QKV_ROPE=0" "NS_DEVICE_KV=f32" "NS_ROUTE_LINKS=0" "NS_MHA_INLAUNCH=0" "NS_ROUTE_LAZY_SYNC=1" "NS_ROUTE_SEG=200" "NS_DEVICE_REPLAY=0"; do
+for cfg in "NS_ROUTE_QKV_ROPE=0" "NS_DEVICE_KV=f32" "NS_ROUTE_LINKS=0" "NS_MHA_INLAUNCH=0" "NS_ROUTE_LAZY_SYNC=0" "NS_ROUTE_SEG=200" "NS_DEVICE_REPLAY=0"; do
 echo "---- $cfg, prompt 1500"; env $cfg NS_ROUTE_TIMING=1 NS_DEV7B_PROMPT=1500 timeout 300 $D device 64 2048 2>&1 | grep "route timing: 61\|us_median" | cut -c1-420
 done
 for cfg in "NS_ROUTE_PREFILL_FUSE=0" "NS_ROUTE_WINDOW=0"; do
