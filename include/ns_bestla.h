@@ -440,6 +440,9 @@ int ns_hip_quant_pack_device(void* dBlob, const float* dW, size_t N, size_t K, s
  * csrc/ns_device.hip).  The pointer-only functions are exported by libns_hip.so AS IS — a reference tree built with
  * -DNS_SYCL binds to them — and the tensor-level ones (bestla_device_mul_f32 / _add_f32 / _elewise_f32 / _rms_norm_f32 /
  * _rope_f32 / _dup_f32 / _mha_f32) are glue/ne_bestla_hip_device.c over the ns_hip_* entries.  "queue" = hipStream_t. ---- */
+/* Threads: the device set is driven by ONE host thread at a time, as the reference's executor drives it (claimed nodes run with n_tasks = 1,
+ * ne_layers.c:11915-12028).  Several device contexts may live in a process and be used in turn — each keeps its own recorded graph and plan — but the
+ * registries behind them (queues, kv mirrors, pools) are not guarded against two threads inside bestla_device_* at the same moment. */
 void* bestla_create_device(bool profile);
 void* bestla_get_device_queue(void* device);
 void bestla_release_device(void* device);

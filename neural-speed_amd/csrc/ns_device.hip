@@ -597,6 +597,7 @@ void bestla_release_device(void* device) {
   finish_pending_loads_if_any();
   ns::Device* d = static_cast<ns::Device*>(device);
   (void)ns::route_sync_point(d->stream);
+  ns::route_invalidate();  // (the mirrors go below: no plan of ANY queue may keep a captured cache write into one)
   ns::route_detach(d->stream);
   ns::kvm_clear();
   (void)hipStreamSynchronize(d->stream);
