@@ -504,6 +504,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
 // A step = 4 keys = one 1 KiB request of K + one of V per wave; ring of kAsSteps steps per wave (refilled behind the reads for longer
 // ranges).  Rows past the range's end lie outside the buffer descriptor (the DMA writes zeros for them); their scores are masked and
 // their V is selected to zero as in attn_split_kernel, so nothing depends on what such a slot holds.
+#ifndef NS_AS_ABL
+#define NS_AS_ABL 0  // timing ablations (diagnostic builds, wrong results): 1 no arithmetic in the key loop, 2 nothing behind the key loop, 3 no key loop at all (nothing streamed), 4 streamed but never read
+#endif
 constexpr int kAsSteps = 8;
 constexpr size_t kAsLdsBytes = size_t(4) * kAsSteps * 2048;
 template <int G, int LPK = 16>  // LPK lanes per key: 16 (head sizes 72 .. 128) or 8 (40 .. 64: a 1 KiB request then holds 8 key rows, a wave step 8 keys)
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
   const bool dact = d0 < hs;
   constexpr int U = G * DPL <= 16 ? 4 : 2;  // keys per lane and softmax update: attn_split_kernel's rule (the update order decides the bits)
   static_assert(kAsSteps % U == 0, "a batch of U steps never wraps inside the ring");
-  const int nsteps = j1 > j0 ? (((j1 - j0 + KPS - 1) / KPS) + U - 1) / U * U : 0;  // whole batches: steps past the end fetch nothing (outside the descriptor)
+  const int nsteps = NS_AS_ABL == 3 ? 0 : j1 > j0 ? (((j1 - j0 + KPS - 1) / KPS) + U - 1) / U * U : 0;  // whole batches: steps past the end fetch nothing (outside the descriptor)
 
   // ---- 0. the query rows are requested first (ordinary loads, OLDER than the stream: loads return in order, a row requested behind the
   //      ring would be usable only when the whole ring has landed) ----
@@ -627,6 +630,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
   };
   for (int s0 = 0; s0 < nsteps; s0 += U) {
     wait_steps(min(nsteps - s0 - U, kAsSteps - U));
+    if (NS_AS_ABL == 4) {
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (s0 + kAsSteps + u < nsteps) issue(s0 + kAsSteps + u);
+      continue;
+    }
     u4_t kr[U], vr[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -642,6 +651,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
     for (int u = 0; u < U; u++)
       if (s0 + kAsSteps + u < nsteps) issue(s0 + kAsSteps + u);
     __builtin_amdgcn_sched_barrier(0);
+    if (NS_AS_ABL == 1) {
+      acc[0][0] += __builtin_bit_cast(float, kr[0].x ^ vr[U - 1].y);
+      continue;
+    }
     const int jb = j0 + KPS * s0 + KPW * w + l / LPK;
     // rows past the range's end and lanes past the head size count as zeros, as attn_split_kernel's unrequested registers do
     half8_t kv[U], vv[U];
@@ -694,6 +707,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
       }
       m[g] = m_new;
     }
+  }
+  if (NS_AS_ABL == 2) {
+    if (acc[0][0] == 123.456f) p.dst[0] = acc[0][1] + m[0] + lsum[0];
+    return;
   }
   __syncthreads();  // every wave has left its ring: its first bytes become attn_split_finish's acc_s
   attn_split_finish<G, DPL, LPK>(sp, acc, m, lsum, reinterpret_cast<float*>(ring_s), ml_s, split, chunk, ihkv, i, ibs, live);
