@@ -490,3 +490,43 @@ def test_a_copy_into_the_kv_cache_between_two_replayed_tokens_reaches_the_attent
     assert nso.rel_l2(plain_out[7], got_out[7]) > 1e-2
     for a, b in zip(ref_c, got_c):
         assert nso.rel_l2(b, a) < 2e-3
+
+
+def test_a_large_result_copy_behind_a_deferred_sync_into_untouched_host_pages(L, nso):
+    """An evaluation ends with bestla_device_sync, copy, sync (ne_layers.c:8345-8346).  The first of the two waits is left to the copy when only launches
+    are pending (route_defer_sync), so the copy of a prompt's logits arrives while the queue still works and its destination — pages the caller has not
+    touched yet — is faulted in meanwhile (csrc/ns_device.hip).  48 MB of results behind a long chain of launches: every byte must arrive, the pages in
+    front of and behind the destination must stay as they were, with the default switches and with NS_ROUTE_LAZY_SYNC / NS_DEVICE_PRETOUCH semantics
+    (a copy into pages that already exist takes the same path minus the faults)."""
+    import mmap
+    _api(L)
+    L.ns_hip_route_set_enabled(1)
+    dev = L.bestla_create_device(False)
+    q = L.bestla_get_device_queue(dev)
+    n = 12 << 20  # floats: 48 MB
+    src, tmp = L.bestla_device_malloc(n * 4, q), L.bestla_device_malloc(n * 4, q)
+    host = np.arange(n, dtype=np.float32) % 1009.0
+    L.bestla_device_memcpy_sync(src, nso.ptr(host), host.nbytes, q)
+    ne, nb = _ll(n, 1, 1, 1), _ll(4, 4 * n, 4 * n, 4 * n)
+    for rep in range(2):   # second pass: the same destination again, its pages present
+        if rep == 0:
+            mm = mmap.mmap(-1, n * 4 + 3 * 4096)  # fresh anonymous pages, never touched
+            dst = np.frombuffer(mm, np.uint8)
+            guard_lo, guard_hi = dst[:4096 + 64], dst[4096 + 64 + n * 4:]
+            guard_lo[:] = 0xA5
+            guard_hi[:] = 0x5A
+            out = dst[4096 + 64:4096 + 64 + n * 4].view(np.float32)   # (not page-aligned on purpose)
+        # a chain of launches that keeps the queue busy for a while: x = x + x, 40 times over 48 MB, then back to the source's values by x * 2^-40
+        L.bestla_device_sync(q)
+        assert L.ns_hip_binary_nd_f32(0, src, src, tmp, ne, nb, ne, nb, nb, q) == 0
+        for _ in range(39):
+            assert L.ns_hip_binary_nd_f32(0, tmp, tmp, tmp, ne, nb, ne, nb, nb, q) == 0
+        L.bestla_device_sync(q)                                        # only launches pending: deferred
+        L.bestla_device_memcpy_sync(nso.ptr(out), tmp, n * 4, q)       # arrives with the queue at work
+        assert np.array_equal(out, host * np.float32(2.0 ** 40))
+        assert np.all(guard_lo == 0xA5) and np.all(guard_hi == 0x5A)
+    L.bestla_device_free(src, q)
+    L.bestla_device_free(tmp, q)
+    L.bestla_release_device(dev)
+    del out, guard_lo, guard_hi, dst
+    mm.close()
