@@ -468,8 +468,9 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
 #pragma unroll
     for (int q = 0; q < NQ; q++) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](auto slot_c, uint32_t srel) {  // srel: k-step inside the slice
-      constexpr int slot = decltype(slot_c)::value;
+    auto compute = [&](auto slot_c, auto tbl_c, uint32_t srel) {  // srel: k-step inside the slice; tbl_c: f4 codes through the LDS pair table (decided ONCE per launch,
+      constexpr int slot = decltype(slot_c)::value;              // outside the stream: as a run-time test it sat in front of every dword of every record)
+      constexpr bool TBLC = decltype(tbl_c)::value;
       constexpr int q = slot % NQ;
       if constexpr (NS_GVS_ABL == 3) return;
       const _Float16* abase = a_lds + srel * KSTEP + aoff;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
           bq[j] = cvt_i8x8(xw[2 * j], xw[2 * j + 1], half2_t{zo8, zo8});
         } else if constexpr (KIND == WK_F8) {
           bq[j] = cvt_f8x8(xw[2 * j], xw[2 * j + 1], p.f8);
-        } else if (TBLK && TBL) {
+        } else if constexpr (TBLK && TBLC) {
           // byte b of the word = codes (i0,i2) (i4,i6) (i1,i3) (i5,i7): entry b of this lane's table copy = their two values
           typedef __attribute__((address_space(3))) const uint32_t* L32;
           uint4v r;
@@ -580,12 +581,13 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
 
     // ---- 4. stream: consume the oldest record, refill its slot with the record PF items ahead; tiles follow each
     //      other without a pause ----
+    auto stream = [&](auto tbl_c) {
     for (uint32_t t0 = 0; t0 < total; t0 += PF) {
       NS_FOR_SLOTS({
         const uint32_t t = t0 + i;
         if (t < total) {
           wait_records(min(total - t - 1u, uint32_t(PF - 1)));
-          compute(ic, kc);
+          compute(ic, tbl_c, kc);
           if constexpr (i % NQ == NQ - 1) {
             kc += NS;
             if (kc >= nks || t + 1u == total) {  // the wave's next unit lies in another tile (or there is none): hand over this tile's sums
@@ -604,6 +606,13 @@ __global__ __launch_bounds__(1024) void gemvs_kernel(const GvsParams p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       })
+    }
+    };
+    if constexpr (TBLK) {
+      if (TBL) stream(std::true_type{});
+      else stream(std::false_type{});
+    } else {
+      stream(std::false_type{});
     }
 #undef NS_FOR_SLOTS
     NS_SSTAMP(5);
