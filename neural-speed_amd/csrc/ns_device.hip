@@ -654,7 +654,7 @@ void bestla_device_free(void* ptr, void* queue) {
 // (10-18 ms either way, run to run); towards the device the runtime was faster outright (24.6 MB: 1.3 vs 3.5 ms).  profiles/r06_route_timings.txt.)
 // Also measured and not adopted: faulting the destination's pages in by eight threads IN FRONT of the copy (the queue already empty): populate + copy
 // 23.6-24.4 ms against 13.9-17.2 ms for the copy alone.  docs/kernels/experiments.md.)
-// What IS done: one thread, while the queue still works on what the copy waits for — bestla_device_sync in front of the copy is deferred (ns_route.cpp
+// What IS done: two threads, while the queue still works on what the copy waits for — bestla_device_sync in front of the copy is deferred (ns_route.cpp
 // route_defer_sync), so the copy call arrives with the prompt's launches in flight and the host otherwise idle.
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
@@ -663,7 +663,9 @@ void bestla_device_free(void* ptr, void* queue) {
 // 8 MB at a time, stopping as soon as the queue is empty; anything the call refuses — an older kernel, a special mapping — is left to the copy)
 static void touch_destination_while_queue_runs(void* dst, size_t size, hipStream_t s) {
   static const bool off = getenv("NS_DEVICE_PRETOUCH") && atoi(getenv("NS_DEVICE_PRETOUCH")) == 0;
-  if (off || size < (size_t(8) << 20) || hipStreamQuery(s) != hipErrorNotReady) {
+  if (off || size < (size_t(8) << 20)) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone || hipStreamQuery(s) != hipErrorNotReady) {  // (a query would end a capture)
     (void)hipGetLastError();
     return;
   }
