@@ -481,7 +481,10 @@ def test_a_copy_into_the_kv_cache_between_two_replayed_tokens_reaches_the_attent
     got_out, got_c, st2 = _run_layers(L, nso, blobs, gam, xs, 3, poke=poke)
     replayed, eager, plans, fallbacks = (st2[i] - st1[i] for i in range(4))
     # 0, 1 -> plan; 2 .. 5 replayed; the copy drops the plan; 6, 7 through the window -> plan; 8 .. 11 replayed
-    assert (replayed, eager, plans) == (8, 4, 2), (replayed, eager, plans, fallbacks)
+    # (NS_DEVICE_KV=f32: no mirror — the plan's attention reads the fp32 cache the copy wrote, nothing to drop)
+    import os
+    f32 = os.environ.get("NS_DEVICE_KV", "") in ("f32", "fp32", "0")
+    assert (replayed, eager, plans) == ((10, 2, 1) if f32 else (8, 4, 2)), (replayed, eager, plans, fallbacks)
     for t, (a, b) in enumerate(zip(ref_out, got_out)):
         assert np.all(np.isfinite(b))
         assert nso.rel_l2(b, a) < 2e-3, (t, nso.rel_l2(b, a))
