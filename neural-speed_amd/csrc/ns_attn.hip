@@ -185,11 +185,27 @@ struct AttnSplitParams {
   // ranges past the live length leave at once, a single live range writes the output row itself, the merge reads the live ones only.
   const int* kmove;
   int kdelta;
+  // ... and the ranges follow the LIVE length (round 6, second half): a plan laid out for n_ctx = 2048 (8 ranges of 256 keys) used to run 1530 cached positions
+  // on 6 of its 8 workgroups per head, 600 positions on 3 — with n_ctx = 4096 half as many again.  Every workgroup applies the host's range rule
+  // (attn_nsplit) to the live length itself: dyn_min_keys / dyn_batch_keys / dyn_single_below are that rule's constants for this launch, nsplit its
+  // upper bound (grid and partials' layout stay those of the longest context).  dyn_min_keys == 0: ranges as laid out (keys_per_split).
+  int dyn_min_keys, dyn_batch_keys, dyn_single_below;
 };
 // live context length / live ranges of a launch (kmove == nullptr: what the host said)
 __device__ __forceinline__ int attn_live_kv(const AttnSplitParams& sp) { return sp.kmove ? sp.a.sl_kv + sp.kdelta * *sp.kmove : sp.a.sl_kv; }
+// keys per range at the live length (the host's rule: as many ranges as the launch has workgroups for, at least dyn_min_keys keys each, whole softmax batches)
+__device__ __forceinline__ int attn_live_kps(const AttnSplitParams& sp, int sl_kv) {
+  if (!sp.kmove || sp.dyn_min_keys <= 0) return sp.keys_per_split;
+  if (sl_kv <= sp.dyn_single_below) return max(sl_kv, 1);
+  const int want = max(1, min(sp.nsplit, (sl_kv + sp.dyn_min_keys - 1) / sp.dyn_min_keys));
+  int kps = (sl_kv + want - 1) / want;
+  if (sp.dyn_batch_keys > 1 && want > 1) kps = (kps + sp.dyn_batch_keys - 1) / sp.dyn_batch_keys * sp.dyn_batch_keys;
+  return kps;
+}
 __device__ __forceinline__ int attn_live_splits(const AttnSplitParams& sp, int sl_kv) {
-  return sp.kmove ? (sl_kv + sp.keys_per_split - 1) / sp.keys_per_split : sp.nsplit;
+  if (!sp.kmove) return sp.nsplit;
+  const int kps = attn_live_kps(sp, sl_kv);
+  return max(1, (sl_kv + kps - 1) / kps);
 }
 
 // stores / loads past every cache (sc0 sc1): partial results cross XCDs inside one launch
@@ -351,7 +367,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_split_kernel(const AttnSpli
   const int sl_kv = attn_live_kv(sp), live = attn_live_splits(sp, sl_kv);
   if (split >= live) return;  // (moving context length: a range past the live keys)
   const int unmasked = causal ? (sl_kv - p.sl_q) + i + 1 : sl_kv;
-  const int j0 = split * sp.keys_per_split, j1 = min(unmasked, j0 + sp.keys_per_split);
+  const int kps = attn_live_kps(sp, sl_kv);
+  const int j0 = split * kps, j1 = min(unmasked, j0 + kps);
   const int d0 = dl * DPL;
   const bool dact = d0 < hs;  // head sizes that are not a multiple of DPL are rejected by the host
 
@@ -533,7 +550,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_stream_kernel(const AttnSpl
   const int sl_kv = attn_live_kv(sp), live = attn_live_splits(sp, sl_kv);
   if (split >= live) return;  // (moving context length: a range past the live keys)
   const int unmasked = causal ? (sl_kv - p.sl_q) + i + 1 : sl_kv;
-  const int j0 = split * sp.keys_per_split, j1 = min(unmasked, j0 + sp.keys_per_split);
+  const int kps = attn_live_kps(sp, sl_kv);
+  const int j0 = split * kps, j1 = min(unmasked, j0 + kps);
   const int d0 = dl * DPL;
   const bool dact = d0 < hs;
   constexpr int U = G * DPL <= 16 ? 4 : 2;  // keys per lane and softmax update: attn_split_kernel's rule (the update order decides the bits)
@@ -1857,6 +1875,15 @@ static hipError_t launch_attn(const attn_fp32_fp16_fp16_fp32_fwd_args_t& a, hipS
     sp.nsplit = nsplit;
     sp.keys_per_split = (rule_kv + nsplit - 1) / nsplit;
     sp.kmove = aff.k, sp.kdelta = int(aff.delta);
+    sp.dyn_min_keys = sp.dyn_batch_keys = sp.dyn_single_below = 0;
+    static const bool dyn_off = getenv("NS_ATTN_DYN_RANGES") && atoi(getenv("NS_ATTN_DYN_RANGES")) == 0;  // A-B runs
+    if (aff.k && nsplit > 1 && !dyn_off && a.sl_q == 1) {
+      // the constants attn_nsplit used above, for the workgroups to apply to the live length
+      const bool ring = stream || a.head_size > 128;
+      sp.dyn_min_keys = ring ? g_attn_min_keys_s.load() : g_attn_min_keys.load();
+      sp.dyn_batch_keys = stream ? batch_keys : 0;
+      sp.dyn_single_below = (ring && size_t(a.heads_kv) * chunks * a.sl_q * a.batch_size >= 32) ? 128 : 0;
+    }
     // dispatch order (round 5, profiles/r05m_attn_layout_order_ab.txt): on a position-major cache ([position][head][dim]: a head's rows are
     // pieces one position stride apart) neighbouring workgroups should be neighbouring HEADS of one context range — split + merge 14.3 -> 13.7 us
     // at 2048 positions, 22.0 -> 19.9 at 4096 (Llama-2-7B shape); on a head-major cache (one slab per head) the ranges of one head first

@@ -384,15 +384,17 @@ def test_plan_carries_the_rms_norms_across_launches(L, pkg, nso):
         assert np.count_nonzero(b) > 0 and nso.rel_l2(b, a) < 2e-3
 
 
-def test_replayed_attention_over_several_context_ranges(L, pkg, nso):
-    """Positions 250 .. 261 of caches made for 512: the replayed attention covers 2 and then 3 live ranges of 128 keys (of the 4 its grid is
-    made for) and its last range to finish merges them inside the launch (ns_device.hip, tickets) — no merge launch in the plan."""
+@pytest.mark.parametrize("nctx,pos0", [(512, 250), (2048, 122), (2048, 700), (2048, 2030)])
+def test_replayed_attention_over_several_context_ranges(L, pkg, nso, nctx, pos0):
+    """Twelve positions from pos0 on of caches made for nctx: the replayed attention's grid and partials are laid out for nctx, its ranges follow the LIVE
+    length (AttnSplitParams::dyn_*: every workgroup applies the host's range rule to the length it reads from the device counter — a few ranges of a
+    few dozen keys at 122 .. 133 positions, crossing the one-range threshold at 128; more at 700; the layout's own at 2030 ..), and the last range to
+    finish merges them inside the launch (ns_device.hip, tickets) — no merge launch in the plan."""
     rng = np.random.default_rng(6)
     mk = lambda n, k: nso.quant_pack((rng.standard_normal((n, k)) * k ** -0.5).astype(np.float32), 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
     blobs = {"wq": mk(D, D), "wk": mk(D, D), "wv": mk(D, D), "wo": mk(D, D), "w1": mk(FF, D), "w3": mk(FF, D), "w2": mk(D, FF)}
     gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
     xs = [rng.standard_normal(D).astype(np.float32) for _ in range(12)]
-    nctx, pos0 = 512, 250
     cache0 = [(0.5 * rng.standard_normal(HEADS * nctx * HS)).astype(np.float32) for _ in range(2 * NL)]
     _api(L)
     ref_out, ref_c, _ = _run_layers(L, nso, blobs, gam, xs, 0, nctx, pos0, cache0)
