@@ -440,18 +440,19 @@ def test_values_beyond_fp16_turn_the_fp16_shortcuts_off_and_the_token_is_evaluat
         L.ns_hip_route_set_enabled(1)
 
 
-def test_replayed_grouped_query_attention_on_the_kv_mirror(L, pkg, nso):
+@pytest.mark.parametrize("nctx,pos0", [(512, 120), (4096, 1500)])
+def test_replayed_grouped_query_attention_on_the_kv_mirror(L, pkg, nso, nctx, pos0):
     """Two kv heads under four query heads (the shape of Mistral / Llama-2-70B layers): the three projections have different widths, so the plan keeps them as
     separate launches (the reference's own graph does, llama.cpp:215) with rope(k), rope(q) and the two cache writes as launches of their own — each cache
     write storing into the fp16 mirror as well — and the replayed attention serves two query heads per kv head of a mirror that grows across a context-range boundary (4 -> 5 live
-    ranges of 32 keys).  Same tokens as plain launches."""
+    ranges of 32 keys; second case: 1500 .. 1513 positions of caches made for 4096 — the launch's layout has 64 ranges of 64 keys per kv head, the live
+    length's rule a couple of dozen).  Same tokens as plain launches."""
     rng = np.random.default_rng(9)
     hkv = 2
     mk = lambda n, k: nso.quant_pack((rng.standard_normal((n, k)) * k ** -0.5).astype(np.float32), 32, nso.S4, nso.BF16, False, nso.CORE_AVX512_VNNI_KB)
     blobs = {"wq": mk(D, D), "wk": mk(hkv * HS, D), "wv": mk(hkv * HS, D), "wo": mk(D, D), "w1": mk(FF, D), "w3": mk(FF, D), "w2": mk(D, FF)}
     gam = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
     xs = [rng.standard_normal(D).astype(np.float32) for _ in range(14)]
-    nctx, pos0 = 512, 120
     cache0 = [(0.5 * rng.standard_normal(hkv * nctx * HS)).astype(np.float32) for _ in range(2 * NL)]
     _api(L)
     ref_out, ref_c, _ = _run_layers(L, nso, blobs, gam, xs, 0, nctx, pos0, cache0, hkv=hkv)
