@@ -86,6 +86,12 @@ def make_prompt(n_prompt):
 def run_device(path, prompt, n_new, n_ctx):
     """-> dict: the reference's device build generating greedily on libns_hip.so (call after libns_hip.so is loaded RTLD_GLOBAL)"""
     ref = C.CDLL(DEV_LIB)
+    if os.environ.get("NS_TUNE"):   # diagnostics: NS_TUNE="attn_stream_wg_target=512,attn_stream_min_keys=64" -> ns_hip_set_tuning before the run
+        hip0 = C.CDLL(HIP_LIB)
+        hip0.ns_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
+        for kv in os.environ["NS_TUNE"].split(","):
+            k, v = kv.split("=")
+            assert hip0.ns_hip_set_tuning(k.strip().encode(), int(v)) == 0, kv
     toks = (C.c_int * n_new)()
     pr = (C.c_int * len(prompt))(*prompt)
     us = C.c_double(0)
